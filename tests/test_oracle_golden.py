@@ -1,0 +1,96 @@
+"""Pin the CPU oracle (oracle/scot_cpu.py) against golden vectors produced by the REAL reference
+(tests/golden/make_fixtures.py).  CPU only; tolerance 1e-6 rel-L2 on outputs (fp32 vs fp32)."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import load_fixture, rel_l2
+from poseidon_amd.config import ScOTConfig
+from poseidon_amd.geometry import param_shapes
+from poseidon_amd.synth import synth_inputs, synth_state_dict
+from oracle import scot_cpu
+
+TOL_OUT = 5e-6  # fp32-vs-fp32 through up to 64 layers (an fp64 evaluation of the oracle sits at the same distance)
+TOL_GRAD = 5e-4  # per tensor (cancellation-dominated tiny grads, e.g. CPB-MLP biases); global vector: 5e-5. NB the reference's own fp32 backward sits 3e-5 from an fp64 evaluation (measured)
+
+
+def _run(meta, grads):
+    cfg = ScOTConfig(**meta["cfg"])
+    sd = synth_state_dict(param_shapes(cfg), meta["regime"])
+    if grads:
+        for v in sd.values():
+            v.requires_grad_(True)
+    size = meta.get("size", cfg.image_size)
+    pv, t, lab = synth_inputs(meta["batch"], cfg.num_channels, cfg.num_out_channels, size, meta["kind"])
+    pm = None
+    if meta.get("with_mask"):
+        pm = torch.zeros(meta["batch"], cfg.num_out_channels, dtype=torch.bool)
+        pm[:, -1] = True
+    loss, out, inter = scot_cpu.scot_forward(sd, cfg, pv, t if cfg.use_conditioning else None, lab, pm,
+                                             return_intermediates=True)
+    if grads:
+        loss.backward()
+    return cfg, sd, loss, out, inter
+
+
+@pytest.mark.parametrize("name", ["tiny_trained", "tiny_hf", "tiny_odd", "tiny_shift3", "tiny_nocond_p2",
+                                  "tiny_learnres_mask"])
+def test_tiny_models_full_grads(name):
+    f, meta = load_fixture(name)
+    cfg, sd, loss, out, inter = _run(meta, grads=True)
+    assert rel_l2(out.detach().numpy(), f["output"]) < TOL_OUT
+    assert abs(float(loss.detach()) - float(f["loss"])) < 1e-5 * max(1.0, abs(float(f["loss"])))
+    num = den = 0.0
+    for k, v in sd.items():
+        ref = f["grad:" + k]
+        g = v.grad.numpy() if v.grad is not None else np.zeros_like(ref)
+        if np.linalg.norm(ref) < 1e-12 and np.linalg.norm(g) < 1e-9:
+            continue
+        # relative to the tensor's norm, with an absolute floor for the ~1e-12 grads of the hf regime
+        err = float(np.linalg.norm(g.astype(np.float64) - ref.astype(np.float64)))
+        assert err < TOL_GRAD * float(np.linalg.norm(ref.astype(np.float64))) + 1e-9, k
+        num += err ** 2
+        den += float(np.linalg.norm(ref.astype(np.float64))) ** 2
+    assert (num / den) ** 0.5 < 5e-5
+    if name == "tiny_trained":
+        assert rel_l2(inter["embeddings"].detach().numpy(), f["enc_hidden:0"]) < TOL_OUT
+        assert rel_l2(inter["enc0"].detach().numpy(), f["enc_hidden:1"]) < TOL_OUT
+        assert rel_l2(inter["enc1"].detach().numpy(), f["enc_hidden:2"]) < TOL_OUT
+
+
+def test_window16_headdim32():
+    f, meta = load_fixture("tiny_w16")
+    cfg, sd, loss, out, _ = _run(meta, grads=True)
+    assert rel_l2(out.detach().numpy(), f["output"]) < TOL_OUT
+    for k in f.files:
+        if k.startswith("grad:"):
+            assert rel_l2(sd[k[5:]].grad.numpy(), f[k]) < TOL_GRAD, k
+
+
+@pytest.mark.parametrize("size", [64, 16])
+def test_spectral_resize(size):
+    f, meta = load_fixture(f"tiny_resize{size}")
+    _, _, loss, out, _ = _run(meta, grads=False)
+    assert rel_l2(out.numpy(), f["output"]) < 5e-6
+    assert abs(float(loss.detach()) - float(f["loss"])) < 1e-5 * abs(float(f["loss"]))
+
+
+@pytest.mark.parametrize("name", ["poseidonT_trained", "poseidonT_hf", "poseidonB_trained", "poseidonB_hf"])
+def test_poseidon_presets(name):
+    f, meta = load_fixture(name)
+    grads = name.startswith("poseidonT")
+    cfg, sd, loss, out, _ = _run(meta, grads=grads)
+    assert rel_l2(out.detach().numpy(), f["output"]) < 5e-6
+    assert abs(float(loss.detach()) - float(f["loss"])) < 2e-5 * abs(float(f["loss"]))
+    if grads:
+        names = [str(n) for n in f["grad_names"]]
+        norms = f["grad_norms"]
+        for n, ref in zip(names, norms):
+            g = sd[n].grad
+            mine = float(g.double().norm()) if g is not None else 0.0
+            assert abs(mine - ref) <= 1e-4 * max(ref, 1e-6) + 1e-9, n
+        for k in f.files:
+            if k.startswith("grad:"):
+                ref = f[k].astype(np.float64)
+                err = float(np.linalg.norm(sd[k[5:]].grad.numpy().astype(np.float64) - ref))
+                assert err < 1e-4 * float(np.linalg.norm(ref)) + 1e-9, k
