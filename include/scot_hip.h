@@ -1,0 +1,108 @@
+/* scot_hip.h — C ABI of libscot_hip.so, the MI355X (gfx950) kernel library behind the scOT forward/backward path.
+ *
+ * Boundary: the reference exposes this path as a Python nn.Module (`scOT.model.ScOT`), whose
+ * arithmetic is stock torch ops.  Each entry point below replaces the torch ops of the cited reference lines
+ * (ref = /root/reference/scOT/model.py, HF = transformers/models/swinv2/modeling_swinv2.py) and is what a
+ * ctypes / pybind / cgo binding would bind; see INTEGRATION.md for the reference-side stub.
+ *
+ * Conventions: every pointer is a DEVICE pointer borrowed for the duration of the enqueue; calls only enqueue
+ * work on `stream` (never allocate, never synchronise, except scot_selftest_tr); return 0 on success, <0 on
+ * bad shape (-1) / dtype (-2) / unsupported configuration (-3) / launch failure (-4).
+ * dtype codes: 0 = float32, 1 = bfloat16 (raw uint16).  compute codes: 0 = exact fp32 MFMA, 1 = bf16 MFMA.
+ */
+#ifndef SCOT_HIP_H
+#define SCOT_HIP_H
+#include <stddef.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct ihipStream_t* scot_stream_t; /* = hipStream_t */
+
+#define SCOT_DT_F32 0
+#define SCOT_DT_BF16 1
+#define SCOT_LAYOUT_NT 0 /* C[M,N] = A[M,K] B[N,K]^T : nn.Linear forward (HF:545-561, HF:389-410, ref:709,747,760) */
+#define SCOT_LAYOUT_NN 1 /* C[M,N] = A[M,K] B[K,N]   : dgrad of nn.Linear; ConvTranspose2d k=s (ref:616-621)      */
+#define SCOT_LAYOUT_TN 2 /* C[M,N] += A[K,M]^T B[K,N] : wgrad of nn.Linear (autograd of the above)                 */
+
+int scot_abi_version(void);
+int scot_selftest_tr(scot_stream_t stream); /* 1: ds_read_b64_tr_b16 path verified & on, 0: scalar-gather fallback */
+void scot_set_use_tr(int v);
+int scot_get_use_tr(void);
+
+/* Dense contraction with fused prologue/epilogue.  a_gelu/b_gelu: apply erf-GELU to the operand while loading
+ * (Swinv2Intermediate's activation, HF:545-548).  Epilogue: (+bias[n]) (*colscale[n]) (*gelu'(aux[m,n])) (+resid[m,n]);
+ * accumulate=1: C += result (required for TN, which splits K and uses fp32 atomics). */
+int scot_gemm(int layout, int compute, int M, int N, int K,
+              const void* A, int a_dt, int lda, int a_gelu,
+              const void* B, int b_dt, int ldb, int b_gelu,
+              void* C, int c_dt, int ldc,
+              const float* bias, const float* colscale,
+              const void* aux, int aux_dt, int ldaux,
+              const void* resid, int res_dt, int ldres,
+              int accumulate, scot_stream_t stream);
+
+/* Shifted-window cosine attention, HF:389-455 + ref:522-559 (roll/partition/mask folded into indexing).
+ * qkv: [batch*Hp*Wp][3C] (q|k|v) in the compute dtype; out: [batch*Hp*Wp][C]; lse: [batch*nW][heads][ws*ws] f32;
+ * bias_table: [heads][(2ws-1)^2] = 16*sigmoid(CPB MLP) from scot_cpb_fwd; logit_scale: [heads]. */
+int scot_window_attn_fwd(int compute, const void* qkv, void* out, float* lse, const float* bias_table,
+                         const float* logit_scale, int batch, int Hp, int Wp, int C, int heads, int ws, int shift,
+                         scot_stream_t stream);
+int scot_window_attn_bwd(int compute, const void* qkv, const void* dout, const float* lse, const float* bias_table,
+                         const float* logit_scale, void* dqkv, float* dbias_table, float* dlogit_scale, int batch,
+                         int Hp, int Wp, int C, int heads, int ws, int shift, scot_stream_t stream);
+
+/* Continuous relative position bias MLP, HF:376-378,418-428 (coords table HF:457-476 is passed in). */
+int scot_cpb_fwd(const float* coords, const float* w0, const float* b0, const float* w2, float* table, float* z, int ws,
+                 int heads, scot_stream_t stream);
+int scot_cpb_bwd(const float* coords, const float* w0, const float* b0, const float* w2, const float* z,
+                 const float* dtable, float* dw0, float* db0, float* dw2, int ws, int heads, scot_stream_t stream);
+
+/* ConditionalLayerNorm / LayerNorm (+ fused residual), ref:135-160, res-post-norm ref:570,574. */
+int scot_cln_fwd(const void* x, int x_dt, const void* resid, int res_dt, void* out, int out_dt, float* mean, float* rstd,
+                 const float* time, const float* gw_w, const float* gw_b, const float* bw_w, const float* bw_b, int rows,
+                 int rows_per_sample, int C, float eps, scot_stream_t stream);
+int scot_cln_bwd(const void* dout, int dout_dt, const void* x, int x_dt, const float* mean, const float* rstd,
+                 const float* time, const float* gw_w, const float* gw_b, void* dx, int dx_dt, float* d_gw_w,
+                 float* d_gw_b, float* d_bw_w, float* d_bw_b, int rows, int rows_per_sample, int C, scot_stream_t stream);
+
+/* Data movement */
+int scot_add(const void* a, int a_dt, const void* b, int b_dt, void* out, int out_dt, size_t n, size_t period,
+             scot_stream_t stream);                                                   /* ref:847-849,1175-1177,361 */
+int scot_batch_sum(const void* x, int x_dt, float* out, int batch, size_t period, scot_stream_t stream);
+int scot_copy2d(const void* src, int s_dt, void* dst, int d_dt, int B, int Hs, int Ws, int Hd, int Wd, int C,
+                scot_stream_t stream);                                                /* ref:480-498, 563-566 */
+int scot_space_to_depth(const void* fine, const void* fine2, int f_dt, void* coarse, int c_dt, int B, int H, int W, int C,
+                        int order, scot_stream_t stream);                             /* ref:672-704 (order 0) */
+int scot_depth_to_space(const void* coarse, int c_dt, void* fine, int f_dt, int B, int H, int W, int H2, int W2, int C,
+                        int order, scot_stream_t stream);                             /* ref:748-756 (order 1) */
+int scot_patchify(const float* img, void* cols, int c_dt, int B, int Cc, int H, int W, int p, scot_stream_t stream); /* ref:286-308 */
+int scot_unpatchify(const void* cols, int c_dt, const float* bias, float* img, int B, int Cc, int H, int W, int gh, int gw,
+                    int p, scot_stream_t stream);                                      /* ref:616-621,632-643 */
+int scot_nchw_channel_sum(const float* x, float* out, int B, int Cc, int HW, scot_stream_t stream);
+int scot_colsum(const void* x, int x_dt, const void* y, int y_dt, float* out, int M, int N, int ld, scot_stream_t stream);
+int scot_scale_residual(const void* y, int y_dt, const float* scale, const void* resid, int r_dt, void* out, int o_dt,
+                        size_t rows, int N, scot_stream_t stream);                     /* ref:212-216 */
+
+/* Stencils */
+int scot_dwconv7(const void* x, int x_dt, const float* w, const float* bias, void* y, int y_dt, int B, int H, int W, int C,
+                 int flip, scot_stream_t stream);                                       /* ref:178-180,206 */
+int scot_dwconv7_wgrad(const void* dy, int dy_dt, const void* x, int x_dt, float* dw, float* db, int B, int H, int W, int C,
+                       scot_stream_t stream);
+int scot_conv5(const float* in, const float* w, float* out, int B, int Cc, int H, int W, int transpose,
+               scot_stream_t stream);                                                   /* ref:623-630,647 */
+int scot_conv5_wgrad(const float* dout, const float* in, float* dw, int B, int Cc, int H, int W, scot_stream_t stream);
+
+/* Head finalisation + loss, ref:1411-1484 */
+int scot_head_finalize(float* pred, const float* pv, int pv_ch, const float* labels, const unsigned char* mask,
+                       int mask_full, const int* group_of_channel, float* sums, int B, int Cc, int HW, int p,
+                       scot_stream_t stream);
+int scot_loss_finish(const float* sums, const float* counts, int G, int normalized, float* loss, scot_stream_t stream);
+int scot_loss_bwd(const float* pred, const float* labels, const unsigned char* mask, int mask_full,
+                  const int* group_of_channel, const float* sums, const float* counts, int G, int normalized,
+                  const float* dloss, float* dpred, int B, int Cc, int HW, int p, scot_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,530 @@
+// Shifted-window cosine attention with continuous relative-position bias — forward and backward.
+//
+// Reference semantics (transformers swinv2 `Swinv2SelfAttention.forward`, HF:389-455, called from reference
+// scOT/model.py:522-559): for every window and head
+//     S = normalize(q) · normalize(k)^T * exp(min(logit_scale, ln 100)) + 16·sigmoid(CPB)[rel(i,j)] + 2·mask(i,j)
+//     O = softmax(S) · v
+// The roll(-s) + window_partition + window_reverse + roll(+s) round trip (model.py:522-559, HF:146-166) is folded
+// into the token index  tok(n) = ((wy·ws + n/ws + s) mod H)·W + ((wx·ws + n%ws + s) mod W); the additive shift
+// mask (model.py:442-478) is evaluated analytically from region ids; S is never materialised in HBM.
+//
+// Workgroup = one (window, head); 4 waves; each wave owns 16-query blocks.  K (normalised) and V of the window
+// live in LDS; the whole logit row of a query (<=256 keys) lives in the accumulator registers of one wave:
+// S^T tiles = mfma(A = Kn[16 keys x d], B = Qn^T) put ONE query per lane column (lane&15) with its keys spread
+// over (lane>>4, reg, tile) → row max / sum need only two xor-shuffles (16, 32), and the probabilities are
+// already in MFMA A-operand order for P·V (no LDS round trip, no permutes).
+#include "common.h"
+
+struct AttnArgs {
+  const void* qkv;   // [tokens][3C]  (q | k | v), dtype = compute type
+  void* out;         // fwd: O [tokens][C];           bwd: dqkv [tokens][3C]
+  const void* dout;  // bwd: dO [tokens][C]
+  float* lse;        // [windows][heads][N]  log-sum-exp of each softmax row (fwd writes, bwd reads)
+  const float* bias_table;   // [heads][(2ws-1)^2]  = 16·sigmoid(CPB-MLP)
+  const float* logit_scale;  // [heads]
+  float* dbias_table;        // bwd, atomically accumulated
+  float* dlogit_scale;       // bwd, atomically accumulated
+  int C, heads, Hp, Wp, ws, shift, nwx, nw_per_img;
+  int use_tr;
+};
+
+__device__ __forceinline__ int win_token(const AttnArgs& p, int win, int n) {
+  const int b = win / p.nw_per_img, w = win % p.nw_per_img;
+  const int wy = w / p.nwx, wx = w % p.nwx;
+  int y = wy * p.ws + n / p.ws + p.shift, x = wx * p.ws + n % p.ws + p.shift;
+  if (y >= p.Hp) y -= p.Hp;
+  if (x >= p.Wp) x -= p.Wp;
+  return (b * p.Hp + y) * p.Wp + x;
+}
+// region id on the shifted grid (reference model.py:450-465), 0 when shift == 0
+__device__ __forceinline__ int win_region(const AttnArgs& p, int win, int n) {
+  if (p.shift == 0) return 0;
+  const int w = win % p.nw_per_img;
+  const int ys = (w / p.nwx) * p.ws + n / p.ws, xs = (w % p.nwx) * p.ws + n % p.ws;
+  const int ry = (ys >= p.Hp - p.ws) + (ys >= p.Hp - p.shift);
+  const int rx = (xs >= p.Wp - p.ws) + (xs >= p.Wp - p.shift);
+  return ry * 3 + rx;
+}
+
+// per-position info packed for the logit loops: (y*(2ws-1) + x) | region << 20 ; region 15 = padding row
+__device__ __forceinline__ int pos_info(const AttnArgs& p, int win, int n, int N) {
+  if (n >= N) return 15 << 20;
+  return ((n / p.ws) * (2 * p.ws - 1) + n % p.ws) | (win_region(p, win, n) << 20);
+}
+// LDS tiles are [n][KD + pad] with KD = HD rounded up to the MFMA K-step (32); columns HD..KD are zero so that
+// K-contiguous fragment reads of head_dim 16 never touch uninitialised LDS.
+template <int HD, typename CT> constexpr int row_pitch() { return ((HD + 31) / 32) * 32 + ct_traits<CT>::kpad; }
+
+// Stage the window's rows of one of q/k/v (column offset `col`) into LDS tile [NP][pitch]; optionally L2-normalise
+// each row (F.normalize, eps 1e-12).  256 threads, HD/8 lanes per row.
+template <typename CT, int HD, int NP>
+__device__ __forceinline__ void stage_rows(CT* tile, const void* src, int ld, int col, const AttnArgs& p, int win, int N,
+                                           bool normalize, int tid) {
+  constexpr int CPR = ((HD + 31) / 32) * 4, pitch = row_pitch<HD, CT>();
+  for (int c = tid; c < NP * CPR; c += 256) {
+    const int n = c / CPR, d8 = (c % CPR) * 8;
+    float v[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) v[j] = 0.f;
+    if (n < N && d8 < HD) ld8(src, ct_traits<CT>::dtype, (size_t)win_token(p, win, n) * ld + col + d8, v);
+    if (normalize) {
+      float ss = 0.f;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) ss += v[j] * v[j];
+#pragma unroll
+      for (int o = 1; o < CPR; o <<= 1) ss += __shfl_xor(ss, o, 64);
+      const float r = 1.0f / fmaxf(sqrtf(ss), 1e-12f);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) v[j] *= r;
+    }
+    CT* dst = tile + n * pitch + d8;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) dst[j] = to_ct<CT>(v[j]);
+  }
+}
+
+// B-operand fragments of a 16-row block read straight from HBM: lane (c = lane&15, g) takes 8 consecutive
+// features d = kk*32 + g*8 .. +7 of row tok(n0+c).  Optionally L2-normalised (returns 1/max(|row|,eps) in *rnorm).
+template <typename CT, int HD>
+__device__ __forceinline__ void load_rows_frag(Frag<CT> (&f)[(HD + 31) / 32], const void* src, int ld, int col,
+                                               const AttnArgs& p, int win, int n0, int N, bool normalize, int lane) {
+  constexpr int KS = (HD + 31) / 32;
+  const int n = n0 + (lane & 15), g = lane >> 4;
+  float v[KS][8];
+  float ss = 0.f;
+  const bool valid = n < N;
+  const size_t base = valid ? (size_t)win_token(p, win, n) * ld + col : 0;
+#pragma unroll
+  for (int kk = 0; kk < KS; ++kk) {
+    const int d = kk * 32 + g * 8;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) v[kk][j] = 0.f;
+    if (valid && d < HD) ld8(src, ct_traits<CT>::dtype, base + d, v[kk]);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) ss += v[kk][j] * v[kk][j];
+  }
+  float r = 1.f;
+  if (normalize) {
+    ss += __shfl_xor(ss, 16, 64);
+    ss += __shfl_xor(ss, 32, 64);
+    r = 1.0f / fmaxf(sqrtf(ss), 1e-12f);
+  }
+#pragma unroll
+  for (int kk = 0; kk < KS; ++kk) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) frag_set(f[kk], j, v[kk][j] * r);
+  }
+}
+
+// ================================================================================================= forward
+template <typename CT, int HD, int NT>  // NT = number of 16-key tiles (even), NP = 16*NT >= N
+__global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnArgs p) {
+  constexpr int NP = NT * 16, KS = (HD + 31) / 32, DT = HD / 16, pitch = row_pitch<HD, CT>();
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  CT* Kn = (CT*)smem;
+  CT* Vs = Kn + NP * pitch;
+  float* tab = (float*)(Vs + NP * pitch);
+  const int ws = p.ws, N = ws * ws, TW = 2 * ws - 1, TS = TW * TW;
+  int* rid = (int*)(tab + ((TS + 3) & ~3));
+
+  const int win = blockIdx.x, h = blockIdx.y;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int ld = 3 * p.C;
+
+  stage_rows<CT, HD, NP>(Kn, p.qkv, ld, p.C + h * HD, p, win, N, true, tid);
+  stage_rows<CT, HD, NP>(Vs, p.qkv, ld, 2 * p.C + h * HD, p, win, N, false, tid);
+  for (int i = tid; i < TS; i += 256) tab[i] = p.bias_table[h * TS + i];
+  for (int i = tid; i < NP; i += 256) rid[i] = pos_info(p, win, i, N);
+  __syncthreads();
+
+  const float scale = __expf(fminf(p.logit_scale[h], 4.605170185988092f));  // exp(min(ls, ln 100)), HF:416
+  const int cen = (ws - 1) * TW + ws - 1;
+  const int g = lane >> 4, qc = lane & 15;
+
+  for (int qb = wave; qb * 16 < N; qb += 4) {
+    const int q0 = qb * 16;
+    Frag<CT> qf[KS];
+    load_rows_frag<CT, HD>(qf, p.qkv, ld, h * HD, p, win, q0, N, true, lane);
+    const int q = q0 + qc;
+    const bool qvalid = q < N;
+    const int qinfo = rid[min(q, NP - 1)];
+    const int qoff = (qinfo & 0xfffff) + cen, qrid = qinfo >> 20;
+
+    f32x4_t s[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+      s[t] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int kk = 0; kk < KS; ++kk) mma16(s[t], lds_frag_kc(Kn, pitch, t * 16, kk * 32, lane), qf[kk]);
+      if (NT >= 8 && (t & 3) == 3) __builtin_amdgcn_sched_barrier(0);  // keep the scheduler from hoisting all tiles' LDS reads
+    }
+    // logits: lane holds query q (=column), keys t*16 + g*4 + r
+    float m = -3.0e38f;
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+      const int4 ki = *(const int4*)&rid[t * 16 + g * 4];
+      const int kia[4] = {ki.x, ki.y, ki.z, ki.w};
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int krid = kia[r] >> 20;
+        float v = -3.0e38f;
+        if (krid != 15 && qvalid) {
+          v = s[t][r] * scale + tab[qoff - (kia[r] & 0xfffff)];
+          if (krid != qrid) v -= 200.0f;  // the -100 mask is added twice in the installed oracle (HF:433-436)
+        }
+        s[t][r] = v;
+        m = fmaxf(m, v);
+      }
+      if (NT >= 8 && (t & 3) == 3) __builtin_amdgcn_sched_barrier(0);
+    }
+    m = fmaxf(m, __shfl_xor(m, 16, 64));
+    m = fmaxf(m, __shfl_xor(m, 32, 64));
+    float l = 0.f;
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float e = __expf(s[t][r] - m);
+        s[t][r] = e;
+        l += e;
+      }
+    }
+    l += __shfl_xor(l, 16, 64);
+    l += __shfl_xor(l, 32, 64);
+    const float inv = 1.0f / l;
+    if (qvalid && g == 0 && p.lse) p.lse[((size_t)win * p.heads + h) * N + q] = m + __logf(l);
+
+    // O = P · V : A = P (already in A-operand order), B = V rows read with the transposing fragment read
+    f32x4_t o[DT];
+#pragma unroll
+    for (int d = 0; d < DT; ++d) o[d] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int tp = 0; tp < NT / 2; ++tp) {
+      Frag<CT> pf;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        frag_set(pf, r, s[2 * tp][r] * inv);
+        frag_set(pf, r + 4, s[2 * tp + 1][r] * inv);
+      }
+#pragma unroll
+      for (int d = 0; d < DT; ++d)
+        mma16(o[d], pf, lds_frag_ks(Vs, pitch, d * 16, (2 * tp) * 16 + g * 4, (2 * tp + 1) * 16 + g * 4, lane, p.use_tr));
+      if (NT >= 8 && (tp & 1) == 1) __builtin_amdgcn_sched_barrier(0);
+    }
+    // o[d]: col = feature d*16 + (lane&15), rows = query q0 + g*4 + r
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int qq = q0 + g * 4 + r;
+      if (qq < N) {
+        const size_t base = (size_t)win_token(p, win, qq) * p.C + h * HD + (lane & 15);
+#pragma unroll
+        for (int d = 0; d < DT; ++d) st1(p.out, ct_traits<CT>::dtype, base + d * 16, o[d][r]);
+      }
+    }
+  }
+}
+
+// ================================================================================================= backward
+// Phase B (queries on lane columns, S^T tiles): recompute P, dP = dO·V^T, delta = rowsum(P∘dP), dS = P∘(dP-delta),
+//   d bias-table (LDS histogram → one atomic pass), d logit_scale, dQn = scale·dS·Kn → dq through the normalisation.
+// Phase A (keys on lane columns, S tiles): recompute P, dS; dV = P^T·dO, dKn = scale·dS^T·Qn → dk.
+// LDS holds two [NP][HD] tiles that are re-filled between the phases (Kn,V then Qn,dO).
+template <typename CT, int HD>
+__device__ __forceinline__ float normalize_bwd_store(const f32x4_t (&acc)[HD / 16], float mul, const void* src, int ld, int col,
+                                                    void* dst, int dcol, const AttnArgs& p, int win, int n0, int N, int lane) {
+  // acc[d][r]: gradient wrt the NORMALISED row n0 + (lane>>4)*4 + r, feature d*16 + (lane&15) (times `mul`).
+  // y = x / max(|x|, eps):  dx = (g - y (y·g)) / |x|   (|x| >= eps),   dx = g / eps otherwise.
+  constexpr int DT = HD / 16;
+  const int g = lane >> 4, c = lane & 15;
+  float dotsum = 0.f;  // Σ_rows y·g (counted once per row: lane c == 0) — this is d/d(logit_scale) of the rows
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const int n = n0 + g * 4 + r;
+    const bool valid = n < N;
+    const size_t tok = valid ? (size_t)win_token(p, win, n) : 0;
+    float x[DT], ss = 0.f, dot = 0.f;
+#pragma unroll
+    for (int d = 0; d < DT; ++d) {
+      x[d] = valid ? ld1(src, ct_traits<CT>::dtype, tok * ld + col + d * 16 + c) : 0.f;
+      ss += x[d] * x[d];
+    }
+#pragma unroll
+    for (int o = 1; o < 16; o <<= 1) ss += __shfl_xor(ss, o, 64);
+    const float nrm = sqrtf(ss);
+    const bool clamped = nrm < 1e-12f;
+    const float rn = 1.0f / fmaxf(nrm, 1e-12f);
+#pragma unroll
+    for (int d = 0; d < DT; ++d) dot += (x[d] * rn) * (acc[d][r] * mul);
+#pragma unroll
+    for (int o = 1; o < 16; o <<= 1) dot += __shfl_xor(dot, o, 64);
+    if (valid && c == 0) dotsum += dot;
+    if (clamped) dot = 0.f;
+    if (valid) {
+#pragma unroll
+      for (int d = 0; d < DT; ++d)
+        st1(dst, ct_traits<CT>::dtype, tok * ld + dcol + d * 16 + c, rn * (acc[d][r] * mul - (x[d] * rn) * dot));
+    }
+  }
+  return dotsum;
+}
+
+template <typename CT, int HD, int NT>
+__global__ __launch_bounds__(256, 2) void attn_bwd_kernel(AttnArgs p) {
+  constexpr int NP = NT * 16, KS = (HD + 31) / 32, DT = HD / 16, pitch = row_pitch<HD, CT>();
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  CT* X = (CT*)smem;            // phase B: Kn   phase A: Qn
+  CT* Y = X + NP * pitch;       // phase B: V    phase A: dO
+  const int ws = p.ws, N = ws * ws, TW = 2 * ws - 1, TS = TW * TW, TSP = (TS + 3) & ~3;
+  float* tab = (float*)(Y + NP * pitch);
+  float* dtab = tab + TSP;
+  float* lse = dtab + TSP;      // [NP]
+  float* delta = lse + NP;      // [NP]
+  int* rid = (int*)(delta + NP);
+  float* red = (float*)(rid + NP);  // [4]
+
+  const int win = blockIdx.x, h = blockIdx.y;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int ld = 3 * p.C, g = lane >> 4, lc = lane & 15;
+
+  stage_rows<CT, HD, NP>(X, p.qkv, ld, p.C + h * HD, p, win, N, true, tid);
+  stage_rows<CT, HD, NP>(Y, p.qkv, ld, 2 * p.C + h * HD, p, win, N, false, tid);
+  for (int i = tid; i < TS; i += 256) { tab[i] = p.bias_table[h * TS + i]; dtab[i] = 0.f; }
+  for (int i = tid; i < NP; i += 256) {
+    rid[i] = pos_info(p, win, i, N);
+    lse[i] = i < N ? p.lse[((size_t)win * p.heads + h) * N + i] : 3.0e38f;
+  }
+  __syncthreads();
+
+  const float ls = p.logit_scale[h];
+  const float scale = __expf(fminf(ls, 4.605170185988092f));
+  const int cen = (ws - 1) * TW + ws - 1;
+  float dls = 0.f;
+
+  // ---------------------------------------------------------------- phase B
+  for (int qb = wave; qb * 16 < N; qb += 4) {
+    const int q0 = qb * 16;
+    Frag<CT> qf[KS], gf[KS];
+    load_rows_frag<CT, HD>(qf, p.qkv, ld, h * HD, p, win, q0, N, true, lane);
+    load_rows_frag<CT, HD>(gf, p.dout, p.C, h * HD, p, win, q0, N, false, lane);
+    const int q = q0 + lc;
+    const bool qvalid = q < N;
+    const int qinfo = rid[min(q, NP - 1)];
+    const int qoff = (qinfo & 0xfffff) + cen, qrid = qinfo >> 20;
+    const float qlse = qvalid ? lse[q] : 3.0e38f;
+
+    f32x4_t s[NT], dp[NT];
+    float dl = 0.f;
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+      s[t] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+      dp[t] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int kk = 0; kk < KS; ++kk) {
+        mma16(s[t], lds_frag_kc(X, pitch, t * 16, kk * 32, lane), qf[kk]);
+        mma16(dp[t], lds_frag_kc(Y, pitch, t * 16, kk * 32, lane), gf[kk]);
+      }
+    }
+    // s: cos -> P
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+      const int4 ki = *(const int4*)&rid[t * 16 + g * 4];
+      const int kia[4] = {ki.x, ki.y, ki.z, ki.w};
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int krid = kia[r] >> 20;
+        float pr = 0.f;
+        if (krid != 15 && qvalid) {
+          float v = s[t][r] * scale + tab[qoff - (kia[r] & 0xfffff)];
+          if (krid != qrid) v -= 200.0f;
+          pr = __expf(v - qlse);
+        }
+        s[t][r] = pr;
+        dl += pr * dp[t][r];
+      }
+    }
+    dl += __shfl_xor(dl, 16, 64);
+    dl += __shfl_xor(dl, 32, 64);
+    if (g == 0 && qvalid) delta[q] = dl;
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+      const int4 ki = *(const int4*)&rid[t * 16 + g * 4];
+      const int kia[4] = {ki.x, ki.y, ki.z, ki.w};
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float ds = s[t][r] * (dp[t][r] - dl);
+        s[t][r] = ds;
+        if ((kia[r] >> 20) != 15 && qvalid) atomicAdd(&dtab[qoff - (kia[r] & 0xfffff)], ds);
+      }
+    }
+    // dQn = scale * dS · Kn   (A = dS in registers, B = Kn rows via the transposing read)
+    f32x4_t dq[DT];
+#pragma unroll
+    for (int d = 0; d < DT; ++d) dq[d] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int tp = 0; tp < NT / 2; ++tp) {
+      Frag<CT> df;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        frag_set(df, r, s[2 * tp][r]);
+        frag_set(df, r + 4, s[2 * tp + 1][r]);
+      }
+#pragma unroll
+      for (int d = 0; d < DT; ++d)
+        mma16(dq[d], df, lds_frag_ks(X, pitch, d * 16, (2 * tp) * 16 + g * 4, (2 * tp + 1) * 16 + g * 4, lane, p.use_tr));
+    }
+    // Σ_keys dS·cos·scale = qn · (scale · dS·Kn) — the row dot product the normalisation backward needs anyway
+    dls += normalize_bwd_store<CT, HD>(dq, scale, p.qkv, ld, h * HD, p.out, h * HD, p, win, q0, N, lane);
+  }
+
+  // d logit_scale: d/dls [cos * exp(ls)] = cos * scale  (0 when clamped at ln 100, HF:416)
+  dls = wave_sum(dls);
+  if (lane == 0) red[wave] = dls;
+  __syncthreads();  // also: every wave is done reading X/Y (phase B) and delta[] is complete
+  if (tid == 0 && ls <= 4.605170185988092f) atomicAdd(&p.dlogit_scale[h], red[0] + red[1] + red[2] + red[3]);
+  for (int i = tid; i < TS; i += 256) atomicAdd(&p.dbias_table[h * TS + i], dtab[i]);
+
+  // ---------------------------------------------------------------- phase A
+  stage_rows<CT, HD, NP>(X, p.qkv, ld, h * HD, p, win, N, true, tid);       // Qn
+  stage_rows<CT, HD, NP>(Y, p.dout, p.C, h * HD, p, win, N, false, tid);    // dO
+  __syncthreads();
+
+  for (int kb = wave; kb * 16 < N; kb += 4) {
+    const int k0 = kb * 16;
+    Frag<CT> kf[KS], vf[KS];
+    load_rows_frag<CT, HD>(kf, p.qkv, ld, p.C + h * HD, p, win, k0, N, true, lane);
+    load_rows_frag<CT, HD>(vf, p.qkv, ld, 2 * p.C + h * HD, p, win, k0, N, false, lane);
+    const int key = k0 + lc;
+    const bool kvalid = key < N;
+    const int kinfo = rid[min(key, NP - 1)];
+    const int koff = kinfo & 0xfffff, krid = kinfo >> 20;
+
+    f32x4_t dv[DT], dk[DT];
+#pragma unroll
+    for (int d = 0; d < DT; ++d) { dv[d] = (f32x4_t){0.f, 0.f, 0.f, 0.f}; dk[d] = (f32x4_t){0.f, 0.f, 0.f, 0.f}; }
+
+#pragma unroll 1
+    for (int tp = 0; tp < NT / 2; ++tp) {
+      Frag<CT> pf, df;
+#pragma unroll
+      for (int half = 0; half < 2; ++half) {
+        const int t = 2 * tp + half;
+        f32x4_t s = {0.f, 0.f, 0.f, 0.f}, dp = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int kk = 0; kk < KS; ++kk) {
+          mma16(s, lds_frag_kc(X, pitch, t * 16, kk * 32, lane), kf[kk]);   // rows = queries, col = key
+          mma16(dp, lds_frag_kc(Y, pitch, t * 16, kk * 32, lane), vf[kk]);
+        }
+        const int4 qi = *(const int4*)&rid[t * 16 + g * 4];
+        const int qia[4] = {qi.x, qi.y, qi.z, qi.w};
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int q = t * 16 + g * 4 + r;
+          const int qrid = qia[r] >> 20;
+          float pr = 0.f, ds = 0.f;
+          if (qrid != 15 && kvalid) {
+            float v = s[r] * scale + tab[(qia[r] & 0xfffff) + cen - koff];
+            if (qrid != krid) v -= 200.0f;
+            pr = __expf(v - lse[q]);
+            ds = pr * (dp[r] - delta[q]);
+          }
+          frag_set(pf, half * 4 + r, pr);
+          frag_set(df, half * 4 + r, ds);
+        }
+      }
+#pragma unroll
+      for (int d = 0; d < DT; ++d) {
+        const int klo = (2 * tp) * 16 + g * 4, khi = (2 * tp + 1) * 16 + g * 4;
+        mma16(dv[d], pf, lds_frag_ks(Y, pitch, d * 16, klo, khi, lane, p.use_tr));   // dV  += P^T  · dO
+        mma16(dk[d], df, lds_frag_ks(X, pitch, d * 16, klo, khi, lane, p.use_tr));   // dKn += dS^T · Qn
+      }
+    }
+    // dv: rows = keys k0 + g*4 + r, col = feature
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int kk2 = k0 + g * 4 + r;
+      if (kk2 < N) {
+        const size_t base = (size_t)win_token(p, win, kk2) * ld + 2 * p.C + h * HD + lc;
+#pragma unroll
+        for (int d = 0; d < DT; ++d) st1(p.out, ct_traits<CT>::dtype, base + d * 16, dv[d][r]);
+      }
+    }
+    normalize_bwd_store<CT, HD>(dk, scale, p.qkv, ld, p.C + h * HD, p.out, p.C + h * HD, p, win, k0, N, lane);
+  }
+}
+
+// ================================================================================================= host side
+extern int g_scot_use_tr;
+
+template <typename CT, int HD, int NT>
+static int launch_attn(const AttnArgs& a, int nwin, bool bwd, hipStream_t s) {
+  constexpr int NP = NT * 16, pitch = row_pitch<HD, CT>();
+  const int TS = (2 * a.ws - 1) * (2 * a.ws - 1), TSP = (TS + 3) & ~3;
+  size_t sh = 2 * NP * pitch * sizeof(CT);
+  if (bwd) sh += (2 * TSP + 2 * NP) * sizeof(float) + NP * sizeof(int) + 4 * sizeof(float);
+  else sh += TSP * sizeof(float) + NP * sizeof(int);
+  if (sh > 160 * 1024) return SCOT_ERR_UNSUPPORTED;
+  dim3 grid(nwin, a.heads), block(256);
+  if (bwd) {
+    if (sh > 64 * 1024) (void)hipFuncSetAttribute((const void*)attn_bwd_kernel<CT, HD, NT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh);
+    hipLaunchKernelGGL((attn_bwd_kernel<CT, HD, NT>), grid, block, sh, s, a);
+  } else {
+    if (sh > 64 * 1024) (void)hipFuncSetAttribute((const void*)attn_fwd_kernel<CT, HD, NT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh);
+    hipLaunchKernelGGL((attn_fwd_kernel<CT, HD, NT>), grid, block, sh, s, a);
+  }
+  return scot_check_launch();
+}
+
+template <typename CT, int HD>
+static int dispatch_nt(const AttnArgs& a, int nwin, bool bwd, hipStream_t s) {
+  const int N = a.ws * a.ws;
+  if (N <= 32) return launch_attn<CT, HD, 2>(a, nwin, bwd, s);
+  if (N <= 64) return launch_attn<CT, HD, 4>(a, nwin, bwd, s);
+  if (N <= 128) return launch_attn<CT, HD, 8>(a, nwin, bwd, s);
+  if (N <= 256) return launch_attn<CT, HD, 16>(a, nwin, bwd, s);
+  return SCOT_ERR_UNSUPPORTED;
+}
+
+template <typename CT>
+static int dispatch_hd(const AttnArgs& a, int hd, int nwin, bool bwd, hipStream_t s) {
+  switch (hd) {
+    case 16: return dispatch_nt<CT, 16>(a, nwin, bwd, s);
+    case 32: return dispatch_nt<CT, 32>(a, nwin, bwd, s);
+    case 64: return dispatch_nt<CT, 64>(a, nwin, bwd, s);
+    default: return SCOT_ERR_UNSUPPORTED;  // head_dim = embed_dim/3 ∈ {16, 32, 64} for T/S, B, L
+  }
+}
+
+static int fill_args(AttnArgs& a, int batch, int Hp, int Wp, int C, int heads, int ws, int shift) {
+  if (batch <= 0 || C % heads || Hp % ws || Wp % ws || shift < 0 || shift >= ws) return SCOT_ERR_SHAPE;
+  a.C = C; a.heads = heads; a.Hp = Hp; a.Wp = Wp; a.ws = ws; a.shift = shift;
+  a.nwx = Wp / ws; a.nw_per_img = (Hp / ws) * (Wp / ws);
+  a.use_tr = g_scot_use_tr;
+  return SCOT_OK;
+}
+
+// compute: SCOT_BF16 → qkv/out are bf16;  SCOT_F32 → f32.   Grid is the (already padded) Hp x Wp token grid.
+extern "C" int scot_window_attn_fwd(int compute, const void* qkv, void* out, float* lse, const float* bias_table,
+                                    const float* logit_scale, int batch, int Hp, int Wp, int C, int heads, int ws,
+                                    int shift, hipStream_t stream) {
+  AttnArgs a{};
+  int rc = fill_args(a, batch, Hp, Wp, C, heads, ws, shift);
+  if (rc) return rc;
+  a.qkv = qkv; a.out = out; a.lse = lse; a.bias_table = bias_table; a.logit_scale = logit_scale;
+  const int nwin = batch * a.nw_per_img;
+  return compute == SCOT_BF16 ? dispatch_hd<bf16_t>(a, C / heads, nwin, false, stream)
+                              : dispatch_hd<float>(a, C / heads, nwin, false, stream);
+}
+
+extern "C" int scot_window_attn_bwd(int compute, const void* qkv, const void* dout, const float* lse,
+                                    const float* bias_table, const float* logit_scale, void* dqkv,
+                                    float* dbias_table, float* dlogit_scale, int batch, int Hp, int Wp, int C,
+                                    int heads, int ws, int shift, hipStream_t stream) {
+  AttnArgs a{};
+  int rc = fill_args(a, batch, Hp, Wp, C, heads, ws, shift);
+  if (rc) return rc;
+  a.qkv = qkv; a.out = dqkv; a.dout = dout; a.lse = (float*)lse; a.bias_table = bias_table; a.logit_scale = logit_scale;
+  a.dbias_table = dbias_table; a.dlogit_scale = dlogit_scale;
+  const int nwin = batch * a.nw_per_img;
+  return compute == SCOT_BF16 ? dispatch_hd<bf16_t>(a, C / heads, nwin, true, stream)
+                              : dispatch_hd<float>(a, C / heads, nwin, true, stream);
+}

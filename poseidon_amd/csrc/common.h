@@ -1,0 +1,178 @@
+// Shared device helpers for the scOT HIP kernels (gfx950 / CDNA4 only — no portability shims).
+//
+// Compute types (template parameter CT):
+//   bf16_t : operands rounded to bf16, v_mfma_f32_16x16x32_bf16, fp32 accumulate  (the fast path)
+//   float  : exact fp32 v_mfma_f32_16x16x4_f32 (k-ordered fmaf chain)              (the 1e-5 parity path)
+// Both use ONE fragment convention so every kernel is written once:
+//   a lane (r = lane&15, g = lane>>4) owns 8 contraction elements k(g,j), j=0..7, of row r (A) / column r (B).
+//   bf16: the 8 elements are the MFMA's native 16x16x32 operand;  f32: element j feeds the j-th of 8
+//   16x16x4 MFMAs, whose native k index is g.  Any k(g,j) bijection is legal as long as A and B agree.
+// Accumulator (C/D) layout of both: col = lane&15, row = (lane>>4)*4 + reg.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#define SCOT_F32 0
+#define SCOT_BF16 1
+
+#define SCOT_OK 0
+#define SCOT_ERR_SHAPE (-1)
+#define SCOT_ERR_DTYPE (-2)
+#define SCOT_ERR_UNSUPPORTED (-3)
+#define SCOT_ERR_LAUNCH (-4)
+
+typedef uint16_t bf16_t;
+typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
+typedef short s16x8_t __attribute__((ext_vector_type(8)));
+typedef short s16x4_t __attribute__((ext_vector_type(4)));
+typedef float f32x4_t __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ float bf2f(bf16_t x) { return __uint_as_float(((uint32_t)x) << 16); }
+__device__ __forceinline__ bf16_t f2bf(float f) {  // round-to-nearest-even
+  uint32_t u = __float_as_uint(f);
+  if ((u & 0x7fffffffu) > 0x7f800000u) return (bf16_t)((u >> 16) | 0x40u);
+  u += 0x7fffu + ((u >> 16) & 1u);
+  return (bf16_t)(u >> 16);
+}
+
+template <typename CT> __device__ __forceinline__ CT to_ct(float f);
+template <> __device__ __forceinline__ float to_ct<float>(float f) { return f; }
+template <> __device__ __forceinline__ bf16_t to_ct<bf16_t>(float f) { return f2bf(f); }
+__device__ __forceinline__ float from_ct(float f) { return f; }
+__device__ __forceinline__ float from_ct(bf16_t f) { return bf2f(f); }
+template <typename CT> struct ct_traits;
+template <> struct ct_traits<float> { static constexpr int dtype = SCOT_F32; static constexpr int kpad = 4; };
+template <> struct ct_traits<bf16_t> { static constexpr int dtype = SCOT_BF16; static constexpr int kpad = 8; };
+
+// ---- runtime-dtype global memory access (dtype is wave-uniform → scalar branch) ----------------------------
+__device__ __forceinline__ float ld1(const void* p, int dt, size_t i) {
+  return dt == SCOT_F32 ? ((const float*)p)[i] : bf2f(((const bf16_t*)p)[i]);
+}
+__device__ __forceinline__ void st1(void* p, int dt, size_t i, float v) {
+  if (dt == SCOT_F32) ((float*)p)[i] = v; else ((bf16_t*)p)[i] = f2bf(v);
+}
+// 8 consecutive elements; caller guarantees 16-byte alignment of element i (f32: 32-byte span, two 16 B loads)
+__device__ __forceinline__ void ld8(const void* p, int dt, size_t i, float v[8]) {
+  if (dt == SCOT_F32) {
+    const float4 a = *(const float4*)((const float*)p + i);
+    const float4 b = *(const float4*)((const float*)p + i + 4);
+    v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
+  } else {
+    const uint4 u = *(const uint4*)((const bf16_t*)p + i);
+    v[0] = __uint_as_float(u.x << 16); v[1] = __uint_as_float(u.x & 0xffff0000u);
+    v[2] = __uint_as_float(u.y << 16); v[3] = __uint_as_float(u.y & 0xffff0000u);
+    v[4] = __uint_as_float(u.z << 16); v[5] = __uint_as_float(u.z & 0xffff0000u);
+    v[6] = __uint_as_float(u.w << 16); v[7] = __uint_as_float(u.w & 0xffff0000u);
+  }
+}
+__device__ __forceinline__ void st8(void* p, int dt, size_t i, const float v[8]) {
+  if (dt == SCOT_F32) {
+    *(float4*)((float*)p + i) = make_float4(v[0], v[1], v[2], v[3]);
+    *(float4*)((float*)p + i + 4) = make_float4(v[4], v[5], v[6], v[7]);
+  } else {
+    uint4 u;
+    u.x = (uint32_t)f2bf(v[0]) | ((uint32_t)f2bf(v[1]) << 16);
+    u.y = (uint32_t)f2bf(v[2]) | ((uint32_t)f2bf(v[3]) << 16);
+    u.z = (uint32_t)f2bf(v[4]) | ((uint32_t)f2bf(v[5]) << 16);
+    u.w = (uint32_t)f2bf(v[6]) | ((uint32_t)f2bf(v[7]) << 16);
+    *(uint4*)((bf16_t*)p + i) = u;
+  }
+}
+
+__device__ __forceinline__ float gelu_f(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752f)); }
+__device__ __forceinline__ float gelu_grad_f(float x) {
+  return 0.5f * (1.0f + erff(x * 0.70710678118654752f)) + x * 0.3989422804014327f * __expf(-0.5f * x * x);
+}
+
+// ---- fragments -------------------------------------------------------------------------------------------
+template <typename CT> struct Frag;
+template <> struct Frag<float> { float v[8]; };
+template <> struct Frag<bf16_t> { s16x8_t v; };
+
+__device__ __forceinline__ void frag_set(Frag<float>& f, int j, float x) { f.v[j] = x; }
+__device__ __forceinline__ void frag_set(Frag<bf16_t>& f, int j, float x) { f.v[j] = (short)f2bf(x); }
+__device__ __forceinline__ void frag_zero(Frag<float>& f) {
+#pragma unroll
+  for (int j = 0; j < 8; ++j) f.v[j] = 0.f;
+}
+__device__ __forceinline__ void frag_zero(Frag<bf16_t>& f) {
+#pragma unroll
+  for (int j = 0; j < 8; ++j) f.v[j] = 0;
+}
+template <typename CT> __device__ __forceinline__ Frag<CT> frag_from_f32(const float x[8]) {
+  Frag<CT> f;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) frag_set(f, j, x[j]);
+  return f;
+}
+
+__device__ __forceinline__ void mma16(f32x4_t& c, const Frag<bf16_t>& a, const Frag<bf16_t>& b) {
+  c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, a.v), __builtin_bit_cast(bf16x8_t, b.v), c, 0, 0, 0);
+}
+__device__ __forceinline__ void mma16(f32x4_t& c, const Frag<float>& a, const Frag<float>& b) {
+#pragma unroll
+  for (int j = 0; j < 8; ++j) c = __builtin_amdgcn_mfma_f32_16x16x4f32(a.v[j], b.v[j], c, 0, 0, 0);
+}
+
+// ---- LDS fragment reads ----------------------------------------------------------------------------------
+// K-contiguous tile  T[row][pitch]: lane reads 8 consecutive k of row r0+(lane&15) at k = kk + (lane>>4)*8.
+__device__ __forceinline__ Frag<bf16_t> lds_frag_kc(const bf16_t* t, int pitch, int r0, int kk, int lane) {
+  Frag<bf16_t> f;
+  f.v = *(const s16x8_t*)(t + (r0 + (lane & 15)) * pitch + kk + (lane >> 4) * 8);
+  return f;
+}
+__device__ __forceinline__ Frag<float> lds_frag_kc(const float* t, int pitch, int r0, int kk, int lane) {
+  Frag<float> f;
+  const float* p = t + (r0 + (lane & 15)) * pitch + kk + (lane >> 4) * 8;
+  const float4 a = *(const float4*)p, b = *(const float4*)(p + 4);
+  f.v[0] = a.x; f.v[1] = a.y; f.v[2] = a.z; f.v[3] = a.w; f.v[4] = b.x; f.v[5] = b.y; f.v[6] = b.z; f.v[7] = b.w;
+  return f;
+}
+// K-strided tile  T[k][pitch] (the fragment's row/column index runs along the contiguous dimension):
+// element j<4 comes from LDS row klo+j, j>=4 from khi+(j-4), column c0+(lane&15).
+// bf16 + use_tr: two ds_read_b64_tr_b16.  Each 16-lane group hands the instruction 16 8-byte chunks forming a
+// row-major [4][16] b16 block (lane i -> row i>>2, chunk i&3) and lane c receives column c of that block.
+// (semantics verified at library init by scot_selftest_tr(); scalar gather otherwise.)
+__device__ __forceinline__ Frag<bf16_t> lds_frag_ks(const bf16_t* t, int pitch, int c0, int klo, int khi, int lane, int use_tr) {
+  Frag<bf16_t> f;
+  const int i = lane & 15;
+  if (use_tr) {
+    typedef __attribute__((address_space(3))) s16x4_t* lds_v4;
+    const bf16_t* p0 = t + (klo + (i >> 2)) * pitch + c0 + (i & 3) * 4;
+    const bf16_t* p1 = t + (khi + (i >> 2)) * pitch + c0 + (i & 3) * 4;
+    const s16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4)p0);
+    const s16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4)p1);
+    f.v = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+  } else {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      f.v[j] = (short)t[(klo + j) * pitch + c0 + i];
+      f.v[j + 4] = (short)t[(khi + j) * pitch + c0 + i];
+    }
+  }
+  return f;
+}
+__device__ __forceinline__ Frag<float> lds_frag_ks(const float* t, int pitch, int c0, int klo, int khi, int lane, int) {
+  Frag<float> f;
+  const int i = lane & 15;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    f.v[j] = t[(klo + j) * pitch + c0 + i];
+    f.v[j + 4] = t[(khi + j) * pitch + c0 + i];
+  }
+  return f;
+}
+
+// ---- wave reductions ---------------------------------------------------------------------------------------
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+  return v;
+}
+
+static inline int scot_check_launch() { return hipGetLastError() == hipSuccess ? SCOT_OK : SCOT_ERR_LAUNCH; }

@@ -1,0 +1,606 @@
+// Data-movement, stencil, reduction and loss kernels of the scOT hot path (everything that is not a dense
+// contraction, attention or a layer norm).  All are HBM-bound: coalesced along the channel (token tensors, NHWC) or
+// the x axis (PDE grids, NCHW), one pass over the data, fp32 accumulation.
+#include "common.h"
+
+#define GRID1D(n, per) dim3((unsigned)(((size_t)(n) + (per) - 1) / (per)))
+
+// ------------------------------------------------------------------ elementwise add (skip connections, grad fan-in)
+// out[i] = a[i] + b[i % period]   (period = n: plain add;  period = L*C: absolute position embeddings, model.py:361)
+__global__ void add_kernel(const void* a, int a_dt, const void* b, int b_dt, void* out, int out_dt, size_t n, size_t period) {
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
+    st1(out, out_dt, i, ld1(a, a_dt, i) + ld1(b, b_dt, i % period));
+}
+extern "C" int scot_add(const void* a, int a_dt, const void* b, int b_dt, void* out, int out_dt, size_t n, size_t period,
+                        hipStream_t s) {
+  if (n == 0 || period == 0) return SCOT_ERR_SHAPE;
+  size_t blocks = (n + 255) / 256; if (blocks > 8192) blocks = 8192;
+  hipLaunchKernelGGL(add_kernel, dim3((unsigned)blocks), dim3(256), 0, s, a, a_dt, b, b_dt, out, out_dt, n, period);
+  return scot_check_launch();
+}
+// out[i] += Σ_b x[b*period + i]   (gradient of a batch-broadcast parameter)
+__global__ void batch_sum_kernel(const void* x, int x_dt, float* out, int batch, size_t period) {
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < period; i += (size_t)gridDim.x * blockDim.x) {
+    float acc = 0.f;
+    for (int b = 0; b < batch; ++b) acc += ld1(x, x_dt, (size_t)b * period + i);
+    out[i] += acc;
+  }
+}
+extern "C" int scot_batch_sum(const void* x, int x_dt, float* out, int batch, size_t period, hipStream_t s) {
+  size_t blocks = (period + 255) / 256; if (blocks > 8192) blocks = 8192;
+  hipLaunchKernelGGL(batch_sum_kernel, dim3((unsigned)blocks), dim3(256), 0, s, x, x_dt, out, batch, period);
+  return scot_check_launch();
+}
+
+// ------------------------------------------------------------------ token-grid pad / crop  (model.py:480-498, 563-566)
+// dst[b,y,x,:] = (y < Hs && x < Ws) ? src[b,y,x,:] : 0    for y < Hd, x < Wd
+__global__ void copy2d_kernel(const void* src, int s_dt, void* dst, int d_dt, int B, int Hs, int Ws, int Hd, int Wd, int C) {
+  const size_t n = (size_t)B * Hd * Wd * C;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+    const int c = i % C; size_t r = i / C;
+    const int x = r % Wd; r /= Wd;
+    const int y = r % Hd; const int b = r / Hd;
+    float v = 0.f;
+    if (y < Hs && x < Ws) v = ld1(src, s_dt, (((size_t)b * Hs + y) * Ws + x) * C + c);
+    st1(dst, d_dt, i, v);
+  }
+}
+extern "C" int scot_copy2d(const void* src, int s_dt, void* dst, int d_dt, int B, int Hs, int Ws, int Hd, int Wd, int C,
+                           hipStream_t s) {
+  const size_t n = (size_t)B * Hd * Wd * C;
+  if (n == 0) return SCOT_ERR_SHAPE;
+  size_t blocks = (n + 255) / 256; if (blocks > 16384) blocks = 16384;
+  hipLaunchKernelGGL(copy2d_kernel, dim3((unsigned)blocks), dim3(256), 0, s, src, s_dt, dst, d_dt, B, Hs, Ws, Hd, Wd, C);
+  return scot_check_launch();
+}
+
+// ------------------------------------------------------------------ space-to-depth / depth-to-space on token grids
+// fine[b, 2Y+dy, 2X+dx, c]  <->  coarse[b, Y, X, q*C + c]
+//   order 0 (patch merging, model.py:694-704):   q = dx*2 + dy      order 1 (patch unmerging, model.py:748-754): q = dy*2 + dx
+// gather : coarse = fine (+ fine2)   (zero beyond the fine grid: odd-size padding, model.py:672-678)
+// scatter: fine = coarse             (fine grid may be a crop, model.py:756)
+__global__ void s2d_kernel(const void* fine, const void* fine2, int f_dt, void* coarse, int c_dt, int B, int H, int W,
+                           int H2, int W2, int C, int order, int scatter) {
+  const size_t n = scatter ? (size_t)B * H * W * C : (size_t)B * H2 * W2 * 4 * C;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+    if (scatter) {
+      const int c = i % C; size_t r = i / C;
+      const int x = r % W; r /= W;
+      const int y = r % H; const int b = r / H;
+      const int dy = y & 1, dx = x & 1;
+      const int q = order == 0 ? dx * 2 + dy : dy * 2 + dx;
+      const size_t ci = ((((size_t)b * H2 + (y >> 1)) * W2 + (x >> 1)) * 4 + q) * C + c;
+      st1((void*)fine, f_dt, i, ld1(coarse, c_dt, ci));
+    } else {
+      const int c = i % C; size_t r = i / C;
+      const int q = r % 4; r /= 4;
+      const int X = r % W2; r /= W2;
+      const int Y = r % H2; const int b = r / H2;
+      const int dy = order == 0 ? (q & 1) : (q >> 1), dx = order == 0 ? (q >> 1) : (q & 1);
+      const int y = 2 * Y + dy, x = 2 * X + dx;
+      float v = 0.f;
+      if (y < H && x < W) {
+        const size_t fi = (((size_t)b * H + y) * W + x) * C + c;
+        v = ld1(fine, f_dt, fi);
+        if (fine2) v += ld1(fine2, f_dt, fi);
+      }
+      st1(coarse, c_dt, i, v);
+    }
+  }
+}
+extern "C" int scot_space_to_depth(const void* fine, const void* fine2, int f_dt, void* coarse, int c_dt, int B, int H, int W,
+                                   int C, int order, hipStream_t s) {
+  const int H2 = (H + 1) / 2, W2 = (W + 1) / 2;
+  const size_t n = (size_t)B * H2 * W2 * 4 * C;
+  if (n == 0) return SCOT_ERR_SHAPE;
+  size_t blocks = (n + 255) / 256; if (blocks > 16384) blocks = 16384;
+  hipLaunchKernelGGL(s2d_kernel, dim3((unsigned)blocks), dim3(256), 0, s, fine, fine2, f_dt, coarse, c_dt, B, H, W, H2, W2, C, order, 0);
+  return scot_check_launch();
+}
+extern "C" int scot_depth_to_space(const void* coarse, int c_dt, void* fine, int f_dt, int B, int H, int W, int H2, int W2,
+                                   int C, int order, hipStream_t s) {
+  const size_t n = (size_t)B * H * W * C;
+  if (n == 0 || H > 2 * H2 || W > 2 * W2) return SCOT_ERR_SHAPE;
+  size_t blocks = (n + 255) / 256; if (blocks > 16384) blocks = 16384;
+  hipLaunchKernelGGL(s2d_kernel, dim3((unsigned)blocks), dim3(256), 0, s, (const void*)fine, (const void*)nullptr, f_dt,
+                     (void*)coarse, c_dt, B, H, W, H2, W2, C, order, 1);
+  return scot_check_launch();
+}
+
+// ------------------------------------------------------------------ patchify / unpatchify of (B,C,H,W) PDE grids
+// cols[(b,gy,gx)][ci*p*p + i*p + j] = img[b,ci,gy*p+i,gx*p+j]  (0 outside: right/bottom pad, model.py:286-293)
+// One thread per (b, ci, y, x-quad): reads a contiguous float4 of the image row (coalesced along x) and writes the
+// 4 (= patch width) consecutive im2col elements.  Generic p falls back to one element per thread.
+__global__ void patchify_kernel(const float* img, void* cols, int c_dt, int B, int Cc, int H, int W, int gh, int gw, int p) {
+  const int Hp = gh * p, Wp = gw * p;
+  const size_t n = (size_t)B * Cc * Hp * Wp;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+    const int x = i % Wp; size_t r = i / Wp;
+    const int y = r % Hp; r /= Hp;
+    const int ci = r % Cc; const int b = r / Cc;
+    const float v = (y < H && x < W) ? img[(((size_t)b * Cc + ci) * H + y) * W + x] : 0.f;
+    const size_t row = ((size_t)b * gh + y / p) * gw + x / p;
+    st1(cols, c_dt, row * (Cc * p * p) + (ci * p + y % p) * p + x % p, v);
+  }
+}
+// img[b,co,y,x] = cols[(b,y/p,x/p)][co*p*p + (y%p)*p + x%p] + bias[co]   for y < H, x < W (crop, model.py:632-637)
+__global__ void unpatchify_kernel(const void* cols, int c_dt, const float* bias, float* img, int B, int Cc, int H, int W,
+                                  int gh, int gw, int p) {
+  const size_t n = (size_t)B * Cc * H * W;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+    const int x = i % W; size_t r = i / W;
+    const int y = r % H; r /= H;
+    const int co = r % Cc; const int b = r / Cc;
+    const size_t row = ((size_t)b * gh + y / p) * gw + x / p;
+    img[i] = ld1(cols, c_dt, row * (Cc * p * p) + (co * p + y % p) * p + x % p) + (bias ? bias[co] : 0.f);
+  }
+}
+extern "C" int scot_patchify(const float* img, void* cols, int c_dt, int B, int Cc, int H, int W, int p, hipStream_t s) {
+  const int gh = (H + p - 1) / p, gw = (W + p - 1) / p;
+  const size_t n = (size_t)B * Cc * gh * p * gw * p;
+  if (n == 0) return SCOT_ERR_SHAPE;
+  size_t blocks = (n + 255) / 256; if (blocks > 16384) blocks = 16384;
+  hipLaunchKernelGGL(patchify_kernel, dim3((unsigned)blocks), dim3(256), 0, s, img, cols, c_dt, B, Cc, H, W, gh, gw, p);
+  return scot_check_launch();
+}
+extern "C" int scot_unpatchify(const void* cols, int c_dt, const float* bias, float* img, int B, int Cc, int H, int W, int gh,
+                               int gw, int p, hipStream_t s) {
+  const size_t n = (size_t)B * Cc * H * W;
+  if (n == 0 || H > gh * p || W > gw * p) return SCOT_ERR_SHAPE;
+  size_t blocks = (n + 255) / 256; if (blocks > 16384) blocks = 16384;
+  hipLaunchKernelGGL(unpatchify_kernel, dim3((unsigned)blocks), dim3(256), 0, s, cols, c_dt, bias, img, B, Cc, H, W, gh, gw, p);
+  return scot_check_launch();
+}
+
+// ------------------------------------------------------------------ per-channel sum of an NCHW tensor (ConvT bias grad)
+__global__ __launch_bounds__(256) void nchw_channel_sum_kernel(const float* x, float* out, int B, int Cc, int HW) {
+  __shared__ float red[4];
+  const int co = blockIdx.x, b = blockIdx.y;
+  const float* p = x + ((size_t)b * Cc + co) * HW;
+  float acc = 0.f;
+  for (int i = threadIdx.x; i < HW; i += 256) acc += p[i];
+  acc = wave_sum(acc);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) atomicAdd(&out[co], red[0] + red[1] + red[2] + red[3]);
+}
+extern "C" int scot_nchw_channel_sum(const float* x, float* out, int B, int Cc, int HW, hipStream_t s) {
+  hipLaunchKernelGGL(nchw_channel_sum_kernel, dim3(Cc, B), dim3(256), 0, s, x, out, B, Cc, HW);
+  return scot_check_launch();
+}
+
+// ------------------------------------------------------------------ column sums (bias grads) and layer-scale grad
+// out[n] += Σ_m x[m][n] (* y[m][n] if y)        grid (ceil(N/64), ceil(M/RC)), wave = 64 consecutive columns of a row
+__global__ __launch_bounds__(256) void colsum_kernel(const void* x, int x_dt, const void* y, int y_dt, float* out, int M, int N,
+                                                     int ld, int rc) {
+  __shared__ float red[4][64];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int col = blockIdx.x * 64 + lane;
+  const int r0 = blockIdx.y * rc, r1 = min(M, r0 + rc);
+  float acc = 0.f;
+  if (col < N) {
+    for (int r = r0 + wave; r < r1; r += 4) {
+      float v = ld1(x, x_dt, (size_t)r * ld + col);
+      if (y) v *= ld1(y, y_dt, (size_t)r * ld + col);
+      acc += v;
+    }
+  }
+  red[wave][lane] = acc;
+  __syncthreads();
+  if (wave == 0 && col < N) atomicAdd(&out[col], red[0][lane] + red[1][lane] + red[2][lane] + red[3][lane]);
+}
+extern "C" int scot_colsum(const void* x, int x_dt, const void* y, int y_dt, float* out, int M, int N, int ld, hipStream_t s) {
+  if (M <= 0 || N <= 0) return SCOT_ERR_SHAPE;
+  const int rc = 256;
+  hipLaunchKernelGGL(colsum_kernel, dim3((N + 63) / 64, (M + rc - 1) / rc), dim3(256), 0, s, x, x_dt, y, y_dt, out, M, N, ld, rc);
+  return scot_check_launch();
+}
+// out[m][n] = resid[m][n] + scale[n]*y[m][n]   (ConvNeXt layer-scale + residual, model.py:212-216; scale may be NULL)
+__global__ void scale_residual_kernel(const void* y, int y_dt, const float* scale, const void* resid, int r_dt, void* out,
+                                      int o_dt, size_t n, int N) {
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+    float v = ld1(y, y_dt, i) * (scale ? scale[i % N] : 1.f);
+    if (resid) v += ld1(resid, r_dt, i);
+    st1(out, o_dt, i, v);
+  }
+}
+extern "C" int scot_scale_residual(const void* y, int y_dt, const float* scale, const void* resid, int r_dt, void* out, int o_dt,
+                                   size_t rows, int N, hipStream_t s) {
+  const size_t n = rows * N;
+  if (n == 0) return SCOT_ERR_SHAPE;
+  size_t blocks = (n + 255) / 256; if (blocks > 16384) blocks = 16384;
+  hipLaunchKernelGGL(scale_residual_kernel, dim3((unsigned)blocks), dim3(256), 0, s, y, y_dt, scale, resid, r_dt, out, o_dt, n, N);
+  return scot_check_launch();
+}
+
+// ------------------------------------------------------------------ depthwise 7x7 convolution on token grids (NHWC)
+// reference: ConvNeXtBlock.dwconv = Conv2d(C, C, 7, padding=3, groups=C) (model.py:178-180,206); weight (C,1,7,7).
+// mode 0: y = conv(x, w) + bias           mode 1 (data grad): dx = conv(dy, flip(w))
+__global__ void dwconv7_kernel(const void* x, int x_dt, const float* w, const float* bias, void* y, int y_dt, int B, int H, int W,
+                               int C, int flip) {
+  const size_t n = (size_t)B * H * W * C;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+    const int c = i % C; size_t r = i / C;
+    const int xx = r % W; r /= W;
+    const int yy = r % H; const int b = r / H;
+    float acc = bias ? bias[c] : 0.f;
+    const float* wc = w + (size_t)c * 49;
+#pragma unroll
+    for (int ki = 0; ki < 7; ++ki) {
+      const int sy = yy + ki - 3;
+      if (sy < 0 || sy >= H) continue;
+#pragma unroll
+      for (int kj = 0; kj < 7; ++kj) {
+        const int sx = xx + kj - 3;
+        if (sx < 0 || sx >= W) continue;
+        const float wv = flip ? wc[(6 - ki) * 7 + (6 - kj)] : wc[ki * 7 + kj];
+        acc += wv * ld1(x, x_dt, (((size_t)b * H + sy) * W + sx) * C + c);
+      }
+    }
+    st1(y, y_dt, i, acc);
+  }
+}
+extern "C" int scot_dwconv7(const void* x, int x_dt, const float* w, const float* bias, void* y, int y_dt, int B, int H, int W,
+                            int C, int flip, hipStream_t s) {
+  const size_t n = (size_t)B * H * W * C;
+  if (n == 0) return SCOT_ERR_SHAPE;
+  size_t blocks = (n + 255) / 256; if (blocks > 32768) blocks = 32768;
+  hipLaunchKernelGGL(dwconv7_kernel, dim3((unsigned)blocks), dim3(256), 0, s, x, x_dt, w, bias, y, y_dt, B, H, W, C, flip);
+  return scot_check_launch();
+}
+// weight/bias grad: dw[c][ki][kj] += Σ dy[b,y,x,c]·x[b,y+ki-3,x+kj-3,c];  db[c] += Σ dy.   thread = channel, block = 64
+// channels x 4 row-groups; each block reduces `rows` image rows of one sample.
+__global__ __launch_bounds__(256) void dwconv7_wgrad_kernel(const void* dy, int dy_dt, const void* x, int x_dt, float* dw, float* db,
+                                                            int B, int H, int W, int C, int rows) {
+  __shared__ float red[4][64];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int c = blockIdx.x * 64 + lane;
+  const int b = blockIdx.z, y0 = blockIdx.y * rows, y1 = min(H, y0 + rows);
+  float acc[50];
+#pragma unroll
+  for (int k = 0; k < 50; ++k) acc[k] = 0.f;
+  if (c < C) {
+    for (int pos = y0 * W + wave; pos < y1 * W; pos += 4) {
+      const int yy = pos / W, xx = pos % W;
+      const float g = ld1(dy, dy_dt, (((size_t)b * H + yy) * W + xx) * C + c);
+      acc[49] += g;
+#pragma unroll
+      for (int ki = 0; ki < 7; ++ki) {
+        const int sy = yy + ki - 3;
+#pragma unroll
+        for (int kj = 0; kj < 7; ++kj) {
+          const int sx = xx + kj - 3;
+          if (sy >= 0 && sy < H && sx >= 0 && sx < W)
+            acc[ki * 7 + kj] += g * ld1(x, x_dt, (((size_t)b * H + sy) * W + sx) * C + c);
+        }
+      }
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < 50; ++k) {
+    red[wave][lane] = acc[k];
+    __syncthreads();
+    if (wave == 0 && c < C) {
+      const float v = red[0][lane] + red[1][lane] + red[2][lane] + red[3][lane];
+      if (k < 49) atomicAdd(&dw[(size_t)c * 49 + k], v); else atomicAdd(&db[c], v);
+    }
+    __syncthreads();
+  }
+}
+extern "C" int scot_dwconv7_wgrad(const void* dy, int dy_dt, const void* x, int x_dt, float* dw, float* db, int B, int H, int W,
+                                  int C, hipStream_t s) {
+  if (B <= 0 || H <= 0 || W <= 0 || C <= 0) return SCOT_ERR_SHAPE;
+  const int rows = H >= 32 ? 8 : (H >= 8 ? 4 : H);
+  hipLaunchKernelGGL(dwconv7_wgrad_kernel, dim3((C + 63) / 64, (H + rows - 1) / rows, B), dim3(256), 0, s, dy, dy_dt, x, x_dt,
+                     dw, db, B, H, W, C, rows);
+  return scot_check_launch();
+}
+
+// ------------------------------------------------------------------ 5x5 "mixup" convolution of the recovery head (NCHW)
+// reference: Conv2d(Cout, Cout, 5, padding=2, bias=False) (model.py:623-630,647).  Cc <= 8.
+// mode 0: out[b,co] = Σ_ci in[b,ci] * w[co][ci]      mode 1 (data grad): din[b,ci] = Σ_co dout[b,co] * flip(w[co][ci])
+__global__ __launch_bounds__(256) void conv5_kernel(const float* in, const float* w, float* out, int B, int Cc, int H, int W, int transpose) {
+  __shared__ float ws[8 * 8 * 25];
+  for (int i = threadIdx.x; i < Cc * Cc * 25; i += 256) {
+    // ws[o][c][k]: weight applied to input channel c for output channel o at tap k (already flipped/transposed)
+    const int k = i % 25, c = (i / 25) % Cc, o = i / (25 * Cc);
+    ws[i] = transpose ? w[((size_t)c * Cc + o) * 25 + (24 - k)] : w[((size_t)o * Cc + c) * 25 + k];
+  }
+  __syncthreads();
+  const size_t n = (size_t)B * H * W;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+    const int x = i % W; size_t r = i / W;
+    const int y = r % H; const int b = r / H;
+    float acc[8];
+#pragma unroll
+    for (int o = 0; o < 8; ++o) acc[o] = 0.f;
+    for (int c = 0; c < Cc; ++c) {
+      const float* ip = in + ((size_t)b * Cc + c) * H * W;
+#pragma unroll
+      for (int ki = 0; ki < 5; ++ki) {
+        const int sy = y + ki - 2;
+        if (sy < 0 || sy >= H) continue;
+#pragma unroll
+        for (int kj = 0; kj < 5; ++kj) {
+          const int sx = x + kj - 2;
+          if (sx < 0 || sx >= W) continue;
+          const float v = ip[(size_t)sy * W + sx];
+#pragma unroll
+          for (int o = 0; o < 8; ++o) if (o < Cc) acc[o] += v * ws[(o * Cc + c) * 25 + ki * 5 + kj];
+        }
+      }
+    }
+#pragma unroll
+    for (int o = 0; o < 8; ++o) if (o < Cc) out[(((size_t)b * Cc + o) * H + y) * W + x] = acc[o];
+  }
+}
+extern "C" int scot_conv5(const float* in, const float* w, float* out, int B, int Cc, int H, int W, int transpose, hipStream_t s) {
+  if (Cc <= 0 || Cc > 8) return SCOT_ERR_UNSUPPORTED;
+  const size_t n = (size_t)B * H * W;
+  size_t blocks = (n + 255) / 256; if (blocks > 16384) blocks = 16384;
+  hipLaunchKernelGGL(conv5_kernel, dim3((unsigned)blocks), dim3(256), 0, s, in, w, out, B, Cc, H, W, transpose);
+  return scot_check_launch();
+}
+// dw[co][ci][ki][kj] += Σ_{b,y,x} dout[b,co,y,x]·in[b,ci,y+ki-2,x+kj-2].  Block = (sample, strip of R rows): the strip of
+// dout and the haloed strip of `in` are staged in LDS, then thread t owns weight-grad element(s) t, t+256, ...
+constexpr int C5_R = 4;
+__global__ __launch_bounds__(256) void conv5_wgrad_kernel(const float* dout, const float* in, float* dw, int B, int Cc, int H, int W) {
+  extern __shared__ float sm[];
+  const int Wh = W + 4;
+  float* sd = sm;                          // [Cc][C5_R][W]
+  float* si = sm + (size_t)Cc * C5_R * W;  // [Cc][C5_R+4][W+4]
+  const int b = blockIdx.y, y0 = blockIdx.x * C5_R;
+  for (int i = threadIdx.x; i < Cc * C5_R * W; i += 256) {
+    const int x = i % W, r = (i / W) % C5_R, c = i / (W * C5_R);
+    const int y = y0 + r;
+    sd[i] = y < H ? dout[(((size_t)b * Cc + c) * H + y) * W + x] : 0.f;
+  }
+  for (int i = threadIdx.x; i < Cc * (C5_R + 4) * Wh; i += 256) {
+    const int x = i % Wh - 2, r = (i / Wh) % (C5_R + 4), c = i / (Wh * (C5_R + 4));
+    const int y = y0 + r - 2;
+    si[i] = (y >= 0 && y < H && x >= 0 && x < W) ? in[(((size_t)b * Cc + c) * H + y) * W + x] : 0.f;
+  }
+  __syncthreads();
+  for (int o = threadIdx.x; o < Cc * Cc * 25; o += 256) {
+    const int kj = o % 5, ki = (o / 5) % 5, ci = (o / 25) % Cc, co = o / (25 * Cc);
+    float acc = 0.f;
+    for (int r = 0; r < C5_R; ++r) {
+      const float* dp = sd + ((size_t)co * C5_R + r) * W;
+      const float* ip = si + ((size_t)ci * (C5_R + 4) + r + ki) * Wh + kj;
+      for (int x = 0; x < W; ++x) acc += dp[x] * ip[x];
+    }
+    atomicAdd(&dw[o], acc);
+  }
+}
+extern "C" int scot_conv5_wgrad(const float* dout, const float* in, float* dw, int B, int Cc, int H, int W, hipStream_t s) {
+  if (Cc <= 0 || Cc > 8) return SCOT_ERR_UNSUPPORTED;
+  const size_t sh = ((size_t)Cc * C5_R * W + (size_t)Cc * (C5_R + 4) * (W + 4)) * sizeof(float);
+  if (sh > 64 * 1024) return SCOT_ERR_UNSUPPORTED;
+  hipLaunchKernelGGL(conv5_wgrad_kernel, dim3((H + C5_R - 1) / C5_R, B), dim3(256), sh, s, dout, in, dw, B, Cc, H, W);
+  return scot_check_launch();
+}
+
+// ------------------------------------------------------------------ prediction head finalisation + loss
+// reference model.py:1411-1484:  pred += pixel_values[:, :Cout] (learn_residual);  pred[mask] = labels[mask];
+// loss = mean_g  L(pred_g, y_g) / (L(y_g, 0) + 1e-10)   (L = mean |.| for p=1, mean (.)^2 for p=2), or L(pred, y).
+// sums[g][0] = Σ |pred-y|^p,  sums[g][1] = Σ |y|^p  over group g.   group_of_channel[c] in [0,G).
+__global__ __launch_bounds__(256) void head_finalize_kernel(float* pred, const float* pv, int pv_ch, const float* labels,
+                                                            const unsigned char* mask, int mask_full, const int* group_of_channel,
+                                                            float* sums, int B, int Cc, int HW, int p) {
+  __shared__ float red[2][4];
+  const int co = blockIdx.y, b = blockIdx.z;
+  const size_t base = ((size_t)b * Cc + co) * HW;
+  const bool plane_masked = mask && !mask_full && mask[b * Cc + co];
+  float s1 = 0.f, s2 = 0.f;
+  for (int i = blockIdx.x * 256 + threadIdx.x; i < HW; i += gridDim.x * 256) {
+    float v = pred[base + i];
+    if (pv) v += pv[((size_t)b * pv_ch + co) * HW + i];
+    if (labels) {
+      const float y = labels[base + i];
+      if (plane_masked || (mask && mask_full && mask[base + i])) v = y;
+      const float d = v - y;
+      s1 += p == 1 ? fabsf(d) : d * d;
+      s2 += p == 1 ? fabsf(y) : y * y;
+    }
+    pred[base + i] = v;
+  }
+  if (!labels) return;
+  s1 = wave_sum(s1); s2 = wave_sum(s2);
+  if ((threadIdx.x & 63) == 0) { red[0][threadIdx.x >> 6] = s1; red[1][threadIdx.x >> 6] = s2; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const int g = group_of_channel[co];
+    if (g >= 0) {
+      atomicAdd(&sums[2 * g], red[0][0] + red[0][1] + red[0][2] + red[0][3]);
+      atomicAdd(&sums[2 * g + 1], red[1][0] + red[1][1] + red[1][2] + red[1][3]);
+    }
+  }
+}
+// loss (scalar, stays on device) from the group sums;  counts[g] = number of elements of group g
+__global__ void loss_finish_kernel(const float* sums, const float* counts, int G, int normalized, float* loss) {
+  if (threadIdx.x == 0 && blockIdx.x == 0) {
+    float acc = 0.f;
+    for (int g = 0; g < G; ++g) {
+      const float num = sums[2 * g] / counts[g];
+      acc += normalized ? num / (sums[2 * g + 1] / counts[g] + 1e-10f) : num;
+    }
+    *loss = acc / G;
+  }
+}
+// dpred = dloss · ∂loss/∂pred
+__global__ void loss_bwd_kernel(const float* pred, const float* labels, const unsigned char* mask, int mask_full,
+                                const int* group_of_channel, const float* sums, const float* counts, int G, int normalized,
+                                const float* dloss, float* dpred, int B, int Cc, int HW, int p) {
+  const size_t n = (size_t)B * Cc * HW;
+  const float gl = dloss ? *dloss : 1.f;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+    const int co = (i / HW) % Cc, b = i / ((size_t)HW * Cc);
+    const int g = group_of_channel[co];
+    float d = 0.f;
+    const bool masked = mask && (mask_full ? mask[i] : mask[b * Cc + co]);
+    if (g >= 0 && !masked) {
+      const float diff = pred[i] - labels[i];
+      float coef = gl / (G * counts[g]);
+      if (normalized) coef /= (sums[2 * g + 1] / counts[g] + 1e-10f);
+      d = p == 1 ? (diff > 0.f ? coef : (diff < 0.f ? -coef : 0.f)) : 2.f * diff * coef;
+    }
+    dpred[i] = d;
+  }
+}
+extern "C" int scot_head_finalize(float* pred, const float* pv, int pv_ch, const float* labels, const unsigned char* mask,
+                                  int mask_full, const int* group_of_channel, float* sums, int B, int Cc, int HW, int p,
+                                  hipStream_t s) {
+  if (B <= 0 || Cc <= 0 || HW <= 0 || (p != 1 && p != 2)) return SCOT_ERR_SHAPE;
+  int bx = (HW + 4095) / 4096; if (bx < 1) bx = 1;
+  hipLaunchKernelGGL(head_finalize_kernel, dim3(bx, Cc, B), dim3(256), 0, s, pred, pv, pv_ch, labels, mask, mask_full,
+                     group_of_channel, sums, B, Cc, HW, p);
+  return scot_check_launch();
+}
+extern "C" int scot_loss_finish(const float* sums, const float* counts, int G, int normalized, float* loss, hipStream_t s) {
+  hipLaunchKernelGGL(loss_finish_kernel, dim3(1), dim3(64), 0, s, sums, counts, G, normalized, loss);
+  return scot_check_launch();
+}
+extern "C" int scot_loss_bwd(const float* pred, const float* labels, const unsigned char* mask, int mask_full,
+                             const int* group_of_channel, const float* sums, const float* counts, int G, int normalized,
+                             const float* dloss, float* dpred, int B, int Cc, int HW, int p, hipStream_t s) {
+  const size_t n = (size_t)B * Cc * HW;
+  size_t blocks = (n + 255) / 256; if (blocks > 16384) blocks = 16384;
+  hipLaunchKernelGGL(loss_bwd_kernel, dim3((unsigned)blocks), dim3(256), 0, s, pred, labels, mask, mask_full, group_of_channel,
+                     sums, counts, G, normalized, dloss, dpred, B, Cc, HW, p);
+  return scot_check_launch();
+}
+
+// ------------------------------------------------------------------ continuous relative position bias MLP
+// reference HF:376-378, 418-428:  table[h][e] = 16·sigmoid( relu(coords[e]·W0^T + b0) · W2[h]^T ),  e over (2ws-1)^2.
+// Batch-independent: once per layer per step.  z (pre-sigmoid) is saved for the backward.
+__global__ __launch_bounds__(256) void cpb_fwd_kernel(const float* coords, const float* w0, const float* b0, const float* w2,
+                                                      float* table, float* z, int TS, int heads) {
+  __shared__ float red[4];
+  const int e = blockIdx.x;
+  const float cy = coords[2 * e], cx = coords[2 * e + 1];
+  float hid[2];
+#pragma unroll
+  for (int k = 0; k < 2; ++k) {
+    const int j = threadIdx.x + 256 * k;
+    hid[k] = fmaxf(w0[2 * j] * cy + w0[2 * j + 1] * cx + b0[j], 0.f);
+  }
+  for (int h = 0; h < heads; ++h) {
+    float acc = hid[0] * w2[h * 512 + threadIdx.x] + hid[1] * w2[h * 512 + threadIdx.x + 256];
+    acc = wave_sum(acc);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      const float zz = red[0] + red[1] + red[2] + red[3];
+      z[(size_t)e * heads + h] = zz;
+      table[(size_t)h * TS + e] = 16.0f / (1.0f + __expf(-zz));
+    }
+    __syncthreads();
+  }
+}
+// Backward: block owns JB hidden units (no atomics, deterministic +=); threads stride over the table entries.
+constexpr int CPB_JB = 4;
+__global__ __launch_bounds__(256) void cpb_bwd_kernel(const float* coords, const float* w0, const float* b0, const float* w2,
+                                                      const float* z, const float* dtable, float* dw0, float* db0, float* dw2,
+                                                      int TS, int heads) {
+  __shared__ float red[4];
+  const int j0 = blockIdx.x * CPB_JB;
+  float a_w2[CPB_JB][24], a_w0y[CPB_JB], a_w0x[CPB_JB], a_b0[CPB_JB];
+#pragma unroll
+  for (int jj = 0; jj < CPB_JB; ++jj) {
+    a_w0y[jj] = a_w0x[jj] = a_b0[jj] = 0.f;
+#pragma unroll
+    for (int h = 0; h < 24; ++h) a_w2[jj][h] = 0.f;
+  }
+  for (int e = threadIdx.x; e < TS; e += 256) {
+    const float cy = coords[2 * e], cx = coords[2 * e + 1];
+    float dz[24];
+#pragma unroll
+    for (int h = 0; h < 24; ++h) {
+      dz[h] = 0.f;
+      if (h < heads) {
+        const float sg = 1.0f / (1.0f + __expf(-z[(size_t)e * heads + h]));
+        dz[h] = dtable[(size_t)h * TS + e] * 16.0f * sg * (1.0f - sg);
+      }
+    }
+#pragma unroll
+    for (int jj = 0; jj < CPB_JB; ++jj) {
+      const int j = j0 + jj;
+      const float pre = w0[2 * j] * cy + w0[2 * j + 1] * cx + b0[j];
+      const float hid = fmaxf(pre, 0.f);
+      float dh = 0.f;
+#pragma unroll
+      for (int h = 0; h < 24; ++h) {
+        if (h < heads) { a_w2[jj][h] += dz[h] * hid; dh += dz[h] * w2[h * 512 + j]; }
+      }
+      const float dpre = pre > 0.f ? dh : 0.f;
+      a_w0y[jj] += dpre * cy; a_w0x[jj] += dpre * cx; a_b0[jj] += dpre;
+    }
+  }
+  auto block_sum = [&](float v) -> float {
+    v = wave_sum(v);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+    __syncthreads();
+    return red[0] + red[1] + red[2] + red[3];
+  };
+#pragma unroll
+  for (int jj = 0; jj < CPB_JB; ++jj) {
+    const int j = j0 + jj;
+    float v = block_sum(a_w0y[jj]); if (threadIdx.x == 0) dw0[2 * j] += v;
+    v = block_sum(a_w0x[jj]); if (threadIdx.x == 0) dw0[2 * j + 1] += v;
+    v = block_sum(a_b0[jj]); if (threadIdx.x == 0) db0[j] += v;
+#pragma unroll
+    for (int h = 0; h < 24; ++h) {
+      if (h < heads) { v = block_sum(a_w2[jj][h]); if (threadIdx.x == 0) dw2[h * 512 + j] += v; }
+    }
+  }
+}
+extern "C" int scot_cpb_fwd(const float* coords, const float* w0, const float* b0, const float* w2, float* table, float* z,
+                            int ws, int heads, hipStream_t s) {
+  const int TS = (2 * ws - 1) * (2 * ws - 1);
+  if (heads <= 0 || heads > 24 || ws <= 0) return SCOT_ERR_UNSUPPORTED;
+  hipLaunchKernelGGL(cpb_fwd_kernel, dim3(TS), dim3(256), 0, s, coords, w0, b0, w2, table, z, TS, heads);
+  return scot_check_launch();
+}
+extern "C" int scot_cpb_bwd(const float* coords, const float* w0, const float* b0, const float* w2, const float* z,
+                            const float* dtable, float* dw0, float* db0, float* dw2, int ws, int heads, hipStream_t s) {
+  const int TS = (2 * ws - 1) * (2 * ws - 1);
+  if (heads <= 0 || heads > 24 || ws <= 0) return SCOT_ERR_UNSUPPORTED;
+  hipLaunchKernelGGL(cpb_bwd_kernel, dim3(512 / CPB_JB), dim3(256), 0, s, coords, w0, b0, w2, z, dtable, dw0, db0, dw2, TS, heads);
+  return scot_check_launch();
+}
+
+// ------------------------------------------------------------------ library state / self test
+int g_scot_use_tr = 1;
+
+__global__ void tr_probe_kernel(int* ok) {
+  __shared__ __attribute__((aligned(16))) bf16_t t[64 * 24];
+  for (int i = threadIdx.x; i < 64 * 24; i += 64) t[i] = (bf16_t)i;
+  __syncthreads();
+  const int lane = threadIdx.x, g = lane >> 4;
+  const Frag<bf16_t> a = lds_frag_ks(t, 24, 0, g * 8, g * 8 + 4, lane, 1);
+  const Frag<bf16_t> b = lds_frag_ks(t, 24, 0, g * 8, g * 8 + 4, lane, 0);
+  int good = 1;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) good &= (a.v[j] == b.v[j]);
+  const unsigned long long m = __ballot(good);
+  if (lane == 0) *ok = (m == ~0ull) ? 1 : 0;
+}
+// Verifies on the device that ds_read_b64_tr_b16 has the lane/element semantics lds_frag_ks assumes; if not, every
+// kernel falls back to the scalar LDS gather (same results, slower).  Returns 1 (tr in use) / 0 (fallback) / <0 error.
+extern "C" int scot_selftest_tr(hipStream_t s) {
+  int* d = nullptr;
+  if (hipMalloc(&d, sizeof(int)) != hipSuccess) return SCOT_ERR_LAUNCH;
+  hipLaunchKernelGGL(tr_probe_kernel, dim3(1), dim3(64), 0, s, d);
+  int h = 0;
+  if (hipMemcpyAsync(&h, d, sizeof(int), hipMemcpyDeviceToHost, s) != hipSuccess || hipStreamSynchronize(s) != hipSuccess) {
+    (void)hipFree(d);
+    return SCOT_ERR_LAUNCH;
+  }
+  (void)hipFree(d);
+  g_scot_use_tr = h ? 1 : 0;
+  return g_scot_use_tr;
+}
+extern "C" void scot_set_use_tr(int v) { g_scot_use_tr = v ? 1 : 0; }
+extern "C" int scot_get_use_tr() { return g_scot_use_tr; }
+extern "C" int scot_abi_version() { return 1; }

@@ -1,0 +1,80 @@
+"""ctypes binding of libscot_hip.so (the C ABI declared in include/scot_hip.h).
+
+The product path has NO fallback: if the library is missing or a call returns a non-zero status a RuntimeError is
+raised.  (`build.py` compiles it in-tree with hipcc for gfx950; the .so travels to the GPU box with the repo.)
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+from ctypes import c_float, c_int, c_size_t, c_void_p
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libscot_hip.so")
+
+P, I, F, Z = c_void_p, c_int, c_float, c_size_t
+
+# name -> argtypes (restype is int unless listed in _VOID)
+PROTOTYPES = {
+    "scot_abi_version": [],
+    "scot_selftest_tr": [P],
+    "scot_set_use_tr": [I],
+    "scot_get_use_tr": [],
+    "scot_gemm": [I, I, I, I, I, P, I, I, I, P, I, I, I, P, I, I, P, P, P, I, I, P, I, I, I, P],
+    "scot_window_attn_fwd": [I, P, P, P, P, P, I, I, I, I, I, I, I, P],
+    "scot_window_attn_bwd": [I, P, P, P, P, P, P, P, P, I, I, I, I, I, I, I, P],
+    "scot_cpb_fwd": [P, P, P, P, P, P, I, I, P],
+    "scot_cpb_bwd": [P, P, P, P, P, P, P, P, P, I, I, P],
+    "scot_cln_fwd": [P, I, P, I, P, I, P, P, P, P, P, P, P, I, I, I, F, P],
+    "scot_cln_bwd": [P, I, P, I, P, P, P, P, P, P, I, P, P, P, P, I, I, I, P],
+    "scot_add": [P, I, P, I, P, I, Z, Z, P],
+    "scot_batch_sum": [P, I, P, I, Z, P],
+    "scot_copy2d": [P, I, P, I, I, I, I, I, I, I, P],
+    "scot_space_to_depth": [P, P, I, P, I, I, I, I, I, I, P],
+    "scot_depth_to_space": [P, I, P, I, I, I, I, I, I, I, I, P],
+    "scot_patchify": [P, P, I, I, I, I, I, I, P],
+    "scot_unpatchify": [P, I, P, P, I, I, I, I, I, I, I, P],
+    "scot_nchw_channel_sum": [P, P, I, I, I, P],
+    "scot_colsum": [P, I, P, I, P, I, I, I, P],
+    "scot_scale_residual": [P, I, P, P, I, P, I, Z, I, P],
+    "scot_dwconv7": [P, I, P, P, P, I, I, I, I, I, I, P],
+    "scot_dwconv7_wgrad": [P, I, P, I, P, P, I, I, I, I, P],
+    "scot_conv5": [P, P, P, I, I, I, I, I, P],
+    "scot_conv5_wgrad": [P, P, P, I, I, I, I, P],
+    "scot_head_finalize": [P, P, I, P, P, I, P, P, I, I, I, I, P],
+    "scot_loss_finish": [P, P, I, I, P, P],
+    "scot_loss_bwd": [P, P, P, I, P, P, P, I, I, P, P, I, I, I, I, P],
+}
+_VOID = {"scot_set_use_tr"}
+
+_lib = None
+
+
+class ScotLibraryError(RuntimeError):
+    pass
+
+
+def load(path: str = LIB_PATH):
+    """Load (once) and type the library.  Raises if it is absent — there is no CPU/PyTorch fallback."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(path):
+        raise ScotLibraryError(
+            f"{path} not found: the scOT hot path is HIP-only. Build it with `python -m poseidon_amd.build` "
+            "(hipcc --offload-arch=gfx950).")
+    lib = ctypes.CDLL(path)
+    for name, argtypes in PROTOTYPES.items():
+        fn = getattr(lib, name)  # AttributeError if a declared symbol is missing
+        fn.argtypes = argtypes
+        fn.restype = None if name in _VOID else c_int
+    _lib = lib
+    return lib
+
+
+_ERR = {-1: "bad shape", -2: "bad dtype", -3: "unsupported configuration", -4: "kernel launch failed"}
+
+
+def check(rc: int, what: str) -> None:
+    if rc != 0:
+        raise ScotLibraryError(f"{what} failed: {_ERR.get(rc, rc)}")

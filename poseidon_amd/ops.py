@@ -1,0 +1,192 @@
+"""Thin tensor-level wrappers over the C ABI: pointers, sizes and the current HIP stream go down, nothing else.
+
+Every function enqueues exactly the kernels named in its docstring on torch's current stream and returns
+immediately (no synchronisation).  Tensors must live on the GPU and be contiguous; dtype is float32 or bfloat16.
+"""
+from __future__ import annotations
+
+from typing import Optional
+
+import torch
+
+from . import lib as _lib
+
+F32, BF16 = 0, 1
+NT, NN, TN = 0, 1, 2
+
+
+def dt(t: torch.Tensor) -> int:
+    if t.dtype == torch.float32:
+        return F32
+    if t.dtype == torch.bfloat16:
+        return BF16
+    raise TypeError(f"unsupported dtype {t.dtype}")
+
+
+def ptr(t: Optional[torch.Tensor]):
+    if t is None:
+        return None
+    if not t.is_cuda:
+        raise _lib.ScotLibraryError("scOT HIP ops need GPU tensors (no CPU path exists in the product)")
+    return t.data_ptr()
+
+
+def stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+_selftested = False
+
+
+def L():
+    """Library handle; runs the one-time device self test of the transposing LDS read on first use."""
+    global _selftested
+    l = _lib.load()
+    if not _selftested and torch.cuda.is_available():
+        rc = l.scot_selftest_tr(stream())
+        if rc < 0:
+            raise _lib.ScotLibraryError("scot_selftest_tr failed to run")
+        _selftested = True
+    return l
+
+
+def gemm(layout: int, compute: int, M: int, N: int, K: int, A, lda: int, B, ldb: int, C, ldc: int, *, bias=None,
+         colscale=None, aux=None, ldaux: int = 0, resid=None, ldres: int = 0, a_gelu: bool = False, b_gelu: bool = False,
+         accumulate: bool = False) -> None:
+    """scot_gemm — see include/scot_hip.h."""
+    rc = L().scot_gemm(layout, compute, M, N, K, ptr(A), dt(A), lda, int(a_gelu), ptr(B), dt(B), ldb, int(b_gelu),
+                       ptr(C), dt(C), ldc, ptr(bias), ptr(colscale), ptr(aux), dt(aux) if aux is not None else 0, ldaux,
+                       ptr(resid), dt(resid) if resid is not None else 0, ldres, int(accumulate), stream())
+    _lib.check(rc, "scot_gemm")
+
+
+def linear_fwd(compute, x, w, out, bias=None, a_gelu=False, K=None):
+    """out[M,N] = act(x)[M,K] @ w[N,K]^T + bias."""
+    M = x.numel() // x.shape[-1]
+    N, Kw = w.shape[0], w.numel() // w.shape[0]
+    gemm(NT, compute, M, N, Kw, x, x.shape[-1], w, Kw, out, out.shape[-1], bias=bias, a_gelu=a_gelu)
+
+
+def linear_dgrad(compute, dy, w, dx, accumulate=False, aux=None):
+    """dx[M,K] (+)= dy[M,N] @ w[N,K]  (* gelu'(aux))."""
+    M = dy.numel() // dy.shape[-1]
+    N, K = w.shape[0], w.numel() // w.shape[0]
+    gemm(NN, compute, M, K, N, dy, dy.shape[-1], w, K, dx, dx.shape[-1], aux=aux, ldaux=aux.shape[-1] if aux is not None else 0,
+         accumulate=accumulate)
+
+
+def linear_wgrad(compute, dy, x, dw, b_gelu=False):
+    """dw[N,K] += dy[M,N]^T @ act(x)[M,K]."""
+    M = dy.numel() // dy.shape[-1]
+    N, K = dy.shape[-1], x.shape[-1]
+    gemm(TN, compute, N, K, M, dy, N, x, K, dw, K, b_gelu=b_gelu, accumulate=True)
+
+
+def colsum(x, out, y=None):
+    M = x.numel() // x.shape[-1]
+    N = x.shape[-1]
+    _lib.check(L().scot_colsum(ptr(x), dt(x), ptr(y), dt(y) if y is not None else 0, ptr(out), M, N, N, stream()), "scot_colsum")
+
+
+def window_attn_fwd(compute, qkv, out, lse, bias_table, logit_scale, batch, Hp, Wp, C, heads, ws, shift):
+    _lib.check(L().scot_window_attn_fwd(compute, ptr(qkv), ptr(out), ptr(lse), ptr(bias_table), ptr(logit_scale), batch, Hp, Wp,
+                                        C, heads, ws, shift, stream()), "scot_window_attn_fwd")
+
+
+def window_attn_bwd(compute, qkv, dout, lse, bias_table, logit_scale, dqkv, dbias_table, dlogit_scale, batch, Hp, Wp, C, heads,
+                    ws, shift):
+    _lib.check(L().scot_window_attn_bwd(compute, ptr(qkv), ptr(dout), ptr(lse), ptr(bias_table), ptr(logit_scale), ptr(dqkv),
+                                        ptr(dbias_table), ptr(dlogit_scale), batch, Hp, Wp, C, heads, ws, shift, stream()),
+               "scot_window_attn_bwd")
+
+
+def cpb_fwd(coords, w0, b0, w2, table, z, ws, heads):
+    _lib.check(L().scot_cpb_fwd(ptr(coords), ptr(w0), ptr(b0), ptr(w2), ptr(table), ptr(z), ws, heads, stream()), "scot_cpb_fwd")
+
+
+def cpb_bwd(coords, w0, b0, w2, z, dtable, dw0, db0, dw2, ws, heads):
+    _lib.check(L().scot_cpb_bwd(ptr(coords), ptr(w0), ptr(b0), ptr(w2), ptr(z), ptr(dtable), ptr(dw0), ptr(db0), ptr(dw2), ws,
+                                heads, stream()), "scot_cpb_bwd")
+
+
+def cln_fwd(x, resid, out, mean, rstd, time, gw_w, gw_b, bw_w, bw_b, rows, rows_per_sample, C, eps):
+    _lib.check(L().scot_cln_fwd(ptr(x), dt(x), ptr(resid), dt(resid) if resid is not None else 0, ptr(out), dt(out), ptr(mean),
+                                ptr(rstd), ptr(time), ptr(gw_w), ptr(gw_b), ptr(bw_w), ptr(bw_b), rows, rows_per_sample, C,
+                                float(eps), stream()), "scot_cln_fwd")
+
+
+def cln_bwd(dout, x, mean, rstd, time, gw_w, gw_b, dx, d_gw_w, d_gw_b, d_bw_w, d_bw_b, rows, rows_per_sample, C):
+    _lib.check(L().scot_cln_bwd(ptr(dout), dt(dout), ptr(x), dt(x), ptr(mean), ptr(rstd), ptr(time), ptr(gw_w), ptr(gw_b),
+                                ptr(dx), dt(dx), ptr(d_gw_w), ptr(d_gw_b), ptr(d_bw_w), ptr(d_bw_b), rows, rows_per_sample, C,
+                                stream()), "scot_cln_bwd")
+
+
+def add(a, b, out, period=None):
+    n = a.numel()
+    _lib.check(L().scot_add(ptr(a), dt(a), ptr(b), dt(b), ptr(out), dt(out), n, period if period is not None else n, stream()),
+               "scot_add")
+
+
+def batch_sum(x, out, batch, period):
+    _lib.check(L().scot_batch_sum(ptr(x), dt(x), ptr(out), batch, period, stream()), "scot_batch_sum")
+
+
+def copy2d(src, dst, B, Hs, Ws, Hd, Wd, C):
+    _lib.check(L().scot_copy2d(ptr(src), dt(src), ptr(dst), dt(dst), B, Hs, Ws, Hd, Wd, C, stream()), "scot_copy2d")
+
+
+def space_to_depth(fine, fine2, coarse, B, H, W, C, order):
+    _lib.check(L().scot_space_to_depth(ptr(fine), ptr(fine2), dt(fine), ptr(coarse), dt(coarse), B, H, W, C, order, stream()),
+               "scot_space_to_depth")
+
+
+def depth_to_space(coarse, fine, B, H, W, H2, W2, C, order):
+    _lib.check(L().scot_depth_to_space(ptr(coarse), dt(coarse), ptr(fine), dt(fine), B, H, W, H2, W2, C, order, stream()),
+               "scot_depth_to_space")
+
+
+def patchify(img, cols, B, Cc, H, W, p):
+    _lib.check(L().scot_patchify(ptr(img), ptr(cols), dt(cols), B, Cc, H, W, p, stream()), "scot_patchify")
+
+
+def unpatchify(cols, bias, img, B, Cc, H, W, gh, gw, p):
+    _lib.check(L().scot_unpatchify(ptr(cols), dt(cols), ptr(bias), ptr(img), B, Cc, H, W, gh, gw, p, stream()), "scot_unpatchify")
+
+
+def nchw_channel_sum(x, out, B, Cc, HW):
+    _lib.check(L().scot_nchw_channel_sum(ptr(x), ptr(out), B, Cc, HW, stream()), "scot_nchw_channel_sum")
+
+
+def scale_residual(y, scale, resid, out, rows, N):
+    _lib.check(L().scot_scale_residual(ptr(y), dt(y), ptr(scale), ptr(resid), dt(resid) if resid is not None else 0, ptr(out),
+                                       dt(out), rows, N, stream()), "scot_scale_residual")
+
+
+def dwconv7(x, w, bias, y, B, H, W, C, flip=False):
+    _lib.check(L().scot_dwconv7(ptr(x), dt(x), ptr(w), ptr(bias), ptr(y), dt(y), B, H, W, C, int(flip), stream()), "scot_dwconv7")
+
+
+def dwconv7_wgrad(dy, x, dw, db, B, H, W, C):
+    _lib.check(L().scot_dwconv7_wgrad(ptr(dy), dt(dy), ptr(x), dt(x), ptr(dw), ptr(db), B, H, W, C, stream()), "scot_dwconv7_wgrad")
+
+
+def conv5(inp, w, out, B, Cc, H, W, transpose=False):
+    _lib.check(L().scot_conv5(ptr(inp), ptr(w), ptr(out), B, Cc, H, W, int(transpose), stream()), "scot_conv5")
+
+
+def conv5_wgrad(dout, inp, dw, B, Cc, H, W):
+    _lib.check(L().scot_conv5_wgrad(ptr(dout), ptr(inp), ptr(dw), B, Cc, H, W, stream()), "scot_conv5_wgrad")
+
+
+def head_finalize(pred, pv, pv_ch, labels, mask, mask_full, group_of_channel, sums, B, Cc, HW, p):
+    _lib.check(L().scot_head_finalize(ptr(pred), ptr(pv), pv_ch, ptr(labels), ptr(mask), int(mask_full), ptr(group_of_channel),
+                                      ptr(sums), B, Cc, HW, p, stream()), "scot_head_finalize")
+
+
+def loss_finish(sums, counts, G, normalized, loss):
+    _lib.check(L().scot_loss_finish(ptr(sums), ptr(counts), G, int(normalized), ptr(loss), stream()), "scot_loss_finish")
+
+
+def loss_bwd(pred, labels, mask, mask_full, group_of_channel, sums, counts, G, normalized, dloss, dpred, B, Cc, HW, p):
+    _lib.check(L().scot_loss_bwd(ptr(pred), ptr(labels), ptr(mask), int(mask_full), ptr(group_of_channel), ptr(sums), ptr(counts),
+                                 G, int(normalized), ptr(dloss), ptr(dpred), B, Cc, HW, p, stream()), "scot_loss_bwd")

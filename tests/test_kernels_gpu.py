@@ -1,0 +1,403 @@
+"""GPU parity tests of every C-ABI kernel against a plain PyTorch reference of the same op (fp64 on the GPU).
+Run on the MI355X box:  python -m pytest tests -m gpu -q
+Tolerances: compute=f32 (exact fp32 MFMA) 2e-5 rel-L2; compute=bf16: operands are rounded to bf16 (2^-9), tolerance
+stated per test (the reference is evaluated on the SAME bf16-rounded operands where that isolates kernel error)."""
+import math
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from poseidon_amd import ops  # noqa: E402
+
+DEV = "cuda"
+
+
+def rel(a, b):
+    a, b = a.double(), b.double()
+    return float((a - b).norm() / b.norm().clamp_min(1e-30))
+
+
+def rnd(*shape, dtype=torch.float32, scale=1.0, seed=0):
+    g = torch.Generator(device="cpu").manual_seed(seed + sum(shape))
+    return (torch.randn(*shape, generator=g) * scale).to(DEV).to(dtype)
+
+
+def test_selftest_tr():
+    l = ops.L()
+    print("use_tr =", l.scot_get_use_tr())
+    assert l.scot_get_use_tr() in (0, 1)
+
+
+# ----------------------------------------------------------------------------------------------- GEMM
+@pytest.mark.parametrize("compute", [ops.F32, ops.BF16])
+@pytest.mark.parametrize("layout", [ops.NT, ops.NN, ops.TN])
+@pytest.mark.parametrize("M,N,K", [(300, 96, 96), (1024, 288, 96), (257, 130, 72), (4096, 384, 96), (64, 64, 3072),
+                                   (1024, 768, 768)])
+def test_gemm_layouts(compute, layout, M, N, K):
+    adt = torch.float32 if compute == ops.F32 else torch.bfloat16
+    if layout == ops.NT:
+        A, B = rnd(M, K, dtype=adt), rnd(N, K, scale=0.1, seed=1)
+        ref = A.double() @ B.double().t()
+    elif layout == ops.NN:
+        A, B = rnd(M, K, dtype=adt), rnd(K, N, scale=0.1, seed=1)
+        ref = A.double() @ B.double()
+    else:
+        A, B = rnd(K, M, dtype=adt), rnd(K, N, dtype=adt, scale=0.1, seed=1)
+        ref = A.double().t() @ B.double()
+    if compute == ops.BF16:  # reference on bf16-rounded operands
+        Bq = B.to(torch.bfloat16).double()
+        ref = (A.double() @ Bq.t()) if layout == ops.NT else ((A.double() @ Bq) if layout == ops.NN else (A.double().t() @ Bq))
+    C = torch.zeros(M, N, device=DEV) if layout == ops.TN else torch.full((M, N), float("nan"), device=DEV)
+    ops.gemm(layout, compute, M, N, K, A, A.shape[1], B, B.shape[1], C, N, accumulate=(layout == ops.TN))
+    torch.cuda.synchronize()
+    tol = 2e-5 if compute == ops.F32 else 2e-3
+    assert rel(C, ref) < tol
+
+
+@pytest.mark.parametrize("compute", [ops.F32, ops.BF16])
+def test_gemm_epilogues(compute):
+    M, N, K = 520, 192, 96
+    cdt = torch.float32 if compute == ops.F32 else torch.bfloat16
+    x, w, b = rnd(M, K), rnd(N, K, scale=0.1, seed=1), rnd(N, seed=2)
+    tol = 2e-5 if compute == ops.F32 else 1e-2
+    # fc1: u = x w^T + b (stored in compute dtype)
+    u = torch.empty(M, N, device=DEV, dtype=cdt)
+    ops.linear_fwd(compute, x, w, u, bias=b)
+    ref_u = x.double() @ w.double().t() + b.double()
+    assert rel(u, ref_u) < tol
+    # fc2 with GELU on load: y = gelu(u) w2^T + b2, f32 out, + residual + colscale
+    w2, b2, cs, res = rnd(K, N, scale=0.1, seed=3), rnd(K, seed=4), rnd(K, seed=5), rnd(M, K, seed=6)
+    y = torch.empty(M, K, device=DEV)
+    ops.gemm(ops.NT, compute, M, K, N, u, N, w2, N, y, K, bias=b2, colscale=cs, resid=res, ldres=K, a_gelu=True)
+    g = torch.nn.functional.gelu(u.double())
+    ref_y = (g @ w2.double().t() + b2.double()) * cs.double() + res.double()
+    assert rel(y, ref_y) < tol
+    # dgrad with gelu' epilogue: du = (dy w2) * gelu'(u); accumulate variant
+    dy = rnd(M, K, dtype=cdt, seed=7)
+    du = torch.empty(M, N, device=DEV, dtype=cdt)
+    ops.linear_dgrad(compute, dy, w2, du, aux=u)
+    ud = u.double()
+    gp = 0.5 * (1 + torch.erf(ud / math.sqrt(2))) + ud * torch.exp(-0.5 * ud * ud) / math.sqrt(2 * math.pi)
+    ref_du = (dy.double() @ w2.double()) * gp
+    assert rel(du, ref_du) < tol
+    acc = rnd(M, N, seed=8)
+    acc0 = acc.clone()
+    ops.linear_dgrad(compute, dy, w2, acc, accumulate=True)
+    assert rel(acc, acc0.double() + dy.double() @ w2.double()) < tol
+    # wgrad with GELU on the B operand: dw2 += dy^T gelu(u);  bias grad via colsum
+    dw2 = torch.zeros(K, N, device=DEV)
+    ops.linear_wgrad(compute, dy, u, dw2, b_gelu=True)
+    assert rel(dw2, dy.double().t() @ g) < tol
+    db = torch.zeros(K, device=DEV)
+    ops.colsum(dy, db)
+    assert rel(db, dy.double().sum(0)) < 1e-5
+
+
+# ----------------------------------------------------------------------------------------------- attention
+def _attn_ref(qkv, table, logit_scale, B, Hp, Wp, C, heads, ws, shift):
+    """fp64 torch restatement on [B, Hp*Wp, 3C] with roll/partition (HF:389-455, ref model.py:522-559)."""
+    N, d = ws * ws, C // heads
+    x = qkv.view(B, Hp, Wp, 3 * C)
+    if shift:
+        x = torch.roll(x, (-shift, -shift), (1, 2))
+    xw = x.view(B, Hp // ws, ws, Wp // ws, ws, 3 * C).permute(0, 1, 3, 2, 4, 5).reshape(-1, N, 3 * C)
+    q, k, v = [t.reshape(-1, N, heads, d).transpose(1, 2) for t in xw.split(C, dim=-1)]
+    qn = q / q.norm(dim=-1, keepdim=True).clamp_min(1e-12)
+    kn = k / k.norm(dim=-1, keepdim=True).clamp_min(1e-12)
+    s = qn @ kn.transpose(-1, -2) * torch.exp(torch.clamp(logit_scale, max=math.log(100.0))).view(1, heads, 1, 1)
+    yy = torch.arange(ws, device=qkv.device).repeat_interleave(ws)
+    xx = torch.arange(ws, device=qkv.device).repeat(ws)
+    idx = (yy.view(-1, 1) - yy.view(1, -1) + ws - 1) * (2 * ws - 1) + (xx.view(-1, 1) - xx.view(1, -1) + ws - 1)
+    s = s + table[:, idx.reshape(-1)].view(1, heads, N, N)
+    if shift:
+        ys, xs = torch.arange(Hp, device=qkv.device), torch.arange(Wp, device=qkv.device)
+        ry = (ys >= Hp - ws).long() + (ys >= Hp - shift).long()
+        rx = (xs >= Wp - ws).long() + (xs >= Wp - shift).long()
+        rid = (ry.view(-1, 1) * 3 + rx.view(1, -1)).view(Hp // ws, ws, Wp // ws, ws).permute(0, 2, 1, 3).reshape(-1, N)
+        m = (rid.unsqueeze(1) != rid.unsqueeze(2)).to(s.dtype) * (-200.0)
+        nW = m.shape[0]
+        s = (s.view(B, nW, heads, N, N) + m.view(1, nW, 1, N, N)).view(-1, heads, N, N)
+    o = (torch.softmax(s, -1) @ v).transpose(1, 2).reshape(-1, ws, ws, C)
+    o = o.view(B, Hp // ws, Wp // ws, ws, ws, C).permute(0, 1, 3, 2, 4, 5).reshape(B, Hp, Wp, C)
+    if shift:
+        o = torch.roll(o, (shift, shift), (1, 2))
+    return o.reshape(B, Hp * Wp, C)
+
+
+ATTN_CASES = [  # B, Hp, Wp, C, heads, ws, shift
+    (2, 32, 32, 96, 3, 16, 8),    # Poseidon-B stage 0 (head_dim 32, N=256, shifted)
+    (2, 32, 32, 48, 3, 16, 0),    # Poseidon-T stage 0 (head_dim 16)
+    (1, 16, 16, 128, 2, 16, 0),   # head_dim 64 (Poseidon-L), N=256
+    (3, 8, 8, 64, 2, 8, 0),       # N=64
+    (2, 8, 8, 32, 2, 4, 2),       # N=16 shifted
+    (2, 4, 4, 128, 2, 4, 0),      # N=16, head_dim 64
+    (1, 14, 14, 32, 1, 7, 3),     # N=49 (not a multiple of 16) shifted
+]
+
+
+@pytest.mark.parametrize("compute", [ops.F32, ops.BF16])
+@pytest.mark.parametrize("case", ATTN_CASES)
+def test_window_attention_fwd_bwd(compute, case):
+    B, Hp, Wp, C, heads, ws, shift = case
+    cdt = torch.float32 if compute == ops.F32 else torch.bfloat16
+    L, TS, N = Hp * Wp, (2 * ws - 1) ** 2, ws * ws
+    qkv = rnd(B, L, 3 * C, dtype=cdt)
+    table = (16 * torch.sigmoid(rnd(heads, TS, seed=1))).contiguous()
+    ls = torch.linspace(math.log(3.0), math.log(20.0), heads, device=DEV)
+    dout = rnd(B, L, C, dtype=cdt, seed=2)
+    out = torch.full((B, L, C), float("nan"), device=DEV, dtype=cdt)
+    nW = (Hp // ws) * (Wp // ws)
+    lse = torch.empty(B * nW, heads, N, device=DEV)
+    ops.window_attn_fwd(compute, qkv, out, lse, table, ls, B, Hp, Wp, C, heads, ws, shift)
+    dqkv = torch.full((B, L, 3 * C), float("nan"), device=DEV, dtype=cdt)
+    dtab = torch.zeros(heads, TS, device=DEV)
+    dls = torch.zeros(heads, device=DEV)
+    ops.window_attn_bwd(compute, qkv, dout, lse, table, ls, dqkv, dtab, dls, B, Hp, Wp, C, heads, ws, shift)
+    torch.cuda.synchronize()
+
+    q64 = qkv.double().requires_grad_(True)
+    t64 = table.double().requires_grad_(True)
+    l64 = ls.double().requires_grad_(True)
+    ref = _attn_ref(q64, t64, l64, B, Hp, Wp, C, heads, ws, shift)
+    ref.backward(dout.double())
+    tol_o, tol_g = (2e-5, 5e-5) if compute == ops.F32 else (2e-2, 4e-2)
+    assert rel(out, ref.detach()) < tol_o, "out"
+    assert rel(dqkv, q64.grad) < tol_g, "dqkv"
+    assert rel(dtab, t64.grad) < tol_g, "dbias_table"
+    # d logit_scale is a heavily cancelling sum over all (q,k) pairs: bf16 operand rounding shows up amplified
+    assert rel(dls, l64.grad) < (tol_g if compute == ops.F32 else 0.15), "dlogit_scale"
+
+
+# ----------------------------------------------------------------------------------------------- CLN
+@pytest.mark.parametrize("cond", [True, False])
+@pytest.mark.parametrize("xdt", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("B,L,C", [(3, 64, 96), (2, 16, 768), (2, 9, 20), (2, 300, 48)])
+def test_cln_fwd_bwd(cond, xdt, B, L, C):
+    x = rnd(B, L, C, dtype=xdt)
+    res = rnd(B, L, C, seed=1)
+    t = torch.rand(B, device=DEV)
+    gw_w, gw_b, bw_w, bw_b = rnd(C, seed=2, scale=0.3), 1 + rnd(C, seed=3, scale=0.1), rnd(C, seed=4, scale=0.1), rnd(C, seed=5, scale=0.1)
+    out = torch.empty(B, L, C, device=DEV)
+    mean, rstd = torch.empty(B * L, device=DEV), torch.empty(B * L, device=DEV)
+    ops.cln_fwd(x, res, out, mean, rstd, t if cond else None, gw_w if cond else None, gw_b, bw_w if cond else None, bw_b,
+                B * L, L, C, 1e-5)
+    dout = rnd(B, L, C, seed=6)
+    dx = torch.empty(B, L, C, device=DEV, dtype=xdt)
+    grads = [torch.zeros(C, device=DEV) for _ in range(4)]
+    ops.cln_bwd(dout, x, mean, rstd, t if cond else None, gw_w if cond else None, gw_b, dx, grads[0], grads[1], grads[2],
+                grads[3], B * L, L, C)
+    torch.cuda.synchronize()
+    x64 = x.double().requires_grad_(True)
+    ps = [p.double().requires_grad_(True) for p in (gw_w, gw_b, bw_w, bw_b)]
+    mu = x64.mean(-1, keepdim=True)
+    var = (x64 * x64).mean(-1, keepdim=True) - mu * mu
+    xh = (x64 - mu) / torch.sqrt(var + 1e-5)
+    if cond:
+        g = t.double().view(B, 1, 1) * ps[0] + ps[1]
+        b = t.double().view(B, 1, 1) * ps[2] + ps[3]
+    else:
+        g, b = ps[1], ps[3]
+    ref = res.double() + g * xh + b
+    ref.backward(dout.double())
+    assert rel(out, ref.detach()) < 1e-5
+    assert rel(dx, x64.grad) < (1e-4 if xdt == torch.float32 else 1e-2)
+    for i in ([0, 1, 2, 3] if cond else [1, 3]):
+        assert rel(grads[i], ps[i].grad) < 1e-4, i
+
+
+# ----------------------------------------------------------------------------------------------- data movement
+def test_copy2d_pad_crop():
+    B, H, W, C = 2, 5, 7, 12
+    x = rnd(B, H, W, C)
+    pad = torch.empty(B, 8, 8, C, device=DEV)
+    ops.copy2d(x, pad, B, H, W, 8, 8, C)
+    ref = torch.nn.functional.pad(x, (0, 0, 0, 1, 0, 3))
+    assert torch.equal(pad, ref)
+    crop = torch.empty(B, 4, 6, C, device=DEV)
+    ops.copy2d(x, crop, B, H, W, 4, 6, C)
+    assert torch.equal(crop, x[:, :4, :6].contiguous())
+
+
+@pytest.mark.parametrize("H,W", [(8, 8), (9, 5)])
+def test_space_depth(H, W):
+    B, C = 2, 6
+    a, b = rnd(B, H, W, C), rnd(B, H, W, C, seed=1)
+    H2, W2 = (H + 1) // 2, (W + 1) // 2
+    co = torch.empty(B, H2, W2, 4 * C, device=DEV)
+    ops.space_to_depth(a, b, co, B, H, W, C, 0)
+    s = torch.nn.functional.pad(a + b, (0, 0, 0, W % 2, 0, H % 2))
+    ref = torch.cat([s[:, 0::2, 0::2], s[:, 1::2, 0::2], s[:, 0::2, 1::2], s[:, 1::2, 1::2]], -1)
+    assert torch.equal(co, ref)
+    # scatter back (gradient of merge): each fine position receives its own slice
+    fine = torch.empty(B, H, W, C, device=DEV)
+    ops.depth_to_space(co, fine, B, H, W, H2, W2, C, 0)
+    assert torch.equal(fine, a + b)
+    # order 1 = pixel shuffle of the unmerge (model.py:748-756) incl. crop
+    z = rnd(B, H2, W2, 4 * C, seed=2)
+    fine2 = torch.empty(B, H, W, C, device=DEV)
+    ops.depth_to_space(z, fine2, B, H, W, H2, W2, C, 1)
+    ref2 = z.view(B, H2, W2, 2, 2, C).permute(0, 1, 3, 2, 4, 5).reshape(B, 2 * H2, 2 * W2, C)[:, :H, :W]
+    assert torch.equal(fine2, ref2.contiguous())
+    back = torch.empty(B, H2, W2, 4 * C, device=DEV)
+    ops.space_to_depth(fine2, None, back, B, H, W, C, 1)
+    mask = torch.zeros(B, 2 * H2, 2 * W2, C, device=DEV)
+    mask[:, :H, :W] = 1
+    mref = (z.view(B, H2, W2, 2, 2, C).permute(0, 1, 3, 2, 4, 5).reshape(B, 2 * H2, 2 * W2, C) * mask)
+    mref = mref.view(B, H2, 2, W2, 2, C).permute(0, 1, 3, 2, 4, 5).reshape(B, H2, W2, 4 * C)
+    assert torch.equal(back, mref)
+
+
+@pytest.mark.parametrize("H,W", [(16, 16), (18, 14)])
+def test_patchify_unpatchify(H, W):
+    B, Cc, p = 2, 3, 4
+    img = rnd(B, Cc, H, W)
+    gh, gw = (H + p - 1) // p, (W + p - 1) // p
+    cols = torch.empty(B * gh * gw, Cc * p * p, device=DEV)
+    ops.patchify(img, cols, B, Cc, H, W, p)
+    padded = torch.nn.functional.pad(img, (0, gw * p - W, 0, gh * p - H))
+    ref = padded.view(B, Cc, gh, p, gw, p).permute(0, 2, 4, 1, 3, 5).reshape(B * gh * gw, Cc * p * p)
+    assert torch.equal(cols, ref)
+    bias = rnd(Cc, seed=1)
+    back = torch.empty(B, Cc, H, W, device=DEV)
+    ops.unpatchify(cols, bias, back, B, Cc, H, W, gh, gw, p)
+    assert torch.allclose(back, img + bias.view(1, -1, 1, 1))
+
+
+def test_reductions_and_scale_residual():
+    B, Cc, HW = 3, 4, 1000
+    x = rnd(B, Cc, HW)
+    out = torch.zeros(Cc, device=DEV)
+    ops.nchw_channel_sum(x, out, B, Cc, HW)
+    assert rel(out, x.double().sum((0, 2))) < 1e-5
+    M, N = 777, 200
+    a, b = rnd(M, N, dtype=torch.bfloat16), rnd(M, N, seed=1)
+    o1 = torch.zeros(N, device=DEV)
+    ops.colsum(a, o1)
+    assert rel(o1, a.double().sum(0)) < 1e-5
+    a32 = a.float()
+    o2 = torch.zeros(N, device=DEV)
+    ops.colsum(a32, o2, y=b)
+    assert rel(o2, (a.double() * b.double()).sum(0)) < 1e-5
+    sc = rnd(N, seed=2)
+    o3 = torch.empty(M, N, device=DEV)
+    ops.scale_residual(a, sc, b, o3, M, N)
+    assert rel(o3, b.double() + sc.double() * a.double()) < 1e-6
+    pe = rnd(N, seed=3)
+    o4 = torch.empty(M, N, device=DEV)
+    ops.add(b, pe, o4, period=N)
+    assert torch.allclose(o4, b + pe)
+    o5 = torch.zeros(HW, device=DEV)
+    ops.batch_sum(x.view(B * Cc, HW), o5, B * Cc, HW)
+    assert rel(o5, x.double().sum((0, 1))) < 1e-5
+
+
+# ----------------------------------------------------------------------------------------------- stencils
+@pytest.mark.parametrize("H,W,C", [(16, 16, 96), (5, 5, 24)])
+def test_dwconv7(H, W, C):
+    B = 2
+    x = rnd(B, H, W, C)
+    w, bias = rnd(C, 1, 7, 7, seed=1, scale=0.2), rnd(C, seed=2)
+    y = torch.empty(B, H, W, C, device=DEV)
+    ops.dwconv7(x, w, bias, y, B, H, W, C)
+    x64 = x.double().requires_grad_(True)
+    w64, b64 = w.double().requires_grad_(True), bias.double().requires_grad_(True)
+    ref = torch.nn.functional.conv2d(x64.permute(0, 3, 1, 2), w64, b64, padding=3, groups=C).permute(0, 2, 3, 1)
+    dy = rnd(B, H, W, C, seed=3)
+    ref.backward(dy.double())
+    assert rel(y, ref.detach()) < 1e-5
+    dx = torch.empty(B, H, W, C, device=DEV)
+    ops.dwconv7(dy, w, None, dx, B, H, W, C, flip=True)
+    assert rel(dx, x64.grad) < 1e-5
+    dw, db = torch.zeros(C, 1, 7, 7, device=DEV), torch.zeros(C, device=DEV)
+    ops.dwconv7_wgrad(dy, x, dw, db, B, H, W, C)
+    assert rel(dw, w64.grad) < 1e-5
+    assert rel(db, b64.grad) < 1e-5
+
+
+@pytest.mark.parametrize("Cc,H,W", [(4, 32, 32), (5, 13, 10)])
+def test_conv5(Cc, H, W):
+    B = 2
+    x, w = rnd(B, Cc, H, W), rnd(Cc, Cc, 5, 5, seed=1, scale=0.2)
+    y = torch.empty(B, Cc, H, W, device=DEV)
+    ops.conv5(x, w, y, B, Cc, H, W)
+    x64, w64 = x.double().requires_grad_(True), w.double().requires_grad_(True)
+    ref = torch.nn.functional.conv2d(x64, w64, None, padding=2)
+    dy = rnd(B, Cc, H, W, seed=2)
+    ref.backward(dy.double())
+    assert rel(y, ref.detach()) < 1e-5
+    dx = torch.empty(B, Cc, H, W, device=DEV)
+    ops.conv5(dy, w, dx, B, Cc, H, W, transpose=True)
+    assert rel(dx, x64.grad) < 1e-5
+    dw = torch.zeros(Cc, Cc, 5, 5, device=DEV)
+    ops.conv5_wgrad(dy, x, dw, B, Cc, H, W)
+    assert rel(dw, w64.grad) < 1e-5
+
+
+# ----------------------------------------------------------------------------------------------- loss
+@pytest.mark.parametrize("p,groups,resid,mask", [(1, [0, 1, 3, 4], False, False), (2, None, False, False),
+                                                  (1, [0, 1, 3, 4], True, True), (2, [0, 2, 4], False, True)])
+def test_head_finalize_loss(p, groups, resid, mask):
+    B, Cc, H, W = 3, 4, 16, 16
+    pred0, lab, pv = rnd(B, Cc, H, W), rnd(B, Cc, H, W, seed=1), rnd(B, 5, H, W, seed=2)
+    pm = torch.zeros(B, Cc, dtype=torch.bool, device=DEV)
+    pm[:, -1] = True
+    G = len(groups) - 1 if groups else 1
+    goc = torch.full((Cc,), -1, dtype=torch.int32)
+    cnt = torch.zeros(G)
+    if groups:
+        for g in range(G):
+            goc[groups[g]:groups[g + 1]] = g
+            cnt[g] = B * (groups[g + 1] - groups[g]) * H * W
+    else:
+        goc[:] = 0
+        cnt[0] = B * Cc * H * W
+    goc, cnt = goc.to(DEV), cnt.to(DEV)
+    pred = pred0.clone()
+    sums = torch.zeros(2 * G, device=DEV)
+    loss = torch.zeros(1, device=DEV)
+    ops.head_finalize(pred, pv if resid else None, 5, lab, pm.to(torch.uint8) if mask else None, False, goc, sums, B, Cc, H * W, p)
+    ops.loss_finish(sums, cnt, G, groups is not None, loss)
+    dpred = torch.empty_like(pred)
+    ops.loss_bwd(pred, lab, pm.to(torch.uint8) if mask else None, False, goc, sums, cnt, G, groups is not None, None, dpred,
+                 B, Cc, H * W, p)
+    torch.cuda.synchronize()
+    p64 = pred0.double().requires_grad_(True)
+    q = p64 + (pv[:, :Cc].double() if resid else 0)
+    if mask:
+        q = torch.where(pm.view(B, Cc, 1, 1).expand_as(q), lab.double(), q)
+    fn = (lambda a, b: (a - b).abs().mean()) if p == 1 else (lambda a, b: ((a - b) ** 2).mean())
+    if groups:
+        ref = torch.stack([fn(q[:, groups[i]:groups[i + 1]], lab[:, groups[i]:groups[i + 1]].double()) /
+                           (fn(lab[:, groups[i]:groups[i + 1]].double(), 0 * lab[:, groups[i]:groups[i + 1]].double()) + 1e-10)
+                           for i in range(G)]).mean()
+    else:
+        ref = fn(q, lab.double())
+    ref.backward()
+    assert rel(pred, q.detach()) < 1e-6
+    assert abs(float(loss) - float(ref.detach())) < 1e-5 * abs(float(ref.detach()))
+    assert rel(dpred, p64.grad) < 1e-5
+
+
+# ----------------------------------------------------------------------------------------------- CPB MLP
+@pytest.mark.parametrize("ws,heads", [(16, 3), (8, 12), (4, 24), (7, 2)])
+def test_cpb(ws, heads):
+    TS = (2 * ws - 1) ** 2
+    r = torch.arange(-(ws - 1), ws, dtype=torch.float32)
+    tab = torch.stack(torch.meshgrid(r, r, indexing="ij"), -1) / max(ws - 1, 1) * 8
+    coords = (torch.sign(tab) * torch.log2(tab.abs() + 1) / 3).reshape(-1, 2).to(DEV)
+    w0, b0, w2 = rnd(512, 2), rnd(512, seed=1, scale=0.5), rnd(heads, 512, seed=2, scale=0.05)
+    table, z = torch.empty(heads, TS, device=DEV), torch.empty(TS, heads, device=DEV)
+    ops.cpb_fwd(coords, w0, b0, w2, table, z, ws, heads)
+    ps = [t.double().requires_grad_(True) for t in (w0, b0, w2)]
+    ref = 16 * torch.sigmoid(torch.relu(coords.double() @ ps[0].t() + ps[1]) @ ps[2].t()).t()
+    dt_ = rnd(heads, TS, seed=3)
+    ref.backward(dt_.double())
+    assert rel(table, ref.detach()) < 1e-5
+    g = [torch.zeros_like(t) for t in (w0, b0, w2)]
+    ops.cpb_bwd(coords, w0, b0, w2, z, dt_, g[0], g[1], g[2], ws, heads)
+    torch.cuda.synchronize()
+    for a, b in zip(g, ps):
+        assert rel(a, b.grad) < 1e-4
