@@ -1,0 +1,518 @@
+"""ScOTEngine — the forward / backward program of the scOT hot path on MI355X.
+
+Host-side orchestration only: every arithmetic operation below is one of the hand-written HIP kernels of
+libscot_hip.so (poseidon_amd/ops.py → include/scot_hip.h); torch supplies device memory and the stream.
+There is no CPU or eager-PyTorch fallback — a missing library raises.
+
+The op sequence follows the reference graph (reference scOT/model.py:1318-1509) with the
+data-flow choices described in DESIGN.md:
+  * residual stream, LN statistics, softmax, q/k normalisation, gradient accumulation: fp32 in every mode;
+  * compute="bf16": GEMM / attention operands are bf16 (activations between GEMMs are stored bf16),
+    compute="fp32": everything fp32 with the exact fp32 MFMA (parity mode, ≤1e-5);
+  * roll / window partition / reverse / mask are index math inside the attention kernel;
+  * GELU is applied while loading the fc2 operand (the 4C activation is stored once, pre-activation);
+  * gradients are accumulated in place into the flat gradient arena (autograd `+=` semantics).
+"""
+from __future__ import annotations
+
+import math
+from typing import Dict, List, Optional
+
+import torch
+
+from . import ops
+from .arena import Arena
+from .geometry import BlockGeom, StageGeom, stage_plan
+
+
+def cpb_coords_table(ws: int) -> torch.Tensor:
+    """relative_coords_table of HF:457-476 → [(2ws-1)^2, 2] (dy, dx), fp32 exactly as torch computes it."""
+    r = torch.arange(-(ws - 1), ws, dtype=torch.int64).float()
+    tab = torch.stack(torch.meshgrid([r, r], indexing="ij")).permute(1, 2, 0).contiguous()
+    if ws > 1:
+        tab = tab / (ws - 1)
+    tab = tab * 8
+    tab = torch.sign(tab) * torch.log2(torch.abs(tab) + 1.0) / math.log2(8)
+    return tab.reshape(-1, 2).contiguous()
+
+
+class ScOTEngine:
+    def __init__(self, cfg, arena: Arena, compute: str = "bf16"):
+        if compute not in ("bf16", "fp32"):
+            raise ValueError("compute must be 'bf16' or 'fp32'")
+        self.cfg = cfg
+        self.arena = arena
+        self.compute = ops.BF16 if compute == "bf16" else ops.F32
+        self.adt = torch.bfloat16 if compute == "bf16" else torch.float32
+        self.device = arena.data.device
+        self.grid, self.enc, self.dec = stage_plan(cfg)
+        self.cond = bool(cfg.use_conditioning)
+        self._coords: Dict[int, torch.Tensor] = {}
+        self._loss_meta = None
+
+    # ------------------------------------------------------------------------------------------ helpers
+    def P(self, name):
+        return self.arena.view(name)
+
+    def G(self, name):
+        return self.arena.gview(name)
+
+    def new(self, *shape, dtype=torch.float32):
+        return torch.empty(*shape, dtype=dtype, device=self.device)
+
+    def zeros(self, *shape, dtype=torch.float32):
+        return torch.zeros(*shape, dtype=dtype, device=self.device)
+
+    def coords(self, ws: int) -> torch.Tensor:
+        t = self._coords.get(ws)
+        if t is None:
+            t = cpb_coords_table(ws).to(self.device)
+            self._coords[ws] = t
+        return t
+
+    def _norm_params(self, prefix):
+        if self.cond:
+            return (self.P(prefix + ".weight.weight"), self.P(prefix + ".weight.bias"), self.P(prefix + ".bias.weight"),
+                    self.P(prefix + ".bias.bias"))
+        return (None, self.P(prefix + ".weight"), None, self.P(prefix + ".bias"))
+
+    def _norm_grads(self, prefix):
+        if self.cond:
+            return (self.G(prefix + ".weight.weight"), self.G(prefix + ".weight.bias"), self.G(prefix + ".bias.weight"),
+                    self.G(prefix + ".bias.bias"))
+        return (None, self.G(prefix + ".weight"), None, self.G(prefix + ".bias"))
+
+    def norm_fwd(self, prefix, x, resid, rows_per_sample, C, eps, time, out_dtype=torch.float32, need_stats=True):
+        rows = x.numel() // C
+        out = self.new(rows, C, dtype=out_dtype)
+        mean = self.new(rows) if need_stats else None
+        rstd = self.new(rows) if need_stats else None
+        gw_w, gw_b, bw_w, bw_b = self._norm_params(prefix)
+        ops.cln_fwd(x, resid, out, mean, rstd, time if self.cond else None, gw_w, gw_b, bw_w, bw_b, rows, rows_per_sample, C, eps)
+        return out, (mean, rstd)
+
+    def norm_bwd(self, prefix, dout, x, stats, rows_per_sample, C, time, dx_dtype):
+        rows = x.numel() // C
+        dx = self.new(rows, C, dtype=dx_dtype)
+        gw_w, gw_b, _, _ = self._norm_params(prefix)
+        g = self._norm_grads(prefix)
+        ops.cln_bwd(dout, x, stats[0], stats[1], time if self.cond else None, gw_w, gw_b, dx, g[0], g[1], g[2], g[3], rows,
+                    rows_per_sample, C)
+        return dx
+
+    def linear_bwd_params(self, wname, bname, dy, x, b_gelu=False):
+        ops.linear_wgrad(self.compute, dy, x, self.G(wname), b_gelu=b_gelu)
+        if bname is not None:
+            ops.colsum(dy, self.G(bname))
+
+    # ------------------------------------------------------------------------------------------ ScOTLayer
+    def layer_fwd(self, blk: BlockGeom, x, B, time, train):
+        """reference ScOTLayer.forward (model.py:500-581) + Swinv2Attention/Intermediate/Output (HF:389-561)."""
+        cfg, cm = self.cfg, self.compute
+        H, W = blk.res
+        C, heads = blk.dim, blk.heads
+        ws, shift = blk.window_shift()
+        Hp, Wp = (H + ws - 1) // ws * ws, (W + ws - 1) // ws * ws
+        padded = (Hp, Wp) != (H, W)
+        L, Lp = H * W, Hp * Wp
+        pre = blk.prefix
+        a = pre + ".attention.self."
+        if padded:
+            xp = self.new(B * Lp, C)
+            ops.copy2d(x, xp, B, H, W, Hp, Wp, C)
+        else:
+            xp = x
+        wqkv = self.arena.span(a + "qkv_weight", 3 * C * C).view(3 * C, C)
+        bqkv = self.arena.span(a + "qkv_bias", 3 * C) if cfg.qkv_bias else None
+        qkv = self.new(B * Lp, 3 * C, dtype=self.adt)
+        ops.linear_fwd(cm, xp, wqkv, qkv, bias=bqkv)
+        tw = blk.table_window
+        if tw != ws:
+            raise NotImplementedError("run-time window differs from the constructor-time CPB table window "
+                                      f"({ws} vs {tw}); the reference would fail to broadcast here too")
+        TS = (2 * ws - 1) ** 2
+        table, z = self.new(heads, TS), self.new(TS, heads)
+        ops.cpb_fwd(self.coords(ws), self.P(a + "continuous_position_bias_mlp.0.weight"),
+                    self.P(a + "continuous_position_bias_mlp.0.bias"), self.P(a + "continuous_position_bias_mlp.2.weight"),
+                    table, z, ws, heads)
+        attn = self.new(B * Lp, C, dtype=self.adt)
+        nW = (Hp // ws) * (Wp // ws)
+        lse = self.new(B * nW, heads, ws * ws)
+        ops.window_attn_fwd(cm, qkv, attn, lse, table, self.P(a + "logit_scale"), B, Hp, Wp, C, heads, ws, shift)
+        if padded:
+            attn_c = self.new(B * L, C, dtype=self.adt)
+            ops.copy2d(attn, attn_c, B, Hp, Wp, H, W, C)
+        else:
+            attn_c = attn
+        proj = self.new(B * L, C)
+        ops.linear_fwd(cm, attn_c, self.P(pre + ".attention.output.dense.weight"), proj,
+                       bias=self.P(pre + ".attention.output.dense.bias"))
+        h, st1 = self.norm_fwd(pre + ".layernorm_before", proj, x, L, C, cfg.layer_norm_eps, time, need_stats=train)
+        hid = int(cfg.mlp_ratio * C)
+        u = self.new(B * L, hid, dtype=self.adt)
+        ops.linear_fwd(cm, h, self.P(pre + ".intermediate.dense.weight"), u, bias=self.P(pre + ".intermediate.dense.bias"))
+        y2 = self.new(B * L, C)
+        ops.linear_fwd(cm, u, self.P(pre + ".output.dense.weight"), y2, bias=self.P(pre + ".output.dense.bias"), a_gelu=True)
+        out, st2 = self.norm_fwd(pre + ".layernorm_after", y2, h, L, C, cfg.layer_norm_eps, time, need_stats=train)
+        rec = None
+        if train:
+            rec = dict(blk=blk, xp=xp, qkv=qkv, table=table, z=z, lse=lse, attn_c=attn_c, proj=proj, st1=st1, h=h, u=u, y2=y2,
+                       st2=st2, geom=(H, W, Hp, Wp, ws, shift, padded))
+        return out, rec
+
+    def layer_bwd(self, rec, g, B, time):
+        """g: fp32 [B*L, C] gradient wrt the layer output; returns the gradient wrt the layer input (same buffer)."""
+        cfg, cm, adt = self.cfg, self.compute, self.adt
+        blk: BlockGeom = rec["blk"]
+        H, W, Hp, Wp, ws, shift, padded = rec["geom"]
+        C, heads, pre = blk.dim, blk.heads, blk.prefix
+        a = pre + ".attention.self."
+        L, Lp = H * W, Hp * Wp
+        hid = int(cfg.mlp_ratio * C)
+        # out = h + CLN_after(y2)
+        d_y2 = self.norm_bwd(pre + ".layernorm_after", g, rec["y2"], rec["st2"], L, C, time, adt)
+        # y2 = gelu(u) W2^T + b2
+        self.linear_bwd_params(pre + ".output.dense.weight", pre + ".output.dense.bias", d_y2, rec["u"], b_gelu=True)
+        d_u = self.new(B * L, hid, dtype=adt)
+        ops.linear_dgrad(cm, d_y2, self.P(pre + ".output.dense.weight"), d_u, aux=rec["u"])
+        # u = h W1^T + b1
+        self.linear_bwd_params(pre + ".intermediate.dense.weight", pre + ".intermediate.dense.bias", d_u, rec["h"])
+        ops.linear_dgrad(cm, d_u, self.P(pre + ".intermediate.dense.weight"), g, accumulate=True)
+        # h = x + CLN_before(proj)
+        d_proj = self.norm_bwd(pre + ".layernorm_before", g, rec["proj"], rec["st1"], L, C, time, adt)
+        self.linear_bwd_params(pre + ".attention.output.dense.weight", pre + ".attention.output.dense.bias", d_proj, rec["attn_c"])
+        d_attn = self.new(B * L, C, dtype=adt)
+        ops.linear_dgrad(cm, d_proj, self.P(pre + ".attention.output.dense.weight"), d_attn)
+        if padded:
+            d_attn_p = self.new(B * Lp, C, dtype=adt)
+            ops.copy2d(d_attn, d_attn_p, B, H, W, Hp, Wp, C)
+        else:
+            d_attn_p = d_attn
+        d_qkv = self.new(B * Lp, 3 * C, dtype=adt)
+        TS = (2 * ws - 1) ** 2
+        d_table = self.zeros(heads, TS)
+        ops.window_attn_bwd(cm, rec["qkv"], d_attn_p, rec["lse"], rec["table"], self.P(a + "logit_scale"), d_qkv, d_table,
+                            self.G(a + "logit_scale"), B, Hp, Wp, C, heads, ws, shift)
+        ops.cpb_bwd(self.coords(ws), self.P(a + "continuous_position_bias_mlp.0.weight"),
+                    self.P(a + "continuous_position_bias_mlp.0.bias"), self.P(a + "continuous_position_bias_mlp.2.weight"),
+                    rec["z"], d_table, self.G(a + "continuous_position_bias_mlp.0.weight"),
+                    self.G(a + "continuous_position_bias_mlp.0.bias"), self.G(a + "continuous_position_bias_mlp.2.weight"), ws, heads)
+        wqkv = self.arena.span(a + "qkv_weight", 3 * C * C).view(3 * C, C)
+        gwqkv = self.arena.span(a + "qkv_weight", 3 * C * C, grad=True).view(3 * C, C)
+        ops.linear_wgrad(cm, d_qkv, rec["xp"], gwqkv)
+        if cfg.qkv_bias:
+            ops.colsum(d_qkv, self.arena.span(a + "qkv_bias", 3 * C, grad=True))
+        if padded:
+            tmp = self.new(B * Lp, C)
+            ops.linear_dgrad(cm, d_qkv, wqkv, tmp)
+            tmpc = self.new(B * L, C)
+            ops.copy2d(tmp, tmpc, B, Hp, Wp, H, W, C)
+            ops.add(g, tmpc, g)
+        else:
+            ops.linear_dgrad(cm, d_qkv, wqkv, g, accumulate=True)
+        return g
+
+    # ------------------------------------------------------------------------------------------ resampling
+    def merge_fwd(self, st: StageGeom, x, stage_in, B, time, train):
+        """reference ScOTPatchMerging (model.py:680-712) on (stage_out + stage_in) (model.py:847-849)."""
+        H, W = st.res
+        C = st.dim
+        H2, W2 = (H + 1) // 2, (W + 1) // 2
+        cat = self.new(B * H2 * W2, 4 * C, dtype=self.adt)
+        ops.space_to_depth(x, stage_in, cat, B, H, W, C, 0)
+        r = self.new(B * H2 * W2, 2 * C)
+        ops.linear_fwd(self.compute, cat, self.P(st.prefix + ".downsample.reduction.weight"), r)
+        out, stats = self.norm_fwd(st.prefix + ".downsample.norm", r, None, H2 * W2, 2 * C, 1e-5, time, need_stats=train)
+        return out, (dict(cat=cat, r=r, stats=stats) if train else None)
+
+    def merge_bwd(self, st: StageGeom, rec, g, B, time):
+        H, W = st.res
+        C = st.dim
+        H2, W2 = (H + 1) // 2, (W + 1) // 2
+        d_r = self.norm_bwd(st.prefix + ".downsample.norm", g, rec["r"], rec["stats"], H2 * W2, 2 * C, time, self.adt)
+        ops.linear_wgrad(self.compute, d_r, rec["cat"], self.G(st.prefix + ".downsample.reduction.weight"))
+        d_cat = self.new(B * H2 * W2, 4 * C)
+        ops.linear_dgrad(self.compute, d_r, self.P(st.prefix + ".downsample.reduction.weight"), d_cat)
+        d_sum = self.new(B * H * W, C)
+        ops.depth_to_space(d_cat, d_sum, B, H, W, H2, W2, C, 0)
+        return d_sum
+
+    def unmerge_fwd(self, st: StageGeom, x, B, time, train):
+        """reference ScOTPatchUnmerging (model.py:737-760)."""
+        h, w = st.res
+        oh, ow = st.out_res
+        C = st.dim
+        up = self.new(B * h * w, 2 * C, dtype=self.adt)
+        ops.linear_fwd(self.compute, x, self.P(st.prefix + ".upsample.upsample.weight"), up)
+        sh = self.new(B * oh * ow, C // 2, dtype=self.adt)
+        ops.depth_to_space(up, sh, B, oh, ow, h, w, C // 2, 1)
+        n, stats = self.norm_fwd(st.prefix + ".upsample.norm", sh, None, oh * ow, C // 2, 1e-5, time, out_dtype=self.adt,
+                                 need_stats=train)
+        out = self.new(B * oh * ow, C // 2)
+        ops.linear_fwd(self.compute, n, self.P(st.prefix + ".upsample.mixup.weight"), out)
+        return out, (dict(x=x, sh=sh, stats=stats, n=n) if train else None)
+
+    def unmerge_bwd(self, st: StageGeom, rec, g, B, time):
+        h, w = st.res
+        oh, ow = st.out_res
+        C = st.dim
+        ops.linear_wgrad(self.compute, g, rec["n"], self.G(st.prefix + ".upsample.mixup.weight"))
+        d_n = self.new(B * oh * ow, C // 2, dtype=self.adt)
+        ops.linear_dgrad(self.compute, g, self.P(st.prefix + ".upsample.mixup.weight"), d_n)
+        d_sh = self.norm_bwd(st.prefix + ".upsample.norm", d_n, rec["sh"], rec["stats"], oh * ow, C // 2, time, self.adt)
+        d_up = self.new(B * h * w, 2 * C, dtype=self.adt)
+        ops.space_to_depth(d_sh, None, d_up, B, oh, ow, C // 2, 1)
+        ops.linear_wgrad(self.compute, d_up, rec["x"], self.G(st.prefix + ".upsample.upsample.weight"))
+        gx = self.new(B * h * w, C)
+        ops.linear_dgrad(self.compute, d_up, self.P(st.prefix + ".upsample.upsample.weight"), gx)
+        return gx
+
+    # ------------------------------------------------------------------------------------------ ConvNeXt skip block
+    def convnext_fwd(self, pre, s, B, H, W, C, time, train):
+        """reference ConvNeXtBlock.forward (model.py:198-217)."""
+        L = H * W
+        dw = self.new(B * L, C)
+        ops.dwconv7(s, self.P(pre + ".dwconv.weight"), self.P(pre + ".dwconv.bias"), dw, B, H, W, C)
+        n, stats = self.norm_fwd(pre + ".norm", dw, None, L, C, self.cfg.layer_norm_eps, time, out_dtype=self.adt, need_stats=train)
+        u = self.new(B * L, 4 * C, dtype=self.adt)
+        ops.linear_fwd(self.compute, n, self.P(pre + ".pwconv1.weight"), u, bias=self.P(pre + ".pwconv1.bias"))
+        y2 = self.new(B * L, C)
+        ops.linear_fwd(self.compute, u, self.P(pre + ".pwconv2.weight"), y2, bias=self.P(pre + ".pwconv2.bias"), a_gelu=True)
+        out = self.new(B * L, C)
+        ops.scale_residual(y2, self.P(pre + ".weight"), s, out, B * L, C)
+        return out, (dict(s=s, dw=dw, stats=stats, n=n, u=u, y2=y2) if train else None)
+
+    def convnext_bwd(self, pre, rec, g, B, H, W, C, time):
+        L = H * W
+        ops.colsum(g, self.G(pre + ".weight"), y=rec["y2"])
+        d_y2 = self.new(B * L, C, dtype=self.adt)
+        ops.scale_residual(g, self.P(pre + ".weight"), None, d_y2, B * L, C)
+        self.linear_bwd_params(pre + ".pwconv2.weight", pre + ".pwconv2.bias", d_y2, rec["u"], b_gelu=True)
+        d_u = self.new(B * L, 4 * C, dtype=self.adt)
+        ops.linear_dgrad(self.compute, d_y2, self.P(pre + ".pwconv2.weight"), d_u, aux=rec["u"])
+        self.linear_bwd_params(pre + ".pwconv1.weight", pre + ".pwconv1.bias", d_u, rec["n"])
+        d_n = self.new(B * L, C, dtype=self.adt)
+        ops.linear_dgrad(self.compute, d_u, self.P(pre + ".pwconv1.weight"), d_n)
+        d_dw = self.norm_bwd(pre + ".norm", d_n, rec["dw"], rec["stats"], L, C, time, torch.float32)
+        ops.dwconv7_wgrad(d_dw, rec["s"], self.G(pre + ".dwconv.weight"), self.G(pre + ".dwconv.bias"), B, H, W, C)
+        d_s = self.new(B * L, C)
+        ops.dwconv7(d_dw, self.P(pre + ".dwconv.weight"), None, d_s, B, H, W, C, flip=True)
+        ops.add(g, d_s, g)
+        return g
+
+    # ------------------------------------------------------------------------------------------ whole model
+    def forward(self, pixel_values, time=None, labels=None, pixel_mask=None, train=True):
+        """→ (loss [1] or None, prediction [B,Cout,H,W], tape or None).  Inputs: fp32 contiguous CUDA tensors."""
+        cfg, cm = self.cfg, self.compute
+        B, Cin, H, W = pixel_values.shape
+        if Cin != cfg.num_channels:
+            raise ValueError("Make sure that the channel dimension of the pixel values match with the one set in the configuration.")
+        if self.cond and time is None:
+            raise ValueError("use_conditioning=True needs `time`")
+        if train and cfg.drop_path_rate > 0.0:
+            raise NotImplementedError("stochastic depth (drop_path_rate > 0) in training is not implemented yet; the "
+                                      "reference training recipe uses 0.0 (train.py:262)")
+        p = cfg.patch_size
+        gh, gw = self.grid
+        C0 = cfg.embed_dim
+        L0 = gh * gw
+        tape = dict(B=B, time=time, enc=[], dec=[], res=[]) if train else None
+
+        # embeddings (model.py:295-366)
+        cols = self.new(B * L0, Cin * p * p, dtype=self.adt)
+        ops.patchify(pixel_values, cols, B, Cin, H, W, p)
+        e = self.new(B * L0, C0)
+        wemb = self.P("embeddings.patch_embeddings.projection.weight").view(C0, Cin * p * p)
+        ops.linear_fwd(cm, cols, wemb, e, bias=self.P("embeddings.patch_embeddings.projection.bias"))
+        x, est = self.norm_fwd("embeddings.norm", e, None, L0, C0, 1e-5, time, need_stats=train)
+        if cfg.use_absolute_embeddings:
+            ops.add(x, self.P("embeddings.position_embeddings").view(-1), x, period=L0 * C0)
+        if train:
+            tape["emb"] = dict(cols=cols, e=e, stats=est)
+        hidden_enc = [x]
+
+        # encoder (model.py:816-861)
+        skips: List[torch.Tensor] = []
+        for st in self.enc:
+            stage_in = x
+            recs = []
+            for blk in st.blocks:
+                x, r = self.layer_fwd(blk, x, B, time, train)
+                recs.append(r)
+            skips.append(x)
+            hidden_enc.append(x)
+            mrec = None
+            if st.resample:
+                x, mrec = self.merge_fwd(st, x, stage_in, B, time, train)
+            if train:
+                tape["enc"].append((recs, mrec))
+
+        # ConvNeXt blocks on the skips (model.py:1388-1393)
+        for i, st in enumerate(self.enc):
+            nblk = int(cfg.skip_connections[i]) if i < len(cfg.skip_connections) else 0
+            rr = []
+            for j in range(nblk):
+                skips[i], r = self.convnext_fwd(f"residual_blocks.{i}.{j}", skips[i], B, st.res[0], st.res[1], st.dim, time, train)
+                rr.append(r)
+            if train:
+                tape["res"].append(rr)
+
+        # decoder (model.py:916-961, 1145-1240)
+        x = skips[-1]
+        hidden_dec = [x]
+        sk = skips[:-1]
+        for k, st in enumerate(self.dec):
+            if k != 0:
+                y = self.new(x.shape[0], x.shape[1])
+                ops.add(x, sk[len(sk) - k], y)
+                x = y
+            recs = []
+            for blk in st.blocks:
+                x, r = self.layer_fwd(blk, x, B, time, train)
+                recs.append(r)
+            hidden_dec.append(x)
+            urec = None
+            if st.resample:
+                x, urec = self.unmerge_fwd(st, x, B, time, train)
+            if train:
+                tape["dec"].append((recs, urec))
+
+        # recovery head (model.py:639-647)
+        Cout = cfg.num_out_channels
+        rc = self.new(B * L0, Cout * p * p)
+        wrec = self.P("patch_recovery.projection.weight").view(C0, Cout * p * p)
+        ops.gemm(ops.NN, cm, B * L0, Cout * p * p, C0, x, C0, wrec, Cout * p * p, rc, Cout * p * p)
+        img = self.new(B, Cout, H, W)
+        ops.unpatchify(rc, self.P("patch_recovery.projection.bias"), img, B, Cout, H, W, gh, gw, p)
+        pred = self.new(B, Cout, H, W)
+        ops.conv5(img, self.P("patch_recovery.mixup.weight"), pred, B, Cout, H, W)
+
+        # learn_residual, pixel_mask overwrite, loss (model.py:1411-1484)
+        loss = None
+        meta = self._loss_setup(Cout, B, H * W) if labels is not None else None
+        pv_res = pixel_values if (cfg.learn_residual and self.cond) else None
+        mask_u8, mask_full = None, False
+        if pixel_mask is not None:
+            if labels is None:
+                raise ValueError("pixel_mask needs labels")
+            mask_full = pixel_mask.dim() != 2
+            mask_u8 = (pixel_mask.expand(B, Cout, H, W) if mask_full else pixel_mask).to(torch.uint8).contiguous()
+        sums = None
+        if labels is not None or pv_res is not None:
+            sums = self.zeros(2 * meta["G"]) if meta else None
+            ops.head_finalize(pred, pv_res, Cin, labels, mask_u8, mask_full, meta["goc"] if meta else None, sums, B, Cout, H * W,
+                              cfg.p)
+        if labels is not None:
+            loss = self.new(1)
+            ops.loss_finish(sums, meta["counts"], meta["G"], meta["normalized"], loss)
+        if train:
+            tape["head"] = dict(x=x, img=img, pred=pred, labels=labels, mask=mask_u8, mask_full=mask_full, sums=sums, meta=meta,
+                                shape=(B, Cout, H, W))
+            tape["hidden"] = (hidden_dec, hidden_enc)
+        self.last_hidden = (hidden_dec, hidden_enc)
+        return loss, pred, tape
+
+    def _loss_setup(self, Cout, B, HW):
+        cfg = self.cfg
+        if cfg.p not in (1, 2):
+            raise ValueError("p must be 1 or 2")
+        groups = cfg.channel_slice_list_normalized_loss
+        key = (Cout, B, HW, tuple(groups) if groups else None)
+        if self._loss_meta and self._loss_meta[0] == key:
+            return self._loss_meta[1]
+        goc = torch.full((Cout,), -1, dtype=torch.int32)
+        if groups:
+            G = len(groups) - 1
+            counts = torch.zeros(G)
+            for g in range(G):
+                goc[groups[g]:groups[g + 1]] = g
+                counts[g] = B * (groups[g + 1] - groups[g]) * HW
+        else:
+            G = 1
+            goc[:] = 0
+            counts = torch.tensor([float(B * Cout * HW)])
+        meta = dict(G=G, goc=goc.to(self.device), counts=counts.to(self.device), normalized=bool(groups))
+        self._loss_meta = (key, meta)
+        return meta
+
+    def backward(self, tape, dloss=None, dpred=None):
+        """Accumulates every parameter gradient into the gradient arena (+=).  dloss: [1] cuda tensor or None (=1)."""
+        cfg, cm, adt = self.cfg, self.compute, self.adt
+        B, time = tape["B"], tape["time"]
+        hd = tape["head"]
+        _, Cout, H, W = hd["shape"]
+        p = cfg.patch_size
+        gh, gw = self.grid
+        C0, L0 = cfg.embed_dim, gh * gw
+        # loss → d pred
+        if hd["labels"] is not None:
+            g_pred = self.new(B, Cout, H, W)
+            meta = hd["meta"]
+            ops.loss_bwd(hd["pred"], hd["labels"], hd["mask"], hd["mask_full"], meta["goc"], hd["sums"], meta["counts"], meta["G"],
+                         meta["normalized"], dloss, g_pred, B, Cout, H * W, cfg.p)
+            if dpred is not None:
+                ops.add(g_pred, dpred.contiguous(), g_pred)
+        elif dpred is not None:
+            g_pred = dpred.contiguous().clone()
+        else:
+            raise RuntimeError("nothing to differentiate: no labels and no gradient for the prediction")
+        # recovery head
+        ops.conv5_wgrad(g_pred, hd["img"], self.G("patch_recovery.mixup.weight"), B, Cout, H, W)
+        d_img = self.new(B, Cout, H, W)
+        ops.conv5(g_pred, self.P("patch_recovery.mixup.weight"), d_img, B, Cout, H, W, transpose=True)
+        ops.nchw_channel_sum(d_img, self.G("patch_recovery.projection.bias"), B, Cout, H * W)
+        d_rc = self.new(B * L0, Cout * p * p, dtype=adt)
+        ops.patchify(d_img, d_rc, B, Cout, H, W, p)
+        wrec = self.P("patch_recovery.projection.weight").view(C0, Cout * p * p)
+        ops.gemm(ops.TN, cm, C0, Cout * p * p, B * L0, hd["x"], C0, d_rc, Cout * p * p,
+                 self.G("patch_recovery.projection.weight").view(C0, Cout * p * p), Cout * p * p, accumulate=True)
+        g = self.new(B * L0, C0)
+        ops.gemm(ops.NT, cm, B * L0, C0, Cout * p * p, d_rc, Cout * p * p, wrec, Cout * p * p, g, C0)
+
+        # decoder, shallow → deep
+        nl = len(self.dec)
+        g_skips: List[Optional[torch.Tensor]] = [None] * nl  # gradient wrt the (ConvNeXt-processed) skips
+        for k in reversed(range(nl)):
+            st = self.dec[k]
+            recs, urec = tape["dec"][k]
+            if st.resample:
+                g = self.unmerge_bwd(st, urec, g, B, time)
+            for blk_rec in reversed(recs):
+                g = self.layer_bwd(blk_rec, g, B, time)
+            if k != 0:
+                g_skips[nl - 1 - k] = g   # x = x_prev + skip: both get g (g keeps flowing to x_prev unchanged)
+                g = g.clone()
+        g_skips[nl - 1] = g  # decoder input = skips[-1]
+
+        # ConvNeXt blocks
+        for i in reversed(range(nl)):
+            st = self.enc[i]
+            for j in reversed(range(len(tape["res"][i]))):
+                g_skips[i] = self.convnext_bwd(f"residual_blocks.{i}.{j}", tape["res"][i][j], g_skips[i], B, st.res[0], st.res[1],
+                                               st.dim, time)
+
+        # encoder, deep → shallow
+        g = None
+        for s in reversed(range(nl)):
+            st = self.enc[s]
+            recs, mrec = tape["enc"][s]
+            if st.resample:
+                d_sum = self.merge_bwd(st, mrec, g, B, time)
+                g = g_skips[s]
+                ops.add(g, d_sum, g)
+            else:
+                g = g_skips[s]
+                d_sum = None
+            for blk_rec in reversed(recs):
+                g = self.layer_bwd(blk_rec, g, B, time)
+            if d_sum is not None:
+                ops.add(g, d_sum, g)
+
+        # embeddings
+        emb = tape["emb"]
+        Cin = cfg.num_channels
+        if cfg.use_absolute_embeddings:
+            ops.batch_sum(g, self.G("embeddings.position_embeddings").view(-1), B, L0 * C0)
+        d_e = self.norm_bwd("embeddings.norm", g, emb["e"], emb["stats"], L0, C0, time, adt)
+        ops.linear_wgrad(cm, d_e, emb["cols"], self.G("embeddings.patch_embeddings.projection.weight").view(C0, Cin * p * p))
+        ops.colsum(d_e, self.G("embeddings.patch_embeddings.projection.bias"))

@@ -1,0 +1,453 @@
+"""scOT.model — the reference's model API on the MI355X-native engine.
+
+Public surface mirrored from the reference (reference scOT/model.py):
+  ScOTConfig, ScOTOutput, LayerNorm, ConditionalLayerNorm, ScOT(config, use_mask_token=False),
+  ScOT.forward(pixel_values, time, bool_masked_pos, head_mask, pixel_mask, labels, output_attentions,
+               output_hidden_states, return_dict) -> ScOTOutput | tuple,
+  ScOT.from_pretrained / save_pretrained (HF checkpoint directory: config.json + model.safetensors | pytorch_model.bin),
+  state_dict keys / shapes identical to the reference.
+
+The module tree below only OWNS parameters (as views into a flat arena, poseidon_amd/arena.py) under the reference's
+names; it contains no arithmetic.  `forward` hands pointers to poseidon_amd.engine.ScOTEngine, whose every op is a
+hand-written HIP kernel.  There is no CPU path: calling forward on CPU tensors raises.
+"""
+from __future__ import annotations
+
+import json
+import math
+import os
+from collections import OrderedDict
+from dataclasses import dataclass, fields
+from typing import Optional, Tuple
+
+import torch
+from torch import nn
+
+from poseidon_amd.arena import Arena
+from poseidon_amd.config import MODEL_MAP, ScOTConfig, preset  # noqa: F401  (re-exported)
+from poseidon_amd.engine import ScOTEngine
+from poseidon_amd.geometry import param_shapes, stage_plan
+from poseidon_amd.lib import ScotLibraryError
+
+
+@dataclass
+class ScOTOutput:
+    """reference model.py:57-63; indexable like HF ModelOutput (`out["loss"]`, `out[0]`, `.output`)."""
+    loss: Optional[torch.Tensor] = None
+    output: Optional[torch.Tensor] = None
+    hidden_states: Optional[Tuple[torch.Tensor, ...]] = None
+    attentions: Optional[Tuple[torch.Tensor, ...]] = None
+    reshaped_hidden_states: Optional[Tuple[torch.Tensor, ...]] = None
+
+    def to_tuple(self):
+        return tuple(getattr(self, f.name) for f in fields(self) if getattr(self, f.name) is not None)
+
+    def __getitem__(self, k):
+        if isinstance(k, str):
+            return getattr(self, k)
+        return self.to_tuple()[k]
+
+    def keys(self):
+        return [f.name for f in fields(self) if getattr(self, f.name) is not None]
+
+    def __contains__(self, k):
+        return k in self.keys()
+
+
+# ---------------------------------------------------------------------------------------------- parameter containers
+class LayerNorm(nn.LayerNorm):
+    """Time-independent variant (reference model.py:135-140): parameters `weight`, `bias` of shape (C,)."""
+
+    def forward(self, x, time=None):  # pragma: no cover - containers hold parameters only
+        raise ScotLibraryError("normalisation runs inside the fused HIP kernels (scot_cln_fwd); call ScOT.forward")
+
+
+class ConditionalLayerNorm(nn.Module):
+    """Time-conditioned layer norm (reference model.py:143-160): gamma = weight(t), beta = bias(t), two nn.Linear(1, C)."""
+
+    def __init__(self, dim, eps=1e-5):
+        super().__init__()
+        self.eps = eps
+        self.weight = nn.Linear(1, dim)
+        self.bias = nn.Linear(1, dim)
+
+    def forward(self, x, time):  # pragma: no cover
+        raise ScotLibraryError("normalisation runs inside the fused HIP kernels (scot_cln_fwd); call ScOT.forward")
+
+
+def _norm(cfg, dim, eps=1e-5):
+    return ConditionalLayerNorm(dim, eps=eps) if cfg.use_conditioning else LayerNorm(dim, eps=eps)
+
+
+class _Holder(nn.Module):
+    """Plain namespace module (children registered by attribute assignment)."""
+
+
+def _attention(cfg, dim, heads):
+    att = _Holder()
+    att.self = _Holder()
+    att.self.logit_scale = nn.Parameter(torch.log(10 * torch.ones((heads, 1, 1))))  # HF:374
+    att.self.continuous_position_bias_mlp = nn.Sequential(nn.Linear(2, 512, bias=True), nn.ReLU(inplace=True),
+                                                          nn.Linear(512, heads, bias=False))
+    att.self.query = nn.Linear(dim, dim, bias=cfg.qkv_bias)
+    att.self.key = nn.Linear(dim, dim, bias=False)
+    att.self.value = nn.Linear(dim, dim, bias=cfg.qkv_bias)
+    att.output = _Holder()
+    att.output.dense = nn.Linear(dim, dim)
+    return att
+
+
+def _block(cfg, dim, heads):
+    b = _Holder()
+    b.attention = _attention(cfg, dim, heads)
+    b.layernorm_before = _norm(cfg, dim, cfg.layer_norm_eps)
+    b.intermediate = _Holder()
+    b.intermediate.dense = nn.Linear(dim, int(cfg.mlp_ratio * dim))
+    b.output = _Holder()
+    b.output.dense = nn.Linear(int(cfg.mlp_ratio * dim), dim)
+    b.layernorm_after = _norm(cfg, dim, cfg.layer_norm_eps)
+    return b
+
+
+def _convnext(cfg, dim):
+    c = _Holder()
+    c.weight = nn.Parameter(1e-6 * torch.ones(dim))  # layer scale (reference model.py:191-195)
+    c.dwconv = nn.Conv2d(dim, dim, kernel_size=7, padding=3, groups=dim)
+    c.norm = _norm(cfg, dim, cfg.layer_norm_eps)
+    c.pwconv1 = nn.Linear(dim, 4 * dim)
+    c.pwconv2 = nn.Linear(4 * dim, dim)
+    return c
+
+
+class _ScOTFunction(torch.autograd.Function):
+    """Connects the engine's explicit forward/backward to torch.autograd.  Parameter gradients are accumulated by the
+    kernels directly into the gradient arena whose slices are the parameters' `.grad` (no per-tensor AccumulateGrad)."""
+
+    @staticmethod
+    def forward(ctx, anchor, model, pixel_values, time, labels, pixel_mask):
+        loss, pred, tape = model._engine.forward(pixel_values, time, labels, pixel_mask, train=True)
+        ctx.model, ctx.tape = model, tape
+        ctx.has_loss = loss is not None
+        ctx.set_materialize_grads(False)  # unused outputs arrive as None instead of zero tensors
+        if loss is None:
+            loss = pred.new_zeros(1)
+        return loss.view(()), pred
+
+    @staticmethod
+    def backward(ctx, dloss, dpred):
+        model, tape = ctx.model, ctx.tape
+        ctx.tape = None
+        if tape is None:
+            raise RuntimeError("ScOT backward called twice (activations are freed after the first backward)")
+        model._prepare_grads()
+        dl = None
+        if ctx.has_loss:
+            dl = (dloss.reshape(1).to(torch.float32).contiguous() if dloss is not None
+                  else torch.zeros(1, device=model._arena.data.device))
+        model._engine.backward(tape, dl, dpred)
+        model._after_backward()
+        return None, None, None, None, None, None
+
+
+class ScOT(nn.Module):
+    config_class = ScOTConfig
+    base_model_prefix = "swinv2"
+    main_input_name = "pixel_values"
+
+    def __init__(self, config: ScOTConfig, use_mask_token: bool = False, compute: Optional[str] = None):
+        super().__init__()
+        if config.residual_model not in ("convnext", "resnet"):
+            raise ValueError("residual_model must be 'convnext' or 'resnet'")
+        if config.residual_model != "convnext":
+            raise NotImplementedError("residual_model='resnet' is unused by every preset and out of scope (SURVEY.md §8a row 18)")
+        if use_mask_token:
+            raise NotImplementedError("mask tokens (bool_masked_pos) are unused by every preset and not implemented")
+        if config.image_size % config.patch_size:
+            raise ValueError("image_size must be a multiple of patch_size")
+        self.config = config
+        self.compute = compute or os.environ.get("SCOT_COMPUTE", "bf16")
+        self.num_layers_encoder = self.num_layers_decoder = len(config.depths)
+        self.num_features = int(config.embed_dim * 2 ** (len(config.depths) - 1))
+        cfg = config
+        c0, p = cfg.embed_dim, cfg.patch_size
+        grid, enc, dec = stage_plan(cfg)
+
+        self.embeddings = _Holder()
+        self.embeddings.patch_embeddings = _Holder()
+        self.embeddings.patch_embeddings.projection = nn.Conv2d(cfg.num_channels, c0, kernel_size=p, stride=p)
+        if cfg.use_absolute_embeddings:
+            self.embeddings.position_embeddings = nn.Parameter(torch.zeros(1, grid[0] * grid[1], c0))
+        self.embeddings.norm = _norm(cfg, c0)
+
+        self.encoder = _Holder()
+        self.encoder.layers = nn.ModuleList()
+        for st in enc:
+            s = _Holder()
+            s.blocks = nn.ModuleList([_block(cfg, st.dim, st.heads) for _ in st.blocks])
+            if st.resample:
+                s.downsample = _Holder()
+                s.downsample.reduction = nn.Linear(4 * st.dim, 2 * st.dim, bias=False)
+                s.downsample.norm = _norm(cfg, 2 * st.dim)
+            self.encoder.layers.append(s)
+        self.decoder = _Holder()
+        self.decoder.layers = nn.ModuleList()
+        for st in dec:
+            s = _Holder()
+            s.blocks = nn.ModuleList([_block(cfg, st.dim, st.heads) for _ in st.blocks])
+            if st.resample:
+                s.upsample = _Holder()
+                s.upsample.upsample = nn.Linear(st.dim, 2 * st.dim, bias=False)
+                s.upsample.mixup = nn.Linear(st.dim // 2, st.dim // 2, bias=False)
+                s.upsample.norm = _norm(cfg, st.dim // 2)
+            self.decoder.layers.append(s)
+        self.patch_recovery = _Holder()
+        self.patch_recovery.projection = nn.ConvTranspose2d(c0, cfg.num_out_channels, kernel_size=p, stride=p)
+        self.patch_recovery.mixup = nn.Conv2d(cfg.num_out_channels, cfg.num_out_channels, kernel_size=5, stride=1, padding=2,
+                                              bias=False)
+        self.residual_blocks = nn.ModuleList([
+            nn.ModuleList([_convnext(cfg, cfg.embed_dim * 2 ** i) for _ in range(int(depth))]) if int(depth) > 0
+            else nn.ModuleList([nn.Identity()]) for i, depth in enumerate(cfg.skip_connections)])
+
+        self._init_weights()
+        self._shapes = param_shapes(cfg)
+        got = OrderedDict((k, tuple(v.shape)) for k, v in self.named_parameters())
+        if list(got.items()) != list(self._shapes.items()):  # schema self-check
+            raise AssertionError("parameter schema drifted from poseidon_amd.geometry.param_shapes")
+        self._arena: Optional[Arena] = None
+        self._engine: Optional[ScOTEngine] = None
+        self._anchor = None
+        self._grad_hooks = []
+
+    # ------------------------------------------------------------------------------------------ init / io
+    def _init_weights(self):
+        """HF `_init_weights` semantics of the pinned stack: Linear/Conv2d ~ N(0, initializer_range),
+        biases 0, LayerNorm 1/0; logit_scale, layer-scale and the ConvTranspose2d keep their constructor values."""
+        std = self.config.initializer_range
+        for m in self.modules():
+            if isinstance(m, (nn.Linear, nn.Conv2d)):
+                m.weight.data.normal_(mean=0.0, std=std)
+                if m.bias is not None:
+                    m.bias.data.zero_()
+            elif isinstance(m, nn.LayerNorm):
+                m.bias.data.zero_()
+                m.weight.data.fill_(1.0)
+
+    def get_input_embeddings(self):
+        return self.embeddings.patch_embeddings
+
+    def num_parameters(self):
+        return sum(p.numel() for p in self.parameters())
+
+    def save_pretrained(self, save_directory: str, safe_serialization: bool = True, **_):
+        os.makedirs(save_directory, exist_ok=True)
+        self.config.save_pretrained(save_directory)
+        sd = {k: v.detach().to("cpu").contiguous().clone() for k, v in self.state_dict().items()}
+        if safe_serialization:
+            from safetensors.torch import save_file
+            save_file(sd, os.path.join(save_directory, "model.safetensors"), metadata={"format": "pt"})
+        else:
+            torch.save(sd, os.path.join(save_directory, "pytorch_model.bin"))
+
+    @classmethod
+    def from_pretrained(cls, pretrained_model_name_or_path: str, config: Optional[ScOTConfig] = None,
+                        ignore_mismatched_sizes: bool = False, compute: Optional[str] = None, **kwargs):
+        path = pretrained_model_name_or_path
+        if not os.path.isdir(path):
+            raise FileNotFoundError(f"{path}: only local HF checkpoint directories are supported (no network here); "
+                                    "download `camlab-ethz/Poseidon-*` and pass the directory")
+        if config is None:
+            config = ScOTConfig.from_pretrained(path)
+        model = cls(config, compute=compute)
+        st, bn = os.path.join(path, "model.safetensors"), os.path.join(path, "pytorch_model.bin")
+        if os.path.exists(st):
+            from safetensors.torch import load_file
+            sd = load_file(st)
+        elif os.path.exists(bn):
+            sd = torch.load(bn, map_location="cpu", weights_only=True)
+        else:
+            raise FileNotFoundError(f"no model.safetensors / pytorch_model.bin in {path}")
+        own = model.state_dict()
+        mism, missing = [], [k for k in own if k not in sd]
+        unexpected = [k for k in sd if k not in own]
+        for k, v in sd.items():
+            if k in own:
+                if tuple(v.shape) != tuple(own[k].shape):
+                    if not ignore_mismatched_sizes:
+                        raise RuntimeError(f"size mismatch for {k}: checkpoint {tuple(v.shape)} vs model {tuple(own[k].shape)} "
+                                           "(pass ignore_mismatched_sizes=True to re-initialise, reference train.py:331-333)")
+                    mism.append(k)
+                else:
+                    own[k].copy_(v)
+        model._load_report = dict(missing=missing, unexpected=unexpected, mismatched=mism)
+        return model
+
+    # ------------------------------------------------------------------------------------------ arena management
+    def _ensure_arena(self, device):
+        params = list(self.named_parameters())
+        ar = self._arena
+        ok = ar is not None and ar.data.device == device
+        if ok:
+            n0, p0 = params[0]
+            n1, p1 = params[-1]
+            ok = p0.data_ptr() == ar.view(n0).data_ptr() and p1.data_ptr() == ar.view(n1).data_ptr()
+        if ok:
+            return
+        ar = Arena(self._shapes, device)
+        with torch.no_grad():
+            for n, p in params:
+                v = ar.view(n)
+                v.copy_(p.data.to(device=device, dtype=torch.float32))
+                p.data = v
+                p.grad = None
+        self._arena = ar
+        self._engine = ScOTEngine(self.config, ar, self.compute)
+        self._anchor = torch.zeros(1, device=device, requires_grad=True)
+        self._params = [p for _, p in params]
+        self._gviews = [ar.gview(n) for n, _ in params]
+
+    def flat_parameters(self) -> torch.Tensor:
+        return self._arena.data
+
+    def flat_grads(self) -> torch.Tensor:
+        return self._arena.grad
+
+    def _prepare_grads(self):
+        """Attach arena slices as `.grad`.  If the grads were set to None (zero_grad(set_to_none=True)) the arena is
+        cleared first, so accumulation semantics match autograd's."""
+        ps = self._params
+        if ps[0].grad is None or ps[0].grad.data_ptr() != self._gviews[0].data_ptr():
+            self._arena.grad.zero_()
+            for p, g in zip(ps, self._gviews):
+                p.grad = g if p.requires_grad else None
+
+    def _after_backward(self):
+        for h in self._grad_hooks:
+            h(self)
+
+    def register_grad_ready_hook(self, fn):
+        """fn(model) is called right after the engine finished writing the gradient arena (used by the DP wrapper)."""
+        self._grad_hooks.append(fn)
+
+    def zero_grad(self, set_to_none: bool = False):
+        if self._arena is not None:
+            self._arena.grad.zero_()
+            if set_to_none:
+                for p in self._params:
+                    p.grad = None
+        else:
+            super().zero_grad(set_to_none=set_to_none)
+
+    # ------------------------------------------------------------------------------------------ forward
+    @staticmethod
+    def _downsample(image, target_size):
+        """Spectral down-sampling (reference model.py:1293-1300); rocFFT via torch.fft, not on the timed hot path."""
+        size = image.shape[-2]
+        freqs = torch.fft.fftfreq(size, d=1 / size, device=image.device)
+        sel = torch.logical_and(freqs >= -target_size / 2, freqs <= target_size / 2 - 1)
+        hat = torch.fft.fft2(image, norm="forward")[:, :, sel, :][:, :, :, sel]
+        return torch.fft.ifft2(hat, norm="forward").real.contiguous()
+
+    @staticmethod
+    def _upsample(image, target_size):
+        """Spectral up-sampling (reference model.py:1302-1316)."""
+        size = image.shape[-2]
+        hat = torch.fft.fftshift(torch.fft.fft2(image, norm="forward"))
+        pad = (target_size - size) // 2
+        real = nn.functional.pad(hat.real, (pad, pad, pad, pad), value=0.0)
+        imag = nn.functional.pad(hat.imag, (pad, pad, pad, pad), value=0.0)
+        return torch.fft.ifft2(torch.fft.ifftshift(torch.complex(real, imag)), norm="forward").real.contiguous()
+
+    def forward(self, pixel_values=None, time=None, bool_masked_pos=None, head_mask=None, pixel_mask=None, labels=None,
+                output_attentions=None, output_hidden_states=None, return_dict=None):
+        cfg = self.config
+        return_dict = return_dict if return_dict is not None else cfg.use_return_dict
+        if pixel_values is None:
+            raise ValueError("pixel_values cannot be None")
+        if output_attentions or (output_attentions is None and cfg.output_attentions):
+            raise NotImplementedError("attention probabilities are never materialised by the fused kernel")
+        if bool_masked_pos is not None:
+            raise NotImplementedError("mask tokens are not implemented")
+        if head_mask is not None:
+            raise NotImplementedError("head_mask is not implemented")
+        if not pixel_values.is_cuda:
+            raise ScotLibraryError("ScOT.forward needs CUDA(HIP) tensors: the hot path is HIP-only (no CPU fallback)")
+        dev = pixel_values.device
+        self._ensure_arena(dev)
+        pv = pixel_values.to(torch.float32).contiguous()
+        B = pv.shape[0]
+        t = None
+        if cfg.use_conditioning:
+            if time is None:
+                raise ValueError("time is required when use_conditioning=True")
+            t = torch.as_tensor(time, device=dev).reshape(-1).to(torch.float32).contiguous()
+            if t.numel() == 1 and B > 1:
+                t = t.expand(B).contiguous()
+        lab = labels.to(device=dev, dtype=torch.float32).contiguous() if labels is not None else None
+        in_size = pv.shape[2]
+        resized = in_size != cfg.image_size
+        if resized:
+            pv = self._upsample(pv, cfg.image_size) if in_size < cfg.image_size else self._downsample(pv, cfg.image_size)
+        want_grad = torch.is_grad_enabled() and any(p.requires_grad for p in self._params)
+        if resized and (lab is not None or pixel_mask is not None):
+            # reference order (model.py:1416-1484): resize the prediction back first, then mask + loss at input resolution
+            loss, pred = self._forward_resized(pv, t, lab, pixel_mask, in_size, want_grad)
+        elif want_grad:
+            loss, pred = _ScOTFunction.apply(self._anchor, self, pv, t, lab, pixel_mask)
+            if lab is None:
+                loss = None
+        else:
+            loss, pred, _ = self._engine.forward(pv, t, lab, pixel_mask, train=False)
+            if loss is not None:
+                loss = loss.view(())
+            if resized:
+                pred = self._upsample(pred, in_size) if in_size > cfg.image_size else self._downsample(pred, in_size)
+        hs = rhs = None
+        if output_hidden_states or (output_hidden_states is None and cfg.output_hidden_states):
+            hd, he = self._engine.last_hidden
+            hs, rhs = self._hidden_tuples(hd, he, B)
+        if not return_dict:
+            out = (pred,) + ((hs,) if hs is not None else ())
+            return ((loss,) + out) if loss is not None else out
+        return ScOTOutput(loss=loss, output=pred, hidden_states=hs, attentions=None, reshaped_hidden_states=rhs)
+
+    def _forward_resized(self, pv, t, lab, pixel_mask, in_size, want_grad):
+        cfg = self.config
+        if want_grad:
+            _, pred = _ScOTFunction.apply(self._anchor, self, pv, t, None, None)
+        else:
+            _, pred, _ = self._engine.forward(pv, t, None, None, train=False)
+        pred = self._upsample(pred, in_size) if in_size > cfg.image_size else self._downsample(pred, in_size)
+        if pixel_mask is not None:
+            m = pixel_mask.view(pixel_mask.shape[0], pixel_mask.shape[1], 1, 1).expand_as(pred) if pixel_mask.dim() == 2 else pixel_mask
+            pred = torch.where(m, lab, pred)
+        loss = None
+        if lab is not None:
+            loss = _torch_loss(pred, lab, cfg.p, cfg.channel_slice_list_normalized_loss)
+        return loss, pred
+
+    def _hidden_tuples(self, hd, he, B):
+        def shp(lst, ress):
+            flat, resh = [], []
+            for h, (hh, ww) in zip(lst, ress):
+                c = h.shape[-1]
+                f = h.view(B, hh * ww, c)
+                flat.append(f)
+                resh.append(f.view(B, hh, ww, c).permute(0, 3, 1, 2))
+            return flat, resh
+        _, enc, dec = stage_plan(self.config)
+        enc_res = [enc[0].res] + [s.res for s in enc]
+        dec_res = [dec[0].res] + [s.res for s in dec]
+        fd, rd = shp(hd, dec_res)
+        fe, re_ = shp(he, enc_res)
+        return tuple(fd + fe), tuple(rd + re_)
+
+
+def _torch_loss(pred, labels, p, groups):
+    """Loss at a resolution different from config.image_size (spectral-resize path only; off the hot path)."""
+    fn = (lambda a, b: (a - b).abs().mean()) if p == 1 else (lambda a, b: ((a - b) ** 2).mean())
+    if groups is None:
+        return fn(pred, labels)
+    terms = [fn(pred[:, groups[i]:groups[i + 1]], labels[:, groups[i]:groups[i + 1]]) /
+             (fn(labels[:, groups[i]:groups[i + 1]], torch.zeros_like(labels[:, groups[i]:groups[i + 1]])) + 1e-10)
+             for i in range(len(groups) - 1)]
+    return torch.stack(terms).mean()

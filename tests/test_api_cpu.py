@@ -1,0 +1,103 @@
+"""CPU-only tests of the boundary: state-dict schema, config JSON, checkpoint round trip, C-ABI symbol export,
+loud failure without a GPU."""
+import ctypes
+import json
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import ROOT, load_fixture
+from poseidon_amd import lib as scotlib
+from poseidon_amd.config import ScOTConfig, preset
+from poseidon_amd.geometry import count_params, param_shapes, stage_plan
+from poseidon_amd.synth import synth_state_dict
+from scOT.model import ConditionalLayerNorm, LayerNorm, ScOT, ScOTOutput
+
+
+def test_param_counts_match_survey():
+    assert count_params(preset("T", image_size=128, num_channels=4, num_out_channels=4)) == 20774444
+    assert count_params(preset("B", image_size=128, num_channels=4, num_out_channels=4)) == 157729988
+    assert count_params(preset("L", image_size=128, num_channels=4, num_out_channels=4)) == 628575524
+
+
+def test_state_dict_schema_matches_reference_fixture():
+    f, meta = load_fixture("tiny_trained")
+    cfg = ScOTConfig(**meta["cfg"])
+    model = ScOT(cfg)
+    ref_keys = [k[5:] for k in f.files if k.startswith("grad:")]
+    assert list(model.state_dict().keys()) == ref_keys
+    for k, v in model.state_dict().items():
+        assert tuple(v.shape) == tuple(f["grad:" + k].shape)
+    f2, meta2 = load_fixture("tiny_nocond_p2")
+    m2 = ScOT(ScOTConfig(**meta2["cfg"]))
+    assert list(m2.state_dict().keys()) == [k[5:] for k in f2.files if k.startswith("grad:")]
+    assert any(isinstance(m, LayerNorm) for m in m2.modules()) and not any(isinstance(m, ConditionalLayerNorm) for m in m2.modules())
+
+
+def test_geometry_poseidon_b():
+    cfg = preset("B", image_size=128, num_channels=4, num_out_channels=4)
+    grid, enc, dec = stage_plan(cfg)
+    assert grid == (32, 32)
+    ws = [[b.window_shift() for b in st.blocks] for st in enc]
+    assert ws[0][:4] == [(16, 0), (16, 8), (16, 0), (16, 8)] and ws[1][1] == (16, 0) and ws[2][1] == (8, 0) and ws[3][1] == (4, 0)
+    assert [b.window_shift() for b in dec[3].blocks][:3] == [(16, 8), (16, 0), (16, 8)]  # reversed construction
+    cfg5 = preset("B", image_size=256, num_channels=4, num_out_channels=4)
+    _, enc5, _ = stage_plan(cfg5)
+    assert [st.blocks[1].window_shift() for st in enc5] == [(16, 8), (16, 8), (16, 0), (8, 0)]
+
+
+def test_config_json_roundtrip(tmp_path):
+    cfg = preset("T", image_size=128, num_channels=4, num_out_channels=4, channel_slice_list_normalized_loss=[0, 1, 3, 4])
+    cfg.save_pretrained(str(tmp_path))
+    d = json.load(open(tmp_path / "config.json"))
+    assert d["model_type"] == "swinv2" and d["hidden_size"] == 384 and d["num_layers"] == 4
+    cfg2 = ScOTConfig.from_pretrained(str(tmp_path))
+    assert cfg2.to_dict() == cfg.to_dict()
+    assert ScOTConfig(learn_residual=True, use_conditioning=False).learn_residual is False  # reference model.py:122
+
+
+@pytest.mark.parametrize("safe", [True, False])
+def test_checkpoint_roundtrip_and_mismatched_sizes(tmp_path, safe):
+    f, meta = load_fixture("tiny_trained")
+    cfg = ScOTConfig(**meta["cfg"])
+    model = ScOT(cfg)
+    model.load_state_dict(synth_state_dict(param_shapes(cfg), "trained"))
+    model.save_pretrained(str(tmp_path), safe_serialization=safe)
+    assert os.path.exists(tmp_path / ("model.safetensors" if safe else "pytorch_model.bin"))
+    m2 = ScOT.from_pretrained(str(tmp_path))
+    for (k, a), (_, b) in zip(model.state_dict().items(), m2.state_dict().items()):
+        assert torch.equal(a, b), k
+    cfg3 = ScOTConfig(**dict(meta["cfg"], num_channels=5, num_out_channels=3, channel_slice_list_normalized_loss=[0, 1, 3]))
+    with pytest.raises(RuntimeError):
+        ScOT.from_pretrained(str(tmp_path), config=cfg3)
+    m3 = ScOT.from_pretrained(str(tmp_path), config=cfg3, ignore_mismatched_sizes=True)
+    assert sorted(m3._load_report["mismatched"]) == sorted([
+        "embeddings.patch_embeddings.projection.weight", "patch_recovery.projection.weight",
+        "patch_recovery.projection.bias", "patch_recovery.mixup.weight"])
+
+
+def test_forward_fails_loudly_without_gpu():
+    f, meta = load_fixture("tiny_trained")
+    model = ScOT(ScOTConfig(**meta["cfg"]))
+    with pytest.raises(scotlib.ScotLibraryError):
+        model(pixel_values=torch.zeros(1, 4, 32, 32), time=torch.zeros(1))
+    with pytest.raises(ValueError):
+        model(pixel_values=None)
+
+
+def test_output_is_indexable_like_hf():
+    o = ScOTOutput(loss=torch.tensor(1.0), output=torch.zeros(1))
+    assert o["loss"] is o.loss and o[0] is o.loss and o[1] is o.output and "loss" in o
+
+
+def test_c_abi_exports_every_declared_symbol():
+    lib = scotlib.load()
+    header = open(os.path.join(ROOT, "include", "scot_hip.h")).read()
+    declared = set(re.findall(r"\b(scot_[a-z0-9_]+)\s*\(", header)) - {"scot_stream_t"}
+    assert declared == set(scotlib.PROTOTYPES.keys())
+    for name in declared:
+        assert getattr(lib, name) is not None
+    assert lib.scot_abi_version() == 1
