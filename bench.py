@@ -1,0 +1,263 @@
+#!/usr/bin/env python
+"""bench.py — PDE-grid samples/s (forward + backward, loss included, optimizer excluded) of the scOT hot path.
+
+  python bench.py --gpus N --steps K --warmup W          (N>1: launched by torch.distributed.run, one rank per GPU)
+
+Workload (BASELINE.json metric / configs[2]): Poseidon-B, per-GPU batch 64, 128x128x4 synthetic CE-RP-shaped grids
+(N(0,1) channels, all active, groups [0,1,3,4]), bf16 MFMA compute, weak scaling (per-device batch fixed, as reference
+train.py:281).  A "step" = zero the gradient arena + ScOT.forward (incl. grouped relative-L1 loss) + backward into the
+arena (+ mean all-reduce of the arena for N>1).  Inputs are resident in HBM before the timed region.
+Prints ONE JSON line (rank 0).
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+# forward GFLOP/sample F (excl. CPB) and batch-independent CPB GFLOP/step P; fwd+bwd = 3(B·F + P)
+FLOPS = {"T": (2.784, 0.139), "B": (18.286, 0.277), "L": (67.948, 0.277)}
+PEAK_TFLOPS = {"bf16": 2500.0, "fp32": 157.3}  # dense MFMA peaks, /opt/skills/guides/MI355X_MICROARCH.md
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--model", default="B", choices=["T", "B", "L"])
+    ap.add_argument("--batch", type=int, default=64, help="per-GPU batch")
+    ap.add_argument("--size", type=int, default=128)
+    ap.add_argument("--channels", type=int, default=4)
+    ap.add_argument("--compute", default="bf16", choices=["bf16", "fp32"])
+    ap.add_argument("--no-graph", action="store_true", help="eager launches instead of one hipGraph per step")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=20.0)
+    ap.add_argument("--wire", default="bf16", choices=["bf16", "fp32"], help="gradient all-reduce wire format (N>1)")
+    ap.add_argument("--_cpu-worker", dest="cpu_worker", action="store_true", help=argparse.SUPPRESS)
+    return ap.parse_args()
+
+
+def usable_cores(cap=32):
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:  # cgroup v2 CPU quota
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()
+        if q != "max":
+            n = min(n, max(1, int(int(q) / int(per))))
+    except Exception:
+        pass
+    return max(1, min(n, cap))
+
+
+def cpu_baseline(model_tag, size, channels, budget_s):
+    """Runs `_cpu_baseline_worker` in a child process with a hard wall-clock limit (a thread-oversubscribed host must
+    not be able to stall the GPU measurement)."""
+    import subprocess
+    cmd = [sys.executable, os.path.abspath(__file__), "--_cpu-worker", "--model", model_tag, "--size", str(size),
+           "--channels", str(channels), "--cpu-seconds", str(budget_s)]
+    try:
+        out = subprocess.run(cmd, capture_output=True, text=True, timeout=budget_s * 4 + 60)
+        for line in reversed(out.stdout.strip().splitlines()):
+            if line.startswith("{"):
+                return json.loads(line)
+        return {"error": "no result", "stderr": out.stderr[-300:]}
+    except subprocess.TimeoutExpired:
+        return {"error": f"cpu baseline exceeded {budget_s * 4 + 60:.0f}s"}
+
+
+def _cpu_baseline_worker(model_tag, size, channels, budget_s):
+    """Oracle (CPU restatement, torch CPU ops, fp32) timed on this host's cores: fwd+bwd, small batch, bounded time."""
+    from oracle import scot_cpu
+    from poseidon_amd.config import preset
+    from poseidon_amd.geometry import param_shapes
+    cores = usable_cores()
+    torch.set_num_threads(cores)
+    groups = [0, 1, channels - 1, channels]
+    cfg = preset(model_tag, image_size=size, num_channels=channels, num_out_channels=channels,
+                 channel_slice_list_normalized_loss=groups)
+    g = torch.Generator().manual_seed(0)
+    sd = {}
+    for k, shp in param_shapes(cfg).items():
+        t = torch.randn(*shp, generator=g) * 0.02
+        if k.endswith("logit_scale"):
+            t = torch.full(shp, 2.3026)
+        sd[k] = t.requires_grad_(True)
+    bs = 2
+    pv, lab, tt = torch.randn(bs, channels, size, size, generator=g), torch.randn(bs, channels, size, size, generator=g), torch.rand(bs, generator=g)
+
+    def step():
+        for v in sd.values():
+            v.grad = None
+        loss, _ = scot_cpu.scot_forward(sd, cfg, pv, tt, lab)
+        loss.backward()
+    step()  # warm-up
+    times, t_start = [], time.time()
+    while len(times) < 2 or (time.time() - t_start < budget_s and len(times) < 10):
+        t0 = time.time()
+        step()
+        times.append(time.time() - t0)
+    times.sort()
+    med = times[len(times) // 2]
+    return {"value": bs / med, "unit": "samples/s", "cores": cores, "kind": "port",
+            "sample": f"oracle/scot_cpu.py fp32 fwd+bwd, Poseidon-{model_tag} batch {bs} {size}x{size}x{channels}, "
+                      f"median of {len(times)} steps, {cores} torch threads"}
+
+
+def dominant_kernel_probe(compute, batch, embed_dim, size):
+    """Live HIP-event timing of the single largest FLOP consumer (MLP fc1 GEMM of stage 0: M = batch·(size/4)^2, K = C,
+    N = 4C, bias epilogue, bf16 store) on the stream the engine launches on."""
+    from poseidon_amd import ops
+    M, K, N = batch * (size // 4) ** 2, embed_dim, 4 * embed_dim
+    cm = ops.BF16 if compute == "bf16" else ops.F32
+    x = torch.randn(M, K, device="cuda")
+    w = torch.randn(N, K, device="cuda") * 0.05
+    b = torch.randn(N, device="cuda")
+    u = torch.empty(M, N, device="cuda", dtype=torch.bfloat16 if compute == "bf16" else torch.float32)
+    for _ in range(3):
+        ops.linear_fwd(cm, x, w, u, bias=b)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    reps = 20
+    e0.record()
+    for _ in range(reps):
+        ops.linear_fwd(cm, x, w, u, bias=b)
+    e1.record()
+    torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / reps
+    flops = 2.0 * M * K * N
+    bytes_alg = M * K * 4 + N * K * 4 + M * N * u.element_size()
+    return {"kernel": "gemm_kernel<NT> fc1 stage0", "shape": [M, N, K], "us": ms * 1e3, "tflops": flops / ms / 1e9,
+            "algorithmic_gbps": bytes_alg / ms / 1e6}
+
+
+def main():
+    a = parse()
+    if a.cpu_worker:
+        print(json.dumps(_cpu_baseline_worker(a.model, a.size, a.channels, a.cpu_seconds)), flush=True)
+        return
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != a.gpus and world > 1:
+        raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}")
+    torch.cuda.set_device(local)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
+
+    from poseidon_amd.config import preset
+    from poseidon_amd.dp import GradAllReducer
+    from scOT.model import ScOT
+
+    ch = a.channels
+    cfg = preset(a.model, image_size=a.size, num_channels=ch, num_out_channels=ch,
+                 channel_slice_list_normalized_loss=[0, 1, ch - 1, ch])
+    torch.manual_seed(1234)  # identical initial weights on every rank (no broadcast needed)
+    model = ScOT(cfg, compute=a.compute)
+    with torch.no_grad():  # "trained-like" statistics so that every branch carries O(1) signal (random data, §5.4 rule 25)
+        for k, p in model.named_parameters():
+            if k.endswith("weight.bias") and ("norm" in k):
+                p.fill_(1.0)
+            elif k.startswith("residual_blocks") and k.count(".") == 2 and k.endswith(".weight"):
+                p.fill_(0.5)
+            elif p.dim() >= 2 and p.shape[-1] > 2:
+                fan = p[0].numel()
+                p.normal_(0, 1.0 / fan ** 0.5)
+    model = model.to("cuda")
+    torch.manual_seed(100 + rank)
+    B = a.batch
+    pv = torch.randn(B, ch, a.size, a.size, device="cuda")
+    lab = torch.randn(B, ch, a.size, a.size, device="cuda")
+    tt = torch.randint(0, 8, (B,), device="cuda").float() / 10.0
+    kw = dict(pixel_values=pv, time=tt, labels=lab)
+
+    reducer = GradAllReducer(model, dist, wire=a.wire) if world > 1 else None
+    loss_buf = torch.zeros((), device="cuda")
+
+    def compute_step():
+        model.zero_grad()
+        out = model(**kw)
+        out.loss.backward()
+        loss_buf.copy_(out.loss.detach())
+
+    # warm-up (eager): builds the arena, runs the device self test, fills allocator pools
+    for _ in range(max(1, min(a.warmup, 2))):
+        compute_step()
+        if reducer:
+            reducer.allreduce()
+    torch.cuda.synchronize()
+
+    graph = None
+    if not a.no_graph:
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph):
+            compute_step()
+        torch.cuda.synchronize()
+
+    def step():
+        if graph is not None:
+            graph.replay()
+        else:
+            compute_step()
+        if reducer:
+            reducer.allreduce()
+
+    for _ in range(a.warmup):
+        step()
+    if dist:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        step()
+    torch.cuda.synchronize()
+    if dist:
+        dist.barrier()
+    dt = time.perf_counter() - t0
+    if dist:
+        tmax = torch.tensor([dt], device="cuda", dtype=torch.float64)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dt = float(tmax)
+    ms = dt / a.steps * 1e3
+    total_samples = B * world * a.steps
+    value = total_samples / dt
+
+    if rank == 0:
+        F, P = FLOPS[a.model]
+        scale = (a.size / 128.0) ** 2
+        step_tflop = 3.0 * (B * F * scale + P) / 1e3            # per GPU per step
+        achieved = step_tflop / (ms / 1e3)                       # TFLOP/s per GPU
+        peak = PEAK_TFLOPS[a.compute]
+        roof = {"bound": "mfma", "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak,
+                "traffic": None, "scope": "whole step, algorithmic FLOPs 3(B*F+P) per GPU (SURVEY.md 8d)"}
+        try:
+            roof["dominant_kernel"] = dominant_kernel_probe(a.compute, B, cfg.embed_dim, a.size)
+        except Exception as e:  # pragma: no cover
+            roof["dominant_kernel"] = {"error": repr(e)}
+        res = {"metric": "PDE-grid samples/sec (fwd+bwd)", "value": value, "unit": "samples/s", "n_gpus": world, "steps": a.steps,
+               "warmup": a.warmup, "ms_per_step": ms, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+               "dtype": a.compute, "data": "synthetic",
+               "config": {"workload": f"Poseidon-{a.model} fwd+bwd, {a.size}x{a.size}x{ch} grids, per-GPU batch {B}",
+                          "global_batch": B * world, "parallelism": f"dp{world}", "graph": graph is not None,
+                          "grad_wire": a.wire if world > 1 else None, "loss": float(loss_buf)},
+               "roofline": roof}
+        if world == 1 and not a.no_cpu_baseline:
+            try:
+                res["cpu_baseline"] = cpu_baseline(a.model, a.size, ch, a.cpu_seconds)
+            except Exception as e:  # pragma: no cover
+                res["cpu_baseline"] = {"error": repr(e)}
+        print(json.dumps(res), flush=True)
+    if dist:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

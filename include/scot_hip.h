@@ -40,7 +40,11 @@ int scot_gemm(int layout, int compute, int M, int N, int K,
               const float* bias, const float* colscale,
               const void* aux, int aux_dt, int ldaux,
               const void* resid, int res_dt, int ldres,
-              int accumulate, scot_stream_t stream);
+              int accumulate, float* colsum_out, void* workspace, size_t ws_bytes, scot_stream_t stream);
+/* colsum_out (optional, fp32, +=): NT/NN: column sums of the stored result; TN: Σ_k A[k][m] — i.e. the bias gradient
+ * when A = dY, taken from the dY tile already staged in LDS.
+ * workspace (optional, 32-byte aligned device scratch owned by the caller): TN splits K over workgroups and writes
+ * partial tiles there, reduced by one extra pass; without it TN falls back to fp32 atomics. */
 
 /* Shifted-window cosine attention, HF:389-455 + ref:522-559 (roll/partition/mask folded into indexing).
  * qkv: [batch*Hp*Wp][3C] (q|k|v) in the compute dtype; out: [batch*Hp*Wp][C]; lse: [batch*nW][heads][ws*ws] f32;
@@ -59,12 +63,15 @@ int scot_cpb_bwd(const float* coords, const float* w0, const float* b0, const fl
                  const float* dtable, float* dw0, float* db0, float* dw2, int ws, int heads, scot_stream_t stream);
 
 /* ConditionalLayerNorm / LayerNorm (+ fused residual), ref:135-160, res-post-norm ref:570,574. */
-int scot_cln_fwd(const void* x, int x_dt, const void* resid, int res_dt, void* out, int out_dt, float* mean, float* rstd,
+int scot_cln_fwd(const void* x, int x_dt, const void* resid, int res_dt, void* out, int out_dt, void* out2, int out2_dt,
+                 float* mean, float* rstd,
                  const float* time, const float* gw_w, const float* gw_b, const float* bw_w, const float* bw_b, int rows,
                  int rows_per_sample, int C, float eps, scot_stream_t stream);
 int scot_cln_bwd(const void* dout, int dout_dt, const void* x, int x_dt, const float* mean, const float* rstd,
                  const float* time, const float* gw_w, const float* gw_b, void* dx, int dx_dt, float* d_gw_w,
-                 float* d_gw_b, float* d_bw_w, float* d_bw_b, int rows, int rows_per_sample, int C, scot_stream_t stream);
+                 float* d_gw_b, float* d_bw_w, float* d_bw_b, float* d_xbias, int rows, int rows_per_sample, int C,
+                 scot_stream_t stream);
+/* out2: optional second copy of the output in the next GEMM's operand dtype; d_xbias: optional += Σ_rows dx. */
 
 /* Data movement */
 int scot_add(const void* a, int a_dt, const void* b, int b_dt, void* out, int out_dt, size_t n, size_t period,

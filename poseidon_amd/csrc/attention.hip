@@ -77,9 +77,7 @@ __device__ __forceinline__ void stage_rows(CT* tile, const void* src, int ld, in
 #pragma unroll
       for (int j = 0; j < 8; ++j) v[j] *= r;
     }
-    CT* dst = tile + n * pitch + d8;
-#pragma unroll
-    for (int j = 0; j < 8; ++j) dst[j] = to_ct<CT>(v[j]);
+    store8_ct(tile + n * pitch + d8, v);
   }
 }
 
@@ -112,7 +110,8 @@ __device__ __forceinline__ void load_rows_frag(Frag<CT> (&f)[(HD + 31) / 32], co
 #pragma unroll
   for (int kk = 0; kk < KS; ++kk) {
 #pragma unroll
-    for (int j = 0; j < 8; ++j) frag_set(f[kk], j, v[kk][j] * r);
+    for (int j = 0; j < 8; ++j) v[kk][j] *= r;
+    f[kk] = frag_from_f32<CT>(v[kk]);
   }
 }
 
@@ -159,6 +158,8 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnArgs p) {
       if (NT >= 8 && (t & 3) == 3) __builtin_amdgcn_sched_barrier(0);  // keep the scheduler from hoisting all tiles' LDS reads
     }
     // logits: lane holds query q (=column), keys t*16 + g*4 + r
+    // branch-free: every bias-table gather is in bounds for any encoded position (padding rows encode position 0),
+    // so all 64 LDS gathers of a query row can be in flight together; masking is done with selects afterwards.
     float m = -3.0e38f;
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
@@ -167,15 +168,12 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnArgs p) {
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const int krid = kia[r] >> 20;
-        float v = -3.0e38f;
-        if (krid != 15 && qvalid) {
-          v = s[t][r] * scale + tab[qoff - (kia[r] & 0xfffff)];
-          if (krid != qrid) v -= 200.0f;  // the -100 mask is added twice in the installed oracle (HF:433-436)
-        }
+        float v = s[t][r] * scale + tab[qoff - (kia[r] & 0xfffff)];
+        v = (krid != qrid) ? v - 200.0f : v;  // the -100 mask is added twice in the installed oracle (HF:433-436)
+        v = (krid == 15 || !qvalid) ? -3.0e38f : v;
         s[t][r] = v;
         m = fmaxf(m, v);
       }
-      if (NT >= 8 && (t & 3) == 3) __builtin_amdgcn_sched_barrier(0);
     }
     m = fmaxf(m, __shfl_xor(m, 16, 64));
     m = fmaxf(m, __shfl_xor(m, 32, 64));
@@ -200,12 +198,10 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnArgs p) {
     for (int d = 0; d < DT; ++d) o[d] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int tp = 0; tp < NT / 2; ++tp) {
-      Frag<CT> pf;
+      float pv[8];
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        frag_set(pf, r, s[2 * tp][r] * inv);
-        frag_set(pf, r + 4, s[2 * tp + 1][r] * inv);
-      }
+      for (int r = 0; r < 4; ++r) { pv[r] = s[2 * tp][r] * inv; pv[r + 4] = s[2 * tp + 1][r] * inv; }
+      const Frag<CT> pf = frag_from_f32<CT>(pv);
 #pragma unroll
       for (int d = 0; d < DT; ++d)
         mma16(o[d], pf, lds_frag_ks(Vs, pitch, d * 16, (2 * tp) * 16 + g * 4, (2 * tp + 1) * 16 + g * 4, lane, p.use_tr));
@@ -324,7 +320,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_kernel(AttnArgs p) {
         mma16(dp[t], lds_frag_kc(Y, pitch, t * 16, kk * 32, lane), gf[kk]);
       }
     }
-    // s: cos -> P
+    // s: cos -> P   (branch-free, see forward)
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
       const int4 ki = *(const int4*)&rid[t * 16 + g * 4];
@@ -332,12 +328,10 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_kernel(AttnArgs p) {
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const int krid = kia[r] >> 20;
-        float pr = 0.f;
-        if (krid != 15 && qvalid) {
-          float v = s[t][r] * scale + tab[qoff - (kia[r] & 0xfffff)];
-          if (krid != qrid) v -= 200.0f;
-          pr = __expf(v - qlse);
-        }
+        float v = s[t][r] * scale + tab[qoff - (kia[r] & 0xfffff)];
+        v = (krid != qrid) ? v - 200.0f : v;
+        float pr = __expf(v - qlse);
+        pr = (krid == 15 || !qvalid) ? 0.f : pr;
         s[t][r] = pr;
         dl += pr * dp[t][r];
       }
@@ -351,9 +345,9 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_kernel(AttnArgs p) {
       const int kia[4] = {ki.x, ki.y, ki.z, ki.w};
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        const float ds = s[t][r] * (dp[t][r] - dl);
+        const float ds = s[t][r] * (dp[t][r] - dl);   // exactly 0 for masked pairs (P = 0)
         s[t][r] = ds;
-        if ((kia[r] >> 20) != 15 && qvalid) atomicAdd(&dtab[qoff - (kia[r] & 0xfffff)], ds);
+        atomicAdd(&dtab[qoff - (kia[r] & 0xfffff)], ds);
       }
     }
     // dQn = scale * dS · Kn   (A = dS in registers, B = Kn rows via the transposing read)
@@ -362,12 +356,10 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_kernel(AttnArgs p) {
     for (int d = 0; d < DT; ++d) dq[d] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int tp = 0; tp < NT / 2; ++tp) {
-      Frag<CT> df;
+      float dv8[8];
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        frag_set(df, r, s[2 * tp][r]);
-        frag_set(df, r + 4, s[2 * tp + 1][r]);
-      }
+      for (int r = 0; r < 4; ++r) { dv8[r] = s[2 * tp][r]; dv8[r + 4] = s[2 * tp + 1][r]; }
+      const Frag<CT> df = frag_from_f32<CT>(dv8);
 #pragma unroll
       for (int d = 0; d < DT; ++d)
         mma16(dq[d], df, lds_frag_ks(X, pitch, d * 16, (2 * tp) * 16 + g * 4, (2 * tp + 1) * 16 + g * 4, lane, p.use_tr));
@@ -404,7 +396,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_kernel(AttnArgs p) {
 
 #pragma unroll 1
     for (int tp = 0; tp < NT / 2; ++tp) {
-      Frag<CT> pf, df;
+      float pf8[8], df8[8];
 #pragma unroll
       for (int half = 0; half < 2; ++half) {
         const int t = 2 * tp + half;
@@ -416,21 +408,22 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_kernel(AttnArgs p) {
         }
         const int4 qi = *(const int4*)&rid[t * 16 + g * 4];
         const int qia[4] = {qi.x, qi.y, qi.z, qi.w};
+        const float4 ql = *(const float4*)&lse[t * 16 + g * 4];
+        const float4 qd = *(const float4*)&delta[t * 16 + g * 4];
+        const float qla[4] = {ql.x, ql.y, ql.z, ql.w}, qda[4] = {qd.x, qd.y, qd.z, qd.w};
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          const int q = t * 16 + g * 4 + r;
           const int qrid = qia[r] >> 20;
-          float pr = 0.f, ds = 0.f;
-          if (qrid != 15 && kvalid) {
-            float v = s[r] * scale + tab[(qia[r] & 0xfffff) + cen - koff];
-            if (qrid != krid) v -= 200.0f;
-            pr = __expf(v - lse[q]);
-            ds = pr * (dp[r] - delta[q]);
-          }
-          frag_set(pf, half * 4 + r, pr);
-          frag_set(df, half * 4 + r, ds);
+          float v = s[r] * scale + tab[(qia[r] & 0xfffff) + cen - koff];
+          v = (qrid != krid) ? v - 200.0f : v;
+          const bool ok = qrid != 15 && kvalid;
+          const float pr = ok ? __expf(v - qla[r]) : 0.f;
+          const float ds = ok ? pr * (dp[r] - qda[r]) : 0.f;
+          pf8[half * 4 + r] = pr;
+          df8[half * 4 + r] = ds;
         }
       }
+      const Frag<CT> pf = frag_from_f32<CT>(pf8), df = frag_from_f32<CT>(df8);
 #pragma unroll
       for (int d = 0; d < DT; ++d) {
         const int klo = (2 * tp) * 16 + g * 4, khi = (2 * tp + 1) * 16 + g * 4;

@@ -28,11 +28,15 @@ typedef short s16x4_t __attribute__((ext_vector_type(4)));
 typedef float f32x4_t __attribute__((ext_vector_type(4)));
 
 __device__ __forceinline__ float bf2f(bf16_t x) { return __uint_as_float(((uint32_t)x) << 16); }
-__device__ __forceinline__ bf16_t f2bf(float f) {  // round-to-nearest-even
-  uint32_t u = __float_as_uint(f);
-  if ((u & 0x7fffffffu) > 0x7f800000u) return (bf16_t)((u >> 16) | 0x40u);
-  u += 0x7fffu + ((u >> 16) & 1u);
-  return (bf16_t)(u >> 16);
+// fp32 -> bf16, round-to-nearest-even, via gfx950's v_cvt_pk_bf16_f32 (the compiler selects it for __bf16 casts; the
+// first version of these helpers did the rounding with 6 integer VALU ops per element — rocprof PMC showed the attention
+// kernels VALU-issue bound with ~1/4 of the instructions being that conversion).
+typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+typedef float f32x2_t __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ bf16_t f2bf(float f) { return __builtin_bit_cast(bf16_t, (__bf16)f); }
+__device__ __forceinline__ uint32_t pack_bf16x2(float lo, float hi) {
+  const f32x2_t v = {lo, hi};
+  return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, bf16x2_t));
 }
 
 template <typename CT> __device__ __forceinline__ CT to_ct(float f);
@@ -71,17 +75,42 @@ __device__ __forceinline__ void st8(void* p, int dt, size_t i, const float v[8])
     *(float4*)((float*)p + i + 4) = make_float4(v[4], v[5], v[6], v[7]);
   } else {
     uint4 u;
-    u.x = (uint32_t)f2bf(v[0]) | ((uint32_t)f2bf(v[1]) << 16);
-    u.y = (uint32_t)f2bf(v[2]) | ((uint32_t)f2bf(v[3]) << 16);
-    u.z = (uint32_t)f2bf(v[4]) | ((uint32_t)f2bf(v[5]) << 16);
-    u.w = (uint32_t)f2bf(v[6]) | ((uint32_t)f2bf(v[7]) << 16);
+    u.x = pack_bf16x2(v[0], v[1]); u.y = pack_bf16x2(v[2], v[3]); u.z = pack_bf16x2(v[4], v[5]); u.w = pack_bf16x2(v[6], v[7]);
     *(uint4*)((bf16_t*)p + i) = u;
   }
 }
 
-__device__ __forceinline__ float gelu_f(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752f)); }
+// erf-GELU (hidden_act="gelu", reference train.py:263).  libm erff costs ~50 VALU ops and sat on the critical path of the
+// fc2 operand loader (rocprof round 1: +40 us per stage-0 fc2); Abramowitz-Stegun 7.1.26 (|abs err| <= 1.5e-7, i.e. below
+// fp32 GELU resolution for the 1e-5 parity mode) needs one exp, one rcp and a degree-5 Horner chain — and the SAME
+// exp(-x^2/2) also gives the Gaussian term of the derivative.
+__device__ __forceinline__ void gelu_terms(float x, float& cdf, float& pdf_times_sqrt2pi) {
+  const float z = fabsf(x) * 0.70710678118654752f;
+  const float t = __frcp_rn(1.0f + 0.3275911f * z);
+  const float e = __expf(-z * z);
+  const float poly = ((((1.061405429f * t - 1.453152027f) * t + 1.421413741f) * t - 0.284496736f) * t + 0.254829592f) * t;
+  const float erf_abs = 1.0f - poly * e;                 // erf(|x|/sqrt2)
+  cdf = 0.5f * (1.0f + copysignf(erf_abs, x));           // Phi(x)
+  pdf_times_sqrt2pi = e;                                 // exp(-x^2/2)
+}
+// 8 consecutive compute-type elements to a 16-byte aligned (LDS or global) address
+__device__ __forceinline__ void store8_ct(bf16_t* p, const float v[8]) {
+  *(uint4*)p = make_uint4(pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]), pack_bf16x2(v[4], v[5]), pack_bf16x2(v[6], v[7]));
+}
+__device__ __forceinline__ void store8_ct(float* p, const float v[8]) {
+  *(float4*)p = make_float4(v[0], v[1], v[2], v[3]);
+  *(float4*)(p + 4) = make_float4(v[4], v[5], v[6], v[7]);
+}
+
+__device__ __forceinline__ float gelu_f(float x) {
+  float cdf, e;
+  gelu_terms(x, cdf, e);
+  return x * cdf;
+}
 __device__ __forceinline__ float gelu_grad_f(float x) {
-  return 0.5f * (1.0f + erff(x * 0.70710678118654752f)) + x * 0.3989422804014327f * __expf(-0.5f * x * x);
+  float cdf, e;
+  gelu_terms(x, cdf, e);
+  return cdf + x * 0.3989422804014327f * e;
 }
 
 // ---- fragments -------------------------------------------------------------------------------------------
@@ -99,10 +128,17 @@ __device__ __forceinline__ void frag_zero(Frag<bf16_t>& f) {
 #pragma unroll
   for (int j = 0; j < 8; ++j) f.v[j] = 0;
 }
-template <typename CT> __device__ __forceinline__ Frag<CT> frag_from_f32(const float x[8]) {
-  Frag<CT> f;
+template <typename CT> __device__ __forceinline__ Frag<CT> frag_from_f32(const float x[8]);
+template <> __device__ __forceinline__ Frag<float> frag_from_f32<float>(const float x[8]) {
+  Frag<float> f;
 #pragma unroll
-  for (int j = 0; j < 8; ++j) frag_set(f, j, x[j]);
+  for (int j = 0; j < 8; ++j) f.v[j] = x[j];
+  return f;
+}
+template <> __device__ __forceinline__ Frag<bf16_t> frag_from_f32<bf16_t>(const float x[8]) {
+  const uint4 u = make_uint4(pack_bf16x2(x[0], x[1]), pack_bf16x2(x[2], x[3]), pack_bf16x2(x[4], x[5]), pack_bf16x2(x[6], x[7]));
+  Frag<bf16_t> f;
+  f.v = __builtin_bit_cast(s16x8_t, u);
   return f;
 }
 

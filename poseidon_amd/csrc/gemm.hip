@@ -87,12 +87,7 @@ template <> __device__ __forceinline__ void lds_store8<float>(float* p, const fl
   *(float4*)(p + 4) = make_float4(v[4], v[5], v[6], v[7]);
 }
 template <> __device__ __forceinline__ void lds_store8<bf16_t>(bf16_t* p, const float v[8]) {
-  uint4 u;
-  u.x = (uint32_t)f2bf(v[0]) | ((uint32_t)f2bf(v[1]) << 16);
-  u.y = (uint32_t)f2bf(v[2]) | ((uint32_t)f2bf(v[3]) << 16);
-  u.z = (uint32_t)f2bf(v[4]) | ((uint32_t)f2bf(v[5]) << 16);
-  u.w = (uint32_t)f2bf(v[6]) | ((uint32_t)f2bf(v[7]) << 16);
-  *(uint4*)p = u;
+  *(uint4*)p = make_uint4(pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]), pack_bf16x2(v[4], v[5]), pack_bf16x2(v[6], v[7]));
 }
 
 template <typename CT, int R, bool KC>
@@ -205,14 +200,15 @@ static int launch_layout(const GemmArgs& a, int layout, int nsplit, hipStream_t 
 
 template <typename CT>
 static int launch_tile(const GemmArgs& a, int layout, int nsplit, hipStream_t s) {
-  // tile choice: fill the 256 CUs; BN=96 for the many N = 96·k shapes of Poseidon-B stage 0.
-  const long t128 = (long)((a.M + 127) / 128) * ((a.N + 127) / 128) * nsplit;
-  if (a.N % 96 == 0 && a.N % 128 != 0 && a.M >= 128) return launch_layout<CT, 128, 96>(a, layout, nsplit, s);
-  if (t128 >= 256 || (a.M >= 4096 && a.N >= 128)) return launch_layout<CT, 128, 128>(a, layout, nsplit, s);
-  return launch_layout<CT, 64, 64>(a, layout, nsplit, s);
+  return launch_layout<CT, 64, 64>(a, layout, nsplit, s);  // generic fallback: one tile shape (the fast path has the rest)
 }
 
 extern int g_scot_use_tr;
+int scot_gemm_fast(int layout, int compute, int M, int N, int K, const void* A, int a_dt, int lda, int a_gelu,
+                   const void* B, int b_dt, int ldb, int b_gelu, void* C, int c_dt, int ldc, const float* bias,
+                   const float* colscale, const void* aux, int aux_dt, int ldaux, const void* resid, int res_dt, int ldres,
+                   int accumulate, float* colsum_out, void* workspace, size_t ws_bytes, hipStream_t stream);
+extern "C" int scot_colsum(const void* x, int x_dt, const void* y, int y_dt, float* out, int M, int N, int ld, hipStream_t s);
 
 extern "C" int scot_gemm(int layout, int compute, int M, int N, int K,
                          const void* A, int a_dt, int lda, int a_gelu,
@@ -221,10 +217,15 @@ extern "C" int scot_gemm(int layout, int compute, int M, int N, int K,
                          const float* bias, const float* colscale,
                          const void* aux, int aux_dt, int ldaux,
                          const void* resid, int res_dt, int ldres,
-                         int accumulate, hipStream_t stream) {
+                         int accumulate, float* colsum_out, void* workspace, size_t ws_bytes, hipStream_t stream) {
   if (M <= 0 || N <= 0 || K <= 0) return SCOT_ERR_SHAPE;
   if (layout < 0 || layout > 2) return SCOT_ERR_UNSUPPORTED;
   if ((a_dt | b_dt | c_dt) & ~1) return SCOT_ERR_DTYPE;
+  {
+    const int rc = scot_gemm_fast(layout, compute, M, N, K, A, a_dt, lda, a_gelu, B, b_dt, ldb, b_gelu, C, c_dt, ldc, bias, colscale,
+                                  aux, aux_dt, ldaux, resid, res_dt, ldres, accumulate, colsum_out, workspace, ws_bytes, stream);
+    if (rc != SCOT_ERR_UNSUPPORTED) return rc;
+  }
   GemmArgs a;
   a.A = A; a.B = B; a.C = C; a.bias = bias; a.colscale = colscale; a.aux = aux; a.resid = resid;
   a.M = M; a.N = N; a.K = K; a.lda = lda; a.ldb = ldb; a.ldc = ldc; a.ldaux = ldaux; a.ldres = ldres;
@@ -253,6 +254,10 @@ extern "C" int scot_gemm(int layout, int compute, int M, int N, int K,
     if (resid != nullptr) return SCOT_ERR_UNSUPPORTED;
     a.resid = C; a.res_dt = c_dt; a.ldres = ldc;
   }
-  return compute == SCOT_BF16 ? launch_tile<bf16_t>(a, layout, nsplit, stream)
-                              : launch_tile<float>(a, layout, nsplit, stream);
+  int rc = compute == SCOT_BF16 ? launch_tile<bf16_t>(a, layout, nsplit, stream) : launch_tile<float>(a, layout, nsplit, stream);
+  if (rc == SCOT_OK && colsum_out) {
+    if (layout == LAYOUT_TN) rc = scot_colsum(A, a_dt, nullptr, 0, colsum_out, K, M, lda, stream);  // Σ_k A[k][m]
+    else rc = scot_colsum(C, c_dt, nullptr, 0, colsum_out, M, N, ldc, stream);
+  }
+  return rc;
 }

@@ -1,0 +1,383 @@
+// gemm_fast — the production GEMM of the scOT hot path (operands already in the compute type, 16-byte aligned).
+//
+// Same three layouts and the same fragment conventions as gemm.hip (the generic fallback for odd shapes / mixed
+// dtypes), restructured after the round-1 rocprof trace showed the generic kernel latency-bound (one dependent
+// HBM round trip per staged chunk, 2-byte scattered stores):
+//   * branch-free staging: every thread issues all of its 16-byte loads for a K-tile back to back (addresses are
+//     clamped instead of guarded; only the K tail is zeroed) into registers, two tiles ahead of the MFMAs;
+//   * LDS double buffering, one barrier per K-tile (BK = 64 bf16 / 32 f32);
+//   * the accumulator tile goes through LDS so that the fused epilogue (bias, column scale, gelu'(aux), residual,
+//     column sums for bias gradients) reads and writes 16/32-byte row segments — fully coalesced;
+//   * wgrad (TN): split-K with fp32 atomics, and the bias gradient (column sums of dY) comes for free from the
+//     dY tile that is already in LDS.
+#include "common.h"
+#include <stdlib.h>
+
+#define LAYOUT_NT 0
+#define LAYOUT_NN 1
+#define LAYOUT_TN 2
+
+struct FastArgs {
+  const void* A; const void* B; void* C;
+  const float* bias; const float* colscale; const void* aux; const void* resid;
+  float* colsum_out;   // NT/NN: += column sums of the stored result;  TN: += column sums of A (=dY) over K
+  int M, N, K;
+  int lda, ldb, ldc, ldaux, ldres;
+  int c_dt, aux_dt, res_dt;
+  int a_gelu, b_gelu, aux_gelu_grad, atomic;
+  int ksplit;
+  int use_tr;
+  float* ws;       // TN split-K: partial tiles ws[z][M][N] (fp32), reduced by splitk_reduce_kernel
+  int rmw;         // TN, single split: C += acc by the unique owner (no atomics)
+};
+
+template <typename CT> struct FT;
+template <> struct FT<bf16_t> { static constexpr int BK = 64, EPC = 8, KPAD = 8, RPAD = 8; };
+template <> struct FT<float> { static constexpr int BK = 32, EPC = 4, KPAD = 4, RPAD = 4; };
+
+template <typename CT, int R, bool KC> struct FTile {
+  static constexpr int BK = FT<CT>::BK, EPC = FT<CT>::EPC;
+  static constexpr int pitch = KC ? (BK + FT<CT>::KPAD) : (R + FT<CT>::RPAD);
+  static constexpr int elems = KC ? R * pitch : BK * pitch;
+  static constexpr int nchunks = R * BK / EPC;      // 16-byte chunks per tile
+  static constexpr int per_thread = nchunks / 256;
+  static_assert(nchunks % 256 == 0, "tile must split evenly over 256 threads");
+};
+
+// issue this thread's loads for K-tile starting at k0 (raw 16-byte chunks, no waits, no branches)
+template <typename CT, int R, bool KC, int NCH>
+__device__ __forceinline__ void fload(uint4 (&st)[NCH], const CT* __restrict__ src, int ld, int row0,
+                                      int rmax, int k0, int kend, int tid) {
+  using T = FTile<CT, R, KC>;
+  constexpr int EPC = T::EPC, BK = T::BK;
+#pragma unroll
+  for (int i = 0; i < T::per_thread; ++i) {
+    const int c = tid + i * 256;
+    size_t idx;
+    if (KC) {
+      constexpr int CPR = BK / EPC;
+      const int row = min(row0 + c / CPR, rmax - 1);
+      const int k = min(k0 + (c % CPR) * EPC, kend - EPC);
+      idx = (size_t)row * ld + k;
+    } else {
+      constexpr int CPR = R / EPC;
+      const int k = min(k0 + c / CPR, kend - 1);
+      const int r = min(row0 + (c % CPR) * EPC, rmax - EPC);
+      idx = (size_t)k * ld + r;
+    }
+    st[i] = *(const uint4*)(src + idx);
+  }
+}
+
+__device__ __forceinline__ uint4 gelu_chunk(uint4 u, bf16_t) {
+  uint32_t w[4] = {u.x, u.y, u.z, u.w};
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const float lo = gelu_f(__uint_as_float(w[j] << 16)), hi = gelu_f(__uint_as_float(w[j] & 0xffff0000u));
+    w[j] = pack_bf16x2(lo, hi);
+  }
+  return make_uint4(w[0], w[1], w[2], w[3]);
+}
+__device__ __forceinline__ uint4 gelu_chunk(uint4 u, float) {
+  return make_uint4(__float_as_uint(gelu_f(__uint_as_float(u.x))), __float_as_uint(gelu_f(__uint_as_float(u.y))),
+                    __float_as_uint(gelu_f(__uint_as_float(u.z))), __float_as_uint(gelu_f(__uint_as_float(u.w))));
+}
+
+template <typename CT, int R, bool KC, int NCH>
+__device__ __forceinline__ void fstore(CT* tile, const uint4 (&st)[NCH], int k0, int kend, int tid, bool gelu) {
+  using T = FTile<CT, R, KC>;
+  constexpr int EPC = T::EPC, BK = T::BK;
+#pragma unroll
+  for (int i = 0; i < T::per_thread; ++i) {
+    const int c = tid + i * 256;
+    uint4 v = st[i];
+    int off, k;
+    if (KC) {
+      constexpr int CPR = BK / EPC;
+      k = k0 + (c % CPR) * EPC;
+      off = (c / CPR) * T::pitch + (c % CPR) * EPC;
+    } else {
+      constexpr int CPR = R / EPC;
+      k = k0 + c / CPR;
+      off = (c / CPR) * T::pitch + (c % CPR) * EPC;
+    }
+    if (gelu) v = gelu_chunk(v, CT());
+    if (k >= kend) v = make_uint4(0, 0, 0, 0);   // K tail (K is a multiple of EPC in this kernel)
+    *(uint4*)(tile + off) = v;
+  }
+}
+
+template <typename CT, int BM, int BN, int LAYOUT>
+__global__ __launch_bounds__(256) void gemm_fast_kernel(FastArgs p) {
+  constexpr bool A_KC = (LAYOUT != LAYOUT_TN);
+  constexpr bool B_KC = (LAYOUT == LAYOUT_NT);
+  using TA = FTile<CT, BM, A_KC>;
+  using TB = FTile<CT, BN, B_KC>;
+  constexpr int BK = FT<CT>::BK;
+  constexpr int MI = BM / 32, NI = BN / 32;
+  constexpr int STAGE = TA::elems + TB::elems;
+  constexpr int CP = BN + 4;                                  // C tile pitch (floats)
+  constexpr size_t LDS_AB = 2 * STAGE * sizeof(CT), LDS_C = (size_t)BM * CP * sizeof(float) + BN * sizeof(float);
+  constexpr size_t LDS_BYTES = LDS_AB > LDS_C ? LDS_AB : LDS_C;
+  __shared__ __attribute__((aligned(16))) char smem[LDS_BYTES];
+  CT* lds = (CT*)smem;
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wr = wave >> 1, wc = wave & 1, g = lane >> 4;
+  const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
+  const int kbeg = blockIdx.z * p.ksplit;
+  const int kend = min(p.K, kbeg + p.ksplit);
+  const int nk = (kend - kbeg + BK - 1) / BK;
+  const CT* A = (const CT*)p.A;
+  const CT* B = (const CT*)p.B;
+
+  f32x4_t acc[MI][NI];
+#pragma unroll
+  for (int i = 0; i < MI; ++i)
+#pragma unroll
+    for (int j = 0; j < NI; ++j) acc[i][j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+  float bsum = 0.f;  // TN bias-grad partial (thread tid < BM owns column m0+tid of dY)
+
+  // Two register sets: the loads of K-tile t+2 are issued at the TOP of iteration t and consumed (written to LDS) at the
+  // END of iteration t+1, i.e. they have two MFMA phases and a barrier to land.
+  uint4 ra0[TA::per_thread], rb0[TB::per_thread], ra1[TA::per_thread], rb1[TB::per_thread];
+  fload<CT, BM, A_KC>(ra0, A, p.lda, m0, p.M, kbeg, kend, tid);
+  fload<CT, BN, B_KC>(rb0, B, p.ldb, n0, p.N, kbeg, kend, tid);
+  if (nk > 1) {
+    fload<CT, BM, A_KC>(ra1, A, p.lda, m0, p.M, kbeg + BK, kend, tid);
+    fload<CT, BN, B_KC>(rb1, B, p.ldb, n0, p.N, kbeg + BK, kend, tid);
+  }
+  fstore<CT, BM, A_KC>(lds, ra0, kbeg, kend, tid, p.a_gelu != 0);
+  fstore<CT, BN, B_KC>(lds + TA::elems, rb0, kbeg, kend, tid, p.b_gelu != 0);
+  __syncthreads();
+
+  auto compute = [&](const CT* As, const CT* Bs) {
+#pragma unroll
+    for (int kk = 0; kk < BK; kk += 32) {
+      Frag<CT> fa[MI], fb[NI];
+#pragma unroll
+      for (int i = 0; i < MI; ++i) {
+        const int r0 = wr * (BM / 2) + i * 16;
+        if (A_KC) fa[i] = lds_frag_kc(As, TA::pitch, r0, kk, lane);
+        else fa[i] = lds_frag_ks(As, TA::pitch, r0, kk + g * 8, kk + g * 8 + 4, lane, p.use_tr);
+      }
+#pragma unroll
+      for (int j = 0; j < NI; ++j) {
+        const int c0 = wc * (BN / 2) + j * 16;
+        if (B_KC) fb[j] = lds_frag_kc(Bs, TB::pitch, c0, kk, lane);
+        else fb[j] = lds_frag_ks(Bs, TB::pitch, c0, kk + g * 8, kk + g * 8 + 4, lane, p.use_tr);
+      }
+#pragma unroll
+      for (int i = 0; i < MI; ++i)
+#pragma unroll
+        for (int j = 0; j < NI; ++j) mma16(acc[i][j], fa[i], fb[j]);
+    }
+    if (LAYOUT == LAYOUT_TN && p.colsum_out && blockIdx.x == 0 && tid < BM) {
+#pragma unroll 8
+      for (int k = 0; k < BK; ++k) bsum += from_ct(As[k * TA::pitch + tid]);
+    }
+  };
+
+  for (int t = 0; t < nk; t += 2) {
+    // even phase: tile t is in buffer 0, set 1 holds tile t+1 (in flight)
+    if (t + 2 < nk) {
+      fload<CT, BM, A_KC>(ra0, A, p.lda, m0, p.M, kbeg + (t + 2) * BK, kend, tid);
+      fload<CT, BN, B_KC>(rb0, B, p.ldb, n0, p.N, kbeg + (t + 2) * BK, kend, tid);
+    }
+    compute(lds, lds + TA::elems);
+    if (t + 1 < nk) {
+      fstore<CT, BM, A_KC>(lds + STAGE, ra1, kbeg + (t + 1) * BK, kend, tid, p.a_gelu != 0);
+      fstore<CT, BN, B_KC>(lds + STAGE + TA::elems, rb1, kbeg + (t + 1) * BK, kend, tid, p.b_gelu != 0);
+    }
+    __syncthreads();
+    if (t + 1 >= nk) break;
+    // odd phase: tile t+1 is in buffer 1, set 0 holds tile t+2
+    if (t + 3 < nk) {
+      fload<CT, BM, A_KC>(ra1, A, p.lda, m0, p.M, kbeg + (t + 3) * BK, kend, tid);
+      fload<CT, BN, B_KC>(rb1, B, p.ldb, n0, p.N, kbeg + (t + 3) * BK, kend, tid);
+    }
+    compute(lds + STAGE, lds + STAGE + TA::elems);
+    if (t + 2 < nk) {
+      fstore<CT, BM, A_KC>(lds, ra0, kbeg + (t + 2) * BK, kend, tid, p.a_gelu != 0);
+      fstore<CT, BN, B_KC>(lds + TA::elems, rb0, kbeg + (t + 2) * BK, kend, tid, p.b_gelu != 0);
+    }
+    __syncthreads();
+  }
+
+  if (LAYOUT == LAYOUT_TN && p.colsum_out && blockIdx.x == 0 && tid < BM && m0 + tid < p.M) atomicAdd(&p.colsum_out[m0 + tid], bsum);
+
+  // ---- epilogue through LDS
+  float* Cs = (float*)smem;
+  float* colacc = Cs + BM * CP;
+#pragma unroll
+  for (int i = 0; i < MI; ++i)
+#pragma unroll
+    for (int j = 0; j < NI; ++j)
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+        Cs[(wr * (BM / 2) + i * 16 + g * 4 + r) * CP + wc * (BN / 2) + j * 16 + (lane & 15)] = acc[i][j][r];
+  const bool want_colsum = (LAYOUT != LAYOUT_TN) && p.colsum_out != nullptr;
+  if (want_colsum && tid < BN) colacc[tid] = 0.f;
+  __syncthreads();
+
+  constexpr int CPRW = BN / 8;  // 8-column chunks per tile row
+  const int cc = tid % CPRW;    // constant per thread because 256 % CPRW == 0
+  const int col = n0 + cc * 8;
+  float csum[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  float bv[8], sv[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    const bool ok = col + j < p.N;
+    bv[j] = (p.bias && ok && blockIdx.z == 0) ? p.bias[col + j] : 0.f;
+    sv[j] = (p.colscale && ok) ? p.colscale[col + j] : 1.f;
+  }
+  if (col < p.N) {
+    for (int row = tid / CPRW; row < BM; row += 256 / CPRW) {
+      const int grow = m0 + row;
+      if (grow >= p.M) break;
+      float v[8];
+      const float4 a = *(const float4*)(Cs + row * CP + cc * 8), b = *(const float4*)(Cs + row * CP + cc * 8 + 4);
+      v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) v[j] = (v[j] + bv[j]) * sv[j];
+      if (p.aux_gelu_grad) {
+        float x[8];
+        ld8(p.aux, p.aux_dt, (size_t)grow * p.ldaux + col, x);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] *= gelu_grad_f(x[j]);
+      }
+      if (p.resid) {
+        float x[8];
+        ld8(p.resid, p.res_dt, (size_t)grow * p.ldres + col, x);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] += x[j];
+      }
+      const size_t ci = (size_t)grow * p.ldc + col;
+      if (LAYOUT == LAYOUT_TN) {
+        if (p.ws) {            // split-K partial tile (dense [M][N], 32-byte aligned rows since N % 8 == 0)
+          st8(p.ws + (size_t)blockIdx.z * p.M * p.N, SCOT_F32, (size_t)grow * p.N + col, v);
+        } else if (p.rmw) {    // single split: this workgroup is the only writer of the tile
+          float o[8];
+          ld8(p.C, SCOT_F32, ci, o);
+#pragma unroll
+          for (int j = 0; j < 8; ++j) o[j] += v[j];
+          st8(p.C, SCOT_F32, ci, o);
+        } else {
+#pragma unroll
+          for (int j = 0; j < 8; ++j) atomicAdd((float*)p.C + ci + j, v[j]);
+        }
+      } else {
+        st8(p.C, p.c_dt, ci, v);
+      }
+      if (want_colsum) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) csum[j] += v[j];
+      }
+    }
+    if (want_colsum) {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) atomicAdd(&colacc[cc * 8 + j], csum[j]);
+    }
+  }
+  if (want_colsum) {
+    __syncthreads();
+    if (tid < BN && n0 + tid < p.N) atomicAdd(&p.colsum_out[n0 + tid], colacc[tid]);
+  }
+}
+
+// C[m][n] += Σ_z ws[z][m][n]
+__global__ void splitk_reduce_kernel(const float* __restrict__ ws, float* C, int M, int N, int ldc, int nsplit) {
+  const size_t n8 = (size_t)M * N / 8;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n8; i += (size_t)gridDim.x * blockDim.x) {
+    const size_t e = i * 8;
+    const int m = e / N, n = e % N;
+    float acc[8], v[8];
+    ld8(C, SCOT_F32, (size_t)m * ldc + n, acc);
+    for (int z = 0; z < nsplit; ++z) {
+      ld8(ws + (size_t)z * M * N, SCOT_F32, e, v);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) acc[j] += v[j];
+    }
+    st8(C, SCOT_F32, (size_t)m * ldc + n, acc);
+  }
+}
+
+template <typename CT, int BM, int BN>
+static int flaunch_layout(const FastArgs& a, int layout, int nsplit, hipStream_t s) {
+  dim3 grid((a.N + BN - 1) / BN, (a.M + BM - 1) / BM, nsplit), block(256);
+  switch (layout) {
+    case LAYOUT_NT: hipLaunchKernelGGL((gemm_fast_kernel<CT, BM, BN, LAYOUT_NT>), grid, block, 0, s, a); break;
+    case LAYOUT_NN: hipLaunchKernelGGL((gemm_fast_kernel<CT, BM, BN, LAYOUT_NN>), grid, block, 0, s, a); break;
+    case LAYOUT_TN: hipLaunchKernelGGL((gemm_fast_kernel<CT, BM, BN, LAYOUT_TN>), grid, block, 0, s, a); break;
+    default: return SCOT_ERR_UNSUPPORTED;
+  }
+  return scot_check_launch();
+}
+
+extern int g_scot_use_tr;
+
+// Returns SCOT_ERR_UNSUPPORTED when the call does not qualify (the caller then uses the generic kernel).
+static int g_tile_override = -1;  // SCOT_GEMM_TILE=64|128 (experiments)
+
+int scot_gemm_fast(int layout, int compute, int M, int N, int K, const void* A, int a_dt, int lda, int a_gelu,
+                   const void* B, int b_dt, int ldb, int b_gelu, void* C, int c_dt, int ldc, const float* bias,
+                   const float* colscale, const void* aux, int aux_dt, int ldaux, const void* resid, int res_dt, int ldres,
+                   int accumulate, float* colsum_out, void* workspace, size_t ws_bytes, hipStream_t stream) {
+  if (g_tile_override < 0) { const char* e = getenv("SCOT_GEMM_TILE"); g_tile_override = e ? atoi(e) : 0; }
+  const int want = compute == SCOT_BF16 ? SCOT_BF16 : SCOT_F32;
+  const int epc = compute == SCOT_BF16 ? 8 : 4;
+  if (a_dt != want || b_dt != want) return SCOT_ERR_UNSUPPORTED;
+  if ((((uintptr_t)A | (uintptr_t)B | (uintptr_t)C | (uintptr_t)aux | (uintptr_t)resid) & 15) != 0) return SCOT_ERR_UNSUPPORTED;
+  if (lda % epc || ldb % epc || ldc % 8 || (aux && ldaux % 8) || (resid && ldres % 8) || N % 8 || K % epc) return SCOT_ERR_UNSUPPORTED;
+  if (layout == LAYOUT_TN ? (M % epc || M < epc) : false) return SCOT_ERR_UNSUPPORTED;
+  if (layout != LAYOUT_NT && N < epc) return SCOT_ERR_UNSUPPORTED;
+  if (K < epc || M < 1) return SCOT_ERR_UNSUPPORTED;
+  FastArgs a;
+  a.A = A; a.B = B; a.C = C; a.bias = bias; a.colscale = colscale; a.aux = aux; a.resid = resid; a.colsum_out = colsum_out;
+  a.M = M; a.N = N; a.K = K; a.lda = lda; a.ldb = ldb; a.ldc = ldc; a.ldaux = ldaux; a.ldres = ldres;
+  a.c_dt = c_dt; a.aux_dt = aux_dt; a.res_dt = res_dt; a.a_gelu = a_gelu; a.b_gelu = b_gelu; a.aux_gelu_grad = aux != nullptr;
+  a.use_tr = g_scot_use_tr; a.atomic = 0; a.ws = nullptr; a.rmw = 0;
+  const int bk = compute == SCOT_BF16 ? 64 : 32;
+  int nsplit = 1;
+  a.ksplit = ((K + bk - 1) / bk) * bk;
+  bool big;
+  if (layout == LAYOUT_TN) {
+    // wgrad: small output, contraction over all tokens.  Split K so that ~512 workgroups stream the operands; each split
+    // writes a partial tile into the workspace and ONE reduce pass adds them into the gradient (12.6 M fp32 atomics per
+    // call in the first version of this kernel cost 300 us; the partials cost < 20 MB of traffic).
+    if (c_dt != SCOT_F32 || !accumulate) return SCOT_ERR_UNSUPPORTED;
+    const long t128 = (long)((M + 127) / 128) * ((N + 127) / 128);
+    big = g_tile_override == 128 && M >= 128 && N >= 64;   // measured: the 64x64 tile (4 workgroups/CU) wins every scOT shape
+    const long tiles = big ? t128 : (long)((M + 63) / 64) * ((N + 63) / 64);
+    long wantsplit = (512 + tiles - 1) / tiles;
+    const long maxsplit = (K + 8 * bk - 1) / (8 * bk);       // >= 8 K-tiles per workgroup
+    long wsmax = workspace ? (long)(ws_bytes / ((size_t)M * N * sizeof(float))) : 1;
+    nsplit = (int)(wantsplit < 1 ? 1 : (wantsplit > maxsplit ? maxsplit : wantsplit));
+    if (nsplit > wsmax) nsplit = (int)(wsmax < 1 ? 1 : wsmax);
+    int per = (K + nsplit - 1) / nsplit;
+    per = ((per + bk - 1) / bk) * bk;
+    a.ksplit = per;
+    nsplit = (K + per - 1) / per;
+    if (nsplit == 1) a.rmw = 1;
+    else if (workspace && (((uintptr_t)workspace & 31) == 0)) a.ws = (float*)workspace;
+    else a.atomic = 1;
+  } else {
+    if (accumulate) {
+      if (resid != nullptr) return SCOT_ERR_UNSUPPORTED;
+      a.resid = C; a.res_dt = c_dt; a.ldres = ldc;
+    }
+    const long t128 = (long)((M + 127) / 128) * ((N + 127) / 128);
+    big = g_tile_override == 128 && t128 >= 192 && M >= 128 && N >= 64;   // see above
+  }
+  int rc;
+  if (compute == SCOT_BF16) rc = big ? flaunch_layout<bf16_t, 128, 128>(a, layout, nsplit, stream)
+                                     : flaunch_layout<bf16_t, 64, 64>(a, layout, nsplit, stream);
+  else rc = big ? flaunch_layout<float, 128, 128>(a, layout, nsplit, stream) : flaunch_layout<float, 64, 64>(a, layout, nsplit, stream);
+  if (rc == SCOT_OK && a.ws) {
+    const size_t n8 = (size_t)M * N / 8;
+    size_t blocks = (n8 + 255) / 256; if (blocks > 2048) blocks = 2048;
+    hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, a.ws, (float*)C, M, N, ldc, nsplit);
+    rc = scot_check_launch();
+  }
+  return rc;
+}

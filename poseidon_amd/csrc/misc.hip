@@ -240,12 +240,110 @@ __global__ void dwconv7_kernel(const void* x, int x_dt, const float* w, const fl
     st1(y, y_dt, i, acc);
   }
 }
+// ---- LDS-tiled versions (round-1 rocprof: the direct kernels above re-read every input 49x through L1/L2: 322 us fwd /
+// 746 us wgrad at stage 0).  Workgroup = 8x8 output pixels x 32 channels; the 14x14x32 haloed input tile is staged once in LDS
+// (channel-contiguous: every LDS access is conflict-free and every HBM access is a full 128-byte line); each thread produces
+// a row of 8 outputs for one channel with its 49 weights in registers.
+constexpr int DW_T = 8, DW_H = DW_T + 6, DW_C = 32;
+__global__ __launch_bounds__(256) void dwconv7_tiled_kernel(const void* x, int x_dt, const float* w, const float* bias, void* y, int y_dt,
+                                                            int B, int H, int W, int C, int flip, int tiles_x) {
+  __shared__ float tile[DW_H * DW_H * DW_C];
+  const int c = blockIdx.y * DW_C + (threadIdx.x & 31), ty = threadIdx.x >> 5, b = blockIdx.z;
+  const int y0 = (blockIdx.x / tiles_x) * DW_T, x0 = (blockIdx.x % tiles_x) * DW_T;
+  const bool cv = c < C;
+  for (int p = ty; p < DW_H * DW_H; p += 8) {
+    const int sy = y0 + p / DW_H - 3, sx = x0 + p % DW_H - 3;
+    float v = 0.f;
+    if (cv && sy >= 0 && sy < H && sx >= 0 && sx < W) v = ld1(x, x_dt, (((size_t)b * H + sy) * W + sx) * C + c);
+    tile[p * DW_C + (threadIdx.x & 31)] = v;
+  }
+  float wr[49];
+#pragma unroll
+  for (int k = 0; k < 49; ++k) wr[k] = cv ? w[(size_t)c * 49 + (flip ? 48 - k : k)] : 0.f;
+  __syncthreads();
+  float acc[DW_T];
+  const float bv = (bias && cv) ? bias[c] : 0.f;
+#pragma unroll
+  for (int i = 0; i < DW_T; ++i) acc[i] = bv;
+#pragma unroll
+  for (int ki = 0; ki < 7; ++ki) {
+    float in[DW_H];
+#pragma unroll
+    for (int i = 0; i < DW_H; ++i) in[i] = tile[((ty + ki) * DW_H + i) * DW_C + (threadIdx.x & 31)];
+#pragma unroll
+    for (int kj = 0; kj < 7; ++kj)
+#pragma unroll
+      for (int i = 0; i < DW_T; ++i) acc[i] += wr[ki * 7 + kj] * in[i + kj];
+  }
+  const int oy = y0 + ty;
+  if (cv && oy < H) {
+#pragma unroll
+    for (int i = 0; i < DW_T; ++i)
+      if (x0 + i < W) st1(y, y_dt, (((size_t)b * H + oy) * W + x0 + i) * C + c, acc[i]);
+  }
+}
+// weight/bias gradient: workgroup = (32 channels, one sample), loops over the sample's 8x8 tiles; thread (c, j) owns tap row
+// ki = j (j < 7: 7 accumulators) or the bias sum (j == 7); one atomicAdd per accumulator per workgroup.
+__global__ __launch_bounds__(256) void dwconv7_wgrad_tiled_kernel(const void* dy, int dy_dt, const void* x, int x_dt, float* dw, float* db,
+                                                                  int B, int H, int W, int C) {
+  __shared__ float tx[DW_H * DW_H * DW_C];
+  __shared__ float tg[DW_T * DW_T * DW_C];
+  const int lc = threadIdx.x & 31, j = threadIdx.x >> 5;
+  const int c = blockIdx.x * DW_C + lc, b = blockIdx.y;
+  const bool cv = c < C;
+  const int tiles_x = (W + DW_T - 1) / DW_T, tiles_y = (H + DW_T - 1) / DW_T;
+  float acc[7] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  float bsum = 0.f;
+  for (int t = 0; t < tiles_x * tiles_y; ++t) {
+    const int y0 = (t / tiles_x) * DW_T, x0 = (t % tiles_x) * DW_T;
+    __syncthreads();
+    for (int p = j; p < DW_H * DW_H; p += 8) {
+      const int sy = y0 + p / DW_H - 3, sx = x0 + p % DW_H - 3;
+      float v = 0.f;
+      if (cv && sy >= 0 && sy < H && sx >= 0 && sx < W) v = ld1(x, x_dt, (((size_t)b * H + sy) * W + sx) * C + c);
+      tx[p * DW_C + lc] = v;
+    }
+    for (int p = j; p < DW_T * DW_T; p += 8) {
+      const int sy = y0 + p / DW_T, sx = x0 + p % DW_T;
+      float v = 0.f;
+      if (cv && sy < H && sx < W) v = ld1(dy, dy_dt, (((size_t)b * H + sy) * W + sx) * C + c);
+      tg[p * DW_C + lc] = v;
+    }
+    __syncthreads();
+    if (j < 7) {
+#pragma unroll
+      for (int oy = 0; oy < DW_T; ++oy) {
+        float in[DW_H], g[DW_T];
+#pragma unroll
+        for (int i = 0; i < DW_H; ++i) in[i] = tx[((oy + j) * DW_H + i) * DW_C + lc];
+#pragma unroll
+        for (int i = 0; i < DW_T; ++i) g[i] = tg[(oy * DW_T + i) * DW_C + lc];
+#pragma unroll
+        for (int kj = 0; kj < 7; ++kj)
+#pragma unroll
+          for (int i = 0; i < DW_T; ++i) acc[kj] += g[i] * in[i + kj];
+      }
+    } else {
+#pragma unroll 8
+      for (int p = 0; p < DW_T * DW_T; ++p) bsum += tg[p * DW_C + lc];
+    }
+  }
+  if (cv) {
+    if (j < 7) {
+#pragma unroll
+      for (int kj = 0; kj < 7; ++kj) atomicAdd(&dw[(size_t)c * 49 + j * 7 + kj], acc[kj]);
+    } else {
+      atomicAdd(&db[c], bsum);
+    }
+  }
+}
 extern "C" int scot_dwconv7(const void* x, int x_dt, const float* w, const float* bias, void* y, int y_dt, int B, int H, int W,
                             int C, int flip, hipStream_t s) {
   const size_t n = (size_t)B * H * W * C;
   if (n == 0) return SCOT_ERR_SHAPE;
-  size_t blocks = (n + 255) / 256; if (blocks > 32768) blocks = 32768;
-  hipLaunchKernelGGL(dwconv7_kernel, dim3((unsigned)blocks), dim3(256), 0, s, x, x_dt, w, bias, y, y_dt, B, H, W, C, flip);
+  const int tx = (W + DW_T - 1) / DW_T, ty = (H + DW_T - 1) / DW_T;
+  hipLaunchKernelGGL(dwconv7_tiled_kernel, dim3(tx * ty, (C + DW_C - 1) / DW_C, B), dim3(256), 0, s, x, x_dt, w, bias, y, y_dt, B, H, W,
+                     C, flip, tx);
   return scot_check_launch();
 }
 // weight/bias grad: dw[c][ki][kj] += Σ dy[b,y,x,c]·x[b,y+ki-3,x+kj-3,c];  db[c] += Σ dy.   thread = channel, block = 64
@@ -290,9 +388,7 @@ __global__ __launch_bounds__(256) void dwconv7_wgrad_kernel(const void* dy, int 
 extern "C" int scot_dwconv7_wgrad(const void* dy, int dy_dt, const void* x, int x_dt, float* dw, float* db, int B, int H, int W,
                                   int C, hipStream_t s) {
   if (B <= 0 || H <= 0 || W <= 0 || C <= 0) return SCOT_ERR_SHAPE;
-  const int rows = H >= 32 ? 8 : (H >= 8 ? 4 : H);
-  hipLaunchKernelGGL(dwconv7_wgrad_kernel, dim3((C + 63) / 64, (H + rows - 1) / rows, B), dim3(256), 0, s, dy, dy_dt, x, x_dt,
-                     dw, db, B, H, W, C, rows);
+  hipLaunchKernelGGL(dwconv7_wgrad_tiled_kernel, dim3((C + DW_C - 1) / DW_C, B), dim3(256), 0, s, dy, dy_dt, x, x_dt, dw, db, B, H, W, C);
   return scot_check_launch();
 }
 

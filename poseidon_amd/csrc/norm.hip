@@ -128,27 +128,64 @@ __global__ __launch_bounds__(256) void cln_bwd_kernel(ClnArgs p, int rpb, int ch
   }
 }
 
-extern "C" int scot_cln_fwd(const void* x, int x_dt, const void* resid, int res_dt, void* out, int out_dt,
+struct ClnFastArgs {  // must match norm_fast.hip
+  const void* x; const void* resid; void* out; void* out2; float* mean; float* rstd;
+  const float* time; const float* gw_w; const float* gw_b; const float* bw_w; const float* bw_b;
+  int x_dt, res_dt, out_dt, out2_dt;
+  int rows, rows_per_sample, C;
+  float eps;
+  const void* dout; void* dx; int dout_dt, dx_dt;
+  float* d_gw_w; float* d_gw_b; float* d_bw_w; float* d_bw_b; float* d_xbias;
+  int rpb, chunks_per_sample;
+};
+int scot_cln_fwd_fast(ClnFastArgs a, hipStream_t s);
+int scot_cln_bwd_fast(ClnFastArgs a, hipStream_t s);
+extern "C" int scot_colsum(const void* x, int x_dt, const void* y, int y_dt, float* out, int M, int N, int ld, hipStream_t s);
+extern "C" int scot_scale_residual(const void* y, int y_dt, const float* scale, const void* resid, int r_dt, void* out, int o_dt,
+                                   size_t rows, int N, hipStream_t s);
+
+// out2 (optional): second copy of the output in dtype out2_dt (the next GEMM's operand type)
+extern "C" int scot_cln_fwd(const void* x, int x_dt, const void* resid, int res_dt, void* out, int out_dt, void* out2, int out2_dt,
                             float* mean, float* rstd, const float* time, const float* gw_w, const float* gw_b,
                             const float* bw_w, const float* bw_b, int rows, int rows_per_sample, int C, float eps,
                             hipStream_t stream) {
   if (rows <= 0 || C <= 0 || rows_per_sample <= 0 || rows % rows_per_sample) return SCOT_ERR_SHAPE;
   if (!gw_b || !bw_b || (gw_w && !time)) return SCOT_ERR_SHAPE;
+  {
+    ClnFastArgs f{};
+    f.x = x; f.resid = resid; f.out = out; f.out2 = out2; f.mean = mean; f.rstd = rstd; f.time = time;
+    f.gw_w = gw_w; f.gw_b = gw_b; f.bw_w = bw_w; f.bw_b = bw_b; f.x_dt = x_dt; f.res_dt = res_dt; f.out_dt = out_dt; f.out2_dt = out2_dt;
+    f.rows = rows; f.rows_per_sample = rows_per_sample; f.C = C; f.eps = eps;
+    const int rc = scot_cln_fwd_fast(f, stream);
+    if (rc != SCOT_ERR_UNSUPPORTED) return rc;
+  }
   ClnArgs a{};
   a.x = x; a.resid = resid; a.out = out; a.mean = mean; a.rstd = rstd; a.time = time;
   a.gw_w = gw_w; a.gw_b = gw_b; a.bw_w = bw_w; a.bw_b = bw_b; a.x_dt = x_dt; a.res_dt = res_dt; a.out_dt = out_dt;
   a.rows = rows; a.rows_per_sample = rows_per_sample; a.C = C; a.eps = eps;
   a.vec = (C % 8 == 0) && (((uintptr_t)x | (uintptr_t)out | (uintptr_t)resid) & 15) == 0;
   hipLaunchKernelGGL(cln_fwd_kernel, dim3((rows + 3) / 4), dim3(256), 0, stream, a);
-  return scot_check_launch();
+  int rc = scot_check_launch();
+  if (rc == SCOT_OK && out2) rc = scot_scale_residual(out, out_dt, nullptr, nullptr, 0, out2, out2_dt, (size_t)rows, C, stream);
+  return rc;
 }
 
+// d_xbias (optional): += Σ_rows dx  (bias gradient of the Linear that produced x)
 extern "C" int scot_cln_bwd(const void* dout, int dout_dt, const void* x, int x_dt, const float* mean, const float* rstd,
                             const float* time, const float* gw_w, const float* gw_b, void* dx, int dx_dt,
-                            float* d_gw_w, float* d_gw_b, float* d_bw_w, float* d_bw_b, int rows, int rows_per_sample,
-                            int C, hipStream_t stream) {
+                            float* d_gw_w, float* d_gw_b, float* d_bw_w, float* d_bw_b, float* d_xbias, int rows,
+                            int rows_per_sample, int C, hipStream_t stream) {
   if (rows <= 0 || C <= 0 || rows_per_sample <= 0 || rows % rows_per_sample) return SCOT_ERR_SHAPE;
   if (!gw_b || !d_gw_b || !d_bw_b || (gw_w && (!time || !d_gw_w || !d_bw_w))) return SCOT_ERR_SHAPE;
+  {
+    ClnFastArgs f{};
+    f.dout = dout; f.dout_dt = dout_dt; f.x = x; f.x_dt = x_dt; f.mean = (float*)mean; f.rstd = (float*)rstd; f.time = time;
+    f.gw_w = gw_w; f.gw_b = gw_b; f.dx = dx; f.dx_dt = dx_dt;
+    f.d_gw_w = gw_w ? d_gw_w : nullptr; f.d_gw_b = d_gw_b; f.d_bw_w = gw_w ? d_bw_w : nullptr; f.d_bw_b = d_bw_b; f.d_xbias = d_xbias;
+    f.rows = rows; f.rows_per_sample = rows_per_sample; f.C = C;
+    const int rc = scot_cln_bwd_fast(f, stream);
+    if (rc != SCOT_ERR_UNSUPPORTED) return rc;
+  }
   ClnArgs a{};
   a.dout = dout; a.dout_dt = dout_dt; a.x = x; a.x_dt = x_dt; a.mean = (float*)mean; a.rstd = (float*)rstd; a.time = time;
   a.gw_w = gw_w; a.gw_b = gw_b; a.dx = dx; a.dx_dt = dx_dt;
@@ -157,5 +194,7 @@ extern "C" int scot_cln_bwd(const void* dout, int dout_dt, const void* x, int x_
   const int rpb = rows_per_sample < 128 ? rows_per_sample : 128;
   const int cps = (rows_per_sample + rpb - 1) / rpb;
   hipLaunchKernelGGL(cln_bwd_kernel, dim3((rows / rows_per_sample) * cps), dim3(256), 0, stream, a, rpb, cps);
-  return scot_check_launch();
+  int rc = scot_check_launch();
+  if (rc == SCOT_OK && d_xbias) rc = scot_colsum(dx, dx_dt, nullptr, 0, d_xbias, rows, C, C, stream);
+  return rc;
 }

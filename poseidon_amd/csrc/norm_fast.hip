@@ -1,0 +1,204 @@
+// Fast path of the (conditional) layer norm for C % 8 == 0, 16-byte aligned rows (every real scOT shape).
+//
+// One row is owned by LPR = 2^k lanes (LPR*8*CPL >= C): the row lives in registers, is read ONCE from HBM with
+// 16/32-byte loads, statistics are reduced with xor-shuffles inside the LPR-lane group, and the outputs are written
+// with 16/32-byte stores: `out` (fp32 residual stream) and optionally `out2` (a copy in the GEMM operand dtype, so the
+// next GEMM streams half the bytes and needs no conversion — traffic-neutral versus converting in the GEMM loader).
+// Backward additionally produces, from the same pass, the per-column sums needed for
+//   dgamma/dbeta (→ the four cond-LN parameter gradients, reference model.py:147-148) and
+//   Σ_rows dx (→ the bias gradient of the Linear that produced x; saves a separate column-sum pass over dx).
+#include "common.h"
+
+struct ClnFastArgs {
+  const void* x; const void* resid; void* out; void* out2; float* mean; float* rstd;
+  const float* time; const float* gw_w; const float* gw_b; const float* bw_w; const float* bw_b;
+  int x_dt, res_dt, out_dt, out2_dt;
+  int rows, rows_per_sample, C;
+  float eps;
+  const void* dout; void* dx; int dout_dt, dx_dt;
+  float* d_gw_w; float* d_gw_b; float* d_bw_w; float* d_bw_b; float* d_xbias;
+  int rpb, chunks_per_sample;
+};
+
+template <int LPR> __device__ __forceinline__ float group_sum(float v) {
+#pragma unroll
+  for (int o = 1; o < LPR; o <<= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+
+template <int LPR, int CPL>
+__global__ __launch_bounds__(256) void cln_fwd_fast_kernel(ClnFastArgs p) {
+  constexpr int RPW = 64 / LPR;  // rows per wave
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int sub = lane / LPR, l = lane % LPR;
+  const int row = (blockIdx.x * 4 + wave) * RPW + sub;
+  const bool rvalid = row < p.rows;
+  const int C = p.C;
+  const size_t base = (size_t)(rvalid ? row : 0) * C;
+  float v[CPL][8];
+  float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+  for (int i = 0; i < CPL; ++i) {
+    const int c = (l + i * LPR) * 8;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) v[i][j] = 0.f;
+    if (c < C) ld8(p.x, p.x_dt, base + c, v[i]);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { s1 += v[i][j]; s2 += v[i][j] * v[i][j]; }
+  }
+  s1 = group_sum<LPR>(s1); s2 = group_sum<LPR>(s2);
+  const float mean = s1 / C;
+  const float rstd = 1.0f / sqrtf(s2 / C - mean * mean + p.eps);
+  if (!rvalid) return;
+  if (l == 0 && p.mean) { p.mean[row] = mean; p.rstd[row] = rstd; }
+  const float t = p.time ? p.time[row / p.rows_per_sample] : 0.f;
+#pragma unroll
+  for (int i = 0; i < CPL; ++i) {
+    const int c = (l + i * LPR) * 8;
+    if (c < C) {
+      float gw[8], gb[8], bw[8], bb[8], r[8], o[8];
+      ld8(p.gw_b, SCOT_F32, c, gb); ld8(p.bw_b, SCOT_F32, c, bb);
+      if (p.gw_w) { ld8(p.gw_w, SCOT_F32, c, gw); ld8(p.bw_w, SCOT_F32, c, bw); }
+      if (p.resid) ld8(p.resid, p.res_dt, base + c, r);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const float g = p.gw_w ? gw[j] * t + gb[j] : gb[j];
+        const float b = p.gw_w ? bw[j] * t + bb[j] : bb[j];
+        o[j] = g * ((v[i][j] - mean) * rstd) + b + (p.resid ? r[j] : 0.f);
+      }
+      st8(p.out, p.out_dt, base + c, o);
+      if (p.out2) st8(p.out2, p.out2_dt, base + c, o);
+    }
+  }
+}
+
+template <int LPR, int CPL>
+__global__ __launch_bounds__(256) void cln_bwd_fast_kernel(ClnFastArgs p) {
+  constexpr int RPW = 64 / LPR;
+  constexpr int NCOL = LPR * CPL * 8;      // columns covered (>= C)
+  __shared__ float red[3][NCOL];           // [dgamma | dbeta | dxsum][col], waves combine with LDS atomics
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int sub = lane / LPR, l = lane % LPR;
+  const int b = blockIdx.x / p.chunks_per_sample, chunk = blockIdx.x % p.chunks_per_sample;
+  const int r0 = chunk * p.rpb, r1 = min(p.rows_per_sample, r0 + p.rpb);
+  const int C = p.C;
+  const float t = p.time ? p.time[b] : 0.f;
+  float gam[CPL][8], ag[CPL][8], ab[CPL][8], ax[CPL][8];
+#pragma unroll
+  for (int i = 0; i < CPL; ++i) {
+    const int c = (l + i * LPR) * 8;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { gam[i][j] = 0.f; ag[i][j] = 0.f; ab[i][j] = 0.f; ax[i][j] = 0.f; }
+    if (c < C) {
+      float gb[8], gw[8];
+      ld8(p.gw_b, SCOT_F32, c, gb);
+      if (p.gw_w) ld8(p.gw_w, SCOT_F32, c, gw);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) gam[i][j] = p.gw_w ? gw[j] * t + gb[j] : gb[j];
+    }
+  }
+  for (int i = threadIdx.x; i < 3 * NCOL; i += 256) (&red[0][0])[i] = 0.f;
+  __syncthreads();
+  for (int r = r0 + wave * RPW + sub; r < r1; r += 4 * RPW) {
+    // the LPR lanes of a row group share `sub`, hence the trip count: group shuffles below are convergent
+    const bool rvalid = true;
+    const int row = b * p.rows_per_sample + r;
+    const size_t base = (size_t)row * C;
+    const float mean = p.mean[row], rstd = p.rstd[row];
+    float d[CPL][8], xh[CPL][8];
+    float m1 = 0.f, m2 = 0.f;
+#pragma unroll
+    for (int i = 0; i < CPL; ++i) {
+      const int c = (l + i * LPR) * 8;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) { d[i][j] = 0.f; xh[i][j] = 0.f; }
+      if (c < C) {
+        ld8(p.dout, p.dout_dt, base + c, d[i]);
+        ld8(p.x, p.x_dt, base + c, xh[i]);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          xh[i][j] = (xh[i][j] - mean) * rstd;
+          const float g = d[i][j] * gam[i][j];
+          m1 += g; m2 += g * xh[i][j];
+        }
+      }
+    }
+    m1 = group_sum<LPR>(m1) / C; m2 = group_sum<LPR>(m2) / C;
+    if (rvalid) {
+#pragma unroll
+      for (int i = 0; i < CPL; ++i) {
+        const int c = (l + i * LPR) * 8;
+        if (c < C) {
+          float o[8];
+#pragma unroll
+          for (int j = 0; j < 8; ++j) {
+            o[j] = rstd * (d[i][j] * gam[i][j] - m1 - xh[i][j] * m2);
+            ag[i][j] += d[i][j] * xh[i][j]; ab[i][j] += d[i][j]; ax[i][j] += o[j];
+          }
+          st8(p.dx, p.dx_dt, base + c, o);
+        }
+      }
+    }
+  }
+  // reduce over the RPW row-groups of the wave (same columns live in lanes l, l+LPR, ...), then over waves via LDS
+#pragma unroll
+  for (int i = 0; i < CPL; ++i)
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+#pragma unroll
+      for (int o = LPR; o < 64; o <<= 1) {
+        ag[i][j] += __shfl_xor(ag[i][j], o, 64); ab[i][j] += __shfl_xor(ab[i][j], o, 64); ax[i][j] += __shfl_xor(ax[i][j], o, 64);
+      }
+      if (sub == 0) {
+        const int c = (l + i * LPR) * 8 + j;
+        atomicAdd(&red[0][c], ag[i][j]); atomicAdd(&red[1][c], ab[i][j]); atomicAdd(&red[2][c], ax[i][j]);
+      }
+    }
+  __syncthreads();
+  for (int c = threadIdx.x; c < C; c += 256) {
+    const float dg = red[0][c], db = red[1][c];
+    if (p.d_gw_w) { atomicAdd(&p.d_gw_w[c], t * dg); atomicAdd(&p.d_bw_w[c], t * db); }
+    atomicAdd(&p.d_gw_b[c], dg);
+    atomicAdd(&p.d_bw_b[c], db);
+    if (p.d_xbias) atomicAdd(&p.d_xbias[c], red[2][c]);
+  }
+}
+
+template <int LPR, int CPL> static void launch_fwd(const ClnFastArgs& a, hipStream_t s) {
+  const int rpb = 4 * (64 / LPR);
+  hipLaunchKernelGGL((cln_fwd_fast_kernel<LPR, CPL>), dim3((a.rows + rpb - 1) / rpb), dim3(256), 0, s, a);
+}
+template <int LPR, int CPL> static void launch_bwd(const ClnFastArgs& a, hipStream_t s) {
+  hipLaunchKernelGGL((cln_bwd_fast_kernel<LPR, CPL>), dim3((a.rows / a.rows_per_sample) * a.chunks_per_sample), dim3(256), 0, s, a);
+}
+
+#define CLN_DISPATCH(FN)                                            \
+  const int nch = a.C / 8;                                          \
+  if (nch <= 1) FN<1, 1>(a, s);                                     \
+  else if (nch <= 2) FN<2, 1>(a, s);                                \
+  else if (nch <= 4) FN<4, 1>(a, s);                                \
+  else if (nch <= 8) FN<8, 1>(a, s);                                \
+  else if (nch <= 16) FN<16, 1>(a, s);                              \
+  else if (nch <= 32) FN<32, 1>(a, s);                              \
+  else if (nch <= 64) FN<64, 1>(a, s);                              \
+  else if (nch <= 128) FN<64, 2>(a, s);                             \
+  else if (nch <= 192) FN<64, 3>(a, s);                             \
+  else return SCOT_ERR_UNSUPPORTED;
+
+static bool aligned16(const void* p) { return (((uintptr_t)p) & 15) == 0; }
+
+int scot_cln_fwd_fast(ClnFastArgs a, hipStream_t s) {
+  if (a.C % 8 || !aligned16(a.x) || !aligned16(a.out) || !aligned16(a.resid) || !aligned16(a.out2) || !aligned16(a.gw_w) ||
+      !aligned16(a.gw_b) || !aligned16(a.bw_w) || !aligned16(a.bw_b))
+    return SCOT_ERR_UNSUPPORTED;
+  CLN_DISPATCH(launch_fwd)
+  return scot_check_launch();
+}
+int scot_cln_bwd_fast(ClnFastArgs a, hipStream_t s) {
+  if (a.C % 8 || !aligned16(a.x) || !aligned16(a.dout) || !aligned16(a.dx) || !aligned16(a.gw_w) || !aligned16(a.gw_b))
+    return SCOT_ERR_UNSUPPORTED;
+  a.rpb = a.rows_per_sample < 256 ? a.rows_per_sample : 256;
+  a.chunks_per_sample = (a.rows_per_sample + a.rpb - 1) / a.rpb;
+  CLN_DISPATCH(launch_bwd)
+  return scot_check_launch();
+}

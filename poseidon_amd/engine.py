@@ -49,6 +49,11 @@ class ScOTEngine:
         self.cond = bool(cfg.use_conditioning)
         self._coords: Dict[int, torch.Tensor] = {}
         self._loss_meta = None
+        # bf16 mode: GEMM operands must already be bf16 in HBM (gemm_fast streams raw 16-byte chunks into LDS), so the
+        # weights get a bf16 shadow arena that is re-cast from the fp32 master at the start of EVERY forward (one pass,
+        # inside the timed step), and every producer of a GEMM operand also writes a bf16 copy.
+        self.shadow = torch.empty(arena.size, dtype=torch.bfloat16, device=self.device) if self.compute == ops.BF16 else None
+        self._wviews: Dict[str, torch.Tensor] = {}
 
     # ------------------------------------------------------------------------------------------ helpers
     def P(self, name):
@@ -56,6 +61,29 @@ class ScOTEngine:
 
     def G(self, name):
         return self.arena.gview(name)
+
+    def W(self, name):
+        """Weight `name` as a GEMM operand (compute dtype)."""
+        if self.shadow is None:
+            return self.arena.view(name)
+        v = self._wviews.get(name)
+        if v is None:
+            o = self.arena.offsets[name]
+            v = self.shadow[o:o + self.arena.numel(name)].view(self.arena.shapes[name])
+            self._wviews[name] = v
+        return v
+
+    def Wspan(self, name, numel):
+        o = self.arena.offsets[name]
+        return (self.shadow if self.shadow is not None else self.arena.data)[o:o + numel]
+
+    def to_adt(self, x):
+        """Copy of fp32 `x` in the GEMM operand dtype (identity in fp32 mode)."""
+        if self.adt == torch.float32:
+            return x
+        y = torch.empty(x.shape, dtype=self.adt, device=self.device)
+        ops.cast(x, y)
+        return y
 
     def new(self, *shape, dtype=torch.float32):
         return torch.empty(*shape, dtype=dtype, device=self.device)
@@ -82,14 +110,19 @@ class ScOTEngine:
                     self.G(prefix + ".bias.bias"))
         return (None, self.G(prefix + ".weight"), None, self.G(prefix + ".bias"))
 
-    def norm_fwd(self, prefix, x, resid, rows_per_sample, C, eps, time, out_dtype=torch.float32, need_stats=True):
+    def norm_fwd(self, prefix, x, resid, rows_per_sample, C, eps, time, out_dtype=torch.float32, need_stats=True, copy=False):
+        """→ (out, out16, stats); out16 = operand-dtype copy of out (only when copy=True; == out in fp32 mode)."""
         rows = x.numel() // C
         out = self.new(rows, C, dtype=out_dtype)
+        out16 = None
+        if copy:
+            out16 = out if (self.adt == torch.float32 or out_dtype == self.adt) else self.new(rows, C, dtype=self.adt)
         mean = self.new(rows) if need_stats else None
         rstd = self.new(rows) if need_stats else None
         gw_w, gw_b, bw_w, bw_b = self._norm_params(prefix)
-        ops.cln_fwd(x, resid, out, mean, rstd, time if self.cond else None, gw_w, gw_b, bw_w, bw_b, rows, rows_per_sample, C, eps)
-        return out, (mean, rstd)
+        ops.cln_fwd(x, resid, out, mean, rstd, time if self.cond else None, gw_w, gw_b, bw_w, bw_b, rows, rows_per_sample, C, eps,
+                    out2=out16 if (out16 is not None and out16 is not out) else None)
+        return out, out16, (mean, rstd)
 
     def norm_bwd(self, prefix, dout, x, stats, rows_per_sample, C, time, dx_dtype):
         rows = x.numel() // C
@@ -101,12 +134,11 @@ class ScOTEngine:
         return dx
 
     def linear_bwd_params(self, wname, bname, dy, x, b_gelu=False):
-        ops.linear_wgrad(self.compute, dy, x, self.G(wname), b_gelu=b_gelu)
-        if bname is not None:
-            ops.colsum(dy, self.G(bname))
+        """dW += dy^T x and db += Σ dy in ONE wgrad launch (the bias sum rides on the dY tiles already in LDS)."""
+        ops.linear_wgrad(self.compute, dy, x, self.G(wname), b_gelu=b_gelu, dbias=self.G(bname) if bname is not None else None)
 
     # ------------------------------------------------------------------------------------------ ScOTLayer
-    def layer_fwd(self, blk: BlockGeom, x, B, time, train):
+    def layer_fwd(self, blk: BlockGeom, x, x16, B, time, train):
         """reference ScOTLayer.forward (model.py:500-581) + Swinv2Attention/Intermediate/Output (HF:389-561)."""
         cfg, cm = self.cfg, self.compute
         H, W = blk.res
@@ -118,11 +150,11 @@ class ScOTEngine:
         pre = blk.prefix
         a = pre + ".attention.self."
         if padded:
-            xp = self.new(B * Lp, C)
-            ops.copy2d(x, xp, B, H, W, Hp, Wp, C)
+            xp = self.new(B * Lp, C, dtype=self.adt)
+            ops.copy2d(x16, xp, B, H, W, Hp, Wp, C)
         else:
-            xp = x
-        wqkv = self.arena.span(a + "qkv_weight", 3 * C * C).view(3 * C, C)
+            xp = x16
+        wqkv = self.Wspan(a + "qkv_weight", 3 * C * C).view(3 * C, C)
         bqkv = self.arena.span(a + "qkv_bias", 3 * C) if cfg.qkv_bias else None
         qkv = self.new(B * Lp, 3 * C, dtype=self.adt)
         ops.linear_fwd(cm, xp, wqkv, qkv, bias=bqkv)
@@ -145,20 +177,20 @@ class ScOTEngine:
         else:
             attn_c = attn
         proj = self.new(B * L, C)
-        ops.linear_fwd(cm, attn_c, self.P(pre + ".attention.output.dense.weight"), proj,
+        ops.linear_fwd(cm, attn_c, self.W(pre + ".attention.output.dense.weight"), proj,
                        bias=self.P(pre + ".attention.output.dense.bias"))
-        h, st1 = self.norm_fwd(pre + ".layernorm_before", proj, x, L, C, cfg.layer_norm_eps, time, need_stats=train)
+        h, h16, st1 = self.norm_fwd(pre + ".layernorm_before", proj, x, L, C, cfg.layer_norm_eps, time, need_stats=train, copy=True)
         hid = int(cfg.mlp_ratio * C)
         u = self.new(B * L, hid, dtype=self.adt)
-        ops.linear_fwd(cm, h, self.P(pre + ".intermediate.dense.weight"), u, bias=self.P(pre + ".intermediate.dense.bias"))
+        ops.linear_fwd(cm, h16, self.W(pre + ".intermediate.dense.weight"), u, bias=self.P(pre + ".intermediate.dense.bias"))
         y2 = self.new(B * L, C)
-        ops.linear_fwd(cm, u, self.P(pre + ".output.dense.weight"), y2, bias=self.P(pre + ".output.dense.bias"), a_gelu=True)
-        out, st2 = self.norm_fwd(pre + ".layernorm_after", y2, h, L, C, cfg.layer_norm_eps, time, need_stats=train)
+        ops.linear_fwd(cm, u, self.W(pre + ".output.dense.weight"), y2, bias=self.P(pre + ".output.dense.bias"), a_gelu=True)
+        out, out16, st2 = self.norm_fwd(pre + ".layernorm_after", y2, h, L, C, cfg.layer_norm_eps, time, need_stats=train, copy=True)
         rec = None
         if train:
-            rec = dict(blk=blk, xp=xp, qkv=qkv, table=table, z=z, lse=lse, attn_c=attn_c, proj=proj, st1=st1, h=h, u=u, y2=y2,
+            rec = dict(blk=blk, xp=xp, qkv=qkv, table=table, z=z, lse=lse, attn_c=attn_c, proj=proj, st1=st1, h16=h16, u=u, y2=y2,
                        st2=st2, geom=(H, W, Hp, Wp, ws, shift, padded))
-        return out, rec
+        return out, out16, rec
 
     def layer_bwd(self, rec, g, B, time):
         """g: fp32 [B*L, C] gradient wrt the layer output; returns the gradient wrt the layer input (same buffer)."""
@@ -174,15 +206,15 @@ class ScOTEngine:
         # y2 = gelu(u) W2^T + b2
         self.linear_bwd_params(pre + ".output.dense.weight", pre + ".output.dense.bias", d_y2, rec["u"], b_gelu=True)
         d_u = self.new(B * L, hid, dtype=adt)
-        ops.linear_dgrad(cm, d_y2, self.P(pre + ".output.dense.weight"), d_u, aux=rec["u"])
+        ops.linear_dgrad(cm, d_y2, self.W(pre + ".output.dense.weight"), d_u, aux=rec["u"])
         # u = h W1^T + b1
-        self.linear_bwd_params(pre + ".intermediate.dense.weight", pre + ".intermediate.dense.bias", d_u, rec["h"])
-        ops.linear_dgrad(cm, d_u, self.P(pre + ".intermediate.dense.weight"), g, accumulate=True)
+        self.linear_bwd_params(pre + ".intermediate.dense.weight", pre + ".intermediate.dense.bias", d_u, rec["h16"])
+        ops.linear_dgrad(cm, d_u, self.W(pre + ".intermediate.dense.weight"), g, accumulate=True)
         # h = x + CLN_before(proj)
         d_proj = self.norm_bwd(pre + ".layernorm_before", g, rec["proj"], rec["st1"], L, C, time, adt)
         self.linear_bwd_params(pre + ".attention.output.dense.weight", pre + ".attention.output.dense.bias", d_proj, rec["attn_c"])
         d_attn = self.new(B * L, C, dtype=adt)
-        ops.linear_dgrad(cm, d_proj, self.P(pre + ".attention.output.dense.weight"), d_attn)
+        ops.linear_dgrad(cm, d_proj, self.W(pre + ".attention.output.dense.weight"), d_attn)
         if padded:
             d_attn_p = self.new(B * Lp, C, dtype=adt)
             ops.copy2d(d_attn, d_attn_p, B, H, W, Hp, Wp, C)
@@ -197,11 +229,10 @@ class ScOTEngine:
                     self.P(a + "continuous_position_bias_mlp.0.bias"), self.P(a + "continuous_position_bias_mlp.2.weight"),
                     rec["z"], d_table, self.G(a + "continuous_position_bias_mlp.0.weight"),
                     self.G(a + "continuous_position_bias_mlp.0.bias"), self.G(a + "continuous_position_bias_mlp.2.weight"), ws, heads)
-        wqkv = self.arena.span(a + "qkv_weight", 3 * C * C).view(3 * C, C)
+        wqkv = self.Wspan(a + "qkv_weight", 3 * C * C).view(3 * C, C)
         gwqkv = self.arena.span(a + "qkv_weight", 3 * C * C, grad=True).view(3 * C, C)
-        ops.linear_wgrad(cm, d_qkv, rec["xp"], gwqkv)
-        if cfg.qkv_bias:
-            ops.colsum(d_qkv, self.arena.span(a + "qkv_bias", 3 * C, grad=True))
+        ops.linear_wgrad(cm, d_qkv, rec["xp"], gwqkv,
+                         dbias=self.arena.span(a + "qkv_bias", 3 * C, grad=True) if cfg.qkv_bias else None)
         if padded:
             tmp = self.new(B * Lp, C)
             ops.linear_dgrad(cm, d_qkv, wqkv, tmp)
@@ -221,9 +252,9 @@ class ScOTEngine:
         cat = self.new(B * H2 * W2, 4 * C, dtype=self.adt)
         ops.space_to_depth(x, stage_in, cat, B, H, W, C, 0)
         r = self.new(B * H2 * W2, 2 * C)
-        ops.linear_fwd(self.compute, cat, self.P(st.prefix + ".downsample.reduction.weight"), r)
-        out, stats = self.norm_fwd(st.prefix + ".downsample.norm", r, None, H2 * W2, 2 * C, 1e-5, time, need_stats=train)
-        return out, (dict(cat=cat, r=r, stats=stats) if train else None)
+        ops.linear_fwd(self.compute, cat, self.W(st.prefix + ".downsample.reduction.weight"), r)
+        out, out16, stats = self.norm_fwd(st.prefix + ".downsample.norm", r, None, H2 * W2, 2 * C, 1e-5, time, need_stats=train, copy=True)
+        return out, out16, (dict(cat=cat, r=r, stats=stats) if train else None)
 
     def merge_bwd(self, st: StageGeom, rec, g, B, time):
         H, W = st.res
@@ -232,39 +263,40 @@ class ScOTEngine:
         d_r = self.norm_bwd(st.prefix + ".downsample.norm", g, rec["r"], rec["stats"], H2 * W2, 2 * C, time, self.adt)
         ops.linear_wgrad(self.compute, d_r, rec["cat"], self.G(st.prefix + ".downsample.reduction.weight"))
         d_cat = self.new(B * H2 * W2, 4 * C)
-        ops.linear_dgrad(self.compute, d_r, self.P(st.prefix + ".downsample.reduction.weight"), d_cat)
+        ops.linear_dgrad(self.compute, d_r, self.W(st.prefix + ".downsample.reduction.weight"), d_cat)
         d_sum = self.new(B * H * W, C)
         ops.depth_to_space(d_cat, d_sum, B, H, W, H2, W2, C, 0)
         return d_sum
 
-    def unmerge_fwd(self, st: StageGeom, x, B, time, train):
+    def unmerge_fwd(self, st: StageGeom, x16, B, time, train):
         """reference ScOTPatchUnmerging (model.py:737-760)."""
         h, w = st.res
         oh, ow = st.out_res
         C = st.dim
         up = self.new(B * h * w, 2 * C, dtype=self.adt)
-        ops.linear_fwd(self.compute, x, self.P(st.prefix + ".upsample.upsample.weight"), up)
+        ops.linear_fwd(self.compute, x16, self.W(st.prefix + ".upsample.upsample.weight"), up)
         sh = self.new(B * oh * ow, C // 2, dtype=self.adt)
         ops.depth_to_space(up, sh, B, oh, ow, h, w, C // 2, 1)
-        n, stats = self.norm_fwd(st.prefix + ".upsample.norm", sh, None, oh * ow, C // 2, 1e-5, time, out_dtype=self.adt,
-                                 need_stats=train)
+        n, _, stats = self.norm_fwd(st.prefix + ".upsample.norm", sh, None, oh * ow, C // 2, 1e-5, time, out_dtype=self.adt,
+                                    need_stats=train)
         out = self.new(B * oh * ow, C // 2)
-        ops.linear_fwd(self.compute, n, self.P(st.prefix + ".upsample.mixup.weight"), out)
-        return out, (dict(x=x, sh=sh, stats=stats, n=n) if train else None)
+        ops.linear_fwd(self.compute, n, self.W(st.prefix + ".upsample.mixup.weight"), out)
+        return out, self.to_adt(out), (dict(x=x16, sh=sh, stats=stats, n=n) if train else None)
 
     def unmerge_bwd(self, st: StageGeom, rec, g, B, time):
         h, w = st.res
         oh, ow = st.out_res
         C = st.dim
-        ops.linear_wgrad(self.compute, g, rec["n"], self.G(st.prefix + ".upsample.mixup.weight"))
+        g16 = self.to_adt(g)
+        ops.linear_wgrad(self.compute, g16, rec["n"], self.G(st.prefix + ".upsample.mixup.weight"))
         d_n = self.new(B * oh * ow, C // 2, dtype=self.adt)
-        ops.linear_dgrad(self.compute, g, self.P(st.prefix + ".upsample.mixup.weight"), d_n)
+        ops.linear_dgrad(self.compute, g16, self.W(st.prefix + ".upsample.mixup.weight"), d_n)
         d_sh = self.norm_bwd(st.prefix + ".upsample.norm", d_n, rec["sh"], rec["stats"], oh * ow, C // 2, time, self.adt)
         d_up = self.new(B * h * w, 2 * C, dtype=self.adt)
         ops.space_to_depth(d_sh, None, d_up, B, oh, ow, C // 2, 1)
         ops.linear_wgrad(self.compute, d_up, rec["x"], self.G(st.prefix + ".upsample.upsample.weight"))
         gx = self.new(B * h * w, C)
-        ops.linear_dgrad(self.compute, d_up, self.P(st.prefix + ".upsample.upsample.weight"), gx)
+        ops.linear_dgrad(self.compute, d_up, self.W(st.prefix + ".upsample.upsample.weight"), gx)
         return gx
 
     # ------------------------------------------------------------------------------------------ ConvNeXt skip block
@@ -273,11 +305,11 @@ class ScOTEngine:
         L = H * W
         dw = self.new(B * L, C)
         ops.dwconv7(s, self.P(pre + ".dwconv.weight"), self.P(pre + ".dwconv.bias"), dw, B, H, W, C)
-        n, stats = self.norm_fwd(pre + ".norm", dw, None, L, C, self.cfg.layer_norm_eps, time, out_dtype=self.adt, need_stats=train)
+        n, _, stats = self.norm_fwd(pre + ".norm", dw, None, L, C, self.cfg.layer_norm_eps, time, out_dtype=self.adt, need_stats=train)
         u = self.new(B * L, 4 * C, dtype=self.adt)
-        ops.linear_fwd(self.compute, n, self.P(pre + ".pwconv1.weight"), u, bias=self.P(pre + ".pwconv1.bias"))
+        ops.linear_fwd(self.compute, n, self.W(pre + ".pwconv1.weight"), u, bias=self.P(pre + ".pwconv1.bias"))
         y2 = self.new(B * L, C)
-        ops.linear_fwd(self.compute, u, self.P(pre + ".pwconv2.weight"), y2, bias=self.P(pre + ".pwconv2.bias"), a_gelu=True)
+        ops.linear_fwd(self.compute, u, self.W(pre + ".pwconv2.weight"), y2, bias=self.P(pre + ".pwconv2.bias"), a_gelu=True)
         out = self.new(B * L, C)
         ops.scale_residual(y2, self.P(pre + ".weight"), s, out, B * L, C)
         return out, (dict(s=s, dw=dw, stats=stats, n=n, u=u, y2=y2) if train else None)
@@ -289,10 +321,10 @@ class ScOTEngine:
         ops.scale_residual(g, self.P(pre + ".weight"), None, d_y2, B * L, C)
         self.linear_bwd_params(pre + ".pwconv2.weight", pre + ".pwconv2.bias", d_y2, rec["u"], b_gelu=True)
         d_u = self.new(B * L, 4 * C, dtype=self.adt)
-        ops.linear_dgrad(self.compute, d_y2, self.P(pre + ".pwconv2.weight"), d_u, aux=rec["u"])
+        ops.linear_dgrad(self.compute, d_y2, self.W(pre + ".pwconv2.weight"), d_u, aux=rec["u"])
         self.linear_bwd_params(pre + ".pwconv1.weight", pre + ".pwconv1.bias", d_u, rec["n"])
         d_n = self.new(B * L, C, dtype=self.adt)
-        ops.linear_dgrad(self.compute, d_u, self.P(pre + ".pwconv1.weight"), d_n)
+        ops.linear_dgrad(self.compute, d_u, self.W(pre + ".pwconv1.weight"), d_n)
         d_dw = self.norm_bwd(pre + ".norm", d_n, rec["dw"], rec["stats"], L, C, time, torch.float32)
         ops.dwconv7_wgrad(d_dw, rec["s"], self.G(pre + ".dwconv.weight"), self.G(pre + ".dwconv.bias"), B, H, W, C)
         d_s = self.new(B * L, C)
@@ -317,16 +349,19 @@ class ScOTEngine:
         C0 = cfg.embed_dim
         L0 = gh * gw
         tape = dict(B=B, time=time, enc=[], dec=[], res=[]) if train else None
+        if self.shadow is not None:
+            ops.cast(self.arena.data, self.shadow)  # fp32 master weights → bf16 GEMM operands (every step)
 
         # embeddings (model.py:295-366)
         cols = self.new(B * L0, Cin * p * p, dtype=self.adt)
         ops.patchify(pixel_values, cols, B, Cin, H, W, p)
         e = self.new(B * L0, C0)
-        wemb = self.P("embeddings.patch_embeddings.projection.weight").view(C0, Cin * p * p)
+        wemb = self.W("embeddings.patch_embeddings.projection.weight").view(C0, Cin * p * p)
         ops.linear_fwd(cm, cols, wemb, e, bias=self.P("embeddings.patch_embeddings.projection.bias"))
-        x, est = self.norm_fwd("embeddings.norm", e, None, L0, C0, 1e-5, time, need_stats=train)
+        x, x16, est = self.norm_fwd("embeddings.norm", e, None, L0, C0, 1e-5, time, need_stats=train, copy=True)
         if cfg.use_absolute_embeddings:
             ops.add(x, self.P("embeddings.position_embeddings").view(-1), x, period=L0 * C0)
+            x16 = self.to_adt(x)
         if train:
             tape["emb"] = dict(cols=cols, e=e, stats=est)
         hidden_enc = [x]
@@ -337,13 +372,13 @@ class ScOTEngine:
             stage_in = x
             recs = []
             for blk in st.blocks:
-                x, r = self.layer_fwd(blk, x, B, time, train)
+                x, x16, r = self.layer_fwd(blk, x, x16, B, time, train)
                 recs.append(r)
             skips.append(x)
             hidden_enc.append(x)
             mrec = None
             if st.resample:
-                x, mrec = self.merge_fwd(st, x, stage_in, B, time, train)
+                x, x16, mrec = self.merge_fwd(st, x, stage_in, B, time, train)
             if train:
                 tape["enc"].append((recs, mrec))
 
@@ -359,6 +394,7 @@ class ScOTEngine:
 
         # decoder (model.py:916-961, 1145-1240)
         x = skips[-1]
+        x16 = self.to_adt(x)
         hidden_dec = [x]
         sk = skips[:-1]
         for k, st in enumerate(self.dec):
@@ -366,22 +402,23 @@ class ScOTEngine:
                 y = self.new(x.shape[0], x.shape[1])
                 ops.add(x, sk[len(sk) - k], y)
                 x = y
+                x16 = self.to_adt(x)
             recs = []
             for blk in st.blocks:
-                x, r = self.layer_fwd(blk, x, B, time, train)
+                x, x16, r = self.layer_fwd(blk, x, x16, B, time, train)
                 recs.append(r)
             hidden_dec.append(x)
             urec = None
             if st.resample:
-                x, urec = self.unmerge_fwd(st, x, B, time, train)
+                x, x16, urec = self.unmerge_fwd(st, x16, B, time, train)
             if train:
                 tape["dec"].append((recs, urec))
 
         # recovery head (model.py:639-647)
         Cout = cfg.num_out_channels
         rc = self.new(B * L0, Cout * p * p)
-        wrec = self.P("patch_recovery.projection.weight").view(C0, Cout * p * p)
-        ops.gemm(ops.NN, cm, B * L0, Cout * p * p, C0, x, C0, wrec, Cout * p * p, rc, Cout * p * p)
+        wrec = self.W("patch_recovery.projection.weight").view(C0, Cout * p * p)
+        ops.gemm(ops.NN, cm, B * L0, Cout * p * p, C0, x16, C0, wrec, Cout * p * p, rc, Cout * p * p)
         img = self.new(B, Cout, H, W)
         ops.unpatchify(rc, self.P("patch_recovery.projection.bias"), img, B, Cout, H, W, gh, gw, p)
         pred = self.new(B, Cout, H, W)
@@ -406,7 +443,7 @@ class ScOTEngine:
             loss = self.new(1)
             ops.loss_finish(sums, meta["counts"], meta["G"], meta["normalized"], loss)
         if train:
-            tape["head"] = dict(x=x, img=img, pred=pred, labels=labels, mask=mask_u8, mask_full=mask_full, sums=sums, meta=meta,
+            tape["head"] = dict(x=x16, img=img, pred=pred, labels=labels, mask=mask_u8, mask_full=mask_full, sums=sums, meta=meta,
                                 shape=(B, Cout, H, W))
             tape["hidden"] = (hidden_dec, hidden_enc)
         self.last_hidden = (hidden_dec, hidden_enc)
@@ -463,7 +500,7 @@ class ScOTEngine:
         ops.nchw_channel_sum(d_img, self.G("patch_recovery.projection.bias"), B, Cout, H * W)
         d_rc = self.new(B * L0, Cout * p * p, dtype=adt)
         ops.patchify(d_img, d_rc, B, Cout, H, W, p)
-        wrec = self.P("patch_recovery.projection.weight").view(C0, Cout * p * p)
+        wrec = self.W("patch_recovery.projection.weight").view(C0, Cout * p * p)
         ops.gemm(ops.TN, cm, C0, Cout * p * p, B * L0, hd["x"], C0, d_rc, Cout * p * p,
                  self.G("patch_recovery.projection.weight").view(C0, Cout * p * p), Cout * p * p, accumulate=True)
         g = self.new(B * L0, C0)
@@ -514,5 +551,5 @@ class ScOTEngine:
         if cfg.use_absolute_embeddings:
             ops.batch_sum(g, self.G("embeddings.position_embeddings").view(-1), B, L0 * C0)
         d_e = self.norm_bwd("embeddings.norm", g, emb["e"], emb["stats"], L0, C0, time, adt)
-        ops.linear_wgrad(cm, d_e, emb["cols"], self.G("embeddings.patch_embeddings.projection.weight").view(C0, Cin * p * p))
-        ops.colsum(d_e, self.G("embeddings.patch_embeddings.projection.bias"))
+        ops.linear_wgrad(cm, d_e, emb["cols"], self.G("embeddings.patch_embeddings.projection.weight").view(C0, Cin * p * p),
+                         dbias=self.G("embeddings.patch_embeddings.projection.bias"))

@@ -20,13 +20,13 @@ PROTOTYPES = {
     "scot_selftest_tr": [P],
     "scot_set_use_tr": [I],
     "scot_get_use_tr": [],
-    "scot_gemm": [I, I, I, I, I, P, I, I, I, P, I, I, I, P, I, I, P, P, P, I, I, P, I, I, I, P],
+    "scot_gemm": [I, I, I, I, I, P, I, I, I, P, I, I, I, P, I, I, P, P, P, I, I, P, I, I, I, P, P, Z, P],
     "scot_window_attn_fwd": [I, P, P, P, P, P, I, I, I, I, I, I, I, P],
     "scot_window_attn_bwd": [I, P, P, P, P, P, P, P, P, I, I, I, I, I, I, I, P],
     "scot_cpb_fwd": [P, P, P, P, P, P, I, I, P],
     "scot_cpb_bwd": [P, P, P, P, P, P, P, P, P, I, I, P],
-    "scot_cln_fwd": [P, I, P, I, P, I, P, P, P, P, P, P, P, I, I, I, F, P],
-    "scot_cln_bwd": [P, I, P, I, P, P, P, P, P, P, I, P, P, P, P, I, I, I, P],
+    "scot_cln_fwd": [P, I, P, I, P, I, P, I, P, P, P, P, P, P, P, I, I, I, F, P],
+    "scot_cln_bwd": [P, I, P, I, P, P, P, P, P, P, I, P, P, P, P, P, I, I, I, P],
     "scot_add": [P, I, P, I, P, I, Z, Z, P],
     "scot_batch_sum": [P, I, P, I, Z, P],
     "scot_copy2d": [P, I, P, I, I, I, I, I, I, I, P],
@@ -59,6 +59,10 @@ def load(path: str = LIB_PATH):
     global _lib
     if _lib is not None:
         return _lib
+    # torch bundles its own libamdhip64.so (dlopen'ed by path).  It MUST be resident before our library is loaded so
+    # that our NEEDED libamdhip64.so.7 resolves (by SONAME) to the same runtime; loading ours first pulls in
+    # /opt/rocm's copy as a SECOND HIP runtime whose streams/pointers are foreign to torch's.
+    import torch  # noqa: F401
     if not os.path.exists(path):
         raise ScotLibraryError(
             f"{path} not found: the scOT hot path is HIP-only. Build it with `python -m poseidon_amd.build` "

@@ -50,13 +50,28 @@ def L():
     return l
 
 
+_workspace = {}
+WORKSPACE_BYTES = 96 << 20
+
+
+def workspace():
+    """Per-device scratch for split-K partial tiles (allocated once; the C ABI never allocates)."""
+    dev = torch.cuda.current_device()
+    w = _workspace.get(dev)
+    if w is None:
+        w = torch.empty(WORKSPACE_BYTES, dtype=torch.uint8, device=f"cuda:{dev}")
+        _workspace[dev] = w
+    return w
+
+
 def gemm(layout: int, compute: int, M: int, N: int, K: int, A, lda: int, B, ldb: int, C, ldc: int, *, bias=None,
          colscale=None, aux=None, ldaux: int = 0, resid=None, ldres: int = 0, a_gelu: bool = False, b_gelu: bool = False,
-         accumulate: bool = False) -> None:
+         accumulate: bool = False, colsum_out=None) -> None:
     """scot_gemm — see include/scot_hip.h."""
     rc = L().scot_gemm(layout, compute, M, N, K, ptr(A), dt(A), lda, int(a_gelu), ptr(B), dt(B), ldb, int(b_gelu),
                        ptr(C), dt(C), ldc, ptr(bias), ptr(colscale), ptr(aux), dt(aux) if aux is not None else 0, ldaux,
-                       ptr(resid), dt(resid) if resid is not None else 0, ldres, int(accumulate), stream())
+                       ptr(resid), dt(resid) if resid is not None else 0, ldres, int(accumulate), ptr(colsum_out),
+                       workspace().data_ptr() if layout == TN else None, WORKSPACE_BYTES if layout == TN else 0, stream())
     _lib.check(rc, "scot_gemm")
 
 
@@ -75,11 +90,11 @@ def linear_dgrad(compute, dy, w, dx, accumulate=False, aux=None):
          accumulate=accumulate)
 
 
-def linear_wgrad(compute, dy, x, dw, b_gelu=False):
-    """dw[N,K] += dy[M,N]^T @ act(x)[M,K]."""
+def linear_wgrad(compute, dy, x, dw, b_gelu=False, dbias=None):
+    """dw[N,K] += dy[M,N]^T @ act(x)[M,K];  dbias[N] += Σ_m dy[m,:] (from the same LDS tiles)."""
     M = dy.numel() // dy.shape[-1]
     N, K = dy.shape[-1], x.shape[-1]
-    gemm(TN, compute, N, K, M, dy, N, x, K, dw, K, b_gelu=b_gelu, accumulate=True)
+    gemm(TN, compute, N, K, M, dy, N, x, K, dw, K, b_gelu=b_gelu, accumulate=True, colsum_out=dbias)
 
 
 def colsum(x, out, y=None):
@@ -109,16 +124,17 @@ def cpb_bwd(coords, w0, b0, w2, z, dtable, dw0, db0, dw2, ws, heads):
                                 heads, stream()), "scot_cpb_bwd")
 
 
-def cln_fwd(x, resid, out, mean, rstd, time, gw_w, gw_b, bw_w, bw_b, rows, rows_per_sample, C, eps):
-    _lib.check(L().scot_cln_fwd(ptr(x), dt(x), ptr(resid), dt(resid) if resid is not None else 0, ptr(out), dt(out), ptr(mean),
+def cln_fwd(x, resid, out, mean, rstd, time, gw_w, gw_b, bw_w, bw_b, rows, rows_per_sample, C, eps, out2=None):
+    _lib.check(L().scot_cln_fwd(ptr(x), dt(x), ptr(resid), dt(resid) if resid is not None else 0, ptr(out), dt(out), ptr(out2),
+                                dt(out2) if out2 is not None else 0, ptr(mean),
                                 ptr(rstd), ptr(time), ptr(gw_w), ptr(gw_b), ptr(bw_w), ptr(bw_b), rows, rows_per_sample, C,
                                 float(eps), stream()), "scot_cln_fwd")
 
 
-def cln_bwd(dout, x, mean, rstd, time, gw_w, gw_b, dx, d_gw_w, d_gw_b, d_bw_w, d_bw_b, rows, rows_per_sample, C):
+def cln_bwd(dout, x, mean, rstd, time, gw_w, gw_b, dx, d_gw_w, d_gw_b, d_bw_w, d_bw_b, rows, rows_per_sample, C, d_xbias=None):
     _lib.check(L().scot_cln_bwd(ptr(dout), dt(dout), ptr(x), dt(x), ptr(mean), ptr(rstd), ptr(time), ptr(gw_w), ptr(gw_b),
-                                ptr(dx), dt(dx), ptr(d_gw_w), ptr(d_gw_b), ptr(d_bw_w), ptr(d_bw_b), rows, rows_per_sample, C,
-                                stream()), "scot_cln_bwd")
+                                ptr(dx), dt(dx), ptr(d_gw_w), ptr(d_gw_b), ptr(d_bw_w), ptr(d_bw_b), ptr(d_xbias), rows,
+                                rows_per_sample, C, stream()), "scot_cln_bwd")
 
 
 def add(a, b, out, period=None):
@@ -155,6 +171,12 @@ def unpatchify(cols, bias, img, B, Cc, H, W, gh, gw, p):
 
 def nchw_channel_sum(x, out, B, Cc, HW):
     _lib.check(L().scot_nchw_channel_sum(ptr(x), ptr(out), B, Cc, HW, stream()), "scot_nchw_channel_sum")
+
+
+def cast(src, dst):
+    """dst <- src (dtype conversion, one pass) — scot_scale_residual with no scale / residual."""
+    n = src.numel()
+    _lib.check(L().scot_scale_residual(ptr(src), dt(src), None, None, 0, ptr(dst), dt(dst), 1, n, stream()), "scot_scale_residual(cast)")
 
 
 def scale_residual(y, scale, resid, out, rows, N):

@@ -34,34 +34,38 @@ def test_selftest_tr():
 # ----------------------------------------------------------------------------------------------- GEMM
 @pytest.mark.parametrize("compute", [ops.F32, ops.BF16])
 @pytest.mark.parametrize("layout", [ops.NT, ops.NN, ops.TN])
-@pytest.mark.parametrize("M,N,K", [(300, 96, 96), (1024, 288, 96), (257, 130, 72), (4096, 384, 96), (64, 64, 3072),
-                                   (1024, 768, 768)])
-def test_gemm_layouts(compute, layout, M, N, K):
+@pytest.mark.parametrize("mixed", [False, True])  # False: operands in the compute dtype (gemm_fast); True: fp32 B (generic)
+@pytest.mark.parametrize("M,N,K", [(304, 96, 96), (1024, 288, 96), (257, 130, 72), (4096, 384, 96), (64, 64, 3072),
+                                   (1024, 768, 768), (65536, 96, 384), (520, 64, 40)])
+def test_gemm_layouts(compute, layout, mixed, M, N, K):
+    if mixed and (compute == ops.F32 or M > 5000):
+        pytest.skip("mixed-dtype operands only exist in bf16 mode")
     adt = torch.float32 if compute == ops.F32 else torch.bfloat16
+    bdt = torch.float32 if mixed else adt
     if layout == ops.NT:
-        A, B = rnd(M, K, dtype=adt), rnd(N, K, scale=0.1, seed=1)
-        ref = A.double() @ B.double().t()
+        A, B = rnd(M, K, dtype=adt), rnd(N, K, dtype=bdt, scale=0.1, seed=1)
     elif layout == ops.NN:
-        A, B = rnd(M, K, dtype=adt), rnd(K, N, scale=0.1, seed=1)
-        ref = A.double() @ B.double()
+        A, B = rnd(M, K, dtype=adt), rnd(K, N, dtype=bdt, scale=0.1, seed=1)
     else:
-        A, B = rnd(K, M, dtype=adt), rnd(K, N, dtype=adt, scale=0.1, seed=1)
-        ref = A.double().t() @ B.double()
-    if compute == ops.BF16:  # reference on bf16-rounded operands
-        Bq = B.to(torch.bfloat16).double()
-        ref = (A.double() @ Bq.t()) if layout == ops.NT else ((A.double() @ Bq) if layout == ops.NN else (A.double().t() @ Bq))
+        A, B = rnd(K, M, dtype=adt), rnd(K, N, dtype=bdt, scale=0.1, seed=1)
+    Aq = A.double()
+    Bq = (B.to(torch.bfloat16) if compute == ops.BF16 else B).double()  # reference on the operands the MFMA sees
+    ref = (Aq @ Bq.t()) if layout == ops.NT else ((Aq @ Bq) if layout == ops.NN else (Aq.t() @ Bq))
     C = torch.zeros(M, N, device=DEV) if layout == ops.TN else torch.full((M, N), float("nan"), device=DEV)
-    ops.gemm(layout, compute, M, N, K, A, A.shape[1], B, B.shape[1], C, N, accumulate=(layout == ops.TN))
+    cs = torch.zeros(M if layout == ops.TN else N, device=DEV)
+    ops.gemm(layout, compute, M, N, K, A, A.shape[1], B, B.shape[1], C, N, accumulate=(layout == ops.TN), colsum_out=cs)
     torch.cuda.synchronize()
     tol = 2e-5 if compute == ops.F32 else 2e-3
     assert rel(C, ref) < tol
+    cs_ref = Aq.sum(0) if layout == ops.TN else C.double().sum(0)
+    assert rel(cs, cs_ref) < 1e-4
 
 
 @pytest.mark.parametrize("compute", [ops.F32, ops.BF16])
 def test_gemm_epilogues(compute):
     M, N, K = 520, 192, 96
     cdt = torch.float32 if compute == ops.F32 else torch.bfloat16
-    x, w, b = rnd(M, K), rnd(N, K, scale=0.1, seed=1), rnd(N, seed=2)
+    x, w, b = rnd(M, K, dtype=cdt), rnd(N, K, dtype=cdt, scale=0.1, seed=1), rnd(N, seed=2)
     tol = 2e-5 if compute == ops.F32 else 1e-2
     # fc1: u = x w^T + b (stored in compute dtype)
     u = torch.empty(M, N, device=DEV, dtype=cdt)
@@ -69,7 +73,7 @@ def test_gemm_epilogues(compute):
     ref_u = x.double() @ w.double().t() + b.double()
     assert rel(u, ref_u) < tol
     # fc2 with GELU on load: y = gelu(u) w2^T + b2, f32 out, + residual + colscale
-    w2, b2, cs, res = rnd(K, N, scale=0.1, seed=3), rnd(K, seed=4), rnd(K, seed=5), rnd(M, K, seed=6)
+    w2, b2, cs, res = rnd(K, N, dtype=cdt, scale=0.1, seed=3), rnd(K, seed=4), rnd(K, seed=5), rnd(M, K, seed=6)
     y = torch.empty(M, K, device=DEV)
     ops.gemm(ops.NT, compute, M, K, N, u, N, w2, N, y, K, bias=b2, colscale=cs, resid=res, ldres=K, a_gelu=True)
     g = torch.nn.functional.gelu(u.double())
@@ -89,11 +93,13 @@ def test_gemm_epilogues(compute):
     assert rel(acc, acc0.double() + dy.double() @ w2.double()) < tol
     # wgrad with GELU on the B operand: dw2 += dy^T gelu(u);  bias grad via colsum
     dw2 = torch.zeros(K, N, device=DEV)
-    ops.linear_wgrad(compute, dy, u, dw2, b_gelu=True)
-    assert rel(dw2, dy.double().t() @ g) < tol
     db = torch.zeros(K, device=DEV)
-    ops.colsum(dy, db)
-    assert rel(db, dy.double().sum(0)) < 1e-5
+    ops.linear_wgrad(compute, dy, u, dw2, b_gelu=True, dbias=db)
+    assert rel(dw2, dy.double().t() @ g) < tol
+    assert rel(db, dy.double().sum(0)) < 1e-4
+    db2 = torch.zeros(K, device=DEV)
+    ops.colsum(dy, db2)
+    assert rel(db2, dy.double().sum(0)) < 1e-5
 
 
 # ----------------------------------------------------------------------------------------------- attention
@@ -174,22 +180,25 @@ def test_window_attention_fwd_bwd(compute, case):
 # ----------------------------------------------------------------------------------------------- CLN
 @pytest.mark.parametrize("cond", [True, False])
 @pytest.mark.parametrize("xdt", [torch.float32, torch.bfloat16])
-@pytest.mark.parametrize("B,L,C", [(3, 64, 96), (2, 16, 768), (2, 9, 20), (2, 300, 48)])
+@pytest.mark.parametrize("B,L,C", [(3, 64, 96), (2, 16, 768), (2, 9, 20), (2, 300, 48), (2, 1024, 192), (2, 5, 1536), (3, 33, 16)])
 def test_cln_fwd_bwd(cond, xdt, B, L, C):
     x = rnd(B, L, C, dtype=xdt)
     res = rnd(B, L, C, seed=1)
     t = torch.rand(B, device=DEV)
     gw_w, gw_b, bw_w, bw_b = rnd(C, seed=2, scale=0.3), 1 + rnd(C, seed=3, scale=0.1), rnd(C, seed=4, scale=0.1), rnd(C, seed=5, scale=0.1)
     out = torch.empty(B, L, C, device=DEV)
+    out16 = torch.empty(B, L, C, device=DEV, dtype=torch.bfloat16)
     mean, rstd = torch.empty(B * L, device=DEV), torch.empty(B * L, device=DEV)
     ops.cln_fwd(x, res, out, mean, rstd, t if cond else None, gw_w if cond else None, gw_b, bw_w if cond else None, bw_b,
-                B * L, L, C, 1e-5)
+                B * L, L, C, 1e-5, out2=out16)
     dout = rnd(B, L, C, seed=6)
     dx = torch.empty(B, L, C, device=DEV, dtype=xdt)
     grads = [torch.zeros(C, device=DEV) for _ in range(4)]
+    dxb = torch.zeros(C, device=DEV)
     ops.cln_bwd(dout, x, mean, rstd, t if cond else None, gw_w if cond else None, gw_b, dx, grads[0], grads[1], grads[2],
-                grads[3], B * L, L, C)
+                grads[3], B * L, L, C, d_xbias=dxb)
     torch.cuda.synchronize()
+    assert torch.equal(out16, out.to(torch.bfloat16))
     x64 = x.double().requires_grad_(True)
     ps = [p.double().requires_grad_(True) for p in (gw_w, gw_b, bw_w, bw_b)]
     mu = x64.mean(-1, keepdim=True)
@@ -204,6 +213,7 @@ def test_cln_fwd_bwd(cond, xdt, B, L, C):
     ref.backward(dout.double())
     assert rel(out, ref.detach()) < 1e-5
     assert rel(dx, x64.grad) < (1e-4 if xdt == torch.float32 else 1e-2)
+    assert rel(dxb, x64.grad.sum((0, 1))) < (2e-3 if xdt == torch.float32 else 5e-2)
     for i in ([0, 1, 2, 3] if cond else [1, 3]):
         assert rel(grads[i], ps[i].grad) < 1e-4, i
 
