@@ -49,6 +49,9 @@ class ScOTEngine:
         self.cond = bool(cfg.use_conditioning)
         self._coords: Dict[int, torch.Tensor] = {}
         self._loss_meta = None
+        # called with a state-dict prefix ("patch_recovery.", "decoder.layers.3.", …) as soon as the backward has FINISHED
+        # writing every gradient under that prefix — the data-parallel wrapper launches that range's all-reduce there
+        self.on_grads_final = None
         # bf16 mode: GEMM operands must already be bf16 in HBM (gemm_fast streams raw 16-byte chunks into LDS), so the
         # weights get a bf16 shadow arena that is re-cast from the fp32 master at the start of EVERY forward (one pass,
         # inside the timed step), and every producer of a GEMM operand also writes a bf16 copy.
@@ -505,6 +508,8 @@ class ScOTEngine:
                  self.G("patch_recovery.projection.weight").view(C0, Cout * p * p), Cout * p * p, accumulate=True)
         g = self.new(B * L0, C0)
         ops.gemm(ops.NT, cm, B * L0, C0, Cout * p * p, d_rc, Cout * p * p, wrec, Cout * p * p, g, C0)
+        done = self.on_grads_final or (lambda prefix: None)
+        done("patch_recovery.")
 
         # decoder, shallow → deep
         nl = len(self.dec)
@@ -516,6 +521,7 @@ class ScOTEngine:
                 g = self.unmerge_bwd(st, urec, g, B, time)
             for blk_rec in reversed(recs):
                 g = self.layer_bwd(blk_rec, g, B, time)
+            done(f"decoder.layers.{k}.")
             if k != 0:
                 g_skips[nl - 1 - k] = g   # x = x_prev + skip: both get g (g keeps flowing to x_prev unchanged)
                 g = g.clone()
@@ -528,6 +534,7 @@ class ScOTEngine:
                 g_skips[i] = self.convnext_bwd(f"residual_blocks.{i}.{j}", tape["res"][i][j], g_skips[i], B, st.res[0], st.res[1],
                                                st.dim, time)
 
+        done("residual_blocks.")
         # encoder, deep → shallow
         g = None
         for s in reversed(range(nl)):
@@ -544,6 +551,7 @@ class ScOTEngine:
                 g = self.layer_bwd(blk_rec, g, B, time)
             if d_sum is not None:
                 ops.add(g, d_sum, g)
+            done(f"encoder.layers.{s}.")
 
         # embeddings
         emb = tape["emb"]
@@ -553,3 +561,4 @@ class ScOTEngine:
         d_e = self.norm_bwd("embeddings.norm", g, emb["e"], emb["stats"], L0, C0, time, adt)
         ops.linear_wgrad(cm, d_e, emb["cols"], self.G("embeddings.patch_embeddings.projection.weight").view(C0, Cin * p * p),
                          dbias=self.G("embeddings.patch_embeddings.projection.bias"))
+        done("embeddings.")

@@ -1,0 +1,41 @@
+"""Harness pins: optimizer group membership equals the reference's (fixture from the real
+reference Trainer), on CPU.  Rollout numerics are GPU tests (tests/test_model_gpu.py)."""
+import json
+import os
+
+import torch
+
+from conftest import GOLDEN
+from poseidon_amd.config import preset
+from poseidon_amd.harness import create_optimizer, optimizer_param_groups
+from scOT.model import ScOT
+
+
+def test_optimizer_groups_match_reference_trainer():
+    ref = json.load(open(os.path.join(GOLDEN, "optimizer_groups_T.json")))
+    cfg = preset("T", image_size=128, num_channels=4, num_out_channels=4, channel_slice_list_normalized_loss=[0, 1, 3, 4])
+    model = ScOT(cfg)
+    groups = optimizer_param_groups(model, weight_decay=1e-6, learning_rate_embedding_recovery=1e-4,
+                                    learning_rate_time_embedding=2e-4, return_names=True)
+    assert [len(g["names"]) for g in groups] == [257, 274, 9, 304]
+    for gi, g in enumerate(groups):
+        r = ref[f"group{gi}"]
+        assert sorted(g["names"]) == r["names"]
+        assert g["weight_decay"] == r["weight_decay"]
+        if "lr" in g:
+            assert g["lr"] == r["lr"]
+    numel = [sum(p.numel() for p in g["params"]) for g in groups]
+    assert numel == [20431272, 283584, 6788, 52800]
+    # quirks
+    names = {n: gi for gi, g in enumerate(groups) for n in g["names"]}
+    assert names["encoder.layers.0.blocks.0.attention.self.continuous_position_bias_mlp.0.weight"] == 1
+    assert names["encoder.layers.0.blocks.0.attention.self.logit_scale"] == 0
+    assert names["residual_blocks.0.0.weight"] == 0
+    assert names["embeddings.norm.weight.weight"] == 2
+    # 2-group and 3-group variants
+    g2 = optimizer_param_groups(model, weight_decay=0.1)
+    assert len(g2) == 2 and sum(len(g["params"]) for g in g2) == 844
+    g3 = optimizer_param_groups(model, weight_decay=0.1, learning_rate_time_embedding=1e-3)
+    assert len(g3) == 3 and len(g3[2]["params"]) == 308  # all cond-LN tensors incl. embeddings.norm
+    opt = create_optimizer(model, 5e-4, 1e-6, learning_rate_embedding_recovery=1e-4, learning_rate_time_embedding=2e-4)
+    assert [g["lr"] for g in opt.param_groups] == [5e-4, 5e-4, 1e-4, 2e-4]

@@ -169,3 +169,27 @@ def test_grad_accumulation_and_eval_mode():
         o = model(**kw)
     assert rel_l2(o.output.cpu().numpy(), f["output"]) < 1.5e-5
     assert o.loss.grad_fn is None
+
+
+def test_ar_rollout_matches_reference_trainer():
+    """reference Trainer._model_forward (trainer.py:452-603) pins generated by the real reference (rollout_tiny.npz)."""
+    import os
+    from conftest import GOLDEN
+    from poseidon_amd.harness import rollout
+    f = np.load(os.path.join(GOLDEN, "rollout_tiny.npz"))
+    fx, meta = load_fixture("tiny_trained")
+    cfg, model = build(meta, "fp32")
+    model.eval()
+    pv, t, lab = synth_inputs(2, 4, 4, 32, "smooth")
+    kw = dict(pixel_values=pv.to(DEV), time=t.to(DEV), labels=lab.to(DEV))
+    with torch.no_grad():
+        o = rollout(model, kw, 3)
+        assert rel_l2(o.output.cpu().numpy(), f["int3_output"]) < 3e-5
+        assert abs(float(o.loss) - float(f["int3_loss"])) < 1e-4 * abs(float(f["int3_loss"]))
+        o = rollout(model, kw, 2, output_all_steps=True)
+        assert tuple(o.output.shape) == (2, 2, 4, 32, 32) and tuple(o.loss.shape) == (2,)
+        assert rel_l2(o.output.cpu().numpy(), f["int2all_output"]) < 3e-5
+        assert rel_l2(o.loss.cpu().numpy(), f["int2all_loss"]) < 1e-4
+        o = rollout(model, dict(kw, time=kw["time"] * 0.5), [1, 2])
+        assert rel_l2(o.output.cpu().numpy(), f["list12_output"]) < 3e-5
+        assert abs(float(o.loss) - float(f["list12_loss"])) < 1e-4 * abs(float(f["list12_loss"]))
