@@ -40,11 +40,14 @@ int scot_gemm(int layout, int compute, int M, int N, int K,
               const float* bias, const float* colscale,
               const void* aux, int aux_dt, int ldaux,
               const void* resid, int res_dt, int ldres,
-              int accumulate, float* colsum_out, void* workspace, size_t ws_bytes, scot_stream_t stream);
+              int accumulate, float* colsum_out, void* workspace, size_t ws_bytes, int aux_mul, void* C2,
+              scot_stream_t stream);
 /* colsum_out (optional, fp32, +=): NT/NN: column sums of the stored result; TN: Σ_k A[k][m] — i.e. the bias gradient
  * when A = dY, taken from the dY tile already staged in LDS.
  * workspace (optional, 32-byte aligned device scratch owned by the caller): TN splits K over workgroups and writes
- * partial tiles there, reduced by one extra pass; without it TN falls back to fp32 atomics. */
+ * partial tiles there, reduced by one extra pass; without it TN falls back to fp32 atomics.
+ * C2 (optional, NT/NN): the epilogue stores gelu(v) to C and gelu'(v) to C2 (same dtype/ld) — the fc1 form, so that no
+ * later kernel re-evaluates erf; aux_mul=1: `aux` already holds that derivative and is multiplied in as is. */
 
 /* Shifted-window cosine attention, HF:389-455 + ref:522-559 (roll/partition/mask folded into indexing).
  * qkv: [batch*Hp*Wp][3C] (q|k|v) in the compute dtype; out: [batch*Hp*Wp][C]; lse: [batch*nW][heads][ws*ws] f32;

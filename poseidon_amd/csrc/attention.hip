@@ -58,7 +58,7 @@ template <int HD, typename CT> constexpr int row_pitch() { return ((HD + 31) / 3
 // Stage the window's rows of one of q/k/v (column offset `col`) into LDS tile [NP][pitch]; optionally L2-normalise
 // each row (F.normalize, eps 1e-12).  256 threads, HD/8 lanes per row.
 template <typename CT, int HD, int NP>
-__device__ __forceinline__ void stage_rows(CT* tile, const void* src, int ld, int col, const AttnArgs& p, int win, int N,
+__device__ __forceinline__ void stage_rows(CT* tile, const void* src, int ld, int col, const int* tok, int N,
                                            bool normalize, int tid) {
   constexpr int CPR = ((HD + 31) / 32) * 4, pitch = row_pitch<HD, CT>();
   for (int c = tid; c < NP * CPR; c += 256) {
@@ -66,7 +66,7 @@ __device__ __forceinline__ void stage_rows(CT* tile, const void* src, int ld, in
     float v[8];
 #pragma unroll
     for (int j = 0; j < 8; ++j) v[j] = 0.f;
-    if (n < N && d8 < HD) ld8(src, ct_traits<CT>::dtype, (size_t)win_token(p, win, n) * ld + col + d8, v);
+    if (n < N && d8 < HD) ld8(src, ct_traits<CT>::dtype, (size_t)tok[n] * ld + col + d8, v);
     if (normalize) {
       float ss = 0.f;
 #pragma unroll
@@ -85,13 +85,13 @@ __device__ __forceinline__ void stage_rows(CT* tile, const void* src, int ld, in
 // features d = kk*32 + g*8 .. +7 of row tok(n0+c).  Optionally L2-normalised (returns 1/max(|row|,eps) in *rnorm).
 template <typename CT, int HD>
 __device__ __forceinline__ void load_rows_frag(Frag<CT> (&f)[(HD + 31) / 32], const void* src, int ld, int col,
-                                               const AttnArgs& p, int win, int n0, int N, bool normalize, int lane) {
+                                               const int* tok, int n0, int N, bool normalize, int lane) {
   constexpr int KS = (HD + 31) / 32;
   const int n = n0 + (lane & 15), g = lane >> 4;
   float v[KS][8];
   float ss = 0.f;
   const bool valid = n < N;
-  const size_t base = valid ? (size_t)win_token(p, win, n) * ld + col : 0;
+  const size_t base = valid ? (size_t)tok[n] * ld + col : 0;
 #pragma unroll
   for (int kk = 0; kk < KS; ++kk) {
     const int d = kk * 32 + g * 8;
@@ -125,15 +125,17 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnArgs p) {
   float* tab = (float*)(Vs + NP * pitch);
   const int ws = p.ws, N = ws * ws, TW = 2 * ws - 1, TS = TW * TW;
   int* rid = (int*)(tab + ((TS + 3) & ~3));
+  int* tok = rid + NP;   // token index of every window position (the roll/partition index math, done once)
 
   const int win = blockIdx.x, h = blockIdx.y;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int ld = 3 * p.C;
 
-  stage_rows<CT, HD, NP>(Kn, p.qkv, ld, p.C + h * HD, p, win, N, true, tid);
-  stage_rows<CT, HD, NP>(Vs, p.qkv, ld, 2 * p.C + h * HD, p, win, N, false, tid);
+  for (int i = tid; i < NP; i += 256) { rid[i] = pos_info(p, win, i, N); tok[i] = i < N ? win_token(p, win, i) : 0; }
   for (int i = tid; i < TS; i += 256) tab[i] = p.bias_table[h * TS + i];
-  for (int i = tid; i < NP; i += 256) rid[i] = pos_info(p, win, i, N);
+  __syncthreads();
+  stage_rows<CT, HD, NP>(Kn, p.qkv, ld, p.C + h * HD, tok, N, true, tid);
+  stage_rows<CT, HD, NP>(Vs, p.qkv, ld, 2 * p.C + h * HD, tok, N, false, tid);
   __syncthreads();
 
   const float scale = __expf(fminf(p.logit_scale[h], 4.605170185988092f));  // exp(min(ls, ln 100)), HF:416
@@ -143,7 +145,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnArgs p) {
   for (int qb = wave; qb * 16 < N; qb += 4) {
     const int q0 = qb * 16;
     Frag<CT> qf[KS];
-    load_rows_frag<CT, HD>(qf, p.qkv, ld, h * HD, p, win, q0, N, true, lane);
+    load_rows_frag<CT, HD>(qf, p.qkv, ld, h * HD, tok, q0, N, true, lane);
     const int q = q0 + qc;
     const bool qvalid = q < N;
     const int qinfo = rid[min(q, NP - 1)];
@@ -212,7 +214,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnArgs p) {
     for (int r = 0; r < 4; ++r) {
       const int qq = q0 + g * 4 + r;
       if (qq < N) {
-        const size_t base = (size_t)win_token(p, win, qq) * p.C + h * HD + (lane & 15);
+        const size_t base = (size_t)tok[qq] * p.C + h * HD + (lane & 15);
 #pragma unroll
         for (int d = 0; d < DT; ++d) st1(p.out, ct_traits<CT>::dtype, base + d * 16, o[d][r]);
       }
@@ -227,7 +229,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnArgs p) {
 // LDS holds two [NP][HD] tiles that are re-filled between the phases (Kn,V then Qn,dO).
 template <typename CT, int HD>
 __device__ __forceinline__ float normalize_bwd_store(const f32x4_t (&acc)[HD / 16], float mul, const void* src, int ld, int col,
-                                                    void* dst, int dcol, const AttnArgs& p, int win, int n0, int N, int lane) {
+                                                    void* dst, int dcol, const int* tokt, int n0, int N, int lane) {
   // acc[d][r]: gradient wrt the NORMALISED row n0 + (lane>>4)*4 + r, feature d*16 + (lane&15) (times `mul`).
   // y = x / max(|x|, eps):  dx = (g - y (y·g)) / |x|   (|x| >= eps),   dx = g / eps otherwise.
   constexpr int DT = HD / 16;
@@ -237,7 +239,7 @@ __device__ __forceinline__ float normalize_bwd_store(const f32x4_t (&acc)[HD / 1
   for (int r = 0; r < 4; ++r) {
     const int n = n0 + g * 4 + r;
     const bool valid = n < N;
-    const size_t tok = valid ? (size_t)win_token(p, win, n) : 0;
+    const size_t tok = valid ? (size_t)tokt[n] : 0;
     float x[DT], ss = 0.f, dot = 0.f;
 #pragma unroll
     for (int d = 0; d < DT; ++d) {
@@ -264,6 +266,11 @@ __device__ __forceinline__ float normalize_bwd_store(const f32x4_t (&acc)[HD / 1
   return dotsum;
 }
 
+// row_shl:k — lane l of each 16-lane row receives lane l+k (0 shifted in);  row_shr:k — lane l receives lane l-k.
+template <int CTRL> __device__ __forceinline__ float dpp_row(float v) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xF, 0xF, true));
+}
+
 template <typename CT, int HD, int NT>
 __global__ __launch_bounds__(256, 2) void attn_bwd_kernel(AttnArgs p) {
   constexpr int NP = NT * 16, KS = (HD + 31) / 32, DT = HD / 16, pitch = row_pitch<HD, CT>();
@@ -276,19 +283,22 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_kernel(AttnArgs p) {
   float* lse = dtab + TSP;      // [NP]
   float* delta = lse + NP;      // [NP]
   int* rid = (int*)(delta + NP);
-  float* red = (float*)(rid + NP);  // [4]
+  int* tok = rid + NP;
+  float* red = (float*)(tok + NP);  // [4]
 
   const int win = blockIdx.x, h = blockIdx.y;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int ld = 3 * p.C, g = lane >> 4, lc = lane & 15;
 
-  stage_rows<CT, HD, NP>(X, p.qkv, ld, p.C + h * HD, p, win, N, true, tid);
-  stage_rows<CT, HD, NP>(Y, p.qkv, ld, 2 * p.C + h * HD, p, win, N, false, tid);
   for (int i = tid; i < TS; i += 256) { tab[i] = p.bias_table[h * TS + i]; dtab[i] = 0.f; }
   for (int i = tid; i < NP; i += 256) {
     rid[i] = pos_info(p, win, i, N);
+    tok[i] = i < N ? win_token(p, win, i) : 0;
     lse[i] = i < N ? p.lse[((size_t)win * p.heads + h) * N + i] : 3.0e38f;
   }
+  __syncthreads();
+  stage_rows<CT, HD, NP>(X, p.qkv, ld, p.C + h * HD, tok, N, true, tid);
+  stage_rows<CT, HD, NP>(Y, p.qkv, ld, 2 * p.C + h * HD, tok, N, false, tid);
   __syncthreads();
 
   const float ls = p.logit_scale[h];
@@ -300,8 +310,8 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_kernel(AttnArgs p) {
   for (int qb = wave; qb * 16 < N; qb += 4) {
     const int q0 = qb * 16;
     Frag<CT> qf[KS], gf[KS];
-    load_rows_frag<CT, HD>(qf, p.qkv, ld, h * HD, p, win, q0, N, true, lane);
-    load_rows_frag<CT, HD>(gf, p.dout, p.C, h * HD, p, win, q0, N, false, lane);
+    load_rows_frag<CT, HD>(qf, p.qkv, ld, h * HD, tok, q0, N, true, lane);
+    load_rows_frag<CT, HD>(gf, p.dout, p.C, h * HD, tok, q0, N, false, lane);
     const int q = q0 + lc;
     const bool qvalid = q < N;
     const int qinfo = rid[min(q, NP - 1)];
@@ -344,10 +354,20 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_kernel(AttnArgs p) {
       const int4 ki = *(const int4*)&rid[t * 16 + g * 4];
       const int kia[4] = {ki.x, ki.y, ki.z, ki.w};
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const float ds = s[t][r] * (dp[t][r] - dl);   // exactly 0 for masked pairs (P = 0)
-        s[t][r] = ds;
-        atomicAdd(&dtab[qoff - (kia[r] & 0xfffff)], ds);
+      for (int r = 0; r < 4; ++r) s[t][r] = s[t][r] * (dp[t][r] - dl);   // dS; exactly 0 for masked pairs (P = 0)
+      if (ws == 16) {
+        // A 16-key tile is one row of the window, a 16-query block one row too: the table row (qy-ky) is uniform and the
+        // column is qx-kx.  Keys kx = 4g+r of this lane group: sum the 4 registers along the anti-diagonal with row
+        // shifts first (lane l <- ds_r[l+r]); the 3 diagonals that fall off the left edge are collected by lanes 13..15.
+        // 76 instead of 256 LDS float atomics per tile (PMC: the per-element atomics kept the LDS busy 57 k cycles/wave).
+        const float a = s[t][0] + dpp_row<0x101>(s[t][1]) + dpp_row<0x102>(s[t][2]) + dpp_row<0x103>(s[t][3]);
+        const float bt = dpp_row<0x11F>(s[t][1]) + dpp_row<0x11E>(s[t][2]) + dpp_row<0x11D>(s[t][3]);
+        const int ia = qoff - (kia[0] & 0xfffff);
+        atomicAdd(&dtab[ia], a);
+        if (lc >= 13) atomicAdd(&dtab[ia - 16], bt);
+      } else {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) atomicAdd(&dtab[qoff - (kia[r] & 0xfffff)], s[t][r]);
       }
     }
     // dQn = scale * dS · Kn   (A = dS in registers, B = Kn rows via the transposing read)
@@ -364,27 +384,22 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_kernel(AttnArgs p) {
       for (int d = 0; d < DT; ++d)
         mma16(dq[d], df, lds_frag_ks(X, pitch, d * 16, (2 * tp) * 16 + g * 4, (2 * tp + 1) * 16 + g * 4, lane, p.use_tr));
     }
-    // Σ_keys dS·cos·scale = qn · (scale · dS·Kn) — the row dot product the normalisation backward needs anyway
-    dls += normalize_bwd_store<CT, HD>(dq, scale, p.qkv, ld, h * HD, p.out, h * HD, p, win, q0, N, lane);
+    normalize_bwd_store<CT, HD>(dq, scale, p.qkv, ld, h * HD, p.out, h * HD, tok, q0, N, lane);
   }
 
-  // d logit_scale: d/dls [cos * exp(ls)] = cos * scale  (0 when clamped at ln 100, HF:416)
-  dls = wave_sum(dls);
-  if (lane == 0) red[wave] = dls;
-  __syncthreads();  // also: every wave is done reading X/Y (phase B) and delta[] is complete
-  if (tid == 0 && ls <= 4.605170185988092f) atomicAdd(&p.dlogit_scale[h], red[0] + red[1] + red[2] + red[3]);
+  __syncthreads();  // every wave is done reading X/Y (phase B) and delta[] is complete
   for (int i = tid; i < TS; i += 256) atomicAdd(&p.dbias_table[h * TS + i], dtab[i]);
 
   // ---------------------------------------------------------------- phase A
-  stage_rows<CT, HD, NP>(X, p.qkv, ld, h * HD, p, win, N, true, tid);       // Qn
-  stage_rows<CT, HD, NP>(Y, p.dout, p.C, h * HD, p, win, N, false, tid);    // dO
+  stage_rows<CT, HD, NP>(X, p.qkv, ld, h * HD, tok, N, true, tid);       // Qn
+  stage_rows<CT, HD, NP>(Y, p.dout, p.C, h * HD, tok, N, false, tid);    // dO
   __syncthreads();
 
   for (int kb = wave; kb * 16 < N; kb += 4) {
     const int k0 = kb * 16;
     Frag<CT> kf[KS], vf[KS];
-    load_rows_frag<CT, HD>(kf, p.qkv, ld, p.C + h * HD, p, win, k0, N, true, lane);
-    load_rows_frag<CT, HD>(vf, p.qkv, ld, 2 * p.C + h * HD, p, win, k0, N, false, lane);
+    load_rows_frag<CT, HD>(kf, p.qkv, ld, p.C + h * HD, tok, k0, N, true, lane);
+    load_rows_frag<CT, HD>(vf, p.qkv, ld, 2 * p.C + h * HD, tok, k0, N, false, lane);
     const int key = k0 + lc;
     const bool kvalid = key < N;
     const int kinfo = rid[min(key, NP - 1)];
@@ -419,6 +434,9 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_kernel(AttnArgs p) {
           const bool ok = qrid != 15 && kvalid;
           const float pr = ok ? __expf(v - qla[r]) : 0.f;
           const float ds = ok ? pr * (dp[r] - qda[r]) : 0.f;
+          // d logit_scale = Σ dS·cos·scale, accumulated HERE in fp32 from the un-rounded dS and the very cos the forward used
+          // (Σ_k dS = 0, so this sum cancels heavily: taking it from the bf16 dS·Kn product was off by O(1) on small heads)
+          dls += ds * s[r];
           pf8[half * 4 + r] = pr;
           df8[half * 4 + r] = ds;
         }
@@ -436,13 +454,18 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_kernel(AttnArgs p) {
     for (int r = 0; r < 4; ++r) {
       const int kk2 = k0 + g * 4 + r;
       if (kk2 < N) {
-        const size_t base = (size_t)win_token(p, win, kk2) * ld + 2 * p.C + h * HD + lc;
+        const size_t base = (size_t)tok[kk2] * ld + 2 * p.C + h * HD + lc;
 #pragma unroll
         for (int d = 0; d < DT; ++d) st1(p.out, ct_traits<CT>::dtype, base + d * 16, dv[d][r]);
       }
     }
-    normalize_bwd_store<CT, HD>(dk, scale, p.qkv, ld, p.C + h * HD, p.out, p.C + h * HD, p, win, k0, N, lane);
+    normalize_bwd_store<CT, HD>(dk, scale, p.qkv, ld, p.C + h * HD, p.out, p.C + h * HD, tok, k0, N, lane);
   }
+  // d/dls [cos * exp(ls)] = cos * scale  (0 when clamped at ln 100, HF:416)
+  dls = wave_sum(dls);
+  if (lane == 0) red[wave] = dls;
+  __syncthreads();
+  if (tid == 0 && ls <= 4.605170185988092f) atomicAdd(&p.dlogit_scale[h], (red[0] + red[1] + red[2] + red[3]) * scale);
 }
 
 // ================================================================================================= host side
@@ -453,8 +476,8 @@ static int launch_attn(const AttnArgs& a, int nwin, bool bwd, hipStream_t s) {
   constexpr int NP = NT * 16, pitch = row_pitch<HD, CT>();
   const int TS = (2 * a.ws - 1) * (2 * a.ws - 1), TSP = (TS + 3) & ~3;
   size_t sh = 2 * NP * pitch * sizeof(CT);
-  if (bwd) sh += (2 * TSP + 2 * NP) * sizeof(float) + NP * sizeof(int) + 4 * sizeof(float);
-  else sh += TSP * sizeof(float) + NP * sizeof(int);
+  if (bwd) sh += (2 * TSP + 2 * NP) * sizeof(float) + 2 * NP * sizeof(int) + 4 * sizeof(float);
+  else sh += TSP * sizeof(float) + 2 * NP * sizeof(int);
   if (sh > 160 * 1024) return SCOT_ERR_UNSUPPORTED;
   dim3 grid(nwin, a.heads), block(256);
   if (bwd) {

@@ -28,6 +28,7 @@ struct GemmArgs {
   int ksplit;   // K elements per blockIdx.z (multiple of 32)
   int a_vec, b_vec;  // 16-byte vector loads legal
   int use_tr;
+  void* C2; int aux_mul;
 };
 
 constexpr int BK = 32;
@@ -176,10 +177,14 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs p) {
         const int row = rowbase + i * 16 + r;
         if (row >= p.M) continue;
         float v = (acc[i][j][r] + bv) * cs;
-        if (p.aux_gelu_grad) v *= gelu_grad_f(ld1(p.aux, p.aux_dt, (size_t)row * p.ldaux + col));
+        if (p.aux_gelu_grad) {
+          const float x = ld1(p.aux, p.aux_dt, (size_t)row * p.ldaux + col);
+          v *= p.aux_mul ? x : gelu_grad_f(x);
+        }
         if (p.resid) v += ld1(p.resid, p.res_dt, (size_t)row * p.ldres + col);
         const size_t ci = (size_t)row * p.ldc + col;
         if (p.atomic) atomicAdd((float*)p.C + ci, v);
+        else if (p.C2) { st1(p.C, p.c_dt, ci, gelu_f(v)); st1(p.C2, p.c_dt, ci, gelu_grad_f(v)); }
         else st1(p.C, p.c_dt, ci, v);
       }
     }
@@ -207,7 +212,7 @@ extern int g_scot_use_tr;
 int scot_gemm_fast(int layout, int compute, int M, int N, int K, const void* A, int a_dt, int lda, int a_gelu,
                    const void* B, int b_dt, int ldb, int b_gelu, void* C, int c_dt, int ldc, const float* bias,
                    const float* colscale, const void* aux, int aux_dt, int ldaux, const void* resid, int res_dt, int ldres,
-                   int accumulate, float* colsum_out, void* workspace, size_t ws_bytes, hipStream_t stream);
+                   int accumulate, float* colsum_out, void* workspace, size_t ws_bytes, int aux_mul, void* C2, hipStream_t stream);
 extern "C" int scot_colsum(const void* x, int x_dt, const void* y, int y_dt, float* out, int M, int N, int ld, hipStream_t s);
 
 extern "C" int scot_gemm(int layout, int compute, int M, int N, int K,
@@ -217,13 +222,14 @@ extern "C" int scot_gemm(int layout, int compute, int M, int N, int K,
                          const float* bias, const float* colscale,
                          const void* aux, int aux_dt, int ldaux,
                          const void* resid, int res_dt, int ldres,
-                         int accumulate, float* colsum_out, void* workspace, size_t ws_bytes, hipStream_t stream) {
+                         int accumulate, float* colsum_out, void* workspace, size_t ws_bytes, int aux_mul, void* C2,
+                         hipStream_t stream) {
   if (M <= 0 || N <= 0 || K <= 0) return SCOT_ERR_SHAPE;
   if (layout < 0 || layout > 2) return SCOT_ERR_UNSUPPORTED;
   if ((a_dt | b_dt | c_dt) & ~1) return SCOT_ERR_DTYPE;
   {
     const int rc = scot_gemm_fast(layout, compute, M, N, K, A, a_dt, lda, a_gelu, B, b_dt, ldb, b_gelu, C, c_dt, ldc, bias, colscale,
-                                  aux, aux_dt, ldaux, resid, res_dt, ldres, accumulate, colsum_out, workspace, ws_bytes, stream);
+                                  aux, aux_dt, ldaux, resid, res_dt, ldres, accumulate, colsum_out, workspace, ws_bytes, aux_mul, C2, stream);
     if (rc != SCOT_ERR_UNSUPPORTED) return rc;
   }
   GemmArgs a;
@@ -231,6 +237,8 @@ extern "C" int scot_gemm(int layout, int compute, int M, int N, int K,
   a.M = M; a.N = N; a.K = K; a.lda = lda; a.ldb = ldb; a.ldc = ldc; a.ldaux = ldaux; a.ldres = ldres;
   a.a_dt = a_dt; a.b_dt = b_dt; a.c_dt = c_dt; a.aux_dt = aux_dt; a.res_dt = res_dt;
   a.a_gelu = a_gelu; a.b_gelu = b_gelu; a.aux_gelu_grad = aux != nullptr; a.use_tr = g_scot_use_tr;
+  a.C2 = C2; a.aux_mul = aux_mul;
+  if (C2 && layout == LAYOUT_TN) return SCOT_ERR_UNSUPPORTED;
   a.a_vec = (((uintptr_t)A & 15) == 0) && (lda % 8 == 0);
   a.b_vec = (((uintptr_t)B & 15) == 0) && (ldb % 8 == 0);
   int nsplit = 1;

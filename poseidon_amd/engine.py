@@ -184,15 +184,19 @@ class ScOTEngine:
                        bias=self.P(pre + ".attention.output.dense.bias"))
         h, h16, st1 = self.norm_fwd(pre + ".layernorm_before", proj, x, L, C, cfg.layer_norm_eps, time, need_stats=train, copy=True)
         hid = int(cfg.mlp_ratio * C)
+        # fc1 epilogue emits a = gelu(u) AND gp = gelu'(u) (one erf, fp32 registers); u itself is never stored
         u = self.new(B * L, hid, dtype=self.adt)
-        ops.linear_fwd(cm, h16, self.W(pre + ".intermediate.dense.weight"), u, bias=self.P(pre + ".intermediate.dense.bias"))
+        gp = self.new(B * L, hid, dtype=self.adt) if train else None
+        ops.linear_fwd(cm, h16, self.W(pre + ".intermediate.dense.weight"), u, bias=self.P(pre + ".intermediate.dense.bias"),
+                       gelu_deriv_out=gp, a_gelu=False)
         y2 = self.new(B * L, C)
-        ops.linear_fwd(cm, u, self.W(pre + ".output.dense.weight"), y2, bias=self.P(pre + ".output.dense.bias"), a_gelu=True)
+        ops.linear_fwd(cm, u, self.W(pre + ".output.dense.weight"), y2, bias=self.P(pre + ".output.dense.bias"),
+                       a_gelu=not train)
         out, out16, st2 = self.norm_fwd(pre + ".layernorm_after", y2, h, L, C, cfg.layer_norm_eps, time, need_stats=train, copy=True)
         rec = None
         if train:
-            rec = dict(blk=blk, xp=xp, qkv=qkv, table=table, z=z, lse=lse, attn_c=attn_c, proj=proj, st1=st1, h16=h16, u=u, y2=y2,
-                       st2=st2, geom=(H, W, Hp, Wp, ws, shift, padded))
+            rec = dict(blk=blk, xp=xp, qkv=qkv, table=table, z=z, lse=lse, attn_c=attn_c, proj=proj, st1=st1, h16=h16, u=u, gp=gp,
+                       y2=y2, st2=st2, geom=(H, W, Hp, Wp, ws, shift, padded))
         return out, out16, rec
 
     def layer_bwd(self, rec, g, B, time):
@@ -207,9 +211,9 @@ class ScOTEngine:
         # out = h + CLN_after(y2)
         d_y2 = self.norm_bwd(pre + ".layernorm_after", g, rec["y2"], rec["st2"], L, C, time, adt)
         # y2 = gelu(u) W2^T + b2
-        self.linear_bwd_params(pre + ".output.dense.weight", pre + ".output.dense.bias", d_y2, rec["u"], b_gelu=True)
+        self.linear_bwd_params(pre + ".output.dense.weight", pre + ".output.dense.bias", d_y2, rec["u"])   # rec["u"] = gelu(u)
         d_u = self.new(B * L, hid, dtype=adt)
-        ops.linear_dgrad(cm, d_y2, self.W(pre + ".output.dense.weight"), d_u, aux=rec["u"])
+        ops.linear_dgrad(cm, d_y2, self.W(pre + ".output.dense.weight"), d_u, aux=rec["gp"], aux_mul=True)
         # u = h W1^T + b1
         self.linear_bwd_params(pre + ".intermediate.dense.weight", pre + ".intermediate.dense.bias", d_u, rec["h16"])
         ops.linear_dgrad(cm, d_u, self.W(pre + ".intermediate.dense.weight"), g, accumulate=True)
@@ -310,21 +314,22 @@ class ScOTEngine:
         ops.dwconv7(s, self.P(pre + ".dwconv.weight"), self.P(pre + ".dwconv.bias"), dw, B, H, W, C)
         n, _, stats = self.norm_fwd(pre + ".norm", dw, None, L, C, self.cfg.layer_norm_eps, time, out_dtype=self.adt, need_stats=train)
         u = self.new(B * L, 4 * C, dtype=self.adt)
-        ops.linear_fwd(self.compute, n, self.W(pre + ".pwconv1.weight"), u, bias=self.P(pre + ".pwconv1.bias"))
+        gp = self.new(B * L, 4 * C, dtype=self.adt) if train else None
+        ops.linear_fwd(self.compute, n, self.W(pre + ".pwconv1.weight"), u, bias=self.P(pre + ".pwconv1.bias"), gelu_deriv_out=gp)
         y2 = self.new(B * L, C)
-        ops.linear_fwd(self.compute, u, self.W(pre + ".pwconv2.weight"), y2, bias=self.P(pre + ".pwconv2.bias"), a_gelu=True)
+        ops.linear_fwd(self.compute, u, self.W(pre + ".pwconv2.weight"), y2, bias=self.P(pre + ".pwconv2.bias"), a_gelu=not train)
         out = self.new(B * L, C)
         ops.scale_residual(y2, self.P(pre + ".weight"), s, out, B * L, C)
-        return out, (dict(s=s, dw=dw, stats=stats, n=n, u=u, y2=y2) if train else None)
+        return out, (dict(s=s, dw=dw, stats=stats, n=n, u=u, gp=gp, y2=y2) if train else None)
 
     def convnext_bwd(self, pre, rec, g, B, H, W, C, time):
         L = H * W
         ops.colsum(g, self.G(pre + ".weight"), y=rec["y2"])
         d_y2 = self.new(B * L, C, dtype=self.adt)
         ops.scale_residual(g, self.P(pre + ".weight"), None, d_y2, B * L, C)
-        self.linear_bwd_params(pre + ".pwconv2.weight", pre + ".pwconv2.bias", d_y2, rec["u"], b_gelu=True)
+        self.linear_bwd_params(pre + ".pwconv2.weight", pre + ".pwconv2.bias", d_y2, rec["u"])
         d_u = self.new(B * L, 4 * C, dtype=self.adt)
-        ops.linear_dgrad(self.compute, d_y2, self.W(pre + ".pwconv2.weight"), d_u, aux=rec["u"])
+        ops.linear_dgrad(self.compute, d_y2, self.W(pre + ".pwconv2.weight"), d_u, aux=rec["gp"], aux_mul=True)
         self.linear_bwd_params(pre + ".pwconv1.weight", pre + ".pwconv1.bias", d_u, rec["n"])
         d_n = self.new(B * L, C, dtype=self.adt)
         ops.linear_dgrad(self.compute, d_u, self.W(pre + ".pwconv1.weight"), d_n)

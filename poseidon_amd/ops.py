@@ -66,28 +66,29 @@ def workspace():
 
 def gemm(layout: int, compute: int, M: int, N: int, K: int, A, lda: int, B, ldb: int, C, ldc: int, *, bias=None,
          colscale=None, aux=None, ldaux: int = 0, resid=None, ldres: int = 0, a_gelu: bool = False, b_gelu: bool = False,
-         accumulate: bool = False, colsum_out=None) -> None:
+         accumulate: bool = False, colsum_out=None, aux_mul: bool = False, gelu_deriv_out=None) -> None:
     """scot_gemm — see include/scot_hip.h."""
     rc = L().scot_gemm(layout, compute, M, N, K, ptr(A), dt(A), lda, int(a_gelu), ptr(B), dt(B), ldb, int(b_gelu),
                        ptr(C), dt(C), ldc, ptr(bias), ptr(colscale), ptr(aux), dt(aux) if aux is not None else 0, ldaux,
                        ptr(resid), dt(resid) if resid is not None else 0, ldres, int(accumulate), ptr(colsum_out),
-                       workspace().data_ptr() if layout == TN else None, WORKSPACE_BYTES if layout == TN else 0, stream())
+                       workspace().data_ptr() if layout == TN else None, WORKSPACE_BYTES if layout == TN else 0,
+                       int(aux_mul), ptr(gelu_deriv_out), stream())
     _lib.check(rc, "scot_gemm")
 
 
-def linear_fwd(compute, x, w, out, bias=None, a_gelu=False, K=None):
-    """out[M,N] = act(x)[M,K] @ w[N,K]^T + bias."""
+def linear_fwd(compute, x, w, out, bias=None, a_gelu=False, gelu_deriv_out=None):
+    """out[M,N] = act(x)[M,K] @ w[N,K]^T + bias;  with gelu_deriv_out: out = gelu(.), gelu_deriv_out = gelu'(.)."""
     M = x.numel() // x.shape[-1]
     N, Kw = w.shape[0], w.numel() // w.shape[0]
-    gemm(NT, compute, M, N, Kw, x, x.shape[-1], w, Kw, out, out.shape[-1], bias=bias, a_gelu=a_gelu)
+    gemm(NT, compute, M, N, Kw, x, x.shape[-1], w, Kw, out, out.shape[-1], bias=bias, a_gelu=a_gelu, gelu_deriv_out=gelu_deriv_out)
 
 
-def linear_dgrad(compute, dy, w, dx, accumulate=False, aux=None):
-    """dx[M,K] (+)= dy[M,N] @ w[N,K]  (* gelu'(aux))."""
+def linear_dgrad(compute, dy, w, dx, accumulate=False, aux=None, aux_mul=False):
+    """dx[M,K] (+)= dy[M,N] @ w[N,K]  (* gelu'(aux), or * aux when aux_mul)."""
     M = dy.numel() // dy.shape[-1]
     N, K = w.shape[0], w.numel() // w.shape[0]
     gemm(NN, compute, M, K, N, dy, dy.shape[-1], w, K, dx, dx.shape[-1], aux=aux, ldaux=aux.shape[-1] if aux is not None else 0,
-         accumulate=accumulate)
+         accumulate=accumulate, aux_mul=aux_mul)
 
 
 def linear_wgrad(compute, dy, x, dw, b_gelu=False, dbias=None):

@@ -100,6 +100,17 @@ def test_gemm_epilogues(compute):
     db2 = torch.zeros(K, device=DEV)
     ops.colsum(dy, db2)
     assert rel(db2, dy.double().sum(0)) < 1e-5
+    # fc1 with the dual epilogue: a = gelu(u), gp = gelu'(u);  dgrad with aux_mul multiplies by gp as is
+    a_ = torch.empty(M, N, device=DEV, dtype=cdt)
+    gp_ = torch.empty(M, N, device=DEV, dtype=cdt)
+    ops.linear_fwd(compute, x, w, a_, bias=b, gelu_deriv_out=gp_)
+    u64 = x.double() @ w.double().t() + b.double()
+    gp64 = 0.5 * (1 + torch.erf(u64 / math.sqrt(2))) + u64 * torch.exp(-0.5 * u64 * u64) / math.sqrt(2 * math.pi)
+    assert rel(a_, torch.nn.functional.gelu(u64)) < tol
+    assert rel(gp_, gp64) < tol
+    du2 = torch.empty(M, N, device=DEV, dtype=cdt)
+    ops.linear_dgrad(compute, dy, w2, du2, aux=gp_, aux_mul=True)
+    assert rel(du2, (dy.double() @ w2.double()) * gp_.double()) < tol
 
 
 # ----------------------------------------------------------------------------------------------- attention
@@ -170,11 +181,12 @@ def test_window_attention_fwd_bwd(compute, case):
     ref = _attn_ref(q64, t64, l64, B, Hp, Wp, C, heads, ws, shift)
     ref.backward(dout.double())
     tol_o, tol_g = (2e-5, 5e-5) if compute == ops.F32 else (2e-2, 4e-2)
+    tol_ls = 2e-4 if compute == ops.F32 else 0.15  # Σ_k dS = 0: d logit_scale is a heavily cancelling sum
     assert rel(out, ref.detach()) < tol_o, "out"
     assert rel(dqkv, q64.grad) < tol_g, "dqkv"
     assert rel(dtab, t64.grad) < tol_g, "dbias_table"
     # d logit_scale is a heavily cancelling sum over all (q,k) pairs: bf16 operand rounding shows up amplified
-    assert rel(dls, l64.grad) < (tol_g if compute == ops.F32 else 0.15), "dlogit_scale"
+    assert rel(dls, l64.grad) < tol_ls, "dlogit_scale"
 
 
 # ----------------------------------------------------------------------------------------------- CLN

@@ -39,7 +39,7 @@ def main():
     ops.L()
     B = 64
     only = sys.argv[1] if len(sys.argv) > 1 else ""
-    for s, (L, C) in [] if only else enumerate([(1024, 96), (256, 192), (64, 384), (16, 768)]):
+    for s, (L, C) in ([(0, (1024, 96))] if only == "gemm0" else [] if only else list(enumerate([(1024, 96), (256, 192), (64, 384), (16, 768)]))):
         M = B * L
         gemm_case(ops.NT, M, 3 * C, C, tag=f"qkv s{s}")
         gemm_case(ops.NT, M, C, C, out=torch.float32, tag=f"proj s{s}")
