@@ -148,7 +148,7 @@ def main():
         raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}")
     torch.cuda.set_device(local)
     dist = None
-    if world > 1:
+    if world > 1 or "RANK" in os.environ:   # under torchrun the collective path is exercised even with one rank
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
@@ -179,7 +179,7 @@ def main():
     tt = torch.randint(0, 8, (B,), device="cuda").float() / 10.0
     kw = dict(pixel_values=pv, time=tt, labels=lab)
 
-    reducer = GradAllReducer(model, dist, wire=a.wire) if world > 1 else None
+    reducer = GradAllReducer(model, dist, wire=a.wire) if dist is not None else None
     loss_buf = torch.zeros((), device="cuda")
 
     def compute_step():

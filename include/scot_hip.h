@@ -65,6 +65,13 @@ int scot_cpb_fwd(const float* coords, const float* w0, const float* b0, const fl
 int scot_cpb_bwd(const float* coords, const float* w0, const float* b0, const float* w2, const float* z,
                  const float* dtable, float* dw0, float* db0, float* dw2, int ws, int heads, scot_stream_t stream);
 
+/* Same MLP for MANY layers in one launch.  desc[l] = {w0_off, b0_off, w2_off, coords_off, ws, heads, tab_off, z_off}
+ * (int32, offsets in floats from params / coords_base / tables / zbuf; grads uses the params offsets). */
+int scot_cpb_fwd_batched(const float* params, const int* desc, int nlayers, int max_ws, const float* coords_base,
+                         float* tables, float* zbuf, scot_stream_t stream);
+int scot_cpb_bwd_batched(const float* params, const int* desc, int first, int count, const float* coords_base,
+                         const float* zbuf, const float* dtables, float* grads, scot_stream_t stream);
+
 /* ConditionalLayerNorm / LayerNorm (+ fused residual), ref:135-160, res-post-norm ref:570,574. */
 int scot_cln_fwd(const void* x, int x_dt, const void* resid, int res_dt, void* out, int out_dt, void* out2, int out2_dt,
                  float* mean, float* rstd,
@@ -73,8 +80,9 @@ int scot_cln_fwd(const void* x, int x_dt, const void* resid, int res_dt, void* o
 int scot_cln_bwd(const void* dout, int dout_dt, const void* x, int x_dt, const float* mean, const float* rstd,
                  const float* time, const float* gw_w, const float* gw_b, void* dx, int dx_dt, float* d_gw_w,
                  float* d_gw_b, float* d_bw_w, float* d_bw_b, float* d_xbias, int rows, int rows_per_sample, int C,
-                 scot_stream_t stream);
-/* out2: optional second copy of the output in the next GEMM's operand dtype; d_xbias: optional += Σ_rows dx. */
+                 void* workspace, size_t ws_bytes, scot_stream_t stream);
+/* out2: optional second copy of the output in the next GEMM's operand dtype; d_xbias: optional += Σ_rows dx;
+ * workspace: optional scratch for per-block column sums (avoids 4·C same-address atomics per block). */
 
 /* Data movement */
 int scot_add(const void* a, int a_dt, const void* b, int b_dt, void* out, int out_dt, size_t n, size_t period,

@@ -109,14 +109,17 @@ __device__ __forceinline__ void fstore(CT* tile, const uint4 (&st)[NCH], int k0,
   }
 }
 
-template <typename CT, int BM, int BN, int LAYOUT>
+// WM x WN = arrangement of the 4 waves over the BM x BN tile (WM*WN == 4); each wave owns (BM/WM) x (BN/WN).
+template <typename CT, int BM, int BN, int WM, int WN, int LAYOUT>
 __global__ __launch_bounds__(256) void gemm_fast_kernel(FastArgs p) {
+  static_assert(WM * WN == 4, "4 waves per workgroup");
   constexpr bool A_KC = (LAYOUT != LAYOUT_TN);
   constexpr bool B_KC = (LAYOUT == LAYOUT_NT);
   using TA = FTile<CT, BM, A_KC>;
   using TB = FTile<CT, BN, B_KC>;
   constexpr int BK = FT<CT>::BK;
-  constexpr int MI = BM / 32, NI = BN / 32;
+  constexpr int MI = BM / (16 * WM), NI = BN / (16 * WN);
+  constexpr int WROWS = BM / WM, WCOLS = BN / WN;
   constexpr int STAGE = TA::elems + TB::elems;
   constexpr int CP = BN + 4;                                  // C tile pitch (floats)
   constexpr size_t LDS_AB = 2 * STAGE * sizeof(CT), LDS_C = (size_t)BM * CP * sizeof(float) + BN * sizeof(float);
@@ -125,7 +128,7 @@ __global__ __launch_bounds__(256) void gemm_fast_kernel(FastArgs p) {
   CT* lds = (CT*)smem;
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int wr = wave >> 1, wc = wave & 1, g = lane >> 4;
+  const int wr = wave / WN, wc = wave % WN, g = lane >> 4;
   const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
   const int kbeg = blockIdx.z * p.ksplit;
   const int kend = min(p.K, kbeg + p.ksplit);
@@ -159,13 +162,13 @@ __global__ __launch_bounds__(256) void gemm_fast_kernel(FastArgs p) {
       Frag<CT> fa[MI], fb[NI];
 #pragma unroll
       for (int i = 0; i < MI; ++i) {
-        const int r0 = wr * (BM / 2) + i * 16;
+        const int r0 = wr * WROWS + i * 16;
         if (A_KC) fa[i] = lds_frag_kc(As, TA::pitch, r0, kk, lane);
         else fa[i] = lds_frag_ks(As, TA::pitch, r0, kk + g * 8, kk + g * 8 + 4, lane, p.use_tr);
       }
 #pragma unroll
       for (int j = 0; j < NI; ++j) {
-        const int c0 = wc * (BN / 2) + j * 16;
+        const int c0 = wc * WCOLS + j * 16;
         if (B_KC) fb[j] = lds_frag_kc(Bs, TB::pitch, c0, kk, lane);
         else fb[j] = lds_frag_ks(Bs, TB::pitch, c0, kk + g * 8, kk + g * 8 + 4, lane, p.use_tr);
       }
@@ -217,13 +220,15 @@ __global__ __launch_bounds__(256) void gemm_fast_kernel(FastArgs p) {
     for (int j = 0; j < NI; ++j)
 #pragma unroll
       for (int r = 0; r < 4; ++r)
-        Cs[(wr * (BM / 2) + i * 16 + g * 4 + r) * CP + wc * (BN / 2) + j * 16 + (lane & 15)] = acc[i][j][r];
+        Cs[(wr * WROWS + i * 16 + g * 4 + r) * CP + wc * WCOLS + j * 16 + (lane & 15)] = acc[i][j][r];
   const bool want_colsum = (LAYOUT != LAYOUT_TN) && p.colsum_out != nullptr;
   if (want_colsum && tid < BN) colacc[tid] = 0.f;
   __syncthreads();
 
-  constexpr int CPRW = BN / 8;  // 8-column chunks per tile row
-  const int cc = tid % CPRW;    // constant per thread because 256 % CPRW == 0
+  constexpr int CPRW = BN / 8;            // 8-column chunks per tile row
+  constexpr int RPP = 256 / CPRW;         // rows per pass; threads >= RPP*CPRW idle (BN = 96: 252 of 256 active)
+  const int cc = tid % CPRW;              // constant per thread over the row loop
+  const bool ep_active = tid < RPP * CPRW;
   const int col = n0 + cc * 8;
   float csum[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
   float bv[8], sv[8];
@@ -233,22 +238,25 @@ __global__ __launch_bounds__(256) void gemm_fast_kernel(FastArgs p) {
     bv[j] = (p.bias && ok && blockIdx.z == 0) ? p.bias[col + j] : 0.f;
     sv[j] = (p.colscale && ok) ? p.colscale[col + j] : 1.f;
   }
-  if (col < p.N) {
-    for (int row = tid / CPRW; row < BM; row += 256 / CPRW) {
+  if (col < p.N && ep_active) {
+    for (int row = tid / CPRW; row < BM; row += RPP) {
       const int grow = m0 + row;
       if (grow >= p.M) break;
       float v[8];
       const float4 a = *(const float4*)(Cs + row * CP + cc * 8), b = *(const float4*)(Cs + row * CP + cc * 8 + 4);
       v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
+      const bool partial = (LAYOUT != LAYOUT_TN) && p.ws != nullptr;
+      if (!partial) {
 #pragma unroll
-      for (int j = 0; j < 8; ++j) v[j] = (v[j] + bv[j]) * sv[j];
-      if (p.aux_gelu_grad) {
+        for (int j = 0; j < 8; ++j) v[j] = (v[j] + bv[j]) * sv[j];
+      }
+      if (p.aux_gelu_grad && !partial) {
         float x[8];
         ld8(p.aux, p.aux_dt, (size_t)grow * p.ldaux + col, x);
 #pragma unroll
         for (int j = 0; j < 8; ++j) v[j] *= p.aux_mul ? x[j] : gelu_grad_f(x[j]);
       }
-      if (p.resid) {
+      if (p.resid && !partial) {
         float x[8];
         ld8(p.resid, p.res_dt, (size_t)grow * p.ldres + col, x);
 #pragma unroll
@@ -268,6 +276,8 @@ __global__ __launch_bounds__(256) void gemm_fast_kernel(FastArgs p) {
 #pragma unroll
           for (int j = 0; j < 8; ++j) atomicAdd((float*)p.C + ci + j, v[j]);
         }
+      } else if (p.ws) {   // NT/NN split-K: raw partial sums; bias/aux/resid are applied by splitk_epilogue_kernel
+        st8(p.ws + (size_t)blockIdx.z * p.M * p.N, SCOT_F32, (size_t)grow * p.N + col, v);
       } else if (p.C2) {
         float gv[8], gd[8];
 #pragma unroll
@@ -513,28 +523,81 @@ __global__ void splitk_reduce_kernel(const float* __restrict__ ws, float* C, int
   }
 }
 
-template <typename CT, int BM, int BN>
+// NT/NN split-K: C = epilogue(Σ_z ws[z])  — same epilogue as the GEMM kernels (bias, column scale, gelu' / aux, residual, dual GELU)
+__global__ void splitk_epilogue_kernel(FastArgs p, int nsplit) {
+  const size_t n8 = (size_t)p.M * p.N / 8;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n8; i += (size_t)gridDim.x * blockDim.x) {
+    const size_t e = i * 8;
+    const int m = e / p.N, n = e % p.N;
+    float v[8], t[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) v[j] = 0.f;
+    for (int z = 0; z < nsplit; ++z) {
+      ld8(p.ws + (size_t)z * p.M * p.N, SCOT_F32, e, t);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) v[j] += t[j];
+    }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) v[j] = (v[j] + (p.bias ? p.bias[n + j] : 0.f)) * (p.colscale ? p.colscale[n + j] : 1.f);
+    if (p.aux_gelu_grad) {
+      ld8(p.aux, p.aux_dt, (size_t)m * p.ldaux + n, t);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) v[j] *= p.aux_mul ? t[j] : gelu_grad_f(t[j]);
+    }
+    if (p.resid) {
+      ld8(p.resid, p.res_dt, (size_t)m * p.ldres + n, t);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) v[j] += t[j];
+    }
+    const size_t ci = (size_t)m * p.ldc + n;
+    if (p.C2) {
+      float gv[8], gd[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) { float cdf, ee; gelu_terms(v[j], cdf, ee); gv[j] = v[j] * cdf; gd[j] = cdf + v[j] * 0.3989422804014327f * ee; }
+      st8(p.C, p.c_dt, ci, gv);
+      st8(p.C2, p.c_dt, ci, gd);
+    } else {
+      st8(p.C, p.c_dt, ci, v);
+    }
+  }
+}
+
+template <typename CT, int BM, int BN, int WM, int WN>
 static int flaunch_layout(const FastArgs& a, int layout, int nsplit, hipStream_t s) {
   dim3 grid((a.N + BN - 1) / BN, (a.M + BM - 1) / BM, nsplit), block(256);
   switch (layout) {
-    case LAYOUT_NT: hipLaunchKernelGGL((gemm_fast_kernel<CT, BM, BN, LAYOUT_NT>), grid, block, 0, s, a); break;
-    case LAYOUT_NN: hipLaunchKernelGGL((gemm_fast_kernel<CT, BM, BN, LAYOUT_NN>), grid, block, 0, s, a); break;
-    case LAYOUT_TN: hipLaunchKernelGGL((gemm_fast_kernel<CT, BM, BN, LAYOUT_TN>), grid, block, 0, s, a); break;
+    case LAYOUT_NT: hipLaunchKernelGGL((gemm_fast_kernel<CT, BM, BN, WM, WN, LAYOUT_NT>), grid, block, 0, s, a); break;
+    case LAYOUT_NN: hipLaunchKernelGGL((gemm_fast_kernel<CT, BM, BN, WM, WN, LAYOUT_NN>), grid, block, 0, s, a); break;
+    case LAYOUT_TN: hipLaunchKernelGGL((gemm_fast_kernel<CT, BM, BN, WM, WN, LAYOUT_TN>), grid, block, 0, s, a); break;
     default: return SCOT_ERR_UNSUPPORTED;
   }
   return scot_check_launch();
+}
+// tile ids: 0 = 64x64 (2x2 waves), 1 = 128x96 (4x1), 2 = 64x96 (2x2), 3 = 128x128 (2x2), 4 = 96x96 (2x2)... bf16 only beyond 0/3
+template <typename CT> static int flaunch_tile(int tile, const FastArgs& a, int layout, int nsplit, hipStream_t s);
+template <> int flaunch_tile<bf16_t>(int tile, const FastArgs& a, int layout, int nsplit, hipStream_t s) {
+  switch (tile) {
+    case 1: return flaunch_layout<bf16_t, 128, 96, 4, 1>(a, layout, nsplit, s);
+    case 2: return flaunch_layout<bf16_t, 64, 96, 2, 2>(a, layout, nsplit, s);
+    case 3: return flaunch_layout<bf16_t, 128, 128, 2, 2>(a, layout, nsplit, s);
+    default: return flaunch_layout<bf16_t, 64, 64, 2, 2>(a, layout, nsplit, s);
+  }
+}
+template <> int flaunch_tile<float>(int tile, const FastArgs& a, int layout, int nsplit, hipStream_t s) {
+  return tile == 3 ? flaunch_layout<float, 128, 128, 2, 2>(a, layout, nsplit, s) : flaunch_layout<float, 64, 64, 2, 2>(a, layout, nsplit, s);
+}
+static void tile_dims(int tile, int& bm, int& bn) {
+  switch (tile) { case 1: bm = 128; bn = 96; break; case 2: bm = 64; bn = 96; break; case 3: bm = 128; bn = 128; break; default: bm = 64; bn = 64; }
 }
 
 extern int g_scot_use_tr;
 
 // Returns SCOT_ERR_UNSUPPORTED when the call does not qualify (the caller then uses the generic kernel).
-static int g_tile_override = -1;  // SCOT_GEMM_TILE=64|128 (experiments)
 
 int scot_gemm_fast(int layout, int compute, int M, int N, int K, const void* A, int a_dt, int lda, int a_gelu,
                    const void* B, int b_dt, int ldb, int b_gelu, void* C, int c_dt, int ldc, const float* bias,
                    const float* colscale, const void* aux, int aux_dt, int ldaux, const void* resid, int res_dt, int ldres,
                    int accumulate, float* colsum_out, void* workspace, size_t ws_bytes, int aux_mul, void* C2, hipStream_t stream) {
-  if (g_tile_override < 0) { const char* e = getenv("SCOT_GEMM_TILE"); g_tile_override = e ? atoi(e) : 0; }
   const int want = compute == SCOT_BF16 ? SCOT_BF16 : SCOT_F32;
   const int epc = compute == SCOT_BF16 ? 8 : 4;
   if (a_dt != want || b_dt != want) return SCOT_ERR_UNSUPPORTED;
@@ -552,15 +615,27 @@ int scot_gemm_fast(int layout, int compute, int M, int N, int K, const void* A, 
   const int bk = compute == SCOT_BF16 ? 64 : 32;
   int nsplit = 1;
   a.ksplit = ((K + bk - 1) / bk) * bk;
-  bool big;
+  // tile choice: SCOT_GEMM_TILE[_NT|_NN|_TN] = 0..3 forces a shape (tuning), otherwise the per-layout policy below
+  static int ov[4] = {-2, -2, -2, -2};
+  if (ov[3] == -2) {
+    const char* names[4] = {"SCOT_GEMM_TILE_NT", "SCOT_GEMM_TILE_NN", "SCOT_GEMM_TILE_TN", "SCOT_GEMM_TILE"};
+    for (int i = 0; i < 4; ++i) { const char* e = getenv(names[i]); ov[i] = e ? atoi(e) : -1; }
+  }
+  int tile = ov[layout] >= 0 ? ov[layout] : (ov[3] >= 0 ? ov[3] : -1);
+  if (tile < 0) {
+    tile = 0;   // policy (see DESIGN.md §3 for the measurements behind it)
+    if (compute == SCOT_BF16 && N == 96) tile = 2;   // one 64x96 column tile: the A operand streams once (64x64 would read it twice)
+  }
+  if (compute != SCOT_BF16 && tile != 0 && tile != 3) tile = 0;   // fp32 instantiates 64x64 and 128x128 only
+  int bm, bn;
+  tile_dims(tile, bm, bn);
+  const long tiles = (long)((M + bm - 1) / bm) * ((N + bn - 1) / bn);
+  const long nkt = (K + bk - 1) / bk;
   if (layout == LAYOUT_TN) {
     // wgrad: small output, contraction over all tokens.  Split K so that ~512 workgroups stream the operands; each split
     // writes a partial tile into the workspace and ONE reduce pass adds them into the gradient (12.6 M fp32 atomics per
     // call in the first version of this kernel cost 300 us; the partials cost < 20 MB of traffic).
     if (c_dt != SCOT_F32 || !accumulate) return SCOT_ERR_UNSUPPORTED;
-    const long t128 = (long)((M + 127) / 128) * ((N + 127) / 128);
-    big = g_tile_override == 128 && M >= 128 && N >= 64;   // measured: the 64x64 tile (4 workgroups/CU) wins every scOT shape
-    const long tiles = big ? t128 : (long)((M + 63) / 64) * ((N + 63) / 64);
     long wantsplit = (512 + tiles - 1) / tiles;
     const long maxsplit = (K + 8 * bk - 1) / (8 * bk);       // >= 8 K-tiles per workgroup
     long wsmax = workspace ? (long)(ws_bytes / ((size_t)M * N * sizeof(float))) : 1;
@@ -578,21 +653,36 @@ int scot_gemm_fast(int layout, int compute, int M, int N, int K, const void* A, 
       if (resid != nullptr) return SCOT_ERR_UNSUPPORTED;
       a.resid = C; a.res_dt = c_dt; a.ldres = ldc;
     }
-    const long t128 = (long)((M + 127) / 128) * ((N + 127) / 128);
-    big = g_tile_override == 128 && t128 >= 192 && M >= 128 && N >= 64;   // see above
+    // small grids with a long contraction (stage-3 fc2 / dgrad: 192 workgroups x 48 K-tiles = one latency-bound workgroup
+    // per CU): split K over more workgroups, partial sums through the workspace, epilogue in the reduce pass.
+    // Measured: pays from K >= 1536 (24 K-tiles); at K = 768 the extra pass costs more than it hides.
+    static int nt_split = -1;
+    if (nt_split < 0) { const char* e = getenv("SCOT_GEMM_NT_SPLIT"); nt_split = e ? atoi(e) : 1; }
+    if (nt_split && !colsum_out && workspace && (((uintptr_t)workspace & 31) == 0) && tiles < 512 && nkt >= 24) {
+      long want = (1024 + tiles - 1) / tiles;
+      long maxs = nkt / 4;
+      long wsmax = (long)(ws_bytes / ((size_t)M * N * sizeof(float)));
+      long ns = want < maxs ? want : maxs;
+      if (ns > wsmax) ns = wsmax;
+      if (ns >= 2) {
+        int per = (int)((K + ns - 1) / ns);
+        per = ((per + bk - 1) / bk) * bk;
+        a.ksplit = per;
+        nsplit = (K + per - 1) / per;
+        a.ws = (float*)workspace;
+      }
+    }
   }
   static int persist = -1;
-  if (persist < 0) { const char* e = getenv("SCOT_GEMM_PERSIST"); persist = e ? atoi(e) : 0; }   // measured: no gain over one tile per workgroup (kept for experiments)
-  if (layout != LAYOUT_TN && !big && persist)
+  if (persist < 0) { const char* e = getenv("SCOT_GEMM_PERSIST"); persist = e ? atoi(e) : 0; }   // measured: no gain (kept for experiments)
+  if (layout != LAYOUT_TN && tile == 0 && persist && nsplit == 1)
     return compute == SCOT_BF16 ? flaunch_persist<bf16_t>(a, layout, stream) : flaunch_persist<float>(a, layout, stream);
-  int rc;
-  if (compute == SCOT_BF16) rc = big ? flaunch_layout<bf16_t, 128, 128>(a, layout, nsplit, stream)
-                                     : flaunch_layout<bf16_t, 64, 64>(a, layout, nsplit, stream);
-  else rc = big ? flaunch_layout<float, 128, 128>(a, layout, nsplit, stream) : flaunch_layout<float, 64, 64>(a, layout, nsplit, stream);
+  int rc = compute == SCOT_BF16 ? flaunch_tile<bf16_t>(tile, a, layout, nsplit, stream) : flaunch_tile<float>(tile, a, layout, nsplit, stream);
   if (rc == SCOT_OK && a.ws) {
     const size_t n8 = (size_t)M * N / 8;
     size_t blocks = (n8 + 255) / 256; if (blocks > 2048) blocks = 2048;
-    hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, a.ws, (float*)C, M, N, ldc, nsplit);
+    if (layout == LAYOUT_TN) hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, a.ws, (float*)C, M, N, ldc, nsplit);
+    else hipLaunchKernelGGL(splitk_epilogue_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, a, nsplit);
     rc = scot_check_launch();
   }
   return rc;

@@ -651,6 +651,124 @@ __global__ __launch_bounds__(256) void cpb_bwd_kernel(const float* coords, const
     }
   }
 }
+// ---- batched over layers: the CPB MLP is batch-independent and layer-parallel, so all layers of a step (64 for
+// Poseidon-B) go in ONE launch instead of 64 (rocprof round 1: 64 x 43 us of mostly launch-latency-bound bwd kernels).
+// desc[l] = {w0_off, b0_off, w2_off, coords_off, ws, heads, tab_off, z_off}; offsets in floats from the given bases.
+__global__ __launch_bounds__(256) void cpb_fwd_batched_kernel(const float* params, const int* desc, const float* coords_base,
+                                                              float* tables, float* zbuf) {
+  const int* d = desc + 8 * blockIdx.y;
+  const int ws = d[4], heads = d[5];
+  const int TS = (2 * ws - 1) * (2 * ws - 1);
+  if ((int)blockIdx.x >= TS) return;
+  __shared__ float red[4];
+  const float* coords = coords_base + d[3];
+  const float* w0 = params + d[0];
+  const float* b0 = params + d[1];
+  const float* w2 = params + d[2];
+  float* table = tables + d[6];
+  float* z = zbuf + d[7];
+  const int e = blockIdx.x;
+  const float cy = coords[2 * e], cx = coords[2 * e + 1];
+  float hid[2];
+#pragma unroll
+  for (int k = 0; k < 2; ++k) {
+    const int j = threadIdx.x + 256 * k;
+    hid[k] = fmaxf(w0[2 * j] * cy + w0[2 * j + 1] * cx + b0[j], 0.f);
+  }
+  for (int h = 0; h < heads; ++h) {
+    float acc = hid[0] * w2[h * 512 + threadIdx.x] + hid[1] * w2[h * 512 + threadIdx.x + 256];
+    acc = wave_sum(acc);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      const float zz = red[0] + red[1] + red[2] + red[3];
+      z[(size_t)e * heads + h] = zz;
+      table[(size_t)h * TS + e] = 16.0f / (1.0f + __expf(-zz));
+    }
+    __syncthreads();
+  }
+}
+__global__ __launch_bounds__(256) void cpb_bwd_batched_kernel(const float* params, const int* desc, int first, const float* coords_base,
+                                                              const float* zbuf, const float* dtables, float* grads) {
+  const int* d = desc + 8 * (first + blockIdx.y);
+  const int ws = d[4], heads = d[5];
+  const int TS = (2 * ws - 1) * (2 * ws - 1);
+  __shared__ float red[4];
+  const float* coords = coords_base + d[3];
+  const float* w0 = params + d[0];
+  const float* b0 = params + d[1];
+  const float* w2 = params + d[2];
+  const float* z = zbuf + d[7];
+  const float* dtable = dtables + d[6];
+  float* dw0 = grads + d[0];
+  float* db0 = grads + d[1];
+  float* dw2 = grads + d[2];
+  const int j0 = blockIdx.x * CPB_JB;
+  float a_w2[CPB_JB][24], a_w0y[CPB_JB], a_w0x[CPB_JB], a_b0[CPB_JB];
+#pragma unroll
+  for (int jj = 0; jj < CPB_JB; ++jj) {
+    a_w0y[jj] = a_w0x[jj] = a_b0[jj] = 0.f;
+#pragma unroll
+    for (int h = 0; h < 24; ++h) a_w2[jj][h] = 0.f;
+  }
+  for (int e = threadIdx.x; e < TS; e += 256) {
+    const float cy = coords[2 * e], cx = coords[2 * e + 1];
+    float dz[24];
+#pragma unroll
+    for (int h = 0; h < 24; ++h) {
+      dz[h] = 0.f;
+      if (h < heads) {
+        const float sg = 1.0f / (1.0f + __expf(-z[(size_t)e * heads + h]));
+        dz[h] = dtable[(size_t)h * TS + e] * 16.0f * sg * (1.0f - sg);
+      }
+    }
+#pragma unroll
+    for (int jj = 0; jj < CPB_JB; ++jj) {
+      const int j = j0 + jj;
+      const float pre = w0[2 * j] * cy + w0[2 * j + 1] * cx + b0[j];
+      const float hid = fmaxf(pre, 0.f);
+      float dh = 0.f;
+#pragma unroll
+      for (int h = 0; h < 24; ++h) {
+        if (h < heads) { a_w2[jj][h] += dz[h] * hid; dh += dz[h] * w2[h * 512 + j]; }
+      }
+      const float dpre = pre > 0.f ? dh : 0.f;
+      a_w0y[jj] += dpre * cy; a_w0x[jj] += dpre * cx; a_b0[jj] += dpre;
+    }
+  }
+  auto block_sum = [&](float v) -> float {
+    v = wave_sum(v);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+    __syncthreads();
+    return red[0] + red[1] + red[2] + red[3];
+  };
+#pragma unroll
+  for (int jj = 0; jj < CPB_JB; ++jj) {
+    const int j = j0 + jj;
+    float v = block_sum(a_w0y[jj]); if (threadIdx.x == 0) dw0[2 * j] += v;
+    v = block_sum(a_w0x[jj]); if (threadIdx.x == 0) dw0[2 * j + 1] += v;
+    v = block_sum(a_b0[jj]); if (threadIdx.x == 0) db0[j] += v;
+#pragma unroll
+    for (int h = 0; h < 24; ++h) {
+      if (h < heads) { v = block_sum(a_w2[jj][h]); if (threadIdx.x == 0) dw2[h * 512 + j] += v; }
+    }
+  }
+}
+extern "C" int scot_cpb_fwd_batched(const float* params, const int* desc, int nlayers, int max_ws, const float* coords_base,
+                                    float* tables, float* zbuf, hipStream_t s) {
+  if (nlayers <= 0 || max_ws <= 0) return SCOT_ERR_SHAPE;
+  const int TS = (2 * max_ws - 1) * (2 * max_ws - 1);
+  hipLaunchKernelGGL(cpb_fwd_batched_kernel, dim3(TS, nlayers), dim3(256), 0, s, params, desc, coords_base, tables, zbuf);
+  return scot_check_launch();
+}
+extern "C" int scot_cpb_bwd_batched(const float* params, const int* desc, int first, int count, const float* coords_base,
+                                    const float* zbuf, const float* dtables, float* grads, hipStream_t s) {
+  if (count <= 0) return SCOT_ERR_SHAPE;
+  hipLaunchKernelGGL(cpb_bwd_batched_kernel, dim3(512 / CPB_JB, count), dim3(256), 0, s, params, desc, first, coords_base, zbuf,
+                     dtables, grads);
+  return scot_check_launch();
+}
 extern "C" int scot_cpb_fwd(const float* coords, const float* w0, const float* b0, const float* w2, float* table, float* z,
                             int ws, int heads, hipStream_t s) {
   const int TS = (2 * ws - 1) * (2 * ws - 1);

@@ -137,9 +137,10 @@ struct ClnFastArgs {  // must match norm_fast.hip
   const void* dout; void* dx; int dout_dt, dx_dt;
   float* d_gw_w; float* d_gw_b; float* d_bw_w; float* d_bw_b; float* d_xbias;
   int rpb, chunks_per_sample;
+  float* partials;
 };
 int scot_cln_fwd_fast(ClnFastArgs a, hipStream_t s);
-int scot_cln_bwd_fast(ClnFastArgs a, hipStream_t s);
+int scot_cln_bwd_fast(ClnFastArgs a, void* workspace, size_t ws_bytes, hipStream_t s);
 extern "C" int scot_colsum(const void* x, int x_dt, const void* y, int y_dt, float* out, int M, int N, int ld, hipStream_t s);
 extern "C" int scot_scale_residual(const void* y, int y_dt, const float* scale, const void* resid, int r_dt, void* out, int o_dt,
                                    size_t rows, int N, hipStream_t s);
@@ -174,7 +175,7 @@ extern "C" int scot_cln_fwd(const void* x, int x_dt, const void* resid, int res_
 extern "C" int scot_cln_bwd(const void* dout, int dout_dt, const void* x, int x_dt, const float* mean, const float* rstd,
                             const float* time, const float* gw_w, const float* gw_b, void* dx, int dx_dt,
                             float* d_gw_w, float* d_gw_b, float* d_bw_w, float* d_bw_b, float* d_xbias, int rows,
-                            int rows_per_sample, int C, hipStream_t stream) {
+                            int rows_per_sample, int C, void* workspace, size_t ws_bytes, hipStream_t stream) {
   if (rows <= 0 || C <= 0 || rows_per_sample <= 0 || rows % rows_per_sample) return SCOT_ERR_SHAPE;
   if (!gw_b || !d_gw_b || !d_bw_b || (gw_w && (!time || !d_gw_w || !d_bw_w))) return SCOT_ERR_SHAPE;
   {
@@ -183,7 +184,7 @@ extern "C" int scot_cln_bwd(const void* dout, int dout_dt, const void* x, int x_
     f.gw_w = gw_w; f.gw_b = gw_b; f.dx = dx; f.dx_dt = dx_dt;
     f.d_gw_w = gw_w ? d_gw_w : nullptr; f.d_gw_b = d_gw_b; f.d_bw_w = gw_w ? d_bw_w : nullptr; f.d_bw_b = d_bw_b; f.d_xbias = d_xbias;
     f.rows = rows; f.rows_per_sample = rows_per_sample; f.C = C;
-    const int rc = scot_cln_bwd_fast(f, stream);
+    const int rc = scot_cln_bwd_fast(f, workspace, ws_bytes, stream);
     if (rc != SCOT_ERR_UNSUPPORTED) return rc;
   }
   ClnArgs a{};

@@ -8,6 +8,7 @@
 //   dgamma/dbeta (→ the four cond-LN parameter gradients, reference model.py:147-148) and
 //   Σ_rows dx (→ the bias gradient of the Linear that produced x; saves a separate column-sum pass over dx).
 #include "common.h"
+#include <stdlib.h>
 
 struct ClnFastArgs {
   const void* x; const void* resid; void* out; void* out2; float* mean; float* rstd;
@@ -18,6 +19,7 @@ struct ClnFastArgs {
   const void* dout; void* dx; int dout_dt, dx_dt;
   float* d_gw_w; float* d_gw_b; float* d_bw_w; float* d_bw_b; float* d_xbias;
   int rpb, chunks_per_sample;
+  float* partials;   // optional [nblocks][3][C] scratch: per-block column sums, combined by cln_bwd_finalize_kernel
 };
 
 template <int LPR> __device__ __forceinline__ float group_sum(float v) {
@@ -155,12 +157,50 @@ __global__ __launch_bounds__(256) void cln_bwd_fast_kernel(ClnFastArgs p) {
       }
     }
   __syncthreads();
+  if (p.partials) {   // no global atomics: 4·C same-address atomics per block were the whole cost of this kernel (25 us floor)
+    float* dst = p.partials + (size_t)blockIdx.x * 3 * C;
+    for (int c = threadIdx.x; c < C; c += 256) { dst[c] = red[0][c]; dst[C + c] = red[1][c]; dst[2 * C + c] = red[2][c]; }
+    return;
+  }
   for (int c = threadIdx.x; c < C; c += 256) {
     const float dg = red[0][c], db = red[1][c];
     if (p.d_gw_w) { atomicAdd(&p.d_gw_w[c], t * dg); atomicAdd(&p.d_bw_w[c], t * db); }
     atomicAdd(&p.d_gw_b[c], dg);
     atomicAdd(&p.d_bw_b[c], db);
     if (p.d_xbias) atomicAdd(&p.d_xbias[c], red[2][c]);
+  }
+}
+
+// workgroup = 32 columns x 8 slices of the block list; every thread sums its slice (independent, coalesced loads), the 8
+// slices are combined through LDS and the column owner adds into the parameter gradients (single writer, no atomics)
+__global__ __launch_bounds__(256) void cln_bwd_finalize_kernel(ClnFastArgs p, int nblocks) {
+  __shared__ float red[5][8][32];
+  const int lc = threadIdx.x & 31, part = threadIdx.x >> 5;
+  const int c = blockIdx.x * 32 + lc;
+  float gw = 0.f, gb = 0.f, bw = 0.f, bb = 0.f, xb = 0.f;
+  if (c < p.C) {
+#pragma unroll 4
+    for (int blk = part; blk < nblocks; blk += 8) {
+      const float* src = p.partials + (size_t)blk * 3 * p.C;
+      const float t = p.time ? p.time[blk / p.chunks_per_sample] : 0.f;
+      const float dg = src[c], db = src[p.C + c];
+      gw += t * dg; gb += dg; bw += t * db; bb += db; xb += src[2 * p.C + c];
+    }
+  }
+  red[0][part][lc] = gw; red[1][part][lc] = gb; red[2][part][lc] = bw; red[3][part][lc] = bb; red[4][part][lc] = xb;
+  __syncthreads();
+  if (part == 0 && c < p.C) {
+    float v[5];
+#pragma unroll
+    for (int k = 0; k < 5; ++k) {
+      v[k] = 0.f;
+#pragma unroll
+      for (int q = 0; q < 8; ++q) v[k] += red[k][q][lc];
+    }
+    if (p.d_gw_w) { p.d_gw_w[c] += v[0]; p.d_bw_w[c] += v[2]; }
+    p.d_gw_b[c] += v[1];
+    p.d_bw_b[c] += v[3];
+    if (p.d_xbias) p.d_xbias[c] += v[4];
   }
 }
 
@@ -194,11 +234,24 @@ int scot_cln_fwd_fast(ClnFastArgs a, hipStream_t s) {
   CLN_DISPATCH(launch_fwd)
   return scot_check_launch();
 }
-int scot_cln_bwd_fast(ClnFastArgs a, hipStream_t s) {
+int scot_cln_bwd_fast(ClnFastArgs a, void* workspace, size_t ws_bytes, hipStream_t s) {
   if (a.C % 8 || !aligned16(a.x) || !aligned16(a.dout) || !aligned16(a.dx) || !aligned16(a.gw_w) || !aligned16(a.gw_b))
     return SCOT_ERR_UNSUPPORTED;
-  a.rpb = a.rows_per_sample < 256 ? a.rows_per_sample : 256;
+  static int rpb_env = -1;
+  if (rpb_env < 0) { const char* e = getenv("SCOT_CLN_RPB"); rpb_env = e ? atoi(e) : 128; }
+  a.rpb = a.rows_per_sample < rpb_env ? a.rows_per_sample : rpb_env;
   a.chunks_per_sample = (a.rows_per_sample + a.rpb - 1) / a.rpb;
+  const int nblocks = (a.rows / a.rows_per_sample) * a.chunks_per_sample;
+  // measured: per-block partials + a finalize pass (33 us) do not beat the fp32 atomics (28 us) — the kernel is bound by
+  // exposed row-load latency, not by the atomics; partials stay available for experiments (SCOT_CLN_PARTIALS=1)
+  static int use_partials = -1;
+  if (use_partials < 0) { const char* e = getenv("SCOT_CLN_PARTIALS"); use_partials = e ? atoi(e) : 0; }
+  a.partials = (use_partials && workspace && ws_bytes >= (size_t)nblocks * 3 * a.C * sizeof(float)) ? (float*)workspace : nullptr;
   CLN_DISPATCH(launch_bwd)
-  return scot_check_launch();
+  int rc = scot_check_launch();
+  if (rc == SCOT_OK && a.partials) {
+    hipLaunchKernelGGL(cln_bwd_finalize_kernel, dim3((a.C + 31) / 32), dim3(256), 0, s, a, nblocks);
+    rc = scot_check_launch();
+  }
+  return rc;
 }

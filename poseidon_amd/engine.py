@@ -57,6 +57,48 @@ class ScOTEngine:
         # inside the timed step), and every producer of a GEMM operand also writes a bf16 copy.
         self.shadow = torch.empty(arena.size, dtype=torch.bfloat16, device=self.device) if self.compute == ops.BF16 else None
         self._wviews: Dict[str, torch.Tensor] = {}
+        self._build_cpb_plan()
+
+    def _build_cpb_plan(self):
+        """All layers' continuous-position-bias MLPs run as ONE batched launch per step (forward) and one per stage
+        (backward, so that a stage's gradients are final before its all-reduce)."""
+        blocks = [b for st in self.enc for b in st.blocks] + [b for st in self.dec for b in st.blocks]
+        wss = sorted({b.window_shift()[0] for b in blocks})
+        coords, coff, cur = [], {}, 0
+        for ws in wss:
+            c = cpb_coords_table(ws)
+            coff[ws] = cur
+            cur += c.numel()
+            coords.append(c.reshape(-1))
+        self.cpb_coords = torch.cat(coords).to(self.device)
+        desc, tab_off, z_off = [], 0, 0
+        self.cpb_index: Dict[str, int] = {}
+        self.cpb_slices: Dict[str, tuple] = {}
+        for i, b in enumerate(blocks):
+            ws = b.window_shift()[0]
+            ts = (2 * ws - 1) ** 2
+            a = b.prefix + ".attention.self.continuous_position_bias_mlp."
+            o = self.arena.offsets
+            desc += [o[a + "0.weight"], o[a + "0.bias"], o[a + "2.weight"], coff[ws], ws, b.heads, tab_off, z_off]
+            self.cpb_index[b.prefix] = i
+            self.cpb_slices[b.prefix] = (tab_off, b.heads, ts)
+            tab_off += b.heads * ts
+            z_off += b.heads * ts
+        self.cpb_desc = torch.tensor(desc, dtype=torch.int32).to(self.device)
+        self.cpb_nlayers = len(blocks)
+        self.cpb_max_ws = max(wss)
+        self.cpb_tables = torch.empty(tab_off, device=self.device)
+        self.cpb_z = torch.empty(z_off, device=self.device)
+        self.cpb_dtables = torch.zeros(tab_off, device=self.device)
+
+    def cpb_table(self, prefix, grad=False):
+        off, heads, ts = self.cpb_slices[prefix]
+        return (self.cpb_dtables if grad else self.cpb_tables)[off:off + heads * ts].view(heads, ts)
+
+    def cpb_backward_range(self, blocks):
+        if blocks:
+            ops.cpb_bwd_batched(self.arena.data, self.cpb_desc, self.cpb_index[blocks[0].prefix], len(blocks), self.cpb_coords,
+                                self.cpb_z, self.cpb_dtables, self.arena.grad)
 
     # ------------------------------------------------------------------------------------------ helpers
     def P(self, name):
@@ -165,11 +207,7 @@ class ScOTEngine:
         if tw != ws:
             raise NotImplementedError("run-time window differs from the constructor-time CPB table window "
                                       f"({ws} vs {tw}); the reference would fail to broadcast here too")
-        TS = (2 * ws - 1) ** 2
-        table, z = self.new(heads, TS), self.new(TS, heads)
-        ops.cpb_fwd(self.coords(ws), self.P(a + "continuous_position_bias_mlp.0.weight"),
-                    self.P(a + "continuous_position_bias_mlp.0.bias"), self.P(a + "continuous_position_bias_mlp.2.weight"),
-                    table, z, ws, heads)
+        table = self.cpb_table(pre)   # computed for all layers by the batched launch at the start of forward()
         attn = self.new(B * Lp, C, dtype=self.adt)
         nW = (Hp // ws) * (Wp // ws)
         lse = self.new(B * nW, heads, ws * ws)
@@ -195,7 +233,7 @@ class ScOTEngine:
         out, out16, st2 = self.norm_fwd(pre + ".layernorm_after", y2, h, L, C, cfg.layer_norm_eps, time, need_stats=train, copy=True)
         rec = None
         if train:
-            rec = dict(blk=blk, xp=xp, qkv=qkv, table=table, z=z, lse=lse, attn_c=attn_c, proj=proj, st1=st1, h16=h16, u=u, gp=gp,
+            rec = dict(blk=blk, xp=xp, qkv=qkv, table=table, lse=lse, attn_c=attn_c, proj=proj, st1=st1, h16=h16, u=u, gp=gp,
                        y2=y2, st2=st2, geom=(H, W, Hp, Wp, ws, shift, padded))
         return out, out16, rec
 
@@ -228,14 +266,9 @@ class ScOTEngine:
         else:
             d_attn_p = d_attn
         d_qkv = self.new(B * Lp, 3 * C, dtype=adt)
-        TS = (2 * ws - 1) ** 2
-        d_table = self.zeros(heads, TS)
+        d_table = self.cpb_table(pre, grad=True)   # zeroed once per backward; its MLP backward is batched per stage
         ops.window_attn_bwd(cm, rec["qkv"], d_attn_p, rec["lse"], rec["table"], self.P(a + "logit_scale"), d_qkv, d_table,
                             self.G(a + "logit_scale"), B, Hp, Wp, C, heads, ws, shift)
-        ops.cpb_bwd(self.coords(ws), self.P(a + "continuous_position_bias_mlp.0.weight"),
-                    self.P(a + "continuous_position_bias_mlp.0.bias"), self.P(a + "continuous_position_bias_mlp.2.weight"),
-                    rec["z"], d_table, self.G(a + "continuous_position_bias_mlp.0.weight"),
-                    self.G(a + "continuous_position_bias_mlp.0.bias"), self.G(a + "continuous_position_bias_mlp.2.weight"), ws, heads)
         wqkv = self.Wspan(a + "qkv_weight", 3 * C * C).view(3 * C, C)
         gwqkv = self.arena.span(a + "qkv_weight", 3 * C * C, grad=True).view(3 * C, C)
         ops.linear_wgrad(cm, d_qkv, rec["xp"], gwqkv,
@@ -359,6 +392,8 @@ class ScOTEngine:
         tape = dict(B=B, time=time, enc=[], dec=[], res=[]) if train else None
         if self.shadow is not None:
             ops.cast(self.arena.data, self.shadow)  # fp32 master weights → bf16 GEMM operands (every step)
+        ops.cpb_fwd_batched(self.arena.data, self.cpb_desc, self.cpb_nlayers, self.cpb_max_ws, self.cpb_coords, self.cpb_tables,
+                            self.cpb_z)
 
         # embeddings (model.py:295-366)
         cols = self.new(B * L0, Cin * p * p, dtype=self.adt)
@@ -485,6 +520,7 @@ class ScOTEngine:
         cfg, cm, adt = self.cfg, self.compute, self.adt
         B, time = tape["B"], tape["time"]
         hd = tape["head"]
+        self.cpb_dtables.zero_()
         _, Cout, H, W = hd["shape"]
         p = cfg.patch_size
         gh, gw = self.grid
@@ -526,6 +562,7 @@ class ScOTEngine:
                 g = self.unmerge_bwd(st, urec, g, B, time)
             for blk_rec in reversed(recs):
                 g = self.layer_bwd(blk_rec, g, B, time)
+            self.cpb_backward_range(st.blocks)
             done(f"decoder.layers.{k}.")
             if k != 0:
                 g_skips[nl - 1 - k] = g   # x = x_prev + skip: both get g (g keeps flowing to x_prev unchanged)
@@ -556,6 +593,7 @@ class ScOTEngine:
                 g = self.layer_bwd(blk_rec, g, B, time)
             if d_sum is not None:
                 ops.add(g, d_sum, g)
+            self.cpb_backward_range(st.blocks)
             done(f"encoder.layers.{s}.")
 
         # embeddings

@@ -71,7 +71,7 @@ def gemm(layout: int, compute: int, M: int, N: int, K: int, A, lda: int, B, ldb:
     rc = L().scot_gemm(layout, compute, M, N, K, ptr(A), dt(A), lda, int(a_gelu), ptr(B), dt(B), ldb, int(b_gelu),
                        ptr(C), dt(C), ldc, ptr(bias), ptr(colscale), ptr(aux), dt(aux) if aux is not None else 0, ldaux,
                        ptr(resid), dt(resid) if resid is not None else 0, ldres, int(accumulate), ptr(colsum_out),
-                       workspace().data_ptr() if layout == TN else None, WORKSPACE_BYTES if layout == TN else 0,
+                       workspace().data_ptr(), WORKSPACE_BYTES,
                        int(aux_mul), ptr(gelu_deriv_out), stream())
     _lib.check(rc, "scot_gemm")
 
@@ -125,6 +125,16 @@ def cpb_bwd(coords, w0, b0, w2, z, dtable, dw0, db0, dw2, ws, heads):
                                 heads, stream()), "scot_cpb_bwd")
 
 
+def cpb_fwd_batched(params, desc, nlayers, max_ws, coords, tables, zbuf):
+    _lib.check(L().scot_cpb_fwd_batched(ptr(params), ptr(desc), nlayers, max_ws, ptr(coords), ptr(tables), ptr(zbuf), stream()),
+               "scot_cpb_fwd_batched")
+
+
+def cpb_bwd_batched(params, desc, first, count, coords, zbuf, dtables, grads):
+    _lib.check(L().scot_cpb_bwd_batched(ptr(params), ptr(desc), first, count, ptr(coords), ptr(zbuf), ptr(dtables), ptr(grads),
+                                        stream()), "scot_cpb_bwd_batched")
+
+
 def cln_fwd(x, resid, out, mean, rstd, time, gw_w, gw_b, bw_w, bw_b, rows, rows_per_sample, C, eps, out2=None):
     _lib.check(L().scot_cln_fwd(ptr(x), dt(x), ptr(resid), dt(resid) if resid is not None else 0, ptr(out), dt(out), ptr(out2),
                                 dt(out2) if out2 is not None else 0, ptr(mean),
@@ -135,7 +145,7 @@ def cln_fwd(x, resid, out, mean, rstd, time, gw_w, gw_b, bw_w, bw_b, rows, rows_
 def cln_bwd(dout, x, mean, rstd, time, gw_w, gw_b, dx, d_gw_w, d_gw_b, d_bw_w, d_bw_b, rows, rows_per_sample, C, d_xbias=None):
     _lib.check(L().scot_cln_bwd(ptr(dout), dt(dout), ptr(x), dt(x), ptr(mean), ptr(rstd), ptr(time), ptr(gw_w), ptr(gw_b),
                                 ptr(dx), dt(dx), ptr(d_gw_w), ptr(d_gw_b), ptr(d_bw_w), ptr(d_bw_b), ptr(d_xbias), rows,
-                                rows_per_sample, C, stream()), "scot_cln_bwd")
+                                rows_per_sample, C, workspace().data_ptr(), WORKSPACE_BYTES, stream()), "scot_cln_bwd")
 
 
 def add(a, b, out, period=None):

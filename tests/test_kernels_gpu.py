@@ -59,6 +59,12 @@ def test_gemm_layouts(compute, layout, mixed, M, N, K):
     assert rel(C, ref) < tol
     cs_ref = Aq.sum(0) if layout == ops.TN else C.double().sum(0)
     assert rel(cs, cs_ref) < 1e-4
+    if layout != ops.TN:  # without the column-sum request small grids take the split-K + epilogue-pass route
+        bias = rnd(N, seed=5)
+        res = rnd(M, N, seed=6)
+        C2 = torch.full((M, N), float("nan"), device=DEV)
+        ops.gemm(layout, compute, M, N, K, A, A.shape[1], B, B.shape[1], C2, N, bias=bias, resid=res, ldres=N)
+        assert rel(C2, ref + bias.double() + res.double()) < tol
 
 
 @pytest.mark.parametrize("compute", [ops.F32, ops.BF16])

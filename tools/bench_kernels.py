@@ -50,7 +50,7 @@ def main():
         gemm_case(ops.TN, 4 * C, C, M, tag=f"wgrad fc1 s{s}")
         gemm_case(ops.TN, C, 4 * C, M, tag=f"wgrad fc2 s{s}")
     # CLN
-    for L, C in [] if only else [(1024, 96), (256, 192), (16, 768)]:
+    for L, C in ([(1024, 96), (256, 192), (64, 384), (16, 768)] if only == "cln" else [] if only else [(1024, 96), (256, 192), (16, 768)]):
         rows = B * L
         x, res = torch.randn(rows, C, device="cuda"), torch.randn(rows, C, device="cuda")
         out, out16 = torch.empty_like(x), torch.empty(rows, C, device="cuda", dtype=torch.bfloat16)
