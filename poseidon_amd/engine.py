@@ -45,6 +45,13 @@ class ScOTEngine:
         self.compute = ops.BF16 if compute == "bf16" else ops.F32
         self.adt = torch.bfloat16 if compute == "bf16" else torch.float32
         self.device = arena.data.device
+        # The "trunk" (patch embed, merge, unmerge, recovery: < 2 % of the FLOPs) is the only path every output pixel's
+        # signal must traverse; each bf16 GEMM on it adds ~1e-3 of relative error that nothing downstream averages out.
+        # It therefore always runs on the exact fp32 MFMA with fp32 operands (SCOT_TRUNK_BF16=1 restores bf16).
+        import os as _os
+        trunk32 = self.compute == ops.BF16 and _os.environ.get("SCOT_TRUNK_BF16", "0") != "1"
+        self.tcm = ops.F32 if (trunk32 or self.compute == ops.F32) else ops.BF16
+        self.tadt = torch.float32 if self.tcm == ops.F32 else torch.bfloat16
         self.grid, self.enc, self.dec = stage_plan(cfg)
         self.cond = bool(cfg.use_conditioning)
         self._coords: Dict[int, torch.Tensor] = {}
@@ -121,6 +128,15 @@ class ScOTEngine:
     def Wspan(self, name, numel):
         o = self.arena.offsets[name]
         return (self.shadow if self.shadow is not None else self.arena.data)[o:o + numel]
+
+    def TW(self, name):
+        """Trunk weight operand (fp32 master when the trunk computes in fp32)."""
+        return self.arena.view(name) if self.tcm == ops.F32 else self.W(name)
+
+    def to_tadt(self, x):
+        if self.tadt == torch.float32:
+            return x
+        return self.to_adt(x)
 
     def to_adt(self, x):
         """Copy of fp32 `x` in the GEMM operand dtype (identity in fp32 mode)."""
@@ -289,10 +305,10 @@ class ScOTEngine:
         H, W = st.res
         C = st.dim
         H2, W2 = (H + 1) // 2, (W + 1) // 2
-        cat = self.new(B * H2 * W2, 4 * C, dtype=self.adt)
+        cat = self.new(B * H2 * W2, 4 * C, dtype=self.tadt)
         ops.space_to_depth(x, stage_in, cat, B, H, W, C, 0)
         r = self.new(B * H2 * W2, 2 * C)
-        ops.linear_fwd(self.compute, cat, self.W(st.prefix + ".downsample.reduction.weight"), r)
+        ops.linear_fwd(self.tcm, cat, self.TW(st.prefix + ".downsample.reduction.weight"), r)
         out, out16, stats = self.norm_fwd(st.prefix + ".downsample.norm", r, None, H2 * W2, 2 * C, 1e-5, time, need_stats=train, copy=True)
         return out, out16, (dict(cat=cat, r=r, stats=stats) if train else None)
 
@@ -300,43 +316,44 @@ class ScOTEngine:
         H, W = st.res
         C = st.dim
         H2, W2 = (H + 1) // 2, (W + 1) // 2
-        d_r = self.norm_bwd(st.prefix + ".downsample.norm", g, rec["r"], rec["stats"], H2 * W2, 2 * C, time, self.adt)
-        ops.linear_wgrad(self.compute, d_r, rec["cat"], self.G(st.prefix + ".downsample.reduction.weight"))
+        d_r = self.norm_bwd(st.prefix + ".downsample.norm", g, rec["r"], rec["stats"], H2 * W2, 2 * C, time, self.tadt)
+        ops.linear_wgrad(self.tcm, d_r, rec["cat"], self.G(st.prefix + ".downsample.reduction.weight"))
         d_cat = self.new(B * H2 * W2, 4 * C)
-        ops.linear_dgrad(self.compute, d_r, self.W(st.prefix + ".downsample.reduction.weight"), d_cat)
+        ops.linear_dgrad(self.tcm, d_r, self.TW(st.prefix + ".downsample.reduction.weight"), d_cat)
         d_sum = self.new(B * H * W, C)
         ops.depth_to_space(d_cat, d_sum, B, H, W, H2, W2, C, 0)
         return d_sum
 
-    def unmerge_fwd(self, st: StageGeom, x16, B, time, train):
+    def unmerge_fwd(self, st: StageGeom, x, x16, B, time, train):
         """reference ScOTPatchUnmerging (model.py:737-760)."""
         h, w = st.res
         oh, ow = st.out_res
         C = st.dim
-        up = self.new(B * h * w, 2 * C, dtype=self.adt)
-        ops.linear_fwd(self.compute, x16, self.W(st.prefix + ".upsample.upsample.weight"), up)
-        sh = self.new(B * oh * ow, C // 2, dtype=self.adt)
+        xin = x if self.tadt == torch.float32 else x16
+        up = self.new(B * h * w, 2 * C, dtype=self.tadt)
+        ops.linear_fwd(self.tcm, xin, self.TW(st.prefix + ".upsample.upsample.weight"), up)
+        sh = self.new(B * oh * ow, C // 2, dtype=self.tadt)
         ops.depth_to_space(up, sh, B, oh, ow, h, w, C // 2, 1)
-        n, _, stats = self.norm_fwd(st.prefix + ".upsample.norm", sh, None, oh * ow, C // 2, 1e-5, time, out_dtype=self.adt,
+        n, _, stats = self.norm_fwd(st.prefix + ".upsample.norm", sh, None, oh * ow, C // 2, 1e-5, time, out_dtype=self.tadt,
                                     need_stats=train)
         out = self.new(B * oh * ow, C // 2)
-        ops.linear_fwd(self.compute, n, self.W(st.prefix + ".upsample.mixup.weight"), out)
-        return out, self.to_adt(out), (dict(x=x16, sh=sh, stats=stats, n=n) if train else None)
+        ops.linear_fwd(self.tcm, n, self.TW(st.prefix + ".upsample.mixup.weight"), out)
+        return out, self.to_adt(out), (dict(x=xin, sh=sh, stats=stats, n=n) if train else None)
 
     def unmerge_bwd(self, st: StageGeom, rec, g, B, time):
         h, w = st.res
         oh, ow = st.out_res
         C = st.dim
-        g16 = self.to_adt(g)
-        ops.linear_wgrad(self.compute, g16, rec["n"], self.G(st.prefix + ".upsample.mixup.weight"))
-        d_n = self.new(B * oh * ow, C // 2, dtype=self.adt)
-        ops.linear_dgrad(self.compute, g16, self.W(st.prefix + ".upsample.mixup.weight"), d_n)
-        d_sh = self.norm_bwd(st.prefix + ".upsample.norm", d_n, rec["sh"], rec["stats"], oh * ow, C // 2, time, self.adt)
-        d_up = self.new(B * h * w, 2 * C, dtype=self.adt)
+        g16 = self.to_tadt(g)
+        ops.linear_wgrad(self.tcm, g16, rec["n"], self.G(st.prefix + ".upsample.mixup.weight"))
+        d_n = self.new(B * oh * ow, C // 2, dtype=self.tadt)
+        ops.linear_dgrad(self.tcm, g16, self.TW(st.prefix + ".upsample.mixup.weight"), d_n)
+        d_sh = self.norm_bwd(st.prefix + ".upsample.norm", d_n, rec["sh"], rec["stats"], oh * ow, C // 2, time, self.tadt)
+        d_up = self.new(B * h * w, 2 * C, dtype=self.tadt)
         ops.space_to_depth(d_sh, None, d_up, B, oh, ow, C // 2, 1)
-        ops.linear_wgrad(self.compute, d_up, rec["x"], self.G(st.prefix + ".upsample.upsample.weight"))
+        ops.linear_wgrad(self.tcm, d_up, rec["x"], self.G(st.prefix + ".upsample.upsample.weight"))
         gx = self.new(B * h * w, C)
-        ops.linear_dgrad(self.compute, d_up, self.W(st.prefix + ".upsample.upsample.weight"), gx)
+        ops.linear_dgrad(self.tcm, d_up, self.TW(st.prefix + ".upsample.upsample.weight"), gx)
         return gx
 
     # ------------------------------------------------------------------------------------------ ConvNeXt skip block
@@ -396,11 +413,11 @@ class ScOTEngine:
                             self.cpb_z)
 
         # embeddings (model.py:295-366)
-        cols = self.new(B * L0, Cin * p * p, dtype=self.adt)
+        cols = self.new(B * L0, Cin * p * p, dtype=self.tadt)
         ops.patchify(pixel_values, cols, B, Cin, H, W, p)
         e = self.new(B * L0, C0)
-        wemb = self.W("embeddings.patch_embeddings.projection.weight").view(C0, Cin * p * p)
-        ops.linear_fwd(cm, cols, wemb, e, bias=self.P("embeddings.patch_embeddings.projection.bias"))
+        wemb = self.TW("embeddings.patch_embeddings.projection.weight").view(C0, Cin * p * p)
+        ops.linear_fwd(self.tcm, cols, wemb, e, bias=self.P("embeddings.patch_embeddings.projection.bias"))
         x, x16, est = self.norm_fwd("embeddings.norm", e, None, L0, C0, 1e-5, time, need_stats=train, copy=True)
         if cfg.use_absolute_embeddings:
             ops.add(x, self.P("embeddings.position_embeddings").view(-1), x, period=L0 * C0)
@@ -453,15 +470,16 @@ class ScOTEngine:
             hidden_dec.append(x)
             urec = None
             if st.resample:
-                x, x16, urec = self.unmerge_fwd(st, x16, B, time, train)
+                x, x16, urec = self.unmerge_fwd(st, x, x16, B, time, train)
             if train:
                 tape["dec"].append((recs, urec))
 
         # recovery head (model.py:639-647)
         Cout = cfg.num_out_channels
         rc = self.new(B * L0, Cout * p * p)
-        wrec = self.W("patch_recovery.projection.weight").view(C0, Cout * p * p)
-        ops.gemm(ops.NN, cm, B * L0, Cout * p * p, C0, x16, C0, wrec, Cout * p * p, rc, Cout * p * p)
+        xr = x if self.tadt == torch.float32 else x16
+        wrec = self.TW("patch_recovery.projection.weight").view(C0, Cout * p * p)
+        ops.gemm(ops.NN, self.tcm, B * L0, Cout * p * p, C0, xr, C0, wrec, Cout * p * p, rc, Cout * p * p)
         img = self.new(B, Cout, H, W)
         ops.unpatchify(rc, self.P("patch_recovery.projection.bias"), img, B, Cout, H, W, gh, gw, p)
         pred = self.new(B, Cout, H, W)
@@ -486,7 +504,7 @@ class ScOTEngine:
             loss = self.new(1)
             ops.loss_finish(sums, meta["counts"], meta["G"], meta["normalized"], loss)
         if train:
-            tape["head"] = dict(x=x16, img=img, pred=pred, labels=labels, mask=mask_u8, mask_full=mask_full, sums=sums, meta=meta,
+            tape["head"] = dict(x=xr, img=img, pred=pred, labels=labels, mask=mask_u8, mask_full=mask_full, sums=sums, meta=meta,
                                 shape=(B, Cout, H, W))
             tape["hidden"] = (hidden_dec, hidden_enc)
         self.last_hidden = (hidden_dec, hidden_enc)
@@ -542,13 +560,13 @@ class ScOTEngine:
         d_img = self.new(B, Cout, H, W)
         ops.conv5(g_pred, self.P("patch_recovery.mixup.weight"), d_img, B, Cout, H, W, transpose=True)
         ops.nchw_channel_sum(d_img, self.G("patch_recovery.projection.bias"), B, Cout, H * W)
-        d_rc = self.new(B * L0, Cout * p * p, dtype=adt)
+        d_rc = self.new(B * L0, Cout * p * p, dtype=self.tadt)
         ops.patchify(d_img, d_rc, B, Cout, H, W, p)
-        wrec = self.W("patch_recovery.projection.weight").view(C0, Cout * p * p)
-        ops.gemm(ops.TN, cm, C0, Cout * p * p, B * L0, hd["x"], C0, d_rc, Cout * p * p,
+        wrec = self.TW("patch_recovery.projection.weight").view(C0, Cout * p * p)
+        ops.gemm(ops.TN, self.tcm, C0, Cout * p * p, B * L0, hd["x"], C0, d_rc, Cout * p * p,
                  self.G("patch_recovery.projection.weight").view(C0, Cout * p * p), Cout * p * p, accumulate=True)
         g = self.new(B * L0, C0)
-        ops.gemm(ops.NT, cm, B * L0, C0, Cout * p * p, d_rc, Cout * p * p, wrec, Cout * p * p, g, C0)
+        ops.gemm(ops.NT, self.tcm, B * L0, C0, Cout * p * p, d_rc, Cout * p * p, wrec, Cout * p * p, g, C0)
         done = self.on_grads_final or (lambda prefix: None)
         done("patch_recovery.")
 
@@ -601,7 +619,7 @@ class ScOTEngine:
         Cin = cfg.num_channels
         if cfg.use_absolute_embeddings:
             ops.batch_sum(g, self.G("embeddings.position_embeddings").view(-1), B, L0 * C0)
-        d_e = self.norm_bwd("embeddings.norm", g, emb["e"], emb["stats"], L0, C0, time, adt)
-        ops.linear_wgrad(cm, d_e, emb["cols"], self.G("embeddings.patch_embeddings.projection.weight").view(C0, Cin * p * p),
+        d_e = self.norm_bwd("embeddings.norm", g, emb["e"], emb["stats"], L0, C0, time, self.tadt)
+        ops.linear_wgrad(self.tcm, d_e, emb["cols"], self.G("embeddings.patch_embeddings.projection.weight").view(C0, Cin * p * p),
                          dbias=self.G("embeddings.patch_embeddings.projection.bias"))
         done("embeddings.")

@@ -93,9 +93,10 @@ def test_bf16_vs_reference_fixture(name):
     # the backward far more than the presets do (Poseidon-T/B: median grad-norm deviation 4e-3..9e-3): regression guard only.
     g, worst = grads_report(model, f, tol_each=1e9, tol_global=0.7, floor=1e-6, skip=("logit_scale",))
     print(f"\n[{name} bf16] out rel-L2 {e_out:.2e}; grads global rel-L2 {g:.2e}, worst {worst}")
-    # MEASURED on MI355X (round 1): hf regime 3.5e-3..6e-3, trained regime 7.6e-3..1.1e-2  — i.e. the north-star
-    # 1e-3 is NOT met by single-pass bf16 operands (DESIGN.md "Numerics"); bounds below only guard regressions.
-    assert e_out < (1e-2 if meta["regime"] == "hf" else 3e-2)
+    # MEASURED on MI355X (round 1, fp32 trunk + bf16 branches): hf regime 2e-4 (tiny) .. 2e-3 (Poseidon-B), trained-like
+    # regime 6e-3..3e-2 — the north-star 1e-3 is NOT met by single-pass bf16 operands in the branches
+    # (DESIGN.md "Numerics"); the bounds below only guard regressions.
+    assert e_out < (3e-3 if meta["regime"] == "hf" else 5e-2)
 
 
 @pytest.mark.parametrize("name,compute", [("poseidonT_trained", "fp32"), ("poseidonT_hf", "fp32"), ("poseidonT_trained", "bf16"),
@@ -120,7 +121,7 @@ def test_poseidon_presets(name, compute):
         assert np.median(dev) < 1e-4
         grads_report(model, f, tol_each=1e-3, tol_global=1e-3)
     else:
-        assert e_out < (1e-2 if meta["regime"] == "hf" else 3e-2)  # measured 3.5e-3..8.5e-3, see DESIGN.md "Numerics"
+        assert e_out < (3e-3 if meta["regime"] == "hf" else 2e-2)  # measured 1.4e-3..2e-3 / 6.3e-3..6.7e-3, DESIGN.md "Numerics"
 
 
 @pytest.mark.parametrize("size", [64, 16])
