@@ -111,29 +111,50 @@ def _cpu_baseline_worker(model_tag, size, channels, budget_s):
 
 
 def dominant_kernel_probe(compute, batch, embed_dim, size):
-    """Live HIP-event timing of the single largest FLOP consumer (MLP fc1 GEMM of stage 0: M = batch·(size/4)^2, K = C,
-    N = 4C, bias epilogue, bf16 store) on the stream the engine launches on."""
+    """Live HIP-event timing (events on torch's current stream = the stream the C ABI launches on) of the kernel with the
+    largest share of the step in the committed rocprof summary (profiles/): `gemm_fast_kernel<.., TN>` — the wgrad GEMM,
+    at its stage-0 fc1 instance  dW[4C, C] += dY[M, 4C]^T · X[M, C],  M = batch·(size/4)^2 (split-K partials + reduce pass
+    included, as in the step).  Also times the runner-up (`attn_bwd_kernel`, stage 0) for reference."""
     from poseidon_amd import ops
-    M, K, N = batch * (size // 4) ** 2, embed_dim, 4 * embed_dim
     cm = ops.BF16 if compute == "bf16" else ops.F32
-    x = torch.randn(M, K, device="cuda")
-    w = torch.randn(N, K, device="cuda") * 0.05
-    b = torch.randn(N, device="cuda")
-    u = torch.empty(M, N, device="cuda", dtype=torch.bfloat16 if compute == "bf16" else torch.float32)
-    for _ in range(3):
-        ops.linear_fwd(cm, x, w, u, bias=b)
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    reps = 20
-    e0.record()
-    for _ in range(reps):
-        ops.linear_fwd(cm, x, w, u, bias=b)
-    e1.record()
-    torch.cuda.synchronize()
-    ms = e0.elapsed_time(e1) / reps
-    flops = 2.0 * M * K * N
-    bytes_alg = M * K * 4 + N * K * 4 + M * N * u.element_size()
-    return {"kernel": "gemm_kernel<NT> fc1 stage0", "shape": [M, N, K], "us": ms * 1e3, "tflops": flops / ms / 1e9,
-            "algorithmic_gbps": bytes_alg / ms / 1e6}
+    dt = torch.bfloat16 if compute == "bf16" else torch.float32
+    M, C = batch * (size // 4) ** 2, embed_dim
+    dy = torch.randn(M, 4 * C, device="cuda").to(dt)
+    x = torch.randn(M, C, device="cuda").to(dt)
+    dw = torch.zeros(4 * C, C, device="cuda")
+
+    def timed(fn, reps=20):
+        for _ in range(3):
+            fn()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(reps):
+            fn()
+        e1.record()
+        torch.cuda.synchronize()
+        return e0.elapsed_time(e1) / reps  # ms
+
+    ms = timed(lambda: ops.linear_wgrad(cm, dy, x, dw))
+    flops = 2.0 * M * 4 * C * C
+    bytes_alg = (dy.numel() + x.numel()) * dy.element_size() + dw.numel() * 4 * 2
+    out = {"kernel": "gemm_fast_kernel<bf16,64,64,TN> (wgrad fc1, stage 0) + splitk_reduce", "shape_MNK": [4 * C, C, M], "us": ms * 1e3,
+           "tflops": flops / ms / 1e9, "algorithmic_bytes": bytes_alg, "algorithmic_gbps": bytes_alg / ms / 1e6}
+    # runner-up: shifted-window attention backward at stage 0
+    Hp, heads, ws = size // 4, 3, 16
+    qkv = torch.randn(batch * Hp * Hp, 3 * C, device="cuda").to(dt)
+    do = torch.randn(batch * Hp * Hp, C, device="cuda").to(dt)
+    nW = (Hp // ws) ** 2
+    lse = torch.zeros(batch * nW, heads, ws * ws, device="cuda")
+    tab = torch.randn(heads, (2 * ws - 1) ** 2, device="cuda")
+    ls = torch.full((heads,), 2.3, device="cuda")
+    o = torch.empty(batch * Hp * Hp, C, device="cuda", dtype=dt)
+    ops.window_attn_fwd(cm, qkv, o, lse, tab, ls, batch, Hp, Hp, C, heads, ws, 8)
+    dq = torch.empty_like(qkv)
+    dtab, dls = torch.zeros_like(tab), torch.zeros(heads, device="cuda")
+    ms2 = timed(lambda: ops.window_attn_bwd(cm, qkv, do, lse, tab, ls, dq, dtab, dls, batch, Hp, Hp, C, heads, ws, 8))
+    fl2 = 2.5 * 4.0 * batch * nW * heads * (ws * ws) ** 2 * (C // heads)
+    out["runner_up"] = {"kernel": "attn_bwd_kernel<bf16,32,16> (stage 0)", "us": ms2 * 1e3, "tflops": fl2 / ms2 / 1e9}
+    return out
 
 
 def main():
@@ -236,12 +257,20 @@ def main():
         step_tflop = 3.0 * (B * F * scale + P) / 1e3            # per GPU per step
         achieved = step_tflop / (ms / 1e3)                       # TFLOP/s per GPU
         peak = PEAK_TFLOPS[a.compute]
-        roof = {"bound": "mfma", "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak,
-                "traffic": None, "scope": "whole step, algorithmic FLOPs 3(B*F+P) per GPU (SURVEY.md 8d)"}
+        step_roof = {"bound": "mfma", "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak,
+                     "scope": "whole step, algorithmic FLOPs 3(B*F+P) per GPU (SURVEY.md 8d)"}
         try:
-            roof["dominant_kernel"] = dominant_kernel_probe(a.compute, B, cfg.embed_dim, a.size)
+            dk = dominant_kernel_probe(a.compute, B, cfg.embed_dim, a.size)
+            traffic = None
+            tpath = os.path.join(ROOT, "profiles", "round1", "pmc_traffic.json")
+            if os.path.exists(tpath):  # HBM bytes per launch of the same kernel from the committed rocprofv3 --pmc run
+                traffic = json.load(open(tpath)).get("wgrad_fc1_stage0_bytes_per_launch")
+            roof = {"bound": "mfma", "achieved": dk["tflops"], "peak": peak, "unit": "TFLOP/s", "frac": dk["tflops"] / peak,
+                    "traffic": traffic, "kernel": dk["kernel"], "us_per_launch": dk["us"], "shape_MNK": dk["shape_MNK"],
+                    "algorithmic_bytes": dk["algorithmic_bytes"], "algorithmic_gbps": dk["algorithmic_gbps"],
+                    "runner_up": dk["runner_up"], "whole_step": step_roof}
         except Exception as e:  # pragma: no cover
-            roof["dominant_kernel"] = {"error": repr(e)}
+            roof = dict(step_roof, traffic=None, error=repr(e))
         res = {"metric": "PDE-grid samples/sec (fwd+bwd)", "value": value, "unit": "samples/s", "n_gpus": world, "steps": a.steps,
                "warmup": a.warmup, "ms_per_step": ms, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
                "dtype": a.compute, "data": "synthetic",

@@ -27,6 +27,7 @@ struct FastArgs {
   int a_gelu, b_gelu, aux_gelu_grad, atomic;
   int ksplit;
   int use_tr;
+  int xcd_swizzle;  // remap workgroup ids so that the tiles sharing a streamed operand run on ONE XCD (its L2 serves the re-reads)
   void* C2;        // optional second output: C = gelu(v), C2 = gelu'(v)   (fc1 epilogue: value and derivative in one pass)
   int aux_mul;     // aux is multiplied in as is (it already holds gelu'(u)) instead of gelu'(aux)
   float* ws;       // TN split-K: partial tiles ws[z][M][N] (fp32), reduced by splitk_reduce_kernel
@@ -129,8 +130,24 @@ __global__ __launch_bounds__(256) void gemm_fast_kernel(FastArgs p) {
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wr = wave / WN, wc = wave % WN, g = lane >> 4;
-  const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
-  const int kbeg = blockIdx.z * p.ksplit;
+  // Workgroup b runs on XCD b % 8 (observed dispatch order, used for speed only).  The tiles that re-read the same streamed
+  // operand — all output tiles of one token chunk (TN), all column tiles of one row block (NT/NN) — are renumbered so that they
+  // are consecutive ON ONE XCD: its 4 MB L2 then serves the re-reads instead of the fabric (PMC: 3.1x algorithmic bytes before).
+  int bx = blockIdx.x, by = blockIdx.y, bz = blockIdx.z;
+  {
+    const int gx = gridDim.x, gy = gridDim.y, gz = gridDim.z;
+    const int G = (LAYOUT == LAYOUT_TN) ? gx * gy : gx;
+    const int NG = (LAYOUT == LAYOUT_TN) ? gz : gy * gz;
+    if (p.xcd_swizzle && NG % 8 == 0) {
+      const int L = bx + gx * (by + gy * bz);
+      const int j = L >> 3;
+      const int group = (L & 7) * (NG >> 3) + j / G, member = j % G;
+      if (LAYOUT == LAYOUT_TN) { bz = group; bx = member % gx; by = member / gx; }
+      else { by = group % gy; bz = group / gy; bx = member; }
+    }
+  }
+  const int m0 = by * BM, n0 = bx * BN;
+  const int kbeg = bz * p.ksplit;
   const int kend = min(p.K, kbeg + p.ksplit);
   const int nk = (kend - kbeg + BK - 1) / BK;
   const CT* A = (const CT*)p.A;
@@ -177,7 +194,7 @@ __global__ __launch_bounds__(256) void gemm_fast_kernel(FastArgs p) {
 #pragma unroll
         for (int j = 0; j < NI; ++j) mma16(acc[i][j], fa[i], fb[j]);
     }
-    if (LAYOUT == LAYOUT_TN && p.colsum_out && blockIdx.x == 0 && tid < BM) {
+    if (LAYOUT == LAYOUT_TN && p.colsum_out && bx == 0 && tid < BM) {
 #pragma unroll 8
       for (int k = 0; k < BK; ++k) bsum += from_ct(As[k * TA::pitch + tid]);
     }
@@ -209,7 +226,7 @@ __global__ __launch_bounds__(256) void gemm_fast_kernel(FastArgs p) {
     __syncthreads();
   }
 
-  if (LAYOUT == LAYOUT_TN && p.colsum_out && blockIdx.x == 0 && tid < BM && m0 + tid < p.M) atomicAdd(&p.colsum_out[m0 + tid], bsum);
+  if (LAYOUT == LAYOUT_TN && p.colsum_out && bx == 0 && tid < BM && m0 + tid < p.M) atomicAdd(&p.colsum_out[m0 + tid], bsum);
 
   // ---- epilogue through LDS
   float* Cs = (float*)smem;
@@ -235,7 +252,7 @@ __global__ __launch_bounds__(256) void gemm_fast_kernel(FastArgs p) {
 #pragma unroll
   for (int j = 0; j < 8; ++j) {
     const bool ok = col + j < p.N;
-    bv[j] = (p.bias && ok && blockIdx.z == 0) ? p.bias[col + j] : 0.f;
+    bv[j] = (p.bias && ok && bz == 0) ? p.bias[col + j] : 0.f;
     sv[j] = (p.colscale && ok) ? p.colscale[col + j] : 1.f;
   }
   if (col < p.N && ep_active) {
@@ -265,7 +282,7 @@ __global__ __launch_bounds__(256) void gemm_fast_kernel(FastArgs p) {
       const size_t ci = (size_t)grow * p.ldc + col;
       if (LAYOUT == LAYOUT_TN) {
         if (p.ws) {            // split-K partial tile (dense [M][N], 32-byte aligned rows since N % 8 == 0)
-          st8(p.ws + (size_t)blockIdx.z * p.M * p.N, SCOT_F32, (size_t)grow * p.N + col, v);
+          st8(p.ws + (size_t)bz * p.M * p.N, SCOT_F32, (size_t)grow * p.N + col, v);
         } else if (p.rmw) {    // single split: this workgroup is the only writer of the tile
           float o[8];
           ld8(p.C, SCOT_F32, ci, o);
@@ -277,7 +294,7 @@ __global__ __launch_bounds__(256) void gemm_fast_kernel(FastArgs p) {
           for (int j = 0; j < 8; ++j) atomicAdd((float*)p.C + ci + j, v[j]);
         }
       } else if (p.ws) {   // NT/NN split-K: raw partial sums; bias/aux/resid are applied by splitk_epilogue_kernel
-        st8(p.ws + (size_t)blockIdx.z * p.M * p.N, SCOT_F32, (size_t)grow * p.N + col, v);
+        st8(p.ws + (size_t)bz * p.M * p.N, SCOT_F32, (size_t)grow * p.N + col, v);
       } else if (p.C2) {
         float gv[8], gd[8];
 #pragma unroll
@@ -611,6 +628,9 @@ int scot_gemm_fast(int layout, int compute, int M, int N, int K, const void* A, 
   a.M = M; a.N = N; a.K = K; a.lda = lda; a.ldb = ldb; a.ldc = ldc; a.ldaux = ldaux; a.ldres = ldres;
   a.c_dt = c_dt; a.aux_dt = aux_dt; a.res_dt = res_dt; a.a_gelu = a_gelu; a.b_gelu = b_gelu; a.aux_gelu_grad = aux != nullptr;
   a.use_tr = g_scot_use_tr; a.atomic = 0; a.ws = nullptr; a.rmw = 0; a.C2 = C2; a.aux_mul = aux_mul;
+  static int xcd = -1;
+  if (xcd < 0) { const char* e = getenv("SCOT_GEMM_XCD"); xcd = e ? atoi(e) : 1; }
+  a.xcd_swizzle = xcd;
   if (C2 && ((((uintptr_t)C2) & 15) != 0 || layout == LAYOUT_TN)) return SCOT_ERR_UNSUPPORTED;
   const int bk = compute == SCOT_BF16 ? 64 : 32;
   int nsplit = 1;
@@ -643,6 +663,10 @@ int scot_gemm_fast(int layout, int compute, int M, int N, int K, const void* A, 
     if (nsplit > wsmax) nsplit = (int)(wsmax < 1 ? 1 : wsmax);
     int per = (K + nsplit - 1) / nsplit;
     per = ((per + bk - 1) / bk) * bk;
+    if (nsplit >= 8) {   // make the split count a multiple of 8 so that the XCD remap applies (one token chunk per XCD at a time)
+      for (int tries = 0; tries < 64 && ((K + per - 1) / per) % 8 != 0; ++tries) per += bk;
+      if (((K + per - 1) / per) % 8 != 0) per = ((((K + nsplit - 1) / nsplit) + bk - 1) / bk) * bk;
+    }
     a.ksplit = per;
     nsplit = (K + per - 1) / per;
     if (nsplit == 1) a.rmw = 1;

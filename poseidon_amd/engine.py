@@ -59,6 +59,13 @@ class ScOTEngine:
         # called with a state-dict prefix ("patch_recovery.", "decoder.layers.3.", …) as soon as the backward has FINISHED
         # writing every gradient under that prefix — the data-parallel wrapper launches that range's all-reduce there
         self.on_grads_final = None
+        # Weight gradients are off the backward's critical path (nothing downstream reads dW): they are launched on a
+        # second HIP stream, forked from / joined into the main stream with events, so that the (latency-bound) wgrad GEMMs
+        # fill the CUs the dgrad / LN / attention chain leaves idle.  SCOT_SIDE_STREAM=0 serialises everything.
+        import os as _os2
+        self.use_side = _os2.environ.get("SCOT_SIDE_STREAM", "1") != "0"
+        self.side = None
+        self._keep = []
         # bf16 mode: GEMM operands must already be bf16 in HBM (gemm_fast streams raw 16-byte chunks into LDS), so the
         # weights get a bf16 shadow arena that is re-cast from the fp32 master at the start of EVERY forward (one pass,
         # inside the timed step), and every producer of a GEMM operand also writes a bf16 copy.
@@ -194,9 +201,36 @@ class ScOTEngine:
                     rows_per_sample, C)
         return dx
 
+    def off_critical_path(self, fn, *tensors):
+        """Run fn() (kernel launches that only WRITE parameter gradients) on the side stream, ordered after everything
+        enqueued so far on the main stream.  `tensors` are kept alive until the join so the allocator cannot recycle them."""
+        if not self.use_side:
+            fn()
+            return
+        if self.side is None:
+            self.side = torch.cuda.Stream(device=self.device)
+        ev = torch.cuda.Event()
+        ev.record()
+        self.side.wait_event(ev)
+        ops.set_workspace_slot(1)
+        try:
+            with torch.cuda.stream(self.side):
+                fn()
+        finally:
+            ops.set_workspace_slot(0)
+        self._keep.append(tensors)
+
+    def join_side(self):
+        if self.use_side and self.side is not None:
+            torch.cuda.current_stream().wait_stream(self.side)
+            self._keep.clear()
+
+    def wgrad(self, cm, dy, x, gw, b_gelu=False, dbias=None):
+        self.off_critical_path(lambda: ops.linear_wgrad(cm, dy, x, gw, b_gelu=b_gelu, dbias=dbias), dy, x)
+
     def linear_bwd_params(self, wname, bname, dy, x, b_gelu=False):
         """dW += dy^T x and db += Σ dy in ONE wgrad launch (the bias sum rides on the dY tiles already in LDS)."""
-        ops.linear_wgrad(self.compute, dy, x, self.G(wname), b_gelu=b_gelu, dbias=self.G(bname) if bname is not None else None)
+        self.wgrad(self.compute, dy, x, self.G(wname), b_gelu=b_gelu, dbias=self.G(bname) if bname is not None else None)
 
     # ------------------------------------------------------------------------------------------ ScOTLayer
     def layer_fwd(self, blk: BlockGeom, x, x16, B, time, train):
@@ -287,8 +321,7 @@ class ScOTEngine:
                             self.G(a + "logit_scale"), B, Hp, Wp, C, heads, ws, shift)
         wqkv = self.Wspan(a + "qkv_weight", 3 * C * C).view(3 * C, C)
         gwqkv = self.arena.span(a + "qkv_weight", 3 * C * C, grad=True).view(3 * C, C)
-        ops.linear_wgrad(cm, d_qkv, rec["xp"], gwqkv,
-                         dbias=self.arena.span(a + "qkv_bias", 3 * C, grad=True) if cfg.qkv_bias else None)
+        self.wgrad(cm, d_qkv, rec["xp"], gwqkv, dbias=self.arena.span(a + "qkv_bias", 3 * C, grad=True) if cfg.qkv_bias else None)
         if padded:
             tmp = self.new(B * Lp, C)
             ops.linear_dgrad(cm, d_qkv, wqkv, tmp)
@@ -317,7 +350,7 @@ class ScOTEngine:
         C = st.dim
         H2, W2 = (H + 1) // 2, (W + 1) // 2
         d_r = self.norm_bwd(st.prefix + ".downsample.norm", g, rec["r"], rec["stats"], H2 * W2, 2 * C, time, self.tadt)
-        ops.linear_wgrad(self.tcm, d_r, rec["cat"], self.G(st.prefix + ".downsample.reduction.weight"))
+        self.wgrad(self.tcm, d_r, rec["cat"], self.G(st.prefix + ".downsample.reduction.weight"))
         d_cat = self.new(B * H2 * W2, 4 * C)
         ops.linear_dgrad(self.tcm, d_r, self.TW(st.prefix + ".downsample.reduction.weight"), d_cat)
         d_sum = self.new(B * H * W, C)
@@ -345,13 +378,13 @@ class ScOTEngine:
         oh, ow = st.out_res
         C = st.dim
         g16 = self.to_tadt(g)
-        ops.linear_wgrad(self.tcm, g16, rec["n"], self.G(st.prefix + ".upsample.mixup.weight"))
+        self.wgrad(self.tcm, g16, rec["n"], self.G(st.prefix + ".upsample.mixup.weight"))
         d_n = self.new(B * oh * ow, C // 2, dtype=self.tadt)
         ops.linear_dgrad(self.tcm, g16, self.TW(st.prefix + ".upsample.mixup.weight"), d_n)
         d_sh = self.norm_bwd(st.prefix + ".upsample.norm", d_n, rec["sh"], rec["stats"], oh * ow, C // 2, time, self.tadt)
         d_up = self.new(B * h * w, 2 * C, dtype=self.tadt)
         ops.space_to_depth(d_sh, None, d_up, B, oh, ow, C // 2, 1)
-        ops.linear_wgrad(self.tcm, d_up, rec["x"], self.G(st.prefix + ".upsample.upsample.weight"))
+        self.wgrad(self.tcm, d_up, rec["x"], self.G(st.prefix + ".upsample.upsample.weight"))
         gx = self.new(B * h * w, C)
         ops.linear_dgrad(self.tcm, d_up, self.TW(st.prefix + ".upsample.upsample.weight"), gx)
         return gx
@@ -384,7 +417,8 @@ class ScOTEngine:
         d_n = self.new(B * L, C, dtype=self.adt)
         ops.linear_dgrad(self.compute, d_u, self.W(pre + ".pwconv1.weight"), d_n)
         d_dw = self.norm_bwd(pre + ".norm", d_n, rec["dw"], rec["stats"], L, C, time, torch.float32)
-        ops.dwconv7_wgrad(d_dw, rec["s"], self.G(pre + ".dwconv.weight"), self.G(pre + ".dwconv.bias"), B, H, W, C)
+        self.off_critical_path(lambda: ops.dwconv7_wgrad(d_dw, rec["s"], self.G(pre + ".dwconv.weight"), self.G(pre + ".dwconv.bias"),
+                                                         B, H, W, C), d_dw, rec["s"])
         d_s = self.new(B * L, C)
         ops.dwconv7(d_dw, self.P(pre + ".dwconv.weight"), None, d_s, B, H, W, C, flip=True)
         ops.add(g, d_s, g)
@@ -563,11 +597,18 @@ class ScOTEngine:
         d_rc = self.new(B * L0, Cout * p * p, dtype=self.tadt)
         ops.patchify(d_img, d_rc, B, Cout, H, W, p)
         wrec = self.TW("patch_recovery.projection.weight").view(C0, Cout * p * p)
-        ops.gemm(ops.TN, self.tcm, C0, Cout * p * p, B * L0, hd["x"], C0, d_rc, Cout * p * p,
-                 self.G("patch_recovery.projection.weight").view(C0, Cout * p * p), Cout * p * p, accumulate=True)
+        self.off_critical_path(lambda: ops.gemm(ops.TN, self.tcm, C0, Cout * p * p, B * L0, hd["x"], C0, d_rc, Cout * p * p,
+                                                self.G("patch_recovery.projection.weight").view(C0, Cout * p * p), Cout * p * p,
+                                                accumulate=True), hd["x"], d_rc)
         g = self.new(B * L0, C0)
         ops.gemm(ops.NT, self.tcm, B * L0, C0, Cout * p * p, d_rc, Cout * p * p, wrec, Cout * p * p, g, C0)
-        done = self.on_grads_final or (lambda prefix: None)
+        if self.on_grads_final is not None:
+            def done(prefix, _cb=self.on_grads_final):
+                self.join_side()   # the range's weight gradients (side stream) must be complete before its all-reduce
+                _cb(prefix)
+        else:
+            def done(prefix):
+                return None
         done("patch_recovery.")
 
         # decoder, shallow → deep
@@ -620,6 +661,7 @@ class ScOTEngine:
         if cfg.use_absolute_embeddings:
             ops.batch_sum(g, self.G("embeddings.position_embeddings").view(-1), B, L0 * C0)
         d_e = self.norm_bwd("embeddings.norm", g, emb["e"], emb["stats"], L0, C0, time, self.tadt)
-        ops.linear_wgrad(self.tcm, d_e, emb["cols"], self.G("embeddings.patch_embeddings.projection.weight").view(C0, Cin * p * p),
-                         dbias=self.G("embeddings.patch_embeddings.projection.bias"))
+        self.wgrad(self.tcm, d_e, emb["cols"], self.G("embeddings.patch_embeddings.projection.weight").view(C0, Cin * p * p),
+                   dbias=self.G("embeddings.patch_embeddings.projection.bias"))
+        self.join_side()
         done("embeddings.")

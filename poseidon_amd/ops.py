@@ -54,13 +54,22 @@ _workspace = {}
 WORKSPACE_BYTES = 96 << 20
 
 
+_slot = 0
+
+
+def set_workspace_slot(slot: int) -> None:
+    """0 = main stream, 1 = side stream: kernels of the two streams run concurrently and must not share split-K scratch."""
+    global _slot
+    _slot = slot
+
+
 def workspace():
-    """Per-device scratch for split-K partial tiles (allocated once; the C ABI never allocates)."""
-    dev = torch.cuda.current_device()
-    w = _workspace.get(dev)
+    """Per-(device, slot) scratch for split-K partial tiles (allocated once, on first eager use; the C ABI never allocates)."""
+    key = (torch.cuda.current_device(), _slot)
+    w = _workspace.get(key)
     if w is None:
-        w = torch.empty(WORKSPACE_BYTES, dtype=torch.uint8, device=f"cuda:{dev}")
-        _workspace[dev] = w
+        w = torch.empty(WORKSPACE_BYTES, dtype=torch.uint8, device=f"cuda:{key[0]}")
+        _workspace[key] = w
     return w
 
 
