@@ -38,20 +38,20 @@ template <typename CT> struct FT;
 template <> struct FT<bf16_t> { static constexpr int BK = 64, EPC = 8, KPAD = 8, RPAD = 8; };
 template <> struct FT<float> { static constexpr int BK = 32, EPC = 4, KPAD = 4, RPAD = 4; };
 
-template <typename CT, int R, bool KC> struct FTile {
-  static constexpr int BK = FT<CT>::BK, EPC = FT<CT>::EPC;
+template <typename CT, int R, bool KC, int BKT = FT<CT>::BK> struct FTile {
+  static constexpr int BK = BKT, EPC = FT<CT>::EPC;
   static constexpr int pitch = KC ? (BK + FT<CT>::KPAD) : (R + FT<CT>::RPAD);
   static constexpr int elems = KC ? R * pitch : BK * pitch;
   static constexpr int nchunks = R * BK / EPC;      // 16-byte chunks per tile
-  static constexpr int per_thread = nchunks / 256;
-  static_assert(nchunks % 256 == 0, "tile must split evenly over 256 threads");
+  static constexpr int per_thread = (nchunks + 255) / 256;
+  static constexpr bool exact = nchunks % 256 == 0;   // otherwise the last pass is guarded (e.g. 96 x 32: 384 chunks)
 };
 
 // issue this thread's loads for K-tile starting at k0 (raw 16-byte chunks, no waits, no branches)
-template <typename CT, int R, bool KC, int NCH>
+template <typename CT, int R, bool KC, int BKT, int NCH>
 __device__ __forceinline__ void fload(uint4 (&st)[NCH], const CT* __restrict__ src, int ld, int row0,
                                       int rmax, int k0, int kend, int tid) {
-  using T = FTile<CT, R, KC>;
+  using T = FTile<CT, R, KC, BKT>;
   constexpr int EPC = T::EPC, BK = T::BK;
 #pragma unroll
   for (int i = 0; i < T::per_thread; ++i) {
@@ -68,7 +68,7 @@ __device__ __forceinline__ void fload(uint4 (&st)[NCH], const CT* __restrict__ s
       const int r = min(row0 + (c % CPR) * EPC, rmax - EPC);
       idx = (size_t)k * ld + r;
     }
-    st[i] = *(const uint4*)(src + idx);
+    if (T::exact || c < T::nchunks) st[i] = *(const uint4*)(src + idx);
   }
 }
 
@@ -86,9 +86,9 @@ __device__ __forceinline__ uint4 gelu_chunk(uint4 u, float) {
                     __float_as_uint(gelu_f(__uint_as_float(u.z))), __float_as_uint(gelu_f(__uint_as_float(u.w))));
 }
 
-template <typename CT, int R, bool KC, int NCH>
+template <typename CT, int R, bool KC, int BKT, int NCH>
 __device__ __forceinline__ void fstore(CT* tile, const uint4 (&st)[NCH], int k0, int kend, int tid, bool gelu) {
-  using T = FTile<CT, R, KC>;
+  using T = FTile<CT, R, KC, BKT>;
   constexpr int EPC = T::EPC, BK = T::BK;
 #pragma unroll
   for (int i = 0; i < T::per_thread; ++i) {
@@ -106,19 +106,19 @@ __device__ __forceinline__ void fstore(CT* tile, const uint4 (&st)[NCH], int k0,
     }
     if (gelu) v = gelu_chunk(v, CT());
     if (k >= kend) v = make_uint4(0, 0, 0, 0);   // K tail (K is a multiple of EPC in this kernel)
-    *(uint4*)(tile + off) = v;
+    if (T::exact || c < T::nchunks) *(uint4*)(tile + off) = v;
   }
 }
 
 // WM x WN = arrangement of the 4 waves over the BM x BN tile (WM*WN == 4); each wave owns (BM/WM) x (BN/WN).
-template <typename CT, int BM, int BN, int WM, int WN, int LAYOUT>
+template <typename CT, int BM, int BN, int WM, int WN, int BKT, int LAYOUT>
 __global__ __launch_bounds__(256) void gemm_fast_kernel(FastArgs p) {
   static_assert(WM * WN == 4, "4 waves per workgroup");
   constexpr bool A_KC = (LAYOUT != LAYOUT_TN);
   constexpr bool B_KC = (LAYOUT == LAYOUT_NT);
-  using TA = FTile<CT, BM, A_KC>;
-  using TB = FTile<CT, BN, B_KC>;
-  constexpr int BK = FT<CT>::BK;
+  using TA = FTile<CT, BM, A_KC, BKT>;
+  using TB = FTile<CT, BN, B_KC, BKT>;
+  constexpr int BK = BKT;
   constexpr int MI = BM / (16 * WM), NI = BN / (16 * WN);
   constexpr int WROWS = BM / WM, WCOLS = BN / WN;
   constexpr int STAGE = TA::elems + TB::elems;
@@ -163,14 +163,14 @@ __global__ __launch_bounds__(256) void gemm_fast_kernel(FastArgs p) {
   // Two register sets: the loads of K-tile t+2 are issued at the TOP of iteration t and consumed (written to LDS) at the
   // END of iteration t+1, i.e. they have two MFMA phases and a barrier to land.
   uint4 ra0[TA::per_thread], rb0[TB::per_thread], ra1[TA::per_thread], rb1[TB::per_thread];
-  fload<CT, BM, A_KC>(ra0, A, p.lda, m0, p.M, kbeg, kend, tid);
-  fload<CT, BN, B_KC>(rb0, B, p.ldb, n0, p.N, kbeg, kend, tid);
+  fload<CT, BM, A_KC, BKT>(ra0, A, p.lda, m0, p.M, kbeg, kend, tid);
+  fload<CT, BN, B_KC, BKT>(rb0, B, p.ldb, n0, p.N, kbeg, kend, tid);
   if (nk > 1) {
-    fload<CT, BM, A_KC>(ra1, A, p.lda, m0, p.M, kbeg + BK, kend, tid);
-    fload<CT, BN, B_KC>(rb1, B, p.ldb, n0, p.N, kbeg + BK, kend, tid);
+    fload<CT, BM, A_KC, BKT>(ra1, A, p.lda, m0, p.M, kbeg + BK, kend, tid);
+    fload<CT, BN, B_KC, BKT>(rb1, B, p.ldb, n0, p.N, kbeg + BK, kend, tid);
   }
-  fstore<CT, BM, A_KC>(lds, ra0, kbeg, kend, tid, p.a_gelu != 0);
-  fstore<CT, BN, B_KC>(lds + TA::elems, rb0, kbeg, kend, tid, p.b_gelu != 0);
+  fstore<CT, BM, A_KC, BKT>(lds, ra0, kbeg, kend, tid, p.a_gelu != 0);
+  fstore<CT, BN, B_KC, BKT>(lds + TA::elems, rb0, kbeg, kend, tid, p.b_gelu != 0);
   __syncthreads();
 
   auto compute = [&](const CT* As, const CT* Bs) {
@@ -203,25 +203,25 @@ __global__ __launch_bounds__(256) void gemm_fast_kernel(FastArgs p) {
   for (int t = 0; t < nk; t += 2) {
     // even phase: tile t is in buffer 0, set 1 holds tile t+1 (in flight)
     if (t + 2 < nk) {
-      fload<CT, BM, A_KC>(ra0, A, p.lda, m0, p.M, kbeg + (t + 2) * BK, kend, tid);
-      fload<CT, BN, B_KC>(rb0, B, p.ldb, n0, p.N, kbeg + (t + 2) * BK, kend, tid);
+      fload<CT, BM, A_KC, BKT>(ra0, A, p.lda, m0, p.M, kbeg + (t + 2) * BK, kend, tid);
+      fload<CT, BN, B_KC, BKT>(rb0, B, p.ldb, n0, p.N, kbeg + (t + 2) * BK, kend, tid);
     }
     compute(lds, lds + TA::elems);
     if (t + 1 < nk) {
-      fstore<CT, BM, A_KC>(lds + STAGE, ra1, kbeg + (t + 1) * BK, kend, tid, p.a_gelu != 0);
-      fstore<CT, BN, B_KC>(lds + STAGE + TA::elems, rb1, kbeg + (t + 1) * BK, kend, tid, p.b_gelu != 0);
+      fstore<CT, BM, A_KC, BKT>(lds + STAGE, ra1, kbeg + (t + 1) * BK, kend, tid, p.a_gelu != 0);
+      fstore<CT, BN, B_KC, BKT>(lds + STAGE + TA::elems, rb1, kbeg + (t + 1) * BK, kend, tid, p.b_gelu != 0);
     }
     __syncthreads();
     if (t + 1 >= nk) break;
     // odd phase: tile t+1 is in buffer 1, set 0 holds tile t+2
     if (t + 3 < nk) {
-      fload<CT, BM, A_KC>(ra1, A, p.lda, m0, p.M, kbeg + (t + 3) * BK, kend, tid);
-      fload<CT, BN, B_KC>(rb1, B, p.ldb, n0, p.N, kbeg + (t + 3) * BK, kend, tid);
+      fload<CT, BM, A_KC, BKT>(ra1, A, p.lda, m0, p.M, kbeg + (t + 3) * BK, kend, tid);
+      fload<CT, BN, B_KC, BKT>(rb1, B, p.ldb, n0, p.N, kbeg + (t + 3) * BK, kend, tid);
     }
     compute(lds + STAGE, lds + STAGE + TA::elems);
     if (t + 2 < nk) {
-      fstore<CT, BM, A_KC>(lds, ra0, kbeg + (t + 2) * BK, kend, tid, p.a_gelu != 0);
-      fstore<CT, BN, B_KC>(lds + TA::elems, rb0, kbeg + (t + 2) * BK, kend, tid, p.b_gelu != 0);
+      fstore<CT, BM, A_KC, BKT>(lds, ra0, kbeg + (t + 2) * BK, kend, tid, p.a_gelu != 0);
+      fstore<CT, BN, B_KC, BKT>(lds + TA::elems, rb0, kbeg + (t + 2) * BK, kend, tid, p.b_gelu != 0);
     }
     __syncthreads();
   }
@@ -374,11 +374,11 @@ __global__ __launch_bounds__(256) void gemm_persist_kernel(FastArgs p) {
   int mt = blockIdx.y;
   bool first = true;
   if (mt < mtiles) {
-    fload<CT, BM, true>(ra0, A, p.lda, mt * BM, p.M, 0, K, tid);
-    fload<CT, BN, B_KC>(rb0, B, p.ldb, n0, p.N, 0, K, tid);
+    fload<CT, BM, true, FT<CT>::BK>(ra0, A, p.lda, mt * BM, p.M, 0, K, tid);
+    fload<CT, BN, B_KC, FT<CT>::BK>(rb0, B, p.ldb, n0, p.N, 0, K, tid);
     if (nk > 1) {
-      fload<CT, BM, true>(ra1, A, p.lda, mt * BM, p.M, BK, K, tid);
-      fload<CT, BN, B_KC>(rb1, B, p.ldb, n0, p.N, BK, K, tid);
+      fload<CT, BM, true, FT<CT>::BK>(ra1, A, p.lda, mt * BM, p.M, BK, K, tid);
+      fload<CT, BN, B_KC, FT<CT>::BK>(rb1, B, p.ldb, n0, p.N, BK, K, tid);
     }
   }
   for (; mt < mtiles; mt += gridDim.y) {
@@ -390,8 +390,8 @@ __global__ __launch_bounds__(256) void gemm_persist_kernel(FastArgs p) {
 #pragma unroll
       for (int j = 0; j < NI; ++j) acc[i][j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
 
-    fstore<CT, BM, true>(As0, ra0, 0, K, tid, p.a_gelu != 0);
-    if (loadB) fstore<CT, BN, B_KC>(Bs0, rb0, 0, K, tid, p.b_gelu != 0);
+    fstore<CT, BM, true, FT<CT>::BK>(As0, ra0, 0, K, tid, p.a_gelu != 0);
+    if (loadB) fstore<CT, BN, B_KC, FT<CT>::BK>(Bs0, rb0, 0, K, tid, p.b_gelu != 0);
     __syncthreads();
 
     auto compute = [&](const CT* As, const CT* Bs) {
@@ -415,24 +415,24 @@ __global__ __launch_bounds__(256) void gemm_persist_kernel(FastArgs p) {
 
     for (int t = 0; t < nk; t += 2) {
       if (t + 2 < nk) {
-        fload<CT, BM, true>(ra0, A, p.lda, m0, p.M, (t + 2) * BK, K, tid);
-        if (loadB) fload<CT, BN, B_KC>(rb0, B, p.ldb, n0, p.N, (t + 2) * BK, K, tid);
+        fload<CT, BM, true, FT<CT>::BK>(ra0, A, p.lda, m0, p.M, (t + 2) * BK, K, tid);
+        if (loadB) fload<CT, BN, B_KC, FT<CT>::BK>(rb0, B, p.ldb, n0, p.N, (t + 2) * BK, K, tid);
       }
       compute(As0, Bs0);
       if (t + 1 < nk) {
-        fstore<CT, BM, true>(As1, ra1, (t + 1) * BK, K, tid, p.a_gelu != 0);
-        if (loadB) fstore<CT, BN, B_KC>(Bs1, rb1, (t + 1) * BK, K, tid, p.b_gelu != 0);
+        fstore<CT, BM, true, FT<CT>::BK>(As1, ra1, (t + 1) * BK, K, tid, p.a_gelu != 0);
+        if (loadB) fstore<CT, BN, B_KC, FT<CT>::BK>(Bs1, rb1, (t + 1) * BK, K, tid, p.b_gelu != 0);
       }
       __syncthreads();
       if (t + 1 >= nk) break;
       if (t + 3 < nk) {
-        fload<CT, BM, true>(ra1, A, p.lda, m0, p.M, (t + 3) * BK, K, tid);
-        if (loadB) fload<CT, BN, B_KC>(rb1, B, p.ldb, n0, p.N, (t + 3) * BK, K, tid);
+        fload<CT, BM, true, FT<CT>::BK>(ra1, A, p.lda, m0, p.M, (t + 3) * BK, K, tid);
+        if (loadB) fload<CT, BN, B_KC, FT<CT>::BK>(rb1, B, p.ldb, n0, p.N, (t + 3) * BK, K, tid);
       }
       compute(As1, Bs1);
       if (t + 2 < nk) {
-        fstore<CT, BM, true>(As0, ra0, (t + 2) * BK, K, tid, p.a_gelu != 0);
-        if (loadB) fstore<CT, BN, B_KC>(Bs0, rb0, (t + 2) * BK, K, tid, p.b_gelu != 0);
+        fstore<CT, BM, true, FT<CT>::BK>(As0, ra0, (t + 2) * BK, K, tid, p.a_gelu != 0);
+        if (loadB) fstore<CT, BN, B_KC, FT<CT>::BK>(Bs0, rb0, (t + 2) * BK, K, tid, p.b_gelu != 0);
       }
       __syncthreads();
     }
@@ -441,11 +441,11 @@ __global__ __launch_bounds__(256) void gemm_persist_kernel(FastArgs p) {
     const int mnext = mt + gridDim.y;
     if (mnext < mtiles) {
       const bool nextB = !b_resident;
-      fload<CT, BM, true>(ra0, A, p.lda, mnext * BM, p.M, 0, K, tid);
-      if (nextB) fload<CT, BN, B_KC>(rb0, B, p.ldb, n0, p.N, 0, K, tid);
+      fload<CT, BM, true, FT<CT>::BK>(ra0, A, p.lda, mnext * BM, p.M, 0, K, tid);
+      if (nextB) fload<CT, BN, B_KC, FT<CT>::BK>(rb0, B, p.ldb, n0, p.N, 0, K, tid);
       if (nk > 1) {
-        fload<CT, BM, true>(ra1, A, p.lda, mnext * BM, p.M, BK, K, tid);
-        if (nextB) fload<CT, BN, B_KC>(rb1, B, p.ldb, n0, p.N, BK, K, tid);
+        fload<CT, BM, true, FT<CT>::BK>(ra1, A, p.lda, mnext * BM, p.M, BK, K, tid);
+        if (nextB) fload<CT, BN, B_KC, FT<CT>::BK>(rb1, B, p.ldb, n0, p.N, BK, K, tid);
       }
     }
     first = false;
@@ -579,13 +579,13 @@ __global__ void splitk_epilogue_kernel(FastArgs p, int nsplit) {
   }
 }
 
-template <typename CT, int BM, int BN, int WM, int WN>
+template <typename CT, int BM, int BN, int WM, int WN, int BKT = FT<CT>::BK>
 static int flaunch_layout(const FastArgs& a, int layout, int nsplit, hipStream_t s) {
   dim3 grid((a.N + BN - 1) / BN, (a.M + BM - 1) / BM, nsplit), block(256);
   switch (layout) {
-    case LAYOUT_NT: hipLaunchKernelGGL((gemm_fast_kernel<CT, BM, BN, WM, WN, LAYOUT_NT>), grid, block, 0, s, a); break;
-    case LAYOUT_NN: hipLaunchKernelGGL((gemm_fast_kernel<CT, BM, BN, WM, WN, LAYOUT_NN>), grid, block, 0, s, a); break;
-    case LAYOUT_TN: hipLaunchKernelGGL((gemm_fast_kernel<CT, BM, BN, WM, WN, LAYOUT_TN>), grid, block, 0, s, a); break;
+    case LAYOUT_NT: hipLaunchKernelGGL((gemm_fast_kernel<CT, BM, BN, WM, WN, BKT, LAYOUT_NT>), grid, block, 0, s, a); break;
+    case LAYOUT_NN: hipLaunchKernelGGL((gemm_fast_kernel<CT, BM, BN, WM, WN, BKT, LAYOUT_NN>), grid, block, 0, s, a); break;
+    case LAYOUT_TN: hipLaunchKernelGGL((gemm_fast_kernel<CT, BM, BN, WM, WN, BKT, LAYOUT_TN>), grid, block, 0, s, a); break;
     default: return SCOT_ERR_UNSUPPORTED;
   }
   return scot_check_launch();
@@ -597,14 +597,28 @@ template <> int flaunch_tile<bf16_t>(int tile, const FastArgs& a, int layout, in
     case 1: return flaunch_layout<bf16_t, 128, 96, 4, 1>(a, layout, nsplit, s);
     case 2: return flaunch_layout<bf16_t, 64, 96, 2, 2>(a, layout, nsplit, s);
     case 3: return flaunch_layout<bf16_t, 128, 128, 2, 2>(a, layout, nsplit, s);
+    case 4: return flaunch_layout<bf16_t, 96, 96, 2, 2, 64>(a, layout, nsplit, s);
+    case 5: return flaunch_layout<bf16_t, 96, 96, 2, 2, 32>(a, layout, nsplit, s);
+    case 6: return flaunch_layout<bf16_t, 64, 64, 2, 2, 32>(a, layout, nsplit, s);
+    case 7: return flaunch_layout<bf16_t, 128, 96, 4, 1, 32>(a, layout, nsplit, s);
     default: return flaunch_layout<bf16_t, 64, 64, 2, 2>(a, layout, nsplit, s);
   }
 }
 template <> int flaunch_tile<float>(int tile, const FastArgs& a, int layout, int nsplit, hipStream_t s) {
   return tile == 3 ? flaunch_layout<float, 128, 128, 2, 2>(a, layout, nsplit, s) : flaunch_layout<float, 64, 64, 2, 2>(a, layout, nsplit, s);
 }
-static void tile_dims(int tile, int& bm, int& bn) {
-  switch (tile) { case 1: bm = 128; bn = 96; break; case 2: bm = 64; bn = 96; break; case 3: bm = 128; bn = 128; break; default: bm = 64; bn = 64; }
+static void tile_dims(int tile, int& bm, int& bn, int& bkt) {
+  bkt = 64;
+  switch (tile) {
+    case 1: bm = 128; bn = 96; break;
+    case 2: bm = 64; bn = 96; break;
+    case 3: bm = 128; bn = 128; break;
+    case 4: bm = 96; bn = 96; break;
+    case 5: bm = 96; bn = 96; bkt = 32; break;
+    case 6: bm = 64; bn = 64; bkt = 32; break;
+    case 7: bm = 128; bn = 96; bkt = 32; break;
+    default: bm = 64; bn = 64;
+  }
 }
 
 extern int g_scot_use_tr;
@@ -632,9 +646,8 @@ int scot_gemm_fast(int layout, int compute, int M, int N, int K, const void* A, 
   if (xcd < 0) { const char* e = getenv("SCOT_GEMM_XCD"); xcd = e ? atoi(e) : 1; }
   a.xcd_swizzle = xcd;
   if (C2 && ((((uintptr_t)C2) & 15) != 0 || layout == LAYOUT_TN)) return SCOT_ERR_UNSUPPORTED;
-  const int bk = compute == SCOT_BF16 ? 64 : 32;
+  int bk = compute == SCOT_BF16 ? 64 : 32;
   int nsplit = 1;
-  a.ksplit = ((K + bk - 1) / bk) * bk;
   // tile choice: SCOT_GEMM_TILE[_NT|_NN|_TN] = 0..3 forces a shape (tuning), otherwise the per-layout policy below
   static int ov[4] = {-2, -2, -2, -2};
   if (ov[3] == -2) {
@@ -645,10 +658,13 @@ int scot_gemm_fast(int layout, int compute, int M, int N, int K, const void* A, 
   if (tile < 0) {
     tile = 0;   // policy (see DESIGN.md §3 for the measurements behind it)
     if (compute == SCOT_BF16 && N == 96) tile = 2;   // one 64x96 column tile: the A operand streams once (64x64 would read it twice)
+    else if (compute == SCOT_BF16 && layout != LAYOUT_TN && K <= 128) tile = 6;   // K = 96: BK = 32 halves LDS -> more workgroups/CU (-12 %)
   }
   if (compute != SCOT_BF16 && tile != 0 && tile != 3) tile = 0;   // fp32 instantiates 64x64 and 128x128 only
-  int bm, bn;
-  tile_dims(tile, bm, bn);
+  int bm, bn, bkt;
+  tile_dims(tile, bm, bn, bkt);
+  if (compute == SCOT_BF16) bk = bkt;
+  a.ksplit = ((K + bk - 1) / bk) * bk;
   const long tiles = (long)((M + bm - 1) / bm) * ((N + bn - 1) / bn);
   const long nkt = (K + bk - 1) / bk;
   if (layout == LAYOUT_TN) {
