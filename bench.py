@@ -151,7 +151,7 @@ def dominant_kernel_probe(compute, batch, embed_dim, size):
     ops.window_attn_fwd(cm, qkv, o, lse, tab, ls, batch, Hp, Hp, C, heads, ws, 8)
     dq = torch.empty_like(qkv)
     dtab, dls = torch.zeros_like(tab), torch.zeros(heads, device="cuda")
-    ms2 = timed(lambda: ops.window_attn_bwd(cm, qkv, do, lse, tab, ls, dq, dtab, dls, batch, Hp, Hp, C, heads, ws, 8))
+    ms2 = timed(lambda: ops.window_attn_bwd(cm, qkv, o, do, lse, tab, ls, dq, dtab, dls, batch, Hp, Hp, C, heads, ws, 8))
     fl2 = 2.5 * 4.0 * batch * nW * heads * (ws * ws) ** 2 * (C // heads)
     out["runner_up"] = {"kernel": "attn_bwd_kernel<bf16,32,16> (stage 0)", "us": ms2 * 1e3, "tflops": fl2 / ms2 / 1e9}
     return out

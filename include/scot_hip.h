@@ -55,7 +55,7 @@ int scot_gemm(int layout, int compute, int M, int N, int K,
 int scot_window_attn_fwd(int compute, const void* qkv, void* out, float* lse, const float* bias_table,
                          const float* logit_scale, int batch, int Hp, int Wp, int C, int heads, int ws, int shift,
                          scot_stream_t stream);
-int scot_window_attn_bwd(int compute, const void* qkv, const void* dout, const float* lse, const float* bias_table,
+int scot_window_attn_bwd(int compute, const void* qkv, const void* out_fwd, const void* dout, const float* lse, const float* bias_table,
                          const float* logit_scale, void* dqkv, float* dbias_table, float* dlogit_scale, int batch,
                          int Hp, int Wp, int C, int heads, int ws, int shift, scot_stream_t stream);
 

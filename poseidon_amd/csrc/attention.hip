@@ -19,6 +19,7 @@ struct AttnArgs {
   const void* qkv;   // [tokens][3C]  (q | k | v), dtype = compute type
   void* out;         // fwd: O [tokens][C];           bwd: dqkv [tokens][3C]
   const void* dout;  // bwd: dO [tokens][C]
+  const void* ofwd;  // bwd: O  [tokens][C] (the forward output; delta = rowsum(dO ∘ O))
   float* lse;        // [windows][heads][N]  log-sum-exp of each softmax row (fwd writes, bwd reads)
   const float* bias_table;   // [heads][(2ws-1)^2]  = 16·sigmoid(CPB-MLP)
   const float* logit_scale;  // [heads]
@@ -271,16 +272,139 @@ template <int CTRL> __device__ __forceinline__ float dpp_row(float v) {
   return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xF, 0xF, true));
 }
 
+// Raw fp32 values of a 16-row block in B-operand order (lane (c = lane&15, g): features kk*32 + g*8 .. +7 of row n0+c).
+template <typename CT, int HD>
+__device__ __forceinline__ void load_rows_f32(float (&v)[(HD + 31) / 32][8], const void* src, int ld, int col, const int* tok,
+                                              int n0, int N, int lane) {
+  constexpr int KS = (HD + 31) / 32;
+  const int n = n0 + (lane & 15), g = lane >> 4;
+  const bool valid = n < N;
+  const size_t base = valid ? (size_t)tok[n] * ld + col : 0;
+#pragma unroll
+  for (int kk = 0; kk < KS; ++kk) {
+    const int d = kk * 32 + g * 8;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) v[kk][j] = 0.f;
+    if (valid && d < HD) ld8(src, ct_traits<CT>::dtype, base + d, v[kk]);
+  }
+}
+
+// ---- backward, kernel 1 of 2: dQ, d bias-table.  Queries on lane columns (S^T tiles); K (normalised) and V in LDS.
+// delta = rowsum(dO ∘ O) comes from the forward output, so every 16x32 block of scores is consumed as soon as it is
+// produced (no 128-register S/dP pair): S^T, dP^T -> P -> dS -> {table histogram, dQ += dS·Kn}.
 template <typename CT, int HD, int NT>
-__global__ __launch_bounds__(256, 2) void attn_bwd_kernel(AttnArgs p) {
+__global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(AttnArgs p) {
   constexpr int NP = NT * 16, KS = (HD + 31) / 32, DT = HD / 16, pitch = row_pitch<HD, CT>();
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  CT* X = (CT*)smem;            // phase B: Kn   phase A: Qn
-  CT* Y = X + NP * pitch;       // phase B: V    phase A: dO
+  CT* X = (CT*)smem;            // Kn
+  CT* Y = X + NP * pitch;       // V
   const int ws = p.ws, N = ws * ws, TW = 2 * ws - 1, TS = TW * TW, TSP = (TS + 3) & ~3;
   float* tab = (float*)(Y + NP * pitch);
   float* dtab = tab + TSP;
-  float* lse = dtab + TSP;      // [NP]
+  int* rid = (int*)(dtab + TSP);
+  int* tok = rid + NP;
+
+  const int win = blockIdx.x, h = blockIdx.y;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int ld = 3 * p.C, g = lane >> 4, lc = lane & 15;
+
+  for (int i = tid; i < TS; i += 256) { tab[i] = p.bias_table[h * TS + i]; dtab[i] = 0.f; }
+  for (int i = tid; i < NP; i += 256) { rid[i] = pos_info(p, win, i, N); tok[i] = i < N ? win_token(p, win, i) : 0; }
+  __syncthreads();
+  stage_rows<CT, HD, NP>(X, p.qkv, ld, p.C + h * HD, tok, N, true, tid);
+  stage_rows<CT, HD, NP>(Y, p.qkv, ld, 2 * p.C + h * HD, tok, N, false, tid);
+  __syncthreads();
+
+  const float scale = __expf(fminf(p.logit_scale[h], 4.605170185988092f));
+  const int cen = (ws - 1) * TW + ws - 1;
+
+  for (int qb = wave; qb * 16 < N; qb += 4) {
+    const int q0 = qb * 16;
+    Frag<CT> qf[KS], gf[KS];
+    load_rows_frag<CT, HD>(qf, p.qkv, ld, h * HD, tok, q0, N, true, lane);
+    float delta = 0.f;
+    {
+      float dov[KS][8], ov[KS][8];
+      load_rows_f32<CT, HD>(dov, p.dout, p.C, h * HD, tok, q0, N, lane);
+      load_rows_f32<CT, HD>(ov, p.ofwd, p.C, h * HD, tok, q0, N, lane);
+#pragma unroll
+      for (int kk = 0; kk < KS; ++kk) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) delta += dov[kk][j] * ov[kk][j];
+        gf[kk] = frag_from_f32<CT>(dov[kk]);
+      }
+      delta += __shfl_xor(delta, 16, 64);
+      delta += __shfl_xor(delta, 32, 64);
+    }
+    const int q = q0 + lc;
+    const bool qvalid = q < N;
+    const int qinfo = rid[min(q, NP - 1)];
+    const int qoff = (qinfo & 0xfffff) + cen, qrid = qinfo >> 20;
+    const float qlse = qvalid ? p.lse[((size_t)win * p.heads + h) * N + q] : 3.0e38f;
+
+    f32x4_t dq[DT];
+#pragma unroll
+    for (int d = 0; d < DT; ++d) dq[d] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+
+#pragma unroll 2
+    for (int tp = 0; tp < NT / 2; ++tp) {
+      float ds8[8];
+#pragma unroll
+      for (int half = 0; half < 2; ++half) {
+        const int t = 2 * tp + half;
+        f32x4_t s = {0.f, 0.f, 0.f, 0.f}, dp = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int kk = 0; kk < KS; ++kk) {
+          mma16(s, lds_frag_kc(X, pitch, t * 16, kk * 32, lane), qf[kk]);
+          mma16(dp, lds_frag_kc(Y, pitch, t * 16, kk * 32, lane), gf[kk]);
+        }
+        const int4 ki = *(const int4*)&rid[t * 16 + g * 4];
+        const int kia[4] = {ki.x, ki.y, ki.z, ki.w};
+        float ds[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int krid = kia[r] >> 20;
+          float v = s[r] * scale + tab[qoff - (kia[r] & 0xfffff)];
+          v = (krid != qrid) ? v - 200.0f : v;
+          float pr = __expf(v - qlse);
+          pr = (krid == 15 || !qvalid) ? 0.f : pr;
+          ds[r] = pr * (dp[r] - delta);
+          ds8[half * 4 + r] = ds[r];
+        }
+        if (ws == 16) {   // anti-diagonal pre-reduction with DPP row shifts, see DESIGN.md
+          const float a = ds[0] + dpp_row<0x101>(ds[1]) + dpp_row<0x102>(ds[2]) + dpp_row<0x103>(ds[3]);
+          const float bt = dpp_row<0x11F>(ds[1]) + dpp_row<0x11E>(ds[2]) + dpp_row<0x11D>(ds[3]);
+          const int ia = qoff - (kia[0] & 0xfffff);
+          atomicAdd(&dtab[ia], a);
+          if (lc >= 13) atomicAdd(&dtab[ia - 16], bt);
+        } else {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) atomicAdd(&dtab[qoff - (kia[r] & 0xfffff)], ds[r]);
+        }
+      }
+      const Frag<CT> df = frag_from_f32<CT>(ds8);
+#pragma unroll
+      for (int d = 0; d < DT; ++d)
+        mma16(dq[d], df, lds_frag_ks(X, pitch, d * 16, (2 * tp) * 16 + g * 4, (2 * tp + 1) * 16 + g * 4, lane, p.use_tr));
+    }
+    normalize_bwd_store<CT, HD>(dq, scale, p.qkv, ld, h * HD, p.out, h * HD, tok, q0, N, lane);
+  }
+  __syncthreads();
+  for (int i = tid; i < TS; i += 256) atomicAdd(&p.dbias_table[h * TS + i], dtab[i]);
+}
+
+// ---- backward, kernel 2 of 2: dK, dV, d logit_scale.  Keys on lane columns (S tiles); Q (normalised) and dO in LDS.
+// Independent of kernel 1 (delta is recomputed from dO ∘ O while dO is staged), so the two can run concurrently.
+template <typename CT, int HD, int NT>
+__global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(AttnArgs p) {
+  constexpr int NP = NT * 16, KS = (HD + 31) / 32, DT = HD / 16, pitch = row_pitch<HD, CT>();
+  constexpr int CPR = KS * 4;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  CT* X = (CT*)smem;            // Qn
+  CT* Y = X + NP * pitch;       // dO
+  const int ws = p.ws, N = ws * ws, TW = 2 * ws - 1, TS = TW * TW, TSP = (TS + 3) & ~3;
+  float* tab = (float*)(Y + NP * pitch);
+  float* lse = tab + TSP;       // [NP]
   float* delta = lse + NP;      // [NP]
   int* rid = (int*)(delta + NP);
   int* tok = rid + NP;
@@ -290,110 +414,38 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_kernel(AttnArgs p) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int ld = 3 * p.C, g = lane >> 4, lc = lane & 15;
 
-  for (int i = tid; i < TS; i += 256) { tab[i] = p.bias_table[h * TS + i]; dtab[i] = 0.f; }
+  for (int i = tid; i < TS; i += 256) tab[i] = p.bias_table[h * TS + i];
   for (int i = tid; i < NP; i += 256) {
     rid[i] = pos_info(p, win, i, N);
     tok[i] = i < N ? win_token(p, win, i) : 0;
     lse[i] = i < N ? p.lse[((size_t)win * p.heads + h) * N + i] : 3.0e38f;
   }
   __syncthreads();
-  stage_rows<CT, HD, NP>(X, p.qkv, ld, p.C + h * HD, tok, N, true, tid);
-  stage_rows<CT, HD, NP>(Y, p.qkv, ld, 2 * p.C + h * HD, tok, N, false, tid);
+  stage_rows<CT, HD, NP>(X, p.qkv, ld, h * HD, tok, N, true, tid);
+  // dO -> LDS and delta[n] = Σ_d dO[n][d]·O[n][d] in the same pass (CPR lanes per row)
+  for (int c = tid; c < NP * CPR; c += 256) {
+    const int n = c / CPR, d8 = (c % CPR) * 8;
+    float v[8], o[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { v[j] = 0.f; o[j] = 0.f; }
+    if (n < N && d8 < HD) {
+      ld8(p.dout, ct_traits<CT>::dtype, (size_t)tok[n] * p.C + h * HD + d8, v);
+      ld8(p.ofwd, ct_traits<CT>::dtype, (size_t)tok[n] * p.C + h * HD + d8, o);
+    }
+    float dot = 0.f;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) dot += v[j] * o[j];
+#pragma unroll
+    for (int of = 1; of < CPR; of <<= 1) dot += __shfl_xor(dot, of, 64);
+    if ((c % CPR) == 0) delta[n] = dot;
+    store8_ct(Y + n * pitch + d8, v);
+  }
   __syncthreads();
 
   const float ls = p.logit_scale[h];
   const float scale = __expf(fminf(ls, 4.605170185988092f));
   const int cen = (ws - 1) * TW + ws - 1;
   float dls = 0.f;
-
-  // ---------------------------------------------------------------- phase B
-  for (int qb = wave; qb * 16 < N; qb += 4) {
-    const int q0 = qb * 16;
-    Frag<CT> qf[KS], gf[KS];
-    load_rows_frag<CT, HD>(qf, p.qkv, ld, h * HD, tok, q0, N, true, lane);
-    load_rows_frag<CT, HD>(gf, p.dout, p.C, h * HD, tok, q0, N, false, lane);
-    const int q = q0 + lc;
-    const bool qvalid = q < N;
-    const int qinfo = rid[min(q, NP - 1)];
-    const int qoff = (qinfo & 0xfffff) + cen, qrid = qinfo >> 20;
-    const float qlse = qvalid ? lse[q] : 3.0e38f;
-
-    f32x4_t s[NT], dp[NT];
-    float dl = 0.f;
-#pragma unroll
-    for (int t = 0; t < NT; ++t) {
-      s[t] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
-      dp[t] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-      for (int kk = 0; kk < KS; ++kk) {
-        mma16(s[t], lds_frag_kc(X, pitch, t * 16, kk * 32, lane), qf[kk]);
-        mma16(dp[t], lds_frag_kc(Y, pitch, t * 16, kk * 32, lane), gf[kk]);
-      }
-    }
-    // s: cos -> P   (branch-free, see forward)
-#pragma unroll
-    for (int t = 0; t < NT; ++t) {
-      const int4 ki = *(const int4*)&rid[t * 16 + g * 4];
-      const int kia[4] = {ki.x, ki.y, ki.z, ki.w};
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int krid = kia[r] >> 20;
-        float v = s[t][r] * scale + tab[qoff - (kia[r] & 0xfffff)];
-        v = (krid != qrid) ? v - 200.0f : v;
-        float pr = __expf(v - qlse);
-        pr = (krid == 15 || !qvalid) ? 0.f : pr;
-        s[t][r] = pr;
-        dl += pr * dp[t][r];
-      }
-    }
-    dl += __shfl_xor(dl, 16, 64);
-    dl += __shfl_xor(dl, 32, 64);
-    if (g == 0 && qvalid) delta[q] = dl;
-#pragma unroll
-    for (int t = 0; t < NT; ++t) {
-      const int4 ki = *(const int4*)&rid[t * 16 + g * 4];
-      const int kia[4] = {ki.x, ki.y, ki.z, ki.w};
-#pragma unroll
-      for (int r = 0; r < 4; ++r) s[t][r] = s[t][r] * (dp[t][r] - dl);   // dS; exactly 0 for masked pairs (P = 0)
-      if (ws == 16) {
-        // A 16-key tile is one row of the window, a 16-query block one row too: the table row (qy-ky) is uniform and the
-        // column is qx-kx.  Keys kx = 4g+r of this lane group: sum the 4 registers along the anti-diagonal with row
-        // shifts first (lane l <- ds_r[l+r]); the 3 diagonals that fall off the left edge are collected by lanes 13..15.
-        // 76 instead of 256 LDS float atomics per tile (PMC: the per-element atomics kept the LDS busy 57 k cycles/wave).
-        const float a = s[t][0] + dpp_row<0x101>(s[t][1]) + dpp_row<0x102>(s[t][2]) + dpp_row<0x103>(s[t][3]);
-        const float bt = dpp_row<0x11F>(s[t][1]) + dpp_row<0x11E>(s[t][2]) + dpp_row<0x11D>(s[t][3]);
-        const int ia = qoff - (kia[0] & 0xfffff);
-        atomicAdd(&dtab[ia], a);
-        if (lc >= 13) atomicAdd(&dtab[ia - 16], bt);
-      } else {
-#pragma unroll
-        for (int r = 0; r < 4; ++r) atomicAdd(&dtab[qoff - (kia[r] & 0xfffff)], s[t][r]);
-      }
-    }
-    // dQn = scale * dS · Kn   (A = dS in registers, B = Kn rows via the transposing read)
-    f32x4_t dq[DT];
-#pragma unroll
-    for (int d = 0; d < DT; ++d) dq[d] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-    for (int tp = 0; tp < NT / 2; ++tp) {
-      float dv8[8];
-#pragma unroll
-      for (int r = 0; r < 4; ++r) { dv8[r] = s[2 * tp][r]; dv8[r + 4] = s[2 * tp + 1][r]; }
-      const Frag<CT> df = frag_from_f32<CT>(dv8);
-#pragma unroll
-      for (int d = 0; d < DT; ++d)
-        mma16(dq[d], df, lds_frag_ks(X, pitch, d * 16, (2 * tp) * 16 + g * 4, (2 * tp + 1) * 16 + g * 4, lane, p.use_tr));
-    }
-    normalize_bwd_store<CT, HD>(dq, scale, p.qkv, ld, h * HD, p.out, h * HD, tok, q0, N, lane);
-  }
-
-  __syncthreads();  // every wave is done reading X/Y (phase B) and delta[] is complete
-  for (int i = tid; i < TS; i += 256) atomicAdd(&p.dbias_table[h * TS + i], dtab[i]);
-
-  // ---------------------------------------------------------------- phase A
-  stage_rows<CT, HD, NP>(X, p.qkv, ld, h * HD, tok, N, true, tid);       // Qn
-  stage_rows<CT, HD, NP>(Y, p.dout, p.C, h * HD, tok, N, false, tid);    // dO
-  __syncthreads();
 
   for (int kb = wave; kb * 16 < N; kb += 4) {
     const int k0 = kb * 16;
@@ -409,7 +461,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_kernel(AttnArgs p) {
 #pragma unroll
     for (int d = 0; d < DT; ++d) { dv[d] = (f32x4_t){0.f, 0.f, 0.f, 0.f}; dk[d] = (f32x4_t){0.f, 0.f, 0.f, 0.f}; }
 
-#pragma unroll 1
+#pragma unroll 2
     for (int tp = 0; tp < NT / 2; ++tp) {
       float pf8[8], df8[8];
 #pragma unroll
@@ -434,8 +486,8 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_kernel(AttnArgs p) {
           const bool ok = qrid != 15 && kvalid;
           const float pr = ok ? __expf(v - qla[r]) : 0.f;
           const float ds = ok ? pr * (dp[r] - qda[r]) : 0.f;
-          // d logit_scale = Σ dS·cos·scale, accumulated HERE in fp32 from the un-rounded dS and the very cos the forward used
-          // (Σ_k dS = 0, so this sum cancels heavily: taking it from the bf16 dS·Kn product was off by O(1) on small heads)
+          // d logit_scale = Σ dS·cos·scale in fp32 from the un-rounded dS and the very cos the forward used (Σ_k dS = 0:
+          // the sum cancels heavily; taking it from the bf16 dS·Kn product was off by O(1) on small heads)
           dls += ds * s[r];
           pf8[half * 4 + r] = pr;
           df8[half * 4 + r] = ds;
@@ -449,7 +501,6 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_kernel(AttnArgs p) {
         mma16(dk[d], df, lds_frag_ks(X, pitch, d * 16, klo, khi, lane, p.use_tr));   // dKn += dS^T · Qn
       }
     }
-    // dv: rows = keys k0 + g*4 + r, col = feature
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       const int kk2 = k0 + g * 4 + r;
@@ -476,13 +527,19 @@ static int launch_attn(const AttnArgs& a, int nwin, bool bwd, hipStream_t s) {
   constexpr int NP = NT * 16, pitch = row_pitch<HD, CT>();
   const int TS = (2 * a.ws - 1) * (2 * a.ws - 1), TSP = (TS + 3) & ~3;
   size_t sh = 2 * NP * pitch * sizeof(CT);
-  if (bwd) sh += (2 * TSP + 2 * NP) * sizeof(float) + 2 * NP * sizeof(int) + 4 * sizeof(float);
+  const size_t sh_dq = sh + 2 * TSP * sizeof(float) + 2 * NP * sizeof(int);
+  const size_t sh_dkv = sh + (TSP + 2 * NP) * sizeof(float) + 2 * NP * sizeof(int) + 4 * sizeof(float);
+  if (bwd) sh = sh_dq > sh_dkv ? sh_dq : sh_dkv;
   else sh += TSP * sizeof(float) + 2 * NP * sizeof(int);
   if (sh > 160 * 1024) return SCOT_ERR_UNSUPPORTED;
   dim3 grid(nwin, a.heads), block(256);
   if (bwd) {
-    if (sh > 64 * 1024) (void)hipFuncSetAttribute((const void*)attn_bwd_kernel<CT, HD, NT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh);
-    hipLaunchKernelGGL((attn_bwd_kernel<CT, HD, NT>), grid, block, sh, s, a);
+    if (sh > 64 * 1024) {
+      (void)hipFuncSetAttribute((const void*)attn_bwd_dq_kernel<CT, HD, NT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh_dq);
+      (void)hipFuncSetAttribute((const void*)attn_bwd_dkv_kernel<CT, HD, NT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh_dkv);
+    }
+    hipLaunchKernelGGL((attn_bwd_dq_kernel<CT, HD, NT>), grid, block, sh_dq, s, a);
+    hipLaunchKernelGGL((attn_bwd_dkv_kernel<CT, HD, NT>), grid, block, sh_dkv, s, a);
   } else {
     if (sh > 64 * 1024) (void)hipFuncSetAttribute((const void*)attn_fwd_kernel<CT, HD, NT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh);
     hipLaunchKernelGGL((attn_fwd_kernel<CT, HD, NT>), grid, block, sh, s, a);
@@ -531,14 +588,14 @@ extern "C" int scot_window_attn_fwd(int compute, const void* qkv, void* out, flo
                               : dispatch_hd<float>(a, C / heads, nwin, false, stream);
 }
 
-extern "C" int scot_window_attn_bwd(int compute, const void* qkv, const void* dout, const float* lse,
+extern "C" int scot_window_attn_bwd(int compute, const void* qkv, const void* out_fwd, const void* dout, const float* lse,
                                     const float* bias_table, const float* logit_scale, void* dqkv,
                                     float* dbias_table, float* dlogit_scale, int batch, int Hp, int Wp, int C,
                                     int heads, int ws, int shift, hipStream_t stream) {
   AttnArgs a{};
   int rc = fill_args(a, batch, Hp, Wp, C, heads, ws, shift);
   if (rc) return rc;
-  a.qkv = qkv; a.out = dqkv; a.dout = dout; a.lse = (float*)lse; a.bias_table = bias_table; a.logit_scale = logit_scale;
+  a.qkv = qkv; a.out = dqkv; a.dout = dout; a.ofwd = out_fwd; a.lse = (float*)lse; a.bias_table = bias_table; a.logit_scale = logit_scale;
   a.dbias_table = dbias_table; a.dlogit_scale = dlogit_scale;
   const int nwin = batch * a.nw_per_img;
   return compute == SCOT_BF16 ? dispatch_hd<bf16_t>(a, C / heads, nwin, true, stream)

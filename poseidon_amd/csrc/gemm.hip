@@ -13,6 +13,7 @@
 // (ds_read_b64_tr_b16 for bf16) — no transposed copies of activations or weights are ever written to HBM.
 // Epilogue (fused): + bias[n], * colscale[n], * gelu'(aux[m,n]), + resid[m,n], store f32/bf16 or atomicAdd.
 #include "common.h"
+#include <stdlib.h>
 
 #define LAYOUT_NT 0
 #define LAYOUT_NN 1
@@ -214,6 +215,10 @@ int scot_gemm_fast(int layout, int compute, int M, int N, int K, const void* A, 
                    const float* colscale, const void* aux, int aux_dt, int ldaux, const void* resid, int res_dt, int ldres,
                    int accumulate, float* colsum_out, void* workspace, size_t ws_bytes, int aux_mul, void* C2, hipStream_t stream);
 extern "C" int scot_colsum(const void* x, int x_dt, const void* y, int y_dt, float* out, int M, int N, int ld, hipStream_t s);
+int scot_gemm_panel(int layout, int compute, int M, int N, int K, const void* A, int a_dt, int lda, int a_gelu, const void* B,
+                    int b_dt, int ldb, int b_gelu, void* C, int c_dt, int ldc, const float* bias, const float* colscale,
+                    const void* aux, int aux_dt, int ldaux, const void* resid, int res_dt, int ldres, int accumulate,
+                    float* colsum_out, int aux_mul, void* C2, hipStream_t stream);
 
 extern "C" int scot_gemm(int layout, int compute, int M, int N, int K,
                          const void* A, int a_dt, int lda, int a_gelu,
@@ -227,6 +232,15 @@ extern "C" int scot_gemm(int layout, int compute, int M, int N, int K,
   if (M <= 0 || N <= 0 || K <= 0) return SCOT_ERR_SHAPE;
   if (layout < 0 || layout > 2) return SCOT_ERR_UNSUPPORTED;
   if ((a_dt | b_dt | c_dt) & ~1) return SCOT_ERR_DTYPE;
+  {
+    static int use_panel = -1;
+    if (use_panel < 0) { const char* e = getenv("SCOT_GEMM_PANEL"); use_panel = e ? atoi(e) : 1; }
+    if (use_panel) {
+      const int rc = scot_gemm_panel(layout, compute, M, N, K, A, a_dt, lda, a_gelu, B, b_dt, ldb, b_gelu, C, c_dt, ldc, bias, colscale,
+                                     aux, aux_dt, ldaux, resid, res_dt, ldres, accumulate, colsum_out, aux_mul, C2, stream);
+      if (rc != SCOT_ERR_UNSUPPORTED) return rc;
+    }
+  }
   {
     const int rc = scot_gemm_fast(layout, compute, M, N, K, A, a_dt, lda, a_gelu, B, b_dt, ldb, b_gelu, C, c_dt, ldc, bias, colscale,
                                   aux, aux_dt, ldaux, resid, res_dt, ldres, accumulate, colsum_out, workspace, ws_bytes, aux_mul, C2, stream);

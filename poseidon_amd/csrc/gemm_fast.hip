@@ -111,8 +111,9 @@ __device__ __forceinline__ void fstore(CT* tile, const uint4 (&st)[NCH], int k0,
 }
 
 // WM x WN = arrangement of the 4 waves over the BM x BN tile (WM*WN == 4); each wave owns (BM/WM) x (BN/WN).
-template <typename CT, int BM, int BN, int WM, int WN, int BKT, int LAYOUT>
+template <typename CT, int BM, int BN, int WM, int WN, int BKT, int NSET, int LAYOUT>
 __global__ __launch_bounds__(256) void gemm_fast_kernel(FastArgs p) {
+  static_assert(NSET == 2 || NSET == 4, "pipeline depth");
   static_assert(WM * WN == 4, "4 waves per workgroup");
   constexpr bool A_KC = (LAYOUT != LAYOUT_TN);
   constexpr bool B_KC = (LAYOUT == LAYOUT_NT);
@@ -160,17 +161,20 @@ __global__ __launch_bounds__(256) void gemm_fast_kernel(FastArgs p) {
     for (int j = 0; j < NI; ++j) acc[i][j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
   float bsum = 0.f;  // TN bias-grad partial (thread tid < BM owns column m0+tid of dY)
 
-  // Two register sets: the loads of K-tile t+2 are issued at the TOP of iteration t and consumed (written to LDS) at the
-  // END of iteration t+1, i.e. they have two MFMA phases and a barrier to land.
-  uint4 ra0[TA::per_thread], rb0[TB::per_thread], ra1[TA::per_thread], rb1[TB::per_thread];
-  fload<CT, BM, A_KC, BKT>(ra0, A, p.lda, m0, p.M, kbeg, kend, tid);
-  fload<CT, BN, B_KC, BKT>(rb0, B, p.ldb, n0, p.N, kbeg, kend, tid);
-  if (nk > 1) {
-    fload<CT, BM, A_KC, BKT>(ra1, A, p.lda, m0, p.M, kbeg + BK, kend, tid);
-    fload<CT, BN, B_KC, BKT>(rb1, B, p.ldb, n0, p.N, kbeg + BK, kend, tid);
+  // NSET register sets: the loads of K-tile t+NSET are issued at the TOP of iteration t and written to LDS at the END of
+  // iteration t+NSET-1, i.e. they have NSET-1 full MFMA phases to land.  NSET = 2 when many workgroups share a CU (their
+  // interleaving hides the latency); NSET = 4 for the small grids of stages 2/3, where ONE workgroup per CU walks 12–48 K-tiles
+  // and each iteration used to stall ~1000 cycles on the HBM round trip of a load issued only one iteration earlier.
+  uint4 ra[NSET][TA::per_thread], rb[NSET][TB::per_thread];
+#pragma unroll
+  for (int u = 0; u < NSET; ++u) {
+    if (u < nk) {
+      fload<CT, BM, A_KC, BKT>(ra[u], A, p.lda, m0, p.M, kbeg + u * BK, kend, tid);
+      fload<CT, BN, B_KC, BKT>(rb[u], B, p.ldb, n0, p.N, kbeg + u * BK, kend, tid);
+    }
   }
-  fstore<CT, BM, A_KC, BKT>(lds, ra0, kbeg, kend, tid, p.a_gelu != 0);
-  fstore<CT, BN, B_KC, BKT>(lds + TA::elems, rb0, kbeg, kend, tid, p.b_gelu != 0);
+  fstore<CT, BM, A_KC, BKT>(lds, ra[0], kbeg, kend, tid, p.a_gelu != 0);
+  fstore<CT, BN, B_KC, BKT>(lds + TA::elems, rb[0], kbeg, kend, tid, p.b_gelu != 0);
   __syncthreads();
 
   auto compute = [&](const CT* As, const CT* Bs) {
@@ -200,30 +204,24 @@ __global__ __launch_bounds__(256) void gemm_fast_kernel(FastArgs p) {
     }
   };
 
-  for (int t = 0; t < nk; t += 2) {
-    // even phase: tile t is in buffer 0, set 1 holds tile t+1 (in flight)
-    if (t + 2 < nk) {
-      fload<CT, BM, A_KC, BKT>(ra0, A, p.lda, m0, p.M, kbeg + (t + 2) * BK, kend, tid);
-      fload<CT, BN, B_KC, BKT>(rb0, B, p.ldb, n0, p.N, kbeg + (t + 2) * BK, kend, tid);
+  for (int t = 0; t < nk; t += NSET) {
+#pragma unroll
+    for (int u = 0; u < NSET; ++u) {
+      const int tt = t + u;
+      if (tt >= nk) break;
+      // set u held tile tt (already in LDS buffer u&1): refill it with tile tt+NSET
+      if (tt + NSET < nk) {
+        fload<CT, BM, A_KC, BKT>(ra[u], A, p.lda, m0, p.M, kbeg + (tt + NSET) * BK, kend, tid);
+        fload<CT, BN, B_KC, BKT>(rb[u], B, p.ldb, n0, p.N, kbeg + (tt + NSET) * BK, kend, tid);
+      }
+      compute(lds + (u & 1) * STAGE, lds + (u & 1) * STAGE + TA::elems);
+      if (tt + 1 < nk) {
+        CT* nb = lds + ((u + 1) & 1) * STAGE;
+        fstore<CT, BM, A_KC, BKT>(nb, ra[(u + 1) % NSET], kbeg + (tt + 1) * BK, kend, tid, p.a_gelu != 0);
+        fstore<CT, BN, B_KC, BKT>(nb + TA::elems, rb[(u + 1) % NSET], kbeg + (tt + 1) * BK, kend, tid, p.b_gelu != 0);
+      }
+      __syncthreads();
     }
-    compute(lds, lds + TA::elems);
-    if (t + 1 < nk) {
-      fstore<CT, BM, A_KC, BKT>(lds + STAGE, ra1, kbeg + (t + 1) * BK, kend, tid, p.a_gelu != 0);
-      fstore<CT, BN, B_KC, BKT>(lds + STAGE + TA::elems, rb1, kbeg + (t + 1) * BK, kend, tid, p.b_gelu != 0);
-    }
-    __syncthreads();
-    if (t + 1 >= nk) break;
-    // odd phase: tile t+1 is in buffer 1, set 0 holds tile t+2
-    if (t + 3 < nk) {
-      fload<CT, BM, A_KC, BKT>(ra1, A, p.lda, m0, p.M, kbeg + (t + 3) * BK, kend, tid);
-      fload<CT, BN, B_KC, BKT>(rb1, B, p.ldb, n0, p.N, kbeg + (t + 3) * BK, kend, tid);
-    }
-    compute(lds + STAGE, lds + STAGE + TA::elems);
-    if (t + 2 < nk) {
-      fstore<CT, BM, A_KC, BKT>(lds, ra0, kbeg + (t + 2) * BK, kend, tid, p.a_gelu != 0);
-      fstore<CT, BN, B_KC, BKT>(lds + TA::elems, rb0, kbeg + (t + 2) * BK, kend, tid, p.b_gelu != 0);
-    }
-    __syncthreads();
   }
 
   if (LAYOUT == LAYOUT_TN && p.colsum_out && bx == 0 && tid < BM && m0 + tid < p.M) atomicAdd(&p.colsum_out[m0 + tid], bsum);
@@ -579,13 +577,13 @@ __global__ void splitk_epilogue_kernel(FastArgs p, int nsplit) {
   }
 }
 
-template <typename CT, int BM, int BN, int WM, int WN, int BKT = FT<CT>::BK>
+template <typename CT, int BM, int BN, int WM, int WN, int BKT = FT<CT>::BK, int NSET = 2>
 static int flaunch_layout(const FastArgs& a, int layout, int nsplit, hipStream_t s) {
   dim3 grid((a.N + BN - 1) / BN, (a.M + BM - 1) / BM, nsplit), block(256);
   switch (layout) {
-    case LAYOUT_NT: hipLaunchKernelGGL((gemm_fast_kernel<CT, BM, BN, WM, WN, BKT, LAYOUT_NT>), grid, block, 0, s, a); break;
-    case LAYOUT_NN: hipLaunchKernelGGL((gemm_fast_kernel<CT, BM, BN, WM, WN, BKT, LAYOUT_NN>), grid, block, 0, s, a); break;
-    case LAYOUT_TN: hipLaunchKernelGGL((gemm_fast_kernel<CT, BM, BN, WM, WN, BKT, LAYOUT_TN>), grid, block, 0, s, a); break;
+    case LAYOUT_NT: hipLaunchKernelGGL((gemm_fast_kernel<CT, BM, BN, WM, WN, BKT, NSET, LAYOUT_NT>), grid, block, 0, s, a); break;
+    case LAYOUT_NN: hipLaunchKernelGGL((gemm_fast_kernel<CT, BM, BN, WM, WN, BKT, NSET, LAYOUT_NN>), grid, block, 0, s, a); break;
+    case LAYOUT_TN: hipLaunchKernelGGL((gemm_fast_kernel<CT, BM, BN, WM, WN, BKT, NSET, LAYOUT_TN>), grid, block, 0, s, a); break;
     default: return SCOT_ERR_UNSUPPORTED;
   }
   return scot_check_launch();
@@ -601,6 +599,7 @@ template <> int flaunch_tile<bf16_t>(int tile, const FastArgs& a, int layout, in
     case 5: return flaunch_layout<bf16_t, 96, 96, 2, 2, 32>(a, layout, nsplit, s);
     case 6: return flaunch_layout<bf16_t, 64, 64, 2, 2, 32>(a, layout, nsplit, s);
     case 7: return flaunch_layout<bf16_t, 128, 96, 4, 1, 32>(a, layout, nsplit, s);
+    case 8: return flaunch_layout<bf16_t, 64, 64, 2, 2, 64, 4>(a, layout, nsplit, s);   // deep pipeline (small grids)
     default: return flaunch_layout<bf16_t, 64, 64, 2, 2>(a, layout, nsplit, s);
   }
 }
@@ -616,6 +615,7 @@ static void tile_dims(int tile, int& bm, int& bn, int& bkt) {
     case 4: bm = 96; bn = 96; break;
     case 5: bm = 96; bn = 96; bkt = 32; break;
     case 6: bm = 64; bn = 64; bkt = 32; break;
+    case 8: bm = 64; bn = 64; break;
     case 7: bm = 128; bn = 96; bkt = 32; break;
     default: bm = 64; bn = 64;
   }

@@ -283,7 +283,7 @@ class ScOTEngine:
         out, out16, st2 = self.norm_fwd(pre + ".layernorm_after", y2, h, L, C, cfg.layer_norm_eps, time, need_stats=train, copy=True)
         rec = None
         if train:
-            rec = dict(blk=blk, xp=xp, qkv=qkv, table=table, lse=lse, attn_c=attn_c, proj=proj, st1=st1, h16=h16, u=u, gp=gp,
+            rec = dict(blk=blk, xp=xp, qkv=qkv, attn_p=attn, table=table, lse=lse, attn_c=attn_c, proj=proj, st1=st1, h16=h16, u=u, gp=gp,
                        y2=y2, st2=st2, geom=(H, W, Hp, Wp, ws, shift, padded))
         return out, out16, rec
 
@@ -317,7 +317,7 @@ class ScOTEngine:
             d_attn_p = d_attn
         d_qkv = self.new(B * Lp, 3 * C, dtype=adt)
         d_table = self.cpb_table(pre, grad=True)   # zeroed once per backward; its MLP backward is batched per stage
-        ops.window_attn_bwd(cm, rec["qkv"], d_attn_p, rec["lse"], rec["table"], self.P(a + "logit_scale"), d_qkv, d_table,
+        ops.window_attn_bwd(cm, rec["qkv"], rec["attn_p"], d_attn_p, rec["lse"], rec["table"], self.P(a + "logit_scale"), d_qkv, d_table,
                             self.G(a + "logit_scale"), B, Hp, Wp, C, heads, ws, shift)
         wqkv = self.Wspan(a + "qkv_weight", 3 * C * C).view(3 * C, C)
         gwqkv = self.arena.span(a + "qkv_weight", 3 * C * C, grad=True).view(3 * C, C)

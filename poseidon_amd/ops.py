@@ -118,9 +118,9 @@ def window_attn_fwd(compute, qkv, out, lse, bias_table, logit_scale, batch, Hp, 
                                         C, heads, ws, shift, stream()), "scot_window_attn_fwd")
 
 
-def window_attn_bwd(compute, qkv, dout, lse, bias_table, logit_scale, dqkv, dbias_table, dlogit_scale, batch, Hp, Wp, C, heads,
-                    ws, shift):
-    _lib.check(L().scot_window_attn_bwd(compute, ptr(qkv), ptr(dout), ptr(lse), ptr(bias_table), ptr(logit_scale), ptr(dqkv),
+def window_attn_bwd(compute, qkv, out_fwd, dout, lse, bias_table, logit_scale, dqkv, dbias_table, dlogit_scale, batch, Hp, Wp, C,
+                    heads, ws, shift):
+    _lib.check(L().scot_window_attn_bwd(compute, ptr(qkv), ptr(out_fwd), ptr(dout), ptr(lse), ptr(bias_table), ptr(logit_scale), ptr(dqkv),
                                         ptr(dbias_table), ptr(dlogit_scale), batch, Hp, Wp, C, heads, ws, shift, stream()),
                "scot_window_attn_bwd")
 

@@ -178,7 +178,7 @@ def test_window_attention_fwd_bwd(compute, case):
     dqkv = torch.full((B, L, 3 * C), float("nan"), device=DEV, dtype=cdt)
     dtab = torch.zeros(heads, TS, device=DEV)
     dls = torch.zeros(heads, device=DEV)
-    ops.window_attn_bwd(compute, qkv, dout, lse, table, ls, dqkv, dtab, dls, B, Hp, Wp, C, heads, ws, shift)
+    ops.window_attn_bwd(compute, qkv, out, dout, lse, table, ls, dqkv, dtab, dls, B, Hp, Wp, C, heads, ws, shift)
     torch.cuda.synchronize()
 
     q64 = qkv.double().requires_grad_(True)

@@ -78,7 +78,7 @@ def main():
         print(f"attn_fwd Hp={Hp} C={C} ws={ws}: {us:7.1f} us  {fl/us/1e6:6.1f} TF/s")
         dq = torch.empty_like(qkv)
         dt_, dl = torch.zeros_like(tab), torch.zeros(heads, device="cuda")
-        us = timeit(lambda: ops.window_attn_bwd(ops.BF16, qkv, o, lse, tab, ls, dq, dt_, dl, B, Hp, Hp, C, heads, ws, shift))
+        us = timeit(lambda: ops.window_attn_bwd(ops.BF16, qkv, o, o, lse, tab, ls, dq, dt_, dl, B, Hp, Hp, C, heads, ws, shift))
         print(f"attn_bwd Hp={Hp} C={C} ws={ws}: {us:7.1f} us  {2.5*fl/us/1e6:6.1f} TF/s")
     # dwconv
     for Hh, C in ([(32, 96)] if only == "dwconv" else [] if only else [(32, 96), (16, 192), (8, 384)]):
