@@ -13,108 +13,7 @@
 // S^T tiles = mfma(A = Kn[16 keys x d], B = Qn^T) put ONE query per lane column (lane&15) with its keys spread
 // over (lane>>4, reg, tile) → row max / sum need only two xor-shuffles (16, 32), and the probabilities are
 // already in MFMA A-operand order for P·V (no LDS round trip, no permutes).
-#include "common.h"
-
-struct AttnArgs {
-  const void* qkv;   // [tokens][3C]  (q | k | v), dtype = compute type
-  void* out;         // fwd: O [tokens][C];           bwd: dqkv [tokens][3C]
-  const void* dout;  // bwd: dO [tokens][C]
-  const void* ofwd;  // bwd: O  [tokens][C] (the forward output; delta = rowsum(dO ∘ O))
-  float* lse;        // [windows][heads][N]  log-sum-exp of each softmax row (fwd writes, bwd reads)
-  const float* bias_table;   // [heads][(2ws-1)^2]  = 16·sigmoid(CPB-MLP)
-  const float* logit_scale;  // [heads]
-  float* dbias_table;        // bwd, atomically accumulated
-  float* dlogit_scale;       // bwd, atomically accumulated
-  int C, heads, Hp, Wp, ws, shift, nwx, nw_per_img;
-  int use_tr;
-};
-
-__device__ __forceinline__ int win_token(const AttnArgs& p, int win, int n) {
-  const int b = win / p.nw_per_img, w = win % p.nw_per_img;
-  const int wy = w / p.nwx, wx = w % p.nwx;
-  int y = wy * p.ws + n / p.ws + p.shift, x = wx * p.ws + n % p.ws + p.shift;
-  if (y >= p.Hp) y -= p.Hp;
-  if (x >= p.Wp) x -= p.Wp;
-  return (b * p.Hp + y) * p.Wp + x;
-}
-// region id on the shifted grid (reference model.py:450-465), 0 when shift == 0
-__device__ __forceinline__ int win_region(const AttnArgs& p, int win, int n) {
-  if (p.shift == 0) return 0;
-  const int w = win % p.nw_per_img;
-  const int ys = (w / p.nwx) * p.ws + n / p.ws, xs = (w % p.nwx) * p.ws + n % p.ws;
-  const int ry = (ys >= p.Hp - p.ws) + (ys >= p.Hp - p.shift);
-  const int rx = (xs >= p.Wp - p.ws) + (xs >= p.Wp - p.shift);
-  return ry * 3 + rx;
-}
-
-// per-position info packed for the logit loops: (y*(2ws-1) + x) | region << 20 ; region 15 = padding row
-__device__ __forceinline__ int pos_info(const AttnArgs& p, int win, int n, int N) {
-  if (n >= N) return 15 << 20;
-  return ((n / p.ws) * (2 * p.ws - 1) + n % p.ws) | (win_region(p, win, n) << 20);
-}
-// LDS tiles are [n][KD + pad] with KD = HD rounded up to the MFMA K-step (32); columns HD..KD are zero so that
-// K-contiguous fragment reads of head_dim 16 never touch uninitialised LDS.
-template <int HD, typename CT> constexpr int row_pitch() { return ((HD + 31) / 32) * 32 + ct_traits<CT>::kpad; }
-
-// Stage the window's rows of one of q/k/v (column offset `col`) into LDS tile [NP][pitch]; optionally L2-normalise
-// each row (F.normalize, eps 1e-12).  256 threads, HD/8 lanes per row.
-template <typename CT, int HD, int NP>
-__device__ __forceinline__ void stage_rows(CT* tile, const void* src, int ld, int col, const int* tok, int N,
-                                           bool normalize, int tid) {
-  constexpr int CPR = ((HD + 31) / 32) * 4, pitch = row_pitch<HD, CT>();
-  for (int c = tid; c < NP * CPR; c += 256) {
-    const int n = c / CPR, d8 = (c % CPR) * 8;
-    float v[8];
-#pragma unroll
-    for (int j = 0; j < 8; ++j) v[j] = 0.f;
-    if (n < N && d8 < HD) ld8(src, ct_traits<CT>::dtype, (size_t)tok[n] * ld + col + d8, v);
-    if (normalize) {
-      float ss = 0.f;
-#pragma unroll
-      for (int j = 0; j < 8; ++j) ss += v[j] * v[j];
-#pragma unroll
-      for (int o = 1; o < CPR; o <<= 1) ss += __shfl_xor(ss, o, 64);
-      const float r = 1.0f / fmaxf(sqrtf(ss), 1e-12f);
-#pragma unroll
-      for (int j = 0; j < 8; ++j) v[j] *= r;
-    }
-    store8_ct(tile + n * pitch + d8, v);
-  }
-}
-
-// B-operand fragments of a 16-row block read straight from HBM: lane (c = lane&15, g) takes 8 consecutive
-// features d = kk*32 + g*8 .. +7 of row tok(n0+c).  Optionally L2-normalised (returns 1/max(|row|,eps) in *rnorm).
-template <typename CT, int HD>
-__device__ __forceinline__ void load_rows_frag(Frag<CT> (&f)[(HD + 31) / 32], const void* src, int ld, int col,
-                                               const int* tok, int n0, int N, bool normalize, int lane) {
-  constexpr int KS = (HD + 31) / 32;
-  const int n = n0 + (lane & 15), g = lane >> 4;
-  float v[KS][8];
-  float ss = 0.f;
-  const bool valid = n < N;
-  const size_t base = valid ? (size_t)tok[n] * ld + col : 0;
-#pragma unroll
-  for (int kk = 0; kk < KS; ++kk) {
-    const int d = kk * 32 + g * 8;
-#pragma unroll
-    for (int j = 0; j < 8; ++j) v[kk][j] = 0.f;
-    if (valid && d < HD) ld8(src, ct_traits<CT>::dtype, base + d, v[kk]);
-#pragma unroll
-    for (int j = 0; j < 8; ++j) ss += v[kk][j] * v[kk][j];
-  }
-  float r = 1.f;
-  if (normalize) {
-    ss += __shfl_xor(ss, 16, 64);
-    ss += __shfl_xor(ss, 32, 64);
-    r = 1.0f / fmaxf(sqrtf(ss), 1e-12f);
-  }
-#pragma unroll
-  for (int kk = 0; kk < KS; ++kk) {
-#pragma unroll
-    for (int j = 0; j < 8; ++j) v[kk][j] *= r;
-    f[kk] = frag_from_f32<CT>(v[kk]);
-  }
-}
+#include "attention.h"
 
 // ================================================================================================= forward
 template <typename CT, int HD, int NT>  // NT = number of 16-key tiles (even), NP = 16*NT >= N
@@ -267,29 +166,7 @@ __device__ __forceinline__ float normalize_bwd_store(const f32x4_t (&acc)[HD / 1
   return dotsum;
 }
 
-// row_shl:k — lane l of each 16-lane row receives lane l+k (0 shifted in);  row_shr:k — lane l receives lane l-k.
-template <int CTRL> __device__ __forceinline__ float dpp_row(float v) {
-  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xF, 0xF, true));
-}
-
-// Raw fp32 values of a 16-row block in B-operand order (lane (c = lane&15, g): features kk*32 + g*8 .. +7 of row n0+c).
-template <typename CT, int HD>
-__device__ __forceinline__ void load_rows_f32(float (&v)[(HD + 31) / 32][8], const void* src, int ld, int col, const int* tok,
-                                              int n0, int N, int lane) {
-  constexpr int KS = (HD + 31) / 32;
-  const int n = n0 + (lane & 15), g = lane >> 4;
-  const bool valid = n < N;
-  const size_t base = valid ? (size_t)tok[n] * ld + col : 0;
-#pragma unroll
-  for (int kk = 0; kk < KS; ++kk) {
-    const int d = kk * 32 + g * 8;
-#pragma unroll
-    for (int j = 0; j < 8; ++j) v[kk][j] = 0.f;
-    if (valid && d < HD) ld8(src, ct_traits<CT>::dtype, base + d, v[kk]);
-  }
-}
-
-// ---- backward, kernel 1 of 2: dQ, d bias-table.  Queries on lane columns (S^T tiles); K (normalised) and V in LDS.
+// ---- backward, kernel 1 of 2: dQ, d bias-table, d logit_scale.  Queries on lane columns (S^T tiles); K (normalised) and V in LDS.
 // delta = rowsum(dO ∘ O) comes from the forward output, so every 16x32 block of scores is consumed as soon as it is
 // produced (no 128-register S/dP pair): S^T, dP^T -> P -> dS -> {table histogram, dQ += dS·Kn}.
 template <typename CT, int HD, int NT>
@@ -300,15 +177,19 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(AttnArgs p) {
   CT* Y = X + NP * pitch;       // V
   const int ws = p.ws, N = ws * ws, TW = 2 * ws - 1, TS = TW * TW, TSP = (TS + 3) & ~3;
   float* tab = (float*)(Y + NP * pitch);
-  float* dtab = tab + TSP;
+  // the table-gradient histogram lives in LDS as DOUBLES: ds_add_f64 issues at full rate on gfx950 while ds_add_f32 is
+  // serialised at ~3 clk per active lane per CU (tools/probes/lds_atomic_probe.hip) — with fp32 the histogram alone was
+  // half of this kernel
+  double* dtab = (double*)(tab + TSP);
   int* rid = (int*)(dtab + TSP);
   int* tok = rid + NP;
+  float* red = (float*)(tok + NP);  // [4]
 
   const int win = blockIdx.x, h = blockIdx.y;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int ld = 3 * p.C, g = lane >> 4, lc = lane & 15;
 
-  for (int i = tid; i < TS; i += 256) { tab[i] = p.bias_table[h * TS + i]; dtab[i] = 0.f; }
+  for (int i = tid; i < TS; i += 256) { tab[i] = p.bias_table[h * TS + i]; dtab[i] = 0.0; }
   for (int i = tid; i < NP; i += 256) { rid[i] = pos_info(p, win, i, N); tok[i] = i < N ? win_token(p, win, i) : 0; }
   __syncthreads();
   stage_rows<CT, HD, NP>(X, p.qkv, ld, p.C + h * HD, tok, N, true, tid);
@@ -317,11 +198,16 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(AttnArgs p) {
 
   const float scale = __expf(fminf(p.logit_scale[h], 4.605170185988092f));
   const int cen = (ws - 1) * TW + ws - 1;
+  // d logit_scale = Σ_qk dS·cos·scale with Σ_k dS = 0 per query: a heavily cancelling sum.  dS uses delta from the
+  // stored (rounded) forward output; the row sums D = Σ_k P·dP and B = Σ_k P·cos taken here in fp32 put the exact
+  // cancellation back:  Σ_k P (dP - D) cos = Σ_k dS·cos + (delta - D)·B.
+  float dls = 0.f;
 
   for (int qb = wave; qb * 16 < N; qb += 4) {
     const int q0 = qb * 16;
     Frag<CT> qf[KS], gf[KS];
     load_rows_frag<CT, HD>(qf, p.qkv, ld, h * HD, tok, q0, N, true, lane);
+    float accD = 0.f, accB = 0.f;
     float delta = 0.f;
     {
       float dov[KS][8], ov[KS][8];
@@ -370,16 +256,22 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(AttnArgs p) {
           pr = (krid == 15 || !qvalid) ? 0.f : pr;
           ds[r] = pr * (dp[r] - delta);
           ds8[half * 4 + r] = ds[r];
+          accD = fmaf(pr, dp[r], accD);
+          accB = fmaf(pr, s[r], accB);
+          dls = fmaf(ds[r], s[r], dls);
         }
-        if (ws == 16) {   // anti-diagonal pre-reduction with DPP row shifts, see DESIGN.md
+        if (ws == 16) {
+          // one window row of queries against one window row of keys: the 16x16 block of dS feeds the 31 entries
+          // (dx = q - k) of ONE table row.  DPP row shifts fold the lane's four keys along the anti-diagonal before the
+          // LDS atomics (folding the four 16-lane rows too, with two ds_bpermute, measured slower: 114 vs 100 us).
           const float a = ds[0] + dpp_row<0x101>(ds[1]) + dpp_row<0x102>(ds[2]) + dpp_row<0x103>(ds[3]);
           const float bt = dpp_row<0x11F>(ds[1]) + dpp_row<0x11E>(ds[2]) + dpp_row<0x11D>(ds[3]);
           const int ia = qoff - (kia[0] & 0xfffff);
-          atomicAdd(&dtab[ia], a);
-          if (lc >= 13) atomicAdd(&dtab[ia - 16], bt);
+          atomicAdd(&dtab[ia], (double)a);
+          if (lc >= 13) atomicAdd(&dtab[ia - 16], (double)bt);
         } else {
 #pragma unroll
-          for (int r = 0; r < 4; ++r) atomicAdd(&dtab[qoff - (kia[r] & 0xfffff)], ds[r]);
+          for (int r = 0; r < 4; ++r) atomicAdd(&dtab[qoff - (kia[r] & 0xfffff)], (double)ds[r]);
         }
       }
       const Frag<CT> df = frag_from_f32<CT>(ds8);
@@ -387,13 +279,20 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(AttnArgs p) {
       for (int d = 0; d < DT; ++d)
         mma16(dq[d], df, lds_frag_ks(X, pitch, d * 16, (2 * tp) * 16 + g * 4, (2 * tp + 1) * 16 + g * 4, lane, p.use_tr));
     }
+    accD += __shfl_xor(accD, 16, 64); accD += __shfl_xor(accD, 32, 64);
+    accB += __shfl_xor(accB, 16, 64); accB += __shfl_xor(accB, 32, 64);
+    if (g == 0 && qvalid) dls = fmaf(delta - accD, accB, dls);
     normalize_bwd_store<CT, HD>(dq, scale, p.qkv, ld, h * HD, p.out, h * HD, tok, q0, N, lane);
   }
+  // d/dls [cos * exp(ls)] = cos * scale  (0 when clamped at ln 100, HF:416)
+  dls = wave_sum(dls);
+  if (lane == 0) red[wave] = dls;
   __syncthreads();
-  for (int i = tid; i < TS; i += 256) atomicAdd(&p.dbias_table[h * TS + i], dtab[i]);
+  for (int i = tid; i < TS; i += 256) atomicAdd(&p.dbias_table[h * TS + i], (float)dtab[i]);
+  if (tid == 0 && p.logit_scale[h] <= 4.605170185988092f) atomicAdd(&p.dlogit_scale[h], (red[0] + red[1] + red[2] + red[3]) * scale);
 }
 
-// ---- backward, kernel 2 of 2: dK, dV, d logit_scale.  Keys on lane columns (S tiles); Q (normalised) and dO in LDS.
+// ---- backward, kernel 2 of 2: dK, dV.  Keys on lane columns (S tiles); Q (normalised) and dO in LDS.
 // Independent of kernel 1 (delta is recomputed from dO ∘ O while dO is staged), so the two can run concurrently.
 template <typename CT, int HD, int NT>
 __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(AttnArgs p) {
@@ -408,7 +307,6 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(AttnArgs p) {
   float* delta = lse + NP;      // [NP]
   int* rid = (int*)(delta + NP);
   int* tok = rid + NP;
-  float* red = (float*)(tok + NP);  // [4]
 
   const int win = blockIdx.x, h = blockIdx.y;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -442,10 +340,8 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(AttnArgs p) {
   }
   __syncthreads();
 
-  const float ls = p.logit_scale[h];
-  const float scale = __expf(fminf(ls, 4.605170185988092f));
+  const float scale = __expf(fminf(p.logit_scale[h], 4.605170185988092f));
   const int cen = (ws - 1) * TW + ws - 1;
-  float dls = 0.f;
 
   for (int kb = wave; kb * 16 < N; kb += 4) {
     const int k0 = kb * 16;
@@ -485,12 +381,8 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(AttnArgs p) {
           v = (qrid != krid) ? v - 200.0f : v;
           const bool ok = qrid != 15 && kvalid;
           const float pr = ok ? __expf(v - qla[r]) : 0.f;
-          const float ds = ok ? pr * (dp[r] - qda[r]) : 0.f;
-          // d logit_scale = Σ dS·cos·scale in fp32 from the un-rounded dS and the very cos the forward used (Σ_k dS = 0:
-          // the sum cancels heavily; taking it from the bf16 dS·Kn product was off by O(1) on small heads)
-          dls += ds * s[r];
           pf8[half * 4 + r] = pr;
-          df8[half * 4 + r] = ds;
+          df8[half * 4 + r] = ok ? pr * (dp[r] - qda[r]) : 0.f;
         }
       }
       const Frag<CT> pf = frag_from_f32<CT>(pf8), df = frag_from_f32<CT>(df8);
@@ -512,23 +404,19 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(AttnArgs p) {
     }
     normalize_bwd_store<CT, HD>(dk, scale, p.qkv, ld, p.C + h * HD, p.out, p.C + h * HD, tok, k0, N, lane);
   }
-  // d/dls [cos * exp(ls)] = cos * scale  (0 when clamped at ln 100, HF:416)
-  dls = wave_sum(dls);
-  if (lane == 0) red[wave] = dls;
-  __syncthreads();
-  if (tid == 0 && ls <= 4.605170185988092f) atomicAdd(&p.dlogit_scale[h], (red[0] + red[1] + red[2] + red[3]) * scale);
 }
 
 // ================================================================================================= host side
 extern int g_scot_use_tr;
+int scot_attn_w16(const AttnArgs& a, int compute, int hd, int nwin, bool bwd, hipStream_t s);   // attention_w16.hip
 
 template <typename CT, int HD, int NT>
 static int launch_attn(const AttnArgs& a, int nwin, bool bwd, hipStream_t s) {
   constexpr int NP = NT * 16, pitch = row_pitch<HD, CT>();
   const int TS = (2 * a.ws - 1) * (2 * a.ws - 1), TSP = (TS + 3) & ~3;
   size_t sh = 2 * NP * pitch * sizeof(CT);
-  const size_t sh_dq = sh + 2 * TSP * sizeof(float) + 2 * NP * sizeof(int);
-  const size_t sh_dkv = sh + (TSP + 2 * NP) * sizeof(float) + 2 * NP * sizeof(int) + 4 * sizeof(float);
+  const size_t sh_dq = sh + TSP * (sizeof(float) + sizeof(double)) + 2 * NP * sizeof(int) + 4 * sizeof(float);
+  const size_t sh_dkv = sh + (TSP + 2 * NP) * sizeof(float) + 2 * NP * sizeof(int);
   if (bwd) sh = sh_dq > sh_dkv ? sh_dq : sh_dkv;
   else sh += TSP * sizeof(float) + 2 * NP * sizeof(int);
   if (sh > 160 * 1024) return SCOT_ERR_UNSUPPORTED;
@@ -584,6 +472,8 @@ extern "C" int scot_window_attn_fwd(int compute, const void* qkv, void* out, flo
   if (rc) return rc;
   a.qkv = qkv; a.out = out; a.lse = lse; a.bias_table = bias_table; a.logit_scale = logit_scale;
   const int nwin = batch * a.nw_per_img;
+  rc = scot_attn_w16(a, compute, C / heads, nwin, false, stream);
+  if (rc != SCOT_ERR_UNSUPPORTED) return rc;
   return compute == SCOT_BF16 ? dispatch_hd<bf16_t>(a, C / heads, nwin, false, stream)
                               : dispatch_hd<float>(a, C / heads, nwin, false, stream);
 }
@@ -598,6 +488,8 @@ extern "C" int scot_window_attn_bwd(int compute, const void* qkv, const void* ou
   a.qkv = qkv; a.out = dqkv; a.dout = dout; a.ofwd = out_fwd; a.lse = (float*)lse; a.bias_table = bias_table; a.logit_scale = logit_scale;
   a.dbias_table = dbias_table; a.dlogit_scale = dlogit_scale;
   const int nwin = batch * a.nw_per_img;
+  rc = scot_attn_w16(a, compute, C / heads, nwin, true, stream);
+  if (rc != SCOT_ERR_UNSUPPORTED) return rc;
   return compute == SCOT_BF16 ? dispatch_hd<bf16_t>(a, C / heads, nwin, true, stream)
                               : dispatch_hd<float>(a, C / heads, nwin, true, stream);
 }

@@ -1,0 +1,482 @@
+// Window attention, 16x16-window fast path (ws = 16, N = 256 keys, shift 0 or 8): stages 0 and 1 of every preset at
+// 128x128 input, i.e. ~90 % of all attention time.  Same math as attention.hip (reference HF:389-455 through
+// scOT/model.py:522-559); what the fixed geometry buys:
+//   * a 16-query block is ONE window row and a 16-key tile is ONE window row, so the relative-position bias of a lane's
+//     four logits is four CONSECUTIVE table entries at  lane_base + uniform(qy - ky): plain ds_read with immediate
+//     offsets, no per-element index arithmetic and no dependent position lookups;
+//   * with shift = ws/2 the shift mask of (query, key) is  [row_region(qy) != row_region(ky)]  (uniform per tile)  OR
+//     [col_region(qx) != col_region(kx)]  (a per-lane constant): one select per tile instead of two per logit;
+//   * logits are kept in the log2 domain (table, scale and lse pre-multiplied by log2 e): v_exp_f32 directly;
+//   * outputs are produced TRANSPOSED (O^T = V^T P^T, dQ^T, dK^T, dV^T): a lane then owns 4 consecutive features of one
+//     token -> 8/16-byte stores and two-step (xor 16, 32) row reductions in the normalisation backward.
+#include "attention.h"
+
+static constexpr float kLog2e = 1.4426950408889634f, kLn2 = 0.6931471805599453f;
+static constexpr float kMask2 = -200.0f * 1.4426950408889634f;   // the -100 mask, added twice (HF:433-436), log2 domain
+
+__device__ __forceinline__ float fast_exp2(float x) { return __builtin_amdgcn_exp2f(x); }
+
+template <typename CT> __device__ __forceinline__ void ld4(const void* p, size_t i, float (&v)[4]);
+template <> __device__ __forceinline__ void ld4<float>(const void* p, size_t i, float (&v)[4]) {
+  const float4 u = *(const float4*)((const float*)p + i);
+  v[0] = u.x; v[1] = u.y; v[2] = u.z; v[3] = u.w;
+}
+template <> __device__ __forceinline__ void ld4<bf16_t>(const void* p, size_t i, float (&v)[4]) {
+  const uint2 u = *(const uint2*)((const bf16_t*)p + i);
+  v[0] = __uint_as_float(u.x << 16); v[1] = __uint_as_float(u.x & 0xffff0000u);
+  v[2] = __uint_as_float(u.y << 16); v[3] = __uint_as_float(u.y & 0xffff0000u);
+}
+template <typename CT> __device__ __forceinline__ void st4(void* p, size_t i, const float (&v)[4]);
+template <> __device__ __forceinline__ void st4<float>(void* p, size_t i, const float (&v)[4]) {
+  *(float4*)((float*)p + i) = make_float4(v[0], v[1], v[2], v[3]);
+}
+template <> __device__ __forceinline__ void st4<bf16_t>(void* p, size_t i, const float (&v)[4]) {
+  *(uint2*)((bf16_t*)p + i) = make_uint2(pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]));
+}
+
+// Fragment reads through per-lane base pointers: every tile / feature-block offset below is a compile-time constant, so
+// the reads become `ds_read ... offset:imm` off ONE address register per tile array (the generic helpers recompute
+// (row0 + lane)·pitch per tile, which the compiler hoists into dozens of live address registers once unrolled).
+template <typename CT, int HD> struct LaneBase {
+  const CT* kc;   // K-contiguous reads: row (lane&15), features (lane>>4)*8 ..
+  const CT* ks;   // K-strided (transposing) reads: see lds_frag_ks
+  __device__ __forceinline__ LaneBase(const CT* T, int lane) {
+    constexpr int pitch = row_pitch<HD, CT>();
+    const int lc = lane & 15, g = lane >> 4;
+    kc = T + lc * pitch + g * 8;
+    ks = sizeof(CT) == 2 ? T + (g * 4 + (lc >> 2)) * pitch + (lc & 3) * 4 : T + g * 4 * pitch + lc;
+  }
+};
+template <int HD> __device__ __forceinline__ Frag<bf16_t> rd_kc(const bf16_t* kc, int t, int kk) {
+  Frag<bf16_t> f;
+  f.v = *(const s16x8_t*)(kc + t * 16 * row_pitch<HD, bf16_t>() + kk * 32);
+  return f;
+}
+template <int HD> __device__ __forceinline__ Frag<float> rd_kc(const float* kc, int t, int kk) {
+  Frag<float> f;
+  const float* q = kc + t * 16 * row_pitch<HD, float>() + kk * 32;
+  const float4 a = *(const float4*)q, b = *(const float4*)(q + 4);
+  f.v[0] = a.x; f.v[1] = a.y; f.v[2] = a.z; f.v[3] = a.w; f.v[4] = b.x; f.v[5] = b.y; f.v[6] = b.z; f.v[7] = b.w;
+  return f;
+}
+// 8 keys of tile pair tp (4 of tile 2tp at rows 4g.., 4 of tile 2tp+1), feature column d*16 + (lane&15)
+template <int HD> __device__ __forceinline__ Frag<bf16_t> rd_ks(const bf16_t* ks, int tp, int d) {
+  typedef __attribute__((address_space(3))) s16x4_t* lds_v4;
+  constexpr int pitch = row_pitch<HD, bf16_t>();
+  const s16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4)(ks + (2 * tp) * 16 * pitch + d * 16));
+  const s16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4)(ks + (2 * tp + 1) * 16 * pitch + d * 16));
+  Frag<bf16_t> f;
+  f.v = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+  return f;
+}
+template <int HD> __device__ __forceinline__ Frag<float> rd_ks(const float* ks, int tp, int d) {
+  constexpr int pitch = row_pitch<HD, float>();
+  Frag<float> f;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    f.v[j] = ks[((2 * tp) * 16 + j) * pitch + d * 16];
+    f.v[j + 4] = ks[((2 * tp + 1) * 16 + j) * pitch + d * 16];
+  }
+  return f;
+}
+
+// geometry of the fast path
+struct W16 {
+  static constexpr int NT = 16, NP = 256, TW = 31, TS = 961, TSP = 964;
+};
+
+// accT[d][r]: gradient (times `mul`) wrt the NORMALISED row of token `tokn`, feature d*16 + (lane>>4)*4 + r.
+// y = x / max(|x|, eps):  dx = (g - y (y·g)) / |x|   (|x| >= eps),   dx = g / eps otherwise  (F.normalize, eps 1e-12).
+template <typename CT, int HD>
+__device__ __forceinline__ void normalize_bwd_store_t(const f32x4_t (&acc)[HD / 16], float mul, const void* src, void* dst, size_t off,
+                                                      int lane) {
+  constexpr int DT = HD / 16;
+  const int g = lane >> 4;
+  float x[DT][4], ss = 0.f, dot = 0.f;
+#pragma unroll
+  for (int d = 0; d < DT; ++d) {
+    ld4<CT>(src, off + d * 16 + g * 4, x[d]);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) ss += x[d][r] * x[d][r];
+  }
+  ss += __shfl_xor(ss, 16, 64);
+  ss += __shfl_xor(ss, 32, 64);
+  const float nrm = sqrtf(ss);
+  const float rn = 1.0f / fmaxf(nrm, 1e-12f);
+#pragma unroll
+  for (int d = 0; d < DT; ++d)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) dot += (x[d][r] * rn) * (acc[d][r] * mul);
+  dot += __shfl_xor(dot, 16, 64);
+  dot += __shfl_xor(dot, 32, 64);
+  if (nrm < 1e-12f) dot = 0.f;
+#pragma unroll
+  for (int d = 0; d < DT; ++d) {
+    float o[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) o[r] = rn * (acc[d][r] * mul - (x[d][r] * rn) * dot);
+    st4<CT>(dst, off + d * 16 + g * 4, o);
+  }
+}
+
+// ================================================================================================= forward
+template <typename CT, int HD, bool SHIFTED>
+__global__ __launch_bounds__(256, 2) void attn16_fwd_kernel(AttnArgs p) {
+  constexpr int NT = W16::NT, NP = W16::NP, KS = (HD + 31) / 32, DT = HD / 16, pitch = row_pitch<HD, CT>();
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  CT* Kn = (CT*)smem;
+  CT* Vs = Kn + NP * pitch;
+  float* tab2 = (float*)(Vs + NP * pitch);
+  int* tok = (int*)(tab2 + W16::TSP);
+
+  const int win = blockIdx.x, h = blockIdx.y;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int ld = 3 * p.C, g = lane >> 4, lc = lane & 15;
+
+  for (int i = tid; i < NP; i += 256) tok[i] = win_token(p, win, i);
+  for (int i = tid; i < W16::TS; i += 256) tab2[i] = p.bias_table[h * W16::TS + i] * kLog2e;
+  __syncthreads();
+  stage_rows<CT, HD, NP>(Kn, p.qkv, ld, p.C + h * HD, tok, NP, true, tid);
+  stage_rows<CT, HD, NP>(Vs, p.qkv, ld, 2 * p.C + h * HD, tok, NP, false, tid);
+  __syncthreads();
+
+  const float scale2 = __expf(fminf(p.logit_scale[h], 4.605170185988092f)) * kLog2e;  // exp(min(ls, ln 100)), HF:416
+  const int w = win % p.nw_per_img;
+  const bool lastrow = SHIFTED && (w / p.nwx) == p.Hp / 16 - 1, lastcol = SHIFTED && (w % p.nwx) == p.nwx - 1;
+  const float mlane = (lastcol && ((lc >= 8) != (g >= 2))) ? kMask2 : 0.f;
+  // bias of (query (qy, qx = lc), key (ky = t, kx = 4g + r)) = tab[(qy - t + 15)*31 + lc - 4g - r + 15]
+  const float* tabl = tab2 + (lc - 4 * g + 12);
+  const LaneBase<CT, HD> kb_(Kn, lane), vb_(Vs, lane);
+
+#pragma nounroll
+  for (int qb = wave; qb < 16; qb += 4) {
+    Frag<CT> qf[KS];
+    load_rows_frag<CT, HD>(qf, p.qkv, ld, h * HD, tok, qb * 16, NP, true, lane);
+    const float* tq = tabl + qb * 31;
+
+    f32x4_t s[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+      s[t] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int kk = 0; kk < KS; ++kk) mma16(s[t], rd_kc<HD>(kb_.kc, t, kk), qf[kk]);
+      if ((t & 3) == 3) __builtin_amdgcn_sched_barrier(0);   // keep the scheduler from hoisting every tile's LDS reads
+    }
+    float m = -3.0e38f;
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+      float madd = 0.f;
+      if (SHIFTED) madd = (lastrow && ((qb >= 8) != (t >= 8))) ? kMask2 : mlane;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float v = fmaf(s[t][r], scale2, tq[(15 - t) * 31 + 3 - r]) + madd;
+        s[t][r] = v;
+        m = fmaxf(m, v);
+      }
+      if ((t & 3) == 3) __builtin_amdgcn_sched_barrier(0);
+    }
+    m = fmaxf(m, __shfl_xor(m, 16, 64));
+    m = fmaxf(m, __shfl_xor(m, 32, 64));
+    float l = 0.f;
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float e = fast_exp2(s[t][r] - m);
+        s[t][r] = e;
+        l += e;
+      }
+    }
+    l += __shfl_xor(l, 16, 64);
+    l += __shfl_xor(l, 32, 64);
+    const float inv = 1.0f / l;
+    const int q = qb * 16 + lc;
+    if (g == 0 && p.lse) p.lse[((size_t)win * p.heads + h) * NP + q] = (m + __log2f(l)) * kLn2;
+
+    // O^T = V^T · P^T : A = V^T (transposing fragment read), B = P^T (the lane's 8 keys of query lc: already in order)
+    f32x4_t o[DT];
+#pragma unroll
+    for (int d = 0; d < DT; ++d) o[d] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int tp = 0; tp < NT / 2; ++tp) {
+      float pv[8];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) { pv[r] = s[2 * tp][r]; pv[r + 4] = s[2 * tp + 1][r]; }
+      const Frag<CT> pf = frag_from_f32<CT>(pv);
+#pragma unroll
+      for (int d = 0; d < DT; ++d)
+        mma16(o[d], rd_ks<HD>(vb_.ks, tp, d), pf);
+      if ((tp & 1) == 1) __builtin_amdgcn_sched_barrier(0);
+    }
+    // o[d][r]: feature d*16 + 4g + r of query q
+    const size_t base = (size_t)tok[q] * p.C + h * HD + g * 4;
+#pragma unroll
+    for (int d = 0; d < DT; ++d) {
+      const float ov[4] = {o[d][0] * inv, o[d][1] * inv, o[d][2] * inv, o[d][3] * inv};
+      st4<CT>(p.out, base + d * 16, ov);
+    }
+  }
+}
+
+// ================================================================================================= backward: dQ, d table, d logit_scale
+template <typename CT, int HD, bool SHIFTED>
+__global__ __launch_bounds__(256, 2) void attn16_bwd_dq_kernel(AttnArgs p) {
+  constexpr int NT = W16::NT, NP = W16::NP, KS = (HD + 31) / 32, DT = HD / 16, pitch = row_pitch<HD, CT>();
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  CT* X = (CT*)smem;            // Kn
+  CT* Y = X + NP * pitch;       // V
+  float* tab2 = (float*)(Y + NP * pitch);
+  double* dtab = (double*)(tab2 + W16::TSP);   // ds_add_f64 is full rate on gfx950, ds_add_f32 is not (see attention.hip)
+  int* tok = (int*)(dtab + W16::TSP);
+  float* red = (float*)(tok + NP);             // [4]
+
+  const int win = blockIdx.x, h = blockIdx.y;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int ld = 3 * p.C, g = lane >> 4, lc = lane & 15;
+
+  for (int i = tid; i < NP; i += 256) tok[i] = win_token(p, win, i);
+  for (int i = tid; i < W16::TS; i += 256) { tab2[i] = p.bias_table[h * W16::TS + i] * kLog2e; dtab[i] = 0.0; }
+  __syncthreads();
+  stage_rows<CT, HD, NP>(X, p.qkv, ld, p.C + h * HD, tok, NP, true, tid);
+  stage_rows<CT, HD, NP>(Y, p.qkv, ld, 2 * p.C + h * HD, tok, NP, false, tid);
+  __syncthreads();
+
+  const float scale = __expf(fminf(p.logit_scale[h], 4.605170185988092f));
+  const float scale2 = scale * kLog2e;
+  const int w = win % p.nw_per_img;
+  const bool lastrow = SHIFTED && (w / p.nwx) == p.Hp / 16 - 1, lastcol = SHIFTED && (w % p.nwx) == p.nwx - 1;
+  const float mlane = (lastcol && ((lc >= 8) != (g >= 2))) ? kMask2 : 0.f;
+  const float* tabl = tab2 + (lc - 4 * g + 12);
+  double* dtabl = dtab + (lc - 4 * g + 15);     // entry of (q = lc, key 4g): the lane's anti-diagonal sum lands here
+  const LaneBase<CT, HD> xb(X, lane), yb(Y, lane);
+  // d logit_scale = Σ_qk dS·cos·scale with Σ_k dS = 0 per query: a heavily cancelling sum.  dS uses delta from the
+  // stored (rounded) forward output; the row sums D = Σ_k P·dP and B = Σ_k P·cos taken here in fp32 put the exact
+  // cancellation back:  Σ_k P (dP - D) cos = Σ_k dS·cos + (delta - D)·B.
+  float dls = 0.f;
+
+#pragma nounroll
+  for (int qb = wave; qb < 16; qb += 4) {
+    const int q = qb * 16 + lc;
+    float accD = 0.f, accB = 0.f;
+    Frag<CT> qf[KS], gf[KS];
+    load_rows_frag<CT, HD>(qf, p.qkv, ld, h * HD, tok, qb * 16, NP, true, lane);
+    float delta = 0.f;
+    {
+      float dov[KS][8], ov[KS][8];
+      load_rows_f32<CT, HD>(dov, p.dout, p.C, h * HD, tok, qb * 16, NP, lane);
+      load_rows_f32<CT, HD>(ov, p.ofwd, p.C, h * HD, tok, qb * 16, NP, lane);
+#pragma unroll
+      for (int kk = 0; kk < KS; ++kk) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) delta += dov[kk][j] * ov[kk][j];
+        gf[kk] = frag_from_f32<CT>(dov[kk]);
+      }
+      delta += __shfl_xor(delta, 16, 64);
+      delta += __shfl_xor(delta, 32, 64);
+    }
+    const float nlse2 = -p.lse[((size_t)win * p.heads + h) * NP + q] * kLog2e;
+    const float* tq = tabl + qb * 31;
+    double* dq_tab = dtabl + qb * 31;
+
+    f32x4_t dq[DT];
+#pragma unroll
+    for (int d = 0; d < DT; ++d) dq[d] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+
+#pragma unroll
+    for (int tp = 0; tp < NT / 2; ++tp) {
+      float ds8[8];
+#pragma unroll
+      for (int half = 0; half < 2; ++half) {
+        const int t = 2 * tp + half;
+        f32x4_t s = {0.f, 0.f, 0.f, 0.f}, dp = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int kk = 0; kk < KS; ++kk) {
+          mma16(s, rd_kc<HD>(xb.kc, t, kk), qf[kk]);
+          mma16(dp, rd_kc<HD>(yb.kc, t, kk), gf[kk]);
+        }
+        float madd = nlse2;
+        if (SHIFTED) madd += (lastrow && ((qb >= 8) != (t >= 8))) ? kMask2 : mlane;
+        float ds[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const float pr = fast_exp2(fmaf(s[r], scale2, tq[(15 - t) * 31 + 3 - r]) + madd);
+          ds[r] = pr * (dp[r] - delta);
+          ds8[half * 4 + r] = ds[r];
+          accD = fmaf(pr, dp[r], accD);
+          accB = fmaf(pr, s[r], accB);
+          dls = fmaf(ds[r], s[r], dls);
+        }
+        // the 16x16 block of dS feeds the 31 entries (dx = qx - kx) of table row (qy - ky): DPP row shifts fold the
+        // lane's four keys along the anti-diagonal, then one LDS atomic per lane (+ 3 lanes for the wrapped tail)
+        const float a = ds[0] + dpp_row<0x101>(ds[1]) + dpp_row<0x102>(ds[2]) + dpp_row<0x103>(ds[3]);
+        const float bt = dpp_row<0x11F>(ds[1]) + dpp_row<0x11E>(ds[2]) + dpp_row<0x11D>(ds[3]);
+        atomicAdd(&dq_tab[(15 - t) * 31], (double)a);
+        if (lc >= 13) atomicAdd(&dq_tab[(15 - t) * 31 - 16], (double)bt);
+      }
+      const Frag<CT> df = frag_from_f32<CT>(ds8);
+#pragma unroll
+      for (int d = 0; d < DT; ++d)   // dQn^T += Kn^T · dS^T
+        mma16(dq[d], rd_ks<HD>(xb.ks, tp, d), df);
+      __builtin_amdgcn_sched_barrier(0);   // one tile pair at a time: unrolled for the immediates, not for hoisting
+    }
+    accD += __shfl_xor(accD, 16, 64); accD += __shfl_xor(accD, 32, 64);
+    accB += __shfl_xor(accB, 16, 64); accB += __shfl_xor(accB, 32, 64);
+    if (g == 0) dls = fmaf(delta - accD, accB, dls);
+    const size_t off = (size_t)tok[q] * ld + h * HD;
+    normalize_bwd_store_t<CT, HD>(dq, scale, p.qkv, p.out, off, lane);
+  }
+  // d/dls [cos * exp(ls)] = cos * scale  (0 when clamped at ln 100, HF:416)
+  dls = wave_sum(dls);
+  if (lane == 0) red[wave] = dls;
+  __syncthreads();
+  for (int i = tid; i < W16::TS; i += 256) atomicAdd(&p.dbias_table[h * W16::TS + i], (float)dtab[i]);
+  if (tid == 0 && p.logit_scale[h] <= 4.605170185988092f) atomicAdd(&p.dlogit_scale[h], (red[0] + red[1] + red[2] + red[3]) * scale);
+}
+
+// ================================================================================================= backward: dK, dV
+template <typename CT, int HD, bool SHIFTED>
+__global__ __launch_bounds__(256, 2) void attn16_bwd_dkv_kernel(AttnArgs p) {
+  constexpr int NT = W16::NT, NP = W16::NP, KS = (HD + 31) / 32, DT = HD / 16, pitch = row_pitch<HD, CT>();
+  constexpr int CPR = KS * 4;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  CT* X = (CT*)smem;            // Qn
+  CT* Y = X + NP * pitch;       // dO
+  float* tab2 = (float*)(Y + NP * pitch);
+  float* nlse2 = tab2 + W16::TSP;   // [NP]  -lse * log2 e
+  float* delta = nlse2 + NP;        // [NP]
+  int* tok = (int*)(delta + NP);
+
+  const int win = blockIdx.x, h = blockIdx.y;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int ld = 3 * p.C, g = lane >> 4, lc = lane & 15;
+
+  for (int i = tid; i < NP; i += 256) {
+    tok[i] = win_token(p, win, i);
+    nlse2[i] = -p.lse[((size_t)win * p.heads + h) * NP + i] * kLog2e;
+  }
+  for (int i = tid; i < W16::TS; i += 256) tab2[i] = p.bias_table[h * W16::TS + i] * kLog2e;
+  __syncthreads();
+  stage_rows<CT, HD, NP>(X, p.qkv, ld, h * HD, tok, NP, true, tid);
+  // dO -> LDS and delta[n] = Σ_d dO[n][d]·O[n][d] in the same pass (CPR lanes per row)
+  for (int c = tid; c < NP * CPR; c += 256) {
+    const int n = c / CPR, d8 = (c % CPR) * 8;
+    float v[8], o[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { v[j] = 0.f; o[j] = 0.f; }
+    if (d8 < HD) {
+      ld8(p.dout, ct_traits<CT>::dtype, (size_t)tok[n] * p.C + h * HD + d8, v);
+      ld8(p.ofwd, ct_traits<CT>::dtype, (size_t)tok[n] * p.C + h * HD + d8, o);
+    }
+    float dot = 0.f;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) dot += v[j] * o[j];
+#pragma unroll
+    for (int of = 1; of < CPR; of <<= 1) dot += __shfl_xor(dot, of, 64);
+    if ((c % CPR) == 0) delta[n] = dot;
+    store8_ct(Y + n * pitch + d8, v);
+  }
+  __syncthreads();
+
+  const float scale = __expf(fminf(p.logit_scale[h], 4.605170185988092f));
+  const float scale2 = scale * kLog2e;
+  const int w = win % p.nw_per_img;
+  const bool lastrow = SHIFTED && (w / p.nwx) == p.Hp / 16 - 1, lastcol = SHIFTED && (w % p.nwx) == p.nwx - 1;
+  const float mlane = (lastcol && ((lc >= 8) != (g >= 2))) ? kMask2 : 0.f;
+  // bias of (query (qy = t, qx = 4g + r), key (ky, kx = lc)) = tab[(t - ky + 15)*31 + 4g + r - lc + 15]
+  const float* tabl = tab2 + (4 * g - lc + 15);
+  const LaneBase<CT, HD> xb(X, lane), yb(Y, lane);
+  const float* nlg = nlse2 + g * 4;
+  const float* dlg = delta + g * 4;
+
+#pragma nounroll
+  for (int kb = wave; kb < 16; kb += 4) {
+    const int key = kb * 16 + lc;
+    Frag<CT> kf[KS], vf[KS];
+    load_rows_frag<CT, HD>(kf, p.qkv, ld, p.C + h * HD, tok, kb * 16, NP, true, lane);
+    load_rows_frag<CT, HD>(vf, p.qkv, ld, 2 * p.C + h * HD, tok, kb * 16, NP, false, lane);
+    const float* tk = tabl + (15 - kb) * 31;
+
+    f32x4_t dv[DT], dk[DT];
+#pragma unroll
+    for (int d = 0; d < DT; ++d) { dv[d] = (f32x4_t){0.f, 0.f, 0.f, 0.f}; dk[d] = (f32x4_t){0.f, 0.f, 0.f, 0.f}; }
+
+#pragma unroll
+    for (int tp = 0; tp < NT / 2; ++tp) {
+      float pf8[8], df8[8];
+#pragma unroll
+      for (int half = 0; half < 2; ++half) {
+        const int t = 2 * tp + half;
+        f32x4_t s = {0.f, 0.f, 0.f, 0.f}, dp = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int kk = 0; kk < KS; ++kk) {
+          mma16(s, rd_kc<HD>(xb.kc, t, kk), kf[kk]);   // rows = queries 4g + r of row t, col = key
+          mma16(dp, rd_kc<HD>(yb.kc, t, kk), vf[kk]);
+        }
+        const float4 nl = *(const float4*)&nlg[t * 16];
+        const float4 qd = *(const float4*)&dlg[t * 16];
+        const float nla[4] = {nl.x, nl.y, nl.z, nl.w}, qda[4] = {qd.x, qd.y, qd.z, qd.w};
+        float madd = 0.f;
+        if (SHIFTED) madd = (lastrow && ((t >= 8) != (kb >= 8))) ? kMask2 : mlane;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const float pr = fast_exp2(fmaf(s[r], scale2, tk[t * 31 + r]) + (madd + nla[r]));
+          pf8[half * 4 + r] = pr;
+          df8[half * 4 + r] = pr * (dp[r] - qda[r]);
+        }
+      }
+      const Frag<CT> pf = frag_from_f32<CT>(pf8), df = frag_from_f32<CT>(df8);
+#pragma unroll
+      for (int d = 0; d < DT; ++d) {
+        mma16(dv[d], rd_ks<HD>(yb.ks, tp, d), pf);   // dV^T  += dO^T · P
+        mma16(dk[d], rd_ks<HD>(xb.ks, tp, d), df);   // dKn^T += Qn^T · dS
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    const size_t off = (size_t)tok[key] * ld + h * HD;
+#pragma unroll
+    for (int d = 0; d < DT; ++d) {
+      const float o[4] = {dv[d][0], dv[d][1], dv[d][2], dv[d][3]};
+      st4<CT>(p.out, off + 2 * p.C + d * 16 + g * 4, o);
+    }
+    normalize_bwd_store_t<CT, HD>(dk, scale, (const CT*)p.qkv + p.C, (CT*)p.out + p.C, off, lane);
+  }
+}
+
+// ================================================================================================= host side
+template <typename CT, int HD, bool SHIFTED>
+static int launch_w16(const AttnArgs& a, int nwin, bool bwd, hipStream_t s) {
+  constexpr int NP = W16::NP, pitch = row_pitch<HD, CT>();
+  const size_t tiles = 2 * NP * pitch * sizeof(CT);
+  const size_t sh_fwd = tiles + W16::TSP * sizeof(float) + NP * sizeof(int);
+  const size_t sh_dq = tiles + W16::TSP * (sizeof(float) + sizeof(double)) + NP * sizeof(int) + 4 * sizeof(float);
+  const size_t sh_dkv = tiles + (W16::TSP + 2 * NP) * sizeof(float) + NP * sizeof(int);
+  dim3 grid(nwin, a.heads), block(256);
+  if (!bwd) {
+    if (sh_fwd > 64 * 1024) (void)hipFuncSetAttribute((const void*)attn16_fwd_kernel<CT, HD, SHIFTED>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh_fwd);
+    hipLaunchKernelGGL((attn16_fwd_kernel<CT, HD, SHIFTED>), grid, block, sh_fwd, s, a);
+  } else {
+    if (sh_dq > 64 * 1024) (void)hipFuncSetAttribute((const void*)attn16_bwd_dq_kernel<CT, HD, SHIFTED>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh_dq);
+    if (sh_dkv > 64 * 1024) (void)hipFuncSetAttribute((const void*)attn16_bwd_dkv_kernel<CT, HD, SHIFTED>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh_dkv);
+    hipLaunchKernelGGL((attn16_bwd_dq_kernel<CT, HD, SHIFTED>), grid, block, sh_dq, s, a);
+    hipLaunchKernelGGL((attn16_bwd_dkv_kernel<CT, HD, SHIFTED>), grid, block, sh_dkv, s, a);
+  }
+  return scot_check_launch();
+}
+
+template <typename CT> static int dispatch_w16(const AttnArgs& a, int hd, int nwin, bool bwd, hipStream_t s) {
+  const bool sh = a.shift != 0;
+  switch (hd) {
+    case 16: return sh ? launch_w16<CT, 16, true>(a, nwin, bwd, s) : launch_w16<CT, 16, false>(a, nwin, bwd, s);
+    case 32: return sh ? launch_w16<CT, 32, true>(a, nwin, bwd, s) : launch_w16<CT, 32, false>(a, nwin, bwd, s);
+    case 64: return sh ? launch_w16<CT, 64, true>(a, nwin, bwd, s) : launch_w16<CT, 64, false>(a, nwin, bwd, s);
+    default: return SCOT_ERR_UNSUPPORTED;
+  }
+}
+
+// returns SCOT_ERR_UNSUPPORTED when the geometry is not the fast path's (the caller then uses the general kernels)
+int scot_attn_w16(const AttnArgs& a, int compute, int hd, int nwin, bool bwd, hipStream_t s) {
+  static int enabled = -1;
+  if (enabled < 0) { const char* e = getenv("SCOT_ATTN_W16"); enabled = e ? atoi(e) : 1; }
+  if (!enabled || !a.use_tr || a.ws != 16 || (a.shift != 0 && a.shift != 8)) return SCOT_ERR_UNSUPPORTED;
+  return compute == SCOT_BF16 ? dispatch_w16<bf16_t>(a, hd, nwin, bwd, s) : dispatch_w16<float>(a, hd, nwin, bwd, s);
+}

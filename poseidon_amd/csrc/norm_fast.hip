@@ -19,6 +19,7 @@ struct ClnFastArgs {
   const void* dout; void* dx; int dout_dt, dx_dt;
   float* d_gw_w; float* d_gw_b; float* d_bw_w; float* d_bw_b; float* d_xbias;
   int rpb, chunks_per_sample;
+  int dbg;           // SCOT_CLN_DEBUG experiment mask (1: no global atomics, 2: no LDS combine, 4: no row loop)
   float* partials;   // optional [nblocks][3][C] scratch: per-block column sums, combined by cln_bwd_finalize_kernel
 };
 
@@ -78,7 +79,10 @@ template <int LPR, int CPL>
 __global__ __launch_bounds__(256) void cln_bwd_fast_kernel(ClnFastArgs p) {
   constexpr int RPW = 64 / LPR;
   constexpr int NCOL = LPR * CPL * 8;      // columns covered (>= C)
-  __shared__ float red[3][NCOL];           // [dgamma | dbeta | dxsum][col], waves combine with LDS atomics
+  // [dgamma | dbeta | dxsum][j][chunk] for column chunk*8 + j: lanes of one ds_add hit consecutive banks (the natural
+  // [col] order put the 64 lanes 8 floats apart: 8-16-way bank conflicts, 15 us of a 24 us kernel at C = 768)
+  __shared__ float red[3][NCOL];
+  constexpr int NCH = NCOL / 8;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int sub = lane / LPR, l = lane % LPR;
   const int b = blockIdx.x / p.chunks_per_sample, chunk = blockIdx.x % p.chunks_per_sample;
@@ -99,50 +103,66 @@ __global__ __launch_bounds__(256) void cln_bwd_fast_kernel(ClnFastArgs p) {
       for (int j = 0; j < 8; ++j) gam[i][j] = p.gw_w ? gw[j] * t + gb[j] : gb[j];
     }
   }
-  for (int i = threadIdx.x; i < 3 * NCOL; i += 256) (&red[0][0])[i] = 0.f;
-  __syncthreads();
-  for (int r = r0 + wave * RPW + sub; r < r1; r += 4 * RPW) {
-    // the LPR lanes of a row group share `sub`, hence the trip count: group shuffles below are convergent
-    const bool rvalid = true;
+  // software-pipelined over rows: the loads of the wave's next row are in flight while the current one is reduced and
+  // stored (the loop was bound by one exposed HBM round trip per row, ~2 us each).  The LPR lanes of a row group share
+  // `sub`, hence the trip count: group shuffles below are convergent.
+  float d[CPL][8], xr[CPL][8], dn[CPL][8], xn[CPL][8];
+  float mean = 0.f, rstd = 0.f, mean_n = 0.f, rstd_n = 0.f;
+  auto load_row = [&](int r, float (&dd)[CPL][8], float (&xx)[CPL][8], float& mu, float& rs) {
     const int row = b * p.rows_per_sample + r;
     const size_t base = (size_t)row * C;
-    const float mean = p.mean[row], rstd = p.rstd[row];
-    float d[CPL][8], xh[CPL][8];
-    float m1 = 0.f, m2 = 0.f;
+    mu = p.mean[row]; rs = p.rstd[row];
 #pragma unroll
     for (int i = 0; i < CPL; ++i) {
       const int c = (l + i * LPR) * 8;
 #pragma unroll
-      for (int j = 0; j < 8; ++j) { d[i][j] = 0.f; xh[i][j] = 0.f; }
+      for (int j = 0; j < 8; ++j) { dd[i][j] = 0.f; xx[i][j] = 0.f; }
       if (c < C) {
-        ld8(p.dout, p.dout_dt, base + c, d[i]);
-        ld8(p.x, p.x_dt, base + c, xh[i]);
+        ld8(p.dout, p.dout_dt, base + c, dd[i]);
+        ld8(p.x, p.x_dt, base + c, xx[i]);
+      }
+    }
+  };
+  int r = r0 + wave * RPW + sub;
+  if (r < r1) load_row(r, d, xr, mean, rstd);
+  for (; r < r1 && !(p.dbg & 4); r += 4 * RPW) {
+    const int rn = r + 4 * RPW;
+    if (rn < r1) load_row(rn, dn, xn, mean_n, rstd_n);
+    const size_t base = (size_t)(b * p.rows_per_sample + r) * C;
+    float xh[CPL][8];
+    float m1 = 0.f, m2 = 0.f;
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {
-          xh[i][j] = (xh[i][j] - mean) * rstd;
-          const float g = d[i][j] * gam[i][j];
-          m1 += g; m2 += g * xh[i][j];
-        }
+    for (int i = 0; i < CPL; ++i) {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        xh[i][j] = (xr[i][j] - mean) * rstd;     // columns >= C hold d = 0, gam = 0: they add nothing below
+        const float g = d[i][j] * gam[i][j];
+        m1 += g; m2 += g * xh[i][j];
       }
     }
     m1 = group_sum<LPR>(m1) / C; m2 = group_sum<LPR>(m2) / C;
-    if (rvalid) {
 #pragma unroll
-      for (int i = 0; i < CPL; ++i) {
-        const int c = (l + i * LPR) * 8;
-        if (c < C) {
-          float o[8];
+    for (int i = 0; i < CPL; ++i) {
+      const int c = (l + i * LPR) * 8;
+      if (c < C) {
+        float o[8];
 #pragma unroll
-          for (int j = 0; j < 8; ++j) {
-            o[j] = rstd * (d[i][j] * gam[i][j] - m1 - xh[i][j] * m2);
-            ag[i][j] += d[i][j] * xh[i][j]; ab[i][j] += d[i][j]; ax[i][j] += o[j];
-          }
-          st8(p.dx, p.dx_dt, base + c, o);
+        for (int j = 0; j < 8; ++j) {
+          o[j] = rstd * (d[i][j] * gam[i][j] - m1 - xh[i][j] * m2);
+          ag[i][j] += d[i][j] * xh[i][j]; ab[i][j] += d[i][j]; ax[i][j] += o[j];
         }
+        st8(p.dx, p.dx_dt, base + c, o);
       }
     }
+#pragma unroll
+    for (int i = 0; i < CPL; ++i)
+#pragma unroll
+      for (int j = 0; j < 8; ++j) { d[i][j] = dn[i][j]; xr[i][j] = xn[i][j]; }
+    mean = mean_n; rstd = rstd_n;
   }
-  // reduce over the RPW row-groups of the wave (same columns live in lanes l, l+LPR, ...), then over waves via LDS
+  // reduce over the RPW row-groups of the wave (same columns live in lanes l, l+LPR, ...), then over the four waves by
+  // taking turns on the LDS copy with plain read-add-write (ds_add_f32 measured ~300 ns per instruction here: 48 of them
+  // were 15 us of a 24 us kernel at C = 768)
 #pragma unroll
   for (int i = 0; i < CPL; ++i)
 #pragma unroll
@@ -151,23 +171,36 @@ __global__ __launch_bounds__(256) void cln_bwd_fast_kernel(ClnFastArgs p) {
       for (int o = LPR; o < 64; o <<= 1) {
         ag[i][j] += __shfl_xor(ag[i][j], o, 64); ab[i][j] += __shfl_xor(ab[i][j], o, 64); ax[i][j] += __shfl_xor(ax[i][j], o, 64);
       }
-      if (sub == 0) {
-        const int c = (l + i * LPR) * 8 + j;
-        atomicAdd(&red[0][c], ag[i][j]); atomicAdd(&red[1][c], ab[i][j]); atomicAdd(&red[2][c], ax[i][j]);
-      }
     }
-  __syncthreads();
+  for (int w = 0; w < 4; ++w) {
+    if (wave == w && sub == 0 && !(p.dbg & 2)) {
+#pragma unroll
+      for (int i = 0; i < CPL; ++i)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          const int c = j * NCH + l + i * LPR;
+          if (w == 0) { red[0][c] = ag[i][j]; red[1][c] = ab[i][j]; red[2][c] = ax[i][j]; }
+          else { red[0][c] += ag[i][j]; red[1][c] += ab[i][j]; red[2][c] += ax[i][j]; }
+        }
+    }
+    __syncthreads();
+  }
   if (p.partials) {   // no global atomics: 4·C same-address atomics per block were the whole cost of this kernel (25 us floor)
     float* dst = p.partials + (size_t)blockIdx.x * 3 * C;
-    for (int c = threadIdx.x; c < C; c += 256) { dst[c] = red[0][c]; dst[C + c] = red[1][c]; dst[2 * C + c] = red[2][c]; }
+    for (int c = threadIdx.x; c < C; c += 256) {
+      const int k = (c & 7) * NCH + (c >> 3);
+      dst[c] = red[0][k]; dst[C + c] = red[1][k]; dst[2 * C + c] = red[2][k];
+    }
     return;
   }
+  if (p.dbg & 1) return;
   for (int c = threadIdx.x; c < C; c += 256) {
-    const float dg = red[0][c], db = red[1][c];
+    const int k = (c & 7) * NCH + (c >> 3);
+    const float dg = red[0][k], db = red[1][k];
     if (p.d_gw_w) { atomicAdd(&p.d_gw_w[c], t * dg); atomicAdd(&p.d_bw_w[c], t * db); }
     atomicAdd(&p.d_gw_b[c], dg);
     atomicAdd(&p.d_bw_b[c], db);
-    if (p.d_xbias) atomicAdd(&p.d_xbias[c], red[2][c]);
+    if (p.d_xbias) atomicAdd(&p.d_xbias[c], red[2][k]);
   }
 }
 
@@ -237,15 +270,25 @@ int scot_cln_fwd_fast(ClnFastArgs a, hipStream_t s) {
 int scot_cln_bwd_fast(ClnFastArgs a, void* workspace, size_t ws_bytes, hipStream_t s) {
   if (a.C % 8 || !aligned16(a.x) || !aligned16(a.dout) || !aligned16(a.dx) || !aligned16(a.gw_w) || !aligned16(a.gw_b))
     return SCOT_ERR_UNSUPPORTED;
-  static int rpb_env = -1;
-  if (rpb_env < 0) { const char* e = getenv("SCOT_CLN_RPB"); rpb_env = e ? atoi(e) : 128; }
-  a.rpb = a.rows_per_sample < rpb_env ? a.rows_per_sample : rpb_env;
+  // rows per block: enough blocks to cover the chip (SCOT_CLN_BLOCKS, default 256: every block ends in 5·C global atomics) but at least two
+  // passes of the four waves, at most 128 rows; SCOT_CLN_RPB pins it
+  static int rpb_env = -1, blocks_env = -1;
+  if (rpb_env < 0) { const char* e = getenv("SCOT_CLN_RPB"); rpb_env = e ? atoi(e) : 0; }
+  if (blocks_env < 0) { const char* e = getenv("SCOT_CLN_BLOCKS"); blocks_env = e ? atoi(e) : 256; }
+  int lpr = 1;
+  while (lpr < 64 && lpr * 8 < a.C) lpr <<= 1;
+  const int rows_per_pass = 4 * (64 / lpr);
+  int rpb = rpb_env > 0 ? rpb_env : (a.rows / blocks_env) / rows_per_pass * rows_per_pass;
+  if (rpb < 2 * rows_per_pass) rpb = 2 * rows_per_pass;
+  if (rpb_env <= 0 && rpb > 128) rpb = 128;
+  a.rpb = a.rows_per_sample < rpb ? a.rows_per_sample : rpb;
   a.chunks_per_sample = (a.rows_per_sample + a.rpb - 1) / a.rpb;
   const int nblocks = (a.rows / a.rows_per_sample) * a.chunks_per_sample;
   // measured: per-block partials + a finalize pass (33 us) do not beat the fp32 atomics (28 us) — the kernel is bound by
   // exposed row-load latency, not by the atomics; partials stay available for experiments (SCOT_CLN_PARTIALS=1)
   static int use_partials = -1;
   if (use_partials < 0) { const char* e = getenv("SCOT_CLN_PARTIALS"); use_partials = e ? atoi(e) : 0; }
+  { const char* e = getenv("SCOT_CLN_DEBUG"); a.dbg = e ? atoi(e) : 0; }
   a.partials = (use_partials && workspace && ws_bytes >= (size_t)nblocks * 3 * a.C * sizeof(float)) ? (float*)workspace : nullptr;
   CLN_DISPATCH(launch_bwd)
   int rc = scot_check_launch();

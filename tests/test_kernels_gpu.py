@@ -154,6 +154,10 @@ ATTN_CASES = [  # B, Hp, Wp, C, heads, ws, shift
     (2, 32, 32, 96, 3, 16, 8),    # Poseidon-B stage 0 (head_dim 32, N=256, shifted)
     (2, 32, 32, 48, 3, 16, 0),    # Poseidon-T stage 0 (head_dim 16)
     (1, 16, 16, 128, 2, 16, 0),   # head_dim 64 (Poseidon-L), N=256
+    (1, 32, 32, 96, 3, 16, 0),    # 16x16 fast path, unshifted, 2x2 windows
+    (2, 32, 32, 48, 3, 16, 8),    # 16x16 fast path, head_dim 16, shifted
+    (1, 48, 32, 96, 3, 16, 8),    # 16x16 fast path, 3x2 windows: interior / last-row / last-column mask regions
+    (1, 32, 48, 128, 2, 16, 8),   # 16x16 fast path, head_dim 64, 2x3 windows
     (3, 8, 8, 64, 2, 8, 0),       # N=64
     (2, 8, 8, 32, 2, 4, 2),       # N=16 shifted
     (2, 4, 4, 128, 2, 4, 0),      # N=16, head_dim 64

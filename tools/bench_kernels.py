@@ -30,7 +30,21 @@ def gemm_case(layout, M, N, K, cdt=torch.bfloat16, out=torch.bfloat16, gelu=Fals
         A, B = torch.randn(K, M, device="cuda").to(cdt), torch.randn(K, N, device="cuda").to(cdt)
         out = torch.float32
     C = torch.zeros(M, N, device="cuda", dtype=out)
-    us = timeit(lambda: ops.gemm(layout, cm, M, N, K, A, A.shape[1], B, B.shape[1], C, N, a_gelu=gelu, accumulate=layout == ops.TN))
+    if os.environ.get("BK_COLD", "0") == "1":
+        # rotate through enough operand copies to defeat the 256 MB Infinity Cache: in the real step every operand comes
+        # from HBM, a loop over ONE buffer set measures the cache-resident rate (2-3x optimistic at stage 0)
+        per = A.numel() * A.element_size() + C.numel() * C.element_size() + (B.numel() * B.element_size() if layout == ops.TN else 0)
+        nb = max(2, min(64, int(800e6 / per) + 1))
+        sets = [(A.clone(), B.clone() if layout == ops.TN else B, C.clone()) for _ in range(nb)]
+        it = [0]
+
+        def run():
+            a, b, c = sets[it[0] % nb]
+            it[0] += 1
+            ops.gemm(layout, cm, M, N, K, a, a.shape[1], b, b.shape[1], c, N, a_gelu=gelu, accumulate=layout == ops.TN)
+        us = timeit(run, reps=max(20, nb))
+    else:
+        us = timeit(lambda: ops.gemm(layout, cm, M, N, K, A, A.shape[1], B, B.shape[1], C, N, a_gelu=gelu, accumulate=layout == ops.TN))
     byt = A.numel() * A.element_size() + B.numel() * B.element_size() + C.numel() * C.element_size()
     print(f"gemm {['NT','NN','TN'][layout]} {tag:14s} M={M:6d} N={N:5d} K={K:6d}: {us:8.1f} us  {2.0*M*N*K/us/1e6:7.1f} TF/s  {byt/us/1e3:7.0f} GB/s")
 
@@ -39,7 +53,7 @@ def main():
     ops.L()
     B = 64
     only = sys.argv[1] if len(sys.argv) > 1 else ""
-    for s, (L, C) in ([(0, (1024, 96))] if only == "gemm0" else [] if only else list(enumerate([(1024, 96), (256, 192), (64, 384), (16, 768)]))):
+    for s, (L, C) in ([(0, (1024, 96))] if only == "gemm0" else [(1, (256, 192))] if only == "gemm1" else [] if only else list(enumerate([(1024, 96), (256, 192), (64, 384), (16, 768)]))):
         M = B * L
         gemm_case(ops.NT, M, 3 * C, C, tag=f"qkv s{s}")
         gemm_case(ops.NT, M, C, C, out=torch.float32, tag=f"proj s{s}")
