@@ -38,6 +38,7 @@ def parse():
     ap.add_argument("--channels", type=int, default=4)
     ap.add_argument("--compute", default="bf16", choices=["bf16", "fp32"])
     ap.add_argument("--no-graph", action="store_true", help="eager launches instead of one hipGraph per step")
+    ap.add_argument("--graph", action="store_true", help="force hipGraph replay (default: time both in the warm-up, keep the faster)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=20.0)
     ap.add_argument("--wire", default="bf16", choices=["bf16", "fp32"], help="gradient all-reduce wire format (N>1)")
@@ -223,14 +224,39 @@ def main():
             compute_step()
         torch.cuda.synchronize()
 
+    use_graph = [graph is not None]
+
     def step():
-        if graph is not None:
+        if use_graph[0]:
             graph.replay()
         else:
             compute_step()
         if reducer:
             reducer.allreduce()
 
+    def probe(flag, n=3):
+        use_graph[0] = flag
+        step()
+        torch.cuda.synchronize()
+        t = time.perf_counter()
+        for _ in range(n):
+            step()
+        t_enq = time.perf_counter() - t
+        torch.cuda.synchronize()
+        return (time.perf_counter() - t) / n, t_enq / n
+
+    # hipGraph replay removes the CPU launch cost but (ROCm 7.2) serialises most of the side-stream overlap; eager launches
+    # overlap the weight-gradient stream with the main chain.  Which wins depends on the host CPU: measure both, keep one.
+    mode_info = {}
+    if graph is not None and not a.graph:
+        tg, _ = probe(True)
+        te, te_enq = probe(False)
+        if dist:
+            tt2 = torch.tensor([tg, te], device="cuda", dtype=torch.float64)
+            dist.all_reduce(tt2, op=dist.ReduceOp.MAX)
+            tg, te = float(tt2[0]), float(tt2[1])
+        use_graph[0] = tg <= te
+        mode_info = {"probe_graph_ms": tg * 1e3, "probe_eager_ms": te * 1e3, "eager_cpu_enqueue_ms": te_enq * 1e3}
     for _ in range(a.warmup):
         step()
     if dist:
@@ -275,7 +301,7 @@ def main():
                "warmup": a.warmup, "ms_per_step": ms, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
                "dtype": a.compute, "data": "synthetic",
                "config": {"workload": f"Poseidon-{a.model} fwd+bwd, {a.size}x{a.size}x{ch} grids, per-GPU batch {B}",
-                          "global_batch": B * world, "parallelism": f"dp{world}", "graph": graph is not None,
+                          "global_batch": B * world, "parallelism": f"dp{world}", "graph": bool(use_graph[0]), **mode_info,
                           "grad_wire": a.wire if world > 1 else None, "loss": float(loss_buf)},
                "roofline": roof}
         if world == 1 and not a.no_cpu_baseline:

@@ -678,7 +678,8 @@ int scot_gemm_fast(int layout, int compute, int M, int N, int K, const void* A, 
   int tile = ov[layout] >= 0 ? ov[layout] : (ov[3] >= 0 ? ov[3] : -1);
   if (tile < 0) {
     tile = 0;   // policy (see DESIGN.md §3 for the measurements behind it)
-    if (compute == SCOT_BF16 && N == 96) tile = 2;   // one 64x96 column tile: the A operand streams once (64x64 would read it twice)
+    if (compute == SCOT_BF16 && layout == LAYOUT_TN && M % 96 == 0 && N % 96 == 0) tile = 4;   // wgrad: 96x96 (cold-cache sweep: 25.6 vs 38.5 us at stage 1)
+    else if (compute == SCOT_BF16 && N == 96) tile = 2;   // one 64x96 column tile: the A operand streams once (64x64 would read it twice)
     else if (compute == SCOT_BF16 && layout != LAYOUT_TN && K <= 128) tile = 6;   // K = 96: BK = 32 halves LDS -> more workgroups/CU (-12 %)
   }
   if (compute != SCOT_BF16 && tile != 0 && tile != 3) tile = 0;   // fp32 instantiates 64x64 and 128x128 only
@@ -693,7 +694,9 @@ int scot_gemm_fast(int layout, int compute, int M, int N, int K, const void* A, 
     // writes a partial tile into the workspace and ONE reduce pass adds them into the gradient (12.6 M fp32 atomics per
     // call in the first version of this kernel cost 300 us; the partials cost < 20 MB of traffic).
     if (c_dt != SCOT_F32 || !accumulate) return SCOT_ERR_UNSUPPORTED;
-    long wantsplit = (512 + tiles - 1) / tiles;
+    static int tn_wgs = -1;
+    if (tn_wgs < 0) { const char* e = getenv("SCOT_GEMM_TN_WGS"); tn_wgs = e ? atoi(e) : 512; }
+    long wantsplit = (tn_wgs + tiles - 1) / tiles;
     const long maxsplit = (K + 8 * bk - 1) / (8 * bk);       // >= 8 K-tiles per workgroup
     long wsmax = workspace ? (long)(ws_bytes / ((size_t)M * N * sizeof(float))) : 1;
     nsplit = (int)(wantsplit < 1 ? 1 : (wantsplit > maxsplit ? maxsplit : wantsplit));

@@ -16,6 +16,7 @@ data-flow choices described in DESIGN.md:
 from __future__ import annotations
 
 import math
+import os
 from typing import Dict, List, Optional
 
 import torch
@@ -41,6 +42,14 @@ class ScOTEngine:
         if compute not in ("bf16", "fp32"):
             raise ValueError("compute must be 'bf16' or 'fp32'")
         self.cfg = cfg
+        self.stage_timing = os.environ.get("SCOT_STAGE_TIMING", "0") == "1"
+        self.marks = []
+        self.chains = int(os.environ.get("SCOT_CHAINS", "1"))            # batch slices walking a deep stage concurrently
+        self.chain_rows = int(os.environ.get("SCOT_CHAIN_ROWS", "4096"))  # ... for stages with at most this many token rows
+        self._chain_streams = []
+        self.side_batch = os.environ.get("SCOT_SIDE_BATCH", "1") == "1"
+        self.side_flush = os.environ.get("SCOT_SIDE_FLUSH", "block")   # block | stage: where queued weight-gradient launches fork
+        self._pending = []
         self.arena = arena
         self.compute = ops.BF16 if compute == "bf16" else ops.F32
         self.adt = torch.bfloat16 if compute == "bf16" else torch.float32
@@ -203,27 +212,118 @@ class ScOTEngine:
 
     def off_critical_path(self, fn, *tensors):
         """Run fn() (kernel launches that only WRITE parameter gradients) on the side stream, ordered after everything
-        enqueued so far on the main stream.  `tensors` are kept alive until the join so the allocator cannot recycle them."""
+        enqueued so far on the current stream.  `tensors` are kept alive until the join so the allocator cannot recycle
+        them.  With batching (default) the launches are queued and handed over by flush_side(): ONE fork per block instead
+        of one per weight gradient — hipGraph replay pays for every cross-stream edge."""
         if not self.use_side:
             fn()
             return
+        self._keep.append(tensors)
+        if self.side_batch:
+            self._pending.append(fn)
+        else:
+            self._run_side([fn])
+
+    def _run_side(self, fns):
         if self.side is None:
             self.side = torch.cuda.Stream(device=self.device)
         ev = torch.cuda.Event()
         ev.record()
         self.side.wait_event(ev)
-        ops.set_workspace_slot(1)
+        prev = ops.set_workspace_slot(1)
         try:
             with torch.cuda.stream(self.side):
-                fn()
+                for fn in fns:
+                    fn()
         finally:
-            ops.set_workspace_slot(0)
-        self._keep.append(tensors)
+            ops.set_workspace_slot(prev)
+
+    def flush_side(self):
+        if self._pending:
+            fns, self._pending = self._pending, []
+            self._run_side(fns)
 
     def join_side(self):
+        self.flush_side()
         if self.use_side and self.side is not None:
             torch.cuda.current_stream().wait_stream(self.side)
             self._keep.clear()
+
+    # ------------------------------------------------------------------------------------------ batch chains
+    # The deep stages (8x8 / 4x4 token grids: 4096 / 1024 rows at batch 64) are chains of ~30 dependent launches per block
+    # that each move a few MB: every launch costs its ~10 us latency floor whatever it computes.  Samples are independent,
+    # so the batch is cut into `n` slices that walk the stage on `n` streams at once (hipGraph: parallel branches); the
+    # slices' weight-gradient launches all go to the one side stream, which keeps their read-modify-write of a gradient
+    # serialised, everything else they accumulate into is atomic.
+    def chains_for(self, rows: int, B: int) -> int:
+        n = self.chains
+        if n <= 1 or rows > self.chain_rows or B % n:
+            return 1
+        return n
+
+    def run_chains(self, n, fn):
+        """fn(c) for c in range(n), each on its own stream forked from (and joined back into) the current stream."""
+        if len(self._chain_streams) < n:
+            self._chain_streams += [torch.cuda.Stream(device=self.device) for _ in range(n - len(self._chain_streams))]
+        cur = torch.cuda.current_stream()
+        ev = torch.cuda.Event()
+        ev.record()
+        outs = []
+        for c in range(n):
+            st = self._chain_streams[c]
+            st.wait_event(ev)
+            prev = ops.set_workspace_slot(2 + c)
+            try:
+                with torch.cuda.stream(st):
+                    outs.append(fn(c))
+            finally:
+                ops.set_workspace_slot(prev)
+        for c in range(n):
+            cur.wait_stream(self._chain_streams[c])
+        return outs
+
+    def blocks_fwd(self, blocks, x, x16, B, time, train):
+        """The ScOTLayers of one stage → (x, x16, recs); recs is a list of per-block records, or ("chains", n, [lists])."""
+        L, C = blocks[0].res[0] * blocks[0].res[1], blocks[0].dim
+        n = self.chains_for(B * L, B)
+        if n == 1:
+            recs = []
+            for blk in blocks:
+                x, x16, r = self.layer_fwd(blk, x, x16, B, time, train)
+                recs.append(r)
+            return x, x16, recs
+        Bc = B // n
+        xs, x16s = x.view(n, Bc * L, C), x16.view(n, Bc * L, C)
+        ts = time.view(n, Bc) if time is not None else [None] * n
+
+        def chain(c):
+            xc, xc16, rc = xs[c], x16s[c], []
+            for blk in blocks:
+                xc, xc16, r = self.layer_fwd(blk, xc, xc16, Bc, ts[c], train)
+                rc.append(r)
+            return xc, xc16, rc
+        outs = self.run_chains(n, chain)
+        x = torch.cat([o[0] for o in outs])
+        x16 = torch.cat([o[1] for o in outs])
+        return x, x16, ("chains", n, [o[2] for o in outs])
+
+    def blocks_bwd(self, recs, g, B, time):
+        if not (isinstance(recs, tuple) and recs[0] == "chains"):
+            for blk_rec in reversed(recs):
+                g = self.layer_bwd(blk_rec, g, B, time)
+            self.flush_side()
+            return g
+        _, n, per = recs
+        Bc = B // n
+        gs = g.view(n, g.shape[0] // n, g.shape[1])
+        ts = time.view(n, Bc) if time is not None else [None] * n
+
+        def chain(c):
+            gc = gs[c]
+            for blk_rec in reversed(per[c]):
+                gc = self.layer_bwd(blk_rec, gc, Bc, ts[c])   # in place on the slice of g
+        self.run_chains(n, chain)
+        return g
 
     def wgrad(self, cm, dy, x, gw, b_gelu=False, dbias=None):
         self.off_critical_path(lambda: ops.linear_wgrad(cm, dy, x, gw, b_gelu=b_gelu, dbias=dbias), dy, x)
@@ -233,6 +333,13 @@ class ScOTEngine:
         self.wgrad(self.compute, dy, x, self.G(wname), b_gelu=b_gelu, dbias=self.G(bname) if bname is not None else None)
 
     # ------------------------------------------------------------------------------------------ ScOTLayer
+    def mark(self, label):
+        """SCOT_STAGE_TIMING=1: record a HIP event at a stage boundary (tools/stage_timing.py turns them into a table)."""
+        if self.stage_timing:
+            ev = torch.cuda.Event(enable_timing=True)
+            ev.record()
+            self.marks.append((label, ev))
+
     def layer_fwd(self, blk: BlockGeom, x, x16, B, time, train):
         """reference ScOTLayer.forward (model.py:500-581) + Swinv2Attention/Intermediate/Output (HF:389-561)."""
         cfg, cm = self.cfg, self.compute
@@ -330,6 +437,8 @@ class ScOTEngine:
             ops.add(g, tmpc, g)
         else:
             ops.linear_dgrad(cm, d_qkv, wqkv, g, accumulate=True)
+        if self.side_flush == "block":
+            self.flush_side()
         return g
 
     # ------------------------------------------------------------------------------------------ resampling
@@ -436,6 +545,7 @@ class ScOTEngine:
         if train and cfg.drop_path_rate > 0.0:
             raise NotImplementedError("stochastic depth (drop_path_rate > 0) in training is not implemented yet; the "
                                       "reference training recipe uses 0.0 (train.py:262)")
+        self.mark("fwd embed")
         p = cfg.patch_size
         gh, gw = self.grid
         C0 = cfg.embed_dim
@@ -462,12 +572,10 @@ class ScOTEngine:
 
         # encoder (model.py:816-861)
         skips: List[torch.Tensor] = []
-        for st in self.enc:
+        for si, st in enumerate(self.enc):
+            self.mark(f"fwd enc{si}")
             stage_in = x
-            recs = []
-            for blk in st.blocks:
-                x, x16, r = self.layer_fwd(blk, x, x16, B, time, train)
-                recs.append(r)
+            x, x16, recs = self.blocks_fwd(st.blocks, x, x16, B, time, train)
             skips.append(x)
             hidden_enc.append(x)
             mrec = None
@@ -477,6 +585,7 @@ class ScOTEngine:
                 tape["enc"].append((recs, mrec))
 
         # ConvNeXt blocks on the skips (model.py:1388-1393)
+        self.mark("fwd convnext")
         for i, st in enumerate(self.enc):
             nblk = int(cfg.skip_connections[i]) if i < len(cfg.skip_connections) else 0
             rr = []
@@ -492,15 +601,13 @@ class ScOTEngine:
         hidden_dec = [x]
         sk = skips[:-1]
         for k, st in enumerate(self.dec):
+            self.mark(f"fwd dec{k}")
             if k != 0:
                 y = self.new(x.shape[0], x.shape[1])
                 ops.add(x, sk[len(sk) - k], y)
                 x = y
                 x16 = self.to_adt(x)
-            recs = []
-            for blk in st.blocks:
-                x, x16, r = self.layer_fwd(blk, x, x16, B, time, train)
-                recs.append(r)
+            x, x16, recs = self.blocks_fwd(st.blocks, x, x16, B, time, train)
             hidden_dec.append(x)
             urec = None
             if st.resample:
@@ -509,6 +616,7 @@ class ScOTEngine:
                 tape["dec"].append((recs, urec))
 
         # recovery head (model.py:639-647)
+        self.mark("fwd head")
         Cout = cfg.num_out_channels
         rc = self.new(B * L0, Cout * p * p)
         xr = x if self.tadt == torch.float32 else x16
@@ -573,6 +681,7 @@ class ScOTEngine:
         B, time = tape["B"], tape["time"]
         hd = tape["head"]
         self.cpb_dtables.zero_()
+        self.mark("bwd head")
         _, Cout, H, W = hd["shape"]
         p = cfg.patch_size
         gh, gw = self.grid
@@ -615,12 +724,12 @@ class ScOTEngine:
         nl = len(self.dec)
         g_skips: List[Optional[torch.Tensor]] = [None] * nl  # gradient wrt the (ConvNeXt-processed) skips
         for k in reversed(range(nl)):
+            self.mark(f"bwd dec{k}")
             st = self.dec[k]
             recs, urec = tape["dec"][k]
             if st.resample:
                 g = self.unmerge_bwd(st, urec, g, B, time)
-            for blk_rec in reversed(recs):
-                g = self.layer_bwd(blk_rec, g, B, time)
+            g = self.blocks_bwd(recs, g, B, time)
             self.cpb_backward_range(st.blocks)
             done(f"decoder.layers.{k}.")
             if k != 0:
@@ -629,6 +738,7 @@ class ScOTEngine:
         g_skips[nl - 1] = g  # decoder input = skips[-1]
 
         # ConvNeXt blocks
+        self.mark("bwd convnext")
         for i in reversed(range(nl)):
             st = self.enc[i]
             for j in reversed(range(len(tape["res"][i]))):
@@ -639,6 +749,7 @@ class ScOTEngine:
         # encoder, deep → shallow
         g = None
         for s in reversed(range(nl)):
+            self.mark(f"bwd enc{s}")
             st = self.enc[s]
             recs, mrec = tape["enc"][s]
             if st.resample:
@@ -648,14 +759,14 @@ class ScOTEngine:
             else:
                 g = g_skips[s]
                 d_sum = None
-            for blk_rec in reversed(recs):
-                g = self.layer_bwd(blk_rec, g, B, time)
+            g = self.blocks_bwd(recs, g, B, time)
             if d_sum is not None:
                 ops.add(g, d_sum, g)
             self.cpb_backward_range(st.blocks)
             done(f"encoder.layers.{s}.")
 
         # embeddings
+        self.mark("bwd embed")
         emb = tape["emb"]
         Cin = cfg.num_channels
         if cfg.use_absolute_embeddings:
@@ -664,4 +775,5 @@ class ScOTEngine:
         self.wgrad(self.tcm, d_e, emb["cols"], self.G("embeddings.patch_embeddings.projection.weight").view(C0, Cin * p * p),
                    dbias=self.G("embeddings.patch_embeddings.projection.bias"))
         self.join_side()
+        self.mark("end")
         done("embeddings.")

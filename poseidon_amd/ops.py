@@ -57,10 +57,12 @@ WORKSPACE_BYTES = 96 << 20
 _slot = 0
 
 
-def set_workspace_slot(slot: int) -> None:
-    """0 = main stream, 1 = side stream: kernels of the two streams run concurrently and must not share split-K scratch."""
+def set_workspace_slot(slot: int) -> int:
+    """0 = main stream, 1 = side stream, 2.. = batch-chain streams: kernels of different streams run concurrently and must
+    not share split-K scratch.  Returns the previous slot."""
     global _slot
-    _slot = slot
+    prev, _slot = _slot, slot
+    return prev
 
 
 def workspace():
