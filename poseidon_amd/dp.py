@@ -96,6 +96,7 @@ class OverlappedGradAllReducer(GradAllReducer):
 
     def attach(self):
         self.model._engine.on_grads_final = self._on_final
+        self.model._engine.reset_tapes()   # a recorded step bakes the hook in
         self.model.register_grad_ready_hook(lambda m: self.finish())
 
     def _on_final(self, prefix: str):

@@ -47,6 +47,13 @@ class ScOTEngine:
         self.chains = int(os.environ.get("SCOT_CHAINS", "1"))            # batch slices walking a deep stage concurrently
         self.chain_rows = int(os.environ.get("SCOT_CHAIN_ROWS", "4096"))  # ... for stages with at most this many token rows
         self._chain_streams = []
+        # step tape: the second training step with a given input signature is recorded (every C-ABI launch with its final
+        # arguments + the host-side stream/event operations between them), later steps replay the list: ~2500 launches per
+        # step cost ~10 us of Python each when issued through the op wrappers, ~1.5 us when replayed.
+        self.tape_mode = os.environ.get("SCOT_TAPE", "1") == "1"
+        self._rec = None
+        self._rec_keep = None
+        self._taped = {}
         self.side_batch = os.environ.get("SCOT_SIDE_BATCH", "1") == "1"
         self.side_flush = os.environ.get("SCOT_SIDE_FLUSH", "block")   # block | stage: where queued weight-gradient launches fork
         self._pending = []
@@ -158,15 +165,32 @@ class ScOTEngine:
         """Copy of fp32 `x` in the GEMM operand dtype (identity in fp32 mode)."""
         if self.adt == torch.float32:
             return x
-        y = torch.empty(x.shape, dtype=self.adt, device=self.device)
+        y = self.new(*x.shape, dtype=self.adt)
         ops.cast(x, y)
         return y
 
     def new(self, *shape, dtype=torch.float32):
-        return torch.empty(*shape, dtype=dtype, device=self.device)
+        t = torch.empty(*shape, dtype=dtype, device=self.device)
+        if self._rec is not None:
+            self._rec_keep.append(t)   # a recorded step owns its buffers for good: replays reuse these very addresses
+        return t
 
     def zeros(self, *shape, dtype=torch.float32):
-        return torch.zeros(*shape, dtype=dtype, device=self.device)
+        t = self.new(*shape, dtype=dtype)
+        self.tdo(t.zero_)
+        return t
+
+    def tdo(self, fn):
+        """Host-side operation that is part of the step but not a C-ABI launch (torch memset/copy, event record, stream
+        wait, DP callback): run it, and log it when a step tape is being recorded."""
+        fn()
+        if self._rec is not None:
+            self._rec.append((fn, None))
+
+    def clone(self, t):
+        y = self.new(*t.shape, dtype=t.dtype)
+        self.tdo(lambda: y.copy_(t))
+        return y
 
     def coords(self, ws: int) -> torch.Tensor:
         t = self._coords.get(ws)
@@ -227,9 +251,12 @@ class ScOTEngine:
     def _run_side(self, fns):
         if self.side is None:
             self.side = torch.cuda.Stream(device=self.device)
-        ev = torch.cuda.Event()
-        ev.record()
-        self.side.wait_event(ev)
+        ev, cur, side = torch.cuda.Event(), torch.cuda.current_stream(), self.side
+
+        def fork():
+            ev.record(cur)
+            side.wait_event(ev)
+        self.tdo(fork)
         prev = ops.set_workspace_slot(1)
         try:
             with torch.cuda.stream(self.side):
@@ -246,7 +273,8 @@ class ScOTEngine:
     def join_side(self):
         self.flush_side()
         if self.use_side and self.side is not None:
-            torch.cuda.current_stream().wait_stream(self.side)
+            cur, side = torch.cuda.current_stream(), self.side
+            self.tdo(lambda: cur.wait_stream(side))
             self._keep.clear()
 
     # ------------------------------------------------------------------------------------------ batch chains
@@ -267,11 +295,11 @@ class ScOTEngine:
             self._chain_streams += [torch.cuda.Stream(device=self.device) for _ in range(n - len(self._chain_streams))]
         cur = torch.cuda.current_stream()
         ev = torch.cuda.Event()
-        ev.record()
+        self.tdo(lambda: ev.record(cur))
         outs = []
         for c in range(n):
             st = self._chain_streams[c]
-            st.wait_event(ev)
+            self.tdo(lambda st=st: st.wait_event(ev))
             prev = ops.set_workspace_slot(2 + c)
             try:
                 with torch.cuda.stream(st):
@@ -279,7 +307,7 @@ class ScOTEngine:
             finally:
                 ops.set_workspace_slot(prev)
         for c in range(n):
-            cur.wait_stream(self._chain_streams[c])
+            self.tdo(lambda st=self._chain_streams[c]: cur.wait_stream(st))
         return outs
 
     def blocks_fwd(self, blocks, x, x16, B, time, train):
@@ -303,8 +331,9 @@ class ScOTEngine:
                 rc.append(r)
             return xc, xc16, rc
         outs = self.run_chains(n, chain)
-        x = torch.cat([o[0] for o in outs])
-        x16 = torch.cat([o[1] for o in outs])
+        x, x16 = self.new(B * L, C), self.new(B * L, C, dtype=self.adt)
+        self.tdo(lambda: torch.cat([o[0] for o in outs], out=x))
+        self.tdo(lambda: torch.cat([o[1] for o in outs], out=x16))
         return x, x16, ("chains", n, [o[2] for o in outs])
 
     def blocks_bwd(self, recs, g, B, time):
@@ -535,7 +564,84 @@ class ScOTEngine:
 
     # ------------------------------------------------------------------------------------------ whole model
     def forward(self, pixel_values, time=None, labels=None, pixel_mask=None, train=True):
-        """→ (loss [1] or None, prediction [B,Cout,H,W], tape or None).  Inputs: fp32 contiguous CUDA tensors."""
+        """→ (loss [1] or None, prediction [B,Cout,H,W], tape or None).  Inputs: fp32 contiguous CUDA tensors.
+
+        Training steps go through the step tape (see __init__): call 1 of a signature runs the ops directly, call 2 runs them
+        and records, later calls copy the inputs into the recorded step's input buffers and replay.  The tensors returned
+        by a replay alias the recorded step's buffers (like a hipGraph's static outputs): read them before the next step."""
+        if not (train and self.tape_mode and labels is not None and not self.stage_timing) or torch.cuda.is_current_stream_capturing():
+            return self._forward(pixel_values, time, labels, pixel_mask, train)
+        key = (tuple(pixel_values.shape), None if time is None else tuple(time.shape), tuple(labels.shape),
+               None if pixel_mask is None else (tuple(pixel_mask.shape), pixel_mask.dtype), torch.cuda.current_stream().cuda_stream)
+        ent = self._taped.get(key)
+        if ent is None:
+            self._taped[key] = dict(state="warm")
+            return self._forward(pixel_values, time, labels, pixel_mask, train)
+        ins = (pixel_values, time, labels, pixel_mask)
+        if ent["state"] == "ready":
+            for dst, src in zip(ent["in"], ins):
+                if dst is not None:
+                    dst.copy_(src)
+            self._replay(ent["fwd"])
+            loss, pred, tape = ent["out"]
+            return loss.detach(), pred.detach(), tape
+        if ent["state"] != "warm":        # recorded forward whose backward never ran, or a tape that was switched off
+            return self._forward(pixel_values, time, labels, pixel_mask, train)
+        ent["in"] = tuple(None if t is None else t.clone() for t in ins)
+        self._rec, self._rec_keep = [], []
+        prev = ops.set_recorder(self._rec)
+        try:
+            loss, pred, tape = self._forward(*ent["in"], train)
+        finally:
+            ops.set_recorder(prev)
+            ent["fwd"], ent["keep"] = self._rec, self._rec_keep
+            self._rec = self._rec_keep = None
+        tape["_ent"] = ent
+        ent["out"] = (loss, pred, tape)
+        ent["state"] = "fwd"
+        return loss.detach(), pred.detach(), tape
+
+    @staticmethod
+    def _replay(cmds):
+        for fn, args in cmds:
+            if args is None:
+                fn()
+            else:
+                rc = fn(*args)
+                if rc:
+                    raise RuntimeError(f"step tape: {getattr(fn, '__name__', fn)} returned {rc}")
+
+    def backward(self, tape, dloss=None, dpred=None):
+        """Accumulates every parameter gradient into the gradient arena (+=).  dloss: [1] cuda tensor or None (=1)."""
+        ent = tape.get("_ent")
+        if ent is None or ent["state"] == "off":
+            return self._backward(tape, dloss, dpred)
+        if dpred is not None or torch.cuda.is_current_stream_capturing():   # not the recorded pattern: plain path, tape off
+            ent["state"] = "off"
+            return self._backward(tape, dloss, dpred)
+        if ent["state"] == "ready":
+            if dloss is None:
+                ent["dloss"].fill_(1.0)
+            else:
+                ent["dloss"].copy_(dloss.reshape(1))
+            self._replay(ent["bwd"])
+            return
+        ent["dloss"] = torch.ones(1, device=self.device) if dloss is None else dloss.reshape(1).to(torch.float32).clone()
+        self._rec, self._rec_keep = [], ent["keep"]
+        prev = ops.set_recorder(self._rec)
+        try:
+            self._backward(tape, ent["dloss"], None)
+        finally:
+            ops.set_recorder(prev)
+            ent["bwd"] = self._rec
+            self._rec = self._rec_keep = None
+        ent["state"] = "ready"
+
+    def reset_tapes(self):
+        """Forget recorded steps (call after changing anything a tape bakes in: hooks, environment knobs)."""
+        self._taped.clear()
+
+    def _forward(self, pixel_values, time=None, labels=None, pixel_mask=None, train=True):
         cfg, cm = self.cfg, self.compute
         B, Cin, H, W = pixel_values.shape
         if Cin != cfg.num_channels:
@@ -636,7 +742,8 @@ class ScOTEngine:
             if labels is None:
                 raise ValueError("pixel_mask needs labels")
             mask_full = pixel_mask.dim() != 2
-            mask_u8 = (pixel_mask.expand(B, Cout, H, W) if mask_full else pixel_mask).to(torch.uint8).contiguous()
+            mask_u8 = self.new(*((B, Cout, H, W) if mask_full else pixel_mask.shape), dtype=torch.uint8)
+            self.tdo(lambda: mask_u8.copy_(pixel_mask.expand(B, Cout, H, W) if mask_full else pixel_mask))
         sums = None
         if labels is not None or pv_res is not None:
             sums = self.zeros(2 * meta["G"]) if meta else None
@@ -675,12 +782,11 @@ class ScOTEngine:
         self._loss_meta = (key, meta)
         return meta
 
-    def backward(self, tape, dloss=None, dpred=None):
-        """Accumulates every parameter gradient into the gradient arena (+=).  dloss: [1] cuda tensor or None (=1)."""
+    def _backward(self, tape, dloss=None, dpred=None):
         cfg, cm, adt = self.cfg, self.compute, self.adt
         B, time = tape["B"], tape["time"]
         hd = tape["head"]
-        self.cpb_dtables.zero_()
+        self.tdo(self.cpb_dtables.zero_)
         self.mark("bwd head")
         _, Cout, H, W = hd["shape"]
         p = cfg.patch_size
@@ -695,7 +801,7 @@ class ScOTEngine:
             if dpred is not None:
                 ops.add(g_pred, dpred.contiguous(), g_pred)
         elif dpred is not None:
-            g_pred = dpred.contiguous().clone()
+            g_pred = self.clone(dpred.contiguous())
         else:
             raise RuntimeError("nothing to differentiate: no labels and no gradient for the prediction")
         # recovery head
@@ -714,7 +820,7 @@ class ScOTEngine:
         if self.on_grads_final is not None:
             def done(prefix, _cb=self.on_grads_final):
                 self.join_side()   # the range's weight gradients (side stream) must be complete before its all-reduce
-                _cb(prefix)
+                self.tdo(lambda: _cb(prefix))
         else:
             def done(prefix):
                 return None
@@ -734,7 +840,7 @@ class ScOTEngine:
             done(f"decoder.layers.{k}.")
             if k != 0:
                 g_skips[nl - 1 - k] = g   # x = x_prev + skip: both get g (g keeps flowing to x_prev unchanged)
-                g = g.clone()
+                g = self.clone(g)
         g_skips[nl - 1] = g  # decoder input = skips[-1]
 
         # ConvNeXt blocks

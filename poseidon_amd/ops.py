@@ -38,6 +38,33 @@ def stream():
 _selftested = False
 
 
+_recorder = None   # a list while the engine records a step tape: every C-ABI call is appended as (function, args)
+
+
+class _Recording:
+    """Library proxy used while a step is being recorded: calls run as usual AND are logged with their final arguments
+    (device addresses, sizes, stream handles) so that `replay` can re-issue exactly the same launches."""
+
+    def __init__(self, lib, log):
+        self._lib, self._log = lib, log
+
+    def __getattr__(self, name):
+        fn = getattr(self._lib, name)
+        log = self._log
+
+        def call(*args):
+            log.append((fn, args))
+            return fn(*args)
+        return call
+
+
+def set_recorder(log):
+    """log: list to append (fn, args) to, or None to stop recording.  Returns the previous recorder."""
+    global _recorder
+    prev, _recorder = _recorder, log
+    return prev
+
+
 def L():
     """Library handle; runs the one-time device self test of the transposing LDS read on first use."""
     global _selftested
@@ -47,6 +74,8 @@ def L():
         if rc < 0:
             raise _lib.ScotLibraryError("scot_selftest_tr failed to run")
         _selftested = True
+    if _recorder is not None:
+        return _Recording(l, _recorder)
     return l
 
 

@@ -200,3 +200,34 @@ def test_ar_rollout_matches_reference_trainer():
         o = rollout(model, dict(kw, time=kw["time"] * 0.5), [1, 2])
         assert rel_l2(o.output.cpu().numpy(), f["list12_output"]) < 1e-3
         assert abs(float(o.loss) - float(f["list12_loss"])) < 1e-3 * abs(float(f["list12_loss"]))
+
+
+@pytest.mark.parametrize("name", ["tiny_trained", "tiny_learnres_mask", "tiny_w16"])
+def test_step_tape_replay_matches_direct_launches(name):
+    """Step tape (engine.forward/backward): step 1 runs the ops, step 2 records, steps 3+ replay the recorded launches on
+    NEW inputs.  Every step must give the loss / prediction / gradients of a model that never tapes."""
+    f, meta = load_fixture(name)
+    cfg, taped = build(meta, "fp32")
+    _, plain = build(meta, "fp32")
+    kw = inputs(cfg, meta)
+    for step in range(5):
+        kws = {k: (v if v.dtype == torch.bool else v * (1.0 + 0.25 * step) + 0.01 * step) for k, v in kw.items()}
+        outs = []
+        for m in (taped, plain):
+            if m._engine is not None:
+                m._engine.tape_mode = m is taped
+            m.zero_grad()
+            out = m(**kws)
+            (out.loss * (1.0 + step)).backward()     # a different upstream gradient every step
+            outs.append((float(out.loss), out.output.detach().clone(), {k: p.grad.detach().clone() for k, p in m.named_parameters()}))
+        if step == 0:
+            continue   # engines exist from here on (step 0 of `plain` may have run with the default tape_mode: it only warms)
+        (l0, o0, g0), (l1, o1, g1) = outs
+        assert abs(l0 - l1) <= 1e-6 * abs(l1), (step, l0, l1)
+        assert rel_l2(o0.cpu().numpy(), o1.cpu().numpy()) < 1e-6, step
+        for k in g0:
+            n = float(g1[k].norm())
+            assert float((g0[k] - g1[k]).norm()) <= 2e-5 * n + 1e-9, (step, k)
+    ent = [e for e in taped._engine._taped.values() if e["state"] == "ready"]
+    assert len(ent) == 1 and len(ent[0]["fwd"]) > 20 and len(ent[0]["bwd"]) > 20
+    assert not plain._engine._taped or all(e["state"] == "warm" for e in plain._engine._taped.values())
