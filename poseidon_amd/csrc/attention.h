@@ -50,6 +50,7 @@ template <typename CT, int HD, int NP>
 __device__ __forceinline__ void stage_rows(CT* tile, const void* src, int ld, int col, const int* tok, int N,
                                            bool normalize, int tid) {
   constexpr int CPR = ((HD + 31) / 32) * 4, pitch = row_pitch<HD, CT>();
+#pragma unroll   // constant trip count: lets the loads of all passes go out before the first one is consumed
   for (int c = tid; c < NP * CPR; c += 256) {
     const int n = c / CPR, d8 = (c % CPR) * 8;
     float v[8];

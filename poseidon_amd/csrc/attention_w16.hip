@@ -9,6 +9,7 @@
 //   * logits are kept in the log2 domain (table, scale and lse pre-multiplied by log2 e): v_exp_f32 directly;
 //   * outputs are produced TRANSPOSED (O^T = V^T P^T, dQ^T, dK^T, dV^T): a lane then owns 4 consecutive features of one
 //     token -> 8/16-byte stores and two-step (xor 16, 32) row reductions in the normalisation backward.
+#include <cstdio>
 #include "attention.h"
 
 static constexpr float kLog2e = 1.4426950408889634f, kLn2 = 0.6931471805599453f;
@@ -34,68 +35,129 @@ template <> __device__ __forceinline__ void st4<bf16_t>(void* p, size_t i, const
   *(uint2*)((bf16_t*)p + i) = make_uint2(pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]));
 }
 
-// Fragment reads through per-lane base pointers: every tile / feature-block offset below is a compile-time constant, so
-// the reads become `ds_read ... offset:imm` off ONE address register per tile array (the generic helpers recompute
-// (row0 + lane)·pitch per tile, which the compiler hoists into dozens of live address registers once unrolled).
-template <typename CT, int HD> struct LaneBase {
-  const CT* kc;   // K-contiguous reads: row (lane&15), features (lane>>4)*8 ..
-  const CT* ks;   // K-strided (transposing) reads: see lds_frag_ks
-  __device__ __forceinline__ LaneBase(const CT* T, int lane) {
-    constexpr int pitch = row_pitch<HD, CT>();
-    const int lc = lane & 15, g = lane >> 4;
-    kc = T + lc * pitch + g * 8;
-    ks = sizeof(CT) == 2 ? T + (g * 4 + (lc >> 2)) * pitch + (lc & 3) * 4 : T + g * 4 * pitch + lc;
-  }
-};
-template <int HD> __device__ __forceinline__ Frag<bf16_t> rd_kc(const bf16_t* kc, int t, int kk) {
-  Frag<bf16_t> f;
-  f.v = *(const s16x8_t*)(kc + t * 16 * row_pitch<HD, bf16_t>() + kk * 32);
-  return f;
-}
-template <int HD> __device__ __forceinline__ Frag<float> rd_kc(const float* kc, int t, int kk) {
-  Frag<float> f;
-  const float* q = kc + t * 16 * row_pitch<HD, float>() + kk * 32;
-  const float4 a = *(const float4*)q, b = *(const float4*)(q + 4);
-  f.v[0] = a.x; f.v[1] = a.y; f.v[2] = a.z; f.v[3] = a.w; f.v[4] = b.x; f.v[5] = b.y; f.v[6] = b.z; f.v[7] = b.w;
-  return f;
-}
-// 8 keys of tile pair tp (4 of tile 2tp at rows 4g.., 4 of tile 2tp+1), feature column d*16 + (lane&15)
-template <int HD> __device__ __forceinline__ Frag<bf16_t> rd_ks(const bf16_t* ks, int tp, int d) {
-  typedef __attribute__((address_space(3))) s16x4_t* lds_v4;
-  constexpr int pitch = row_pitch<HD, bf16_t>();
-  const s16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4)(ks + (2 * tp) * 16 * pitch + d * 16));
-  const s16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4)(ks + (2 * tp + 1) * 16 * pitch + d * 16));
-  Frag<bf16_t> f;
-  f.v = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
-  return f;
-}
-template <int HD> __device__ __forceinline__ Frag<float> rd_ks(const float* ks, int tp, int d) {
-  constexpr int pitch = row_pitch<HD, float>();
-  Frag<float> f;
-#pragma unroll
-  for (int j = 0; j < 4; ++j) {
-    f.v[j] = ks[((2 * tp) * 16 + j) * pitch + d * 16];
-    f.v[j + 4] = ks[((2 * tp + 1) * 16 + j) * pitch + d * 16];
-  }
-  return f;
-}
-
 // geometry of the fast path
 struct W16 {
   static constexpr int NT = 16, NP = 256, TW = 31, TS = 961, TSP = 964;
 };
 
+// LDS tiles of the fast path.  bf16 with the head_dim padded to 32 (Poseidon-T/S/B): PAD-FREE rows of 64 bytes whose four
+// 16-byte chunks sit at positions chunk ^ ((row >> 2) & 3) — the 16 rows of a K-contiguous fragment read and the 4x4 blocks
+// of a transposing read then spread over all banks without the 8-element row padding: 16 KB per tile instead of 20 KB, which
+// is the difference between 3 and 4 workgroups per CU.  Otherwise (fp32 compute, head_dim 64): padded rows as in attention.hip.
+// All reads go through per-lane base pointers + compile-time offsets (`ds_read ... offset:imm`).
+template <typename CT, int HD> struct Tile16 {
+  static constexpr int KD = ((HD + 31) / 32) * 32, DT = HD / 16;
+  static constexpr bool swz = KD == 32 && sizeof(CT) == 2;
+  static constexpr int pitch = swz ? 32 : row_pitch<HD, CT>();
+  static constexpr int elems = W16::NP * pitch;
+  const CT* kc;        // K-contiguous reads: row (lane&15), features (lane>>4)*8 ..
+  const CT* ks[DT];    // transposing reads of feature block d (bf16) / strided element reads (fp32)
+  __device__ __forceinline__ Tile16(const CT* T, int lane) {
+    const int lc = lane & 15, g = lane >> 4;
+    kc = T + lc * pitch + (swz ? (g ^ ((lc >> 2) & 3)) : g) * 8;
+#pragma unroll
+    for (int d = 0; d < DT; ++d) {
+      if (sizeof(CT) == 2) {
+        // lane i of a 16-lane group hands the instruction the 8-byte piece (i & 3) of row 4g + (i >> 2), columns d*16 ..
+        const int chunk = d * 2 + ((lc & 3) >> 1);
+        ks[d] = T + (g * 4 + (lc >> 2)) * pitch + (swz ? (chunk ^ g) : chunk) * 8 + (lc & 1) * 4;
+      } else {
+        ks[d] = T + g * 4 * pitch + d * 16 + lc;
+      }
+    }
+  }
+  // where chunk `ch` (8 elements) of row n is stored
+  static __device__ __forceinline__ int store_off(int n, int ch) { return n * pitch + (swz ? (ch ^ ((n >> 2) & 3)) : ch) * 8; }
+};
+template <int HD> __device__ __forceinline__ Frag<bf16_t> rd_kc(const Tile16<bf16_t, HD>& T, int t, int kk) {
+  Frag<bf16_t> f;
+  f.v = *(const s16x8_t*)(T.kc + t * 16 * Tile16<bf16_t, HD>::pitch + kk * 32);
+  return f;
+}
+template <int HD> __device__ __forceinline__ Frag<float> rd_kc(const Tile16<float, HD>& T, int t, int kk) {
+  Frag<float> f;
+  const float* q = T.kc + t * 16 * Tile16<float, HD>::pitch + kk * 32;
+  const float4 a = *(const float4*)q, b = *(const float4*)(q + 4);
+  f.v[0] = a.x; f.v[1] = a.y; f.v[2] = a.z; f.v[3] = a.w; f.v[4] = b.x; f.v[5] = b.y; f.v[6] = b.z; f.v[7] = b.w;
+  return f;
+}
+// 8 keys of tile pair tp (4 of tile 2tp at rows 4g.., 4 of tile 2tp+1), feature column d*16 + (lane&15)
+template <int HD> __device__ __forceinline__ Frag<bf16_t> rd_ks(const Tile16<bf16_t, HD>& T, int tp, int d) {
+  typedef __attribute__((address_space(3))) s16x4_t* lds_v4;
+  constexpr int pitch = Tile16<bf16_t, HD>::pitch;
+  const s16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4)(T.ks[d] + (2 * tp) * 16 * pitch));
+  const s16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4)(T.ks[d] + (2 * tp + 1) * 16 * pitch));
+  Frag<bf16_t> f;
+  f.v = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+  return f;
+}
+template <int HD> __device__ __forceinline__ Frag<float> rd_ks(const Tile16<float, HD>& T, int tp, int d) {
+  constexpr int pitch = Tile16<float, HD>::pitch;
+  Frag<float> f;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    f.v[j] = T.ks[d][((2 * tp) * 16 + j) * pitch];
+    f.v[j + 4] = T.ks[d][((2 * tp + 1) * 16 + j) * pitch];
+  }
+  return f;
+}
+
+
+// token of window position n = (y, x) — the roll(-shift) + window_partition index math (reference model.py:522-559), in
+// registers: no LDS token table (1 KB that decided between 2 and 3 workgroups per CU for the dQ kernel)
+struct W16Tok {
+  int base, y0, x0, Hp, Wp;
+  __device__ __forceinline__ W16Tok(const AttnArgs& p, int win) {
+    const int b = win / p.nw_per_img, w = win % p.nw_per_img;
+    base = b * p.Hp * p.Wp; y0 = (w / p.nwx) * 16 + p.shift; x0 = (w % p.nwx) * 16 + p.shift; Hp = p.Hp; Wp = p.Wp;
+  }
+  __device__ __forceinline__ int operator()(int n) const {
+    int y = y0 + (n >> 4), x = x0 + (n & 15);
+    if (y >= Hp) y -= Hp;
+    if (x >= Wp) x -= Wp;
+    return base + y * Wp + x;
+  }
+};
+
+// stage the window's rows of q/k/v/dO (column offset `col`) into an LDS tile, optionally L2-normalised (F.normalize, eps 1e-12)
+template <typename CT, int HD, bool NORM>
+__device__ __forceinline__ void w16_stage(CT* tile, const void* src, int ld, int col, const W16Tok& T, int tid) {
+  constexpr int CPR = ((HD + 31) / 32) * 4;
+#pragma unroll 2
+  for (int c = tid; c < W16::NP * CPR; c += 256) {
+    const int n = c / CPR, ch = c % CPR;
+    float v[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) v[j] = 0.f;
+    if (ch * 8 < HD) ld8(src, ct_traits<CT>::dtype, (size_t)T(n) * ld + col + ch * 8, v);
+    if (NORM) {
+      float ss = 0.f;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) ss += v[j] * v[j];
+#pragma unroll
+      for (int o = 1; o < CPR; o <<= 1) ss += __shfl_xor(ss, o, 64);
+      const float r = 1.0f / fmaxf(sqrtf(ss), 1e-12f);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) v[j] *= r;
+    }
+    store8_ct(tile + Tile16<CT, HD>::store_off(n, ch), v);
+  }
+}
 // accT[d][r]: gradient (times `mul`) wrt the NORMALISED row of token `tokn`, feature d*16 + (lane>>4)*4 + r.
 // y = x / max(|x|, eps):  dx = (g - y (y·g)) / |x|   (|x| >= eps),   dx = g / eps otherwise  (F.normalize, eps 1e-12).
 template <typename CT, int HD>
-__device__ __forceinline__ void normalize_bwd_store_t(const f32x4_t (&acc)[HD / 16], float mul, const void* src, void* dst, size_t off,
-                                                      int lane) {
+__device__ __forceinline__ void normalize_bwd_load(float (&x)[HD / 16][4], const void* src, size_t off, int lane) {
+#pragma unroll
+  for (int d = 0; d < HD / 16; ++d) ld4<CT>(src, off + d * 16 + (lane >> 4) * 4, x[d]);
+}
+template <typename CT, int HD>
+__device__ __forceinline__ void normalize_bwd_store_t(const f32x4_t (&acc)[HD / 16], float mul, const float (&x)[HD / 16][4], void* dst,
+                                                      size_t off, int lane) {
   constexpr int DT = HD / 16;
   const int g = lane >> 4;
-  float x[DT][4], ss = 0.f, dot = 0.f;
+  float ss = 0.f, dot = 0.f;
 #pragma unroll
   for (int d = 0; d < DT; ++d) {
-    ld4<CT>(src, off + d * 16 + g * 4, x[d]);
 #pragma unroll
     for (int r = 0; r < 4; ++r) ss += x[d][r] * x[d][r];
   }
@@ -119,25 +181,59 @@ __device__ __forceinline__ void normalize_bwd_store_t(const f32x4_t (&acc)[HD / 
   }
 }
 
+// B-operand fragments of ONE row per lane column read straight from HBM: lane (lc, g) takes features kk*32 + g*8 .. +7 of
+// the row at element offset `rowoff` (optionally L2-normalised over the whole row: two xor-shuffles)
+template <typename CT, int HD>
+__device__ __forceinline__ void row_f32(float (&v)[(HD + 31) / 32][8], const void* src, size_t rowoff, int lane) {
+  const int g = lane >> 4;
+#pragma unroll
+  for (int kk = 0; kk < (HD + 31) / 32; ++kk) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) v[kk][j] = 0.f;
+    if (kk * 32 + g * 8 < HD) ld8(src, ct_traits<CT>::dtype, rowoff + kk * 32 + g * 8, v[kk]);
+  }
+}
+template <typename CT, int HD>
+__device__ __forceinline__ void row_frag(Frag<CT> (&f)[(HD + 31) / 32], const void* src, size_t rowoff, bool normalize, int lane) {
+  constexpr int KS = (HD + 31) / 32;
+  float v[KS][8];
+  row_f32<CT, HD>(v, src, rowoff, lane);
+  float r = 1.f;
+  if (normalize) {
+    float ss = 0.f;
+#pragma unroll
+    for (int kk = 0; kk < KS; ++kk)
+#pragma unroll
+      for (int j = 0; j < 8; ++j) ss += v[kk][j] * v[kk][j];
+    ss += __shfl_xor(ss, 16, 64);
+    ss += __shfl_xor(ss, 32, 64);
+    r = 1.0f / fmaxf(sqrtf(ss), 1e-12f);
+  }
+#pragma unroll
+  for (int kk = 0; kk < KS; ++kk) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) v[kk][j] *= r;
+    f[kk] = frag_from_f32<CT>(v[kk]);
+  }
+}
+
 // ================================================================================================= forward
 template <typename CT, int HD, bool SHIFTED>
 __global__ __launch_bounds__(256, 2) void attn16_fwd_kernel(AttnArgs p) {
-  constexpr int NT = W16::NT, NP = W16::NP, KS = (HD + 31) / 32, DT = HD / 16, pitch = row_pitch<HD, CT>();
+  constexpr int NT = W16::NT, NP = W16::NP, KS = (HD + 31) / 32, DT = HD / 16, TE = Tile16<CT, HD>::elems;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   CT* Kn = (CT*)smem;
-  CT* Vs = Kn + NP * pitch;
-  float* tab2 = (float*)(Vs + NP * pitch);
-  int* tok = (int*)(tab2 + W16::TSP);
+  CT* Vs = Kn + TE;
+  float* tab2 = (float*)(Vs + TE);
 
   const int win = blockIdx.x, h = blockIdx.y;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int ld = 3 * p.C, g = lane >> 4, lc = lane & 15;
+  const W16Tok tokf(p, win);
 
-  for (int i = tid; i < NP; i += 256) tok[i] = win_token(p, win, i);
   for (int i = tid; i < W16::TS; i += 256) tab2[i] = p.bias_table[h * W16::TS + i] * kLog2e;
-  __syncthreads();
-  stage_rows<CT, HD, NP>(Kn, p.qkv, ld, p.C + h * HD, tok, NP, true, tid);
-  stage_rows<CT, HD, NP>(Vs, p.qkv, ld, 2 * p.C + h * HD, tok, NP, false, tid);
+  w16_stage<CT, HD, true>(Kn, p.qkv, ld, p.C + h * HD, tokf, tid);
+  w16_stage<CT, HD, false>(Vs, p.qkv, ld, 2 * p.C + h * HD, tokf, tid);
   __syncthreads();
 
   const float scale2 = __expf(fminf(p.logit_scale[h], 4.605170185988092f)) * kLog2e;  // exp(min(ls, ln 100)), HF:416
@@ -146,12 +242,14 @@ __global__ __launch_bounds__(256, 2) void attn16_fwd_kernel(AttnArgs p) {
   const float mlane = (lastcol && ((lc >= 8) != (g >= 2))) ? kMask2 : 0.f;
   // bias of (query (qy, qx = lc), key (ky = t, kx = 4g + r)) = tab[(qy - t + 15)*31 + lc - 4g - r + 15]
   const float* tabl = tab2 + (lc - 4 * g + 12);
-  const LaneBase<CT, HD> kb_(Kn, lane), vb_(Vs, lane);
+  const Tile16<CT, HD> kt(Kn, lane), vt(Vs, lane);
 
 #pragma nounroll
   for (int qb = wave; qb < 16; qb += 4) {
     Frag<CT> qf[KS];
-    load_rows_frag<CT, HD>(qf, p.qkv, ld, h * HD, tok, qb * 16, NP, true, lane);
+    const int q = qb * 16 + lc;
+    const int tokq = tokf(q);
+    row_frag<CT, HD>(qf, p.qkv, (size_t)tokq * ld + h * HD, true, lane);
     const float* tq = tabl + qb * 31;
 
     f32x4_t s[NT];
@@ -159,7 +257,7 @@ __global__ __launch_bounds__(256, 2) void attn16_fwd_kernel(AttnArgs p) {
     for (int t = 0; t < NT; ++t) {
       s[t] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-      for (int kk = 0; kk < KS; ++kk) mma16(s[t], rd_kc<HD>(kb_.kc, t, kk), qf[kk]);
+      for (int kk = 0; kk < KS; ++kk) mma16(s[t], rd_kc<HD>(kt, t, kk), qf[kk]);
       if ((t & 3) == 3) __builtin_amdgcn_sched_barrier(0);   // keep the scheduler from hoisting every tile's LDS reads
     }
     float m = -3.0e38f;
@@ -190,7 +288,6 @@ __global__ __launch_bounds__(256, 2) void attn16_fwd_kernel(AttnArgs p) {
     l += __shfl_xor(l, 16, 64);
     l += __shfl_xor(l, 32, 64);
     const float inv = 1.0f / l;
-    const int q = qb * 16 + lc;
     if (g == 0 && p.lse) p.lse[((size_t)win * p.heads + h) * NP + q] = (m + __log2f(l)) * kLn2;
 
     // O^T = V^T · P^T : A = V^T (transposing fragment read), B = P^T (the lane's 8 keys of query lc: already in order)
@@ -205,11 +302,11 @@ __global__ __launch_bounds__(256, 2) void attn16_fwd_kernel(AttnArgs p) {
       const Frag<CT> pf = frag_from_f32<CT>(pv);
 #pragma unroll
       for (int d = 0; d < DT; ++d)
-        mma16(o[d], rd_ks<HD>(vb_.ks, tp, d), pf);
+        mma16(o[d], rd_ks<HD>(vt, tp, d), pf);
       if ((tp & 1) == 1) __builtin_amdgcn_sched_barrier(0);
     }
     // o[d][r]: feature d*16 + 4g + r of query q
-    const size_t base = (size_t)tok[q] * p.C + h * HD + g * 4;
+    const size_t base = (size_t)tokq * p.C + h * HD + g * 4;
 #pragma unroll
     for (int d = 0; d < DT; ++d) {
       const float ov[4] = {o[d][0] * inv, o[d][1] * inv, o[d][2] * inv, o[d][3] * inv};
@@ -221,24 +318,22 @@ __global__ __launch_bounds__(256, 2) void attn16_fwd_kernel(AttnArgs p) {
 // ================================================================================================= backward: dQ, d table, d logit_scale
 template <typename CT, int HD, bool SHIFTED>
 __global__ __launch_bounds__(256, 2) void attn16_bwd_dq_kernel(AttnArgs p) {
-  constexpr int NT = W16::NT, NP = W16::NP, KS = (HD + 31) / 32, DT = HD / 16, pitch = row_pitch<HD, CT>();
+  constexpr int NT = W16::NT, NP = W16::NP, KS = (HD + 31) / 32, DT = HD / 16, TE = Tile16<CT, HD>::elems;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   CT* X = (CT*)smem;            // Kn
-  CT* Y = X + NP * pitch;       // V
-  float* tab2 = (float*)(Y + NP * pitch);
+  CT* Y = X + TE;               // V
+  float* tab2 = (float*)(Y + TE);
   double* dtab = (double*)(tab2 + W16::TSP);   // ds_add_f64 is full rate on gfx950, ds_add_f32 is not (see attention.hip)
-  int* tok = (int*)(dtab + W16::TSP);
-  float* red = (float*)(tok + NP);             // [4]
+  float* red = (float*)(dtab + W16::TSP);      // [4]
 
   const int win = blockIdx.x, h = blockIdx.y;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int ld = 3 * p.C, g = lane >> 4, lc = lane & 15;
+  const W16Tok tokf(p, win);
 
-  for (int i = tid; i < NP; i += 256) tok[i] = win_token(p, win, i);
   for (int i = tid; i < W16::TS; i += 256) { tab2[i] = p.bias_table[h * W16::TS + i] * kLog2e; dtab[i] = 0.0; }
-  __syncthreads();
-  stage_rows<CT, HD, NP>(X, p.qkv, ld, p.C + h * HD, tok, NP, true, tid);
-  stage_rows<CT, HD, NP>(Y, p.qkv, ld, 2 * p.C + h * HD, tok, NP, false, tid);
+  w16_stage<CT, HD, true>(X, p.qkv, ld, p.C + h * HD, tokf, tid);
+  w16_stage<CT, HD, false>(Y, p.qkv, ld, 2 * p.C + h * HD, tokf, tid);
   __syncthreads();
 
   const float scale = __expf(fminf(p.logit_scale[h], 4.605170185988092f));
@@ -248,7 +343,7 @@ __global__ __launch_bounds__(256, 2) void attn16_bwd_dq_kernel(AttnArgs p) {
   const float mlane = (lastcol && ((lc >= 8) != (g >= 2))) ? kMask2 : 0.f;
   const float* tabl = tab2 + (lc - 4 * g + 12);
   double* dtabl = dtab + (lc - 4 * g + 15);     // entry of (q = lc, key 4g): the lane's anti-diagonal sum lands here
-  const LaneBase<CT, HD> xb(X, lane), yb(Y, lane);
+  const Tile16<CT, HD> xb(X, lane), yb(Y, lane);
   // d logit_scale = Σ_qk dS·cos·scale with Σ_k dS = 0 per query: a heavily cancelling sum.  dS uses delta from the
   // stored (rounded) forward output; the row sums D = Σ_k P·dP and B = Σ_k P·cos taken here in fp32 put the exact
   // cancellation back:  Σ_k P (dP - D) cos = Σ_k dS·cos + (delta - D)·B.
@@ -257,14 +352,15 @@ __global__ __launch_bounds__(256, 2) void attn16_bwd_dq_kernel(AttnArgs p) {
 #pragma nounroll
   for (int qb = wave; qb < 16; qb += 4) {
     const int q = qb * 16 + lc;
+    const int tokq = tokf(q);
     float accD = 0.f, accB = 0.f;
     Frag<CT> qf[KS], gf[KS];
-    load_rows_frag<CT, HD>(qf, p.qkv, ld, h * HD, tok, qb * 16, NP, true, lane);
+    row_frag<CT, HD>(qf, p.qkv, (size_t)tokq * ld + h * HD, true, lane);
     float delta = 0.f;
     {
       float dov[KS][8], ov[KS][8];
-      load_rows_f32<CT, HD>(dov, p.dout, p.C, h * HD, tok, qb * 16, NP, lane);
-      load_rows_f32<CT, HD>(ov, p.ofwd, p.C, h * HD, tok, qb * 16, NP, lane);
+      row_f32<CT, HD>(dov, p.dout, (size_t)tokq * p.C + h * HD, lane);
+      row_f32<CT, HD>(ov, p.ofwd, (size_t)tokq * p.C + h * HD, lane);
 #pragma unroll
       for (int kk = 0; kk < KS; ++kk) {
 #pragma unroll
@@ -275,6 +371,9 @@ __global__ __launch_bounds__(256, 2) void attn16_bwd_dq_kernel(AttnArgs p) {
       delta += __shfl_xor(delta, 32, 64);
     }
     const float nlse2 = -p.lse[((size_t)win * p.heads + h) * NP + q] * kLog2e;
+    const size_t off = (size_t)tokq * ld + h * HD;
+    float xq[DT][4];   // the un-normalised q row again, in the layout of the transposed result: loaded here, used by the epilogue
+    normalize_bwd_load<CT, HD>(xq, p.qkv, off, lane);
     const float* tq = tabl + qb * 31;
     double* dq_tab = dtabl + qb * 31;
 
@@ -291,8 +390,8 @@ __global__ __launch_bounds__(256, 2) void attn16_bwd_dq_kernel(AttnArgs p) {
         f32x4_t s = {0.f, 0.f, 0.f, 0.f}, dp = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int kk = 0; kk < KS; ++kk) {
-          mma16(s, rd_kc<HD>(xb.kc, t, kk), qf[kk]);
-          mma16(dp, rd_kc<HD>(yb.kc, t, kk), gf[kk]);
+          mma16(s, rd_kc<HD>(xb, t, kk), qf[kk]);
+          mma16(dp, rd_kc<HD>(yb, t, kk), gf[kk]);
         }
         float madd = nlse2;
         if (SHIFTED) madd += (lastrow && ((qb >= 8) != (t >= 8))) ? kMask2 : mlane;
@@ -306,6 +405,9 @@ __global__ __launch_bounds__(256, 2) void attn16_bwd_dq_kernel(AttnArgs p) {
           accB = fmaf(pr, s[r], accB);
           dls = fmaf(ds[r], s[r], dls);
         }
+        // pin the three running sums here: left alone, the scheduler sinks all 192 of a query block's multiply-adds to the
+        // block's end and keeps their operands alive (256 VGPRs + scratch instead of ~90)
+        asm volatile("" : "+v"(accD), "+v"(accB), "+v"(dls));
         // the 16x16 block of dS feeds the 31 entries (dx = qx - kx) of table row (qy - ky): DPP row shifts fold the
         // lane's four keys along the anti-diagonal, then one LDS atomic per lane (+ 3 lanes for the wrapped tail)
         const float a = ds[0] + dpp_row<0x101>(ds[1]) + dpp_row<0x102>(ds[2]) + dpp_row<0x103>(ds[3]);
@@ -316,14 +418,13 @@ __global__ __launch_bounds__(256, 2) void attn16_bwd_dq_kernel(AttnArgs p) {
       const Frag<CT> df = frag_from_f32<CT>(ds8);
 #pragma unroll
       for (int d = 0; d < DT; ++d)   // dQn^T += Kn^T · dS^T
-        mma16(dq[d], rd_ks<HD>(xb.ks, tp, d), df);
+        mma16(dq[d], rd_ks<HD>(xb, tp, d), df);
       __builtin_amdgcn_sched_barrier(0);   // one tile pair at a time: unrolled for the immediates, not for hoisting
     }
     accD += __shfl_xor(accD, 16, 64); accD += __shfl_xor(accD, 32, 64);
     accB += __shfl_xor(accB, 16, 64); accB += __shfl_xor(accB, 32, 64);
     if (g == 0) dls = fmaf(delta - accD, accB, dls);
-    const size_t off = (size_t)tok[q] * ld + h * HD;
-    normalize_bwd_store_t<CT, HD>(dq, scale, p.qkv, p.out, off, lane);
+    normalize_bwd_store_t<CT, HD>(dq, scale, xq, p.out, off, lane);
   }
   // d/dls [cos * exp(ls)] = cos * scale  (0 when clamped at ln 100, HF:416)
   dls = wave_sum(dls);
@@ -336,36 +437,34 @@ __global__ __launch_bounds__(256, 2) void attn16_bwd_dq_kernel(AttnArgs p) {
 // ================================================================================================= backward: dK, dV
 template <typename CT, int HD, bool SHIFTED>
 __global__ __launch_bounds__(256, 2) void attn16_bwd_dkv_kernel(AttnArgs p) {
-  constexpr int NT = W16::NT, NP = W16::NP, KS = (HD + 31) / 32, DT = HD / 16, pitch = row_pitch<HD, CT>();
+  constexpr int NT = W16::NT, NP = W16::NP, KS = (HD + 31) / 32, DT = HD / 16, TE = Tile16<CT, HD>::elems;
   constexpr int CPR = KS * 4;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   CT* X = (CT*)smem;            // Qn
-  CT* Y = X + NP * pitch;       // dO
-  float* tab2 = (float*)(Y + NP * pitch);
+  CT* Y = X + TE;               // dO
+  float* tab2 = (float*)(Y + TE);
   float* nlse2 = tab2 + W16::TSP;   // [NP]  -lse * log2 e
   float* delta = nlse2 + NP;        // [NP]
-  int* tok = (int*)(delta + NP);
 
   const int win = blockIdx.x, h = blockIdx.y;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int ld = 3 * p.C, g = lane >> 4, lc = lane & 15;
 
-  for (int i = tid; i < NP; i += 256) {
-    tok[i] = win_token(p, win, i);
-    nlse2[i] = -p.lse[((size_t)win * p.heads + h) * NP + i] * kLog2e;
-  }
+  const W16Tok tokf(p, win);
+  for (int i = tid; i < NP; i += 256) nlse2[i] = -p.lse[((size_t)win * p.heads + h) * NP + i] * kLog2e;
   for (int i = tid; i < W16::TS; i += 256) tab2[i] = p.bias_table[h * W16::TS + i] * kLog2e;
-  __syncthreads();
-  stage_rows<CT, HD, NP>(X, p.qkv, ld, h * HD, tok, NP, true, tid);
+  w16_stage<CT, HD, true>(X, p.qkv, ld, h * HD, tokf, tid);
   // dO -> LDS and delta[n] = Σ_d dO[n][d]·O[n][d] in the same pass (CPR lanes per row)
+#pragma unroll
   for (int c = tid; c < NP * CPR; c += 256) {
     const int n = c / CPR, d8 = (c % CPR) * 8;
     float v[8], o[8];
 #pragma unroll
     for (int j = 0; j < 8; ++j) { v[j] = 0.f; o[j] = 0.f; }
     if (d8 < HD) {
-      ld8(p.dout, ct_traits<CT>::dtype, (size_t)tok[n] * p.C + h * HD + d8, v);
-      ld8(p.ofwd, ct_traits<CT>::dtype, (size_t)tok[n] * p.C + h * HD + d8, o);
+      const size_t ro = (size_t)tokf(n) * p.C + h * HD + d8;
+      ld8(p.dout, ct_traits<CT>::dtype, ro, v);
+      ld8(p.ofwd, ct_traits<CT>::dtype, ro, o);
     }
     float dot = 0.f;
 #pragma unroll
@@ -373,7 +472,7 @@ __global__ __launch_bounds__(256, 2) void attn16_bwd_dkv_kernel(AttnArgs p) {
 #pragma unroll
     for (int of = 1; of < CPR; of <<= 1) dot += __shfl_xor(dot, of, 64);
     if ((c % CPR) == 0) delta[n] = dot;
-    store8_ct(Y + n * pitch + d8, v);
+    store8_ct(Y + Tile16<CT, HD>::store_off(n, c % CPR), v);
   }
   __syncthreads();
 
@@ -384,17 +483,20 @@ __global__ __launch_bounds__(256, 2) void attn16_bwd_dkv_kernel(AttnArgs p) {
   const float mlane = (lastcol && ((lc >= 8) != (g >= 2))) ? kMask2 : 0.f;
   // bias of (query (qy = t, qx = 4g + r), key (ky, kx = lc)) = tab[(t - ky + 15)*31 + 4g + r - lc + 15]
   const float* tabl = tab2 + (4 * g - lc + 15);
-  const LaneBase<CT, HD> xb(X, lane), yb(Y, lane);
+  const Tile16<CT, HD> xb(X, lane), yb(Y, lane);
   const float* nlg = nlse2 + g * 4;
   const float* dlg = delta + g * 4;
 
 #pragma nounroll
   for (int kb = wave; kb < 16; kb += 4) {
-    const int key = kb * 16 + lc;
+    const int tokk = tokf(kb * 16 + lc);
     Frag<CT> kf[KS], vf[KS];
-    load_rows_frag<CT, HD>(kf, p.qkv, ld, p.C + h * HD, tok, kb * 16, NP, true, lane);
-    load_rows_frag<CT, HD>(vf, p.qkv, ld, 2 * p.C + h * HD, tok, kb * 16, NP, false, lane);
+    row_frag<CT, HD>(kf, p.qkv, (size_t)tokk * ld + p.C + h * HD, true, lane);
+    row_frag<CT, HD>(vf, p.qkv, (size_t)tokk * ld + 2 * p.C + h * HD, false, lane);
     const float* tk = tabl + (15 - kb) * 31;
+    const size_t off = (size_t)tokk * ld + h * HD;
+    float xk[DT][4];
+    normalize_bwd_load<CT, HD>(xk, (const CT*)p.qkv + p.C, off, lane);
 
     f32x4_t dv[DT], dk[DT];
 #pragma unroll
@@ -409,8 +511,8 @@ __global__ __launch_bounds__(256, 2) void attn16_bwd_dkv_kernel(AttnArgs p) {
         f32x4_t s = {0.f, 0.f, 0.f, 0.f}, dp = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int kk = 0; kk < KS; ++kk) {
-          mma16(s, rd_kc<HD>(xb.kc, t, kk), kf[kk]);   // rows = queries 4g + r of row t, col = key
-          mma16(dp, rd_kc<HD>(yb.kc, t, kk), vf[kk]);
+          mma16(s, rd_kc<HD>(xb, t, kk), kf[kk]);   // rows = queries 4g + r of row t, col = key
+          mma16(dp, rd_kc<HD>(yb, t, kk), vf[kk]);
         }
         const float4 nl = *(const float4*)&nlg[t * 16];
         const float4 qd = *(const float4*)&dlg[t * 16];
@@ -427,29 +529,28 @@ __global__ __launch_bounds__(256, 2) void attn16_bwd_dkv_kernel(AttnArgs p) {
       const Frag<CT> pf = frag_from_f32<CT>(pf8), df = frag_from_f32<CT>(df8);
 #pragma unroll
       for (int d = 0; d < DT; ++d) {
-        mma16(dv[d], rd_ks<HD>(yb.ks, tp, d), pf);   // dV^T  += dO^T · P
-        mma16(dk[d], rd_ks<HD>(xb.ks, tp, d), df);   // dKn^T += Qn^T · dS
+        mma16(dv[d], rd_ks<HD>(yb, tp, d), pf);   // dV^T  += dO^T · P
+        mma16(dk[d], rd_ks<HD>(xb, tp, d), df);   // dKn^T += Qn^T · dS
       }
       __builtin_amdgcn_sched_barrier(0);
     }
-    const size_t off = (size_t)tok[key] * ld + h * HD;
 #pragma unroll
     for (int d = 0; d < DT; ++d) {
       const float o[4] = {dv[d][0], dv[d][1], dv[d][2], dv[d][3]};
       st4<CT>(p.out, off + 2 * p.C + d * 16 + g * 4, o);
     }
-    normalize_bwd_store_t<CT, HD>(dk, scale, (const CT*)p.qkv + p.C, (CT*)p.out + p.C, off, lane);
+    normalize_bwd_store_t<CT, HD>(dk, scale, xk, (CT*)p.out + p.C, off, lane);
   }
 }
 
 // ================================================================================================= host side
 template <typename CT, int HD, bool SHIFTED>
 static int launch_w16(const AttnArgs& a, int nwin, bool bwd, hipStream_t s) {
-  constexpr int NP = W16::NP, pitch = row_pitch<HD, CT>();
-  const size_t tiles = 2 * NP * pitch * sizeof(CT);
-  const size_t sh_fwd = tiles + W16::TSP * sizeof(float) + NP * sizeof(int);
-  const size_t sh_dq = tiles + W16::TSP * (sizeof(float) + sizeof(double)) + NP * sizeof(int) + 4 * sizeof(float);
-  const size_t sh_dkv = tiles + (W16::TSP + 2 * NP) * sizeof(float) + NP * sizeof(int);
+  constexpr int NP = W16::NP;
+  const size_t tiles = 2 * Tile16<CT, HD>::elems * sizeof(CT);
+  const size_t sh_fwd = tiles + W16::TSP * sizeof(float);
+  const size_t sh_dq = tiles + W16::TSP * (sizeof(float) + sizeof(double)) + 4 * sizeof(float);
+  const size_t sh_dkv = tiles + (W16::TSP + 2 * NP) * sizeof(float);
   dim3 grid(nwin, a.heads), block(256);
   if (!bwd) {
     if (sh_fwd > 64 * 1024) (void)hipFuncSetAttribute((const void*)attn16_fwd_kernel<CT, HD, SHIFTED>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh_fwd);
@@ -457,6 +558,13 @@ static int launch_w16(const AttnArgs& a, int nwin, bool bwd, hipStream_t s) {
   } else {
     if (sh_dq > 64 * 1024) (void)hipFuncSetAttribute((const void*)attn16_bwd_dq_kernel<CT, HD, SHIFTED>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh_dq);
     if (sh_dkv > 64 * 1024) (void)hipFuncSetAttribute((const void*)attn16_bwd_dkv_kernel<CT, HD, SHIFTED>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh_dkv);
+    if (getenv("SCOT_ATTN_OCC")) {
+      int n1 = 0, n2 = 0, n3 = 0;
+      (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&n1, attn16_bwd_dq_kernel<CT, HD, SHIFTED>, 256, sh_dq);
+      (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&n2, attn16_bwd_dkv_kernel<CT, HD, SHIFTED>, 256, sh_dkv);
+      (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&n3, attn16_fwd_kernel<CT, HD, SHIFTED>, 256, sh_fwd);
+      fprintf(stderr, "[w16 occupancy] dq %d (lds %zu)  dkv %d (lds %zu)  fwd %d (lds %zu)\n", n1, sh_dq, n2, sh_dkv, n3, sh_fwd);
+    }
     hipLaunchKernelGGL((attn16_bwd_dq_kernel<CT, HD, SHIFTED>), grid, block, sh_dq, s, a);
     hipLaunchKernelGGL((attn16_bwd_dkv_kernel<CT, HD, SHIFTED>), grid, block, sh_dkv, s, a);
   }

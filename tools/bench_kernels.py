@@ -92,6 +92,23 @@ def main():
         print(f"attn_fwd Hp={Hp} C={C} ws={ws}: {us:7.1f} us  {fl/us/1e6:6.1f} TF/s")
         dq = torch.empty_like(qkv)
         dt_, dl = torch.zeros_like(tab), torch.zeros(heads, device="cuda")
+        if os.environ.get("BK_COLD", "0") == "1":
+            nb = 10
+            sets = [(qkv.clone(), o.clone(), torch.randn_like(o), torch.empty_like(qkv)) for _ in range(nb)]
+            it = [0]
+
+            def run_f():
+                a, b, _, _ = sets[it[0] % nb]
+                it[0] += 1
+                ops.window_attn_fwd(ops.BF16, a, b, lse, tab, ls, B, Hp, Hp, C, heads, ws, shift)
+
+            def run_b():
+                a, b, c, d = sets[it[0] % nb]
+                it[0] += 1
+                ops.window_attn_bwd(ops.BF16, a, b, c, lse, tab, ls, d, dt_, dl, B, Hp, Hp, C, heads, ws, shift)
+            usf, usb = timeit(run_f, reps=30), timeit(run_b, reps=30)
+            print(f"attn cold Hp={Hp} C={C} ws={ws}: fwd {usf:7.1f} us  bwd {usb:7.1f} us")
+            continue
         us = timeit(lambda: ops.window_attn_bwd(ops.BF16, qkv, o, o, lse, tab, ls, dq, dt_, dl, B, Hp, Hp, C, heads, ws, shift))
         print(f"attn_bwd Hp={Hp} C={C} ws={ws}: {us:7.1f} us  {2.5*fl/us/1e6:6.1f} TF/s")
     # dwconv
