@@ -46,7 +46,8 @@ int scot_gemm(int layout, int compute, int M, int N, int K,
  * when A = dY, taken from the dY tile already staged in LDS.
  * workspace (optional, 32-byte aligned device scratch owned by the caller): TN splits K over workgroups and writes
  * partial tiles there, reduced by one extra pass; without it TN falls back to fp32 atomics.
- * C2 (optional, NT/NN): the epilogue stores gelu(v) to C and gelu'(v) to C2 (same dtype/ld) — the fc1 form, so that no
+ * C2 (optional, NT/NN): the epilogue stores gelu(v) to C and gelu'(v) to C2 (same dtype/ld; C2 == C: gelu(v) only, the
+ * inference form) — the fc1 form, so that no
  * later kernel re-evaluates erf; aux_mul=1: `aux` already holds that derivative and is multiplied in as is. */
 
 /* Shifted-window cosine attention, HF:389-455 + ref:522-559 (roll/partition/mask folded into indexing).

@@ -185,7 +185,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs p) {
         if (p.resid) v += ld1(p.resid, p.res_dt, (size_t)row * p.ldres + col);
         const size_t ci = (size_t)row * p.ldc + col;
         if (p.atomic) atomicAdd((float*)p.C + ci, v);
-        else if (p.C2) { st1(p.C, p.c_dt, ci, gelu_f(v)); st1(p.C2, p.c_dt, ci, gelu_grad_f(v)); }
+        else if (p.C2) { st1(p.C, p.c_dt, ci, gelu_f(v)); if (p.C2 != p.C) st1(p.C2, p.c_dt, ci, gelu_grad_f(v)); }
         else st1(p.C, p.c_dt, ci, v);
       }
     }

@@ -87,7 +87,7 @@ __device__ __forceinline__ uint4 gelu_chunk(uint4 u, float) {
 }
 
 template <typename CT, int R, bool KC, int BKT, int NCH>
-__device__ __forceinline__ void fstore(CT* tile, const uint4 (&st)[NCH], int k0, int kend, int tid, bool gelu) {
+__device__ __forceinline__ void fstore(CT* tile, const uint4 (&st)[NCH], int k0, int kend, int tid) {
   using T = FTile<CT, R, KC, BKT>;
   constexpr int EPC = T::EPC, BK = T::BK;
 #pragma unroll
@@ -104,7 +104,6 @@ __device__ __forceinline__ void fstore(CT* tile, const uint4 (&st)[NCH], int k0,
       k = k0 + c / CPR;
       off = (c / CPR) * T::pitch + (c % CPR) * EPC;
     }
-    if (gelu) v = gelu_chunk(v, CT());
     if (k >= kend) v = make_uint4(0, 0, 0, 0);   // K tail (K is a multiple of EPC in this kernel)
     if (T::exact || c < T::nchunks) *(uint4*)(tile + off) = v;
   }
@@ -167,14 +166,12 @@ __global__ __launch_bounds__(256) void gemm_fast_kernel(FastArgs p) {
   // and each iteration used to stall ~1000 cycles on the HBM round trip of a load issued only one iteration earlier.
   uint4 ra[NSET][TA::per_thread], rb[NSET][TB::per_thread];
 #pragma unroll
-  for (int u = 0; u < NSET; ++u) {
-    if (u < nk) {
-      fload<CT, BM, A_KC, BKT>(ra[u], A, p.lda, m0, p.M, kbeg + u * BK, kend, tid);
-      fload<CT, BN, B_KC, BKT>(rb[u], B, p.ldb, n0, p.N, kbeg + u * BK, kend, tid);
-    }
+  for (int u = 0; u < NSET; ++u) {   // unconditional: fload clamps its addresses, fstore zero-fills tiles past kend
+    fload<CT, BM, A_KC, BKT>(ra[u], A, p.lda, m0, p.M, kbeg + u * BK, kend, tid);
+    fload<CT, BN, B_KC, BKT>(rb[u], B, p.ldb, n0, p.N, kbeg + u * BK, kend, tid);
   }
-  fstore<CT, BM, A_KC, BKT>(lds, ra[0], kbeg, kend, tid, p.a_gelu != 0);
-  fstore<CT, BN, B_KC, BKT>(lds + TA::elems, rb[0], kbeg, kend, tid, p.b_gelu != 0);
+  fstore<CT, BM, A_KC, BKT>(lds, ra[0], kbeg, kend, tid);
+  fstore<CT, BN, B_KC, BKT>(lds + TA::elems, rb[0], kbeg, kend, tid);
   __syncthreads();
 
   auto compute = [&](const CT* As, const CT* Bs) {
@@ -204,22 +201,22 @@ __global__ __launch_bounds__(256) void gemm_fast_kernel(FastArgs p) {
     }
   };
 
-  for (int t = 0; t < nk; t += NSET) {
+  // Every iteration issues its loads, computes and stores UNCONDITIONALLY (loads past the end re-read clamped addresses,
+  // their tiles are zero-filled by fstore and add nothing): with `if (tile exists)` around the loads the compiler cannot count
+  // the loads in flight and falls back to s_waitcnt vmcnt(0) before every LDS store — i.e. no prefetch at all.  The trip
+  // count is rounded up to a multiple of NSET for the same reason.
+  const int nk_pad = (nk + NSET - 1) / NSET * NSET;
+  for (int t = 0; t < nk_pad; t += NSET) {
 #pragma unroll
     for (int u = 0; u < NSET; ++u) {
       const int tt = t + u;
-      if (tt >= nk) break;
       // set u held tile tt (already in LDS buffer u&1): refill it with tile tt+NSET
-      if (tt + NSET < nk) {
-        fload<CT, BM, A_KC, BKT>(ra[u], A, p.lda, m0, p.M, kbeg + (tt + NSET) * BK, kend, tid);
-        fload<CT, BN, B_KC, BKT>(rb[u], B, p.ldb, n0, p.N, kbeg + (tt + NSET) * BK, kend, tid);
-      }
+      fload<CT, BM, A_KC, BKT>(ra[u], A, p.lda, m0, p.M, kbeg + (tt + NSET) * BK, kend, tid);
+      fload<CT, BN, B_KC, BKT>(rb[u], B, p.ldb, n0, p.N, kbeg + (tt + NSET) * BK, kend, tid);
       compute(lds + (u & 1) * STAGE, lds + (u & 1) * STAGE + TA::elems);
-      if (tt + 1 < nk) {
-        CT* nb = lds + ((u + 1) & 1) * STAGE;
-        fstore<CT, BM, A_KC, BKT>(nb, ra[(u + 1) % NSET], kbeg + (tt + 1) * BK, kend, tid, p.a_gelu != 0);
-        fstore<CT, BN, B_KC, BKT>(nb + TA::elems, rb[(u + 1) % NSET], kbeg + (tt + 1) * BK, kend, tid, p.b_gelu != 0);
-      }
+      CT* nb = lds + ((u + 1) & 1) * STAGE;
+      fstore<CT, BM, A_KC, BKT>(nb, ra[(u + 1) % NSET], kbeg + (tt + 1) * BK, kend, tid);
+      fstore<CT, BN, B_KC, BKT>(nb + TA::elems, rb[(u + 1) % NSET], kbeg + (tt + 1) * BK, kend, tid);
       __syncthreads();
     }
   }
@@ -298,7 +295,7 @@ __global__ __launch_bounds__(256) void gemm_fast_kernel(FastArgs p) {
 #pragma unroll
         for (int j = 0; j < 8; ++j) { float cdf, e; gelu_terms(v[j], cdf, e); gv[j] = v[j] * cdf; gd[j] = cdf + v[j] * 0.3989422804014327f * e; }
         st8(p.C, p.c_dt, ci, gv);
-        st8(p.C2, p.c_dt, ci, gd);
+        if (p.C2 != p.C) st8(p.C2, p.c_dt, ci, gd);
       } else {
         st8(p.C, p.c_dt, ci, v);
       }
@@ -388,8 +385,8 @@ __global__ __launch_bounds__(256) void gemm_persist_kernel(FastArgs p) {
 #pragma unroll
       for (int j = 0; j < NI; ++j) acc[i][j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
 
-    fstore<CT, BM, true, FT<CT>::BK>(As0, ra0, 0, K, tid, p.a_gelu != 0);
-    if (loadB) fstore<CT, BN, B_KC, FT<CT>::BK>(Bs0, rb0, 0, K, tid, p.b_gelu != 0);
+    fstore<CT, BM, true, FT<CT>::BK>(As0, ra0, 0, K, tid);
+    if (loadB) fstore<CT, BN, B_KC, FT<CT>::BK>(Bs0, rb0, 0, K, tid);
     __syncthreads();
 
     auto compute = [&](const CT* As, const CT* Bs) {
@@ -418,8 +415,8 @@ __global__ __launch_bounds__(256) void gemm_persist_kernel(FastArgs p) {
       }
       compute(As0, Bs0);
       if (t + 1 < nk) {
-        fstore<CT, BM, true, FT<CT>::BK>(As1, ra1, (t + 1) * BK, K, tid, p.a_gelu != 0);
-        if (loadB) fstore<CT, BN, B_KC, FT<CT>::BK>(Bs1, rb1, (t + 1) * BK, K, tid, p.b_gelu != 0);
+        fstore<CT, BM, true, FT<CT>::BK>(As1, ra1, (t + 1) * BK, K, tid);
+        if (loadB) fstore<CT, BN, B_KC, FT<CT>::BK>(Bs1, rb1, (t + 1) * BK, K, tid);
       }
       __syncthreads();
       if (t + 1 >= nk) break;
@@ -429,8 +426,8 @@ __global__ __launch_bounds__(256) void gemm_persist_kernel(FastArgs p) {
       }
       compute(As1, Bs1);
       if (t + 2 < nk) {
-        fstore<CT, BM, true, FT<CT>::BK>(As0, ra0, (t + 2) * BK, K, tid, p.a_gelu != 0);
-        if (loadB) fstore<CT, BN, B_KC, FT<CT>::BK>(Bs0, rb0, (t + 2) * BK, K, tid, p.b_gelu != 0);
+        fstore<CT, BM, true, FT<CT>::BK>(As0, ra0, (t + 2) * BK, K, tid);
+        if (loadB) fstore<CT, BN, B_KC, FT<CT>::BK>(Bs0, rb0, (t + 2) * BK, K, tid);
       }
       __syncthreads();
     }
@@ -483,7 +480,7 @@ __global__ __launch_bounds__(256) void gemm_persist_kernel(FastArgs p) {
 #pragma unroll
           for (int j = 0; j < 8; ++j) { float cdf, e; gelu_terms(v[j], cdf, e); gv[j] = v[j] * cdf; gd[j] = cdf + v[j] * 0.3989422804014327f * e; }
           st8(p.C, p.c_dt, (size_t)grow * p.ldc + col, gv);
-          st8(p.C2, p.c_dt, (size_t)grow * p.ldc + col, gd);
+          if (p.C2 != p.C) st8(p.C2, p.c_dt, (size_t)grow * p.ldc + col, gd);
         } else {
           st8(p.C, p.c_dt, (size_t)grow * p.ldc + col, v);
         }
@@ -591,7 +588,7 @@ __global__ __launch_bounds__(256) void splitk_epilogue_kernel(FastArgs p, int ns
 #pragma unroll
       for (int j = 0; j < 8; ++j) { float cdf, ee; gelu_terms(v[j], cdf, ee); gv[j] = v[j] * cdf; gd[j] = cdf + v[j] * 0.3989422804014327f * ee; }
       st8(p.C, p.c_dt, ci, gv);
-      st8(p.C2, p.c_dt, ci, gd);
+      if (p.C2 != p.C) st8(p.C2, p.c_dt, ci, gd);
     } else {
       st8(p.C, p.c_dt, ci, v);
     }
@@ -667,6 +664,7 @@ int scot_gemm_fast(int layout, int compute, int M, int N, int K, const void* A, 
   if (xcd < 0) { const char* e = getenv("SCOT_GEMM_XCD"); xcd = e ? atoi(e) : 1; }
   a.xcd_swizzle = xcd;
   if (C2 && ((((uintptr_t)C2) & 15) != 0 || layout == LAYOUT_TN)) return SCOT_ERR_UNSUPPORTED;
+  if (a_gelu || b_gelu) return SCOT_ERR_UNSUPPORTED;   // GELU-on-load is the general kernel's (the engine stores GELU(u) from the fc1 epilogue)
   int bk = compute == SCOT_BF16 ? 64 : 32;
   int nsplit = 1;
   // tile choice: SCOT_GEMM_TILE[_NT|_NN|_TN] = 0..3 forces a shape (tuning), otherwise the per-layout policy below

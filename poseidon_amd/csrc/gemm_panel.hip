@@ -152,7 +152,7 @@ __global__ __launch_bounds__(256, 2) void gemm_panel_kernel(PanelArgs p) {
 #pragma unroll
             for (int j = 0; j < 8; ++j) { float cdf, e; gelu_terms(v[j], cdf, e); gv[j] = v[j] * cdf; gd[j] = cdf + v[j] * 0.3989422804014327f * e; }
             st8(p.C, p.c_dt, ci, gv);
-            st8(p.C2, p.c_dt, ci, gd);
+            if (p.C2 != p.C) st8(p.C2, p.c_dt, ci, gd);
           } else {
             st8(p.C, p.c_dt, ci, v);
           }

@@ -412,10 +412,9 @@ class ScOTEngine:
         u = self.new(B * L, hid, dtype=self.adt)
         gp = self.new(B * L, hid, dtype=self.adt) if train else None
         ops.linear_fwd(cm, h16, self.W(pre + ".intermediate.dense.weight"), u, bias=self.P(pre + ".intermediate.dense.bias"),
-                       gelu_deriv_out=gp, a_gelu=False)
+                       gelu_deriv_out=gp if train else u)     # eval: GELU(u) only (`gelu_deriv_out is out`)
         y2 = self.new(B * L, C)
-        ops.linear_fwd(cm, u, self.W(pre + ".output.dense.weight"), y2, bias=self.P(pre + ".output.dense.bias"),
-                       a_gelu=not train)
+        ops.linear_fwd(cm, u, self.W(pre + ".output.dense.weight"), y2, bias=self.P(pre + ".output.dense.bias"))
         out, out16, st2 = self.norm_fwd(pre + ".layernorm_after", y2, h, L, C, cfg.layer_norm_eps, time, need_stats=train, copy=True)
         rec = None
         if train:
@@ -536,9 +535,11 @@ class ScOTEngine:
         n, _, stats = self.norm_fwd(pre + ".norm", dw, None, L, C, self.cfg.layer_norm_eps, time, out_dtype=self.adt, need_stats=train)
         u = self.new(B * L, 4 * C, dtype=self.adt)
         gp = self.new(B * L, 4 * C, dtype=self.adt) if train else None
-        ops.linear_fwd(self.compute, n, self.W(pre + ".pwconv1.weight"), u, bias=self.P(pre + ".pwconv1.bias"), gelu_deriv_out=gp)
+        # the epilogue stores GELU(v) (and GELU'(v) when training; `gelu_deriv_out is out` = value only)
+        ops.linear_fwd(self.compute, n, self.W(pre + ".pwconv1.weight"), u, bias=self.P(pre + ".pwconv1.bias"),
+                       gelu_deriv_out=gp if train else u)
         y2 = self.new(B * L, C)
-        ops.linear_fwd(self.compute, u, self.W(pre + ".pwconv2.weight"), y2, bias=self.P(pre + ".pwconv2.bias"), a_gelu=not train)
+        ops.linear_fwd(self.compute, u, self.W(pre + ".pwconv2.weight"), y2, bias=self.P(pre + ".pwconv2.bias"))
         out = self.new(B * L, C)
         ops.scale_residual(y2, self.P(pre + ".weight"), s, out, B * L, C)
         return out, (dict(s=s, dw=dw, stats=stats, n=n, u=u, gp=gp, y2=y2) if train else None)

@@ -53,7 +53,7 @@ def main():
     ops.L()
     B = 64
     only = sys.argv[1] if len(sys.argv) > 1 else ""
-    for s, (L, C) in ([(0, (1024, 96))] if only == "gemm0" else [(1, (256, 192))] if only == "gemm1" else [] if only else list(enumerate([(1024, 96), (256, 192), (64, 384), (16, 768)]))):
+    for s, (L, C) in ([(0, (1024, 96))] if only == "gemm0" else [(1, (256, 192))] if only == "gemm1" else [(2, (64, 384))] if only == "gemm2" else [(3, (16, 768))] if only == "gemm3" else [] if only else list(enumerate([(1024, 96), (256, 192), (64, 384), (16, 768)]))):
         M = B * L
         gemm_case(ops.NT, M, 3 * C, C, tag=f"qkv s{s}")
         gemm_case(ops.NT, M, C, C, out=torch.float32, tag=f"proj s{s}")
