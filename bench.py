@@ -42,6 +42,10 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=20.0)
     ap.add_argument("--wire", default="bf16", choices=["bf16", "fp32"], help="gradient all-reduce wire format (N>1)")
+    ap.add_argument("--dp", default="auto", choices=["auto", "overlap", "after"],
+                    help="N>1: all-reduce each gradient range from inside the backward as soon as it is final (RCCL on a side "
+                         "stream, eager launches), or one chunked all-reduce after the step (works with hipGraph replay); "
+                         "auto: time both in the warm-up, keep the faster")
     ap.add_argument("--_cpu-worker", dest="cpu_worker", action="store_true", help=argparse.SUPPRESS)
     return ap.parse_args()
 
@@ -176,7 +180,7 @@ def main():
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
 
     from poseidon_amd.config import preset
-    from poseidon_amd.dp import GradAllReducer
+    from poseidon_amd.dp import GradAllReducer, OverlappedGradAllReducer
     from scOT.model import ScOT
 
     ch = a.channels
@@ -201,7 +205,9 @@ def main():
     tt = torch.randint(0, 8, (B,), device="cuda").float() / 10.0
     kw = dict(pixel_values=pv, time=tt, labels=lab)
 
-    reducer = GradAllReducer(model, dist, wire=a.wire) if dist is not None else None
+    after = GradAllReducer(model, dist, wire=a.wire) if dist is not None else None
+    overlapped = OverlappedGradAllReducer(model, dist, wire=a.wire) if (dist is not None and a.dp != "after") else None
+    exchange = [None if dist is None else ("after" if a.dp != "overlap" else "overlap")]   # current mode
     loss_buf = torch.zeros((), device="cuda")
 
     def compute_step():
@@ -210,15 +216,17 @@ def main():
         out.loss.backward()
         loss_buf.copy_(out.loss.detach())
 
-    # warm-up (eager): builds the arena, runs the device self test, fills allocator pools
-    for _ in range(max(1, min(a.warmup, 2))):
+    # warm-up (eager): builds the arena, runs the device self test, fills allocator pools, records the step tape
+    for i in range(4):   # (call 1 of a step signature runs the ops, call 2 records the step tape, later calls replay it)
         compute_step()
-        if reducer:
-            reducer.allreduce()
+        if exchange[0] == "after":
+            after.allreduce()
+        if exchange[0] == "overlap" and i == 0:
+            overlapped.attach()   # the engine exists now: from here on the backward launches the range all-reduces itself
     torch.cuda.synchronize()
 
     graph = None
-    if not a.no_graph:
+    if not a.no_graph and exchange[0] != "overlap":
         graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(graph):
             compute_step()
@@ -231,8 +239,8 @@ def main():
             graph.replay()
         else:
             compute_step()
-        if reducer:
-            reducer.allreduce()
+        if exchange[0] == "after":
+            after.allreduce()
 
     def probe(flag, n=3):
         use_graph[0] = flag
@@ -257,6 +265,27 @@ def main():
             tg, te = float(tt2[0]), float(tt2[1])
         use_graph[0] = tg <= te
         mode_info = {"probe_graph_ms": tg * 1e3, "probe_eager_ms": te * 1e3, "eager_cpu_enqueue_ms": te_enq * 1e3}
+    if dist is not None and a.dp == "auto":
+        # gradient exchange: one chunked all-reduce after the step vs range all-reduces launched from inside the backward
+        ug = use_graph[0]
+        t_after, _ = probe(ug)
+        overlapped.attach()
+        exchange[0] = "overlap"
+        for _ in range(3):
+            probe(False, n=1)                       # warm / record / first replay of the hooked step
+        t_over, _ = probe(False)
+        tt2 = torch.tensor([t_after, t_over], device="cuda", dtype=torch.float64)
+        dist.all_reduce(tt2, op=dist.ReduceOp.MAX)
+        t_after, t_over = float(tt2[0]), float(tt2[1])
+        mode_info.update({"probe_dp_after_ms": t_after * 1e3, "probe_dp_overlap_ms": t_over * 1e3})
+        if t_after <= t_over:
+            overlapped.detach()
+            exchange[0] = "after"
+            for _ in range(3):
+                probe(ug, n=1)
+            use_graph[0] = ug
+        else:
+            use_graph[0] = False
     for _ in range(a.warmup):
         step()
     if dist:
@@ -302,7 +331,7 @@ def main():
                "dtype": a.compute, "data": "synthetic",
                "config": {"workload": f"Poseidon-{a.model} fwd+bwd, {a.size}x{a.size}x{ch} grids, per-GPU batch {B}",
                           "global_batch": B * world, "parallelism": f"dp{world}", "graph": bool(use_graph[0]), **mode_info,
-                          "grad_wire": a.wire if world > 1 else None, "loss": float(loss_buf)},
+                          "grad_wire": a.wire if world > 1 else None, "grad_exchange": exchange[0], "loss": float(loss_buf)},
                "roofline": roof}
         if world == 1 and not a.no_cpu_baseline:
             try:

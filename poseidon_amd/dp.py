@@ -70,10 +70,9 @@ class GradAllReducer:
                 if self._wire_buf is None or self._wire_buf.numel() < self.chunk:
                     self._wire_buf = torch.empty(self.chunk, dtype=torch.bfloat16, device=flat.device)
                 w = self._wire_buf[: e - s]
-                w.copy_(seg)
-                w.div_(self.world)
-                self.dist.all_reduce(w, group=self.group)
-                seg.copy_(w)
+                w.copy_(seg)                                   # fp32 -> bf16 (one pass)
+                self.dist.all_reduce(w, group=self.group)      # sum on the wire
+                torch.mul(w, 1.0 / self.world, out=seg)        # bf16 -> fp32 and the mean's 1/N in the same pass
             else:
                 seg.div_(self.world)
                 self.dist.all_reduce(seg, group=self.group)
@@ -93,11 +92,19 @@ class OverlappedGradAllReducer(GradAllReducer):
         self._ranges = None
         self.comm_stream = torch.cuda.Stream()
         self._pending = False
+        self._hooked = False
 
     def attach(self):
         self.model._engine.on_grads_final = self._on_final
         self.model._engine.reset_tapes()   # a recorded step bakes the hook in
-        self.model.register_grad_ready_hook(lambda m: self.finish())
+        if not self._hooked:
+            self.model.register_grad_ready_hook(lambda m: self.finish())
+            self._hooked = True
+
+    def detach(self):
+        self.finish()
+        self.model._engine.on_grads_final = None
+        self.model._engine.reset_tapes()
 
     def _on_final(self, prefix: str):
         if self._ranges is None:

@@ -1,6 +1,9 @@
-for t in 8 6; do
+for t in 8; do
   echo "tile $t"
   export SCOT_GEMM_TILE=$t
-  BK_COLD=1 python tools/bench_kernels.py gemm2 | grep "gemm" | grep -v "fc2 s"
-  BK_COLD=1 python tools/bench_kernels.py gemm3 | grep "gemm" | grep -v "fc2 s"
+  for g in gemm1 gemm2 gemm3; do BK_COLD=1 python tools/bench_kernels.py $g | grep "gemm" | grep -v "NT fc2 s"; done
 done
+unset SCOT_GEMM_TILE
+echo TN0
+export SCOT_GEMM_TILE_TN=0
+for g in gemm1 gemm2 gemm3; do BK_COLD=1 python tools/bench_kernels.py $g | grep "gemm TN"; done
