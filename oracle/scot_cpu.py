@@ -150,8 +150,9 @@ def attention(sd, prefix: str, xw: Tensor, heads: int, ws: int, mask: Optional[T
 
 
 def scot_layer(sd, prefix: str, x: Tensor, hw: Tuple[int, int], time, heads: int, target_window: int,
-               target_shift: int, eps: float, cond: bool) -> Tensor:
-    """ScOTLayer.forward (model.py:500-581) — res-post-norm."""
+               target_shift: int, eps: float, cond: bool, drop_masks=None) -> Tensor:
+    """ScOTLayer.forward (model.py:500-581) — res-post-norm.  drop_masks: {(prefix, 0|1): [B] mask/keep_prob} =
+    Swinv2DropPath (HF:565-586) on the two normed branches (model.py:570,574) with the random draw supplied."""
     h, w = hw
     b, l, c = x.shape
     ws, shift = clamp_window_shift(h, target_window, target_shift)
@@ -169,10 +170,13 @@ def scot_layer(sd, prefix: str, x: Tensor, hw: Tuple[int, int], time, heads: int
     out = torch.zeros(b, hp * wp, c, dtype=x.dtype)
     out[:, idx.reshape(-1)] = aw.reshape(b, nw * n, c)
     out = out.view(b, hp, wp, c)[:, :h, :w].reshape(b, l, c)
-    hid = x + norm(sd, prefix + ".layernorm_before", out, time, eps, cond)
+    def dp(t, which):
+        m = drop_masks.get((prefix, which)) if drop_masks else None
+        return t if m is None else t * m.to(t.dtype).view(-1, 1, 1)
+    hid = x + dp(norm(sd, prefix + ".layernorm_before", out, time, eps, cond), 0)
     y = gelu(hid @ sd[prefix + ".intermediate.dense.weight"].t() + sd[prefix + ".intermediate.dense.bias"])
     y = y @ sd[prefix + ".output.dense.weight"].t() + sd[prefix + ".output.dense.bias"]
-    return hid + norm(sd, prefix + ".layernorm_after", y, time, eps, cond)
+    return hid + dp(norm(sd, prefix + ".layernorm_after", y, time, eps, cond), 1)
 
 
 def patch_embed(sd, x: Tensor, patch: int) -> Tuple[Tensor, Tuple[int, int]]:
@@ -277,7 +281,7 @@ def spectral_resize(img: Tensor, target: int) -> Tensor:
 
 def scot_forward(sd: Dict[str, Tensor], cfg, pixel_values: Tensor, time: Optional[Tensor] = None,
                  labels: Optional[Tensor] = None, pixel_mask: Optional[Tensor] = None,
-                 return_intermediates: bool = False):
+                 return_intermediates: bool = False, drop_masks=None):
     """ScOT.forward (model.py:1318-1509) → (loss or None, prediction[, intermediates])."""
     if pixel_values is None:
         raise ValueError("pixel_values cannot be None")
@@ -309,7 +313,7 @@ def scot_forward(sd: Dict[str, Tensor], cfg, pixel_values: Tensor, time: Optiona
         stage_in = x
         for i in range(depths[s]):
             cw, cs = ctor_window_shift(gh // (2 ** s), window, 0 if i % 2 == 0 else window // 2)
-            x = scot_layer(sd, f"encoder.layers.{s}.blocks.{i}", x, hw, time, heads[s], cw, cs, eps, cond)
+            x = scot_layer(sd, f"encoder.layers.{s}.blocks.{i}", x, hw, time, heads[s], cw, cs, eps, cond, drop_masks)
         skip_states.append(x)  # hidden_states_before_downsampling
         inter[f"enc{s}"] = x
         if s < nl - 1:
@@ -335,7 +339,7 @@ def scot_forward(sd: Dict[str, Tensor], cfg, pixel_values: Tensor, time: Optiona
         for j in range(depth):
             i = depth - 1 - j  # blocks are built for i in reversed(range(depth)) (model.py:885-902)
             cw, cs = ctor_window_shift(gh // (2 ** i_layer), window, 0 if i % 2 == 0 else window // 2)
-            x = scot_layer(sd, f"decoder.layers.{k}.blocks.{j}", x, hw, time, heads[i_layer], cw, cs, eps, cond)
+            x = scot_layer(sd, f"decoder.layers.{k}.blocks.{j}", x, hw, time, heads[i_layer], cw, cs, eps, cond, drop_masks)
         inter[f"dec{k}"] = x
         if i_layer > 0:
             up = (gh // (2 ** (i_layer - 1)), gw // (2 ** (i_layer - 1)))

@@ -5,7 +5,9 @@
 // With use_conditioning=False the reference uses nn.LayerNorm ignoring `time` (model.py:135-140): pass gw_w = bw_w = NULL
 // and the plain weight/bias as gw_b / bw_b.  SwinV2 "res-post-norm" (model.py:570,574) is the fused form
 // out = resid + y.  Statistics, gamma/beta and the residual stream stay in fp32 in every compute mode.
-#include "common.h"
+// sample_scale (optional, [rows / rows_per_sample]): out = resid + s_b·y — Swinv2DropPath (HF:565-586, applied to the normed
+// branch at model.py:570,574): s_b = mask_b / keep_prob drawn by the caller; the backward scales the upstream gradient by s_b.
+#include "norm.h"
 
 struct ClnArgs {
   const void* x; const void* resid; void* out; float* mean; float* rstd;
@@ -17,6 +19,7 @@ struct ClnArgs {
   const void* dout; void* dx; int dout_dt, dx_dt;
   float* d_gw_w; float* d_gw_b; float* d_bw_w; float* d_bw_b;
   int vec;
+  const float* sscale;
 };
 
 // one wave per row
@@ -43,6 +46,7 @@ __global__ __launch_bounds__(256) void cln_fwd_kernel(ClnArgs p) {
   const float rstd = 1.0f / sqrtf(var + p.eps);
   if (lane == 0 && p.mean) { p.mean[row] = mean; p.rstd[row] = rstd; }
   const float t = p.time ? p.time[row / p.rows_per_sample] : 0.f;
+  const float sc = p.sscale ? p.sscale[row / p.rows_per_sample] : 1.f;
   if (p.vec) {
     for (int c = lane * 8; c < C; c += 512) {
       float v[8], r[8], o[8];
@@ -52,7 +56,7 @@ __global__ __launch_bounds__(256) void cln_fwd_kernel(ClnArgs p) {
       for (int j = 0; j < 8; ++j) {
         const float g = p.gw_w ? p.gw_w[c + j] * t + p.gw_b[c + j] : p.gw_b[c + j];
         const float b = p.bw_w ? p.bw_w[c + j] * t + p.bw_b[c + j] : p.bw_b[c + j];
-        o[j] = g * ((v[j] - mean) * rstd) + b + (p.resid ? r[j] : 0.f);
+        o[j] = sc * (g * ((v[j] - mean) * rstd) + b) + (p.resid ? r[j] : 0.f);
       }
       st8(p.out, p.out_dt, base + c, o);
     }
@@ -60,7 +64,7 @@ __global__ __launch_bounds__(256) void cln_fwd_kernel(ClnArgs p) {
     for (int c = lane; c < C; c += 64) {
       const float g = p.gw_w ? p.gw_w[c] * t + p.gw_b[c] : p.gw_b[c];
       const float b = p.bw_w ? p.bw_w[c] * t + p.bw_b[c] : p.bw_b[c];
-      float o = g * ((ld1(p.x, p.x_dt, base + c) - mean) * rstd) + b;
+      float o = sc * (g * ((ld1(p.x, p.x_dt, base + c) - mean) * rstd) + b);
       if (p.resid) o += ld1(p.resid, p.res_dt, base + c);
       st1(p.out, p.out_dt, base + c, o);
     }
@@ -79,6 +83,7 @@ __global__ __launch_bounds__(256) void cln_bwd_kernel(ClnArgs p, int rpb, int ch
   const int r0 = chunk * rpb, r1 = min(p.rows_per_sample, r0 + rpb);
   const int C = p.C;
   const float t = p.time ? p.time[b] : 0.f;
+  const float sc = p.sscale ? p.sscale[b] : 1.f;
   // columns are processed in passes of 256 so that register arrays stay small and statically indexed
   for (int cb = 0; cb < C; cb += 256) {
     float ag[4] = {0.f, 0.f, 0.f, 0.f}, ab[4] = {0.f, 0.f, 0.f, 0.f};
@@ -91,14 +96,14 @@ __global__ __launch_bounds__(256) void cln_bwd_kernel(ClnArgs p, int rpb, int ch
         float m1 = 0.f, m2 = 0.f;
         for (int c = lane; c < C; c += 64) {
           const float gam = p.gw_w ? p.gw_w[c] * t + p.gw_b[c] : p.gw_b[c];
-          const float g = ld1(p.dout, p.dout_dt, base + c) * gam;
+          const float g = sc * ld1(p.dout, p.dout_dt, base + c) * gam;
           const float xh = (ld1(p.x, p.x_dt, base + c) - mean) * rstd;
           m1 += g; m2 += g * xh;
         }
         m1 = wave_sum(m1) / C; m2 = wave_sum(m2) / C;
         for (int c = lane; c < C; c += 64) {
           const float gam = p.gw_w ? p.gw_w[c] * t + p.gw_b[c] : p.gw_b[c];
-          const float g = ld1(p.dout, p.dout_dt, base + c) * gam;
+          const float g = sc * ld1(p.dout, p.dout_dt, base + c) * gam;
           const float xh = (ld1(p.x, p.x_dt, base + c) - mean) * rstd;
           st1(p.dx, p.dx_dt, base + c, rstd * (g - m1 - xh * m2));
         }
@@ -107,7 +112,7 @@ __global__ __launch_bounds__(256) void cln_bwd_kernel(ClnArgs p, int rpb, int ch
       for (int i = 0; i < 4; ++i) {
         const int c = cb + lane + 64 * i;
         if (c < C) {
-          const float d = ld1(p.dout, p.dout_dt, base + c);
+          const float d = sc * ld1(p.dout, p.dout_dt, base + c);
           const float xh = (ld1(p.x, p.x_dt, base + c) - mean) * rstd;
           ag[i] += d * xh; ab[i] += d;
         }
@@ -128,19 +133,6 @@ __global__ __launch_bounds__(256) void cln_bwd_kernel(ClnArgs p, int rpb, int ch
   }
 }
 
-struct ClnFastArgs {  // must match norm_fast.hip
-  const void* x; const void* resid; void* out; void* out2; float* mean; float* rstd;
-  const float* time; const float* gw_w; const float* gw_b; const float* bw_w; const float* bw_b;
-  int x_dt, res_dt, out_dt, out2_dt;
-  int rows, rows_per_sample, C;
-  float eps;
-  const void* dout; void* dx; int dout_dt, dx_dt;
-  float* d_gw_w; float* d_gw_b; float* d_bw_w; float* d_bw_b; float* d_xbias;
-  int rpb, chunks_per_sample;
-  float* partials;
-};
-int scot_cln_fwd_fast(ClnFastArgs a, hipStream_t s);
-int scot_cln_bwd_fast(ClnFastArgs a, void* workspace, size_t ws_bytes, hipStream_t s);
 extern "C" int scot_colsum(const void* x, int x_dt, const void* y, int y_dt, float* out, int M, int N, int ld, hipStream_t s);
 extern "C" int scot_scale_residual(const void* y, int y_dt, const float* scale, const void* resid, int r_dt, void* out, int o_dt,
                                    size_t rows, int N, hipStream_t s);
@@ -149,21 +141,21 @@ extern "C" int scot_scale_residual(const void* y, int y_dt, const float* scale, 
 extern "C" int scot_cln_fwd(const void* x, int x_dt, const void* resid, int res_dt, void* out, int out_dt, void* out2, int out2_dt,
                             float* mean, float* rstd, const float* time, const float* gw_w, const float* gw_b,
                             const float* bw_w, const float* bw_b, int rows, int rows_per_sample, int C, float eps,
-                            hipStream_t stream) {
+                            const float* sample_scale, hipStream_t stream) {
   if (rows <= 0 || C <= 0 || rows_per_sample <= 0 || rows % rows_per_sample) return SCOT_ERR_SHAPE;
   if (!gw_b || !bw_b || (gw_w && !time)) return SCOT_ERR_SHAPE;
   {
     ClnFastArgs f{};
     f.x = x; f.resid = resid; f.out = out; f.out2 = out2; f.mean = mean; f.rstd = rstd; f.time = time;
     f.gw_w = gw_w; f.gw_b = gw_b; f.bw_w = bw_w; f.bw_b = bw_b; f.x_dt = x_dt; f.res_dt = res_dt; f.out_dt = out_dt; f.out2_dt = out2_dt;
-    f.rows = rows; f.rows_per_sample = rows_per_sample; f.C = C; f.eps = eps;
+    f.rows = rows; f.rows_per_sample = rows_per_sample; f.C = C; f.eps = eps; f.sscale = sample_scale;
     const int rc = scot_cln_fwd_fast(f, stream);
     if (rc != SCOT_ERR_UNSUPPORTED) return rc;
   }
   ClnArgs a{};
   a.x = x; a.resid = resid; a.out = out; a.mean = mean; a.rstd = rstd; a.time = time;
   a.gw_w = gw_w; a.gw_b = gw_b; a.bw_w = bw_w; a.bw_b = bw_b; a.x_dt = x_dt; a.res_dt = res_dt; a.out_dt = out_dt;
-  a.rows = rows; a.rows_per_sample = rows_per_sample; a.C = C; a.eps = eps;
+  a.rows = rows; a.rows_per_sample = rows_per_sample; a.C = C; a.eps = eps; a.sscale = sample_scale;
   a.vec = (C % 8 == 0) && (((uintptr_t)x | (uintptr_t)out | (uintptr_t)resid) & 15) == 0;
   hipLaunchKernelGGL(cln_fwd_kernel, dim3((rows + 3) / 4), dim3(256), 0, stream, a);
   int rc = scot_check_launch();
@@ -175,7 +167,8 @@ extern "C" int scot_cln_fwd(const void* x, int x_dt, const void* resid, int res_
 extern "C" int scot_cln_bwd(const void* dout, int dout_dt, const void* x, int x_dt, const float* mean, const float* rstd,
                             const float* time, const float* gw_w, const float* gw_b, void* dx, int dx_dt,
                             float* d_gw_w, float* d_gw_b, float* d_bw_w, float* d_bw_b, float* d_xbias, int rows,
-                            int rows_per_sample, int C, void* workspace, size_t ws_bytes, hipStream_t stream) {
+                            int rows_per_sample, int C, void* workspace, size_t ws_bytes, const float* sample_scale,
+                            hipStream_t stream) {
   if (rows <= 0 || C <= 0 || rows_per_sample <= 0 || rows % rows_per_sample) return SCOT_ERR_SHAPE;
   if (!gw_b || !d_gw_b || !d_bw_b || (gw_w && (!time || !d_gw_w || !d_bw_w))) return SCOT_ERR_SHAPE;
   {
@@ -183,7 +176,7 @@ extern "C" int scot_cln_bwd(const void* dout, int dout_dt, const void* x, int x_
     f.dout = dout; f.dout_dt = dout_dt; f.x = x; f.x_dt = x_dt; f.mean = (float*)mean; f.rstd = (float*)rstd; f.time = time;
     f.gw_w = gw_w; f.gw_b = gw_b; f.dx = dx; f.dx_dt = dx_dt;
     f.d_gw_w = gw_w ? d_gw_w : nullptr; f.d_gw_b = d_gw_b; f.d_bw_w = gw_w ? d_bw_w : nullptr; f.d_bw_b = d_bw_b; f.d_xbias = d_xbias;
-    f.rows = rows; f.rows_per_sample = rows_per_sample; f.C = C;
+    f.rows = rows; f.rows_per_sample = rows_per_sample; f.C = C; f.sscale = sample_scale;
     const int rc = scot_cln_bwd_fast(f, workspace, ws_bytes, stream);
     if (rc != SCOT_ERR_UNSUPPORTED) return rc;
   }
@@ -191,7 +184,7 @@ extern "C" int scot_cln_bwd(const void* dout, int dout_dt, const void* x, int x_
   a.dout = dout; a.dout_dt = dout_dt; a.x = x; a.x_dt = x_dt; a.mean = (float*)mean; a.rstd = (float*)rstd; a.time = time;
   a.gw_w = gw_w; a.gw_b = gw_b; a.dx = dx; a.dx_dt = dx_dt;
   a.d_gw_w = gw_w ? d_gw_w : nullptr; a.d_gw_b = d_gw_b; a.d_bw_w = gw_w ? d_bw_w : nullptr; a.d_bw_b = d_bw_b;
-  a.rows = rows; a.rows_per_sample = rows_per_sample; a.C = C;
+  a.rows = rows; a.rows_per_sample = rows_per_sample; a.C = C; a.sscale = sample_scale;
   const int rpb = rows_per_sample < 128 ? rows_per_sample : 128;
   const int cps = (rows_per_sample + rpb - 1) / rpb;
   hipLaunchKernelGGL(cln_bwd_kernel, dim3((rows / rows_per_sample) * cps), dim3(256), 0, stream, a, rpb, cps);

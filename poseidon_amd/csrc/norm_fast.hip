@@ -10,18 +10,7 @@
 #include "common.h"
 #include <stdlib.h>
 
-struct ClnFastArgs {
-  const void* x; const void* resid; void* out; void* out2; float* mean; float* rstd;
-  const float* time; const float* gw_w; const float* gw_b; const float* bw_w; const float* bw_b;
-  int x_dt, res_dt, out_dt, out2_dt;
-  int rows, rows_per_sample, C;
-  float eps;
-  const void* dout; void* dx; int dout_dt, dx_dt;
-  float* d_gw_w; float* d_gw_b; float* d_bw_w; float* d_bw_b; float* d_xbias;
-  int rpb, chunks_per_sample;
-  int dbg;           // SCOT_CLN_DEBUG experiment mask (1: no global atomics, 2: no LDS combine, 4: no row loop)
-  float* partials;   // optional [nblocks][3][C] scratch: per-block column sums, combined by cln_bwd_finalize_kernel
-};
+#include "norm.h"
 
 template <int LPR> __device__ __forceinline__ float group_sum(float v) {
 #pragma unroll
@@ -55,6 +44,7 @@ __global__ __launch_bounds__(256) void cln_fwd_fast_kernel(ClnFastArgs p) {
   if (!rvalid) return;
   if (l == 0 && p.mean) { p.mean[row] = mean; p.rstd[row] = rstd; }
   const float t = p.time ? p.time[row / p.rows_per_sample] : 0.f;
+  const float sc = p.sscale ? p.sscale[row / p.rows_per_sample] : 1.f;
 #pragma unroll
   for (int i = 0; i < CPL; ++i) {
     const int c = (l + i * LPR) * 8;
@@ -67,7 +57,7 @@ __global__ __launch_bounds__(256) void cln_fwd_fast_kernel(ClnFastArgs p) {
       for (int j = 0; j < 8; ++j) {
         const float g = p.gw_w ? gw[j] * t + gb[j] : gb[j];
         const float b = p.gw_w ? bw[j] * t + bb[j] : bb[j];
-        o[j] = g * ((v[i][j] - mean) * rstd) + b + (p.resid ? r[j] : 0.f);
+        o[j] = sc * (g * ((v[i][j] - mean) * rstd) + b) + (p.resid ? r[j] : 0.f);
       }
       st8(p.out, p.out_dt, base + c, o);
       if (p.out2) st8(p.out2, p.out2_dt, base + c, o);
@@ -89,6 +79,7 @@ __global__ __launch_bounds__(256) void cln_bwd_fast_kernel(ClnFastArgs p) {
   const int r0 = chunk * p.rpb, r1 = min(p.rows_per_sample, r0 + p.rpb);
   const int C = p.C;
   const float t = p.time ? p.time[b] : 0.f;
+  const float sc = p.sscale ? p.sscale[b] : 1.f;
   float gam[CPL][8], ag[CPL][8], ab[CPL][8], ax[CPL][8];
 #pragma unroll
   for (int i = 0; i < CPL; ++i) {
@@ -120,12 +111,14 @@ __global__ __launch_bounds__(256) void cln_bwd_fast_kernel(ClnFastArgs p) {
       if (c < C) {
         ld8(p.dout, p.dout_dt, base + c, dd[i]);
         ld8(p.x, p.x_dt, base + c, xx[i]);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) dd[i][j] *= sc;
       }
     }
   };
   int r = r0 + wave * RPW + sub;
   if (r < r1) load_row(r, d, xr, mean, rstd);
-  for (; r < r1 && !(p.dbg & 4); r += 4 * RPW) {
+  for (; r < r1; r += 4 * RPW) {
     const int rn = r + 4 * RPW;
     if (rn < r1) load_row(rn, dn, xn, mean_n, rstd_n);
     const size_t base = (size_t)(b * p.rows_per_sample + r) * C;
@@ -173,7 +166,7 @@ __global__ __launch_bounds__(256) void cln_bwd_fast_kernel(ClnFastArgs p) {
       }
     }
   for (int w = 0; w < 4; ++w) {
-    if (wave == w && sub == 0 && !(p.dbg & 2)) {
+    if (wave == w && sub == 0) {
 #pragma unroll
       for (int i = 0; i < CPL; ++i)
 #pragma unroll
@@ -193,7 +186,6 @@ __global__ __launch_bounds__(256) void cln_bwd_fast_kernel(ClnFastArgs p) {
     }
     return;
   }
-  if (p.dbg & 1) return;
   for (int c = threadIdx.x; c < C; c += 256) {
     const int k = (c & 7) * NCH + (c >> 3);
     const float dg = red[0][k], db = red[1][k];
@@ -288,7 +280,6 @@ int scot_cln_bwd_fast(ClnFastArgs a, void* workspace, size_t ws_bytes, hipStream
   // exposed row-load latency, not by the atomics; partials stay available for experiments (SCOT_CLN_PARTIALS=1)
   static int use_partials = -1;
   if (use_partials < 0) { const char* e = getenv("SCOT_CLN_PARTIALS"); use_partials = e ? atoi(e) : 0; }
-  { const char* e = getenv("SCOT_CLN_DEBUG"); a.dbg = e ? atoi(e) : 0; }
   a.partials = (use_partials && workspace && ws_bytes >= (size_t)nblocks * 3 * a.C * sizeof(float)) ? (float*)workspace : nullptr;
   CLN_DISPATCH(launch_bwd)
   int rc = scot_check_launch();

@@ -23,7 +23,7 @@ import torch
 
 from . import ops
 from .arena import Arena
-from .geometry import BlockGeom, StageGeom, stage_plan
+from .geometry import drop_path_rates, BlockGeom, StageGeom, stage_plan
 
 
 def cpb_coords_table(ws: int) -> torch.Tensor:
@@ -69,6 +69,8 @@ class ScOTEngine:
         self.tcm = ops.F32 if (trunk32 or self.compute == ops.F32) else ops.BF16
         self.tadt = torch.float32 if self.tcm == ops.F32 else torch.bfloat16
         self.grid, self.enc, self.dec = stage_plan(cfg)
+        self.drop_rates = drop_path_rates(cfg)      # per-layer stochastic-depth rate (0 for the training recipe, train.py:262)
+        self.drop_path_masks = None                 # tests: {(layer prefix, branch 0|1): [B] scale} instead of random draws
         self.cond = bool(cfg.use_conditioning)
         self._coords: Dict[int, torch.Tensor] = {}
         self._loss_meta = None
@@ -211,7 +213,8 @@ class ScOTEngine:
                     self.G(prefix + ".bias.bias"))
         return (None, self.G(prefix + ".weight"), None, self.G(prefix + ".bias"))
 
-    def norm_fwd(self, prefix, x, resid, rows_per_sample, C, eps, time, out_dtype=torch.float32, need_stats=True, copy=False):
+    def norm_fwd(self, prefix, x, resid, rows_per_sample, C, eps, time, out_dtype=torch.float32, need_stats=True, copy=False,
+                 sample_scale=None):
         """→ (out, out16, stats); out16 = operand-dtype copy of out (only when copy=True; == out in fp32 mode)."""
         rows = x.numel() // C
         out = self.new(rows, C, dtype=out_dtype)
@@ -222,17 +225,31 @@ class ScOTEngine:
         rstd = self.new(rows) if need_stats else None
         gw_w, gw_b, bw_w, bw_b = self._norm_params(prefix)
         ops.cln_fwd(x, resid, out, mean, rstd, time if self.cond else None, gw_w, gw_b, bw_w, bw_b, rows, rows_per_sample, C, eps,
-                    out2=out16 if (out16 is not None and out16 is not out) else None)
+                    out2=out16 if (out16 is not None and out16 is not out) else None, sample_scale=sample_scale)
         return out, out16, (mean, rstd)
 
-    def norm_bwd(self, prefix, dout, x, stats, rows_per_sample, C, time, dx_dtype):
+    def norm_bwd(self, prefix, dout, x, stats, rows_per_sample, C, time, dx_dtype, sample_scale=None):
         rows = x.numel() // C
         dx = self.new(rows, C, dtype=dx_dtype)
         gw_w, gw_b, _, _ = self._norm_params(prefix)
         g = self._norm_grads(prefix)
         ops.cln_bwd(dout, x, stats[0], stats[1], time if self.cond else None, gw_w, gw_b, dx, g[0], g[1], g[2], g[3], rows,
-                    rows_per_sample, C)
+                    rows_per_sample, C, sample_scale=sample_scale)
         return dx
+
+    def drop_path_scale(self, prefix: str, B: int, which: int):
+        """Swinv2DropPath (HF:565-586): per-sample keep mask / keep_prob for one residual branch of one layer, or None
+        (rate 0 / not training).  `drop_path_masks[(prefix, which)]`, when set (tests), overrides the random draw."""
+        if self.drop_path_masks is not None:
+            m = self.drop_path_masks.get((prefix, which))
+            return None if m is None else m.to(self.device, torch.float32)
+        rate = self.drop_rates.get(prefix, 0.0)
+        if rate <= 0.0:
+            return None
+        keep = 1.0 - rate
+        m = self.new(B)
+        self.tdo(lambda: m.bernoulli_(keep).div_(keep))
+        return m
 
     def off_critical_path(self, fn, *tensors):
         """Run fn() (kernel launches that only WRITE parameter gradients) on the side stream, ordered after everything
@@ -406,7 +423,10 @@ class ScOTEngine:
         proj = self.new(B * L, C)
         ops.linear_fwd(cm, attn_c, self.W(pre + ".attention.output.dense.weight"), proj,
                        bias=self.P(pre + ".attention.output.dense.bias"))
-        h, h16, st1 = self.norm_fwd(pre + ".layernorm_before", proj, x, L, C, cfg.layer_norm_eps, time, need_stats=train, copy=True)
+        dp1 = self.drop_path_scale(pre, B, 0) if train else None
+        dp2 = self.drop_path_scale(pre, B, 1) if train else None
+        h, h16, st1 = self.norm_fwd(pre + ".layernorm_before", proj, x, L, C, cfg.layer_norm_eps, time, need_stats=train, copy=True,
+                                    sample_scale=dp1)
         hid = int(cfg.mlp_ratio * C)
         # fc1 epilogue emits a = gelu(u) AND gp = gelu'(u) (one erf, fp32 registers); u itself is never stored
         u = self.new(B * L, hid, dtype=self.adt)
@@ -415,11 +435,12 @@ class ScOTEngine:
                        gelu_deriv_out=gp if train else u)     # eval: GELU(u) only (`gelu_deriv_out is out`)
         y2 = self.new(B * L, C)
         ops.linear_fwd(cm, u, self.W(pre + ".output.dense.weight"), y2, bias=self.P(pre + ".output.dense.bias"))
-        out, out16, st2 = self.norm_fwd(pre + ".layernorm_after", y2, h, L, C, cfg.layer_norm_eps, time, need_stats=train, copy=True)
+        out, out16, st2 = self.norm_fwd(pre + ".layernorm_after", y2, h, L, C, cfg.layer_norm_eps, time, need_stats=train, copy=True,
+                                        sample_scale=dp2)
         rec = None
         if train:
             rec = dict(blk=blk, xp=xp, qkv=qkv, attn_p=attn, table=table, lse=lse, attn_c=attn_c, proj=proj, st1=st1, h16=h16, u=u, gp=gp,
-                       y2=y2, st2=st2, geom=(H, W, Hp, Wp, ws, shift, padded))
+                       y2=y2, st2=st2, geom=(H, W, Hp, Wp, ws, shift, padded), dp=(dp1, dp2))
         return out, out16, rec
 
     def layer_bwd(self, rec, g, B, time):
@@ -432,7 +453,7 @@ class ScOTEngine:
         L, Lp = H * W, Hp * Wp
         hid = int(cfg.mlp_ratio * C)
         # out = h + CLN_after(y2)
-        d_y2 = self.norm_bwd(pre + ".layernorm_after", g, rec["y2"], rec["st2"], L, C, time, adt)
+        d_y2 = self.norm_bwd(pre + ".layernorm_after", g, rec["y2"], rec["st2"], L, C, time, adt, sample_scale=rec["dp"][1])
         # y2 = gelu(u) W2^T + b2
         self.linear_bwd_params(pre + ".output.dense.weight", pre + ".output.dense.bias", d_y2, rec["u"])   # rec["u"] = gelu(u)
         d_u = self.new(B * L, hid, dtype=adt)
@@ -441,7 +462,7 @@ class ScOTEngine:
         self.linear_bwd_params(pre + ".intermediate.dense.weight", pre + ".intermediate.dense.bias", d_u, rec["h16"])
         ops.linear_dgrad(cm, d_u, self.W(pre + ".intermediate.dense.weight"), g, accumulate=True)
         # h = x + CLN_before(proj)
-        d_proj = self.norm_bwd(pre + ".layernorm_before", g, rec["proj"], rec["st1"], L, C, time, adt)
+        d_proj = self.norm_bwd(pre + ".layernorm_before", g, rec["proj"], rec["st1"], L, C, time, adt, sample_scale=rec["dp"][0])
         self.linear_bwd_params(pre + ".attention.output.dense.weight", pre + ".attention.output.dense.bias", d_proj, rec["attn_c"])
         d_attn = self.new(B * L, C, dtype=adt)
         ops.linear_dgrad(cm, d_proj, self.W(pre + ".attention.output.dense.weight"), d_attn)
@@ -649,9 +670,6 @@ class ScOTEngine:
             raise ValueError("Make sure that the channel dimension of the pixel values match with the one set in the configuration.")
         if self.cond and time is None:
             raise ValueError("use_conditioning=True needs `time`")
-        if train and cfg.drop_path_rate > 0.0:
-            raise NotImplementedError("stochastic depth (drop_path_rate > 0) in training is not implemented yet; the "
-                                      "reference training recipe uses 0.0 (train.py:262)")
         self.mark("fwd embed")
         p = cfg.patch_size
         gh, gw = self.grid

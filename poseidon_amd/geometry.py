@@ -86,6 +86,32 @@ def stage_plan(cfg) -> Tuple[Tuple[int, int], List[StageGeom], List[StageGeom]]:
     return (gh, gw), enc, dec
 
 
+def drop_path_rates(cfg) -> Dict[str, float]:
+    """Stochastic-depth rate of every ScOTLayer, keyed by its state_dict prefix.
+
+    Reference: one `linspace(0, drop_path_rate, 2·Σdepths)`; the encoder takes the first half in block order
+    (model.py:976-996, block i of a stage gets `drop_path[i]`, :795); the decoder takes the second half, stage of
+    resolution level i_layer gets `dpr[Σ depths[i_layer+1:] : Σ depths[i_layer:]]` (:1111-1131) and — its blocks being
+    built in reversed order with `drop_path[depth-1-i]` (:885-899) — block at POSITION j of the stage gets entry j."""
+    depths = list(cfg.depths)
+    total = sum(depths)
+    n = 2 * total
+    rate = float(cfg.drop_path_rate)
+    lin = [rate * i / (n - 1) if n > 1 else 0.0 for i in range(n)]
+    out: Dict[str, float] = {}
+    for s, d in enumerate(depths):
+        for i in range(d):
+            out[f"encoder.layers.{s}.blocks.{i}"] = lin[sum(depths[:s]) + i]
+    dec = lin[total:]
+    nl = len(depths)
+    for k in range(nl):
+        i_layer = nl - 1 - k
+        sl = dec[sum(depths[i_layer + 1:]): sum(depths[i_layer:])]
+        for j in range(depths[i_layer]):
+            out[f"decoder.layers.{k}.blocks.{j}"] = sl[j]
+    return out
+
+
 def _norm_keys(out: "OrderedDict[str, Tuple[int, ...]]", prefix: str, dim: int, cond: bool) -> None:
     if cond:
         out[prefix + ".weight.weight"] = (dim, 1)

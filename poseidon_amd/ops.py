@@ -175,17 +175,19 @@ def cpb_bwd_batched(params, desc, first, count, coords, zbuf, dtables, grads):
                                         stream()), "scot_cpb_bwd_batched")
 
 
-def cln_fwd(x, resid, out, mean, rstd, time, gw_w, gw_b, bw_w, bw_b, rows, rows_per_sample, C, eps, out2=None):
+def cln_fwd(x, resid, out, mean, rstd, time, gw_w, gw_b, bw_w, bw_b, rows, rows_per_sample, C, eps, out2=None, sample_scale=None):
     _lib.check(L().scot_cln_fwd(ptr(x), dt(x), ptr(resid), dt(resid) if resid is not None else 0, ptr(out), dt(out), ptr(out2),
                                 dt(out2) if out2 is not None else 0, ptr(mean),
                                 ptr(rstd), ptr(time), ptr(gw_w), ptr(gw_b), ptr(bw_w), ptr(bw_b), rows, rows_per_sample, C,
-                                float(eps), stream()), "scot_cln_fwd")
+                                float(eps), ptr(sample_scale), stream()), "scot_cln_fwd")
 
 
-def cln_bwd(dout, x, mean, rstd, time, gw_w, gw_b, dx, d_gw_w, d_gw_b, d_bw_w, d_bw_b, rows, rows_per_sample, C, d_xbias=None):
+def cln_bwd(dout, x, mean, rstd, time, gw_w, gw_b, dx, d_gw_w, d_gw_b, d_bw_w, d_bw_b, rows, rows_per_sample, C, d_xbias=None,
+            sample_scale=None):
     _lib.check(L().scot_cln_bwd(ptr(dout), dt(dout), ptr(x), dt(x), ptr(mean), ptr(rstd), ptr(time), ptr(gw_w), ptr(gw_b),
                                 ptr(dx), dt(dx), ptr(d_gw_w), ptr(d_gw_b), ptr(d_bw_w), ptr(d_bw_b), ptr(d_xbias), rows,
-                                rows_per_sample, C, workspace().data_ptr(), WORKSPACE_BYTES, stream()), "scot_cln_bwd")
+                                rows_per_sample, C, workspace().data_ptr(), WORKSPACE_BYTES, ptr(sample_scale), stream()),
+               "scot_cln_bwd")
 
 
 def add(a, b, out, period=None):

@@ -231,3 +231,40 @@ def test_step_tape_replay_matches_direct_launches(name):
     ent = [e for e in taped._engine._taped.values() if e["state"] == "ready"]
     assert len(ent) == 1 and len(ent[0]["fwd"]) > 20 and len(ent[0]["bwd"]) > 20
     assert not plain._engine._taped or all(e["state"] == "warm" for e in plain._engine._taped.values())
+
+
+def test_stochastic_depth_matches_reference_draws():
+    """drop_path_rate > 0 in training: the per-sample scale goes through the LN kernels; with the
+    reference's recorded keep masks injected the step must reproduce the reference's training-mode step."""
+    f, meta = load_fixture("tiny_droppath")
+    cfg, model = build(meta, "fp32")
+    kw = inputs(cfg, meta)
+    model.train()
+    model(**kw).loss.backward()          # builds the engine (random draws: only checks that it runs and differs from eval)
+    eng = model._engine
+    eng.tape_mode = False
+    eng.drop_path_masks = {}
+    for k in f.files:
+        if k.startswith("mask:"):
+            _, name, which = k.split(":")
+            eng.drop_path_masks[(name, int(which))] = torch.from_numpy(f[k])
+    model.zero_grad()
+    out = model(**kw)
+    out.loss.backward()
+    assert rel_l2(out.output.detach().cpu().numpy(), f["output"]) < 1e-5
+    assert abs(float(out.loss) - float(f["loss"])) < 1e-5 * abs(float(f["loss"]))
+    grads_report(model, f, tol_each=5e-3, tol_global=1e-4)   # global 5.5e-5 (the CPU oracle sits at 6.9e-5 from this fixture); worst tensor: a logit_scale (cancelling sum, |g| = 2.6e-3): 2.5e-3
+    # random draws: training differs from eval, eval is deterministic and ignores the rate
+    eng.drop_path_masks = None
+    model.eval()
+    with torch.no_grad():
+        e1, e2 = model(**kw).output.clone(), model(**kw).output.clone()
+    assert torch.equal(e1, e2)
+    model.train()
+    diffs = []
+    for _ in range(4):
+        with torch.enable_grad():
+            o = model(**kw)
+        o.loss.backward()
+        diffs.append(float((o.output.detach() - e1).abs().max()))
+    assert max(diffs) > 1e-3            # 14 branches x 4 samples at rates up to 0.5: some branch is dropped

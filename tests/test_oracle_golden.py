@@ -94,3 +94,53 @@ def test_poseidon_presets(name):
                 ref = f[k].astype(np.float64)
                 err = float(np.linalg.norm(sd[k[5:]].grad.numpy().astype(np.float64) - ref))
                 assert err < 1e-4 * float(np.linalg.norm(ref)) + 1e-9, k
+
+
+def _drop_masks(f):
+    """{(layer prefix, branch): [B] mask/keep_prob} from the `mask:<layer>:<branch>` arrays of the stochastic-depth fixture."""
+    out = {}
+    for k in f.files:
+        if k.startswith("mask:"):
+            _, name, which = k.split(":")
+            out[(name, int(which))] = torch.from_numpy(f[k])
+    return out
+
+
+def test_stochastic_depth_against_reference_draws():
+    """Swinv2DropPath (row 15): the reference in training mode with its keep masks recorded (make_droppath_fixture.py)."""
+    f, meta = load_fixture("tiny_droppath")
+    cfg = ScOTConfig(**meta["cfg"])
+    sd = synth_state_dict(param_shapes(cfg), meta["regime"])
+    for v in sd.values():
+        v.requires_grad_(True)
+    pv, t, lab = synth_inputs(meta["batch"], cfg.num_channels, cfg.num_out_channels, cfg.image_size, meta["kind"])
+    masks = _drop_masks(f)
+    assert len(masks) == 14 and any(float(m.min()) == 0.0 for m in masks.values())
+    loss, out = scot_cpu.scot_forward(sd, cfg, pv, t, lab, None, drop_masks=masks)
+    loss.backward()
+    assert rel_l2(out.detach().numpy(), f["output"]) < TOL_OUT
+    assert abs(float(loss) - float(f["loss"])) < 1e-6 * abs(float(f["loss"]))
+    num = den = 0.0
+    for k, v in sd.items():
+        ref = f["grad:" + k].astype(np.float64)
+        num += float(np.linalg.norm(v.grad.numpy().astype(np.float64) - ref)) ** 2
+        den += float(np.linalg.norm(ref)) ** 2
+    assert (num / den) ** 0.5 < 1e-4   # measured 6.9e-5 (fp32 vs fp32; kept branches are scaled by 1/keep = up to 2)
+
+
+def test_drop_path_rate_schedule():
+    import json
+    import os
+    from poseidon_amd.config import preset
+    from poseidon_amd.geometry import drop_path_rates
+    pins = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "drop_path_rates.json")))
+    for tag in ("T", "B"):
+        cfg = preset(tag, image_size=128, num_channels=4, num_out_channels=4, drop_path_rate=pins[tag]["drop_path_rate"])
+        mine = drop_path_rates(cfg)
+        assert set(mine) == set(pins[tag]["layers"])
+        for k, r in pins[tag]["layers"].items():
+            assert abs(mine[k] - r) < 1e-6, (tag, k, mine[k], r)
+    f, meta = load_fixture("tiny_droppath")
+    mine = drop_path_rates(ScOTConfig(**meta["cfg"]))
+    for k, r in pins["tiny"]["layers"].items():
+        assert abs(mine[k] - r) < 1e-6, (k, mine[k], r)
