@@ -170,7 +170,7 @@ __device__ __forceinline__ float normalize_bwd_store(const f32x4_t (&acc)[HD / 1
 // delta = rowsum(dO ∘ O) comes from the forward output, so every 16x32 block of scores is consumed as soon as it is
 // produced (no 128-register S/dP pair): S^T, dP^T -> P -> dS -> {table histogram, dQ += dS·Kn}.
 template <typename CT, int HD, int NT>
-__global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(AttnArgs p) {
+__device__ __forceinline__ void attn_bwd_dq_body(const AttnArgs& p) {
   constexpr int NP = NT * 16, KS = (HD + 31) / 32, DT = HD / 16, pitch = row_pitch<HD, CT>();
   extern __shared__ __attribute__((aligned(16))) char smem[];
   CT* X = (CT*)smem;            // Kn
@@ -295,7 +295,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(AttnArgs p) {
 // ---- backward, kernel 2 of 2: dK, dV.  Keys on lane columns (S tiles); Q (normalised) and dO in LDS.
 // Independent of kernel 1 (delta is recomputed from dO ∘ O while dO is staged), so the two can run concurrently.
 template <typename CT, int HD, int NT>
-__global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(AttnArgs p) {
+__device__ __forceinline__ void attn_bwd_dkv_body(const AttnArgs& p) {
   constexpr int NP = NT * 16, KS = (HD + 31) / 32, DT = HD / 16, pitch = row_pitch<HD, CT>();
   constexpr int CPR = KS * 4;
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -406,6 +406,13 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(AttnArgs p) {
   }
 }
 
+// one launch for both halves (blockIdx.z): they are independent, see attention_w16.hip
+template <typename CT, int HD, int NT>
+__global__ __launch_bounds__(256, 2) void attn_bwd_kernel(AttnArgs p) {
+  if (blockIdx.z == 0) attn_bwd_dq_body<CT, HD, NT>(p);
+  else attn_bwd_dkv_body<CT, HD, NT>(p);
+}
+
 // ================================================================================================= host side
 extern int g_scot_use_tr;
 int scot_attn_w16(const AttnArgs& a, int compute, int hd, int nwin, bool bwd, hipStream_t s);   // attention_w16.hip
@@ -422,12 +429,8 @@ static int launch_attn(const AttnArgs& a, int nwin, bool bwd, hipStream_t s) {
   if (sh > 160 * 1024) return SCOT_ERR_UNSUPPORTED;
   dim3 grid(nwin, a.heads), block(256);
   if (bwd) {
-    if (sh > 64 * 1024) {
-      (void)hipFuncSetAttribute((const void*)attn_bwd_dq_kernel<CT, HD, NT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh_dq);
-      (void)hipFuncSetAttribute((const void*)attn_bwd_dkv_kernel<CT, HD, NT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh_dkv);
-    }
-    hipLaunchKernelGGL((attn_bwd_dq_kernel<CT, HD, NT>), grid, block, sh_dq, s, a);
-    hipLaunchKernelGGL((attn_bwd_dkv_kernel<CT, HD, NT>), grid, block, sh_dkv, s, a);
+    if (sh > 64 * 1024) (void)hipFuncSetAttribute((const void*)attn_bwd_kernel<CT, HD, NT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh);
+    hipLaunchKernelGGL((attn_bwd_kernel<CT, HD, NT>), dim3(nwin, a.heads, 2), block, sh, s, a);
   } else {
     if (sh > 64 * 1024) (void)hipFuncSetAttribute((const void*)attn_fwd_kernel<CT, HD, NT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh);
     hipLaunchKernelGGL((attn_fwd_kernel<CT, HD, NT>), grid, block, sh, s, a);

@@ -317,7 +317,7 @@ __global__ __launch_bounds__(256, 2) void attn16_fwd_kernel(AttnArgs p) {
 
 // ================================================================================================= backward: dQ, d table, d logit_scale
 template <typename CT, int HD, bool SHIFTED>
-__global__ __launch_bounds__(256, 2) void attn16_bwd_dq_kernel(AttnArgs p) {
+__device__ __forceinline__ void attn16_bwd_dq_body(const AttnArgs& p) {
   constexpr int NT = W16::NT, NP = W16::NP, KS = (HD + 31) / 32, DT = HD / 16, TE = Tile16<CT, HD>::elems;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   CT* X = (CT*)smem;            // Kn
@@ -436,7 +436,7 @@ __global__ __launch_bounds__(256, 2) void attn16_bwd_dq_kernel(AttnArgs p) {
 
 // ================================================================================================= backward: dK, dV
 template <typename CT, int HD, bool SHIFTED>
-__global__ __launch_bounds__(256, 2) void attn16_bwd_dkv_kernel(AttnArgs p) {
+__device__ __forceinline__ void attn16_bwd_dkv_body(const AttnArgs& p) {
   constexpr int NT = W16::NT, NP = W16::NP, KS = (HD + 31) / 32, DT = HD / 16, TE = Tile16<CT, HD>::elems;
   constexpr int CPR = KS * 4;
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -543,6 +543,15 @@ __global__ __launch_bounds__(256, 2) void attn16_bwd_dkv_kernel(AttnArgs p) {
   }
 }
 
+// One launch for the whole backward: blockIdx.z selects the half.  The two halves are independent (each recomputes P from
+// q, k, lse and takes delta from dO·O), so their workgroups simply share the grid: no launch boundary between them and
+// the dK/dV workgroups fill the CUs as the dQ ones drain.
+template <typename CT, int HD, bool SHIFTED>
+__global__ __launch_bounds__(256, 2) void attn16_bwd_kernel(AttnArgs p) {
+  if (blockIdx.z == 0) attn16_bwd_dq_body<CT, HD, SHIFTED>(p);
+  else attn16_bwd_dkv_body<CT, HD, SHIFTED>(p);
+}
+
 // ================================================================================================= host side
 template <typename CT, int HD, bool SHIFTED>
 static int launch_w16(const AttnArgs& a, int nwin, bool bwd, hipStream_t s) {
@@ -556,17 +565,9 @@ static int launch_w16(const AttnArgs& a, int nwin, bool bwd, hipStream_t s) {
     if (sh_fwd > 64 * 1024) (void)hipFuncSetAttribute((const void*)attn16_fwd_kernel<CT, HD, SHIFTED>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh_fwd);
     hipLaunchKernelGGL((attn16_fwd_kernel<CT, HD, SHIFTED>), grid, block, sh_fwd, s, a);
   } else {
-    if (sh_dq > 64 * 1024) (void)hipFuncSetAttribute((const void*)attn16_bwd_dq_kernel<CT, HD, SHIFTED>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh_dq);
-    if (sh_dkv > 64 * 1024) (void)hipFuncSetAttribute((const void*)attn16_bwd_dkv_kernel<CT, HD, SHIFTED>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh_dkv);
-    if (getenv("SCOT_ATTN_OCC")) {
-      int n1 = 0, n2 = 0, n3 = 0;
-      (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&n1, attn16_bwd_dq_kernel<CT, HD, SHIFTED>, 256, sh_dq);
-      (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&n2, attn16_bwd_dkv_kernel<CT, HD, SHIFTED>, 256, sh_dkv);
-      (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&n3, attn16_fwd_kernel<CT, HD, SHIFTED>, 256, sh_fwd);
-      fprintf(stderr, "[w16 occupancy] dq %d (lds %zu)  dkv %d (lds %zu)  fwd %d (lds %zu)\n", n1, sh_dq, n2, sh_dkv, n3, sh_fwd);
-    }
-    hipLaunchKernelGGL((attn16_bwd_dq_kernel<CT, HD, SHIFTED>), grid, block, sh_dq, s, a);
-    hipLaunchKernelGGL((attn16_bwd_dkv_kernel<CT, HD, SHIFTED>), grid, block, sh_dkv, s, a);
+    const size_t sh_b = sh_dq > sh_dkv ? sh_dq : sh_dkv;
+    if (sh_b > 64 * 1024) (void)hipFuncSetAttribute((const void*)attn16_bwd_kernel<CT, HD, SHIFTED>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh_b);
+    hipLaunchKernelGGL((attn16_bwd_kernel<CT, HD, SHIFTED>), dim3(nwin, a.heads, 2), block, sh_b, s, a);
   }
   return scot_check_launch();
 }
