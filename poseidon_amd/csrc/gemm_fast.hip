@@ -676,7 +676,9 @@ int scot_gemm_fast(int layout, int compute, int M, int N, int K, const void* A, 
   int tile = ov[layout] >= 0 ? ov[layout] : (ov[3] >= 0 ? ov[3] : -1);
   if (tile < 0) {
     tile = 0;   // policy (see DESIGN.md §3 for the measurements behind it)
-    if (compute == SCOT_BF16 && layout == LAYOUT_TN && M % 96 == 0 && N % 96 == 0) tile = 4;   // wgrad: 96x96 (cold-cache sweep: 25.6 vs 38.5 us at stage 1)
+    // wgrad with a long token dimension (stages 0/1): 96x96 (cold-cache sweep: 25.6 vs 38.5 us at stage 1); with K <= 4096
+    // (stages 2/3) the 64x64 grid is already large enough to run unsplit (no partials, no reduce pass): 22 vs 27 us
+    if (compute == SCOT_BF16 && layout == LAYOUT_TN && M % 96 == 0 && N % 96 == 0 && K >= 8192) tile = 4;
     else if (compute == SCOT_BF16 && N == 96) tile = 2;   // one 64x96 column tile: the A operand streams once (64x64 would read it twice)
     else if (compute == SCOT_BF16 && layout != LAYOUT_TN && K <= 128) tile = 6;   // K = 96: BK = 32 halves LDS -> more workgroups/CU (-12 %)
   }
