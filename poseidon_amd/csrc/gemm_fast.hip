@@ -744,11 +744,12 @@ int scot_gemm_fast(int layout, int compute, int M, int N, int K, const void* A, 
   int rc = compute == SCOT_BF16 ? flaunch_tile<bf16_t>(tile, a, layout, nsplit, stream) : flaunch_tile<float>(tile, a, layout, nsplit, stream);
   if (rc == SCOT_OK && a.ws) {
     const size_t n8 = (size_t)M * N / 8;
-    const int zl = nsplit >= 16 ? 8 : nsplit >= 4 ? 4 : 1;
+    const int zl = (nsplit >= 64 && layout == LAYOUT_TN) ? 32 : nsplit >= 16 ? 8 : nsplit >= 4 ? 4 : 1;
     size_t blocks = (n8 * zl + 255) / 256; if (blocks > 4096) blocks = 4096;
     const dim3 g((unsigned)blocks), b(256);
     if (layout == LAYOUT_TN) {
-      if (zl == 8) hipLaunchKernelGGL(splitk_reduce_kernel<8>, g, b, 0, stream, a.ws, (float*)C, M, N, ldc, nsplit);
+      if (zl == 32) hipLaunchKernelGGL(splitk_reduce_kernel<32>, g, b, 0, stream, a.ws, (float*)C, M, N, ldc, nsplit);
+      else if (zl == 8) hipLaunchKernelGGL(splitk_reduce_kernel<8>, g, b, 0, stream, a.ws, (float*)C, M, N, ldc, nsplit);
       else if (zl == 4) hipLaunchKernelGGL(splitk_reduce_kernel<4>, g, b, 0, stream, a.ws, (float*)C, M, N, ldc, nsplit);
       else hipLaunchKernelGGL(splitk_reduce_kernel<1>, g, b, 0, stream, a.ws, (float*)C, M, N, ldc, nsplit);
     } else {

@@ -128,9 +128,13 @@ class ScOTEngine:
         return (self.cpb_dtables if grad else self.cpb_tables)[off:off + heads * ts].view(heads, ts)
 
     def cpb_backward_range(self, blocks):
+        """Bias-MLP backward of a stage's layers (reads the table gradients the attention backward accumulated, writes only
+        parameter gradients): ~100 us per call that nothing downstream waits for -> side stream."""
         if blocks:
-            ops.cpb_bwd_batched(self.arena.data, self.cpb_desc, self.cpb_index[blocks[0].prefix], len(blocks), self.cpb_coords,
-                                self.cpb_z, self.cpb_dtables, self.arena.grad)
+            first, n = self.cpb_index[blocks[0].prefix], len(blocks)
+            self.off_critical_path(lambda: ops.cpb_bwd_batched(self.arena.data, self.cpb_desc, first, n, self.cpb_coords, self.cpb_z,
+                                                               self.cpb_dtables, self.arena.grad))
+            self.flush_side()
 
     # ------------------------------------------------------------------------------------------ helpers
     def P(self, name):
