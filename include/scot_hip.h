@@ -75,7 +75,9 @@ int scot_cpb_bwd_batched(const float* params, const int* desc, int first, int co
 
 /* ConditionalLayerNorm / LayerNorm (+ fused residual), ref:135-160, res-post-norm ref:570,574.
  * sample_scale (optional, one float per sample): out = resid + s_b * norm(x) — Swinv2DropPath (HF:565-586) on the normed
- * branch, s_b = mask_b / keep_prob drawn by the caller; the backward applies the same s_b to dout. */
+ * branch, s_b = mask_b / keep_prob drawn by the caller; the backward applies the same s_b to dout.
+ * scot_cln_bwd mode: 0 = dx and the four parameter gradients (+=), 1 = dx only, 2 = parameter gradients only (dx may be
+ * NULL) — lets the caller keep the dependent chain a pure stream and take the column reductions on another stream. */
 int scot_cln_fwd(const void* x, int x_dt, const void* resid, int res_dt, void* out, int out_dt, void* out2, int out2_dt,
                  float* mean, float* rstd,
                  const float* time, const float* gw_w, const float* gw_b, const float* bw_w, const float* bw_b, int rows,
@@ -83,7 +85,7 @@ int scot_cln_fwd(const void* x, int x_dt, const void* resid, int res_dt, void* o
 int scot_cln_bwd(const void* dout, int dout_dt, const void* x, int x_dt, const float* mean, const float* rstd,
                  const float* time, const float* gw_w, const float* gw_b, void* dx, int dx_dt, float* d_gw_w,
                  float* d_gw_b, float* d_bw_w, float* d_bw_b, float* d_xbias, int rows, int rows_per_sample, int C,
-                 void* workspace, size_t ws_bytes, const float* sample_scale, scot_stream_t stream);
+                 void* workspace, size_t ws_bytes, const float* sample_scale, int mode, scot_stream_t stream);
 /* out2: optional second copy of the output in the next GEMM's operand dtype; d_xbias: optional += Σ_rows dx;
  * workspace: optional scratch for per-block column sums (avoids 4·C same-address atomics per block). */
 

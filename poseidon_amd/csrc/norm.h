@@ -13,6 +13,7 @@ struct ClnFastArgs {
   int rpb, chunks_per_sample;
   float* partials;   // optional [nblocks][3][C] scratch: per-block column sums, combined by cln_bwd_finalize_kernel
   const float* sscale;   // optional per-sample scale of the normed branch (DropPath), see norm.hip
+  int mode;              // backward: 0 = dx + parameter gradients, 1 = dx only, 2 = parameter gradients only
 };
 
 int scot_cln_fwd_fast(ClnFastArgs a, hipStream_t s);

@@ -20,6 +20,7 @@ struct ClnArgs {
   float* d_gw_w; float* d_gw_b; float* d_bw_w; float* d_bw_b;
   int vec;
   const float* sscale;
+  int mode;   // backward: 0 = dx + parameter gradients, 1 = dx only, 2 = parameter gradients only
 };
 
 // one wave per row
@@ -91,7 +92,7 @@ __global__ __launch_bounds__(256) void cln_bwd_kernel(ClnArgs p, int rpb, int ch
       const int row = b * p.rows_per_sample + r;
       const size_t base = (size_t)row * C;
       const float mean = p.mean[row], rstd = p.rstd[row];
-      if (cb == 0) {
+      if (cb == 0 && p.mode != 2) {
         // full-row reductions m1 = mean(g), m2 = mean(g·xhat) and dx for ALL columns (done once, on the first pass)
         float m1 = 0.f, m2 = 0.f;
         for (int c = lane; c < C; c += 64) {
@@ -122,7 +123,7 @@ __global__ __launch_bounds__(256) void cln_bwd_kernel(ClnArgs p, int rpb, int ch
     for (int i = 0; i < 4; ++i) { sg[wave][lane + 64 * i] = ag[i]; sb[wave][lane + 64 * i] = ab[i]; }
     __syncthreads();
     const int c = cb + threadIdx.x;
-    if (c < C) {
+    if (c < C && p.mode != 1) {
       const float dg = sg[0][threadIdx.x] + sg[1][threadIdx.x] + sg[2][threadIdx.x] + sg[3][threadIdx.x];
       const float db = sb[0][threadIdx.x] + sb[1][threadIdx.x] + sb[2][threadIdx.x] + sb[3][threadIdx.x];
       if (p.d_gw_w) { atomicAdd(&p.d_gw_w[c], t * dg); atomicAdd(&p.d_bw_w[c], t * db); }
@@ -167,16 +168,17 @@ extern "C" int scot_cln_fwd(const void* x, int x_dt, const void* resid, int res_
 extern "C" int scot_cln_bwd(const void* dout, int dout_dt, const void* x, int x_dt, const float* mean, const float* rstd,
                             const float* time, const float* gw_w, const float* gw_b, void* dx, int dx_dt,
                             float* d_gw_w, float* d_gw_b, float* d_bw_w, float* d_bw_b, float* d_xbias, int rows,
-                            int rows_per_sample, int C, void* workspace, size_t ws_bytes, const float* sample_scale,
+                            int rows_per_sample, int C, void* workspace, size_t ws_bytes, const float* sample_scale, int mode,
                             hipStream_t stream) {
   if (rows <= 0 || C <= 0 || rows_per_sample <= 0 || rows % rows_per_sample) return SCOT_ERR_SHAPE;
-  if (!gw_b || !d_gw_b || !d_bw_b || (gw_w && (!time || !d_gw_w || !d_bw_w))) return SCOT_ERR_SHAPE;
+  if (mode < 0 || mode > 2 || (mode == 2 && d_xbias)) return SCOT_ERR_SHAPE;
+  if (!gw_b || (mode != 1 && (!d_gw_b || !d_bw_b || (gw_w && (!d_gw_w || !d_bw_w)))) || (gw_w && !time)) return SCOT_ERR_SHAPE;
   {
     ClnFastArgs f{};
     f.dout = dout; f.dout_dt = dout_dt; f.x = x; f.x_dt = x_dt; f.mean = (float*)mean; f.rstd = (float*)rstd; f.time = time;
     f.gw_w = gw_w; f.gw_b = gw_b; f.dx = dx; f.dx_dt = dx_dt;
     f.d_gw_w = gw_w ? d_gw_w : nullptr; f.d_gw_b = d_gw_b; f.d_bw_w = gw_w ? d_bw_w : nullptr; f.d_bw_b = d_bw_b; f.d_xbias = d_xbias;
-    f.rows = rows; f.rows_per_sample = rows_per_sample; f.C = C; f.sscale = sample_scale;
+    f.rows = rows; f.rows_per_sample = rows_per_sample; f.C = C; f.sscale = sample_scale; f.mode = mode;
     const int rc = scot_cln_bwd_fast(f, workspace, ws_bytes, stream);
     if (rc != SCOT_ERR_UNSUPPORTED) return rc;
   }
@@ -184,11 +186,11 @@ extern "C" int scot_cln_bwd(const void* dout, int dout_dt, const void* x, int x_
   a.dout = dout; a.dout_dt = dout_dt; a.x = x; a.x_dt = x_dt; a.mean = (float*)mean; a.rstd = (float*)rstd; a.time = time;
   a.gw_w = gw_w; a.gw_b = gw_b; a.dx = dx; a.dx_dt = dx_dt;
   a.d_gw_w = gw_w ? d_gw_w : nullptr; a.d_gw_b = d_gw_b; a.d_bw_w = gw_w ? d_bw_w : nullptr; a.d_bw_b = d_bw_b;
-  a.rows = rows; a.rows_per_sample = rows_per_sample; a.C = C; a.sscale = sample_scale;
+  a.rows = rows; a.rows_per_sample = rows_per_sample; a.C = C; a.sscale = sample_scale; a.mode = mode;
   const int rpb = rows_per_sample < 128 ? rows_per_sample : 128;
   const int cps = (rows_per_sample + rpb - 1) / rpb;
   hipLaunchKernelGGL(cln_bwd_kernel, dim3((rows / rows_per_sample) * cps), dim3(256), 0, stream, a, rpb, cps);
   int rc = scot_check_launch();
-  if (rc == SCOT_OK && d_xbias) rc = scot_colsum(dx, dx_dt, nullptr, 0, d_xbias, rows, C, C, stream);
+  if (rc == SCOT_OK && d_xbias && mode != 2) rc = scot_colsum(dx, dx_dt, nullptr, 0, d_xbias, rows, C, C, stream);
   return rc;
 }

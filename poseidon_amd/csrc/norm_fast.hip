@@ -65,7 +65,9 @@ __global__ __launch_bounds__(256) void cln_fwd_fast_kernel(ClnFastArgs p) {
   }
 }
 
-template <int LPR, int CPL>
+// MODE 0: dx and the parameter gradients;  1: dx only (the dependent chain's half: a pure stream, no reductions over rows);
+// 2: parameter gradients only (no row statistics needed: Σ dout·xhat, Σ dout) — the engine runs this half on the side stream.
+template <int LPR, int CPL, int MODE>
 __global__ __launch_bounds__(256) void cln_bwd_fast_kernel(ClnFastArgs p) {
   constexpr int RPW = 64 / LPR;
   constexpr int NCOL = LPR * CPL * 8;      // columns covered (>= C)
@@ -119,6 +121,8 @@ __global__ __launch_bounds__(256) void cln_bwd_fast_kernel(ClnFastArgs p) {
   int r = r0 + wave * RPW + sub;
   if (r < r1) load_row(r, d, xr, mean, rstd);
   for (; r < r1; r += 4 * RPW) {
+    // (an unconditional prefetch — re-reading the last row — was tried so that the compiler can count loads in flight:
+    // the extra row costs more than the tighter waits save when a block only makes 2-8 passes)
     const int rn = r + 4 * RPW;
     if (rn < r1) load_row(rn, dn, xn, mean_n, rstd_n);
     const size_t base = (size_t)(b * p.rows_per_sample + r) * C;
@@ -133,7 +137,7 @@ __global__ __launch_bounds__(256) void cln_bwd_fast_kernel(ClnFastArgs p) {
         m1 += g; m2 += g * xh[i][j];
       }
     }
-    m1 = group_sum<LPR>(m1) / C; m2 = group_sum<LPR>(m2) / C;
+    if (MODE != 2) { m1 = group_sum<LPR>(m1) / C; m2 = group_sum<LPR>(m2) / C; }
 #pragma unroll
     for (int i = 0; i < CPL; ++i) {
       const int c = (l + i * LPR) * 8;
@@ -142,9 +146,10 @@ __global__ __launch_bounds__(256) void cln_bwd_fast_kernel(ClnFastArgs p) {
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
           o[j] = rstd * (d[i][j] * gam[i][j] - m1 - xh[i][j] * m2);
-          ag[i][j] += d[i][j] * xh[i][j]; ab[i][j] += d[i][j]; ax[i][j] += o[j];
+          if (MODE != 1) { ag[i][j] += d[i][j] * xh[i][j]; ab[i][j] += d[i][j]; }
+          if (MODE == 0) ax[i][j] += o[j];
         }
-        st8(p.dx, p.dx_dt, base + c, o);
+        if (MODE != 2) st8(p.dx, p.dx_dt, base + c, o);
       }
     }
 #pragma unroll
@@ -153,6 +158,7 @@ __global__ __launch_bounds__(256) void cln_bwd_fast_kernel(ClnFastArgs p) {
       for (int j = 0; j < 8; ++j) { d[i][j] = dn[i][j]; xr[i][j] = xn[i][j]; }
     mean = mean_n; rstd = rstd_n;
   }
+  if (MODE == 1) return;
   // reduce over the RPW row-groups of the wave (same columns live in lanes l, l+LPR, ...), then over the four waves by
   // taking turns on the LDS copy with plain read-add-write (ds_add_f32 measured ~300 ns per instruction here: 48 of them
   // were 15 us of a 24 us kernel at C = 768)
@@ -234,7 +240,10 @@ template <int LPR, int CPL> static void launch_fwd(const ClnFastArgs& a, hipStre
   hipLaunchKernelGGL((cln_fwd_fast_kernel<LPR, CPL>), dim3((a.rows + rpb - 1) / rpb), dim3(256), 0, s, a);
 }
 template <int LPR, int CPL> static void launch_bwd(const ClnFastArgs& a, hipStream_t s) {
-  hipLaunchKernelGGL((cln_bwd_fast_kernel<LPR, CPL>), dim3((a.rows / a.rows_per_sample) * a.chunks_per_sample), dim3(256), 0, s, a);
+  const dim3 grid((a.rows / a.rows_per_sample) * a.chunks_per_sample), block(256);
+  if (a.mode == 1) hipLaunchKernelGGL((cln_bwd_fast_kernel<LPR, CPL, 1>), grid, block, 0, s, a);
+  else if (a.mode == 2) hipLaunchKernelGGL((cln_bwd_fast_kernel<LPR, CPL, 2>), grid, block, 0, s, a);
+  else hipLaunchKernelGGL((cln_bwd_fast_kernel<LPR, CPL, 0>), grid, block, 0, s, a);
 }
 
 #define CLN_DISPATCH(FN)                                            \
@@ -262,6 +271,7 @@ int scot_cln_fwd_fast(ClnFastArgs a, hipStream_t s) {
 int scot_cln_bwd_fast(ClnFastArgs a, void* workspace, size_t ws_bytes, hipStream_t s) {
   if (a.C % 8 || !aligned16(a.x) || !aligned16(a.dout) || !aligned16(a.dx) || !aligned16(a.gw_w) || !aligned16(a.gw_b))
     return SCOT_ERR_UNSUPPORTED;
+  if (a.mode == 2 && a.d_xbias) return SCOT_ERR_UNSUPPORTED;   // Σ dx needs dx
   // rows per block: enough blocks to cover the chip (SCOT_CLN_BLOCKS, default 256: every block ends in 5·C global atomics) but at least two
   // passes of the four waves, at most 128 rows; SCOT_CLN_RPB pins it
   static int rpb_env = -1, blocks_env = -1;
@@ -270,7 +280,8 @@ int scot_cln_bwd_fast(ClnFastArgs a, void* workspace, size_t ws_bytes, hipStream
   int lpr = 1;
   while (lpr < 64 && lpr * 8 < a.C) lpr <<= 1;
   const int rows_per_pass = 4 * (64 / lpr);
-  int rpb = rpb_env > 0 ? rpb_env : (a.rows / blocks_env) / rows_per_pass * rows_per_pass;
+  const int target_blocks = a.mode == 1 ? 2048 : blocks_env;   // dx only: nothing to flush per block, so many short blocks
+  int rpb = rpb_env > 0 ? rpb_env : (a.rows / target_blocks) / rows_per_pass * rows_per_pass;
   if (rpb < 2 * rows_per_pass) rpb = 2 * rows_per_pass;
   if (rpb_env <= 0 && rpb > 128) rpb = 128;
   a.rpb = a.rows_per_sample < rpb ? a.rows_per_sample : rpb;

@@ -123,12 +123,12 @@ def linear_fwd(compute, x, w, out, bias=None, a_gelu=False, gelu_deriv_out=None)
     gemm(NT, compute, M, N, Kw, x, x.shape[-1], w, Kw, out, out.shape[-1], bias=bias, a_gelu=a_gelu, gelu_deriv_out=gelu_deriv_out)
 
 
-def linear_dgrad(compute, dy, w, dx, accumulate=False, aux=None, aux_mul=False):
-    """dx[M,K] (+)= dy[M,N] @ w[N,K]  (* gelu'(aux), or * aux when aux_mul)."""
+def linear_dgrad(compute, dy, w, dx, accumulate=False, aux=None, aux_mul=False, resid=None):
+    """dx[M,K] (+)= dy[M,N] @ w[N,K]  (* gelu'(aux), or * aux when aux_mul);  resid: dx = resid + ... (out of place)."""
     M = dy.numel() // dy.shape[-1]
     N, K = w.shape[0], w.numel() // w.shape[0]
     gemm(NN, compute, M, K, N, dy, dy.shape[-1], w, K, dx, dx.shape[-1], aux=aux, ldaux=aux.shape[-1] if aux is not None else 0,
-         accumulate=accumulate, aux_mul=aux_mul)
+         accumulate=accumulate, aux_mul=aux_mul, resid=resid, ldres=resid.shape[-1] if resid is not None else 0)
 
 
 def linear_wgrad(compute, dy, x, dw, b_gelu=False, dbias=None):
@@ -183,11 +183,12 @@ def cln_fwd(x, resid, out, mean, rstd, time, gw_w, gw_b, bw_w, bw_b, rows, rows_
 
 
 def cln_bwd(dout, x, mean, rstd, time, gw_w, gw_b, dx, d_gw_w, d_gw_b, d_bw_w, d_bw_b, rows, rows_per_sample, C, d_xbias=None,
-            sample_scale=None):
+            sample_scale=None, mode=0):
+    """mode 0: dx and parameter gradients; 1: dx only; 2: parameter gradients only (dx may be None)."""
     _lib.check(L().scot_cln_bwd(ptr(dout), dt(dout), ptr(x), dt(x), ptr(mean), ptr(rstd), ptr(time), ptr(gw_w), ptr(gw_b),
-                                ptr(dx), dt(dx), ptr(d_gw_w), ptr(d_gw_b), ptr(d_bw_w), ptr(d_bw_b), ptr(d_xbias), rows,
-                                rows_per_sample, C, workspace().data_ptr(), WORKSPACE_BYTES, ptr(sample_scale), stream()),
-               "scot_cln_bwd")
+                                ptr(dx), dt(dx) if dx is not None else 0, ptr(d_gw_w), ptr(d_gw_b), ptr(d_bw_w), ptr(d_bw_b), ptr(d_xbias), rows,
+                                rows_per_sample, C, workspace().data_ptr(), WORKSPACE_BYTES, ptr(sample_scale), int(mode),
+                                stream()), "scot_cln_bwd")
 
 
 def add(a, b, out, period=None):
