@@ -125,6 +125,16 @@ int scot_loss_bwd(const float* pred, const float* labels, const unsigned char* m
                   const int* group_of_channel, const float* sums, const float* counts, int G, int normalized,
                   const float* dloss, float* dpred, int B, int Cc, int HW, int p, scot_stream_t stream);
 
+/* ---- optimizer step over the flat arenas (reference scOT/trainer.py:295-445 builds the groups, HF Trainer
+ * clips with clip_grad_norm_ and steps torch.optim.AdamW).  map8[i] = parameter-group id (0..7) of arena elements 8i..8i+7, 255 =
+ * not a parameter (alignment padding, the key-bias slot of the fused qkv bias).  n = arena size in floats (multiple of 8). */
+int scot_optim_blocks(size_t n);                       /* floats of `partial` scratch scot_grad_sqnorm needs */
+int scot_grad_sqnorm(const float* grad, const unsigned char* map8, size_t n, float* partial, scot_stream_t stream);
+int scot_clip_coef(const float* partial, int nblocks, float max_norm, float* out2 /* {coef, total_norm} */, scot_stream_t stream);
+int scot_adamw_step(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, const unsigned char* map8, size_t n,
+                    const float* lr /* host[ngroups] */, const float* wd /* host[ngroups] */, int ngroups, float beta1, float beta2,
+                    float eps, int step, const float* clip /* device {coef,..} or NULL */, scot_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,111 @@
+// Fused AdamW (+ global gradient-norm clip) over the flat parameter / gradient arenas.
+//
+// Reference: the training step either side of the hot path — HF `Trainer` clips with
+// `torch.nn.utils.clip_grad_norm_(model.parameters(), max_grad_norm)` and steps `torch.optim.AdamW` over up to four
+// parameter groups built by the reference's `create_optimizer` (scOT/trainer.py:295-445; run.yaml: max_grad_norm 5.0).
+// With 1580 parameter tensors that is thousands of tiny launches; here the parameters already live in ONE fp32 arena
+// (poseidon_amd/arena.py), so a step is three launches over it:
+//   scot_grad_sqnorm  per-block partial sums of g² (parameters only: `map8` marks padding / non-parameter regions),
+//   scot_clip_coef    total norm and min(1, max_norm / (norm + 1e-6)),
+//   scot_adamw_step   p, m, v updated in place in one pass (28 bytes per parameter), group hyper-parameters by value.
+// torch.optim.AdamW arithmetic, in its order (torch/optim/adamw.py, single-tensor path):
+//   p *= 1 - lr·wd;  m += (g - m)(1 - β1);  v = β2·v + (1 - β2)·g²;  p -= (lr / bc1) · m / (sqrt(v)/sqrt(bc2) + eps).
+#include "common.h"
+
+constexpr int OPT_MAX_GROUPS = 8;
+struct AdamGroups { float lr[OPT_MAX_GROUPS]; float wd[OPT_MAX_GROUPS]; };
+
+// map8[i] = group id of elements 8i .. 8i+7 (255: not a parameter)
+__global__ __launch_bounds__(256) void grad_sqnorm_kernel(const float* __restrict__ g, const uint8_t* __restrict__ map8, size_t n8,
+                                                          float* __restrict__ partial) {
+  __shared__ float red[4];
+  float acc = 0.f;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n8; i += (size_t)gridDim.x * 256) {
+    if (map8[i] == 255) continue;
+    float v[8];
+    ld8(g, SCOT_F32, i * 8, v);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) acc += v[j] * v[j];
+  }
+  acc = wave_sum(acc);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) partial[blockIdx.x] = red[0] + red[1] + red[2] + red[3];
+}
+
+// out[0] = clip coefficient, out[1] = total norm
+__global__ __launch_bounds__(256) void clip_coef_kernel(const float* __restrict__ partial, int nblocks, float max_norm, float* out) {
+  __shared__ double red[4];
+  double acc = 0.0;
+  for (int i = threadIdx.x; i < nblocks; i += 256) acc += (double)partial[i];
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o, 64);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const float norm = (float)sqrt(red[0] + red[1] + red[2] + red[3]);
+    const float coef = max_norm / (norm + 1e-6f);   // torch.nn.utils.clip_grad_norm_: clamped to 1
+    out[0] = coef < 1.f ? coef : 1.f;
+    out[1] = norm;
+  }
+}
+
+__global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
+                                                    float* __restrict__ v, const uint8_t* __restrict__ map8, size_t n8, AdamGroups grp,
+                                                    float beta1, float beta2, float eps, float bc1, float rsqrt_bc2,
+                                                    const float* __restrict__ clip) {
+  const float cc = clip ? clip[0] : 1.f;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n8; i += (size_t)gridDim.x * 256) {
+    const int gi = map8[i];
+    if (gi == 255) continue;
+    const float lr = grp.lr[gi], wd = grp.wd[gi];
+    const float step = lr / bc1;
+    float pv[8], gv[8], mv[8], vv[8];
+    ld8(p, SCOT_F32, i * 8, pv); ld8(g, SCOT_F32, i * 8, gv); ld8(m, SCOT_F32, i * 8, mv); ld8(v, SCOT_F32, i * 8, vv);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const float gj = gv[j] * cc;
+      pv[j] *= 1.f - lr * wd;
+      mv[j] += (gj - mv[j]) * (1.f - beta1);
+      vv[j] = vv[j] * beta2 + (1.f - beta2) * gj * gj;
+      const float denom = sqrtf(vv[j]) * rsqrt_bc2 + eps;
+      pv[j] -= step * (mv[j] / denom);
+    }
+    st8(p, SCOT_F32, i * 8, pv); st8(m, SCOT_F32, i * 8, mv); st8(v, SCOT_F32, i * 8, vv);
+  }
+}
+
+static int opt_blocks(size_t n8) {
+  size_t b = (n8 + 255) / 256;
+  return (int)(b > 4096 ? 4096 : (b < 1 ? 1 : b));
+}
+
+// partial: [scot_optim_blocks(n)] floats of scratch owned by the caller
+extern "C" int scot_optim_blocks(size_t n) { return opt_blocks(n / 8); }
+
+extern "C" int scot_grad_sqnorm(const float* grad, const uint8_t* map8, size_t n, float* partial, hipStream_t stream) {
+  if (!grad || !map8 || !partial || n % 8) return SCOT_ERR_SHAPE;
+  hipLaunchKernelGGL(grad_sqnorm_kernel, dim3(opt_blocks(n / 8)), dim3(256), 0, stream, grad, map8, n / 8, partial);
+  return scot_check_launch();
+}
+
+extern "C" int scot_clip_coef(const float* partial, int nblocks, float max_norm, float* out2, hipStream_t stream) {
+  if (!partial || !out2 || nblocks <= 0) return SCOT_ERR_SHAPE;
+  hipLaunchKernelGGL(clip_coef_kernel, dim3(1), dim3(256), 0, stream, partial, nblocks, max_norm, out2);
+  return scot_check_launch();
+}
+
+// lr / wd: HOST arrays of ngroups floats (passed to the kernel by value); step >= 1; clip: device pointer to the
+// coefficient written by scot_clip_coef, or NULL
+extern "C" int scot_adamw_step(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, const uint8_t* map8, size_t n,
+                               const float* lr, const float* wd, int ngroups, float beta1, float beta2, float eps, int step,
+                               const float* clip, hipStream_t stream) {
+  if (!params || !grads || !exp_avg || !exp_avg_sq || !map8 || n % 8 || ngroups < 1 || ngroups > OPT_MAX_GROUPS || step < 1)
+    return SCOT_ERR_SHAPE;
+  AdamGroups grp{};
+  for (int i = 0; i < ngroups; ++i) { grp.lr[i] = lr[i]; grp.wd[i] = wd[i]; }
+  const double bc1 = 1.0 - pow((double)beta1, step), bc2 = 1.0 - pow((double)beta2, step);
+  hipLaunchKernelGGL(adamw_kernel, dim3(opt_blocks(n / 8)), dim3(256), 0, stream, params, grads, exp_avg, exp_avg_sq, map8, n / 8, grp,
+                     beta1, beta2, eps, (float)bc1, (float)(1.0 / sqrt(bc2)), clip);
+  return scot_check_launch();
+}

@@ -46,6 +46,10 @@ PROTOTYPES = {
     "scot_head_finalize": [P, P, I, P, P, I, P, P, I, I, I, I, P],
     "scot_loss_finish": [P, P, I, I, P, P],
     "scot_loss_bwd": [P, P, P, I, P, P, P, I, I, P, P, I, I, I, I, P],
+    "scot_optim_blocks": [Z],
+    "scot_grad_sqnorm": [P, P, Z, P, P],
+    "scot_clip_coef": [P, I, F, P, P],
+    "scot_adamw_step": [P, P, P, P, P, Z, P, P, I, F, F, F, I, P, P],
 }
 _VOID = {"scot_set_use_tr"}
 

@@ -3,4 +3,5 @@
 poseidon_amd.harness and are re-exported here."""
 from poseidon_amd.harness import (conditional_norm_parameter_names, create_optimizer, decay_parameter_names,  # noqa: F401
                                   optimizer_param_groups, rollout)
+from poseidon_amd.optim import FusedAdamW  # noqa: F401  (arena-wide AdamW + grad-norm clip: 3 launches per step)
 from scOT.model import ConditionalLayerNorm, LayerNorm  # noqa: F401

@@ -39,3 +39,32 @@ def test_optimizer_groups_match_reference_trainer():
     assert len(g3) == 3 and len(g3[2]["params"]) == 308  # all cond-LN tensors incl. embeddings.norm
     opt = create_optimizer(model, 5e-4, 1e-6, learning_rate_embedding_recovery=1e-4, learning_rate_time_embedding=2e-4)
     assert [g["lr"] for g in opt.param_groups] == [5e-4, 5e-4, 1e-4, 2e-4]
+
+
+def test_fused_optimizer_group_map_covers_exactly_the_parameters():
+    """poseidon_amd.optim.group_map8: every parameter's arena range carries its group id, everything else (alignment padding,
+    the key-bias slot of the fused qkv bias) is marked 'not a parameter'."""
+    import numpy as np
+    from poseidon_amd.arena import Arena
+    from poseidon_amd.config import preset
+    from poseidon_amd.geometry import param_shapes
+    from poseidon_amd.optim import SKIP, group_map8
+    cfg = preset("T", image_size=128, num_channels=4, num_out_channels=4)
+    shapes = param_shapes(cfg)
+    arena = Arena(shapes, "cpu", requires_grad_arena=False)
+    names = list(shapes)
+    groups = [names[0::3], names[1::3], names[2::3]]
+    m = group_map8(arena, groups)
+    owner = np.full(arena.size, SKIP, dtype=np.int64)
+    for gi, g in enumerate(groups):
+        for n in g:
+            o = arena.offsets[n]
+            owner[o:o + arena.numel(n)] = gi
+    got = np.repeat(m, 8).astype(np.int64)
+    assert (got[owner != SKIP] == owner[owner != SKIP]).all()          # every parameter element carries its group
+    extra = (got != SKIP) & (owner == SKIP)                             # chunk tails of tensors whose size is not 8k: padding
+    assert int(extra.sum()) < 8 * len(names) and float(arena.data[torch.from_numpy(extra)].abs().max()) == 0.0
+    # the fused qkv bias keeps a zero slot for the bias-free key projection: it must never be stepped
+    pre = "encoder.layers.0.blocks.0.attention.self."
+    o, c = arena.offsets[pre + "qkv_bias"], shapes[pre + "query.bias"][0]
+    assert (m[(o + c) // 8:(o + 2 * c) // 8] == SKIP).all() and (m[o // 8:(o + c) // 8] != SKIP).all()

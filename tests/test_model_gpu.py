@@ -268,3 +268,42 @@ def test_stochastic_depth_matches_reference_draws():
         o.loss.backward()
         diffs.append(float((o.output.detach() - e1).abs().max()))
     assert max(diffs) > 1e-3            # 14 branches x 4 samples at rates up to 0.5: some branch is dropped
+
+
+def test_fused_adamw_matches_torch_adamw_with_clipping():
+    """scOT.trainer.FusedAdamW (3 launches over the arenas) vs torch.optim.AdamW on the reference's parameter groups +
+    torch.nn.utils.clip_grad_norm_ (HF Trainer's step): same parameters after 4 steps."""
+    from scOT.trainer import FusedAdamW, create_optimizer
+    f, meta = load_fixture("tiny_trained")
+    cfg, ma = build(meta, "fp32")
+    _, mb = build(meta, "fp32")
+    kw = inputs(cfg, meta)
+    gk = dict(learning_rate_embedding_recovery=3e-3, learning_rate_time_embedding=2e-3)
+    ma(**kw).loss.backward()      # engines / arenas exist
+    mb(**kw).loss.backward()
+    fa = FusedAdamW(ma, lr=5e-3, weight_decay=0.05, max_grad_norm=0.05, **gk)
+    tb = create_optimizer(mb, 5e-3, weight_decay=0.05, **gk)
+    assert [len(g["params"]) for g in fa.param_groups] == [len(g["params"]) for g in tb.param_groups]
+    for step in range(4):
+        fa.zero_grad()
+        (ma(**kw).loss * (1.0 + step)).backward()
+        # identical gradients for both optimizers: Adam's first steps are ~lr·sign(g), so the 1e-7 run-to-run noise of the
+        # atomically accumulated gradients would flip near-zero entries and mask what is compared here (the step arithmetic)
+        mb._prepare_grads()
+        mb._arena.grad.copy_(ma._arena.grad)
+        norm_b = torch.nn.utils.clip_grad_norm_(mb.parameters(), 0.05)
+        fa.param_groups[0]["lr"] = tb.param_groups[0]["lr"] = 5e-3 * (1.0 - 0.1 * step)    # what a scheduler does
+        fa.step()
+        tb.step()
+        assert abs(float(fa.last_grad_norm) - float(norm_b)) < 1e-5 * float(norm_b)
+        assert float(norm_b) > 0.05                                                          # clipping is active
+    worst = 0.0
+    for (n, pa), (_, pb) in zip(ma.named_parameters(), mb.named_parameters()):
+        d = float((pa - pb).abs().max()) / (float(pb.abs().max()) + 1e-12)
+        worst = max(worst, d)
+        assert d < 2e-5, (n, d)
+    # the zero slot of the fused qkv bias (bias-free key projection) is untouched
+    a = ma._arena
+    pre = "encoder.layers.0.blocks.0.attention.self."
+    o, c = a.offsets[pre + "qkv_bias"], ma.config.embed_dim
+    assert float(a.data[o + c:o + 2 * c].abs().max()) == 0.0
