@@ -50,8 +50,7 @@ template <typename CT, int HD, int NP>
 __device__ __forceinline__ void stage_rows(CT* tile, const void* src, int ld, int col, const int* tok, int N,
                                            bool normalize, int tid) {
   constexpr int CPR = ((HD + 31) / 32) * 4, pitch = row_pitch<HD, CT>();
-#pragma unroll   // constant trip count: lets the loads of all passes go out before the first one is consumed
-  for (int c = tid; c < NP * CPR; c += 256) {
+  for (int c = tid; c < NP * CPR; c += (int)blockDim.x) {
     const int n = c / CPR, d8 = (c % CPR) * 8;
     float v[8];
 #pragma unroll
@@ -127,3 +126,25 @@ __device__ __forceinline__ void load_rows_f32(float (&v)[(HD + 31) / 32][8], con
   }
 }
 
+// fragments from raw fp32 rows in B-operand order (see load_rows_f32), optionally L2-normalised over the whole row
+template <typename CT, int HD>
+__device__ __forceinline__ void rows_to_frag(Frag<CT> (&f)[(HD + 31) / 32], float (&v)[(HD + 31) / 32][8], bool normalize) {
+  constexpr int KS = (HD + 31) / 32;
+  float r = 1.f;
+  if (normalize) {
+    float ss = 0.f;
+#pragma unroll
+    for (int kk = 0; kk < KS; ++kk)
+#pragma unroll
+      for (int j = 0; j < 8; ++j) ss += v[kk][j] * v[kk][j];
+    ss += __shfl_xor(ss, 16, 64);
+    ss += __shfl_xor(ss, 32, 64);
+    r = 1.0f / fmaxf(sqrtf(ss), 1e-12f);
+  }
+#pragma unroll
+  for (int kk = 0; kk < KS; ++kk) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) v[kk][j] *= r;
+    f[kk] = frag_from_f32<CT>(v[kk]);
+  }
+}

@@ -29,10 +29,11 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnArgs p) {
 
   const int win = blockIdx.x, h = blockIdx.y;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int nthr = blockDim.x, nwv = nthr >> 6;   // 1, 2 or 4 waves per (window, head): small windows leave waves idle otherwise
   const int ld = 3 * p.C;
 
-  for (int i = tid; i < NP; i += 256) { rid[i] = pos_info(p, win, i, N); tok[i] = i < N ? win_token(p, win, i) : 0; }
-  for (int i = tid; i < TS; i += 256) tab[i] = p.bias_table[h * TS + i];
+  for (int i = tid; i < NP; i += nthr) { rid[i] = pos_info(p, win, i, N); tok[i] = i < N ? win_token(p, win, i) : 0; }
+  for (int i = tid; i < TS; i += nthr) tab[i] = p.bias_table[h * TS + i];
   __syncthreads();
   stage_rows<CT, HD, NP>(Kn, p.qkv, ld, p.C + h * HD, tok, N, true, tid);
   stage_rows<CT, HD, NP>(Vs, p.qkv, ld, 2 * p.C + h * HD, tok, N, false, tid);
@@ -42,7 +43,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnArgs p) {
   const int cen = (ws - 1) * TW + ws - 1;
   const int g = lane >> 4, qc = lane & 15;
 
-  for (int qb = wave; qb * 16 < N; qb += 4) {
+  for (int qb = wave; qb * 16 < N; qb += nwv) {
     const int q0 = qb * 16;
     Frag<CT> qf[KS];
     load_rows_frag<CT, HD>(qf, p.qkv, ld, h * HD, tok, q0, N, true, lane);
@@ -127,43 +128,54 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnArgs p) {
 //   d bias-table (LDS histogram → one atomic pass), d logit_scale, dQn = scale·dS·Kn → dq through the normalisation.
 // Phase A (keys on lane columns, S tiles): recompute P, dS; dV = P^T·dO, dKn = scale·dS^T·Qn → dk.
 // LDS holds two [NP][HD] tiles that are re-filled between the phases (Kn,V then Qn,dO).
+// The un-normalised rows again, in the layout of the accumulators (row n0 + (lane>>4)*4 + r, feature d*16 + (lane&15)).  Loaded
+// separately from (and well before) the stores of normalize_bwd_store: behind a store to `dst` the compiler must assume
+// aliasing and would issue one dependent global round trip per row — 4 of the ~10 serial round trips that made the backward of
+// the 8x8 / 4x4 windows take 25 us for a few kFLOP.
 template <typename CT, int HD>
-__device__ __forceinline__ float normalize_bwd_store(const f32x4_t (&acc)[HD / 16], float mul, const void* src, int ld, int col,
-                                                    void* dst, int dcol, const int* tokt, int n0, int N, int lane) {
-  // acc[d][r]: gradient wrt the NORMALISED row n0 + (lane>>4)*4 + r, feature d*16 + (lane&15) (times `mul`).
-  // y = x / max(|x|, eps):  dx = (g - y (y·g)) / |x|   (|x| >= eps),   dx = g / eps otherwise.
-  constexpr int DT = HD / 16;
+__device__ __forceinline__ void normalize_bwd_load(float (&x)[4][HD / 16], const void* src, int ld, int col, const int* tokt, int n0, int N,
+                                                   int lane) {
   const int g = lane >> 4, c = lane & 15;
-  float dotsum = 0.f;  // Σ_rows y·g (counted once per row: lane c == 0) — this is d/d(logit_scale) of the rows
 #pragma unroll
   for (int r = 0; r < 4; ++r) {
     const int n = n0 + g * 4 + r;
     const bool valid = n < N;
     const size_t tok = valid ? (size_t)tokt[n] : 0;
-    float x[DT], ss = 0.f, dot = 0.f;
 #pragma unroll
-    for (int d = 0; d < DT; ++d) {
-      x[d] = valid ? ld1(src, ct_traits<CT>::dtype, tok * ld + col + d * 16 + c) : 0.f;
-      ss += x[d] * x[d];
-    }
+    for (int d = 0; d < HD / 16; ++d) x[r][d] = valid ? ld1(src, ct_traits<CT>::dtype, tok * ld + col + d * 16 + c) : 0.f;
+  }
+}
+template <typename CT, int HD>
+__device__ __forceinline__ void normalize_bwd_store(const f32x4_t (&acc)[HD / 16], float mul, const float (&x)[4][HD / 16], int ld,
+                                                    void* dst, int dcol, const int* tokt, int n0, int N, int lane) {
+  // acc[d][r]: gradient wrt the NORMALISED row n0 + (lane>>4)*4 + r, feature d*16 + (lane&15) (times `mul`).
+  // y = x / max(|x|, eps):  dx = (g - y (y·g)) / |x|   (|x| >= eps),   dx = g / eps otherwise.
+  constexpr int DT = HD / 16;
+  const int g = lane >> 4, c = lane & 15;
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const int n = n0 + g * 4 + r;
+    const bool valid = n < N;
+    const size_t tok = valid ? (size_t)tokt[n] : 0;
+    float ss = 0.f, dot = 0.f;
+#pragma unroll
+    for (int d = 0; d < DT; ++d) ss += x[r][d] * x[r][d];
 #pragma unroll
     for (int o = 1; o < 16; o <<= 1) ss += __shfl_xor(ss, o, 64);
     const float nrm = sqrtf(ss);
     const bool clamped = nrm < 1e-12f;
     const float rn = 1.0f / fmaxf(nrm, 1e-12f);
 #pragma unroll
-    for (int d = 0; d < DT; ++d) dot += (x[d] * rn) * (acc[d][r] * mul);
+    for (int d = 0; d < DT; ++d) dot += (x[r][d] * rn) * (acc[d][r] * mul);
 #pragma unroll
     for (int o = 1; o < 16; o <<= 1) dot += __shfl_xor(dot, o, 64);
-    if (valid && c == 0) dotsum += dot;
     if (clamped) dot = 0.f;
     if (valid) {
 #pragma unroll
       for (int d = 0; d < DT; ++d)
-        st1(dst, ct_traits<CT>::dtype, tok * ld + dcol + d * 16 + c, rn * (acc[d][r] * mul - (x[d] * rn) * dot));
+        st1(dst, ct_traits<CT>::dtype, tok * ld + dcol + d * 16 + c, rn * (acc[d][r] * mul - (x[r][d] * rn) * dot));
     }
   }
-  return dotsum;
 }
 
 // ---- backward, kernel 1 of 2: dQ, d bias-table, d logit_scale.  Queries on lane columns (S^T tiles); K (normalised) and V in LDS.
@@ -187,10 +199,11 @@ __device__ __forceinline__ void attn_bwd_dq_body(const AttnArgs& p) {
 
   const int win = blockIdx.x, h = blockIdx.y;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int nthr = blockDim.x, nwv = nthr >> 6;   // 1, 2 or 4 waves per (window, head): small windows leave waves idle otherwise
   const int ld = 3 * p.C, g = lane >> 4, lc = lane & 15;
 
-  for (int i = tid; i < TS; i += 256) { tab[i] = p.bias_table[h * TS + i]; dtab[i] = 0.0; }
-  for (int i = tid; i < NP; i += 256) { rid[i] = pos_info(p, win, i, N); tok[i] = i < N ? win_token(p, win, i) : 0; }
+  for (int i = tid; i < TS; i += nthr) { tab[i] = p.bias_table[h * TS + i]; dtab[i] = 0.0; }
+  for (int i = tid; i < NP; i += nthr) { rid[i] = pos_info(p, win, i, N); tok[i] = i < N ? win_token(p, win, i) : 0; }
   __syncthreads();
   stage_rows<CT, HD, NP>(X, p.qkv, ld, p.C + h * HD, tok, N, true, tid);
   stage_rows<CT, HD, NP>(Y, p.qkv, ld, 2 * p.C + h * HD, tok, N, false, tid);
@@ -203,31 +216,33 @@ __device__ __forceinline__ void attn_bwd_dq_body(const AttnArgs& p) {
   // cancellation back:  Σ_k P (dP - D) cos = Σ_k dS·cos + (delta - D)·B.
   float dls = 0.f;
 
-  for (int qb = wave; qb * 16 < N; qb += 4) {
+  for (int qb = wave; qb * 16 < N; qb += nwv) {
     const int q0 = qb * 16;
+    // every global load of the query block goes out first (q, dO, O here; lse and the epilogue's rows below): interleaved with
+    // their consumers they were dependent round trips
     Frag<CT> qf[KS], gf[KS];
-    load_rows_frag<CT, HD>(qf, p.qkv, ld, h * HD, tok, q0, N, true, lane);
+    float qv[KS][8], dov[KS][8], ov[KS][8];
+    load_rows_f32<CT, HD>(qv, p.qkv, ld, h * HD, tok, q0, N, lane);
+    load_rows_f32<CT, HD>(dov, p.dout, p.C, h * HD, tok, q0, N, lane);
+    load_rows_f32<CT, HD>(ov, p.ofwd, p.C, h * HD, tok, q0, N, lane);
+    float xq[4][DT];
+    normalize_bwd_load<CT, HD>(xq, p.qkv, ld, h * HD, tok, q0, N, lane);
+    rows_to_frag<CT, HD>(qf, qv, true);
     float accD = 0.f, accB = 0.f;
     float delta = 0.f;
-    {
-      float dov[KS][8], ov[KS][8];
-      load_rows_f32<CT, HD>(dov, p.dout, p.C, h * HD, tok, q0, N, lane);
-      load_rows_f32<CT, HD>(ov, p.ofwd, p.C, h * HD, tok, q0, N, lane);
 #pragma unroll
-      for (int kk = 0; kk < KS; ++kk) {
+    for (int kk = 0; kk < KS; ++kk) {
 #pragma unroll
-        for (int j = 0; j < 8; ++j) delta += dov[kk][j] * ov[kk][j];
-        gf[kk] = frag_from_f32<CT>(dov[kk]);
-      }
-      delta += __shfl_xor(delta, 16, 64);
-      delta += __shfl_xor(delta, 32, 64);
+      for (int j = 0; j < 8; ++j) delta += dov[kk][j] * ov[kk][j];
+      gf[kk] = frag_from_f32<CT>(dov[kk]);
     }
+    delta += __shfl_xor(delta, 16, 64);
+    delta += __shfl_xor(delta, 32, 64);
     const int q = q0 + lc;
     const bool qvalid = q < N;
     const int qinfo = rid[min(q, NP - 1)];
     const int qoff = (qinfo & 0xfffff) + cen, qrid = qinfo >> 20;
     const float qlse = qvalid ? p.lse[((size_t)win * p.heads + h) * N + q] : 3.0e38f;
-
     f32x4_t dq[DT];
 #pragma unroll
     for (int d = 0; d < DT; ++d) dq[d] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
@@ -282,14 +297,18 @@ __device__ __forceinline__ void attn_bwd_dq_body(const AttnArgs& p) {
     accD += __shfl_xor(accD, 16, 64); accD += __shfl_xor(accD, 32, 64);
     accB += __shfl_xor(accB, 16, 64); accB += __shfl_xor(accB, 32, 64);
     if (g == 0 && qvalid) dls = fmaf(delta - accD, accB, dls);
-    normalize_bwd_store<CT, HD>(dq, scale, p.qkv, ld, h * HD, p.out, h * HD, tok, q0, N, lane);
+    normalize_bwd_store<CT, HD>(dq, scale, xq, ld, p.out, h * HD, tok, q0, N, lane);
   }
   // d/dls [cos * exp(ls)] = cos * scale  (0 when clamped at ln 100, HF:416)
   dls = wave_sum(dls);
   if (lane == 0) red[wave] = dls;
   __syncthreads();
-  for (int i = tid; i < TS; i += 256) atomicAdd(&p.dbias_table[h * TS + i], (float)dtab[i]);
-  if (tid == 0 && p.logit_scale[h] <= 4.605170185988092f) atomicAdd(&p.dlogit_scale[h], (red[0] + red[1] + red[2] + red[3]) * scale);
+  for (int i = tid; i < TS; i += nthr) atomicAdd(&p.dbias_table[h * TS + i], (float)dtab[i]);
+  if (tid == 0 && p.logit_scale[h] <= 4.605170185988092f) {
+    float tot = 0.f;
+    for (int w = 0; w < nwv; ++w) tot += red[w];
+    atomicAdd(&p.dlogit_scale[h], tot * scale);
+  }
 }
 
 // ---- backward, kernel 2 of 2: dK, dV.  Keys on lane columns (S tiles); Q (normalised) and dO in LDS.
@@ -310,10 +329,11 @@ __device__ __forceinline__ void attn_bwd_dkv_body(const AttnArgs& p) {
 
   const int win = blockIdx.x, h = blockIdx.y;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int nthr = blockDim.x, nwv = nthr >> 6;   // 1, 2 or 4 waves per (window, head): small windows leave waves idle otherwise
   const int ld = 3 * p.C, g = lane >> 4, lc = lane & 15;
 
-  for (int i = tid; i < TS; i += 256) tab[i] = p.bias_table[h * TS + i];
-  for (int i = tid; i < NP; i += 256) {
+  for (int i = tid; i < TS; i += nthr) tab[i] = p.bias_table[h * TS + i];
+  for (int i = tid; i < NP; i += nthr) {
     rid[i] = pos_info(p, win, i, N);
     tok[i] = i < N ? win_token(p, win, i) : 0;
     lse[i] = i < N ? p.lse[((size_t)win * p.heads + h) * N + i] : 3.0e38f;
@@ -321,7 +341,7 @@ __device__ __forceinline__ void attn_bwd_dkv_body(const AttnArgs& p) {
   __syncthreads();
   stage_rows<CT, HD, NP>(X, p.qkv, ld, h * HD, tok, N, true, tid);
   // dO -> LDS and delta[n] = Σ_d dO[n][d]·O[n][d] in the same pass (CPR lanes per row)
-  for (int c = tid; c < NP * CPR; c += 256) {
+  for (int c = tid; c < NP * CPR; c += nthr) {
     const int n = c / CPR, d8 = (c % CPR) * 8;
     float v[8], o[8];
 #pragma unroll
@@ -343,11 +363,15 @@ __device__ __forceinline__ void attn_bwd_dkv_body(const AttnArgs& p) {
   const float scale = __expf(fminf(p.logit_scale[h], 4.605170185988092f));
   const int cen = (ws - 1) * TW + ws - 1;
 
-  for (int kb = wave; kb * 16 < N; kb += 4) {
+  for (int kb = wave; kb * 16 < N; kb += nwv) {
     const int k0 = kb * 16;
     Frag<CT> kf[KS], vf[KS];
-    load_rows_frag<CT, HD>(kf, p.qkv, ld, p.C + h * HD, tok, k0, N, true, lane);
-    load_rows_frag<CT, HD>(vf, p.qkv, ld, 2 * p.C + h * HD, tok, k0, N, false, lane);
+    float kv[KS][8], vv[KS][8], xk[4][DT];
+    load_rows_f32<CT, HD>(kv, p.qkv, ld, p.C + h * HD, tok, k0, N, lane);
+    load_rows_f32<CT, HD>(vv, p.qkv, ld, 2 * p.C + h * HD, tok, k0, N, lane);
+    normalize_bwd_load<CT, HD>(xk, p.qkv, ld, p.C + h * HD, tok, k0, N, lane);
+    rows_to_frag<CT, HD>(kf, kv, true);
+    rows_to_frag<CT, HD>(vf, vv, false);
     const int key = k0 + lc;
     const bool kvalid = key < N;
     const int kinfo = rid[min(key, NP - 1)];
@@ -402,7 +426,7 @@ __device__ __forceinline__ void attn_bwd_dkv_body(const AttnArgs& p) {
         for (int d = 0; d < DT; ++d) st1(p.out, ct_traits<CT>::dtype, base + d * 16, dv[d][r]);
       }
     }
-    normalize_bwd_store<CT, HD>(dk, scale, p.qkv, ld, p.C + h * HD, p.out, p.C + h * HD, tok, k0, N, lane);
+    normalize_bwd_store<CT, HD>(dk, scale, xk, ld, p.out, p.C + h * HD, tok, k0, N, lane);
   }
 }
 
@@ -427,7 +451,12 @@ static int launch_attn(const AttnArgs& a, int nwin, bool bwd, hipStream_t s) {
   if (bwd) sh = sh_dq > sh_dkv ? sh_dq : sh_dkv;
   else sh += TSP * sizeof(float) + 2 * NP * sizeof(int);
   if (sh > 160 * 1024) return SCOT_ERR_UNSUPPORTED;
-  dim3 grid(nwin, a.heads), block(256);
+  // waves per workgroup: a 4x4 window has ONE 16-query block — with 4 waves per workgroup three of them only held wave slots and
+  // the 3072-workgroup grid needed three rounds of its ~10 us latency chain
+  static int nw_env = -1;
+  if (nw_env < 0) { const char* e = getenv("SCOT_ATTN_NW"); nw_env = e ? atoi(e) : 0; }
+  const int nw = nw_env > 0 ? nw_env : (NT <= 2 ? 1 : 4);   // measured (bwd, cold): 4x4 windows 22 vs 33 us with 1 wave; 8x8 windows best with 4
+  dim3 grid(nwin, a.heads), block(64 * nw);
   if (bwd) {
     if (sh > 64 * 1024) (void)hipFuncSetAttribute((const void*)attn_bwd_kernel<CT, HD, NT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh);
     hipLaunchKernelGGL((attn_bwd_kernel<CT, HD, NT>), dim3(nwin, a.heads, 2), block, sh, s, a);

@@ -78,7 +78,7 @@ def main():
         us = timeit(lambda: ops.cln_bwd(out, x, mean, rstd, t, ps[0], ps[1], dx, gr[0], gr[1], gr[2], gr[3], rows, L, C))
         print(f"cln_bwd rows={rows} C={C}: {us:7.1f} us  {(2*4+2)*rows*C/us/1e3:6.0f} GB/s")
     # attention
-    for (Hp, C, heads, ws, shift) in ([(32, 96, 3, 16, 8)] if only == "attn" else [] if only else
+    for (Hp, C, heads, ws, shift) in ([(32, 96, 3, 16, 8)] if only == "attn" else [(4, 768, 24, 4, 0), (8, 384, 12, 8, 0)] if only == "attn3" else [] if only else
                                       [(32, 96, 3, 16, 8), (16, 192, 6, 16, 0), (8, 384, 12, 8, 0), (4, 768, 24, 4, 0)]):
         Lp = Hp * Hp
         qkv = torch.randn(B * Lp, 3 * C, device="cuda").to(torch.bfloat16)
