@@ -51,6 +51,7 @@ class ScOTEngine:
         # arguments + the host-side stream/event operations between them), later steps replay the list: ~2500 launches per
         # step cost ~10 us of Python each when issued through the op wrappers, ~1.5 us when replayed.
         self.tape_mode = os.environ.get("SCOT_TAPE", "1") == "1"
+        self.tape_max = max(1, int(os.environ.get("SCOT_TAPE_MAX", "2")))
         self._rec = None
         self._rec_keep = None
         self._taped = {}
@@ -629,8 +630,13 @@ class ScOTEngine:
                None if pixel_mask is None else (tuple(pixel_mask.shape), pixel_mask.dtype), torch.cuda.current_stream().cuda_stream)
         ent = self._taped.get(key)
         if ent is None:
+            # a recorded step pins all of its buffers (GBs): keep at most `tape_max` signatures (e.g. the full batch and the
+            # epoch's short last batch); the least recently used one is dropped, its buffers go back to the allocator
+            while len(self._taped) >= self.tape_max:
+                self._taped.pop(next(iter(self._taped)))
             self._taped[key] = dict(state="warm")
             return self._forward(pixel_values, time, labels, pixel_mask, train)
+        self._taped[key] = self._taped.pop(key)   # most recently used last
         ins = (pixel_values, time, labels, pixel_mask)
         if ent["state"] == "ready":
             for dst, src in zip(ent["in"], ins):
