@@ -72,20 +72,6 @@ __device__ __forceinline__ void fload(uint4 (&st)[NCH], const CT* __restrict__ s
   }
 }
 
-__device__ __forceinline__ uint4 gelu_chunk(uint4 u, bf16_t) {
-  uint32_t w[4] = {u.x, u.y, u.z, u.w};
-#pragma unroll
-  for (int j = 0; j < 4; ++j) {
-    const float lo = gelu_f(__uint_as_float(w[j] << 16)), hi = gelu_f(__uint_as_float(w[j] & 0xffff0000u));
-    w[j] = pack_bf16x2(lo, hi);
-  }
-  return make_uint4(w[0], w[1], w[2], w[3]);
-}
-__device__ __forceinline__ uint4 gelu_chunk(uint4 u, float) {
-  return make_uint4(__float_as_uint(gelu_f(__uint_as_float(u.x))), __float_as_uint(gelu_f(__uint_as_float(u.y))),
-                    __float_as_uint(gelu_f(__uint_as_float(u.z))), __float_as_uint(gelu_f(__uint_as_float(u.w))));
-}
-
 template <typename CT, int R, bool KC, int BKT, int NCH>
 __device__ __forceinline__ void fstore(CT* tile, const uint4 (&st)[NCH], int k0, int kend, int tid) {
   using T = FTile<CT, R, KC, BKT>;
@@ -315,209 +301,6 @@ __global__ __launch_bounds__(256) void gemm_fast_kernel(FastArgs p) {
   }
 }
 
-// ---------------------------------------------------------------------------------------------------------------
-// Persistent variant for NT / NN (forward and dgrad): M is huge (tokens) and K is tiny (96..768), so a workgroup that
-// computes ONE 64x64 tile spends most of its life waiting for its first K-tile and for its epilogue.  Here a workgroup
-// walks several M-tiles of one N-column: the loads of the NEXT tile's first two K-tiles are issued before the epilogue
-// of the current tile (so HBM latency hides behind the LDS round trip + stores), and when the whole K fits the two LDS
-// stages (K <= 2·BK, every stage-0 GEMM of Poseidon-B) the weight tiles stay resident in LDS for all M-tiles.
-// LDS map: [A stage0][A stage1][B stage0][B stage1]; the fp32 C tile of the epilogue aliases the two A stages only.
-template <typename CT, int LAYOUT>
-__global__ __launch_bounds__(256) void gemm_persist_kernel(FastArgs p) {
-  constexpr int BM = 64, BN = 64;
-  constexpr bool B_KC = (LAYOUT == LAYOUT_NT);
-  using TA = FTile<CT, BM, true>;
-  using TB = FTile<CT, BN, B_KC>;
-  constexpr int BK = FT<CT>::BK;
-  constexpr int MI = BM / 32, NI = BN / 32;
-  constexpr int CP = BN + 4;
-  constexpr size_t LDS_A = 2 * TA::elems * sizeof(CT), LDS_B = 2 * TB::elems * sizeof(CT);
-  constexpr size_t LDS_C = (size_t)BM * CP * sizeof(float) + BN * sizeof(float);
-  static_assert(LDS_C <= LDS_A, "C tile must fit in the A stages");
-  __shared__ __attribute__((aligned(16))) char smem[LDS_A + LDS_B];
-  CT* As0 = (CT*)smem;
-  CT* As1 = As0 + TA::elems;
-  CT* Bs0 = (CT*)(smem + LDS_A);
-  CT* Bs1 = Bs0 + TB::elems;
-  float* Cs = (float*)smem;
-  float* colacc = Cs + BM * CP;
-
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int wr = wave >> 1, wc = wave & 1, g = lane >> 4;
-  const int n0 = blockIdx.x * BN;
-  const int K = p.K;
-  const int nk = (K + BK - 1) / BK;
-  const int mtiles = (p.M + BM - 1) / BM;
-  const bool b_resident = nk <= 2;
-  const CT* A = (const CT*)p.A;
-  const CT* B = (const CT*)p.B;
-  const bool want_colsum = p.colsum_out != nullptr;
-
-  constexpr int CPRW = BN / 8;
-  const int cc = tid % CPRW;
-  const int col = n0 + cc * 8;
-  float bv[8], sv[8], csum[8];
-#pragma unroll
-  for (int j = 0; j < 8; ++j) {
-    const bool ok = col + j < p.N;
-    bv[j] = (p.bias && ok) ? p.bias[col + j] : 0.f;
-    sv[j] = (p.colscale && ok) ? p.colscale[col + j] : 1.f;
-    csum[j] = 0.f;
-  }
-
-  uint4 ra0[TA::per_thread], rb0[TB::per_thread], ra1[TA::per_thread], rb1[TB::per_thread];
-  int mt = blockIdx.y;
-  bool first = true;
-  if (mt < mtiles) {
-    fload<CT, BM, true, FT<CT>::BK>(ra0, A, p.lda, mt * BM, p.M, 0, K, tid);
-    fload<CT, BN, B_KC, FT<CT>::BK>(rb0, B, p.ldb, n0, p.N, 0, K, tid);
-    if (nk > 1) {
-      fload<CT, BM, true, FT<CT>::BK>(ra1, A, p.lda, mt * BM, p.M, BK, K, tid);
-      fload<CT, BN, B_KC, FT<CT>::BK>(rb1, B, p.ldb, n0, p.N, BK, K, tid);
-    }
-  }
-  for (; mt < mtiles; mt += gridDim.y) {
-    const int m0 = mt * BM;
-    const bool loadB = first || !b_resident;
-    f32x4_t acc[MI][NI];
-#pragma unroll
-    for (int i = 0; i < MI; ++i)
-#pragma unroll
-      for (int j = 0; j < NI; ++j) acc[i][j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
-
-    fstore<CT, BM, true, FT<CT>::BK>(As0, ra0, 0, K, tid);
-    if (loadB) fstore<CT, BN, B_KC, FT<CT>::BK>(Bs0, rb0, 0, K, tid);
-    __syncthreads();
-
-    auto compute = [&](const CT* As, const CT* Bs) {
-#pragma unroll
-      for (int kk = 0; kk < BK; kk += 32) {
-        Frag<CT> fa[MI], fb[NI];
-#pragma unroll
-        for (int i = 0; i < MI; ++i) fa[i] = lds_frag_kc(As, TA::pitch, wr * (BM / 2) + i * 16, kk, lane);
-#pragma unroll
-        for (int j = 0; j < NI; ++j) {
-          const int c0 = wc * (BN / 2) + j * 16;
-          if (B_KC) fb[j] = lds_frag_kc(Bs, TB::pitch, c0, kk, lane);
-          else fb[j] = lds_frag_ks(Bs, TB::pitch, c0, kk + g * 8, kk + g * 8 + 4, lane, p.use_tr);
-        }
-#pragma unroll
-        for (int i = 0; i < MI; ++i)
-#pragma unroll
-          for (int j = 0; j < NI; ++j) mma16(acc[i][j], fa[i], fb[j]);
-      }
-    };
-
-    for (int t = 0; t < nk; t += 2) {
-      if (t + 2 < nk) {
-        fload<CT, BM, true, FT<CT>::BK>(ra0, A, p.lda, m0, p.M, (t + 2) * BK, K, tid);
-        if (loadB) fload<CT, BN, B_KC, FT<CT>::BK>(rb0, B, p.ldb, n0, p.N, (t + 2) * BK, K, tid);
-      }
-      compute(As0, Bs0);
-      if (t + 1 < nk) {
-        fstore<CT, BM, true, FT<CT>::BK>(As1, ra1, (t + 1) * BK, K, tid);
-        if (loadB) fstore<CT, BN, B_KC, FT<CT>::BK>(Bs1, rb1, (t + 1) * BK, K, tid);
-      }
-      __syncthreads();
-      if (t + 1 >= nk) break;
-      if (t + 3 < nk) {
-        fload<CT, BM, true, FT<CT>::BK>(ra1, A, p.lda, m0, p.M, (t + 3) * BK, K, tid);
-        if (loadB) fload<CT, BN, B_KC, FT<CT>::BK>(rb1, B, p.ldb, n0, p.N, (t + 3) * BK, K, tid);
-      }
-      compute(As1, Bs1);
-      if (t + 2 < nk) {
-        fstore<CT, BM, true, FT<CT>::BK>(As0, ra0, (t + 2) * BK, K, tid);
-        if (loadB) fstore<CT, BN, B_KC, FT<CT>::BK>(Bs0, rb0, (t + 2) * BK, K, tid);
-      }
-      __syncthreads();
-    }
-
-    // prefetch the next M-tile's first two K-tiles; they land while this tile's epilogue runs
-    const int mnext = mt + gridDim.y;
-    if (mnext < mtiles) {
-      const bool nextB = !b_resident;
-      fload<CT, BM, true, FT<CT>::BK>(ra0, A, p.lda, mnext * BM, p.M, 0, K, tid);
-      if (nextB) fload<CT, BN, B_KC, FT<CT>::BK>(rb0, B, p.ldb, n0, p.N, 0, K, tid);
-      if (nk > 1) {
-        fload<CT, BM, true, FT<CT>::BK>(ra1, A, p.lda, mnext * BM, p.M, BK, K, tid);
-        if (nextB) fload<CT, BN, B_KC, FT<CT>::BK>(rb1, B, p.ldb, n0, p.N, BK, K, tid);
-      }
-    }
-    first = false;
-
-    // epilogue through LDS (aliases the A stages; all waves are past the last compute because of the loop's barrier)
-#pragma unroll
-    for (int i = 0; i < MI; ++i)
-#pragma unroll
-      for (int j = 0; j < NI; ++j)
-#pragma unroll
-        for (int r = 0; r < 4; ++r)
-          Cs[(wr * (BM / 2) + i * 16 + g * 4 + r) * CP + wc * (BN / 2) + j * 16 + (lane & 15)] = acc[i][j][r];
-    __syncthreads();
-    if (col < p.N) {
-      for (int row = tid / CPRW; row < BM; row += 256 / CPRW) {
-        const int grow = m0 + row;
-        if (grow >= p.M) break;
-        float v[8];
-        const float4 a = *(const float4*)(Cs + row * CP + cc * 8), b = *(const float4*)(Cs + row * CP + cc * 8 + 4);
-        v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
-#pragma unroll
-        for (int j = 0; j < 8; ++j) v[j] = (v[j] + bv[j]) * sv[j];
-        if (p.aux_gelu_grad) {
-          float x[8];
-          ld8(p.aux, p.aux_dt, (size_t)grow * p.ldaux + col, x);
-#pragma unroll
-          for (int j = 0; j < 8; ++j) v[j] *= p.aux_mul ? x[j] : gelu_grad_f(x[j]);
-        }
-        if (p.resid) {
-          float x[8];
-          ld8(p.resid, p.res_dt, (size_t)grow * p.ldres + col, x);
-#pragma unroll
-          for (int j = 0; j < 8; ++j) v[j] += x[j];
-        }
-        if (p.C2) {
-          float gv[8], gd[8];
-#pragma unroll
-          for (int j = 0; j < 8; ++j) { float cdf, e; gelu_terms(v[j], cdf, e); gv[j] = v[j] * cdf; gd[j] = cdf + v[j] * 0.3989422804014327f * e; }
-          st8(p.C, p.c_dt, (size_t)grow * p.ldc + col, gv);
-          if (p.C2 != p.C) st8(p.C2, p.c_dt, (size_t)grow * p.ldc + col, gd);
-        } else {
-          st8(p.C, p.c_dt, (size_t)grow * p.ldc + col, v);
-        }
-        if (want_colsum) {
-#pragma unroll
-          for (int j = 0; j < 8; ++j) csum[j] += v[j];
-        }
-      }
-    }
-    __syncthreads();  // C tile consumed before the next tile's A stage is written
-  }
-  if (want_colsum) {
-    if (tid < BN) colacc[tid] = 0.f;
-    __syncthreads();
-    if (col < p.N) {
-#pragma unroll
-      for (int j = 0; j < 8; ++j) atomicAdd(&colacc[cc * 8 + j], csum[j]);
-    }
-    __syncthreads();
-    if (tid < BN && n0 + tid < p.N) atomicAdd(&p.colsum_out[n0 + tid], colacc[tid]);
-  }
-}
-
-template <typename CT>
-static int flaunch_persist(const FastArgs& a, int layout, hipStream_t s) {
-  const int ntn = (a.N + 63) / 64, mtiles = (a.M + 63) / 64;
-  static int target = -1;
-  if (target < 0) { const char* e = getenv("SCOT_GEMM_PERSIST_WGS"); target = e ? atoi(e) : 512; }
-  int gy = target / ntn;   // resident workgroups chip-wide (2 per CU at this kernel's register budget)
-  if (gy < 1) gy = 1;
-  if (gy > mtiles) gy = mtiles;
-  dim3 grid(ntn, gy, 1), block(256);
-  if (layout == LAYOUT_NT) hipLaunchKernelGGL((gemm_persist_kernel<CT, LAYOUT_NT>), grid, block, 0, s, a);
-  else hipLaunchKernelGGL((gemm_persist_kernel<CT, LAYOUT_NN>), grid, block, 0, s, a);
-  return scot_check_launch();
-}
-
 // Σ_z ws[z][e .. e+7]: ZL consecutive lanes share one 8-float group and take every ZL-th partial (independent loads,
 // unrolled), then fold with shuffles.  (One thread per group walking all partials in turn was a chain of `nsplit`
 // dependent L2 round trips: 36 us for a 96x96 gradient with 64 partials.)
@@ -737,10 +520,6 @@ int scot_gemm_fast(int layout, int compute, int M, int N, int K, const void* A, 
       }
     }
   }
-  static int persist = -1;
-  if (persist < 0) { const char* e = getenv("SCOT_GEMM_PERSIST"); persist = e ? atoi(e) : 0; }   // measured: no gain (kept for experiments)
-  if (layout != LAYOUT_TN && tile == 0 && persist && nsplit == 1)
-    return compute == SCOT_BF16 ? flaunch_persist<bf16_t>(a, layout, stream) : flaunch_persist<float>(a, layout, stream);
   int rc = compute == SCOT_BF16 ? flaunch_tile<bf16_t>(tile, a, layout, nsplit, stream) : flaunch_tile<float>(tile, a, layout, nsplit, stream);
   if (rc == SCOT_OK && a.ws) {
     const size_t n8 = (size_t)M * N / 8;

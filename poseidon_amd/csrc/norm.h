@@ -10,8 +10,7 @@ struct ClnFastArgs {
   float eps;
   const void* dout; void* dx; int dout_dt, dx_dt;
   float* d_gw_w; float* d_gw_b; float* d_bw_w; float* d_bw_b; float* d_xbias;
-  int rpb, chunks_per_sample;
-  float* partials;   // optional [nblocks][3][C] scratch: per-block column sums, combined by cln_bwd_finalize_kernel
+  int rpb, chunks_per_sample, nwv;
   const float* sscale;   // optional per-sample scale of the normed branch (DropPath), see norm.hip
   int mode;              // backward: 0 = dx + parameter gradients, 1 = dx only, 2 = parameter gradients only
 };

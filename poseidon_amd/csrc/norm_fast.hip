@@ -67,13 +67,15 @@ __global__ __launch_bounds__(256) void cln_fwd_fast_kernel(ClnFastArgs p) {
 
 // MODE 0: dx and the parameter gradients;  1: dx only (the dependent chain's half: a pure stream, no reductions over rows);
 // 2: parameter gradients only (no row statistics needed: Σ dout·xhat, Σ dout) — the engine runs this half on the side stream.
-template <int LPR, int CPL, int MODE>
-__global__ __launch_bounds__(256) void cln_bwd_fast_kernel(ClnFastArgs p) {
+// NWV = waves per block (4 or 8).  Every block ends in 4-5 global atomics per column, so with many rows (stages 0/1) twice the
+// waves per block = half the blocks = half the atomics at the same number of rows per wave.
+template <int LPR, int CPL, int MODE, int NWV>
+__global__ __launch_bounds__(NWV * 64) void cln_bwd_fast_kernel(ClnFastArgs p) {
   constexpr int RPW = 64 / LPR;
   constexpr int NCOL = LPR * CPL * 8;      // columns covered (>= C)
-  // [dgamma | dbeta | dxsum][j][chunk] for column chunk*8 + j: lanes of one ds_add hit consecutive banks (the natural
-  // [col] order put the 64 lanes 8 floats apart: 8-16-way bank conflicts, 15 us of a 24 us kernel at C = 768)
-  __shared__ float red[3][NCOL];
+  // [copy][dgamma | dbeta | dxsum][j][chunk] for column chunk*8 + j (chunk-major within j: the lanes of one access hit
+  // consecutive banks); waves 0-3 combine into copy 0, waves 4-7 into copy 1
+  __shared__ float red[NWV / 4][3][NCOL];
   constexpr int NCH = NCOL / 8;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int sub = lane / LPR, l = lane % LPR;
@@ -118,12 +120,12 @@ __global__ __launch_bounds__(256) void cln_bwd_fast_kernel(ClnFastArgs p) {
       }
     }
   };
-  int r = r0 + wave * RPW + sub;
+  int r = r0 + wave * RPW + sub;   // wave < NWV
   if (r < r1) load_row(r, d, xr, mean, rstd);
-  for (; r < r1; r += 4 * RPW) {
+  for (; r < r1; r += NWV * RPW) {
     // (an unconditional prefetch — re-reading the last row — was tried so that the compiler can count loads in flight:
     // the extra row costs more than the tighter waits save when a block only makes 2-8 passes)
-    const int rn = r + 4 * RPW;
+    const int rn = r + NWV * RPW;
     if (rn < r1) load_row(rn, dn, xn, mean_n, rstd_n);
     const size_t base = (size_t)(b * p.rows_per_sample + r) * C;
     float xh[CPL][8];
@@ -171,67 +173,28 @@ __global__ __launch_bounds__(256) void cln_bwd_fast_kernel(ClnFastArgs p) {
         ag[i][j] += __shfl_xor(ag[i][j], o, 64); ab[i][j] += __shfl_xor(ab[i][j], o, 64); ax[i][j] += __shfl_xor(ax[i][j], o, 64);
       }
     }
+  float (*rc)[NCOL] = red[wave >> 2];
   for (int w = 0; w < 4; ++w) {
-    if (wave == w && sub == 0) {
+    if ((wave & 3) == w && sub == 0) {
 #pragma unroll
       for (int i = 0; i < CPL; ++i)
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
           const int c = j * NCH + l + i * LPR;
-          if (w == 0) { red[0][c] = ag[i][j]; red[1][c] = ab[i][j]; red[2][c] = ax[i][j]; }
-          else { red[0][c] += ag[i][j]; red[1][c] += ab[i][j]; red[2][c] += ax[i][j]; }
+          if (w == 0) { rc[0][c] = ag[i][j]; rc[1][c] = ab[i][j]; rc[2][c] = ax[i][j]; }
+          else { rc[0][c] += ag[i][j]; rc[1][c] += ab[i][j]; rc[2][c] += ax[i][j]; }
         }
     }
     __syncthreads();
   }
-  if (p.partials) {   // no global atomics: 4·C same-address atomics per block were the whole cost of this kernel (25 us floor)
-    float* dst = p.partials + (size_t)blockIdx.x * 3 * C;
-    for (int c = threadIdx.x; c < C; c += 256) {
-      const int k = (c & 7) * NCH + (c >> 3);
-      dst[c] = red[0][k]; dst[C + c] = red[1][k]; dst[2 * C + c] = red[2][k];
-    }
-    return;
-  }
-  for (int c = threadIdx.x; c < C; c += 256) {
+  for (int c = threadIdx.x; c < C; c += NWV * 64) {
     const int k = (c & 7) * NCH + (c >> 3);
-    const float dg = red[0][k], db = red[1][k];
+    float dg = red[0][0][k], db = red[0][1][k], dxs = red[0][2][k];
+    if (NWV == 8) { dg += red[NWV / 4 - 1][0][k]; db += red[NWV / 4 - 1][1][k]; dxs += red[NWV / 4 - 1][2][k]; }
     if (p.d_gw_w) { atomicAdd(&p.d_gw_w[c], t * dg); atomicAdd(&p.d_bw_w[c], t * db); }
     atomicAdd(&p.d_gw_b[c], dg);
     atomicAdd(&p.d_bw_b[c], db);
-    if (p.d_xbias) atomicAdd(&p.d_xbias[c], red[2][k]);
-  }
-}
-
-// workgroup = 32 columns x 8 slices of the block list; every thread sums its slice (independent, coalesced loads), the 8
-// slices are combined through LDS and the column owner adds into the parameter gradients (single writer, no atomics)
-__global__ __launch_bounds__(256) void cln_bwd_finalize_kernel(ClnFastArgs p, int nblocks) {
-  __shared__ float red[5][8][32];
-  const int lc = threadIdx.x & 31, part = threadIdx.x >> 5;
-  const int c = blockIdx.x * 32 + lc;
-  float gw = 0.f, gb = 0.f, bw = 0.f, bb = 0.f, xb = 0.f;
-  if (c < p.C) {
-#pragma unroll 4
-    for (int blk = part; blk < nblocks; blk += 8) {
-      const float* src = p.partials + (size_t)blk * 3 * p.C;
-      const float t = p.time ? p.time[blk / p.chunks_per_sample] : 0.f;
-      const float dg = src[c], db = src[p.C + c];
-      gw += t * dg; gb += dg; bw += t * db; bb += db; xb += src[2 * p.C + c];
-    }
-  }
-  red[0][part][lc] = gw; red[1][part][lc] = gb; red[2][part][lc] = bw; red[3][part][lc] = bb; red[4][part][lc] = xb;
-  __syncthreads();
-  if (part == 0 && c < p.C) {
-    float v[5];
-#pragma unroll
-    for (int k = 0; k < 5; ++k) {
-      v[k] = 0.f;
-#pragma unroll
-      for (int q = 0; q < 8; ++q) v[k] += red[k][q][lc];
-    }
-    if (p.d_gw_w) { p.d_gw_w[c] += v[0]; p.d_bw_w[c] += v[2]; }
-    p.d_gw_b[c] += v[1];
-    p.d_bw_b[c] += v[3];
-    if (p.d_xbias) p.d_xbias[c] += v[4];
+    if (p.d_xbias) atomicAdd(&p.d_xbias[c], dxs);
   }
 }
 
@@ -240,10 +203,11 @@ template <int LPR, int CPL> static void launch_fwd(const ClnFastArgs& a, hipStre
   hipLaunchKernelGGL((cln_fwd_fast_kernel<LPR, CPL>), dim3((a.rows + rpb - 1) / rpb), dim3(256), 0, s, a);
 }
 template <int LPR, int CPL> static void launch_bwd(const ClnFastArgs& a, hipStream_t s) {
-  const dim3 grid((a.rows / a.rows_per_sample) * a.chunks_per_sample), block(256);
-  if (a.mode == 1) hipLaunchKernelGGL((cln_bwd_fast_kernel<LPR, CPL, 1>), grid, block, 0, s, a);
-  else if (a.mode == 2) hipLaunchKernelGGL((cln_bwd_fast_kernel<LPR, CPL, 2>), grid, block, 0, s, a);
-  else hipLaunchKernelGGL((cln_bwd_fast_kernel<LPR, CPL, 0>), grid, block, 0, s, a);
+  const dim3 grid((a.rows / a.rows_per_sample) * a.chunks_per_sample);
+  if (a.mode == 1) hipLaunchKernelGGL((cln_bwd_fast_kernel<LPR, CPL, 1, 4>), grid, dim3(256), 0, s, a);
+  else if (a.mode == 2) hipLaunchKernelGGL((cln_bwd_fast_kernel<LPR, CPL, 2, 4>), grid, dim3(256), 0, s, a);
+  else if (a.nwv == 8) hipLaunchKernelGGL((cln_bwd_fast_kernel<LPR, CPL, 0, 8>), grid, dim3(512), 0, s, a);
+  else hipLaunchKernelGGL((cln_bwd_fast_kernel<LPR, CPL, 0, 4>), grid, dim3(256), 0, s, a);
 }
 
 #define CLN_DISPATCH(FN)                                            \
@@ -279,24 +243,16 @@ int scot_cln_bwd_fast(ClnFastArgs a, void* workspace, size_t ws_bytes, hipStream
   if (blocks_env < 0) { const char* e = getenv("SCOT_CLN_BLOCKS"); blocks_env = e ? atoi(e) : 256; }
   int lpr = 1;
   while (lpr < 64 && lpr * 8 < a.C) lpr <<= 1;
-  const int rows_per_pass = 4 * (64 / lpr);
+  static int nwv_env = -1;
+  if (nwv_env < 0) { const char* e = getenv("SCOT_CLN_NWV"); nwv_env = e ? atoi(e) : 0; }
+  a.nwv = nwv_env ? nwv_env : ((a.mode == 0 && a.rows >= 16384) ? 8 : 4);
+  const int rows_per_pass = a.nwv * (64 / lpr);
   const int target_blocks = a.mode == 1 ? 2048 : blocks_env;   // dx only: nothing to flush per block, so many short blocks
   int rpb = rpb_env > 0 ? rpb_env : (a.rows / target_blocks) / rows_per_pass * rows_per_pass;
   if (rpb < 2 * rows_per_pass) rpb = 2 * rows_per_pass;
-  if (rpb_env <= 0 && rpb > 128) rpb = 128;
+  if (rpb_env <= 0 && rpb > 32 * a.nwv) rpb = 32 * a.nwv;
   a.rpb = a.rows_per_sample < rpb ? a.rows_per_sample : rpb;
   a.chunks_per_sample = (a.rows_per_sample + a.rpb - 1) / a.rpb;
-  const int nblocks = (a.rows / a.rows_per_sample) * a.chunks_per_sample;
-  // measured: per-block partials + a finalize pass (33 us) do not beat the fp32 atomics (28 us) — the kernel is bound by
-  // exposed row-load latency, not by the atomics; partials stay available for experiments (SCOT_CLN_PARTIALS=1)
-  static int use_partials = -1;
-  if (use_partials < 0) { const char* e = getenv("SCOT_CLN_PARTIALS"); use_partials = e ? atoi(e) : 0; }
-  a.partials = (use_partials && workspace && ws_bytes >= (size_t)nblocks * 3 * a.C * sizeof(float)) ? (float*)workspace : nullptr;
   CLN_DISPATCH(launch_bwd)
-  int rc = scot_check_launch();
-  if (rc == SCOT_OK && a.partials) {
-    hipLaunchKernelGGL(cln_bwd_finalize_kernel, dim3((a.C + 31) / 32), dim3(256), 0, s, a, nblocks);
-    rc = scot_check_launch();
-  }
-  return rc;
+  return scot_check_launch();
 }
