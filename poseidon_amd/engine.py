@@ -71,6 +71,7 @@ class ScOTEngine:
         self.tadt = torch.float32 if self.tcm == ops.F32 else torch.bfloat16
         self.grid, self.enc, self.dec = stage_plan(cfg)
         self.drop_rates = drop_path_rates(cfg)      # per-layer stochastic-depth rate (0 for the training recipe, train.py:262)
+        self.precision_probe = None                 # tools/probes: set of layer pieces run in fp32 during an inference forward
         self.drop_path_masks = None                 # tests: {(layer prefix, branch 0|1): [B] scale} instead of random draws
         self.cond = bool(cfg.use_conditioning)
         self._coords: Dict[int, torch.Tensor] = {}
@@ -423,6 +424,9 @@ class ScOTEngine:
             xp = x16
         wqkv = self.Wspan(a + "qkv_weight", 3 * C * C).view(3 * C, C)
         bqkv = self.arena.span(a + "qkv_bias", 3 * C) if cfg.qkv_bias else None
+        ex = self.precision_probe if (self.precision_probe and not train and not padded) else None
+        if ex:   # tools/probes/bf16_error_sources.py: selected pieces of an inference forward in fp32 (never on the product path)
+            return self._layer_fwd_probe(blk, x, x16, B, time, ex)
         qkv = self.new(B * Lp, 3 * C, dtype=self.adt)
         ops.linear_fwd(cm, xp, wqkv, qkv, bias=bqkv)
         tw = blk.table_window
@@ -471,6 +475,70 @@ class ScOTEngine:
         g2 = self.new(*g.shape)
         ops.linear_dgrad(cm, dy, w, g2, resid=g)
         return g2
+
+    def _layer_fwd_probe(self, blk, x, x16, B, time, ex):
+        """Inference forward of one ScOTLayer with chosen pieces in fp32 (ex: set of 'qkv', 'attn', 'proj', 'mlp'): measures
+        where the bf16 mode's error comes from.  Not used by any product path."""
+        cfg, cm = self.cfg, self.compute
+        H, W = blk.res
+        C, heads, pre = blk.dim, blk.heads, blk.prefix
+        ws, shift = blk.window_shift()
+        L = H * W
+        a = pre + ".attention.self."
+        f32 = torch.float32
+        bqkv = self.arena.span(a + "qkv_bias", 3 * C) if cfg.qkv_bias else None
+        qdt = f32 if ("attn" in ex or "qkv" in ex) else self.adt
+        qkv = self.new(B * L, 3 * C, dtype=qdt)
+        if "qkv" in ex:
+            ops.linear_fwd(ops.F32, x, self.arena.span(a + "qkv_weight", 3 * C * C).view(3 * C, C), qkv, bias=bqkv)
+        else:
+            ops.linear_fwd(cm, x16, self.Wspan(a + "qkv_weight", 3 * C * C).view(3 * C, C), qkv, bias=bqkv)
+        table = self.cpb_table(pre)
+        nW = (H // ws) * (W // ws)
+        lse = self.new(B * nW, heads, ws * ws)
+        if "attn" in ex:
+            if qkv.dtype != f32:
+                q2 = self.new(B * L, 3 * C)
+                ops.cast(qkv, q2)
+                qkv = q2
+            attn = self.new(B * L, C)
+            ops.window_attn_fwd(ops.F32, qkv, attn, lse, table, self.P(a + "logit_scale"), B, H, W, C, heads, ws, shift)
+        else:
+            if qkv.dtype != self.adt:
+                q2 = self.new(B * L, 3 * C, dtype=self.adt)
+                ops.cast(qkv, q2)
+                qkv = q2
+            attn = self.new(B * L, C, dtype=self.adt)
+            ops.window_attn_fwd(cm, qkv, attn, lse, table, self.P(a + "logit_scale"), B, H, W, C, heads, ws, shift)
+        proj = self.new(B * L, C)
+        if "proj" in ex:
+            if attn.dtype != f32:
+                a2 = self.new(B * L, C)
+                ops.cast(attn, a2)
+                attn = a2
+            ops.linear_fwd(ops.F32, attn, self.arena.view(pre + ".attention.output.dense.weight"), proj,
+                           bias=self.P(pre + ".attention.output.dense.bias"))
+        else:
+            if attn.dtype != self.adt:
+                a2 = self.new(B * L, C, dtype=self.adt)
+                ops.cast(attn, a2)
+                attn = a2
+            ops.linear_fwd(cm, attn, self.W(pre + ".attention.output.dense.weight"), proj, bias=self.P(pre + ".attention.output.dense.bias"))
+        h, h16, _ = self.norm_fwd(pre + ".layernorm_before", proj, x, L, C, cfg.layer_norm_eps, time, need_stats=False, copy=True)
+        hid = int(cfg.mlp_ratio * C)
+        y2 = self.new(B * L, C)
+        if "mlp" in ex:
+            u = self.new(B * L, hid)
+            ops.linear_fwd(ops.F32, h, self.arena.view(pre + ".intermediate.dense.weight"), u, bias=self.P(pre + ".intermediate.dense.bias"),
+                           gelu_deriv_out=u)
+            ops.linear_fwd(ops.F32, u, self.arena.view(pre + ".output.dense.weight"), y2, bias=self.P(pre + ".output.dense.bias"))
+        else:
+            u = self.new(B * L, hid, dtype=self.adt)
+            ops.linear_fwd(cm, h16, self.W(pre + ".intermediate.dense.weight"), u, bias=self.P(pre + ".intermediate.dense.bias"),
+                           gelu_deriv_out=u)
+            ops.linear_fwd(cm, u, self.W(pre + ".output.dense.weight"), y2, bias=self.P(pre + ".output.dense.bias"))
+        out, out16, _ = self.norm_fwd(pre + ".layernorm_after", y2, h, L, C, cfg.layer_norm_eps, time, need_stats=False, copy=True)
+        return out, out16, None
 
     def layer_bwd(self, rec, g, B, time):
         """g: fp32 [B*L, C] gradient wrt the layer output; returns the gradient wrt the layer input (the same buffer when
