@@ -24,7 +24,7 @@ sys.path.insert(0, ROOT)
 
 # forward GFLOP/sample F (excl. CPB) and batch-independent CPB GFLOP/step P; fwd+bwd = 3(B·F + P)
 FLOPS = {"T": (2.784, 0.139), "B": (18.286, 0.277), "L": (67.948, 0.277)}
-PEAK_TFLOPS = {"bf16": 2500.0, "fp32": 157.3}  # dense MFMA peaks, /opt/skills/guides/MI355X_MICROARCH.md
+PEAK_TFLOPS = {"bf16": 2500.0, "fp32": 157.3, "bf16x3": 2500.0 / 3}   # bf16x3 = three bf16 MFMAs per product  # dense MFMA peaks, /opt/skills/guides/MI355X_MICROARCH.md
 
 
 def parse():
@@ -36,7 +36,7 @@ def parse():
     ap.add_argument("--batch", type=int, default=64, help="per-GPU batch")
     ap.add_argument("--size", type=int, default=128)
     ap.add_argument("--channels", type=int, default=4)
-    ap.add_argument("--compute", default="bf16", choices=["bf16", "fp32"])
+    ap.add_argument("--compute", default="bf16", choices=["bf16", "fp32", "bf16x3"])
     ap.add_argument("--no-graph", action="store_true", help="eager launches instead of one hipGraph per step")
     ap.add_argument("--graph", action="store_true", help="force hipGraph replay (default: time both in the warm-up, keep the faster)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -121,7 +121,7 @@ def dominant_kernel_probe(compute, batch, embed_dim, size):
     at its stage-0 fc1 instance  dW[4C, C] += dY[M, 4C]^T · X[M, C],  M = batch·(size/4)^2 (split-K partials + reduce pass
     included, as in the step).  Also times the runner-up (`attn_bwd_kernel`, stage 0) for reference."""
     from poseidon_amd import ops
-    cm = ops.BF16 if compute == "bf16" else ops.F32
+    cm = {"bf16": ops.BF16, "fp32": ops.F32, "bf16x3": ops.X3}[compute]
     dt = torch.bfloat16 if compute == "bf16" else torch.float32
     M, C = batch * (size // 4) ** 2, embed_dim
     # operands rotate through > 800 MB so that nothing is served by the 256 MB Infinity Cache, as in the real step (a loop over
@@ -165,7 +165,7 @@ def dominant_kernel_probe(compute, batch, embed_dim, size):
         qkv = torch.randn(batch * Hp * Hp, 3 * C, device="cuda").to(dt)
         asets.append((qkv, torch.empty(batch * Hp * Hp, C, device="cuda", dtype=dt), torch.randn(batch * Hp * Hp, C, device="cuda").to(dt),
                       torch.empty_like(qkv)))
-    ops.window_attn_fwd(cm, asets[0][0], asets[0][1], lse, tab, ls, batch, Hp, Hp, C, heads, ws, 8)
+    ops.window_attn_fwd(min(cm, 1) if cm != 2 else 0, asets[0][0], asets[0][1], lse, tab, ls, batch, Hp, Hp, C, heads, ws, 8)
     for a_ in asets[1:]:
         a_[1].copy_(asets[0][1])
     dtab, dls = torch.zeros_like(tab), torch.zeros(heads, device="cuda")
@@ -173,7 +173,7 @@ def dominant_kernel_probe(compute, batch, embed_dim, size):
     def abwd():
         qkv, o, do, dq = asets[it[0] % nset]
         it[0] += 1
-        ops.window_attn_bwd(cm, qkv, o, do, lse, tab, ls, dq, dtab, dls, batch, Hp, Hp, C, heads, ws, 8)
+        ops.window_attn_bwd(min(cm, 1) if cm != 2 else 0, qkv, o, do, lse, tab, ls, dq, dtab, dls, batch, Hp, Hp, C, heads, ws, 8)
     ms2 = timed(abwd)
     fl2 = 2.5 * 4.0 * batch * nW * heads * (ws * ws) ** 2 * (C // heads)
     out["runner_up"] = {"kernel": "attn16_bwd_kernel<bf16,32,shifted> (stage 0, dQ and dK/dV halves in one launch), cold operands",

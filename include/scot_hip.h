@@ -30,7 +30,9 @@ int scot_selftest_tr(scot_stream_t stream); /* 1: ds_read_b64_tr_b16 path verifi
 void scot_set_use_tr(int v);
 int scot_get_use_tr(void);
 
-/* Dense contraction with fused prologue/epilogue.  a_gelu/b_gelu: apply erf-GELU to the operand while loading
+/* compute: 0 = fp32 (exact v_mfma_f32_16x16x4_f32), 1 = bf16 operands (v_mfma_f32_16x16x32_bf16, fp32 accumulate), 2 = bf16x3:
+ * fp32 operands split into hi + lo bf16 on the way into LDS, hi·hi + hi·lo + lo·hi on the bf16 MFMA (~2^-17 operand error).
+ * Dense contraction with fused prologue/epilogue.  a_gelu/b_gelu: apply erf-GELU to the operand while loading
  * (Swinv2Intermediate's activation, HF:545-548).  Epilogue: (+bias[n]) (*colscale[n]) (*gelu'(aux[m,n])) (+resid[m,n]);
  * accumulate=1: C += result (required for TN, which splits K and uses fp32 atomics). */
 int scot_gemm(int layout, int compute, int M, int N, int K,

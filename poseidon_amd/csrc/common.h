@@ -14,6 +14,7 @@
 
 #define SCOT_F32 0
 #define SCOT_BF16 1
+#define SCOT_BF16X3 2   /* compute mode only (never a storage dtype): fp32 operands, hi/lo bf16 split, 3 MFMAs per K-step */
 
 #define SCOT_OK 0
 #define SCOT_ERR_SHAPE (-1)

@@ -230,8 +230,9 @@ extern "C" int scot_gemm(int layout, int compute, int M, int N, int K,
                          int accumulate, float* colsum_out, void* workspace, size_t ws_bytes, int aux_mul, void* C2,
                          hipStream_t stream) {
   if (M <= 0 || N <= 0 || K <= 0) return SCOT_ERR_SHAPE;
-  if (layout < 0 || layout > 2) return SCOT_ERR_UNSUPPORTED;
+  if (layout < 0 || layout > 2 || compute < 0 || compute > SCOT_BF16X3) return SCOT_ERR_UNSUPPORTED;
   if ((a_dt | b_dt | c_dt) & ~1) return SCOT_ERR_DTYPE;
+  if (compute == SCOT_BF16X3 && (a_dt != SCOT_F32 || b_dt != SCOT_F32)) return SCOT_ERR_DTYPE;   // bf16x3 splits fp32 operands
   {
     static int use_panel = -1;
     if (use_panel < 0) { const char* e = getenv("SCOT_GEMM_PANEL"); use_panel = e ? atoi(e) : 1; }

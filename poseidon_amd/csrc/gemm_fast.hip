@@ -10,6 +10,7 @@
 //     column sums for bias gradients) reads and writes 16/32-byte row segments — fully coalesced;
 //   * wgrad (TN): split-K with fp32 atomics, and the bias gradient (column sums of dY) comes for free from the
 //     dY tile that is already in LDS.
+#include <type_traits>
 #include "common.h"
 #include <stdlib.h>
 
@@ -95,19 +96,59 @@ __device__ __forceinline__ void fstore(CT* tile, const uint4 (&st)[NCH], int k0,
   }
 }
 
+// bf16x3: the operands are fp32 in memory; every 4-float chunk is split into hi = bf16(x) and lo = bf16(x - hi) while it is
+// staged into LDS (two bf16 tiles per operand), and the product is accumulated as hi·hi + hi·lo + lo·hi — three bf16 MFMAs per
+// K-step with ~2^-17 operand error instead of bf16's 2^-9 (the dropped lo·lo term is 2^-18).  MFMA time is < 10 % of these
+// kernels, so tripling it is affordable; the price is the fp32 operand traffic.
+template <int R, bool KC, int BKT, int NCH>
+__device__ __forceinline__ void fstore_x3(bf16_t* hi, bf16_t* lo, const uint4 (&st)[NCH], int k0, int kend, int tid) {
+  using L = FTile<float, R, KC, BKT>;     // source chunks: 4 floats
+  using T = FTile<bf16_t, R, KC, BKT>;    // LDS tile geometry
+#pragma unroll
+  for (int i = 0; i < L::per_thread; ++i) {
+    const int c = tid + i * 256;
+    int off, k;
+    if (KC) {
+      constexpr int CPR = BKT / 4;
+      k = k0 + (c % CPR) * 4;
+      off = (c / CPR) * T::pitch + (c % CPR) * 4;
+    } else {
+      constexpr int CPR = R / 4;
+      k = k0 + c / CPR;
+      off = (c / CPR) * T::pitch + (c % CPR) * 4;
+    }
+    uint4 v = st[i];
+    if (k >= kend) v = make_uint4(0, 0, 0, 0);
+    const float x[4] = {__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w)};
+    float h[4], l[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { h[j] = bf2f(f2bf(x[j])); l[j] = x[j] - h[j]; }
+    if (L::exact || c < L::nchunks) {
+      *(uint2*)(hi + off) = make_uint2(pack_bf16x2(h[0], h[1]), pack_bf16x2(h[2], h[3]));
+      *(uint2*)(lo + off) = make_uint2(pack_bf16x2(l[0], l[1]), pack_bf16x2(l[2], l[3]));
+    }
+  }
+}
+
 // WM x WN = arrangement of the 4 waves over the BM x BN tile (WM*WN == 4); each wave owns (BM/WM) x (BN/WN).
-template <typename CT, int BM, int BN, int WM, int WN, int BKT, int NSET, int LAYOUT>
+// X3 (CT = bf16_t, BKT = 32): fp32 operands in memory, split into hi/lo bf16 tiles in LDS, 3 MFMAs per K-step (see fstore_x3).
+template <typename CT, int BM, int BN, int WM, int WN, int BKT, int NSET, int LAYOUT, bool X3 = false>
 __global__ __launch_bounds__(256) void gemm_fast_kernel(FastArgs p) {
   static_assert(NSET == 2 || NSET == 4, "pipeline depth");
   static_assert(WM * WN == 4, "4 waves per workgroup");
+  static_assert(!X3 || (sizeof(CT) == 2 && BKT == 32), "bf16x3: bf16 tiles, one MFMA K-step per tile");
   constexpr bool A_KC = (LAYOUT != LAYOUT_TN);
   constexpr bool B_KC = (LAYOUT == LAYOUT_NT);
   using TA = FTile<CT, BM, A_KC, BKT>;
   using TB = FTile<CT, BN, B_KC, BKT>;
+  using MT = typename std::conditional<X3, float, CT>::type;     // element type in memory
+  using LA = FTile<MT, BM, A_KC, BKT>;                            // load geometry (16-byte chunks of MT)
+  using LB = FTile<MT, BN, B_KC, BKT>;
   constexpr int BK = BKT;
   constexpr int MI = BM / (16 * WM), NI = BN / (16 * WN);
   constexpr int WROWS = BM / WM, WCOLS = BN / WN;
-  constexpr int STAGE = TA::elems + TB::elems;
+  constexpr int STAGE = (X3 ? 2 : 1) * (TA::elems + TB::elems);   // X3: [A hi][A lo][B hi][B lo]
+  constexpr int BOFF = (X3 ? 2 : 1) * TA::elems;                  // offset of the B tile(s) in a stage
   constexpr int CP = BN + 4;                                  // C tile pitch (floats)
   constexpr size_t LDS_AB = 2 * STAGE * sizeof(CT), LDS_C = (size_t)BM * CP * sizeof(float) + BN * sizeof(float);
   constexpr size_t LDS_BYTES = LDS_AB > LDS_C ? LDS_AB : LDS_C;
@@ -136,8 +177,8 @@ __global__ __launch_bounds__(256) void gemm_fast_kernel(FastArgs p) {
   const int kbeg = bz * p.ksplit;
   const int kend = min(p.K, kbeg + p.ksplit);
   const int nk = (kend - kbeg + BK - 1) / BK;
-  const CT* A = (const CT*)p.A;
-  const CT* B = (const CT*)p.B;
+  const MT* A = (const MT*)p.A;
+  const MT* B = (const MT*)p.B;
 
   f32x4_t acc[MI][NI];
 #pragma unroll
@@ -150,40 +191,71 @@ __global__ __launch_bounds__(256) void gemm_fast_kernel(FastArgs p) {
   // iteration t+NSET-1, i.e. they have NSET-1 full MFMA phases to land.  NSET = 2 when many workgroups share a CU (their
   // interleaving hides the latency); NSET = 4 for the small grids of stages 2/3, where ONE workgroup per CU walks 12–48 K-tiles
   // and each iteration used to stall ~1000 cycles on the HBM round trip of a load issued only one iteration earlier.
-  uint4 ra[NSET][TA::per_thread], rb[NSET][TB::per_thread];
+  uint4 ra[NSET][LA::per_thread], rb[NSET][LB::per_thread];
+  // stage `st` <- register set: plain copy, or the hi/lo split of bf16x3
+  auto stage_store = [&](CT* st, const uint4 (&a)[LA::per_thread], const uint4 (&b)[LB::per_thread], int k0) {
+    if constexpr (X3) {
+      fstore_x3<BM, A_KC, BKT>((bf16_t*)st, (bf16_t*)st + TA::elems, a, k0, kend, tid);
+      fstore_x3<BN, B_KC, BKT>((bf16_t*)st + BOFF, (bf16_t*)st + BOFF + TB::elems, b, k0, kend, tid);
+    } else {
+      fstore<CT, BM, A_KC, BKT>(st, a, k0, kend, tid);
+      fstore<CT, BN, B_KC, BKT>(st + BOFF, b, k0, kend, tid);
+    }
+  };
 #pragma unroll
   for (int u = 0; u < NSET; ++u) {   // unconditional: fload clamps its addresses, fstore zero-fills tiles past kend
-    fload<CT, BM, A_KC, BKT>(ra[u], A, p.lda, m0, p.M, kbeg + u * BK, kend, tid);
-    fload<CT, BN, B_KC, BKT>(rb[u], B, p.ldb, n0, p.N, kbeg + u * BK, kend, tid);
+    fload<MT, BM, A_KC, BKT>(ra[u], A, p.lda, m0, p.M, kbeg + u * BK, kend, tid);
+    fload<MT, BN, B_KC, BKT>(rb[u], B, p.ldb, n0, p.N, kbeg + u * BK, kend, tid);
   }
-  fstore<CT, BM, A_KC, BKT>(lds, ra[0], kbeg, kend, tid);
-  fstore<CT, BN, B_KC, BKT>(lds + TA::elems, rb[0], kbeg, kend, tid);
+  stage_store(lds, ra[0], rb[0], kbeg);
   __syncthreads();
 
-  auto compute = [&](const CT* As, const CT* Bs) {
+  auto frag_a = [&](const CT* As, int i, int kk) {
+    const int r0 = wr * WROWS + i * 16;
+    if (A_KC) return lds_frag_kc(As, TA::pitch, r0, kk, lane);
+    return lds_frag_ks(As, TA::pitch, r0, kk + g * 8, kk + g * 8 + 4, lane, p.use_tr);
+  };
+  auto frag_b = [&](const CT* Bs, int j, int kk) {
+    const int c0 = wc * WCOLS + j * 16;
+    if (B_KC) return lds_frag_kc(Bs, TB::pitch, c0, kk, lane);
+    return lds_frag_ks(Bs, TB::pitch, c0, kk + g * 8, kk + g * 8 + 4, lane, p.use_tr);
+  };
+  auto compute = [&](const CT* st) {
+    const CT* As = st;
+    const CT* Bs = st + BOFF;
 #pragma unroll
     for (int kk = 0; kk < BK; kk += 32) {
       Frag<CT> fa[MI], fb[NI];
 #pragma unroll
-      for (int i = 0; i < MI; ++i) {
-        const int r0 = wr * WROWS + i * 16;
-        if (A_KC) fa[i] = lds_frag_kc(As, TA::pitch, r0, kk, lane);
-        else fa[i] = lds_frag_ks(As, TA::pitch, r0, kk + g * 8, kk + g * 8 + 4, lane, p.use_tr);
-      }
+      for (int i = 0; i < MI; ++i) fa[i] = frag_a(As, i, kk);
 #pragma unroll
-      for (int j = 0; j < NI; ++j) {
-        const int c0 = wc * WCOLS + j * 16;
-        if (B_KC) fb[j] = lds_frag_kc(Bs, TB::pitch, c0, kk, lane);
-        else fb[j] = lds_frag_ks(Bs, TB::pitch, c0, kk + g * 8, kk + g * 8 + 4, lane, p.use_tr);
-      }
+      for (int j = 0; j < NI; ++j) fb[j] = frag_b(Bs, j, kk);
 #pragma unroll
       for (int i = 0; i < MI; ++i)
 #pragma unroll
         for (int j = 0; j < NI; ++j) mma16(acc[i][j], fa[i], fb[j]);
+      if constexpr (X3) {
+        Frag<CT> fl[MI > NI ? MI : NI];
+#pragma unroll
+        for (int j = 0; j < NI; ++j) fl[j] = frag_b(Bs + TB::elems, j, kk);        // B lo
+#pragma unroll
+        for (int i = 0; i < MI; ++i)
+#pragma unroll
+          for (int j = 0; j < NI; ++j) mma16(acc[i][j], fa[i], fl[j]);
+#pragma unroll
+        for (int i = 0; i < MI; ++i) fl[i] = frag_a(As + TA::elems, i, kk);        // A lo
+#pragma unroll
+        for (int i = 0; i < MI; ++i)
+#pragma unroll
+          for (int j = 0; j < NI; ++j) mma16(acc[i][j], fl[i], fb[j]);
+      }
     }
     if (LAYOUT == LAYOUT_TN && p.colsum_out && bx == 0 && tid < BM) {
 #pragma unroll 8
-      for (int k = 0; k < BK; ++k) bsum += from_ct(As[k * TA::pitch + tid]);
+      for (int k = 0; k < BK; ++k) {
+        bsum += from_ct(As[k * TA::pitch + tid]);
+        if constexpr (X3) bsum += from_ct(As[TA::elems + k * TA::pitch + tid]);
+      }
     }
   };
 
@@ -197,12 +269,10 @@ __global__ __launch_bounds__(256) void gemm_fast_kernel(FastArgs p) {
     for (int u = 0; u < NSET; ++u) {
       const int tt = t + u;
       // set u held tile tt (already in LDS buffer u&1): refill it with tile tt+NSET
-      fload<CT, BM, A_KC, BKT>(ra[u], A, p.lda, m0, p.M, kbeg + (tt + NSET) * BK, kend, tid);
-      fload<CT, BN, B_KC, BKT>(rb[u], B, p.ldb, n0, p.N, kbeg + (tt + NSET) * BK, kend, tid);
-      compute(lds + (u & 1) * STAGE, lds + (u & 1) * STAGE + TA::elems);
-      CT* nb = lds + ((u + 1) & 1) * STAGE;
-      fstore<CT, BM, A_KC, BKT>(nb, ra[(u + 1) % NSET], kbeg + (tt + 1) * BK, kend, tid);
-      fstore<CT, BN, B_KC, BKT>(nb + TA::elems, rb[(u + 1) % NSET], kbeg + (tt + 1) * BK, kend, tid);
+      fload<MT, BM, A_KC, BKT>(ra[u], A, p.lda, m0, p.M, kbeg + (tt + NSET) * BK, kend, tid);
+      fload<MT, BN, B_KC, BKT>(rb[u], B, p.ldb, n0, p.N, kbeg + (tt + NSET) * BK, kend, tid);
+      compute(lds + (u & 1) * STAGE);
+      stage_store(lds + ((u + 1) & 1) * STAGE, ra[(u + 1) % NSET], rb[(u + 1) % NSET], kbeg + (tt + 1) * BK);
       __syncthreads();
     }
   }
@@ -407,6 +477,25 @@ template <> int flaunch_tile<bf16_t>(int tile, const FastArgs& a, int layout, in
 template <> int flaunch_tile<float>(int tile, const FastArgs& a, int layout, int nsplit, hipStream_t s) {
   return tile == 3 ? flaunch_layout<float, 128, 128, 2, 2>(a, layout, nsplit, s) : flaunch_layout<float, 64, 64, 2, 2>(a, layout, nsplit, s);
 }
+// bf16x3 (fp32 operands in memory): 64x64, 64x96 and 96x96 tiles, BK = 32
+template <int BM, int BN>
+static int flaunch_x3_layout(const FastArgs& a, int layout, int nsplit, hipStream_t s) {
+  dim3 grid((a.N + BN - 1) / BN, (a.M + BM - 1) / BM, nsplit), block(256);
+  switch (layout) {
+    case LAYOUT_NT: hipLaunchKernelGGL((gemm_fast_kernel<bf16_t, BM, BN, 2, 2, 32, 2, LAYOUT_NT, true>), grid, block, 0, s, a); break;
+    case LAYOUT_NN: hipLaunchKernelGGL((gemm_fast_kernel<bf16_t, BM, BN, 2, 2, 32, 2, LAYOUT_NN, true>), grid, block, 0, s, a); break;
+    case LAYOUT_TN: hipLaunchKernelGGL((gemm_fast_kernel<bf16_t, BM, BN, 2, 2, 32, 2, LAYOUT_TN, true>), grid, block, 0, s, a); break;
+    default: return SCOT_ERR_UNSUPPORTED;
+  }
+  return scot_check_launch();
+}
+static int flaunch_x3(int tile, const FastArgs& a, int layout, int nsplit, hipStream_t s) {
+  switch (tile) {
+    case 2: return flaunch_x3_layout<64, 96>(a, layout, nsplit, s);
+    case 4: return flaunch_x3_layout<96, 96>(a, layout, nsplit, s);
+    default: return flaunch_x3_layout<64, 64>(a, layout, nsplit, s);
+  }
+}
 static void tile_dims(int tile, int& bm, int& bn, int& bkt) {
   bkt = 64;
   switch (tile) {
@@ -430,7 +519,8 @@ int scot_gemm_fast(int layout, int compute, int M, int N, int K, const void* A, 
                    const void* B, int b_dt, int ldb, int b_gelu, void* C, int c_dt, int ldc, const float* bias,
                    const float* colscale, const void* aux, int aux_dt, int ldaux, const void* resid, int res_dt, int ldres,
                    int accumulate, float* colsum_out, void* workspace, size_t ws_bytes, int aux_mul, void* C2, hipStream_t stream) {
-  const int want = compute == SCOT_BF16 ? SCOT_BF16 : SCOT_F32;
+  const bool x3 = compute == SCOT_BF16X3;
+  const int want = compute == SCOT_BF16 ? SCOT_BF16 : SCOT_F32;   // bf16x3 keeps its operands in fp32
   const int epc = compute == SCOT_BF16 ? 8 : 4;
   if (a_dt != want || b_dt != want) return SCOT_ERR_UNSUPPORTED;
   if ((((uintptr_t)A | (uintptr_t)B | (uintptr_t)C | (uintptr_t)aux | (uintptr_t)resid) & 15) != 0) return SCOT_ERR_UNSUPPORTED;
@@ -461,11 +551,12 @@ int scot_gemm_fast(int layout, int compute, int M, int N, int K, const void* A, 
     tile = 0;   // policy (see DESIGN.md §3 for the measurements behind it)
     // wgrad with a long token dimension (stages 0/1): 96x96 (cold-cache sweep: 25.6 vs 38.5 us at stage 1); with K <= 4096
     // (stages 2/3) the 64x64 grid is already large enough to run unsplit (no partials, no reduce pass): 22 vs 27 us
-    if (compute == SCOT_BF16 && layout == LAYOUT_TN && M % 96 == 0 && N % 96 == 0 && K >= 8192) tile = 4;
-    else if (compute == SCOT_BF16 && N == 96) tile = 2;   // one 64x96 column tile: the A operand streams once (64x64 would read it twice)
+    if ((compute == SCOT_BF16 || x3) && layout == LAYOUT_TN && M % 96 == 0 && N % 96 == 0 && K >= 8192) tile = 4;
+    else if ((compute == SCOT_BF16 || x3) && N == 96) tile = 2;   // one 64x96 column tile: the A operand streams once (64x64 would read it twice)
     else if (compute == SCOT_BF16 && layout != LAYOUT_TN && K <= 128) tile = 6;   // K = 96: BK = 32 halves LDS -> more workgroups/CU (-12 %)
   }
-  if (compute != SCOT_BF16 && tile != 0 && tile != 3) tile = 0;   // fp32 instantiates 64x64 and 128x128 only
+  if (x3 && tile != 2 && tile != 4) tile = 0;                     // bf16x3 instantiates 64x64, 64x96, 96x96
+  if (compute == SCOT_F32 && tile != 0 && tile != 3) tile = 0;    // fp32 instantiates 64x64 and 128x128 only
   int bm, bn, bkt;
   tile_dims(tile, bm, bn, bkt);
   if (compute == SCOT_BF16) bk = bkt;
@@ -520,7 +611,8 @@ int scot_gemm_fast(int layout, int compute, int M, int N, int K, const void* A, 
       }
     }
   }
-  int rc = compute == SCOT_BF16 ? flaunch_tile<bf16_t>(tile, a, layout, nsplit, stream) : flaunch_tile<float>(tile, a, layout, nsplit, stream);
+  int rc = x3 ? flaunch_x3(tile, a, layout, nsplit, stream)
+              : compute == SCOT_BF16 ? flaunch_tile<bf16_t>(tile, a, layout, nsplit, stream) : flaunch_tile<float>(tile, a, layout, nsplit, stream);
   if (rc == SCOT_OK && a.ws) {
     const size_t n8 = (size_t)M * N / 8;
     const int zl = (nsplit >= 64 && layout == LAYOUT_TN) ? 32 : nsplit >= 16 ? 8 : nsplit >= 4 ? 4 : 1;

@@ -39,8 +39,8 @@ def cpb_coords_table(ws: int) -> torch.Tensor:
 
 class ScOTEngine:
     def __init__(self, cfg, arena: Arena, compute: str = "bf16"):
-        if compute not in ("bf16", "fp32"):
-            raise ValueError("compute must be 'bf16' or 'fp32'")
+        if compute not in ("bf16", "fp32", "bf16x3"):
+            raise ValueError("compute must be 'bf16', 'fp32' or 'bf16x3'")
         self.cfg = cfg
         self.stage_timing = os.environ.get("SCOT_STAGE_TIMING", "0") == "1"
         self.marks = []
@@ -59,7 +59,10 @@ class ScOTEngine:
         self.side_flush = os.environ.get("SCOT_SIDE_FLUSH", "block")   # block | stage: where queued weight-gradient launches fork
         self._pending = []
         self.arena = arena
-        self.compute = ops.BF16 if compute == "bf16" else ops.F32
+        # bf16x3: activations and weights stay fp32 in HBM; the GEMMs split them into hi + lo bf16 while staging into LDS and
+        # run three bf16 MFMAs per K-step (≈ fp32 accuracy at the bf16 MFMA rate); attention uses the exact fp32 kernels
+        self.compute = {"bf16": ops.BF16, "fp32": ops.F32, "bf16x3": ops.X3}[compute]
+        self.acm = ops.BF16 if compute == "bf16" else ops.F32      # attention kernels' arithmetic
         self.adt = torch.bfloat16 if compute == "bf16" else torch.float32
         self.device = arena.data.device
         # The "trunk" (patch embed, merge, unmerge, recovery: < 2 % of the FLOPs) is the only path every output pixel's
@@ -67,7 +70,7 @@ class ScOTEngine:
         # It therefore always runs on the exact fp32 MFMA with fp32 operands (SCOT_TRUNK_BF16=1 restores bf16).
         import os as _os
         trunk32 = self.compute == ops.BF16 and _os.environ.get("SCOT_TRUNK_BF16", "0") != "1"
-        self.tcm = ops.F32 if (trunk32 or self.compute == ops.F32) else ops.BF16
+        self.tcm = ops.F32 if (trunk32 or self.compute != ops.BF16) else ops.BF16
         self.tadt = torch.float32 if self.tcm == ops.F32 else torch.bfloat16
         self.grid, self.enc, self.dec = stage_plan(cfg)
         self.drop_rates = drop_path_rates(cfg)      # per-layer stochastic-depth rate (0 for the training recipe, train.py:262)
@@ -437,7 +440,7 @@ class ScOTEngine:
         attn = self.new(B * Lp, C, dtype=self.adt)
         nW = (Hp // ws) * (Wp // ws)
         lse = self.new(B * nW, heads, ws * ws)
-        ops.window_attn_fwd(cm, qkv, attn, lse, table, self.P(a + "logit_scale"), B, Hp, Wp, C, heads, ws, shift)
+        ops.window_attn_fwd(self.acm, qkv, attn, lse, table, self.P(a + "logit_scale"), B, Hp, Wp, C, heads, ws, shift)
         if padded:
             attn_c = self.new(B * L, C, dtype=self.adt)
             ops.copy2d(attn, attn_c, B, Hp, Wp, H, W, C)
@@ -571,7 +574,7 @@ class ScOTEngine:
             d_attn_p = d_attn
         d_qkv = self.new(B * Lp, 3 * C, dtype=adt)
         d_table = self.cpb_table(pre, grad=True)   # zeroed once per backward; its MLP backward is batched per stage
-        ops.window_attn_bwd(cm, rec["qkv"], rec["attn_p"], d_attn_p, rec["lse"], rec["table"], self.P(a + "logit_scale"), d_qkv, d_table,
+        ops.window_attn_bwd(self.acm, rec["qkv"], rec["attn_p"], d_attn_p, rec["lse"], rec["table"], self.P(a + "logit_scale"), d_qkv, d_table,
                             self.G(a + "logit_scale"), B, Hp, Wp, C, heads, ws, shift)
         wqkv = self.Wspan(a + "qkv_weight", 3 * C * C).view(3 * C, C)
         gwqkv = self.arena.span(a + "qkv_weight", 3 * C * C, grad=True).view(3 * C, C)

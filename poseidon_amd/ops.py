@@ -11,7 +11,7 @@ import torch
 
 from . import lib as _lib
 
-F32, BF16 = 0, 1
+F32, BF16, X3 = 0, 1, 2   # compute modes of scot_gemm (X3 = bf16x3: fp32 operands, hi/lo bf16 split, 3 MFMAs per K-step)
 NT, NN, TN = 0, 1, 2
 
 

@@ -433,3 +433,32 @@ def test_cpb(ws, heads):
     torch.cuda.synchronize()
     for a, b in zip(g, ps):
         assert rel(a, b.grad) < 1e-4
+
+
+# ----------------------------------------------------------------------------------------------- bf16x3 GEMM
+@pytest.mark.parametrize("layout,M,N,K", [(ops.NT, 4096, 288, 96), (ops.NT, 1024, 96, 384), (ops.NN, 2048, 96, 384), (ops.NN, 1000, 384, 96),
+                                          (ops.TN, 384, 96, 8192), (ops.TN, 96, 288, 4100 // 4 * 4), (ops.NT, 300, 72, 40)])
+def test_gemm_bf16x3_is_fp32_class(layout, M, N, K):
+    """compute = bf16x3: fp32 operands split into hi + lo bf16, three bf16 MFMAs per K-step.  Against an fp64 product the error
+    must be in the fp32 class (operand error ~2^-17), two orders of magnitude below plain bf16 operands (2^-9)."""
+    if layout == ops.NT:
+        A, B = rnd(M, K), rnd(N, K, seed=1)
+        ref = A.double() @ B.double().t()
+    elif layout == ops.NN:
+        A, B = rnd(M, K), rnd(K, N, seed=1)
+        ref = A.double() @ B.double()
+    else:
+        A, B = rnd(K, M), rnd(K, N, seed=1)
+        ref = A.double().t() @ B.double()
+    C = torch.zeros(M, N, device=DEV)
+    bias = rnd(N, seed=2) if layout != ops.TN else None
+    ops.gemm(layout, ops.X3, M, N, K, A, A.shape[1], B, B.shape[1], C, N, bias=bias, accumulate=layout == ops.TN)
+    torch.cuda.synchronize()
+    if bias is not None:
+        ref = ref + bias.double()
+    e = rel(C, ref)
+    assert e < 2e-5, e
+    Cb = torch.zeros(M, N, device=DEV)
+    ops.gemm(layout, ops.BF16, M, N, K, A.bfloat16(), A.shape[1], B.bfloat16(), B.shape[1], Cb, N, bias=bias, accumulate=layout == ops.TN)
+    torch.cuda.synchronize()
+    assert rel(Cb, ref) > 20 * e      # what the split buys

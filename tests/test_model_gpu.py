@@ -101,7 +101,8 @@ def test_bf16_vs_reference_fixture(name):
 
 @pytest.mark.parametrize("name,compute", [("poseidonT_trained", "fp32"), ("poseidonT_hf", "fp32"), ("poseidonT_trained", "bf16"),
                                           ("poseidonT_hf", "bf16"), ("poseidonB_trained", "fp32"), ("poseidonB_trained", "bf16"),
-                                          ("poseidonB_hf", "bf16")])
+                                          ("poseidonB_hf", "bf16"), ("poseidonT_trained", "bf16x3"), ("poseidonT_hf", "bf16x3"),
+                                          ("poseidonB_trained", "bf16x3")])
 def test_poseidon_presets(name, compute):
     f, meta = load_fixture(name)
     cfg, model = build(meta, compute)
@@ -120,6 +121,12 @@ def test_poseidon_presets(name, compute):
         assert e_loss < 2e-5
         assert np.median(dev) < 1e-4
         grads_report(model, f, tol_each=1e-3, tol_global=1e-3)
+    elif compute == "bf16x3":
+        # fp32 operands split into hi + lo bf16 (three bf16 MFMAs per product): the north star's 1e-3 bound for the bf16 path,
+        # with margin — on BOTH parameter regimes
+        assert e_out < 1e-4 and e_loss < 1e-4
+        assert np.median(dev) < 1e-3
+        grads_report(model, f, tol_each=2e-2, tol_global=2e-3)
     else:
         assert e_out < (3e-3 if meta["regime"] == "hf" else 2e-2)  # measured 1.4e-3..2e-3 / 6.3e-3..6.7e-3, DESIGN.md "Numerics"
 
