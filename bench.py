@@ -353,7 +353,7 @@ def main():
                           "global_batch": B * world, "parallelism": f"dp{world}", "graph": bool(use_graph[0]), **mode_info,
                           "grad_wire": a.wire if world > 1 else None, "grad_exchange": exchange[0], "loss": float(loss_buf),
                           "parity_vs_reference_fixtures": {"bf16": "output rel-L2 1.4e-3..2.0e-3 (HF-init), 6.3e-3..6.7e-3 (trained-like)",
-                                                           "bf16x3": "1e-5 (--compute bf16x3: 1567 samples/s)",
+                                                           "bf16x3": "1e-5 (--compute bf16x3: 1768 samples/s)",
                                                            "fp32": "1e-6 (--compute fp32: 1168 samples/s)",
                                                            "source": "tests/test_model_gpu.py::test_poseidon_presets"}},
                "roofline": roof}

@@ -10,6 +10,7 @@
 //   * outputs are produced TRANSPOSED (O^T = V^T P^T, dQ^T, dK^T, dV^T): a lane then owns 4 consecutive features of one
 //     token -> 8/16-byte stores and two-step (xor 16, 32) row reductions in the normalisation backward.
 #include <cstdio>
+#include <type_traits>
 #include "attention.h"
 
 static constexpr float kLog2e = 1.4426950408889634f, kLn2 = 0.6931471805599453f;
@@ -103,6 +104,57 @@ template <int HD> __device__ __forceinline__ Frag<float> rd_ks(const Tile16<floa
 }
 
 
+// ---- bf16x3 (X3): q/k/v/dO/O and the results are fp32 in memory, every MFMA operand is a (hi, lo) pair of bf16 fragments —
+// hi = bf16(x), lo = bf16(x - hi) — and every product is hi·hi + hi·lo + lo·hi on the bf16 MFMA (operand error ~2^-17, the dropped
+// lo·lo term 2^-18): the accuracy class of the fp32 kernels at three bf16 MFMAs instead of eight fp32 ones per 32-deep product.
+// LDS tiles come in pairs (hi tile, lo tile `elems` further).  With X3 = false everything below degenerates to the single-fragment code.
+template <typename CT, bool X3> struct FragX { Frag<CT> hi, lo; };
+template <typename CT, bool X3> __device__ __forceinline__ FragX<CT, X3> fragx_from_f32(const float (&x)[8]) {
+  FragX<CT, X3> f;
+  if constexpr (X3) {
+    float h[8], l[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { h[j] = bf2f(f2bf(x[j])); l[j] = x[j] - h[j]; }
+    f.hi = frag_from_f32<CT>(h);
+    f.lo = frag_from_f32<CT>(l);
+  } else {
+    f.hi = frag_from_f32<CT>(x);
+  }
+  return f;
+}
+template <typename CT, bool X3> __device__ __forceinline__ void mmax(f32x4_t& acc, const FragX<CT, X3>& a, const FragX<CT, X3>& b) {
+  mma16(acc, a.hi, b.hi);
+  if constexpr (X3) { mma16(acc, a.hi, b.lo); mma16(acc, a.lo, b.hi); }
+}
+template <typename CT, int HD, bool X3> struct TileX {
+  Tile16<CT, HD> hi, lo;
+  __device__ __forceinline__ TileX(const CT* T, int lane) : hi(T, lane), lo(T + (X3 ? Tile16<CT, HD>::elems : 0), lane) {}
+};
+template <int HD, typename CT, bool X3> __device__ __forceinline__ FragX<CT, X3> rdx_kc(const TileX<CT, HD, X3>& T, int t, int kk) {
+  FragX<CT, X3> f;
+  f.hi = rd_kc<HD>(T.hi, t, kk);
+  if constexpr (X3) f.lo = rd_kc<HD>(T.lo, t, kk);
+  return f;
+}
+template <int HD, typename CT, bool X3> __device__ __forceinline__ FragX<CT, X3> rdx_ks(const TileX<CT, HD, X3>& T, int tp, int d) {
+  FragX<CT, X3> f;
+  f.hi = rd_ks<HD>(T.hi, tp, d);
+  if constexpr (X3) f.lo = rd_ks<HD>(T.lo, tp, d);
+  return f;
+}
+// 8 floats -> LDS at `off` of the hi tile (and their bf16 remainder into the lo tile)
+template <typename CT, int HD, bool X3> __device__ __forceinline__ void store8_x(CT* tile, int off, const float (&v)[8]) {
+  if constexpr (X3) {
+    float h[8], l[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { h[j] = bf2f(f2bf(v[j])); l[j] = v[j] - h[j]; }
+    store8_ct(tile + off, h);
+    store8_ct(tile + Tile16<CT, HD>::elems + off, l);
+  } else {
+    store8_ct(tile + off, v);
+  }
+}
+
 // token of window position n = (y, x) — the roll(-shift) + window_partition index math (reference model.py:522-559), in
 // registers: no LDS token table (1 KB that decided between 2 and 3 workgroups per CU for the dQ kernel)
 struct W16Tok {
@@ -120,7 +172,7 @@ struct W16Tok {
 };
 
 // stage the window's rows of q/k/v/dO (column offset `col`) into an LDS tile, optionally L2-normalised (F.normalize, eps 1e-12)
-template <typename CT, int HD, bool NORM>
+template <typename CT, typename MT, int HD, bool NORM, bool X3>
 __device__ __forceinline__ void w16_stage(CT* tile, const void* src, int ld, int col, const W16Tok& T, int tid) {
   constexpr int CPR = ((HD + 31) / 32) * 4;
 #pragma unroll 2
@@ -129,7 +181,7 @@ __device__ __forceinline__ void w16_stage(CT* tile, const void* src, int ld, int
     float v[8];
 #pragma unroll
     for (int j = 0; j < 8; ++j) v[j] = 0.f;
-    if (ch * 8 < HD) ld8(src, ct_traits<CT>::dtype, (size_t)T(n) * ld + col + ch * 8, v);
+    if (ch * 8 < HD) ld8(src, ct_traits<MT>::dtype, (size_t)T(n) * ld + col + ch * 8, v);
     if (NORM) {
       float ss = 0.f;
 #pragma unroll
@@ -140,7 +192,7 @@ __device__ __forceinline__ void w16_stage(CT* tile, const void* src, int ld, int
 #pragma unroll
       for (int j = 0; j < 8; ++j) v[j] *= r;
     }
-    store8_ct(tile + Tile16<CT, HD>::store_off(n, ch), v);
+    store8_x<CT, HD, X3>(tile, Tile16<CT, HD>::store_off(n, ch), v);
   }
 }
 // accT[d][r]: gradient (times `mul`) wrt the NORMALISED row of token `tokn`, feature d*16 + (lane>>4)*4 + r.
@@ -193,11 +245,11 @@ __device__ __forceinline__ void row_f32(float (&v)[(HD + 31) / 32][8], const voi
     if (kk * 32 + g * 8 < HD) ld8(src, ct_traits<CT>::dtype, rowoff + kk * 32 + g * 8, v[kk]);
   }
 }
-template <typename CT, int HD>
-__device__ __forceinline__ void row_frag(Frag<CT> (&f)[(HD + 31) / 32], const void* src, size_t rowoff, bool normalize, int lane) {
+template <typename CT, typename MT, int HD, bool X3>
+__device__ __forceinline__ void row_frag(FragX<CT, X3> (&f)[(HD + 31) / 32], const void* src, size_t rowoff, bool normalize, int lane) {
   constexpr int KS = (HD + 31) / 32;
   float v[KS][8];
-  row_f32<CT, HD>(v, src, rowoff, lane);
+  row_f32<MT, HD>(v, src, rowoff, lane);
   float r = 1.f;
   if (normalize) {
     float ss = 0.f;
@@ -213,14 +265,15 @@ __device__ __forceinline__ void row_frag(Frag<CT> (&f)[(HD + 31) / 32], const vo
   for (int kk = 0; kk < KS; ++kk) {
 #pragma unroll
     for (int j = 0; j < 8; ++j) v[kk][j] *= r;
-    f[kk] = frag_from_f32<CT>(v[kk]);
+    f[kk] = fragx_from_f32<CT, X3>(v[kk]);
   }
 }
 
 // ================================================================================================= forward
-template <typename CT, int HD, bool SHIFTED>
+template <typename CT, int HD, bool SHIFTED, bool X3>
 __global__ __launch_bounds__(256, 2) void attn16_fwd_kernel(AttnArgs p) {
-  constexpr int NT = W16::NT, NP = W16::NP, KS = (HD + 31) / 32, DT = HD / 16, TE = Tile16<CT, HD>::elems;
+  using MT = typename std::conditional<X3, float, CT>::type;   // element type of q/k/v/out in memory
+  constexpr int NT = W16::NT, NP = W16::NP, KS = (HD + 31) / 32, DT = HD / 16, TE = (X3 ? 2 : 1) * Tile16<CT, HD>::elems;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   CT* Kn = (CT*)smem;
   CT* Vs = Kn + TE;
@@ -232,8 +285,8 @@ __global__ __launch_bounds__(256, 2) void attn16_fwd_kernel(AttnArgs p) {
   const W16Tok tokf(p, win);
 
   for (int i = tid; i < W16::TS; i += 256) tab2[i] = p.bias_table[h * W16::TS + i] * kLog2e;
-  w16_stage<CT, HD, true>(Kn, p.qkv, ld, p.C + h * HD, tokf, tid);
-  w16_stage<CT, HD, false>(Vs, p.qkv, ld, 2 * p.C + h * HD, tokf, tid);
+  w16_stage<CT, MT, HD, true, X3>(Kn, p.qkv, ld, p.C + h * HD, tokf, tid);
+  w16_stage<CT, MT, HD, false, X3>(Vs, p.qkv, ld, 2 * p.C + h * HD, tokf, tid);
   __syncthreads();
 
   const float scale2 = __expf(fminf(p.logit_scale[h], 4.605170185988092f)) * kLog2e;  // exp(min(ls, ln 100)), HF:416
@@ -242,14 +295,14 @@ __global__ __launch_bounds__(256, 2) void attn16_fwd_kernel(AttnArgs p) {
   const float mlane = (lastcol && ((lc >= 8) != (g >= 2))) ? kMask2 : 0.f;
   // bias of (query (qy, qx = lc), key (ky = t, kx = 4g + r)) = tab[(qy - t + 15)*31 + lc - 4g - r + 15]
   const float* tabl = tab2 + (lc - 4 * g + 12);
-  const Tile16<CT, HD> kt(Kn, lane), vt(Vs, lane);
+  const TileX<CT, HD, X3> kt(Kn, lane), vt(Vs, lane);
 
 #pragma nounroll
   for (int qb = wave; qb < 16; qb += 4) {
-    Frag<CT> qf[KS];
+    FragX<CT, X3> qf[KS];
     const int q = qb * 16 + lc;
     const int tokq = tokf(q);
-    row_frag<CT, HD>(qf, p.qkv, (size_t)tokq * ld + h * HD, true, lane);
+    row_frag<CT, MT, HD, X3>(qf, p.qkv, (size_t)tokq * ld + h * HD, true, lane);
     const float* tq = tabl + qb * 31;
 
     f32x4_t s[NT];
@@ -257,7 +310,7 @@ __global__ __launch_bounds__(256, 2) void attn16_fwd_kernel(AttnArgs p) {
     for (int t = 0; t < NT; ++t) {
       s[t] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-      for (int kk = 0; kk < KS; ++kk) mma16(s[t], rd_kc<HD>(kt, t, kk), qf[kk]);
+      for (int kk = 0; kk < KS; ++kk) mmax(s[t], rdx_kc<HD>(kt, t, kk), qf[kk]);
       if ((t & 3) == 3) __builtin_amdgcn_sched_barrier(0);   // keep the scheduler from hoisting every tile's LDS reads
     }
     float m = -3.0e38f;
@@ -299,10 +352,10 @@ __global__ __launch_bounds__(256, 2) void attn16_fwd_kernel(AttnArgs p) {
       float pv[8];
 #pragma unroll
       for (int r = 0; r < 4; ++r) { pv[r] = s[2 * tp][r]; pv[r + 4] = s[2 * tp + 1][r]; }
-      const Frag<CT> pf = frag_from_f32<CT>(pv);
+      const FragX<CT, X3> pf = fragx_from_f32<CT, X3>(pv);
 #pragma unroll
       for (int d = 0; d < DT; ++d)
-        mma16(o[d], rd_ks<HD>(vt, tp, d), pf);
+        mmax(o[d], rdx_ks<HD>(vt, tp, d), pf);
       if ((tp & 1) == 1) __builtin_amdgcn_sched_barrier(0);
     }
     // o[d][r]: feature d*16 + 4g + r of query q
@@ -310,15 +363,16 @@ __global__ __launch_bounds__(256, 2) void attn16_fwd_kernel(AttnArgs p) {
 #pragma unroll
     for (int d = 0; d < DT; ++d) {
       const float ov[4] = {o[d][0] * inv, o[d][1] * inv, o[d][2] * inv, o[d][3] * inv};
-      st4<CT>(p.out, base + d * 16, ov);
+      st4<MT>(p.out, base + d * 16, ov);
     }
   }
 }
 
 // ================================================================================================= backward: dQ, d table, d logit_scale
-template <typename CT, int HD, bool SHIFTED>
+template <typename CT, int HD, bool SHIFTED, bool X3>
 __device__ __forceinline__ void attn16_bwd_dq_body(const AttnArgs& p) {
-  constexpr int NT = W16::NT, NP = W16::NP, KS = (HD + 31) / 32, DT = HD / 16, TE = Tile16<CT, HD>::elems;
+  using MT = typename std::conditional<X3, float, CT>::type;
+  constexpr int NT = W16::NT, NP = W16::NP, KS = (HD + 31) / 32, DT = HD / 16, TE = (X3 ? 2 : 1) * Tile16<CT, HD>::elems;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   CT* X = (CT*)smem;            // Kn
   CT* Y = X + TE;               // V
@@ -332,8 +386,8 @@ __device__ __forceinline__ void attn16_bwd_dq_body(const AttnArgs& p) {
   const W16Tok tokf(p, win);
 
   for (int i = tid; i < W16::TS; i += 256) { tab2[i] = p.bias_table[h * W16::TS + i] * kLog2e; dtab[i] = 0.0; }
-  w16_stage<CT, HD, true>(X, p.qkv, ld, p.C + h * HD, tokf, tid);
-  w16_stage<CT, HD, false>(Y, p.qkv, ld, 2 * p.C + h * HD, tokf, tid);
+  w16_stage<CT, MT, HD, true, X3>(X, p.qkv, ld, p.C + h * HD, tokf, tid);
+  w16_stage<CT, MT, HD, false, X3>(Y, p.qkv, ld, 2 * p.C + h * HD, tokf, tid);
   __syncthreads();
 
   const float scale = __expf(fminf(p.logit_scale[h], 4.605170185988092f));
@@ -343,7 +397,7 @@ __device__ __forceinline__ void attn16_bwd_dq_body(const AttnArgs& p) {
   const float mlane = (lastcol && ((lc >= 8) != (g >= 2))) ? kMask2 : 0.f;
   const float* tabl = tab2 + (lc - 4 * g + 12);
   double* dtabl = dtab + (lc - 4 * g + 15);     // entry of (q = lc, key 4g): the lane's anti-diagonal sum lands here
-  const Tile16<CT, HD> xb(X, lane), yb(Y, lane);
+  const TileX<CT, HD, X3> xb(X, lane), yb(Y, lane);
   // d logit_scale = Σ_qk dS·cos·scale with Σ_k dS = 0 per query: a heavily cancelling sum.  dS uses delta from the
   // stored (rounded) forward output; the row sums D = Σ_k P·dP and B = Σ_k P·cos taken here in fp32 put the exact
   // cancellation back:  Σ_k P (dP - D) cos = Σ_k dS·cos + (delta - D)·B.
@@ -354,18 +408,18 @@ __device__ __forceinline__ void attn16_bwd_dq_body(const AttnArgs& p) {
     const int q = qb * 16 + lc;
     const int tokq = tokf(q);
     float accD = 0.f, accB = 0.f;
-    Frag<CT> qf[KS], gf[KS];
-    row_frag<CT, HD>(qf, p.qkv, (size_t)tokq * ld + h * HD, true, lane);
+    FragX<CT, X3> qf[KS], gf[KS];
+    row_frag<CT, MT, HD, X3>(qf, p.qkv, (size_t)tokq * ld + h * HD, true, lane);
     float delta = 0.f;
     {
       float dov[KS][8], ov[KS][8];
-      row_f32<CT, HD>(dov, p.dout, (size_t)tokq * p.C + h * HD, lane);
-      row_f32<CT, HD>(ov, p.ofwd, (size_t)tokq * p.C + h * HD, lane);
+      row_f32<MT, HD>(dov, p.dout, (size_t)tokq * p.C + h * HD, lane);
+      row_f32<MT, HD>(ov, p.ofwd, (size_t)tokq * p.C + h * HD, lane);
 #pragma unroll
       for (int kk = 0; kk < KS; ++kk) {
 #pragma unroll
         for (int j = 0; j < 8; ++j) delta += dov[kk][j] * ov[kk][j];
-        gf[kk] = frag_from_f32<CT>(dov[kk]);
+        gf[kk] = fragx_from_f32<CT, X3>(dov[kk]);
       }
       delta += __shfl_xor(delta, 16, 64);
       delta += __shfl_xor(delta, 32, 64);
@@ -373,7 +427,7 @@ __device__ __forceinline__ void attn16_bwd_dq_body(const AttnArgs& p) {
     const float nlse2 = -p.lse[((size_t)win * p.heads + h) * NP + q] * kLog2e;
     const size_t off = (size_t)tokq * ld + h * HD;
     float xq[DT][4];   // the un-normalised q row again, in the layout of the transposed result: loaded here, used by the epilogue
-    normalize_bwd_load<CT, HD>(xq, p.qkv, off, lane);
+    normalize_bwd_load<MT, HD>(xq, p.qkv, off, lane);
     const float* tq = tabl + qb * 31;
     double* dq_tab = dtabl + qb * 31;
 
@@ -390,8 +444,8 @@ __device__ __forceinline__ void attn16_bwd_dq_body(const AttnArgs& p) {
         f32x4_t s = {0.f, 0.f, 0.f, 0.f}, dp = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int kk = 0; kk < KS; ++kk) {
-          mma16(s, rd_kc<HD>(xb, t, kk), qf[kk]);
-          mma16(dp, rd_kc<HD>(yb, t, kk), gf[kk]);
+          mmax(s, rdx_kc<HD>(xb, t, kk), qf[kk]);
+          mmax(dp, rdx_kc<HD>(yb, t, kk), gf[kk]);
         }
         float madd = nlse2;
         if (SHIFTED) madd += (lastrow && ((qb >= 8) != (t >= 8))) ? kMask2 : mlane;
@@ -415,16 +469,16 @@ __device__ __forceinline__ void attn16_bwd_dq_body(const AttnArgs& p) {
         atomicAdd(&dq_tab[(15 - t) * 31], (double)a);
         if (lc >= 13) atomicAdd(&dq_tab[(15 - t) * 31 - 16], (double)bt);
       }
-      const Frag<CT> df = frag_from_f32<CT>(ds8);
+      const FragX<CT, X3> df = fragx_from_f32<CT, X3>(ds8);
 #pragma unroll
       for (int d = 0; d < DT; ++d)   // dQn^T += Kn^T · dS^T
-        mma16(dq[d], rd_ks<HD>(xb, tp, d), df);
+        mmax(dq[d], rdx_ks<HD>(xb, tp, d), df);
       __builtin_amdgcn_sched_barrier(0);   // one tile pair at a time: unrolled for the immediates, not for hoisting
     }
     accD += __shfl_xor(accD, 16, 64); accD += __shfl_xor(accD, 32, 64);
     accB += __shfl_xor(accB, 16, 64); accB += __shfl_xor(accB, 32, 64);
     if (g == 0) dls = fmaf(delta - accD, accB, dls);
-    normalize_bwd_store_t<CT, HD>(dq, scale, xq, p.out, off, lane);
+    normalize_bwd_store_t<MT, HD>(dq, scale, xq, p.out, off, lane);
   }
   // d/dls [cos * exp(ls)] = cos * scale  (0 when clamped at ln 100, HF:416)
   dls = wave_sum(dls);
@@ -435,9 +489,10 @@ __device__ __forceinline__ void attn16_bwd_dq_body(const AttnArgs& p) {
 }
 
 // ================================================================================================= backward: dK, dV
-template <typename CT, int HD, bool SHIFTED>
+template <typename CT, int HD, bool SHIFTED, bool X3>
 __device__ __forceinline__ void attn16_bwd_dkv_body(const AttnArgs& p) {
-  constexpr int NT = W16::NT, NP = W16::NP, KS = (HD + 31) / 32, DT = HD / 16, TE = Tile16<CT, HD>::elems;
+  using MT = typename std::conditional<X3, float, CT>::type;
+  constexpr int NT = W16::NT, NP = W16::NP, KS = (HD + 31) / 32, DT = HD / 16, TE = (X3 ? 2 : 1) * Tile16<CT, HD>::elems;
   constexpr int CPR = KS * 4;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   CT* X = (CT*)smem;            // Qn
@@ -453,7 +508,7 @@ __device__ __forceinline__ void attn16_bwd_dkv_body(const AttnArgs& p) {
   const W16Tok tokf(p, win);
   for (int i = tid; i < NP; i += 256) nlse2[i] = -p.lse[((size_t)win * p.heads + h) * NP + i] * kLog2e;
   for (int i = tid; i < W16::TS; i += 256) tab2[i] = p.bias_table[h * W16::TS + i] * kLog2e;
-  w16_stage<CT, HD, true>(X, p.qkv, ld, h * HD, tokf, tid);
+  w16_stage<CT, MT, HD, true, X3>(X, p.qkv, ld, h * HD, tokf, tid);
   // dO -> LDS and delta[n] = Σ_d dO[n][d]·O[n][d] in the same pass (CPR lanes per row)
 #pragma unroll
   for (int c = tid; c < NP * CPR; c += 256) {
@@ -463,8 +518,8 @@ __device__ __forceinline__ void attn16_bwd_dkv_body(const AttnArgs& p) {
     for (int j = 0; j < 8; ++j) { v[j] = 0.f; o[j] = 0.f; }
     if (d8 < HD) {
       const size_t ro = (size_t)tokf(n) * p.C + h * HD + d8;
-      ld8(p.dout, ct_traits<CT>::dtype, ro, v);
-      ld8(p.ofwd, ct_traits<CT>::dtype, ro, o);
+      ld8(p.dout, ct_traits<MT>::dtype, ro, v);
+      ld8(p.ofwd, ct_traits<MT>::dtype, ro, o);
     }
     float dot = 0.f;
 #pragma unroll
@@ -472,7 +527,7 @@ __device__ __forceinline__ void attn16_bwd_dkv_body(const AttnArgs& p) {
 #pragma unroll
     for (int of = 1; of < CPR; of <<= 1) dot += __shfl_xor(dot, of, 64);
     if ((c % CPR) == 0) delta[n] = dot;
-    store8_ct(Y + Tile16<CT, HD>::store_off(n, c % CPR), v);
+    store8_x<CT, HD, X3>(Y, Tile16<CT, HD>::store_off(n, c % CPR), v);
   }
   __syncthreads();
 
@@ -483,20 +538,20 @@ __device__ __forceinline__ void attn16_bwd_dkv_body(const AttnArgs& p) {
   const float mlane = (lastcol && ((lc >= 8) != (g >= 2))) ? kMask2 : 0.f;
   // bias of (query (qy = t, qx = 4g + r), key (ky, kx = lc)) = tab[(t - ky + 15)*31 + 4g + r - lc + 15]
   const float* tabl = tab2 + (4 * g - lc + 15);
-  const Tile16<CT, HD> xb(X, lane), yb(Y, lane);
+  const TileX<CT, HD, X3> xb(X, lane), yb(Y, lane);
   const float* nlg = nlse2 + g * 4;
   const float* dlg = delta + g * 4;
 
 #pragma nounroll
   for (int kb = wave; kb < 16; kb += 4) {
     const int tokk = tokf(kb * 16 + lc);
-    Frag<CT> kf[KS], vf[KS];
-    row_frag<CT, HD>(kf, p.qkv, (size_t)tokk * ld + p.C + h * HD, true, lane);
-    row_frag<CT, HD>(vf, p.qkv, (size_t)tokk * ld + 2 * p.C + h * HD, false, lane);
+    FragX<CT, X3> kf[KS], vf[KS];
+    row_frag<CT, MT, HD, X3>(kf, p.qkv, (size_t)tokk * ld + p.C + h * HD, true, lane);
+    row_frag<CT, MT, HD, X3>(vf, p.qkv, (size_t)tokk * ld + 2 * p.C + h * HD, false, lane);
     const float* tk = tabl + (15 - kb) * 31;
     const size_t off = (size_t)tokk * ld + h * HD;
     float xk[DT][4];
-    normalize_bwd_load<CT, HD>(xk, (const CT*)p.qkv + p.C, off, lane);
+    normalize_bwd_load<MT, HD>(xk, (const MT*)p.qkv + p.C, off, lane);
 
     f32x4_t dv[DT], dk[DT];
 #pragma unroll
@@ -511,8 +566,8 @@ __device__ __forceinline__ void attn16_bwd_dkv_body(const AttnArgs& p) {
         f32x4_t s = {0.f, 0.f, 0.f, 0.f}, dp = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int kk = 0; kk < KS; ++kk) {
-          mma16(s, rd_kc<HD>(xb, t, kk), kf[kk]);   // rows = queries 4g + r of row t, col = key
-          mma16(dp, rd_kc<HD>(yb, t, kk), vf[kk]);
+          mmax(s, rdx_kc<HD>(xb, t, kk), kf[kk]);   // rows = queries 4g + r of row t, col = key
+          mmax(dp, rdx_kc<HD>(yb, t, kk), vf[kk]);
         }
         const float4 nl = *(const float4*)&nlg[t * 16];
         const float4 qd = *(const float4*)&dlg[t * 16];
@@ -526,66 +581,70 @@ __device__ __forceinline__ void attn16_bwd_dkv_body(const AttnArgs& p) {
           df8[half * 4 + r] = pr * (dp[r] - qda[r]);
         }
       }
-      const Frag<CT> pf = frag_from_f32<CT>(pf8), df = frag_from_f32<CT>(df8);
+      const FragX<CT, X3> pf = fragx_from_f32<CT, X3>(pf8), df = fragx_from_f32<CT, X3>(df8);
 #pragma unroll
       for (int d = 0; d < DT; ++d) {
-        mma16(dv[d], rd_ks<HD>(yb, tp, d), pf);   // dV^T  += dO^T · P
-        mma16(dk[d], rd_ks<HD>(xb, tp, d), df);   // dKn^T += Qn^T · dS
+        mmax(dv[d], rdx_ks<HD>(yb, tp, d), pf);   // dV^T  += dO^T · P
+        mmax(dk[d], rdx_ks<HD>(xb, tp, d), df);   // dKn^T += Qn^T · dS
       }
       __builtin_amdgcn_sched_barrier(0);
     }
 #pragma unroll
     for (int d = 0; d < DT; ++d) {
       const float o[4] = {dv[d][0], dv[d][1], dv[d][2], dv[d][3]};
-      st4<CT>(p.out, off + 2 * p.C + d * 16 + g * 4, o);
+      st4<MT>(p.out, off + 2 * p.C + d * 16 + g * 4, o);
     }
-    normalize_bwd_store_t<CT, HD>(dk, scale, xk, (CT*)p.out + p.C, off, lane);
+    normalize_bwd_store_t<MT, HD>(dk, scale, xk, (MT*)p.out + p.C, off, lane);
   }
 }
 
 // One launch for the whole backward: blockIdx.z selects the half.  The two halves are independent (each recomputes P from
 // q, k, lse and takes delta from dO·O), so their workgroups simply share the grid: no launch boundary between them and
 // the dK/dV workgroups fill the CUs as the dQ ones drain.
-template <typename CT, int HD, bool SHIFTED>
+template <typename CT, int HD, bool SHIFTED, bool X3>
 __global__ __launch_bounds__(256, 2) void attn16_bwd_kernel(AttnArgs p) {
-  if (blockIdx.z == 0) attn16_bwd_dq_body<CT, HD, SHIFTED>(p);
-  else attn16_bwd_dkv_body<CT, HD, SHIFTED>(p);
+  if (blockIdx.z == 0) attn16_bwd_dq_body<CT, HD, SHIFTED, X3>(p);
+  else attn16_bwd_dkv_body<CT, HD, SHIFTED, X3>(p);
 }
 
 // ================================================================================================= host side
-template <typename CT, int HD, bool SHIFTED>
+template <typename CT, int HD, bool SHIFTED, bool X3>
 static int launch_w16(const AttnArgs& a, int nwin, bool bwd, hipStream_t s) {
   constexpr int NP = W16::NP;
-  const size_t tiles = 2 * Tile16<CT, HD>::elems * sizeof(CT);
+  const size_t tiles = (X3 ? 4 : 2) * Tile16<CT, HD>::elems * sizeof(CT);     // bf16x3: a hi and a lo tile per operand
   const size_t sh_fwd = tiles + W16::TSP * sizeof(float);
   const size_t sh_dq = tiles + W16::TSP * (sizeof(float) + sizeof(double)) + 4 * sizeof(float);
   const size_t sh_dkv = tiles + (W16::TSP + 2 * NP) * sizeof(float);
   dim3 grid(nwin, a.heads), block(256);
   if (!bwd) {
-    if (sh_fwd > 64 * 1024) (void)hipFuncSetAttribute((const void*)attn16_fwd_kernel<CT, HD, SHIFTED>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh_fwd);
-    hipLaunchKernelGGL((attn16_fwd_kernel<CT, HD, SHIFTED>), grid, block, sh_fwd, s, a);
+    if (sh_fwd > 160 * 1024) return SCOT_ERR_UNSUPPORTED;
+    if (sh_fwd > 64 * 1024) (void)hipFuncSetAttribute((const void*)attn16_fwd_kernel<CT, HD, SHIFTED, X3>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh_fwd);
+    hipLaunchKernelGGL((attn16_fwd_kernel<CT, HD, SHIFTED, X3>), grid, block, sh_fwd, s, a);
   } else {
     const size_t sh_b = sh_dq > sh_dkv ? sh_dq : sh_dkv;
-    if (sh_b > 64 * 1024) (void)hipFuncSetAttribute((const void*)attn16_bwd_kernel<CT, HD, SHIFTED>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh_b);
-    hipLaunchKernelGGL((attn16_bwd_kernel<CT, HD, SHIFTED>), dim3(nwin, a.heads, 2), block, sh_b, s, a);
+    if (sh_b > 160 * 1024) return SCOT_ERR_UNSUPPORTED;
+    if (sh_b > 64 * 1024) (void)hipFuncSetAttribute((const void*)attn16_bwd_kernel<CT, HD, SHIFTED, X3>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh_b);
+    hipLaunchKernelGGL((attn16_bwd_kernel<CT, HD, SHIFTED, X3>), dim3(nwin, a.heads, 2), block, sh_b, s, a);
   }
   return scot_check_launch();
 }
 
-template <typename CT> static int dispatch_w16(const AttnArgs& a, int hd, int nwin, bool bwd, hipStream_t s) {
+template <typename CT, bool X3> static int dispatch_w16(const AttnArgs& a, int hd, int nwin, bool bwd, hipStream_t s) {
   const bool sh = a.shift != 0;
   switch (hd) {
-    case 16: return sh ? launch_w16<CT, 16, true>(a, nwin, bwd, s) : launch_w16<CT, 16, false>(a, nwin, bwd, s);
-    case 32: return sh ? launch_w16<CT, 32, true>(a, nwin, bwd, s) : launch_w16<CT, 32, false>(a, nwin, bwd, s);
-    case 64: return sh ? launch_w16<CT, 64, true>(a, nwin, bwd, s) : launch_w16<CT, 64, false>(a, nwin, bwd, s);
+    case 16: return sh ? launch_w16<CT, 16, true, X3>(a, nwin, bwd, s) : launch_w16<CT, 16, false, X3>(a, nwin, bwd, s);
+    case 32: return sh ? launch_w16<CT, 32, true, X3>(a, nwin, bwd, s) : launch_w16<CT, 32, false, X3>(a, nwin, bwd, s);
+    case 64: return sh ? launch_w16<CT, 64, true, X3>(a, nwin, bwd, s) : launch_w16<CT, 64, false, X3>(a, nwin, bwd, s);
     default: return SCOT_ERR_UNSUPPORTED;
   }
 }
 
+// compute: SCOT_F32 / SCOT_BF16 / SCOT_BF16X3 (fp32 tensors, split bf16 MFMAs).
 // returns SCOT_ERR_UNSUPPORTED when the geometry is not the fast path's (the caller then uses the general kernels)
 int scot_attn_w16(const AttnArgs& a, int compute, int hd, int nwin, bool bwd, hipStream_t s) {
   static int enabled = -1;
   if (enabled < 0) { const char* e = getenv("SCOT_ATTN_W16"); enabled = e ? atoi(e) : 1; }
   if (!enabled || !a.use_tr || a.ws != 16 || (a.shift != 0 && a.shift != 8)) return SCOT_ERR_UNSUPPORTED;
-  return compute == SCOT_BF16 ? dispatch_w16<bf16_t>(a, hd, nwin, bwd, s) : dispatch_w16<float>(a, hd, nwin, bwd, s);
+  if (compute == SCOT_BF16X3) return dispatch_w16<bf16_t, true>(a, hd, nwin, bwd, s);
+  return compute == SCOT_BF16 ? dispatch_w16<bf16_t, false>(a, hd, nwin, bwd, s) : dispatch_w16<float, false>(a, hd, nwin, bwd, s);
 }

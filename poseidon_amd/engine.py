@@ -60,9 +60,11 @@ class ScOTEngine:
         self._pending = []
         self.arena = arena
         # bf16x3: activations and weights stay fp32 in HBM; the GEMMs split them into hi + lo bf16 while staging into LDS and
-        # run three bf16 MFMAs per K-step (≈ fp32 accuracy at the bf16 MFMA rate); attention uses the exact fp32 kernels
+        # run three bf16 MFMAs per K-step (≈ fp32 accuracy at the bf16 MFMA rate); so do the 16x16-window attention kernels
         self.compute = {"bf16": ops.BF16, "fp32": ops.F32, "bf16x3": ops.X3}[compute]
-        self.acm = ops.BF16 if compute == "bf16" else ops.F32      # attention kernels' arithmetic
+        # attention kernels' arithmetic: bf16x3 also splits inside the 16x16-window kernels (SCOT_ATTN_X3=0: exact fp32 MFMA)
+        self.acm = ops.BF16 if compute == "bf16" else (ops.X3 if (compute == "bf16x3" and os.environ.get("SCOT_ATTN_X3", "1") == "1")
+                                                      else ops.F32)
         self.adt = torch.bfloat16 if compute == "bf16" else torch.float32
         self.device = arena.data.device
         # The "trunk" (patch embed, merge, unmerge, recovery: < 2 % of the FLOPs) is the only path every output pixel's
