@@ -68,3 +68,43 @@ def test_fused_optimizer_group_map_covers_exactly_the_parameters():
     pre = "encoder.layers.0.blocks.0.attention.self."
     o, c = arena.offsets[pre + "qkv_bias"], shapes[pre + "query.bias"][0]
     assert (m[(o + c) // 8:(o + 2 * c) // 8] == SKIP).all() and (m[o // 8:(o + c) // 8] != SKIP).all()
+
+
+def test_metrics_match_reference_pins():
+    """scOT.metrics (numpy in → numpy out, torch in → torch out on the tensor's device) against values produced by the
+    reference's metrics module (tests/golden/make_metrics_pins.py), including the zero-target guard and the group statistics
+    of the reference's inference driver."""
+    import json
+    import os
+    import numpy as np
+    import torch
+    from poseidon_amd.synth import closed_form_tensor
+    from scOT import metrics as M
+    pins = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "metrics_pins.json")))
+    pr = np.asarray(closed_form_tensor("metrics:pred", (6, 4, 16, 16), 1.0), dtype=np.float32)
+    tg = np.asarray(closed_form_tensor("metrics:target", (6, 4, 16, 16), 1.0), dtype=np.float32)
+    tg[3] = 0.0
+
+    def close(a, b, tol=2e-6):
+        a, b = np.asarray(a, dtype=np.float64), np.asarray(b, dtype=np.float64)
+        return np.all(np.abs(a - b) <= tol * np.maximum(np.abs(b), 1e-30))
+
+    for p in (1, 2):
+        for args in ((pr, tg), (torch.from_numpy(pr), torch.from_numpy(tg))):
+            is_t = isinstance(args[0], torch.Tensor)
+            e = M.lp_error(*args, p=p)
+            assert isinstance(e, torch.Tensor) == is_t and close(e, pins[f"lp_error_p{p}"])
+            assert close(M.relative_lp_error(*args, p=p), pins[f"relative_lp_error_p{p}"])
+            assert close(M.relative_lp_error(*args, p=p, return_percent=False), pins[f"relative_lp_error_p{p}_nopercent"])
+            assert close(M.mean_relative_lp_error(*args, p=p), pins[f"mean_relative_p{p}"])
+            assert close(M.median_relative_lp_error(*args, p=p), pins[f"median_relative_p{p}"])
+    out = M.channel_group_metrics(torch.from_numpy(pr), torch.from_numpy(tg), [0, 1, 3, 4], ["rho", "uv", "p"])
+    for i, n in enumerate(["rho", "uv", "p"]):
+        g = pins[f"group{i}"]
+        assert close(out[n + "/median_relative_l1_error"], g["median_rel"]) and close(out[n + "/mean_relative_l1_error"], g["mean_rel"])
+        assert close(out[n + "/std_relative_l1_error"], g["std_rel"], 1e-5) and close(out[n + "/max_relative_l1_error"], g["max_rel"])
+        assert close(out[n + "/median_l1_error"], g["median_abs"]) and close(out[n + "/std_l1_error"], g["std_abs"], 1e-5)
+    assert close(out["mean_relative_l1_error"], np.mean([pins[f"group{i}"]["mean_rel"] for i in range(3)]))
+    assert close(out["mean_over_median_l1_error"], np.mean([pins[f"group{i}"]["median_abs"] for i in range(3)]))
+    single = M.channel_group_metrics(pr[:, :1], tg[:, :1], [0, 1], full_data=True)
+    assert close(single["mean_relative_l1_error"], pins["group0"]["mean_rel"]) and len(single["full_data"]) == 6
