@@ -11,7 +11,7 @@ pytestmark = pytest.mark.gpu
 from conftest import load_fixture, rel_l2  # noqa: E402
 from poseidon_amd.config import ScOTConfig  # noqa: E402
 from poseidon_amd.geometry import param_shapes  # noqa: E402
-from poseidon_amd.synth import synth_inputs, synth_state_dict  # noqa: E402
+from poseidon_amd.synth import apply_obstacle, synth_inputs, synth_obstacle_mask, synth_state_dict  # noqa: E402
 from scOT.model import ScOT  # noqa: E402
 
 DEV = "cuda"
@@ -27,10 +27,16 @@ def build(meta, compute):
 def inputs(cfg, meta):
     size = meta.get("size", cfg.image_size)
     pv, t, lab = synth_inputs(meta["batch"], cfg.num_channels, cfg.num_out_channels, size, meta["kind"])
+    pm = None
+    if meta.get("with_mask") == "obstacle":  # (B,1,H,W) mask, Airfoil-style (tests/golden/make_obstacle_fixture.py)
+        pm = synth_obstacle_mask(meta["batch"], size)
+        pv, lab = apply_obstacle(pv, lab, pm)
     kw = dict(pixel_values=pv.to(DEV), labels=lab.to(DEV))
     if cfg.use_conditioning:
         kw["time"] = t.to(DEV)
-    if meta.get("with_mask"):
+    if pm is not None:
+        kw["pixel_mask"] = pm.to(DEV)
+    elif meta.get("with_mask"):
         pm = torch.zeros(meta["batch"], cfg.num_out_channels, dtype=torch.bool)
         pm[:, -1] = True
         kw["pixel_mask"] = pm.to(DEV)
@@ -58,7 +64,8 @@ def grads_report(model, f, tol_each, tol_global, floor=1e-9, skip=()):
     return (num / max(den, 1e-300)) ** 0.5, worst
 
 
-TINY = ["tiny_trained", "tiny_hf", "tiny_odd", "tiny_shift3", "tiny_nocond_p2", "tiny_learnres_mask", "tiny_w16"]
+TINY = ["tiny_trained", "tiny_hf", "tiny_odd", "tiny_shift3", "tiny_nocond_p2", "tiny_learnres_mask", "tiny_obstacle_mask",
+        "tiny_w16"]
 
 
 @pytest.mark.parametrize("name", TINY)

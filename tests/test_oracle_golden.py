@@ -7,7 +7,7 @@ import torch
 from conftest import load_fixture, rel_l2
 from poseidon_amd.config import ScOTConfig
 from poseidon_amd.geometry import param_shapes
-from poseidon_amd.synth import synth_inputs, synth_state_dict
+from poseidon_amd.synth import apply_obstacle, synth_inputs, synth_obstacle_mask, synth_state_dict
 from oracle import scot_cpu
 
 TOL_OUT = 5e-6  # fp32-vs-fp32 through up to 64 layers (an fp64 evaluation of the oracle sits at the same distance)
@@ -23,7 +23,10 @@ def _run(meta, grads):
     size = meta.get("size", cfg.image_size)
     pv, t, lab = synth_inputs(meta["batch"], cfg.num_channels, cfg.num_out_channels, size, meta["kind"])
     pm = None
-    if meta.get("with_mask"):
+    if meta.get("with_mask") == "obstacle":  # (B,1,H,W) mask, Airfoil-style (make_obstacle_fixture.py)
+        pm = synth_obstacle_mask(meta["batch"], size)
+        pv, lab = apply_obstacle(pv, lab, pm)
+    elif meta.get("with_mask"):
         pm = torch.zeros(meta["batch"], cfg.num_out_channels, dtype=torch.bool)
         pm[:, -1] = True
     loss, out, inter = scot_cpu.scot_forward(sd, cfg, pv, t if cfg.use_conditioning else None, lab, pm,
@@ -34,7 +37,7 @@ def _run(meta, grads):
 
 
 @pytest.mark.parametrize("name", ["tiny_trained", "tiny_hf", "tiny_odd", "tiny_shift3", "tiny_nocond_p2",
-                                  "tiny_learnres_mask"])
+                                  "tiny_learnres_mask", "tiny_obstacle_mask"])
 def test_tiny_models_full_grads(name):
     f, meta = load_fixture(name)
     cfg, sd, loss, out, inter = _run(meta, grads=True)
