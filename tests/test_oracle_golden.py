@@ -7,7 +7,7 @@ import torch
 from conftest import load_fixture, rel_l2
 from poseidon_amd.config import ScOTConfig
 from poseidon_amd.geometry import param_shapes
-from poseidon_amd.synth import apply_obstacle, synth_inputs, synth_obstacle_mask, synth_state_dict
+from poseidon_amd.synth import apply_obstacle, generate_on, synth_inputs, synth_obstacle_mask, synth_state_dict
 from oracle import scot_cpu
 
 TOL_OUT = 5e-6  # fp32-vs-fp32 through up to 64 layers (an fp64 evaluation of the oracle sits at the same distance)
@@ -97,6 +97,20 @@ def test_poseidon_presets(name):
                 ref = f[k].astype(np.float64)
                 err = float(np.linalg.norm(sd[k[5:]].grad.numpy().astype(np.float64) - ref))
                 assert err < 1e-4 * float(np.linalg.norm(ref)) + 1e-9, k
+
+
+def test_poseidon_L_forward():
+    """BASELINE config 4's shape (embed_dim 192, 5→5 channels, groups [0,1,3,4,5]); forward + loss only (629 M parameters).
+    Parameters come from the torch float64 evaluation of the closed form (multi-threaded; asserted bit-identical below)."""
+    f, meta = load_fixture("poseidonL_trained")
+    k = "encoder.layers.1.blocks.0.output.dense.weight"
+    shp = {k: param_shapes(ScOTConfig(**meta["cfg"]))[k]}
+    host = synth_state_dict(shp, "trained")[k]
+    with generate_on("cpu"):
+        assert torch.equal(synth_state_dict(shp, "trained")[k], host)
+        _, _, loss, out, _ = _run(meta, grads=False)
+    assert rel_l2(out.detach().numpy(), f["output"]) < 5e-6
+    assert abs(float(loss.detach()) - float(f["loss"])) < 2e-5 * abs(float(f["loss"]))
 
 
 def _drop_masks(f):
