@@ -91,6 +91,18 @@ int scot_cln_bwd(const void* dout, int dout_dt, const void* x, int x_dt, const f
 /* out2: optional second copy of the output in the next GEMM's operand dtype; d_xbias: optional += Σ_rows dx;
  * workspace: optional scratch for per-block column sums (avoids 4·C same-address atomics per block). */
 
+/* EXPERIMENTAL (off unless SCOT_FUSED_MLP=1; see poseidon_amd/csrc/mlp_fused.hip) — the MLP half of a ScOTLayer in one launch:
+ *   z = gelu(h16·W1^T + b1)·W2^T + b2   (Swinv2Intermediate + Swinv2Output, HF modeling_swinv2.py:533-561)
+ *   out = h + s_b·CLN(z), out16 = bf16(out)   (res-post-norm, reference scOT/model.py:566-579)
+ * h16 [M,C] bf16, h [M,C] fp32, W1 [hid,C] bf16, W2 [C,hid] bf16; training also stores act = gelu(u), dact = gelu'(u)
+ * ([M,hid] bf16), z [M,C] fp32, mean/rstd [M] (all-or-nothing per pair; NULL in inference).  bf16 operands only,
+ * C in {96, 192}: anything else returns SCOT_ERR_UNSUPPORTED and the caller runs scot_gemm x2 + scot_cln_fwd. */
+int scot_mlp_block_fwd(const void* h16, const float* h, const void* W1, const float* b1, const void* W2, const float* b2,
+                       float* out, void* out16, void* act, void* dact, float* z, float* mean, float* rstd,
+                       const float* time, const float* gw_w, const float* gw_b, const float* bw_w, const float* bw_b,
+                       const float* sample_scale, int M, int rows_per_sample, int C, int hid, float eps,
+                       scot_stream_t stream);
+
 /* Data movement */
 int scot_add(const void* a, int a_dt, const void* b, int b_dt, void* out, int out_dt, size_t n, size_t period,
              scot_stream_t stream);                                                   /* ref:847-849,1175-1177,361 */

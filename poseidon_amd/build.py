@@ -8,7 +8,7 @@ import time
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
-SOURCES = ["gemm.hip", "gemm_fast.hip", "gemm_panel.hip", "attention.hip", "attention_w16.hip", "norm.hip", "norm_fast.hip", "misc.hip", "optim.hip"]
+SOURCES = ["gemm.hip", "gemm_fast.hip", "gemm_panel.hip", "attention.hip", "attention_w16.hip", "norm.hip", "norm_fast.hip", "mlp_fused.hip", "misc.hip", "optim.hip"]
 LIB = os.path.join(HERE, "libscot_hip.so")
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fno-gpu-rdc", "-Wno-unused-result"]

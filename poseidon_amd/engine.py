@@ -96,6 +96,9 @@ class ScOTEngine:
         self.inplace_g = not self.split_ln_bwd
         self.side = None
         self._keep = []
+        # EXPERIMENTAL (csrc/mlp_fused.hip; not yet run on a GPU): fc1 → GELU → fc2 → cond-LN → residual in one launch for the
+        # C = 96 / 192 stages, bf16 mode only
+        self.fused_mlp = os.environ.get("SCOT_FUSED_MLP", "0") == "1" and compute == "bf16"
         # bf16 mode: GEMM operands must already be bf16 in HBM (gemm_fast streams raw 16-byte chunks into LDS), so the
         # weights get a bf16 shadow arena that is re-cast from the fp32 master at the start of EVERY forward (one pass,
         # inside the timed step), and every producer of a GEMM operand also writes a bf16 copy.
@@ -456,15 +459,28 @@ class ScOTEngine:
         h, h16, st1 = self.norm_fwd(pre + ".layernorm_before", proj, x, L, C, cfg.layer_norm_eps, time, need_stats=train, copy=True,
                                     sample_scale=dp1)
         hid = int(cfg.mlp_ratio * C)
-        # fc1 epilogue emits a = gelu(u) AND gp = gelu'(u) (one erf, fp32 registers); u itself is never stored
-        u = self.new(B * L, hid, dtype=self.adt)
-        gp = self.new(B * L, hid, dtype=self.adt) if train else None
-        ops.linear_fwd(cm, h16, self.W(pre + ".intermediate.dense.weight"), u, bias=self.P(pre + ".intermediate.dense.bias"),
-                       gelu_deriv_out=gp if train else u)     # eval: GELU(u) only (`gelu_deriv_out is out`)
-        y2 = self.new(B * L, C)
-        ops.linear_fwd(cm, u, self.W(pre + ".output.dense.weight"), y2, bias=self.P(pre + ".output.dense.bias"))
-        out, out16, st2 = self.norm_fwd(pre + ".layernorm_after", y2, h, L, C, cfg.layer_norm_eps, time, need_stats=train, copy=True,
-                                        sample_scale=dp2)
+        if self.fused_mlp and C in (96, 192) and hid % (96 if C == 96 else 64) == 0:
+            u = self.new(B * L, hid, dtype=self.adt) if train else None
+            gp = self.new(B * L, hid, dtype=self.adt) if train else None
+            y2 = self.new(B * L, C) if train else None
+            st2 = (self.new(B * L), self.new(B * L)) if train else (None, None)
+            out, out16 = self.new(B * L, C), self.new(B * L, C, dtype=self.adt)
+            gw_w, gw_b, bw_w, bw_b = self._norm_params(pre + ".layernorm_after")
+            if not ops.mlp_block_fwd(h16, h, self.W(pre + ".intermediate.dense.weight"), self.P(pre + ".intermediate.dense.bias"),
+                                     self.W(pre + ".output.dense.weight"), self.P(pre + ".output.dense.bias"), out, out16, u, gp, y2,
+                                     st2[0], st2[1], time if self.cond else None, gw_w, gw_b, bw_w, bw_b, dp2, B * L, L, C, hid,
+                                     cfg.layer_norm_eps):
+                raise RuntimeError("scot_mlp_block_fwd rejected a shape the engine selected it for")
+        else:
+            # fc1 epilogue emits a = gelu(u) AND gp = gelu'(u) (one erf, fp32 registers); u itself is never stored
+            u = self.new(B * L, hid, dtype=self.adt)
+            gp = self.new(B * L, hid, dtype=self.adt) if train else None
+            ops.linear_fwd(cm, h16, self.W(pre + ".intermediate.dense.weight"), u, bias=self.P(pre + ".intermediate.dense.bias"),
+                           gelu_deriv_out=gp if train else u)     # eval: GELU(u) only (`gelu_deriv_out is out`)
+            y2 = self.new(B * L, C)
+            ops.linear_fwd(cm, u, self.W(pre + ".output.dense.weight"), y2, bias=self.P(pre + ".output.dense.bias"))
+            out, out16, st2 = self.norm_fwd(pre + ".layernorm_after", y2, h, L, C, cfg.layer_norm_eps, time, need_stats=train,
+                                            copy=True, sample_scale=dp2)
         rec = None
         if train:
             rec = dict(blk=blk, xp=xp, qkv=qkv, attn_p=attn, table=table, lse=lse, attn_c=attn_c, proj=proj, st1=st1, h16=h16, u=u, gp=gp,

@@ -182,6 +182,19 @@ def cln_fwd(x, resid, out, mean, rstd, time, gw_w, gw_b, bw_w, bw_b, rows, rows_
                                 float(eps), ptr(sample_scale), stream()), "scot_cln_fwd")
 
 
+def mlp_block_fwd(h16, h, w1, b1, w2, b2, out, out16, act, dact, z, mean, rstd, time, gw_w, gw_b, bw_w, bw_b, sample_scale,
+                  rows, rows_per_sample, C, hid, eps) -> bool:
+    """EXPERIMENTAL fused fc1 → GELU → fc2 → cond-LN → residual (csrc/mlp_fused.hip).  False = shape not covered (the
+    caller runs the three-kernel path); any other failure raises."""
+    rc = L().scot_mlp_block_fwd(ptr(h16), ptr(h), ptr(w1), ptr(b1), ptr(w2), ptr(b2), ptr(out), ptr(out16), ptr(act), ptr(dact),
+                                ptr(z), ptr(mean), ptr(rstd), ptr(time), ptr(gw_w), ptr(gw_b), ptr(bw_w), ptr(bw_b),
+                                ptr(sample_scale), rows, rows_per_sample, C, hid, float(eps), stream())
+    if rc == -3:   # SCOT_ERR_UNSUPPORTED
+        return False
+    _lib.check(rc, "scot_mlp_block_fwd")
+    return True
+
+
 def cln_bwd(dout, x, mean, rstd, time, gw_w, gw_b, dx, d_gw_w, d_gw_b, d_bw_w, d_bw_b, rows, rows_per_sample, C, d_xbias=None,
             sample_scale=None, mode=0):
     """mode 0: dx and parameter gradients; 1: dx only; 2: parameter gradients only (dx may be None)."""
