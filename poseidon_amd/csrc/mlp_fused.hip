@@ -23,6 +23,9 @@
 #include "common.h"
 #include <stdlib.h>
 
+// prefetch registers: a NATIVE vector type — arrays of HIP's uint4 struct were left in scratch memory by the compiler here
+typedef unsigned int u32x4_t __attribute__((ext_vector_type(4)));
+
 struct MlpArgs {
   const bf16_t* h16; const float* h;
   const bf16_t* W1; const float* b1;
@@ -70,19 +73,19 @@ __global__ __launch_bounds__(256, 2) void mlp_fused_kernel(MlpArgs p) {
   }
 
   // ---- weight chunk: global -> registers (unconditional, clamped piece index) -> LDS
-  uint4 r1[PW1], r2[PW2];
+  u32x4_t r1[PW1], r2[PW2];
   auto load_chunk = [&](int c) {
     const bf16_t* s1 = p.W1 + (size_t)c * HC * C;           // HC full rows of W1: one contiguous block
 #pragma unroll
     for (int u = 0; u < PW1; ++u) {
       const int i = min(tid + u * 256, N1 - 1);
-      r1[u] = *(const uint4*)(s1 + (size_t)i * 8);
+      r1[u] = *(const u32x4_t*)(s1 + (size_t)i * 8);
     }
 #pragma unroll
     for (int u = 0; u < PW2; ++u) {
       const int i = min(tid + u * 256, N2 - 1);
       const int row = i / (HC / 8), c8 = (i % (HC / 8)) * 8;
-      r2[u] = *(const uint4*)(p.W2 + (size_t)row * HID + (size_t)c * HC + c8);
+      r2[u] = *(const u32x4_t*)(p.W2 + (size_t)row * HID + (size_t)c * HC + c8);
     }
   };
   auto store_chunk = [&](int c) {
@@ -93,7 +96,7 @@ __global__ __launch_bounds__(256, 2) void mlp_fused_kernel(MlpArgs p) {
         const int x = i / (C / 8), k8 = (i % (C / 8)) * 8;   // x: hidden unit within the chunk
         const int y = x & 31;
         const int rho = (x & ~31) + (((y >> 2) & 1) << 4) + ((y >> 3) << 2) + (y & 3);   // [blk][t][a][b] of y = 8a + 4t + b
-        *(uint4*)(W1c + rho * P1 + k8) = r1[u];
+        *(u32x4_t*)(W1c + rho * P1 + k8) = r1[u];
       }
     }
 #pragma unroll
@@ -101,7 +104,7 @@ __global__ __launch_bounds__(256, 2) void mlp_fused_kernel(MlpArgs p) {
       const int i = tid + u * 256;
       if (i < N2) {
         const int row = i / (HC / 8), c8 = (i % (HC / 8)) * 8;
-        *(uint4*)(W2c + row * P2 + c8) = r2[u];
+        *(u32x4_t*)(W2c + row * P2 + c8) = r2[u];
       }
     }
     if (tid < HC) b1c[tid] = p.b1[c * HC + tid];
@@ -267,7 +270,8 @@ extern "C" int scot_mlp_block_fwd(const void* h16, const float* h, const void* W
   static int tt_env = -1;
   if (tt_env < 0) { const char* e = getenv("SCOT_MLP_TT"); tt_env = e ? atoi(e) : 0; }
   // 64·TT rows per workgroup: TT = 2 halves the LDS weight reads per MFMA; TT = 1 when that would leave CUs without work
-  const int tt = tt_env ? tt_env : (M >= 64 * 2 * 512 ? 2 : 1);
+  // (C = 192 with TT = 2 needs 256 VGPRs + spills: TT = 1 unless forced)
+  const int tt = tt_env ? tt_env : ((C == 96 && M >= 64 * 2 * 512) ? 2 : 1);
   if (C == 96) return tt == 2 ? launch_mlp<96, 96, 2>(a, stream) : launch_mlp<96, 96, 1>(a, stream);
   return tt == 2 ? launch_mlp<192, 64, 2>(a, stream) : launch_mlp<192, 64, 1>(a, stream);
 }
