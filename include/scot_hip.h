@@ -102,6 +102,15 @@ int scot_mlp_block_fwd(const void* h16, const float* h, const void* W1, const fl
                        const float* time, const float* gw_w, const float* gw_b, const float* bw_w, const float* bw_b,
                        const float* sample_scale, int M, int rows_per_sample, int C, int hid, float eps,
                        scot_stream_t stream);
+/* EXPERIMENTAL, same status: the dependent chain of that block's backward in one launch —
+ *   dz = CLN_bwd(s_b·g; z, mean, rstd) (+= the four cond-LN parameter gradients), du = (dz·W2) ⊙ dact, g_out = g + du·W1
+ * (replaces scot_cln_bwd + two dgrad scot_gemm calls; the weight gradients remain scot_gemm(TN) on dz / du).
+ * g_out may alias g.  Requires rows_per_sample % 64 == 0 (one conditioning time per workgroup). */
+int scot_mlp_block_bwd(const float* g, float* g_out, const float* z, const float* mean, const float* rstd,
+                       const float* time, const float* gw_w, const float* gw_b, const float* sample_scale,
+                       const void* dact, const void* W1, const void* W2, void* dz, void* du, float* d_gw_w,
+                       float* d_gw_b, float* d_bw_w, float* d_bw_b, int M, int rows_per_sample, int C, int hid,
+                       scot_stream_t stream);
 
 /* Data movement */
 int scot_add(const void* a, int a_dt, const void* b, int b_dt, void* out, int out_dt, size_t n, size_t period,

@@ -275,3 +275,318 @@ extern "C" int scot_mlp_block_fwd(const void* h16, const float* h, const void* W
   if (C == 96) return tt == 2 ? launch_mlp<96, 96, 2>(a, stream) : launch_mlp<96, 96, 1>(a, stream);
   return tt == 2 ? launch_mlp<192, 64, 2>(a, stream) : launch_mlp<192, 64, 1>(a, stream);
 }
+
+// ------------------------------------------------------------------------------------------------------------------------
+// Backward of the same block along the dependent chain, in one launch (the two weight gradients stay separate GEMMs on
+// the side stream; they consume the dz and du written here):
+//     dz  = CLN_bwd(s_b · g; z, mean, rstd)            (+= the four cond-LN parameter gradients)
+//     du  = (dz · W2) ⊙ gelu'(u)
+//     g'  = g + du · W1                                 (gradient wrt the block input h; may be written over g)
+// replaces cln_bwd + dgrad fc2 (aux = gelu') + dgrad fc1 (into g) of engine.layer_bwd.  Same structure as the forward:
+// GEMM 1 transposed (dA^T = W2^T · dz^T) so that, after the multiply by gelu'(u), a lane holds 8 consecutive hidden units of
+// one token = the A operand of GEMM 2 and one 16-byte store of du.  Both weight chunks are K-strided here (W2[c][hidden]
+// with k = c; W1[hidden][c] with k = hidden): the transposing LDS read (ds_read_b64_tr_b16) builds the fragments, and the
+// permutation "lane 4a+b of tile t <- hidden 8a+4t+b" is folded into its chunk pointer instead of the LDS store.
+// t (the conditioning time) must be uniform over a workgroup's rows: rows_per_sample % (64·TT) == 0.
+struct MlpBwdArgs {
+  const float* g; float* g_out;
+  const float* z; const float* mean; const float* rstd;
+  const float* time; const float* gw_w; const float* gw_b; const float* sscale;
+  const bf16_t* dact; const bf16_t* W1; const bf16_t* W2;
+  bf16_t* dz; bf16_t* du;
+  float* d_gw_w; float* d_gw_b; float* d_bw_w; float* d_bw_b;
+  int M, rows_per_sample, hid, use_tr;
+};
+
+// A-operand fragment of GEMM 1 (backward): rows = hidden units 8a+4t+b (a = lane>>2 & 3, b = lane & 3 of the 16-lane
+// group), k = channels klo..klo+3, khi..khi+3, from the K-strided chunk T[k][pitch] (column = chunk-local hidden unit).
+__device__ __forceinline__ Frag<bf16_t> lds_frag_ks_perm(const bf16_t* t, int pitch, int h0, int tsel, int klo, int khi, int lane,
+                                                         int use_tr) {
+  Frag<bf16_t> f;
+  const int i = lane & 15;
+  if (use_tr) {
+    typedef __attribute__((address_space(3))) s16x4_t* lds_v4;
+    const bf16_t* p0 = t + (klo + (i >> 2)) * pitch + h0 + (i & 3) * 8 + tsel * 4;
+    const bf16_t* p1 = t + (khi + (i >> 2)) * pitch + h0 + (i & 3) * 8 + tsel * 4;
+    const s16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4)p0);
+    const s16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4)p1);
+    f.v = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+  } else {
+    const int col = h0 + (i >> 2) * 8 + tsel * 4 + (i & 3);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      f.v[j] = (short)t[(klo + j) * pitch + col];
+      f.v[j + 4] = (short)t[(khi + j) * pitch + col];
+    }
+  }
+  return f;
+}
+
+template <int C, int HC, int TT>
+__global__ __launch_bounds__(256, 2) void mlp_bwd_fused_kernel(MlpBwdArgs p) {
+  constexpr int KJ = C / 32, NT = C / 16, NB = HC / 32;
+  constexpr int P1 = C + 8;            // W1 chunk [HC][P1]: k = hidden (rows), columns = channels
+  constexpr int P2 = HC + 8;           // W2 chunk [C][P2]:  k = channels (rows), columns = hidden
+  constexpr int PD = C + 8;            // dz patch [16][PD] bf16, K-contiguous
+  constexpr int CP = C + 4;            // epilogue patch pitch (floats)
+  constexpr int W1_EL = HC * P1, W2_EL = C * P2;
+  constexpr int N1 = HC * C / 8, N2 = C * HC / 8;
+  constexpr int PW1 = (N1 + 255) / 256, PW2 = (N2 + 255) / 256;
+  constexpr size_t WBYTES = (size_t)(W1_EL + W2_EL) * 2;
+  constexpr size_t PBYTES = (size_t)4 * 16 * CP * 4;
+  constexpr size_t RBYTES = (size_t)4 * 2 * C * 4;
+  constexpr size_t DZ_BYTES = (size_t)4 * 16 * PD * 2;
+  // one region, three lives: [dz patches | column sums] (phase 1)  ->  weight chunks (phase 2)  ->  fp32 patches (phase 3)
+  constexpr size_t P1BYTES = DZ_BYTES + RBYTES;
+  constexpr size_t LDS_BYTES = WBYTES > PBYTES ? (WBYTES > P1BYTES ? WBYTES : P1BYTES) : (PBYTES > P1BYTES ? PBYTES : P1BYTES);
+  static_assert(DZ_BYTES % 16 == 0 && (W1_EL * 2) % 16 == 0, "layout");
+  __shared__ __attribute__((aligned(16))) char smem[LDS_BYTES];
+  bf16_t* W1c = (bf16_t*)smem;
+  bf16_t* W2c = W1c + W1_EL;
+  float* red = (float*)(smem + DZ_BYTES);                      // [wave][2][C]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4, lc = lane & 15;
+  bf16_t* Dz = (bf16_t*)smem + wave * 16 * PD;
+  const int HID = p.hid, nch = HID / HC;
+  const int wg_row0 = blockIdx.x * (64 * TT);
+  const int row0 = wg_row0 + wave * (16 * TT);
+  const int prow = lane >> 2, q = lane & 3;
+
+  u32x4_t r1[PW1], r2[PW2];
+  auto load_chunk = [&](int c) {
+    const bf16_t* s1 = p.W1 + (size_t)c * HC * C;
+#pragma unroll
+    for (int u = 0; u < PW1; ++u) {
+      const int i = min(tid + u * 256, N1 - 1);
+      r1[u] = *(const u32x4_t*)(s1 + (size_t)i * 8);
+    }
+#pragma unroll
+    for (int u = 0; u < PW2; ++u) {
+      const int i = min(tid + u * 256, N2 - 1);
+      const int row = i / (HC / 8), c8 = (i % (HC / 8)) * 8;
+      r2[u] = *(const u32x4_t*)(p.W2 + (size_t)row * HID + (size_t)c * HC + c8);
+    }
+  };
+  auto store_chunk = [&]() {
+#pragma unroll
+    for (int u = 0; u < PW1; ++u) {
+      const int i = tid + u * 256;
+      if (i < N1) *(u32x4_t*)(W1c + (i / (C / 8)) * P1 + (i % (C / 8)) * 8) = r1[u];
+    }
+#pragma unroll
+    for (int u = 0; u < PW2; ++u) {
+      const int i = tid + u * 256;
+      if (i < N2) *(u32x4_t*)(W2c + (i / (HC / 8)) * P2 + (i % (HC / 8)) * 8) = r2[u];
+    }
+  };
+
+  // ---- phase 1: dz = CLN_bwd(s·g) in the row-contiguous layout (4 lanes per row), parameter-gradient column sums
+  const int samp = min(wg_row0, p.M - 1) / p.rows_per_sample;  // uniform over the workgroup (host-checked)
+  const float t = p.time ? p.time[samp] : 0.f;
+  const float sc = p.sscale ? p.sscale[samp] : 1.f;
+  float ag[KJ][8], ab[KJ][8];
+#pragma unroll
+  for (int pp = 0; pp < KJ; ++pp)
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { ag[pp][j] = 0.f; ab[pp][j] = 0.f; }
+  // gamma = gw_w·t + gw_b for 8 columns: re-read (L1/L2) where needed rather than held in 8·KJ registers
+  auto gamma8 = [&](int col, float (&ga)[8]) {
+    float gb[8], gw[8];
+    ld8(p.gw_b, SCOT_F32, col, gb);
+    if (p.gw_w) ld8(p.gw_w, SCOT_F32, col, gw);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) ga[j] = p.gw_w ? gw[j] * t + gb[j] : gb[j];
+  };
+  Frag<bf16_t> dzf[TT][KJ];
+#pragma unroll
+  for (int tt = 0; tt < TT; ++tt) {
+    const int grow = row0 + tt * 16 + prow;
+    const bool valid = grow < p.M;
+    const int rowc = valid ? grow : p.M - 1;
+    const size_t base = (size_t)rowc * C;
+    const float mean = p.mean[rowc], rstd = p.rstd[rowc];
+    float d[KJ][8], xh[KJ][8];
+    float m1 = 0.f, m2 = 0.f;
+#pragma unroll
+    for (int pp = 0; pp < KJ; ++pp) {
+      const int col = pp * 32 + q * 8;
+      float zz[8], ga[8];
+      ld8(p.g, SCOT_F32, base + col, d[pp]);
+      ld8(p.z, SCOT_F32, base + col, zz);
+      gamma8(col, ga);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const float dd = valid ? d[pp][j] * sc : 0.f;
+        xh[pp][j] = (zz[j] - mean) * rstd;
+        ag[pp][j] += dd * xh[pp][j];
+        ab[pp][j] += dd;
+        d[pp][j] = dd * ga[j];                 // from here on: dout·gamma
+        m1 += d[pp][j]; m2 += d[pp][j] * xh[pp][j];
+      }
+    }
+    m1 += __shfl_xor(m1, 1, 64); m1 += __shfl_xor(m1, 2, 64);
+    m2 += __shfl_xor(m2, 1, 64); m2 += __shfl_xor(m2, 2, 64);
+    m1 *= 1.0f / C; m2 *= 1.0f / C;
+#pragma unroll
+    for (int pp = 0; pp < KJ; ++pp) {
+      const int col = pp * 32 + q * 8;
+      float o[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) o[j] = rstd * (d[pp][j] - m1 - xh[pp][j] * m2);
+      if (valid) st8(p.dz, SCOT_BF16, base + col, o);
+      store8_ct(Dz + prow * PD + col, o);
+    }
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int j = 0; j < KJ; ++j) dzf[tt][j] = lds_frag_kc(Dz, PD, 0, j * 32, lane);   // column = token lc, k = channel
+    __builtin_amdgcn_wave_barrier();
+  }
+  // column sums over the wave's rows (the 16 rows of a pass live in lanes q, q+4, ...), then over the four waves via LDS
+#pragma unroll
+  for (int pp = 0; pp < KJ; ++pp)
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+#pragma unroll
+      for (int o = 4; o < 64; o <<= 1) { ag[pp][j] += __shfl_xor(ag[pp][j], o, 64); ab[pp][j] += __shfl_xor(ab[pp][j], o, 64); }
+    }
+  if (lane < 4) {
+#pragma unroll
+    for (int pp = 0; pp < KJ; ++pp)
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        red[(wave * 2 + 0) * C + pp * 32 + q * 8 + j] = ag[pp][j];
+        red[(wave * 2 + 1) * C + pp * 32 + q * 8 + j] = ab[pp][j];
+      }
+  }
+  __syncthreads();
+  if (tid < C) {
+    float dg = 0.f, db = 0.f;
+#pragma unroll
+    for (int w = 0; w < 4; ++w) { dg += red[(w * 2 + 0) * C + tid]; db += red[(w * 2 + 1) * C + tid]; }
+    if (p.d_gw_w) { atomicAdd(&p.d_gw_w[tid], t * dg); atomicAdd(&p.d_bw_w[tid], t * db); }
+    atomicAdd(&p.d_gw_b[tid], dg);
+    atomicAdd(&p.d_bw_b[tid], db);
+  }
+  load_chunk(0);
+  __syncthreads();                                             // the dz patches and `red` alias the weight chunk
+  store_chunk();
+  __syncthreads();
+
+  // ---- phase 2: hidden chunks
+  f32x4_t Y[TT][NT];
+#pragma unroll
+  for (int tt = 0; tt < TT; ++tt)
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) Y[tt][nt] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+  int rowt[TT];
+#pragma unroll
+  for (int tt = 0; tt < TT; ++tt) rowt[tt] = row0 + tt * 16 + lc;
+
+  for (int c = 0; c < nch; ++c) {
+    load_chunk(min(c + 1, nch - 1));
+    // gelu'(u) of this chunk for the lane's token and its 8 hidden units per block: in flight during the first MFMAs
+    s16x8_t gpv[TT][NB];
+#pragma unroll
+    for (int tt = 0; tt < TT; ++tt)
+#pragma unroll
+      for (int blk = 0; blk < NB; ++blk)
+        gpv[tt][blk] = *(const s16x8_t*)(p.dact + (size_t)min(rowt[tt], p.M - 1) * HID + (size_t)c * HC + blk * 32 + g * 8);
+#pragma unroll
+    for (int blk = 0; blk < NB; ++blk) {
+      f32x4_t U[TT][2];
+#pragma unroll
+      for (int tt = 0; tt < TT; ++tt) { U[tt][0] = (f32x4_t){0.f, 0.f, 0.f, 0.f}; U[tt][1] = (f32x4_t){0.f, 0.f, 0.f, 0.f}; }
+#pragma unroll
+      for (int j = 0; j < KJ; ++j) {
+#pragma unroll
+        for (int ts = 0; ts < 2; ++ts) {
+          const Frag<bf16_t> w = lds_frag_ks_perm(W2c, P2, blk * 32, ts, j * 32 + g * 8, j * 32 + g * 8 + 4, lane, p.use_tr);
+#pragma unroll
+          for (int tt = 0; tt < TT; ++tt) mma16(U[tt][ts], w, dzf[tt][j]);
+        }
+      }
+      Frag<bf16_t> af[TT];
+#pragma unroll
+      for (int tt = 0; tt < TT; ++tt) {
+        float dv[8];
+#pragma unroll
+        for (int ts = 0; ts < 2; ++ts)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) dv[4 * ts + r] = U[tt][ts][r] * bf2f((bf16_t)gpv[tt][blk][4 * ts + r]);
+        af[tt] = frag_from_f32<bf16_t>(dv);
+        if (rowt[tt] < p.M) *(s16x8_t*)(p.du + (size_t)rowt[tt] * HID + (size_t)c * HC + blk * 32 + g * 8) = af[tt].v;
+      }
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) {
+        const Frag<bf16_t> w = lds_frag_ks(W1c, P1, nt * 16, blk * 32 + g * 8, blk * 32 + g * 8 + 4, lane, p.use_tr);
+#pragma unroll
+        for (int tt = 0; tt < TT; ++tt) mma16(Y[tt][nt], af[tt], w);
+      }
+    }
+    __syncthreads();
+    if (c + 1 < nch) {
+      store_chunk();
+      __syncthreads();
+    }
+  }
+
+  // ---- phase 3: g' = g + du·W1, through the per-wave patch (aliases the dead weight chunk) for row-contiguous stores
+  float* Ct = (float*)smem + wave * 16 * CP;
+#pragma unroll
+  for (int tt = 0; tt < TT; ++tt) {
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) Ct[(g * 4 + r) * CP + nt * 16 + lc] = Y[tt][nt][r];
+    __builtin_amdgcn_wave_barrier();
+    const int grow = row0 + tt * 16 + prow;
+    if (grow < p.M) {
+      const size_t base = (size_t)grow * C;
+#pragma unroll
+      for (int pp = 0; pp < KJ; ++pp) {
+        const int col = pp * 32 + q * 8;
+        const float4 x0 = *(const float4*)(Ct + prow * CP + col), x1 = *(const float4*)(Ct + prow * CP + col + 4);
+        float gi[8], o[8];
+        ld8(p.g, SCOT_F32, base + col, gi);
+        o[0] = gi[0] + x0.x; o[1] = gi[1] + x0.y; o[2] = gi[2] + x0.z; o[3] = gi[3] + x0.w;
+        o[4] = gi[4] + x1.x; o[5] = gi[5] + x1.y; o[6] = gi[6] + x1.z; o[7] = gi[7] + x1.w;
+        st8(p.g_out, SCOT_F32, base + col, o);
+      }
+    }
+    __builtin_amdgcn_wave_barrier();
+  }
+}
+
+extern int g_scot_use_tr;
+
+template <int C, int HC, int TT>
+static int launch_mlp_bwd(const MlpBwdArgs& a, hipStream_t s) {
+  dim3 grid((a.M + 64 * TT - 1) / (64 * TT)), block(256);
+  hipLaunchKernelGGL((mlp_bwd_fused_kernel<C, HC, TT>), grid, block, 0, s, a);
+  return scot_check_launch();
+}
+
+// include/scot_hip.h: scot_mlp_block_bwd
+extern "C" int scot_mlp_block_bwd(const float* g, float* g_out, const float* z, const float* mean, const float* rstd,
+                                  const float* time, const float* gw_w, const float* gw_b, const float* sample_scale,
+                                  const void* dact, const void* W1, const void* W2, void* dz, void* du, float* d_gw_w,
+                                  float* d_gw_b, float* d_bw_w, float* d_bw_b, int M, int rows_per_sample, int C, int hid,
+                                  hipStream_t stream) {
+  if (M <= 0 || rows_per_sample <= 0) return SCOT_ERR_SHAPE;
+  if (C != 96 && C != 192) return SCOT_ERR_UNSUPPORTED;
+  const int hc = C == 96 ? 96 : 64;
+  if (hid < hc || hid % hc != 0) return SCOT_ERR_UNSUPPORTED;
+  if (!g || !g_out || !z || !mean || !rstd || !gw_b || !dact || !W1 || !W2 || !dz || !du || !d_gw_b || !d_bw_b) return SCOT_ERR_SHAPE;
+  if ((gw_w == nullptr) != (d_gw_w == nullptr) || (d_gw_w == nullptr) != (d_bw_w == nullptr)) return SCOT_ERR_SHAPE;
+  static int tt_env = -1;
+  if (tt_env < 0) { const char* e = getenv("SCOT_MLP_TT"); tt_env = e ? atoi(e) : 0; }
+  int tt = tt_env ? tt_env : ((C == 96 && M >= 64 * 2 * 512) ? 2 : 1);
+  if (rows_per_sample % (64 * tt) != 0) tt = 1;
+  if (rows_per_sample % 64 != 0) return SCOT_ERR_UNSUPPORTED;      // the conditioning time must be uniform per workgroup
+  MlpBwdArgs a;
+  a.g = g; a.g_out = g_out; a.z = z; a.mean = mean; a.rstd = rstd; a.time = time; a.gw_w = gw_w; a.gw_b = gw_b; a.sscale = sample_scale;
+  a.dact = (const bf16_t*)dact; a.W1 = (const bf16_t*)W1; a.W2 = (const bf16_t*)W2; a.dz = (bf16_t*)dz; a.du = (bf16_t*)du;
+  a.d_gw_w = d_gw_w; a.d_gw_b = d_gw_b; a.d_bw_w = d_bw_w; a.d_bw_b = d_bw_b;
+  a.M = M; a.rows_per_sample = rows_per_sample; a.hid = hid; a.use_tr = g_scot_use_tr;
+  if (C == 96) return tt == 2 ? launch_mlp_bwd<96, 96, 2>(a, stream) : launch_mlp_bwd<96, 96, 1>(a, stream);
+  return tt == 2 ? launch_mlp_bwd<192, 64, 2>(a, stream) : launch_mlp_bwd<192, 64, 1>(a, stream);
+}

@@ -571,15 +571,30 @@ class ScOTEngine:
         a = pre + ".attention.self."
         L, Lp = H * W, Hp * Wp
         hid = int(cfg.mlp_ratio * C)
-        # out = h + CLN_after(y2)
-        d_y2 = self.norm_bwd(pre + ".layernorm_after", g, rec["y2"], rec["st2"], L, C, time, adt, sample_scale=rec["dp"][1])
-        # y2 = gelu(u) W2^T + b2
-        self.linear_bwd_params(pre + ".output.dense.weight", pre + ".output.dense.bias", d_y2, rec["u"])   # rec["u"] = gelu(u)
-        d_u = self.new(B * L, hid, dtype=adt)
-        ops.linear_dgrad(cm, d_y2, self.W(pre + ".output.dense.weight"), d_u, aux=rec["gp"], aux_mul=True)
-        # u = h W1^T + b1
-        self.linear_bwd_params(pre + ".intermediate.dense.weight", pre + ".intermediate.dense.bias", d_u, rec["h16"])
-        g = self.dgrad_into(cm, d_u, self.W(pre + ".intermediate.dense.weight"), g)
+        if (self.fused_mlp and C in (96, 192) and hid % (96 if C == 96 else 64) == 0 and L % 64 == 0 and not self.split_ln_bwd):
+            # the whole dependent chain of the MLP half in one launch; the two weight gradients follow on the side stream
+            d_y2 = self.new(B * L, C, dtype=adt)
+            d_u = self.new(B * L, hid, dtype=adt)
+            gw_w, gw_b, _, _ = self._norm_params(pre + ".layernorm_after")
+            gg = self._norm_grads(pre + ".layernorm_after")
+            g2 = g if self.inplace_g else self.new(B * L, C)
+            if not ops.mlp_block_bwd(g, g2, rec["y2"], rec["st2"][0], rec["st2"][1], time if self.cond else None, gw_w, gw_b,
+                                     rec["dp"][1], rec["gp"], self.W(pre + ".intermediate.dense.weight"),
+                                     self.W(pre + ".output.dense.weight"), d_y2, d_u, gg[0], gg[1], gg[2], gg[3], B * L, L, C, hid):
+                raise RuntimeError("scot_mlp_block_bwd rejected a shape the engine selected it for")
+            g = g2
+            self.linear_bwd_params(pre + ".output.dense.weight", pre + ".output.dense.bias", d_y2, rec["u"])
+            self.linear_bwd_params(pre + ".intermediate.dense.weight", pre + ".intermediate.dense.bias", d_u, rec["h16"])
+        else:
+            # out = h + CLN_after(y2)
+            d_y2 = self.norm_bwd(pre + ".layernorm_after", g, rec["y2"], rec["st2"], L, C, time, adt, sample_scale=rec["dp"][1])
+            # y2 = gelu(u) W2^T + b2
+            self.linear_bwd_params(pre + ".output.dense.weight", pre + ".output.dense.bias", d_y2, rec["u"])   # rec["u"] = gelu(u)
+            d_u = self.new(B * L, hid, dtype=adt)
+            ops.linear_dgrad(cm, d_y2, self.W(pre + ".output.dense.weight"), d_u, aux=rec["gp"], aux_mul=True)
+            # u = h W1^T + b1
+            self.linear_bwd_params(pre + ".intermediate.dense.weight", pre + ".intermediate.dense.bias", d_u, rec["h16"])
+            g = self.dgrad_into(cm, d_u, self.W(pre + ".intermediate.dense.weight"), g)
         # h = x + CLN_before(proj)
         d_proj = self.norm_bwd(pre + ".layernorm_before", g, rec["proj"], rec["st1"], L, C, time, adt, sample_scale=rec["dp"][0])
         self.linear_bwd_params(pre + ".attention.output.dense.weight", pre + ".attention.output.dense.bias", d_proj, rec["attn_c"])

@@ -195,6 +195,18 @@ def mlp_block_fwd(h16, h, w1, b1, w2, b2, out, out16, act, dact, z, mean, rstd, 
     return True
 
 
+def mlp_block_bwd(g, g_out, z, mean, rstd, time, gw_w, gw_b, sample_scale, dact, w1, w2, dz, du, d_gw_w, d_gw_b, d_bw_w, d_bw_b,
+                  rows, rows_per_sample, C, hid) -> bool:
+    """EXPERIMENTAL fused cond-LN backward → dgrad fc2 (·gelu') → dgrad fc1 (+ g) (csrc/mlp_fused.hip).  False = not covered."""
+    rc = L().scot_mlp_block_bwd(ptr(g), ptr(g_out), ptr(z), ptr(mean), ptr(rstd), ptr(time), ptr(gw_w), ptr(gw_b),
+                                ptr(sample_scale), ptr(dact), ptr(w1), ptr(w2), ptr(dz), ptr(du), ptr(d_gw_w), ptr(d_gw_b),
+                                ptr(d_bw_w), ptr(d_bw_b), rows, rows_per_sample, C, hid, stream())
+    if rc == -3:   # SCOT_ERR_UNSUPPORTED
+        return False
+    _lib.check(rc, "scot_mlp_block_bwd")
+    return True
+
+
 def cln_bwd(dout, x, mean, rstd, time, gw_w, gw_b, dx, d_gw_w, d_gw_b, d_bw_w, d_bw_b, rows, rows_per_sample, C, d_xbias=None,
             sample_scale=None, mode=0):
     """mode 0: dx and parameter gradients; 1: dx only; 2: parameter gradients only (dx may be None)."""
