@@ -111,6 +111,18 @@ int scot_mlp_block_bwd(const float* g, float* g_out, const float* z, const float
                        const void* dact, const void* W1, const void* W2, void* dz, void* du, float* d_gw_w,
                        float* d_gw_b, float* d_bw_w, float* d_bw_b, int M, int rows_per_sample, int C, int hid,
                        scot_stream_t stream);
+/* EXPERIMENTAL, same status: the tail of the attention half with the layer norm in the GEMM epilogue —
+ *   out = resid + s_b·CLN(a·W^T + bias), out16 = bf16(out)   (Swinv2SelfOutput, HF modeling_swinv2.py:478-489, + res-post-norm,
+ *   reference scOT/model.py:560-565);  a [M,C] bf16, W [C,C] bf16 (N x K);  training also stores z = a·W^T + bias and mean/rstd.
+ * scot_proj_cln_bwd: dz = CLN_bwd(s_b·g; z, mean, rstd) (+= the four cond-LN parameter gradients), da = dz·W. */
+int scot_proj_cln_fwd(const void* a, const void* W, const float* bias, const float* resid, float* out, void* out16, float* z,
+                      float* mean, float* rstd, const float* time, const float* gw_w, const float* gw_b, const float* bw_w,
+                      const float* bw_b, const float* sample_scale, int M, int rows_per_sample, int C, float eps,
+                      scot_stream_t stream);
+int scot_proj_cln_bwd(const float* g, const float* z, const float* mean, const float* rstd, const float* time,
+                      const float* gw_w, const float* gw_b, const float* sample_scale, const void* W, void* dz, void* da,
+                      float* d_gw_w, float* d_gw_b, float* d_bw_w, float* d_bw_b, int M, int rows_per_sample, int C,
+                      scot_stream_t stream);
 
 /* Data movement */
 int scot_add(const void* a, int a_dt, const void* b, int b_dt, void* out, int out_dt, size_t n, size_t period,

@@ -23,6 +23,8 @@
 #include "common.h"
 #include <stdlib.h>
 
+#include "block_fused.h"
+
 // prefetch registers: a NATIVE vector type — arrays of HIP's uint4 struct were left in scratch memory by the compiler here
 typedef unsigned int u32x4_t __attribute__((ext_vector_type(4)));
 
@@ -179,65 +181,11 @@ __global__ __launch_bounds__(256, 2) void mlp_fused_kernel(MlpArgs p) {
 
   // ---- epilogue: + b2, layer norm over the row, conditional affine, DropPath scale, residual.  The weight chunk is dead
   // (barrier above): each wave stages one 16-row tile at a time in its own patch and re-reads it row-contiguously.
-  float* Ct = (float*)smem + wave * 16 * CP;
-  const int prow = lane >> 2, q = lane & 3;
-#pragma unroll
-  for (int tt = 0; tt < TT; ++tt) {
-#pragma unroll
-    for (int nt = 0; nt < NT; ++nt)
-#pragma unroll
-      for (int r = 0; r < 4; ++r) Ct[(g * 4 + r) * CP + nt * 16 + lc] = Y[tt][nt][r];
-    __builtin_amdgcn_wave_barrier();
-    const int grow = row0 + tt * 16 + prow;
-    const bool valid = grow < p.M;
-    float v[KJ][8];
-    float s1 = 0.f;
-#pragma unroll
-    for (int pp = 0; pp < KJ; ++pp) {
-      const int col = pp * 32 + q * 8;
-      const float4 x0 = *(const float4*)(Ct + prow * CP + col), x1 = *(const float4*)(Ct + prow * CP + col + 4);
-      float bb[8];
-      ld8(p.b2, SCOT_F32, col, bb);
-      v[pp][0] = x0.x + bb[0]; v[pp][1] = x0.y + bb[1]; v[pp][2] = x0.z + bb[2]; v[pp][3] = x0.w + bb[3];
-      v[pp][4] = x1.x + bb[4]; v[pp][5] = x1.y + bb[5]; v[pp][6] = x1.z + bb[6]; v[pp][7] = x1.w + bb[7];
-#pragma unroll
-      for (int j = 0; j < 8; ++j) s1 += v[pp][j];
-    }
-    s1 += __shfl_xor(s1, 1, 64); s1 += __shfl_xor(s1, 2, 64);
-    const float mean = s1 * (1.0f / C);
-    float s2 = 0.f;
-#pragma unroll
-    for (int pp = 0; pp < KJ; ++pp)
-#pragma unroll
-      for (int j = 0; j < 8; ++j) { const float d = v[pp][j] - mean; s2 += d * d; }
-    s2 += __shfl_xor(s2, 1, 64); s2 += __shfl_xor(s2, 2, 64);
-    const float rstd = 1.0f / sqrtf(s2 * (1.0f / C) + p.eps);
-    if (valid) {
-      const size_t base = (size_t)grow * C;
-      if (p.mean && q == 0) { p.mean[grow] = mean; p.rstd[grow] = rstd; }
-      const int samp = grow / p.rows_per_sample;
-      const float t = p.time ? p.time[samp] : 0.f;
-      const float sc = p.sscale ? p.sscale[samp] : 1.f;
-#pragma unroll
-      for (int pp = 0; pp < KJ; ++pp) {
-        const int col = pp * 32 + q * 8;
-        if (p.z) st8(p.z, SCOT_F32, base + col, v[pp]);
-        float gw[8], gb[8], bw[8], bbv[8], res[8], o[8];
-        ld8(p.gw_b, SCOT_F32, col, gb); ld8(p.bw_b, SCOT_F32, col, bbv);
-        if (p.gw_w) { ld8(p.gw_w, SCOT_F32, col, gw); ld8(p.bw_w, SCOT_F32, col, bw); }
-        ld8(p.h, SCOT_F32, base + col, res);
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {
-          const float ga = p.gw_w ? gw[j] * t + gb[j] : gb[j];
-          const float be = p.gw_w ? bw[j] * t + bbv[j] : bbv[j];
-          o[j] = sc * (ga * ((v[pp][j] - mean) * rstd) + be) + res[j];
-        }
-        st8(p.out, SCOT_F32, base + col, o);
-        if (p.out16) st8(p.out16, SCOT_BF16, base + col, o);
-      }
-    }
-    __builtin_amdgcn_wave_barrier();
-  }
+  ClnRowsOut e;
+  e.bias = p.b2; e.z = p.z; e.mean = p.mean; e.rstd = p.rstd; e.time = p.time; e.gw_w = p.gw_w; e.gw_b = p.gw_b; e.bw_w = p.bw_w;
+  e.bw_b = p.bw_b; e.sscale = p.sscale; e.resid = p.h; e.out = p.out; e.out16 = p.out16; e.M = p.M; e.rows_per_sample = p.rows_per_sample;
+  e.eps = p.eps;
+  cln_rows_epilogue<C, TT>(Y, (float*)smem, row0, e);
 }
 
 template <int C, int HC, int TT>
@@ -327,25 +275,20 @@ __global__ __launch_bounds__(256, 2) void mlp_bwd_fused_kernel(MlpBwdArgs p) {
   constexpr int KJ = C / 32, NT = C / 16, NB = HC / 32;
   constexpr int P1 = C + 8;            // W1 chunk [HC][P1]: k = hidden (rows), columns = channels
   constexpr int P2 = HC + 8;           // W2 chunk [C][P2]:  k = channels (rows), columns = hidden
-  constexpr int PD = C + 8;            // dz patch [16][PD] bf16, K-contiguous
   constexpr int CP = C + 4;            // epilogue patch pitch (floats)
   constexpr int W1_EL = HC * P1, W2_EL = C * P2;
   constexpr int N1 = HC * C / 8, N2 = C * HC / 8;
   constexpr int PW1 = (N1 + 255) / 256, PW2 = (N2 + 255) / 256;
   constexpr size_t WBYTES = (size_t)(W1_EL + W2_EL) * 2;
   constexpr size_t PBYTES = (size_t)4 * 16 * CP * 4;
-  constexpr size_t RBYTES = (size_t)4 * 2 * C * 4;
-  constexpr size_t DZ_BYTES = (size_t)4 * 16 * PD * 2;
   // one region, three lives: [dz patches | column sums] (phase 1)  ->  weight chunks (phase 2)  ->  fp32 patches (phase 3)
-  constexpr size_t P1BYTES = DZ_BYTES + RBYTES;
+  constexpr size_t P1BYTES = ClnBwdLds<C>::bytes;
   constexpr size_t LDS_BYTES = WBYTES > PBYTES ? (WBYTES > P1BYTES ? WBYTES : P1BYTES) : (PBYTES > P1BYTES ? PBYTES : P1BYTES);
-  static_assert(DZ_BYTES % 16 == 0 && (W1_EL * 2) % 16 == 0, "layout");
+  static_assert((W1_EL * 2) % 16 == 0, "layout");
   __shared__ __attribute__((aligned(16))) char smem[LDS_BYTES];
   bf16_t* W1c = (bf16_t*)smem;
   bf16_t* W2c = W1c + W1_EL;
-  float* red = (float*)(smem + DZ_BYTES);                      // [wave][2][C]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4, lc = lane & 15;
-  bf16_t* Dz = (bf16_t*)smem + wave * 16 * PD;
   const int HID = p.hid, nch = HID / HC;
   const int wg_row0 = blockIdx.x * (64 * TT);
   const int row0 = wg_row0 + wave * (16 * TT);
@@ -380,92 +323,12 @@ __global__ __launch_bounds__(256, 2) void mlp_bwd_fused_kernel(MlpBwdArgs p) {
   };
 
   // ---- phase 1: dz = CLN_bwd(s·g) in the row-contiguous layout (4 lanes per row), parameter-gradient column sums
-  const int samp = min(wg_row0, p.M - 1) / p.rows_per_sample;  // uniform over the workgroup (host-checked)
-  const float t = p.time ? p.time[samp] : 0.f;
-  const float sc = p.sscale ? p.sscale[samp] : 1.f;
-  float ag[KJ][8], ab[KJ][8];
-#pragma unroll
-  for (int pp = 0; pp < KJ; ++pp)
-#pragma unroll
-    for (int j = 0; j < 8; ++j) { ag[pp][j] = 0.f; ab[pp][j] = 0.f; }
-  // gamma = gw_w·t + gw_b for 8 columns: re-read (L1/L2) where needed rather than held in 8·KJ registers
-  auto gamma8 = [&](int col, float (&ga)[8]) {
-    float gb[8], gw[8];
-    ld8(p.gw_b, SCOT_F32, col, gb);
-    if (p.gw_w) ld8(p.gw_w, SCOT_F32, col, gw);
-#pragma unroll
-    for (int j = 0; j < 8; ++j) ga[j] = p.gw_w ? gw[j] * t + gb[j] : gb[j];
-  };
+  ClnRowsBwd b;
+  b.g = p.g; b.z = p.z; b.mean = p.mean; b.rstd = p.rstd; b.time = p.time; b.gw_w = p.gw_w; b.gw_b = p.gw_b; b.sscale = p.sscale;
+  b.dz = p.dz; b.d_gw_w = p.d_gw_w; b.d_gw_b = p.d_gw_b; b.d_bw_w = p.d_bw_w; b.d_bw_b = p.d_bw_b; b.M = p.M;
+  b.rows_per_sample = p.rows_per_sample;
   Frag<bf16_t> dzf[TT][KJ];
-#pragma unroll
-  for (int tt = 0; tt < TT; ++tt) {
-    const int grow = row0 + tt * 16 + prow;
-    const bool valid = grow < p.M;
-    const int rowc = valid ? grow : p.M - 1;
-    const size_t base = (size_t)rowc * C;
-    const float mean = p.mean[rowc], rstd = p.rstd[rowc];
-    float d[KJ][8], xh[KJ][8];
-    float m1 = 0.f, m2 = 0.f;
-#pragma unroll
-    for (int pp = 0; pp < KJ; ++pp) {
-      const int col = pp * 32 + q * 8;
-      float zz[8], ga[8];
-      ld8(p.g, SCOT_F32, base + col, d[pp]);
-      ld8(p.z, SCOT_F32, base + col, zz);
-      gamma8(col, ga);
-#pragma unroll
-      for (int j = 0; j < 8; ++j) {
-        const float dd = valid ? d[pp][j] * sc : 0.f;
-        xh[pp][j] = (zz[j] - mean) * rstd;
-        ag[pp][j] += dd * xh[pp][j];
-        ab[pp][j] += dd;
-        d[pp][j] = dd * ga[j];                 // from here on: dout·gamma
-        m1 += d[pp][j]; m2 += d[pp][j] * xh[pp][j];
-      }
-    }
-    m1 += __shfl_xor(m1, 1, 64); m1 += __shfl_xor(m1, 2, 64);
-    m2 += __shfl_xor(m2, 1, 64); m2 += __shfl_xor(m2, 2, 64);
-    m1 *= 1.0f / C; m2 *= 1.0f / C;
-#pragma unroll
-    for (int pp = 0; pp < KJ; ++pp) {
-      const int col = pp * 32 + q * 8;
-      float o[8];
-#pragma unroll
-      for (int j = 0; j < 8; ++j) o[j] = rstd * (d[pp][j] - m1 - xh[pp][j] * m2);
-      if (valid) st8(p.dz, SCOT_BF16, base + col, o);
-      store8_ct(Dz + prow * PD + col, o);
-    }
-    __builtin_amdgcn_wave_barrier();
-#pragma unroll
-    for (int j = 0; j < KJ; ++j) dzf[tt][j] = lds_frag_kc(Dz, PD, 0, j * 32, lane);   // column = token lc, k = channel
-    __builtin_amdgcn_wave_barrier();
-  }
-  // column sums over the wave's rows (the 16 rows of a pass live in lanes q, q+4, ...), then over the four waves via LDS
-#pragma unroll
-  for (int pp = 0; pp < KJ; ++pp)
-#pragma unroll
-    for (int j = 0; j < 8; ++j) {
-#pragma unroll
-      for (int o = 4; o < 64; o <<= 1) { ag[pp][j] += __shfl_xor(ag[pp][j], o, 64); ab[pp][j] += __shfl_xor(ab[pp][j], o, 64); }
-    }
-  if (lane < 4) {
-#pragma unroll
-    for (int pp = 0; pp < KJ; ++pp)
-#pragma unroll
-      for (int j = 0; j < 8; ++j) {
-        red[(wave * 2 + 0) * C + pp * 32 + q * 8 + j] = ag[pp][j];
-        red[(wave * 2 + 1) * C + pp * 32 + q * 8 + j] = ab[pp][j];
-      }
-  }
-  __syncthreads();
-  if (tid < C) {
-    float dg = 0.f, db = 0.f;
-#pragma unroll
-    for (int w = 0; w < 4; ++w) { dg += red[(w * 2 + 0) * C + tid]; db += red[(w * 2 + 1) * C + tid]; }
-    if (p.d_gw_w) { atomicAdd(&p.d_gw_w[tid], t * dg); atomicAdd(&p.d_bw_w[tid], t * db); }
-    atomicAdd(&p.d_gw_b[tid], dg);
-    atomicAdd(&p.d_bw_b[tid], db);
-  }
+  cln_bwd_rows<C, TT>(dzf, smem, wg_row0, b);
   load_chunk(0);
   __syncthreads();                                             // the dz patches and `red` alias the weight chunk
   store_chunk();
@@ -589,4 +452,199 @@ extern "C" int scot_mlp_block_bwd(const float* g, float* g_out, const float* z, 
   a.M = M; a.rows_per_sample = rows_per_sample; a.hid = hid; a.use_tr = g_scot_use_tr;
   if (C == 96) return tt == 2 ? launch_mlp_bwd<96, 96, 2>(a, stream) : launch_mlp_bwd<96, 96, 1>(a, stream);
   return tt == 2 ? launch_mlp_bwd<192, 64, 2>(a, stream) : launch_mlp_bwd<192, 64, 1>(a, stream);
+}
+
+// ------------------------------------------------------------------------------------------------------------------------
+// The attention half's tail, same row ownership:  out = x + s_b · CLN(a · W^T + b)   (Swinv2SelfOutput + res-post-norm,
+// HF:478-489, reference model.py:560-565) — the out-projection GEMM with the layer norm in its epilogue (one workgroup owns
+// whole rows because N = C <= 192), and its backward along the chain:  dz = CLN_bwd(s_b · g),  da = dz · W.
+struct ProjClnArgs {
+  const bf16_t* a; const bf16_t* W;      // [M, C] attention output (operand dtype), [C, C] weight (N x K)
+  ClnRowsOut e;
+};
+
+template <int C, int TT>
+__global__ __launch_bounds__(256, 2) void proj_cln_fused_kernel(ProjClnArgs p) {
+  constexpr int KJ = C / 32, NT = C / 16, KC = 96, NKC = C / KC;
+  constexpr int PW = KC + 8;                       // W chunk [C][PW]: K-contiguous columns kc·96 .. +95 of every row
+  constexpr int NP = C * KC / 8, PWN = (NP + 255) / 256;
+  constexpr size_t WBYTES = (size_t)C * PW * 2, PBYTES = (size_t)4 * 16 * (C + 4) * 4;
+  constexpr size_t LDS_BYTES = WBYTES > PBYTES ? WBYTES : PBYTES;
+  static_assert(C % KC == 0, "K chunking");
+  __shared__ __attribute__((aligned(16))) char smem[LDS_BYTES];
+  bf16_t* Wc = (bf16_t*)smem;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4, lc = lane & 15;
+  const int row0 = (blockIdx.x * 4 + wave) * (16 * TT);
+
+  Frag<bf16_t> af[TT][KJ];                         // A operand straight from HBM: row = token lc, k = 32 j + 8 g ..
+#pragma unroll
+  for (int tt = 0; tt < TT; ++tt) {
+    const bf16_t* src = p.a + (size_t)min(row0 + tt * 16 + lc, p.e.M - 1) * C + g * 8;
+#pragma unroll
+    for (int j = 0; j < KJ; ++j) af[tt][j].v = *(const s16x8_t*)(src + j * 32);
+  }
+  f32x4_t Y[TT][NT];
+#pragma unroll
+  for (int tt = 0; tt < TT; ++tt)
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) Y[tt][nt] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+  u32x4_t rw[PWN];
+#pragma unroll
+  for (int kc = 0; kc < NKC; ++kc) {
+#pragma unroll
+    for (int u = 0; u < PWN; ++u) {
+      const int i = min(tid + u * 256, NP - 1);
+      rw[u] = *(const u32x4_t*)(p.W + (size_t)(i / (KC / 8)) * C + kc * KC + (i % (KC / 8)) * 8);
+    }
+    if (kc) __syncthreads();                       // every wave is done with the previous chunk
+#pragma unroll
+    for (int u = 0; u < PWN; ++u) {
+      const int i = tid + u * 256;
+      if (i < NP) *(u32x4_t*)(Wc + (i / (KC / 8)) * PW + (i % (KC / 8)) * 8) = rw[u];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < KC / 32; ++j)
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) {
+        const Frag<bf16_t> w = lds_frag_kc(Wc, PW, nt * 16, j * 32, lane);
+#pragma unroll
+        for (int tt = 0; tt < TT; ++tt) mma16(Y[tt][nt], af[tt][kc * (KC / 32) + j], w);
+      }
+  }
+  __syncthreads();                                 // the epilogue patches alias the weight chunk
+  cln_rows_epilogue<C, TT>(Y, (float*)smem, row0, p.e);
+}
+
+struct ProjClnBwdArgs {
+  const bf16_t* W;                       // [C, C] (N x K): da[:, k] = Σ_n dz[:, n] · W[n, k]
+  bf16_t* da;                            // [M, C]
+  ClnRowsBwd b;
+  int use_tr;
+};
+
+template <int C, int TT>
+__global__ __launch_bounds__(256, 2) void proj_cln_bwd_fused_kernel(ProjClnBwdArgs p) {
+  constexpr int NT = C / 16, KC = 96, NKC = C / KC;
+  constexpr int PW = C + 8;                        // W chunk [KC rows n][PW]: the contraction index runs over rows (K-strided)
+  constexpr int NP = KC * C / 8, PWN = (NP + 255) / 256;
+  constexpr int CP = C + 4;
+  constexpr size_t WBYTES = (size_t)KC * PW * 2, PBYTES = (size_t)4 * 16 * CP * 4, P1BYTES = ClnBwdLds<C>::bytes;
+  constexpr size_t LDS_BYTES = WBYTES > PBYTES ? (WBYTES > P1BYTES ? WBYTES : P1BYTES) : (PBYTES > P1BYTES ? PBYTES : P1BYTES);
+  __shared__ __attribute__((aligned(16))) char smem[LDS_BYTES];
+  bf16_t* Wc = (bf16_t*)smem;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4, lc = lane & 15;
+  const int wg_row0 = blockIdx.x * (64 * TT);
+  const int row0 = wg_row0 + wave * (16 * TT);
+
+  Frag<bf16_t> dzf[TT][C / 32];
+  cln_bwd_rows<C, TT>(dzf, smem, wg_row0, p.b);
+  f32x4_t Y[TT][NT];
+#pragma unroll
+  for (int tt = 0; tt < TT; ++tt)
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) Y[tt][nt] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+  u32x4_t rw[PWN];
+#pragma unroll
+  for (int kc = 0; kc < NKC; ++kc) {
+    const bf16_t* src = p.W + (size_t)kc * KC * C;               // KC full rows: one contiguous block
+#pragma unroll
+    for (int u = 0; u < PWN; ++u) rw[u] = *(const u32x4_t*)(src + (size_t)min(tid + u * 256, NP - 1) * 8);
+    __syncthreads();                               // phase-1 LDS (kc = 0) / the previous chunk (kc > 0) is dead
+#pragma unroll
+    for (int u = 0; u < PWN; ++u) {
+      const int i = tid + u * 256;
+      if (i < NP) *(u32x4_t*)(Wc + (i / (C / 8)) * PW + (i % (C / 8)) * 8) = rw[u];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < KC / 32; ++j)
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) {
+        const Frag<bf16_t> w = lds_frag_ks(Wc, PW, nt * 16, j * 32 + g * 8, j * 32 + g * 8 + 4, lane, p.use_tr);
+#pragma unroll
+        for (int tt = 0; tt < TT; ++tt) mma16(Y[tt][nt], dzf[tt][kc * (KC / 32) + j], w);
+      }
+  }
+  __syncthreads();
+  // da rows through the per-wave fp32 patch -> 16-byte bf16 row segments
+  float* Ct = (float*)smem + wave * 16 * CP;
+  const int prow = lane >> 2, q = lane & 3;
+#pragma unroll
+  for (int tt = 0; tt < TT; ++tt) {
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) Ct[(g * 4 + r) * CP + nt * 16 + lc] = Y[tt][nt][r];
+    __builtin_amdgcn_wave_barrier();
+    const int grow = row0 + tt * 16 + prow;
+    if (grow < p.b.M) {
+#pragma unroll
+      for (int pp = 0; pp < C / 32; ++pp) {
+        const int col = pp * 32 + q * 8;
+        const float4 x0 = *(const float4*)(Ct + prow * CP + col), x1 = *(const float4*)(Ct + prow * CP + col + 4);
+        const float o[8] = {x0.x, x0.y, x0.z, x0.w, x1.x, x1.y, x1.z, x1.w};
+        st8(p.da, SCOT_BF16, (size_t)grow * C + col, o);
+      }
+    }
+    __builtin_amdgcn_wave_barrier();
+  }
+}
+
+static int rows_tile_count(int C, int M, int rows_per_sample) {
+  static int tt_env = -1;
+  if (tt_env < 0) { const char* e = getenv("SCOT_MLP_TT"); tt_env = e ? atoi(e) : 0; }
+  int tt = tt_env ? tt_env : ((C == 96 && M >= 64 * 2 * 512) ? 2 : 1);
+  if (rows_per_sample % (64 * tt) != 0) tt = 1;
+  return tt;
+}
+
+// include/scot_hip.h: scot_proj_cln_fwd
+extern "C" int scot_proj_cln_fwd(const void* a, const void* W, const float* bias, const float* resid, float* out, void* out16,
+                                 float* z, float* mean, float* rstd, const float* time, const float* gw_w, const float* gw_b,
+                                 const float* bw_w, const float* bw_b, const float* sample_scale, int M, int rows_per_sample,
+                                 int C, float eps, hipStream_t stream) {
+  if (M <= 0 || rows_per_sample <= 0) return SCOT_ERR_SHAPE;
+  if (C != 96 && C != 192) return SCOT_ERR_UNSUPPORTED;
+  if (!a || !W || !bias || !resid || !out || !gw_b || !bw_b) return SCOT_ERR_SHAPE;
+  if ((mean == nullptr) != (rstd == nullptr) || (gw_w == nullptr) != (bw_w == nullptr)) return SCOT_ERR_SHAPE;
+  ProjClnArgs p;
+  p.a = (const bf16_t*)a; p.W = (const bf16_t*)W;
+  p.e.bias = bias; p.e.z = z; p.e.mean = mean; p.e.rstd = rstd; p.e.time = time; p.e.gw_w = gw_w; p.e.gw_b = gw_b; p.e.bw_w = bw_w;
+  p.e.bw_b = bw_b; p.e.sscale = sample_scale; p.e.resid = resid; p.e.out = out; p.e.out16 = (bf16_t*)out16; p.e.M = M;
+  p.e.rows_per_sample = rows_per_sample; p.e.eps = eps;
+  const int tt = rows_tile_count(C, M, 64 * 2);    // no per-workgroup uniformity needed in the forward
+  dim3 grid((M + 64 * tt - 1) / (64 * tt)), block(256);
+  if (C == 96) {
+    if (tt == 2) hipLaunchKernelGGL((proj_cln_fused_kernel<96, 2>), grid, block, 0, stream, p);
+    else hipLaunchKernelGGL((proj_cln_fused_kernel<96, 1>), grid, block, 0, stream, p);
+  } else {
+    hipLaunchKernelGGL((proj_cln_fused_kernel<192, 1>), dim3((M + 63) / 64), block, 0, stream, p);
+  }
+  return scot_check_launch();
+}
+
+// include/scot_hip.h: scot_proj_cln_bwd
+extern "C" int scot_proj_cln_bwd(const float* g, const float* z, const float* mean, const float* rstd, const float* time,
+                                 const float* gw_w, const float* gw_b, const float* sample_scale, const void* W, void* dz, void* da,
+                                 float* d_gw_w, float* d_gw_b, float* d_bw_w, float* d_bw_b, int M, int rows_per_sample, int C,
+                                 hipStream_t stream) {
+  if (M <= 0 || rows_per_sample <= 0) return SCOT_ERR_SHAPE;
+  if ((C != 96 && C != 192) || rows_per_sample % 64 != 0) return SCOT_ERR_UNSUPPORTED;
+  if (!g || !z || !mean || !rstd || !gw_b || !W || !dz || !da || !d_gw_b || !d_bw_b) return SCOT_ERR_SHAPE;
+  if ((gw_w == nullptr) != (d_gw_w == nullptr) || (d_gw_w == nullptr) != (d_bw_w == nullptr)) return SCOT_ERR_SHAPE;
+  ProjClnBwdArgs p;
+  p.W = (const bf16_t*)W; p.da = (bf16_t*)da; p.use_tr = g_scot_use_tr;
+  p.b.g = g; p.b.z = z; p.b.mean = mean; p.b.rstd = rstd; p.b.time = time; p.b.gw_w = gw_w; p.b.gw_b = gw_b; p.b.sscale = sample_scale;
+  p.b.dz = (bf16_t*)dz; p.b.d_gw_w = d_gw_w; p.b.d_gw_b = d_gw_b; p.b.d_bw_w = d_bw_w; p.b.d_bw_b = d_bw_b; p.b.M = M;
+  p.b.rows_per_sample = rows_per_sample;
+  const int tt = C == 96 ? rows_tile_count(C, M, rows_per_sample) : 1;
+  dim3 grid((M + 64 * tt - 1) / (64 * tt)), block(256);
+  if (C == 96) {
+    if (tt == 2) hipLaunchKernelGGL((proj_cln_bwd_fused_kernel<96, 2>), grid, block, 0, stream, p);
+    else hipLaunchKernelGGL((proj_cln_bwd_fused_kernel<96, 1>), grid, block, 0, stream, p);
+  } else {
+    hipLaunchKernelGGL((proj_cln_bwd_fused_kernel<192, 1>), grid, block, 0, stream, p);
+  }
+  return scot_check_launch();
 }

@@ -451,13 +451,23 @@ class ScOTEngine:
             ops.copy2d(attn, attn_c, B, Hp, Wp, H, W, C)
         else:
             attn_c = attn
-        proj = self.new(B * L, C)
-        ops.linear_fwd(cm, attn_c, self.W(pre + ".attention.output.dense.weight"), proj,
-                       bias=self.P(pre + ".attention.output.dense.bias"))
         dp1 = self.drop_path_scale(pre, B, 0) if train else None
         dp2 = self.drop_path_scale(pre, B, 1) if train else None
-        h, h16, st1 = self.norm_fwd(pre + ".layernorm_before", proj, x, L, C, cfg.layer_norm_eps, time, need_stats=train, copy=True,
-                                    sample_scale=dp1)
+        if self.fused_mlp and C in (96, 192):
+            proj = self.new(B * L, C) if train else None
+            st1 = (self.new(B * L), self.new(B * L)) if train else (None, None)
+            h, h16 = self.new(B * L, C), self.new(B * L, C, dtype=self.adt)
+            gw_w, gw_b, bw_w, bw_b = self._norm_params(pre + ".layernorm_before")
+            if not ops.proj_cln_fwd(attn_c, self.W(pre + ".attention.output.dense.weight"), self.P(pre + ".attention.output.dense.bias"),
+                                    x, h, h16, proj, st1[0], st1[1], time if self.cond else None, gw_w, gw_b, bw_w, bw_b, dp1, B * L, L,
+                                    C, cfg.layer_norm_eps):
+                raise RuntimeError("scot_proj_cln_fwd rejected a shape the engine selected it for")
+        else:
+            proj = self.new(B * L, C)
+            ops.linear_fwd(cm, attn_c, self.W(pre + ".attention.output.dense.weight"), proj,
+                           bias=self.P(pre + ".attention.output.dense.bias"))
+            h, h16, st1 = self.norm_fwd(pre + ".layernorm_before", proj, x, L, C, cfg.layer_norm_eps, time, need_stats=train,
+                                        copy=True, sample_scale=dp1)
         hid = int(cfg.mlp_ratio * C)
         if self.fused_mlp and C in (96, 192) and hid % (96 if C == 96 else 64) == 0:
             u = self.new(B * L, hid, dtype=self.adt) if train else None
@@ -596,10 +606,20 @@ class ScOTEngine:
             self.linear_bwd_params(pre + ".intermediate.dense.weight", pre + ".intermediate.dense.bias", d_u, rec["h16"])
             g = self.dgrad_into(cm, d_u, self.W(pre + ".intermediate.dense.weight"), g)
         # h = x + CLN_before(proj)
-        d_proj = self.norm_bwd(pre + ".layernorm_before", g, rec["proj"], rec["st1"], L, C, time, adt, sample_scale=rec["dp"][0])
-        self.linear_bwd_params(pre + ".attention.output.dense.weight", pre + ".attention.output.dense.bias", d_proj, rec["attn_c"])
         d_attn = self.new(B * L, C, dtype=adt)
-        ops.linear_dgrad(cm, d_proj, self.W(pre + ".attention.output.dense.weight"), d_attn)
+        if self.fused_mlp and C in (96, 192) and L % 64 == 0 and not self.split_ln_bwd:
+            d_proj = self.new(B * L, C, dtype=adt)
+            gw_w, gw_b, _, _ = self._norm_params(pre + ".layernorm_before")
+            gg = self._norm_grads(pre + ".layernorm_before")
+            if not ops.proj_cln_bwd(g, rec["proj"], rec["st1"][0], rec["st1"][1], time if self.cond else None, gw_w, gw_b, rec["dp"][0],
+                                    self.W(pre + ".attention.output.dense.weight"), d_proj, d_attn, gg[0], gg[1], gg[2], gg[3], B * L,
+                                    L, C):
+                raise RuntimeError("scot_proj_cln_bwd rejected a shape the engine selected it for")
+            self.linear_bwd_params(pre + ".attention.output.dense.weight", pre + ".attention.output.dense.bias", d_proj, rec["attn_c"])
+        else:
+            d_proj = self.norm_bwd(pre + ".layernorm_before", g, rec["proj"], rec["st1"], L, C, time, adt, sample_scale=rec["dp"][0])
+            self.linear_bwd_params(pre + ".attention.output.dense.weight", pre + ".attention.output.dense.bias", d_proj, rec["attn_c"])
+            ops.linear_dgrad(cm, d_proj, self.W(pre + ".attention.output.dense.weight"), d_attn)
         if padded:
             d_attn_p = self.new(B * Lp, C, dtype=adt)
             ops.copy2d(d_attn, d_attn_p, B, H, W, Hp, Wp, C)

@@ -30,6 +30,8 @@ PROTOTYPES = {
     "scot_cln_fwd": [P, I, P, I, P, I, P, I, P, P, P, P, P, P, P, I, I, I, F, P, P],
     "scot_mlp_block_fwd": [P, P, P, P, P, P, P, P, P, P, P, P, P, P, P, P, P, P, P, I, I, I, I, F, P],
     "scot_mlp_block_bwd": [P, P, P, P, P, P, P, P, P, P, P, P, P, P, P, P, P, P, I, I, I, I, P],
+    "scot_proj_cln_fwd": [P, P, P, P, P, P, P, P, P, P, P, P, P, P, P, I, I, I, F, P],
+    "scot_proj_cln_bwd": [P, P, P, P, P, P, P, P, P, P, P, P, P, P, P, I, I, I, P],
     "scot_cln_bwd": [P, I, P, I, P, P, P, P, P, P, I, P, P, P, P, P, I, I, I, P, Z, P, I, P],
     "scot_add": [P, I, P, I, P, I, Z, Z, P],
     "scot_batch_sum": [P, I, P, I, Z, P],

@@ -207,6 +207,29 @@ def mlp_block_bwd(g, g_out, z, mean, rstd, time, gw_w, gw_b, sample_scale, dact,
     return True
 
 
+def proj_cln_fwd(a, w, bias, resid, out, out16, z, mean, rstd, time, gw_w, gw_b, bw_w, bw_b, sample_scale, rows, rows_per_sample, C,
+                 eps) -> bool:
+    """EXPERIMENTAL out-projection GEMM with cond-LN + residual in its epilogue (csrc/mlp_fused.hip).  False = not covered."""
+    rc = L().scot_proj_cln_fwd(ptr(a), ptr(w), ptr(bias), ptr(resid), ptr(out), ptr(out16), ptr(z), ptr(mean), ptr(rstd), ptr(time),
+                               ptr(gw_w), ptr(gw_b), ptr(bw_w), ptr(bw_b), ptr(sample_scale), rows, rows_per_sample, C, float(eps),
+                               stream())
+    if rc == -3:
+        return False
+    _lib.check(rc, "scot_proj_cln_fwd")
+    return True
+
+
+def proj_cln_bwd(g, z, mean, rstd, time, gw_w, gw_b, sample_scale, w, dz, da, d_gw_w, d_gw_b, d_bw_w, d_bw_b, rows, rows_per_sample,
+                 C) -> bool:
+    """EXPERIMENTAL cond-LN backward → dgrad of the out-projection in one launch.  False = not covered."""
+    rc = L().scot_proj_cln_bwd(ptr(g), ptr(z), ptr(mean), ptr(rstd), ptr(time), ptr(gw_w), ptr(gw_b), ptr(sample_scale), ptr(w),
+                               ptr(dz), ptr(da), ptr(d_gw_w), ptr(d_gw_b), ptr(d_bw_w), ptr(d_bw_b), rows, rows_per_sample, C, stream())
+    if rc == -3:
+        return False
+    _lib.check(rc, "scot_proj_cln_bwd")
+    return True
+
+
 def cln_bwd(dout, x, mean, rstd, time, gw_w, gw_b, dx, d_gw_w, d_gw_b, d_bw_w, d_bw_b, rows, rows_per_sample, C, d_xbias=None,
             sample_scale=None, mode=0):
     """mode 0: dx and parameter gradients; 1: dx only; 2: parameter gradients only (dx may be None)."""

@@ -356,6 +356,74 @@ def test_mlp_block_bwd_fused(cond, B, L, C):
     assert rel(fdz.float(), rdz) < 6e-3 and rel(fdu.float(), rdu) < 1e-2 and rel(fgh, rgh) < 5e-3
 
 
+@pytest.mark.skipif(__import__("os").environ.get("SCOT_EXPERIMENTAL") != "1",
+                    reason="csrc/mlp_fused.hip was written without GPU time left (round 1): run with SCOT_EXPERIMENTAL=1")
+@pytest.mark.parametrize("train", [True, False])
+@pytest.mark.parametrize("cond", [True, False])
+@pytest.mark.parametrize("B,L,C", [(2, 1024, 96), (3, 200, 96), (64, 1024, 96), (2, 256, 192), (5, 72, 192)])
+def test_proj_cln_fused(train, cond, B, L, C):
+    """scot_proj_cln_fwd vs linear_fwd + cln_fwd on the same operands."""
+    M = B * L
+    bf = torch.bfloat16
+    a = rnd(M, C, seed=1).to(bf)
+    x = rnd(M, C, seed=2)
+    w, bias = rnd(C, C, scale=C ** -0.5, seed=3).to(bf), rnd(C, seed=4, scale=0.2)
+    t = torch.rand(B, device=DEV)
+    sc = (torch.rand(B, device=DEV) > 0.3).float() / 0.7
+    gw_w, gw_b, bw_w, bw_b = rnd(C, seed=6, scale=0.3), 1 + rnd(C, seed=7, scale=0.1), rnd(C, seed=8, scale=0.1), rnd(C, seed=9, scale=0.1)
+    cw = (gw_w, bw_w) if cond else (None, None)
+    z = torch.empty(M, C, device=DEV)
+    ops.linear_fwd(ops.BF16, a, w, z, bias=bias)
+    out, out16 = torch.empty(M, C, device=DEV), torch.empty(M, C, device=DEV, dtype=bf)
+    mean, rstd = torch.empty(M, device=DEV), torch.empty(M, device=DEV)
+    ops.cln_fwd(z, x, out, mean, rstd, t if cond else None, cw[0], gw_b, cw[1], bw_b, M, L, C, 1e-5, out2=out16, sample_scale=sc)
+    nan = float("nan")
+    fz = torch.full((M, C), nan, device=DEV) if train else None
+    fmean = torch.full((M,), nan, device=DEV) if train else None
+    frstd = torch.full((M,), nan, device=DEV) if train else None
+    fout, fout16 = torch.full((M, C), nan, device=DEV), torch.full((M, C), nan, device=DEV, dtype=bf)
+    assert ops.proj_cln_fwd(a, w, bias, x, fout, fout16, fz, fmean, frstd, t if cond else None, cw[0], gw_b, cw[1], bw_b, sc, M, L, C, 1e-5)
+    torch.cuda.synchronize()
+    assert torch.isfinite(fout).all()
+    assert rel(fout, out) < 2e-5 and torch.equal(fout16, fout.to(bf))
+    if train:
+        assert rel(fz, z) < 2e-5 and rel(fmean, mean) < 1e-4 and rel(frstd, rstd) < 1e-4
+
+
+@pytest.mark.skipif(__import__("os").environ.get("SCOT_EXPERIMENTAL") != "1",
+                    reason="csrc/mlp_fused.hip was written without GPU time left (round 1): run with SCOT_EXPERIMENTAL=1")
+@pytest.mark.parametrize("cond", [True, False])
+@pytest.mark.parametrize("B,L,C", [(2, 1024, 96), (3, 192, 96), (64, 1024, 96), (2, 256, 192), (5, 64, 192)])
+def test_proj_cln_bwd_fused(cond, B, L, C):
+    """scot_proj_cln_bwd vs cln_bwd + linear_dgrad on the same operands."""
+    M = B * L
+    bf = torch.bfloat16
+    g = rnd(M, C, seed=1)
+    z = rnd(M, C, seed=2, scale=1.5) + 0.3
+    mean = z.mean(-1)
+    rstd = 1.0 / torch.sqrt(z.var(-1, unbiased=False) + 1e-5)
+    w = rnd(C, C, scale=C ** -0.5, seed=4).to(bf)
+    t = torch.rand(B, device=DEV)
+    sc = (torch.rand(B, device=DEV) > 0.3).float() / 0.7
+    gw_w, gw_b = rnd(C, seed=6, scale=0.3), 1 + rnd(C, seed=7, scale=0.1)
+    dz = torch.empty(M, C, device=DEV, dtype=bf)
+    grads = [torch.zeros(C, device=DEV) for _ in range(4)]
+    ops.cln_bwd(g, z, mean, rstd, t if cond else None, gw_w if cond else None, gw_b, dz, grads[0], grads[1], grads[2], grads[3],
+                M, L, C, sample_scale=sc)
+    da = torch.empty(M, C, device=DEV, dtype=bf)
+    ops.linear_dgrad(ops.BF16, dz, w, da)
+    fdz = torch.full((M, C), float("nan"), device=DEV, dtype=bf)
+    fda = torch.full((M, C), float("nan"), device=DEV, dtype=bf)
+    fgr = [torch.zeros(C, device=DEV) for _ in range(4)]
+    assert ops.proj_cln_bwd(g, z, mean, rstd, t if cond else None, gw_w if cond else None, gw_b, sc, w, fdz, fda,
+                            fgr[0] if cond else None, fgr[1], fgr[2] if cond else None, fgr[3], M, L, C)
+    torch.cuda.synchronize()
+    assert torch.isfinite(fda.float()).all()
+    assert rel(fdz.float(), dz.float()) < 1e-3 and rel(fda.float(), da.float()) < 5e-3
+    for i in ([0, 1, 2, 3] if cond else [1, 3]):
+        assert rel(fgr[i], grads[i]) < 1e-4, i
+
+
 # ----------------------------------------------------------------------------------------------- data movement
 def test_copy2d_pad_crop():
     B, H, W, C = 2, 5, 7, 12

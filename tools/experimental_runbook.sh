@@ -7,8 +7,8 @@ set -u
 out=gpurun_out/experimental
 mkdir -p $out
 export SCOT_EXPERIMENTAL=1
-echo "== 1. kernel parity (fused MLP forward / backward vs the three-launch path)" | tee $out/summary.txt
-timeout 300 python -m pytest tests/test_kernels_gpu.py -q -x -k "mlp_block" 2>&1 | tail -15 | tee -a $out/summary.txt
+echo "== 1. kernel parity (fused MLP block and projection+LN kernels vs the launches they replace)" | tee $out/summary.txt
+timeout 300 python -m pytest tests/test_kernels_gpu.py -q -x -k "mlp_block or proj_cln" 2>&1 | tail -15 | tee -a $out/summary.txt
 echo "== 2. whole-model parity with the fused kernels on (Poseidon-T/B presets, bf16 + fixtures)" | tee -a $out/summary.txt
 SCOT_FUSED_MLP=1 timeout 400 python -m pytest tests/test_model_gpu.py -q -x -k "presets or bf16_vs_reference or tape" 2>&1 | tail -15 | tee -a $out/summary.txt
 echo "== 3. bench A/B (Poseidon-B, batch 64): flag off, flag on" | tee -a $out/summary.txt
