@@ -51,10 +51,11 @@ __global__ __launch_bounds__(256, 2) void mlp_fused_kernel(MlpArgs p) {
   constexpr int W1_EL = HC * P1, W2_EL = C * P2;
   constexpr int N1 = HC * C / 8, N2 = C * HC / 8;          // 16-byte pieces per chunk
   constexpr int PW1 = (N1 + 255) / 256, PW2 = (N2 + 255) / 256;
-  constexpr size_t WBYTES = (size_t)(W1_EL + W2_EL) * 2 + (size_t)HC * 4;
+  constexpr size_t WBYTES = (size_t)(W1_EL + W2_EL) * 2 + (size_t)256 * 4;      // + b1 chunk, one slot per thread (HC used)
   constexpr size_t PBYTES = (size_t)4 * 16 * CP * 4;
   constexpr size_t LDS_BYTES = WBYTES > PBYTES ? WBYTES : PBYTES;
-  static_assert(C % 32 == 0 && HC % 32 == 0 && (W1_EL * 2) % 16 == 0 && ((W1_EL + W2_EL) * 2) % 16 == 0, "layout");
+  static_assert(N1 % 256 == 0 && N2 % 256 == 0, "weight chunk pieces must divide over the 256 threads");
+  static_assert(HC <= 256 && C % 32 == 0 && HC % 32 == 0 && (W1_EL * 2) % 16 == 0 && ((W1_EL + W2_EL) * 2) % 16 == 0, "layout");
   __shared__ __attribute__((aligned(16))) char smem[LDS_BYTES];
   bf16_t* W1c = (bf16_t*)smem;
   bf16_t* W2c = W1c + W1_EL;
@@ -76,7 +77,9 @@ __global__ __launch_bounds__(256, 2) void mlp_fused_kernel(MlpArgs p) {
 
   // ---- weight chunk: global -> registers (unconditional, clamped piece index) -> LDS
   u32x4_t r1[PW1], r2[PW2];
+  float rb1;
   auto load_chunk = [&](int c) {
+    rb1 = p.b1[c * HC + min(tid, HC - 1)];                  // every thread loads AND stores (no load left pending on a skipped path)
     const bf16_t* s1 = p.W1 + (size_t)c * HC * C;           // HC full rows of W1: one contiguous block
 #pragma unroll
     for (int u = 0; u < PW1; ++u) {
@@ -90,26 +93,22 @@ __global__ __launch_bounds__(256, 2) void mlp_fused_kernel(MlpArgs p) {
       r2[u] = *(const u32x4_t*)(p.W2 + (size_t)row * HID + (size_t)c * HC + c8);
     }
   };
-  auto store_chunk = [&](int c) {
+  auto store_chunk = [&]() {
 #pragma unroll
     for (int u = 0; u < PW1; ++u) {
-      const int i = tid + u * 256;
-      if (i < N1) {
-        const int x = i / (C / 8), k8 = (i % (C / 8)) * 8;   // x: hidden unit within the chunk
-        const int y = x & 31;
-        const int rho = (x & ~31) + (((y >> 2) & 1) << 4) + ((y >> 3) << 2) + (y & 3);   // [blk][t][a][b] of y = 8a + 4t + b
-        *(u32x4_t*)(W1c + rho * P1 + k8) = r1[u];
-      }
+      const int i = tid + u * 256;                           // < N1: the pieces divide evenly (static_assert), no guard —
+      const int x = i / (C / 8), k8 = (i % (C / 8)) * 8;     // a guarded store would leave its load unconsumed on the skipped path
+      const int y = x & 31;                                  // x: hidden unit within the chunk
+      const int rho = (x & ~31) + (((y >> 2) & 1) << 4) + ((y >> 3) << 2) + (y & 3);   // [blk][t][a][b] of y = 8a + 4t + b
+      *(u32x4_t*)(W1c + rho * P1 + k8) = r1[u];
     }
 #pragma unroll
     for (int u = 0; u < PW2; ++u) {
       const int i = tid + u * 256;
-      if (i < N2) {
-        const int row = i / (HC / 8), c8 = (i % (HC / 8)) * 8;
-        *(u32x4_t*)(W2c + row * P2 + c8) = r2[u];
-      }
+      const int row = i / (HC / 8), c8 = (i % (HC / 8)) * 8;
+      *(u32x4_t*)(W2c + row * P2 + c8) = r2[u];
     }
-    if (tid < HC) b1c[tid] = p.b1[c * HC + tid];
+    b1c[tid] = rb1;
   };
 
   f32x4_t Y[TT][NT];
@@ -119,11 +118,10 @@ __global__ __launch_bounds__(256, 2) void mlp_fused_kernel(MlpArgs p) {
     for (int nt = 0; nt < NT; ++nt) Y[tt][nt] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
 
   load_chunk(0);
-  store_chunk(0);
+  store_chunk();
   __syncthreads();
 
-  for (int c = 0; c < nch; ++c) {
-    load_chunk(min(c + 1, nch - 1));          // in flight during the multiply (the last iteration re-reads its own chunk: L2 hit)
+  auto multiply_chunk = [&](int c) {
 #pragma unroll
     for (int blk = 0; blk < NB; ++blk) {
       f32x4_t U[TT][2];
@@ -172,12 +170,18 @@ __global__ __launch_bounds__(256, 2) void mlp_fused_kernel(MlpArgs p) {
         for (int tt = 0; tt < TT; ++tt) mma16(Y[tt][nt], af[tt], w);
       }
     }
+  };
+  // The last chunk is peeled: a prefetch that is issued but never consumed inside the loop leaves loads pending on the
+  // back edge, and the compiler then waits for EVERYTHING in flight (including the act/dact stores) at the top of each iteration.
+  for (int c = 0; c + 1 < nch; ++c) {
+    load_chunk(c + 1);                         // in flight during the multiply
+    multiply_chunk(c);
     __syncthreads();                           // every wave is done reading chunk c
-    if (c + 1 < nch) {
-      store_chunk(c + 1);
-      __syncthreads();
-    }
+    store_chunk();
+    __syncthreads();
   }
+  multiply_chunk(nch - 1);
+  __syncthreads();
 
   // ---- epilogue: + b2, layer norm over the row, conditional affine, DropPath scale, residual.  The weight chunk is dead
   // (barrier above): each wave stages one 16-row tile at a time in its own patch and re-reads it row-contiguously.
@@ -188,8 +192,19 @@ __global__ __launch_bounds__(256, 2) void mlp_fused_kernel(MlpArgs p) {
   cln_rows_epilogue<C, TT>(Y, (float*)smem, row0, e);
 }
 
+// Hidden units per LDS weight chunk.  The chunk's 16-byte pieces must divide evenly over the 256 threads (HC·C/8 % 256 == 0:
+// with a ragged last piece the skipped LDS stores leave loads the compiler cannot prove consumed, and it then waits for all
+// memory traffic at the top of every chunk iteration): 64 (27 KB of LDS at C = 96, 54 KB at C = 192), or 128 at C = 96
+// (53 KB, half the barriers; SCOT_MLP_HC=128).
+static int mlp_chunk(int C) {
+  static int hc_env = -1;
+  if (hc_env < 0) { const char* e = getenv("SCOT_MLP_HC"); hc_env = e ? atoi(e) : 0; }
+  return (C == 96 && hc_env == 128) ? 128 : 64;
+}
+
 template <int C, int HC, int TT>
 static int launch_mlp(const MlpArgs& a, hipStream_t s) {
+  static_assert((HC * C / 8) % 256 == 0, "ragged weight chunk");
   const int rows_per_wg = 64 * TT;
   dim3 grid((a.M + rows_per_wg - 1) / rows_per_wg), block(256);
   hipLaunchKernelGGL((mlp_fused_kernel<C, HC, TT>), grid, block, 0, s, a);
@@ -205,7 +220,7 @@ extern "C" int scot_mlp_block_fwd(const void* h16, const float* h, const void* W
                                   hipStream_t stream) {
   if (M <= 0 || rows_per_sample <= 0) return SCOT_ERR_SHAPE;
   if (C != 96 && C != 192) return SCOT_ERR_UNSUPPORTED;
-  const int hc = C == 96 ? 96 : 64;          // hidden units per LDS chunk: 40 KB (C = 96) / 54 KB (C = 192) of weights per workgroup
+  const int hc = mlp_chunk(C);
   if (hid < hc || hid % hc != 0) return SCOT_ERR_UNSUPPORTED;
   if (!h16 || !h || !W1 || !b1 || !W2 || !b2 || !out || !gw_b || !bw_b) return SCOT_ERR_SHAPE;
   if ((act == nullptr) != (dact == nullptr) || (mean == nullptr) != (rstd == nullptr) || (gw_w == nullptr) != (bw_w == nullptr))
@@ -220,7 +235,10 @@ extern "C" int scot_mlp_block_fwd(const void* h16, const float* h, const void* W
   // 64·TT rows per workgroup: TT = 2 halves the LDS weight reads per MFMA; TT = 1 when that would leave CUs without work
   // (C = 192 with TT = 2 needs 256 VGPRs + spills: TT = 1 unless forced)
   const int tt = tt_env ? tt_env : ((C == 96 && M >= 64 * 2 * 512) ? 2 : 1);
-  if (C == 96) return tt == 2 ? launch_mlp<96, 96, 2>(a, stream) : launch_mlp<96, 96, 1>(a, stream);
+  if (C == 96) {
+    if (hc == 128) return tt == 2 ? launch_mlp<96, 128, 2>(a, stream) : launch_mlp<96, 128, 1>(a, stream);
+    return tt == 2 ? launch_mlp<96, 64, 2>(a, stream) : launch_mlp<96, 64, 1>(a, stream);
+  }
   return tt == 2 ? launch_mlp<192, 64, 2>(a, stream) : launch_mlp<192, 64, 1>(a, stream);
 }
 
@@ -285,6 +303,7 @@ __global__ __launch_bounds__(256, 2) void mlp_bwd_fused_kernel(MlpBwdArgs p) {
   constexpr size_t P1BYTES = ClnBwdLds<C>::bytes;
   constexpr size_t LDS_BYTES = WBYTES > PBYTES ? (WBYTES > P1BYTES ? WBYTES : P1BYTES) : (PBYTES > P1BYTES ? PBYTES : P1BYTES);
   static_assert((W1_EL * 2) % 16 == 0, "layout");
+  static_assert(N1 % 256 == 0 && N2 % 256 == 0, "weight chunk pieces must divide over the 256 threads");
   __shared__ __attribute__((aligned(16))) char smem[LDS_BYTES];
   bf16_t* W1c = (bf16_t*)smem;
   bf16_t* W2c = W1c + W1_EL;
@@ -312,13 +331,13 @@ __global__ __launch_bounds__(256, 2) void mlp_bwd_fused_kernel(MlpBwdArgs p) {
   auto store_chunk = [&]() {
 #pragma unroll
     for (int u = 0; u < PW1; ++u) {
-      const int i = tid + u * 256;
-      if (i < N1) *(u32x4_t*)(W1c + (i / (C / 8)) * P1 + (i % (C / 8)) * 8) = r1[u];
+      const int i = tid + u * 256;                 // pieces divide evenly (static_assert): unguarded, see the forward kernel
+      *(u32x4_t*)(W1c + (i / (C / 8)) * P1 + (i % (C / 8)) * 8) = r1[u];
     }
 #pragma unroll
     for (int u = 0; u < PW2; ++u) {
       const int i = tid + u * 256;
-      if (i < N2) *(u32x4_t*)(W2c + (i / (HC / 8)) * P2 + (i % (HC / 8)) * 8) = r2[u];
+      *(u32x4_t*)(W2c + (i / (HC / 8)) * P2 + (i % (HC / 8)) * 8) = r2[u];
     }
   };
 
@@ -344,8 +363,7 @@ __global__ __launch_bounds__(256, 2) void mlp_bwd_fused_kernel(MlpBwdArgs p) {
 #pragma unroll
   for (int tt = 0; tt < TT; ++tt) rowt[tt] = row0 + tt * 16 + lc;
 
-  for (int c = 0; c < nch; ++c) {
-    load_chunk(min(c + 1, nch - 1));
+  auto multiply_chunk = [&](int c) {
     // gelu'(u) of this chunk for the lane's token and its 8 hidden units per block: in flight during the first MFMAs
     s16x8_t gpv[TT][NB];
 #pragma unroll
@@ -385,12 +403,16 @@ __global__ __launch_bounds__(256, 2) void mlp_bwd_fused_kernel(MlpBwdArgs p) {
         for (int tt = 0; tt < TT; ++tt) mma16(Y[tt][nt], af[tt], w);
       }
     }
+  };
+  for (int c = 0; c + 1 < nch; ++c) {          // last chunk peeled, see the forward kernel
+    load_chunk(c + 1);
+    multiply_chunk(c);
     __syncthreads();
-    if (c + 1 < nch) {
-      store_chunk();
-      __syncthreads();
-    }
+    store_chunk();
+    __syncthreads();
   }
+  multiply_chunk(nch - 1);
+  __syncthreads();
 
   // ---- phase 3: g' = g + du·W1, through the per-wave patch (aliases the dead weight chunk) for row-contiguous stores
   float* Ct = (float*)smem + wave * 16 * CP;
@@ -436,7 +458,7 @@ extern "C" int scot_mlp_block_bwd(const float* g, float* g_out, const float* z, 
                                   hipStream_t stream) {
   if (M <= 0 || rows_per_sample <= 0) return SCOT_ERR_SHAPE;
   if (C != 96 && C != 192) return SCOT_ERR_UNSUPPORTED;
-  const int hc = C == 96 ? 96 : 64;
+  const int hc = mlp_chunk(C);
   if (hid < hc || hid % hc != 0) return SCOT_ERR_UNSUPPORTED;
   if (!g || !g_out || !z || !mean || !rstd || !gw_b || !dact || !W1 || !W2 || !dz || !du || !d_gw_b || !d_bw_b) return SCOT_ERR_SHAPE;
   if ((gw_w == nullptr) != (d_gw_w == nullptr) || (d_gw_w == nullptr) != (d_bw_w == nullptr)) return SCOT_ERR_SHAPE;
@@ -450,7 +472,10 @@ extern "C" int scot_mlp_block_bwd(const float* g, float* g_out, const float* z, 
   a.dact = (const bf16_t*)dact; a.W1 = (const bf16_t*)W1; a.W2 = (const bf16_t*)W2; a.dz = (bf16_t*)dz; a.du = (bf16_t*)du;
   a.d_gw_w = d_gw_w; a.d_gw_b = d_gw_b; a.d_bw_w = d_bw_w; a.d_bw_b = d_bw_b;
   a.M = M; a.rows_per_sample = rows_per_sample; a.hid = hid; a.use_tr = g_scot_use_tr;
-  if (C == 96) return tt == 2 ? launch_mlp_bwd<96, 96, 2>(a, stream) : launch_mlp_bwd<96, 96, 1>(a, stream);
+  if (C == 96) {
+    if (hc == 128) return tt == 2 ? launch_mlp_bwd<96, 128, 2>(a, stream) : launch_mlp_bwd<96, 128, 1>(a, stream);
+    return tt == 2 ? launch_mlp_bwd<96, 64, 2>(a, stream) : launch_mlp_bwd<96, 64, 1>(a, stream);
+  }
   return tt == 2 ? launch_mlp_bwd<192, 64, 2>(a, stream) : launch_mlp_bwd<192, 64, 1>(a, stream);
 }
 

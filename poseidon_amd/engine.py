@@ -469,7 +469,7 @@ class ScOTEngine:
             h, h16, st1 = self.norm_fwd(pre + ".layernorm_before", proj, x, L, C, cfg.layer_norm_eps, time, need_stats=train,
                                         copy=True, sample_scale=dp1)
         hid = int(cfg.mlp_ratio * C)
-        if self.fused_mlp and C in (96, 192) and hid % (96 if C == 96 else 64) == 0:
+        if self.fused_mlp and C in (96, 192) and hid % 128 == 0:
             u = self.new(B * L, hid, dtype=self.adt) if train else None
             gp = self.new(B * L, hid, dtype=self.adt) if train else None
             y2 = self.new(B * L, C) if train else None
@@ -581,7 +581,7 @@ class ScOTEngine:
         a = pre + ".attention.self."
         L, Lp = H * W, Hp * Wp
         hid = int(cfg.mlp_ratio * C)
-        if (self.fused_mlp and C in (96, 192) and hid % (96 if C == 96 else 64) == 0 and L % 64 == 0 and not self.split_ln_bwd):
+        if (self.fused_mlp and C in (96, 192) and hid % 128 == 0 and L % 64 == 0 and not self.split_ln_bwd):
             # the whole dependent chain of the MLP half in one launch; the two weight gradients follow on the side stream
             d_y2 = self.new(B * L, C, dtype=adt)
             d_u = self.new(B * L, hid, dtype=adt)

@@ -1,0 +1,187 @@
+// hipemu — a tiny HOST stand-in for <hip/hip_runtime.h>, test infrastructure only (never linked into libscot_hip.so).
+//
+// It lets a kernel source file of poseidon_amd/csrc/ be compiled as plain C++ (x86, the ROCm clang) and executed on the CPU
+// with one std::thread per work-item, so that the index algebra, LDS aliasing and barrier placement of a kernel can be
+// checked WITHOUT a GPU (tests/test_hipemu_cpu.py).  What is emulated, and with which semantics:
+//   * threadIdx / blockIdx / blockDim / gridDim, __shared__ (a static array: blocks run one after another), __syncthreads
+//   * wave64 cross-lane operations by rendezvous on a per-wave barrier: __shfl_xor, v_mfma_f32_16x16x32_bf16 (the fragment
+//     convention of csrc/common.h: A lane (r, g) = row r, k = 8g..8g+7; B lane (r, g) = column r; D lane (c, g) = column c,
+//     rows 4g..4g+3), v_mfma_f32_16x16x4_f32, ds_read_b64_tr_b16 (as documented at lds_frag_ks in common.h)
+//   * __builtin_amdgcn_wave_barrier() is a REAL wave barrier here (lanes are threads; on the GPU a wave runs in lockstep)
+//   * atomicAdd(float*), float4/uint4/dim3, hipLaunchKernelGGL (synchronous)
+// NOT emulated: timing, bank conflicts, register limits, memory-model subtleties — a pass here says the arithmetic and the
+// data movement are right, nothing about speed.
+#pragma once
+#include <atomic>
+#include <barrier>
+#include <cmath>
+#include <cstdint>
+#include <cstdlib>
+#include <cstring>
+#include <memory>
+#include <thread>
+#include <vector>
+
+#define __global__
+#define __device__
+#define __host__
+#define __forceinline__ inline __attribute__((always_inline))
+#define __launch_bounds__(...)
+#define __shared__ static
+
+struct dim3 {
+  unsigned x, y, z;
+  dim3(unsigned x_ = 1, unsigned y_ = 1, unsigned z_ = 1) : x(x_), y(y_), z(z_) {}
+};
+struct uint3_emu { unsigned x, y, z; };
+inline thread_local uint3_emu threadIdx, blockIdx;
+inline thread_local dim3 blockDim, gridDim;
+
+struct float4 { float x, y, z, w; };
+struct uint4 { unsigned x, y, z, w; };
+inline float4 make_float4(float x, float y, float z, float w) { return {x, y, z, w}; }
+inline uint4 make_uint4(unsigned x, unsigned y, unsigned z, unsigned w) { return {x, y, z, w}; }
+
+typedef int hipError_t;
+typedef void* hipStream_t;
+#define hipSuccess 0
+#define hipFuncAttributeMaxDynamicSharedMemorySize 0
+inline hipError_t hipGetLastError() { return hipSuccess; }
+template <typename T> inline hipError_t hipFuncSetAttribute(T, int, int) { return hipSuccess; }
+
+using std::max;
+using std::min;
+inline float __uint_as_float(uint32_t u) { float f; std::memcpy(&f, &u, 4); return f; }
+inline uint32_t __float_as_uint(float f) { uint32_t u; std::memcpy(&u, &f, 4); return u; }
+inline float __frcp_rn(float x) { return 1.0f / x; }
+inline float __expf(float x) { return std::exp(x); }
+
+namespace hipemu {
+struct Wave {
+  std::barrier<> bar{64};
+  float f[64];
+  uint64_t a[64][2], b[64][2];     // 8 x b16 operands
+  float fa[64][8], fb[64][8];      // fp32 operands
+  const void* ptr[64];
+};
+struct Block {
+  std::unique_ptr<std::barrier<>> bar;
+  std::vector<std::unique_ptr<Wave>> waves;
+};
+inline Block* g_block = nullptr;
+inline Wave& wave() { return *g_block->waves[threadIdx.x >> 6]; }
+inline int lane() { return threadIdx.x & 63; }
+inline float bf2f(uint16_t x) { return __uint_as_float(((uint32_t)x) << 16); }
+}  // namespace hipemu
+
+inline void __syncthreads() { hipemu::g_block->bar->arrive_and_wait(); }
+inline void emu_wave_barrier() { hipemu::wave().bar.arrive_and_wait(); }
+#define __builtin_amdgcn_wave_barrier emu_wave_barrier
+#define __builtin_amdgcn_sched_barrier(x) ((void)0)
+
+inline float __shfl_xor(float v, int mask, int = 64) {
+  auto& w = hipemu::wave();
+  const int l = hipemu::lane();
+  w.f[l] = v;
+  w.bar.arrive_and_wait();
+  const float r = w.f[l ^ mask];
+  w.bar.arrive_and_wait();
+  return r;
+}
+
+typedef __bf16 emu_bf16x8 __attribute__((ext_vector_type(8)));
+typedef float emu_f32x4 __attribute__((ext_vector_type(4)));
+typedef short emu_s16x4 __attribute__((ext_vector_type(4)));
+
+inline emu_f32x4 emu_mfma_f32_16x16x32_bf16(emu_bf16x8 a, emu_bf16x8 b, emu_f32x4 c, int, int, int) {
+  auto& w = hipemu::wave();
+  const int l = hipemu::lane(), g = l >> 4, lc = l & 15;
+  std::memcpy(w.a[l], &a, 16);
+  std::memcpy(w.b[l], &b, 16);
+  w.bar.arrive_and_wait();
+  emu_f32x4 d = c;
+  for (int r = 0; r < 4; ++r) {
+    const int row = 4 * g + r;
+    float s = c[r];
+    for (int gg = 0; gg < 4; ++gg) {
+      const uint16_t* pa = (const uint16_t*)w.a[gg * 16 + row];
+      const uint16_t* pb = (const uint16_t*)w.b[gg * 16 + lc];
+      for (int j = 0; j < 8; ++j) s += hipemu::bf2f(pa[j]) * hipemu::bf2f(pb[j]);
+    }
+    d[r] = s;
+  }
+  w.bar.arrive_and_wait();
+  return d;
+}
+#define __builtin_amdgcn_mfma_f32_16x16x32_bf16 emu_mfma_f32_16x16x32_bf16
+
+// v_mfma_f32_16x16x4_f32: A lane (r, g) holds A[r][k = g], B lane (r, g) holds B[k = g][r]
+inline emu_f32x4 emu_mfma_f32_16x16x4f32(float a, float b, emu_f32x4 c, int, int, int) {
+  auto& w = hipemu::wave();
+  const int l = hipemu::lane(), g = l >> 4, lc = l & 15;
+  w.fa[l][0] = a; w.fb[l][0] = b;
+  w.bar.arrive_and_wait();
+  emu_f32x4 d = c;
+  for (int r = 0; r < 4; ++r) {
+    float s = c[r];
+    for (int k = 0; k < 4; ++k) s = std::fma(w.fa[k * 16 + 4 * g + r][0], w.fb[k * 16 + lc][0], s);
+    d[r] = s;
+  }
+  w.bar.arrive_and_wait();
+  return d;
+}
+#define __builtin_amdgcn_mfma_f32_16x16x4f32 emu_mfma_f32_16x16x4f32
+
+// ds_read_b64_tr_b16: within a 16-lane group, lane i supplies the address of 4 consecutive b16 = block[i>>2][4(i&3) .. +3];
+// lane c receives column c of that [4][16] block.
+template <typename P> inline emu_s16x4 emu_ds_read_tr16_b64(P p) {
+  auto& w = hipemu::wave();
+  const int l = hipemu::lane(), base = l & ~15, c = l & 15;
+  w.ptr[l] = (const void*)p;
+  w.bar.arrive_and_wait();
+  emu_s16x4 r;
+  for (int k = 0; k < 4; ++k) r[k] = ((const short*)w.ptr[base + 4 * k + (c >> 2)])[c & 3];
+  w.bar.arrive_and_wait();
+  return r;
+}
+#define __builtin_amdgcn_ds_read_tr16_b64_v4i16 emu_ds_read_tr16_b64
+
+inline float atomicAdd(float* p, float v) {
+  std::atomic_ref<float> r(*p);
+  float old = r.load();
+  while (!r.compare_exchange_weak(old, old + v)) {}
+  return old;
+}
+inline double atomicAdd(double* p, double v) {
+  std::atomic_ref<double> r(*p);
+  double old = r.load();
+  while (!r.compare_exchange_weak(old, old + v)) {}
+  return old;
+}
+
+namespace hipemu {
+template <typename K, typename... A> void launch(K kernel, dim3 grid, dim3 block, A... args) {
+  const unsigned nthr = block.x * block.y * block.z;
+  if (block.y != 1 || block.z != 1 || nthr % 64) std::abort();
+  for (unsigned bz = 0; bz < grid.z; ++bz)
+    for (unsigned by = 0; by < grid.y; ++by)
+      for (unsigned bx = 0; bx < grid.x; ++bx) {
+        Block blk;
+        blk.bar = std::make_unique<std::barrier<>>(nthr);
+        for (unsigned w = 0; w < nthr / 64; ++w) blk.waves.push_back(std::make_unique<Wave>());
+        g_block = &blk;
+        std::vector<std::thread> th;
+        for (unsigned t = 0; t < nthr; ++t)
+          th.emplace_back([=] {
+            threadIdx = {t, 0, 0};
+            blockIdx = {bx, by, bz};
+            blockDim = block;
+            gridDim = grid;
+            kernel(args...);
+          });
+        for (auto& x : th) x.join();
+        g_block = nullptr;
+      }
+}
+}  // namespace hipemu
+#define hipLaunchKernelGGL(kernel, grid, block, shmem, stream, ...) hipemu::launch(kernel, grid, block, __VA_ARGS__)
