@@ -39,8 +39,16 @@ inline thread_local dim3 blockDim, gridDim;
 
 struct float4 { float x, y, z, w; };
 struct uint4 { unsigned x, y, z, w; };
+struct int4 { int x, y, z, w; };
+struct float2 { float x, y; };
+struct uint2 { unsigned x, y; };
+struct int2 { int x, y; };
 inline float4 make_float4(float x, float y, float z, float w) { return {x, y, z, w}; }
 inline uint4 make_uint4(unsigned x, unsigned y, unsigned z, unsigned w) { return {x, y, z, w}; }
+inline uint2 make_uint2(unsigned x, unsigned y) { return {x, y}; }
+inline float2 make_float2(float x, float y) { return {x, y}; }
+inline int2 make_int2(int x, int y) { return {x, y}; }
+inline int4 make_int4(int x, int y, int z, int w) { return {x, y, z, w}; }
 
 typedef int hipError_t;
 typedef void* hipStream_t;
@@ -55,6 +63,15 @@ inline float __uint_as_float(uint32_t u) { float f; std::memcpy(&f, &u, 4); retu
 inline uint32_t __float_as_uint(float f) { uint32_t u; std::memcpy(&u, &f, 4); return u; }
 inline float __frcp_rn(float x) { return 1.0f / x; }
 inline float __expf(float x) { return std::exp(x); }
+inline float __logf(float x) { return std::log(x); }
+#define __log2f(x) std::log2((float)(x))        /* glibc declares (but does not export) a function of this name */
+inline float emu_exp2f(float x) { return std::exp2(x); }
+#define __builtin_amdgcn_exp2f emu_exp2f
+#define hipMemcpyDeviceToHost 2
+inline hipError_t hipMemcpyAsync(void* dst, const void* src, size_t n, int, hipStream_t) { std::memcpy(dst, src, n); return hipSuccess; }
+inline hipError_t hipStreamSynchronize(hipStream_t) { return hipSuccess; }
+template <typename T> inline hipError_t hipMalloc(T** p, size_t n) { *p = (T*)std::malloc(n); return *p ? hipSuccess : 1; }
+inline hipError_t hipFree(void* p) { std::free(p); return hipSuccess; }
 
 namespace hipemu {
 struct Wave {
@@ -146,6 +163,35 @@ template <typename P> inline emu_s16x4 emu_ds_read_tr16_b64(P p) {
 }
 #define __builtin_amdgcn_ds_read_tr16_b64_v4i16 emu_ds_read_tr16_b64
 
+// v_mov_b32 dpp row_shl:n (0x101..0x10F): lane i of a 16-lane row reads lane i+n;  row_shr:n (0x111..0x11F): lane i-n;
+// bound_ctrl = true: lanes without a source get 0.  (the only DPP controls the kernels use)
+inline int emu_update_dpp(int, int v, int ctrl, int, int, bool) {
+  auto& w = hipemu::wave();
+  const int l = hipemu::lane(), row = l & ~15, i = l & 15;
+  std::memcpy(&w.f[l], &v, 4);
+  w.bar.arrive_and_wait();
+  int src = -1;
+  if (ctrl >= 0x101 && ctrl <= 0x10F) src = i + (ctrl - 0x100);
+  else if (ctrl >= 0x111 && ctrl <= 0x11F) src = i - (ctrl - 0x110);
+  else std::abort();
+  int r = 0;
+  if (src >= 0 && src < 16) std::memcpy(&r, &w.f[row + src], 4);
+  w.bar.arrive_and_wait();
+  return r;
+}
+#define __builtin_amdgcn_update_dpp emu_update_dpp
+
+inline unsigned long long __ballot(int pred) {
+  auto& w = hipemu::wave();
+  const int l = hipemu::lane();
+  w.f[l] = pred ? 1.f : 0.f;
+  w.bar.arrive_and_wait();
+  unsigned long long m = 0;
+  for (int i = 0; i < 64; ++i) if (w.f[i] != 0.f) m |= 1ull << i;
+  w.bar.arrive_and_wait();
+  return m;
+}
+
 inline float atomicAdd(float* p, float v) {
   std::atomic_ref<float> r(*p);
   float old = r.load();
@@ -160,6 +206,11 @@ inline double atomicAdd(double* p, double v) {
 }
 
 namespace hipemu {
+// dynamic shared memory: the test build rewrites `extern __shared__ T name[];` into `T* name = (T*)hipemu::dyn_smem();`
+inline char* dyn_smem() {
+  alignas(16) static char buf[160 * 1024];
+  return buf;
+}
 template <typename K, typename... A> void launch(K kernel, dim3 grid, dim3 block, A... args) {
   const unsigned nthr = block.x * block.y * block.z;
   if (block.y != 1 || block.z != 1 || nthr % 64) std::abort();

@@ -25,13 +25,11 @@ def emu(tmp_path_factory):
     return exe
 
 
+# the in-process emulation tests (test_kernels_emu_cpu.py) run the default configuration (64 rows per workgroup, 64 hidden units per
+# LDS chunk); the variants selected by environment variables that the library reads once per process are covered here
 CASES = [  # case, C, B, L, cond, train, use_tr, SCOT_MLP_TT (16-row tiles per wave), SCOT_MLP_HC (hidden units per LDS chunk)
-    ("mlp_fwd", 96, 2, 128, 1, 1, 1, 2, 64), ("mlp_fwd", 96, 2, 100, 0, 1, 1, 1, 128), ("mlp_fwd", 96, 3, 72, 1, 0, 1, 2, 64),
-    ("mlp_fwd", 192, 2, 64, 1, 1, 1, 1, 64), ("mlp_fwd", 192, 1, 100, 0, 0, 1, 1, 64),
-    ("mlp_bwd", 96, 2, 128, 1, 1, 1, 2, 64), ("mlp_bwd", 96, 3, 64, 0, 1, 0, 1, 128), ("mlp_bwd", 192, 2, 64, 1, 1, 1, 1, 64),
-    ("mlp_bwd", 192, 2, 64, 0, 1, 0, 1, 64),
-    ("proj_fwd", 96, 2, 128, 0, 0, 1, 2, 64), ("proj_fwd", 96, 2, 100, 1, 1, 1, 1, 64), ("proj_fwd", 192, 2, 72, 1, 1, 1, 1, 64),
-    ("proj_bwd", 96, 2, 128, 1, 1, 1, 2, 64), ("proj_bwd", 96, 3, 64, 0, 1, 0, 1, 64), ("proj_bwd", 192, 2, 64, 1, 1, 0, 1, 64),
+    ("mlp_fwd", 96, 1, 128, 1, 1, 1, 2, 64), ("mlp_fwd", 96, 1, 100, 0, 1, 1, 1, 128), ("mlp_bwd", 96, 1, 128, 1, 1, 1, 2, 64),
+    ("mlp_bwd", 96, 1, 64, 0, 1, 0, 1, 128), ("proj_fwd", 96, 1, 128, 0, 0, 1, 2, 64), ("proj_bwd", 96, 1, 128, 1, 1, 1, 2, 64),
 ]
 
 

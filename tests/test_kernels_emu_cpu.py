@@ -1,0 +1,192 @@
+"""The production kernels of poseidon_amd/csrc executed on the CPU: every .hip source compiled as host C++ against the
+hipemu shim (tests/hipemu: one std::thread per work-item, wave64 cross-lane ops / MFMA / transposing LDS read emulated) and
+called through the SAME C ABI and the same `poseidon_amd.ops` wrappers as on the GPU, with CPU tensors.  Small shapes only
+(an emulated MFMA costs two thread barriers).  Test infrastructure: the emulated library is built into a temp directory and
+never loaded by the product (`poseidon_amd.lib` only ever opens libscot_hip.so; `ops.ptr` rejects CPU tensors outside this
+module's monkeypatch).  What a pass means: index algebra, LDS layout and barrier placement of the kernel sources are right
+under the fragment conventions of csrc/common.h — nothing about speed.  The GPU parity tests remain the gate."""
+import ctypes
+import math
+import os
+import shutil
+import sys
+
+import pytest
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.join(HERE, "hipemu"))
+from poseidon_amd import lib as scot_lib  # noqa: E402
+from poseidon_amd import ops  # noqa: E402
+
+
+@pytest.fixture(scope="module")
+def emu_lib():
+    import build_emu
+    if not (os.path.exists(build_emu.CLANG) or shutil.which(build_emu.CLANG)):
+        pytest.skip("no host clang with __bf16 vector support")
+    lib = ctypes.CDLL(build_emu.build_cached())
+    for name, argtypes in scot_lib.PROTOTYPES.items():
+        fn = getattr(lib, name)          # every symbol of the C ABI must exist in the emulated build too
+        fn.argtypes = argtypes
+        fn.restype = None if name in scot_lib._VOID else ctypes.c_int
+    assert lib.scot_selftest_tr(None) >= 0 and lib.scot_get_use_tr() == 1   # the emulated transposing LDS read = the kernels' contract
+    return lib
+
+
+@pytest.fixture()
+def emu(emu_lib, monkeypatch):
+    ws = torch.empty(8 << 20, dtype=torch.uint8)
+    monkeypatch.setattr(ops, "L", lambda: emu_lib)
+    monkeypatch.setattr(ops, "ptr", lambda t: None if t is None else t.data_ptr())
+    monkeypatch.setattr(ops, "stream", lambda: None)
+    monkeypatch.setattr(ops, "workspace", lambda: ws)
+    monkeypatch.setattr(ops, "WORKSPACE_BYTES", 8 << 20)
+    return emu_lib
+
+
+FULL = os.environ.get("SCOT_EMU_FULL") == "1"   # default: a subset that keeps the CPU suite at a few minutes
+
+
+def full_only(*cases):
+    return list(cases) if FULL else []
+
+
+def rel(a, b):
+    a, b = a.double(), b.double()
+    return float((a - b).norm() / b.norm().clamp_min(1e-30))
+
+
+def rnd(*shape, dtype=torch.float32, scale=1.0, seed=0):
+    g = torch.Generator().manual_seed(seed + sum(shape))
+    return (torch.randn(*shape, generator=g) * scale).to(dtype)
+
+
+TOL = {ops.F32: 2e-5, ops.BF16: 6e-3, ops.X3: 5e-5}
+DT = {ops.F32: torch.float32, ops.BF16: torch.bfloat16, ops.X3: torch.float32}
+
+
+@pytest.mark.parametrize("compute,M,N,K", [(ops.F32, 70, 40, 24), (ops.X3, 130, 72, 40), (ops.BF16, 130, 72, 40), (ops.BF16, 256, 96, 96),
+                                           (ops.BF16, 128, 288, 96)] + full_only((ops.BF16, 512, 288, 96), (ops.X3, 128, 96, 96)))
+def test_linear_fwd_dgrad_wgrad(emu, compute, M, N, K):
+    cdt = DT[compute]
+    x, w, b = rnd(M, K, dtype=cdt), rnd(N, K, dtype=cdt, scale=K ** -0.5, seed=1), rnd(N, seed=2)
+    y = torch.empty(M, N, dtype=cdt)
+    gp = torch.empty(M, N, dtype=cdt)
+    ops.linear_fwd(compute, x, w, y, bias=b, gelu_deriv_out=gp)           # gelu(u), gelu'(u)
+    u = x.double() @ w.double().t() + b.double()
+    assert rel(y, torch.nn.functional.gelu(u)) < TOL[compute]
+    assert rel(gp, 0.5 * (1 + torch.erf(u / math.sqrt(2))) + u * torch.exp(-0.5 * u * u) / math.sqrt(2 * math.pi)) < TOL[compute]
+    dy = rnd(M, N, dtype=cdt, seed=3)
+    dx = torch.empty(M, K, dtype=cdt)
+    ops.linear_dgrad(compute, dy, w, dx)
+    assert rel(dx, dy.double() @ w.double()) < TOL[compute]
+    g = rnd(M, K, seed=4)
+    gref = g.double() + dy.double() @ w.double()
+    ops.linear_dgrad(compute, dy, w, g, accumulate=True)
+    assert rel(g, gref) < TOL[compute]
+    dw, db = torch.zeros(N, K), torch.zeros(N)
+    ops.linear_wgrad(compute, dy, x, dw, dbias=db)
+    assert rel(dw, dy.double().t() @ x.double()) < TOL[compute]
+    assert rel(db, dy.double().sum(0)) < 1e-4
+
+
+def test_wgrad_split_k(emu):
+    """TN layout with split-K partials + reduce pass (many token rows, small output)."""
+    M, N, K = 2048, 96, 96
+    dy, x = rnd(M, N, dtype=torch.bfloat16), rnd(M, K, dtype=torch.bfloat16, seed=1)
+    dw, db = rnd(N, K, seed=2), torch.zeros(N)
+    ref = dw.double() + dy.double().t() @ x.double()
+    ops.linear_wgrad(ops.BF16, dy, x, dw, dbias=db)
+    assert rel(dw, ref) < 1e-5
+    assert rel(db, dy.double().sum(0)) < 1e-4
+
+
+@pytest.mark.parametrize("cond", [True, False])
+@pytest.mark.parametrize("xdt,B,L,C", [(torch.float32, 2, 40, 96), (torch.bfloat16, 2, 64, 192), (torch.float32, 3, 9, 20)])
+def test_cln_fwd_bwd(emu, cond, xdt, B, L, C):
+    x, res, t = rnd(B, L, C, dtype=xdt), rnd(B, L, C, seed=1), torch.rand(B)
+    gw_w, gw_b, bw_w, bw_b = rnd(C, seed=2, scale=0.3), 1 + rnd(C, seed=3, scale=0.1), rnd(C, seed=4, scale=0.1), rnd(C, seed=5, scale=0.1)
+    sc = torch.tensor([1.0 / 0.7, 0.0, 1.0 / 0.7][:B])
+    out, out16 = torch.empty(B, L, C), torch.empty(B, L, C, dtype=torch.bfloat16)
+    mean, rstd = torch.empty(B * L), torch.empty(B * L)
+    ops.cln_fwd(x, res, out, mean, rstd, t if cond else None, gw_w if cond else None, gw_b, bw_w if cond else None, bw_b,
+                B * L, L, C, 1e-5, out2=out16, sample_scale=sc)
+    dout = rnd(B, L, C, seed=6)
+    dx = torch.empty(B, L, C, dtype=xdt)
+    grads = [torch.zeros(C) for _ in range(4)]
+    ops.cln_bwd(dout, x, mean, rstd, t if cond else None, gw_w if cond else None, gw_b, dx, grads[0], grads[1], grads[2], grads[3],
+                B * L, L, C, sample_scale=sc)
+    x64 = x.double().requires_grad_(True)
+    ps = [p.double().requires_grad_(True) for p in (gw_w, gw_b, bw_w, bw_b)]
+    mu = x64.mean(-1, keepdim=True)
+    xh = (x64 - mu) / torch.sqrt(x64.var(-1, unbiased=False, keepdim=True) + 1e-5)
+    g = t.double().view(B, 1, 1) * ps[0] + ps[1] if cond else ps[1]
+    b = t.double().view(B, 1, 1) * ps[2] + ps[3] if cond else ps[3]
+    ref = res.double() + sc.double().view(B, 1, 1) * (g * xh + b)
+    ref.backward(dout.double())
+    assert rel(out, ref.detach()) < 1e-5 and torch.equal(out16, out.to(torch.bfloat16))
+    assert rel(dx, x64.grad) < (1e-4 if xdt == torch.float32 else 1e-2)
+    for i in ([0, 1, 2, 3] if cond else [1, 3]):
+        assert rel(grads[i], ps[i].grad) < 1e-4, i
+
+
+ATTN = [  # compute, B, Hp, Wp, C, heads, ws, shift
+    (ops.BF16, 1, 16, 16, 32, 1, 16, 0),     # 16x16-window fast path, one window, head_dim 32
+    (ops.BF16, 1, 32, 32, 32, 1, 16, 8),     # ... shifted: all mask regions (4 windows)
+    (ops.BF16, 2, 8, 8, 32, 2, 4, 2),        # general kernels, N = 16, shifted
+    (ops.F32, 1, 7, 7, 16, 1, 7, 0),         # general kernels, N = 49 (ragged tiles), exact fp32 MFMA
+] + full_only((ops.X3, 1, 16, 16, 16, 1, 16, 0))   # 16x16 fast path with hi/lo split operands, head_dim 16
+
+
+@pytest.mark.parametrize("case", ATTN, ids=lambda c: "-".join(str(x) for x in c))
+def test_window_attention_fwd_bwd(emu, case):
+    from test_kernels_gpu import _attn_ref
+    compute, B, Hp, Wp, C, heads, ws, shift = case
+    cdt = DT[compute]
+    L, TS, N = Hp * Wp, (2 * ws - 1) ** 2, ws * ws
+    qkv = rnd(B, L, 3 * C, dtype=cdt)
+    table = (16 * torch.sigmoid(rnd(heads, TS, seed=1))).contiguous()
+    ls = torch.linspace(math.log(3.0), math.log(20.0), heads)
+    dout = rnd(B, L, C, dtype=cdt, seed=2)
+    out = torch.full((B, L, C), float("nan"), dtype=cdt)
+    nW = (Hp // ws) * (Wp // ws)
+    lse = torch.empty(B * nW, heads, N)
+    ops.window_attn_fwd(compute, qkv, out, lse, table, ls, B, Hp, Wp, C, heads, ws, shift)
+    dqkv = torch.full((B, L, 3 * C), float("nan"), dtype=cdt)
+    dtab, dls = torch.zeros(heads, TS), torch.zeros(heads)
+    ops.window_attn_bwd(compute, qkv, out, dout, lse, table, ls, dqkv, dtab, dls, B, Hp, Wp, C, heads, ws, shift)
+    q64, t64, l64 = qkv.double().requires_grad_(True), table.double().requires_grad_(True), ls.double().requires_grad_(True)
+    ref = _attn_ref(q64, t64, l64, B, Hp, Wp, C, heads, ws, shift)
+    ref.backward(dout.double())
+    tol_o, tol_g = (2e-5, 5e-5) if compute == ops.F32 else (5e-5, 2e-4) if compute == ops.X3 else (2e-2, 4e-2)
+    assert rel(out, ref.detach()) < tol_o
+    assert rel(dqkv, q64.grad) < tol_g
+    assert rel(dtab, t64.grad) < tol_g
+    assert rel(dls, l64.grad) < (2e-4 if compute == ops.F32 else 2e-3 if compute == ops.X3 else 0.15)
+
+
+# ---- the fused block kernels of csrc/mlp_fused.hip: the bodies of their (still gated) GPU parity tests, run here on CPU tensors
+FUSED = [(1, 72, 96), (1, 64, 192)] + full_only((2, 128, 96), (3, 72, 96))
+
+
+@pytest.fixture()
+def gpu_test_bodies(emu, monkeypatch):
+    import test_kernels_gpu as G
+    monkeypatch.setattr(G, "DEV", "cpu")
+    monkeypatch.setattr(torch.cuda, "synchronize", lambda *a, **k: None)
+    return G
+
+
+@pytest.mark.parametrize("B,L,C", FUSED)
+@pytest.mark.parametrize("train,cond", [(True, True), (False, False)])
+def test_fused_mlp_and_projection_forward(gpu_test_bodies, train, cond, B, L, C):
+    gpu_test_bodies.test_mlp_block_fused(train, cond, B, L, C)
+    gpu_test_bodies.test_proj_cln_fused(train, cond, B, L, C)
+
+
+@pytest.mark.parametrize("cond,B,L,C", [(True, 1, 64, 96), (False, 1, 64, 192)] + full_only((False, 2, 128, 96), (True, 3, 64, 96),
+                                                                                          (True, 1, 64, 192)))
+def test_fused_mlp_and_projection_backward(gpu_test_bodies, cond, B, L, C):
+    gpu_test_bodies.test_mlp_block_bwd_fused(cond, B, L, C)
+    gpu_test_bodies.test_proj_cln_bwd_fused(cond, B, L, C)
