@@ -28,6 +28,8 @@ def build(out_dir: str, sanitize: str = "", opt: str = "-O1") -> str:
             units.append(dst)
     flags = [CLANG, "-x", "c++", "-std=c++20", opt, "-g", "-fPIC", "-pthread", "-I", HERE, "-I", src_dir, "-Wno-unused-value",
              "-Wno-unknown-attributes"] + ([f"-fsanitize={sanitize}"] if sanitize else [])
+    if sanitize or os.environ.get("HIPEMU_THREADS") == "1":
+        flags.append("-DHIPEMU_THREADS")     # work-items as OS threads: what the sanitizers can reason about
 
     def cc(u):
         obj = u[:-4] + ".o"

@@ -1,0 +1,39 @@
+"""Shared by the CPU emulation tests: build / load libscot_emu.so and point `poseidon_amd.ops` at it for one test."""
+import ctypes
+import os
+import shutil
+
+import pytest
+import torch
+
+import build_emu
+from poseidon_amd import lib as scot_lib
+from poseidon_amd import ops
+
+_lib = None
+
+
+def load_emu():
+    global _lib
+    if _lib is None:
+        if not (os.path.exists(build_emu.CLANG) or shutil.which(build_emu.CLANG)):
+            pytest.skip("no host clang with __bf16 vector support")
+        lib = ctypes.CDLL(build_emu.build_cached())
+        for name, argtypes in scot_lib.PROTOTYPES.items():
+            fn = getattr(lib, name)          # every symbol of the C ABI must exist in the emulated build too
+            fn.argtypes = argtypes
+            fn.restype = None if name in scot_lib._VOID else ctypes.c_int
+        # the emulated transposing LDS read must satisfy the kernels' own self test (the contract validated on the GPU)
+        assert lib.scot_selftest_tr(None) >= 0 and lib.scot_get_use_tr() == 1
+        _lib = lib
+    return _lib
+
+
+def patch_ops(monkeypatch, lib, workspace_bytes=32 << 20):
+    """CPU tensors go down the same wrappers for the duration of one test (the product's `ops.ptr` refuses them)."""
+    ws = torch.empty(workspace_bytes, dtype=torch.uint8)
+    monkeypatch.setattr(ops, "L", lambda: lib)
+    monkeypatch.setattr(ops, "ptr", lambda t: None if t is None else t.data_ptr())
+    monkeypatch.setattr(ops, "stream", lambda: None)
+    monkeypatch.setattr(ops, "workspace", lambda: ws)
+    monkeypatch.setattr(ops, "WORKSPACE_BYTES", workspace_bytes)

@@ -1,14 +1,12 @@
 """The production kernels of poseidon_amd/csrc executed on the CPU: every .hip source compiled as host C++ against the
 hipemu shim (tests/hipemu: one std::thread per work-item, wave64 cross-lane ops / MFMA / transposing LDS read emulated) and
-called through the SAME C ABI and the same `poseidon_amd.ops` wrappers as on the GPU, with CPU tensors.  Small shapes only
-(an emulated MFMA costs two thread barriers).  Test infrastructure: the emulated library is built into a temp directory and
+called through the SAME C ABI and the same `poseidon_amd.ops` wrappers as on the GPU, with CPU tensors.  Small shapes only (the arithmetic of every MFMA is
+redone per lane).  Test infrastructure: the emulated library is built into a temp directory and
 never loaded by the product (`poseidon_amd.lib` only ever opens libscot_hip.so; `ops.ptr` rejects CPU tensors outside this
 module's monkeypatch).  What a pass means: index algebra, LDS layout and barrier placement of the kernel sources are right
 under the fragment conventions of csrc/common.h — nothing about speed.  The GPU parity tests remain the gate."""
-import ctypes
 import math
 import os
-import shutil
 import sys
 
 import pytest
@@ -16,40 +14,19 @@ import torch
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, os.path.join(HERE, "hipemu"))
-from poseidon_amd import lib as scot_lib  # noqa: E402
 from poseidon_amd import ops  # noqa: E402
 
 
-@pytest.fixture(scope="module")
-def emu_lib():
-    import build_emu
-    if not (os.path.exists(build_emu.CLANG) or shutil.which(build_emu.CLANG)):
-        pytest.skip("no host clang with __bf16 vector support")
-    lib = ctypes.CDLL(build_emu.build_cached())
-    for name, argtypes in scot_lib.PROTOTYPES.items():
-        fn = getattr(lib, name)          # every symbol of the C ABI must exist in the emulated build too
-        fn.argtypes = argtypes
-        fn.restype = None if name in scot_lib._VOID else ctypes.c_int
-    assert lib.scot_selftest_tr(None) >= 0 and lib.scot_get_use_tr() == 1   # the emulated transposing LDS read = the kernels' contract
+@pytest.fixture()
+def emu(monkeypatch):
+    import emu_session
+    lib = emu_session.load_emu()
+    emu_session.patch_ops(monkeypatch, lib)
     return lib
 
 
-@pytest.fixture()
-def emu(emu_lib, monkeypatch):
-    ws = torch.empty(8 << 20, dtype=torch.uint8)
-    monkeypatch.setattr(ops, "L", lambda: emu_lib)
-    monkeypatch.setattr(ops, "ptr", lambda t: None if t is None else t.data_ptr())
-    monkeypatch.setattr(ops, "stream", lambda: None)
-    monkeypatch.setattr(ops, "workspace", lambda: ws)
-    monkeypatch.setattr(ops, "WORKSPACE_BYTES", 8 << 20)
-    return emu_lib
-
-
-FULL = os.environ.get("SCOT_EMU_FULL") == "1"   # default: a subset that keeps the CPU suite at a few minutes
-
-
-def full_only(*cases):
-    return list(cases) if FULL else []
+def full_only(*cases):   # (was a slow-case gate while work-items were OS threads; as fibers the whole list takes seconds)
+    return list(cases)
 
 
 def rel(a, b):
