@@ -18,8 +18,11 @@
 // Training additionally stores what the backward consumes (gelu(u), gelu'(u), z, mean, rstd) — same tensors, same dtypes and
 // the same rounding points as the three-kernel path, so the two paths agree to accumulation order.
 //
-// STATUS: written at the end of round 1 without GPU time left — compiled for gfx950 only.  OFF unless SCOT_FUSED_MLP=1; the
-// parity tests for it (tests/test_kernels_gpu.py::test_mlp_block_fused, SCOT_EXPERIMENTAL=1) have not run yet.
+// STATUS (end of round 1, no GPU time left): NOT yet run on a GPU, therefore OFF unless SCOT_FUSED_MLP=1.  Verified on the CPU
+// through tests/hipemu (this very source compiled for the host, work-items as fibers, MFMA / transposing LDS read / shuffles
+// emulated with the lane conventions of common.h): every kernel here against fp64 loops and against the launches it replaces,
+// the engine with the flag on against the layer-by-layer engine, the oracle and the Poseidon-T fixture (forward + backward),
+// clean under AddressSanitizer / ThreadSanitizer.  Unknown: speed.  tools/experimental_runbook.sh is the first GPU call.
 #include "common.h"
 #include <stdlib.h>
 
