@@ -101,6 +101,7 @@ struct Sched {
   std::vector<Fiber> fib;
   void* main_sp = nullptr;
   unsigned cur = 0;
+  uint64_t events = 0;                  // barrier arrivals, published exchanges, completions: a scheduler round without any = deadlock
   std::function<void(unsigned)> job;
 };
 inline Sched* g_sched = nullptr;
@@ -117,6 +118,7 @@ struct Barrier {
   uint64_t gen = 0;
   explicit Barrier(unsigned n_) : n(n_) {}
   void arrive_and_wait() {
+    ++g_sched->events;
     if (++count == n) { count = 0; ++gen; return; }
     Fiber& f = g_sched->fib[g_sched->cur];
     f.wait_gen = &gen;
@@ -124,6 +126,12 @@ struct Barrier {
     emu_switch(&f.sp, g_sched->main_sp);     // resumed by the scheduler once gen has moved on
   }
 };
+// give the other work-items a turn (the caller re-checks its own condition when it is resumed)
+inline void park() {
+  Fiber& f = g_sched->fib[g_sched->cur];
+  f.wait_gen = nullptr;
+  emu_switch(&f.sp, g_sched->main_sp);
+}
 #endif
 struct Wave {
   Barrier bar{64};
@@ -131,6 +139,10 @@ struct Wave {
   uint64_t a[64][2], b[64][2];     // 8 x b16 operands
   float fa[64][8], fb[64][8];      // fp32 operands
   const void* ptr[64];
+#ifndef HIPEMU_THREADS
+  uint32_t xcnt[64][64] = {};      // xcnt[l][p]: exchanges lane l has published for lane p
+  float xval[64][64][2];
+#endif
 };
 struct Block {
   std::unique_ptr<Barrier> bar;
@@ -147,6 +159,7 @@ inline void emu_wave_barrier() { hipemu::wave().bar.arrive_and_wait(); }
 #define __builtin_amdgcn_wave_barrier emu_wave_barrier
 #define __builtin_amdgcn_sched_barrier(x) ((void)0)
 
+#ifdef HIPEMU_THREADS
 inline float __shfl_xor(float v, int mask, int = 64) {
   auto& w = hipemu::wave();
   const int l = hipemu::lane();
@@ -156,6 +169,21 @@ inline float __shfl_xor(float v, int mask, int = 64) {
   w.bar.arrive_and_wait();
   return r;
 }
+#else
+// Pairwise rendezvous instead of a whole-wave one: lane l only needs lane l^mask.  The k-th exchange between a pair matches the
+// partner's k-th exchange with it, whatever else either lane has executed in between — so shuffles inside sub-wave groups that
+// run different trip counts (cln_bwd_fast_kernel on ragged row counts), and the cross-group shuffles after such a loop, pair up
+// exactly as the hardware's lane masking / reconvergence makes them.
+inline float __shfl_xor(float v, int mask, int = 64) {
+  auto& w = hipemu::wave();
+  const int l = hipemu::lane(), p = (l ^ mask) & 63;
+  const uint32_t k = w.xcnt[l][p]++;
+  w.xval[l][p][k & 1] = v;
+  ++hipemu::g_sched->events;
+  while (w.xcnt[p][l] <= k) hipemu::park();
+  return w.xval[p][l][k & 1];
+}
+#endif
 
 typedef __bf16 emu_bf16x8 __attribute__((ext_vector_type(8)));
 typedef float emu_f32x4 __attribute__((ext_vector_type(4)));
@@ -319,6 +347,7 @@ inline void fiber_entry() {
   const unsigned me = s->cur;
   s->job(me);
   s->fib[me].done = true;
+  ++s->events;
   void* dummy;
   emu_switch(&dummy, s->main_sp);
   std::abort();   // a finished fiber is never resumed
@@ -344,7 +373,7 @@ inline void run_block(unsigned nthr, std::function<void(unsigned)> f) {
   }
   unsigned live = nthr;
   while (live) {
-    bool progress = false;
+    const uint64_t before = s->events;
     for (unsigned t = 0; t < nthr; ++t) {
       Fiber& fb = s->fib[t];
       if (fb.done) continue;
@@ -355,14 +384,13 @@ inline void run_block(unsigned nthr, std::function<void(unsigned)> f) {
       s->cur = t;
       threadIdx = {t, 0, 0};
       emu_switch(&s->main_sp, fb.sp);
-      progress = true;
       if (fb.done) --live;
     }
+    const bool progress = s->events != before;
     if (!progress) {
-      // Every live work-item is parked at a rendezvous that cannot complete.  Either a kernel bug (a barrier under divergent
-      // control flow) or the one thing this emulation cannot express: cross-lane operations inside wave-divergent control flow
-      // that the hardware handles by masking / reconverging lanes (e.g. sub-wave row groups with different trip counts in
-      // cln_bwd_fast_kernel on ragged row counts).  The fibers are abandoned and the launch is reported as failed.
+      // Every live work-item is parked at a rendezvous that cannot complete: a kernel bug (a barrier or a whole-wave operation
+      // under divergent control flow) or a construct this emulation cannot express.  The fibers are abandoned and the launch is
+      // reported as failed.
       std::fprintf(stderr, "hipemu: block (%u,%u,%u): all live work-items are parked at a barrier — launch abandoned\n", blockIdx.x,
                    blockIdx.y, blockIdx.z);
       g_emu_error = 719;   // hipErrorLaunchFailure
