@@ -84,3 +84,80 @@ def test_two_rank_mean_allreduce(tmp_path, wire):
     out = str(tmp_path / "ok")
     mp.spawn(_worker, args=(2, port, wire, out), nprocs=2, join=True)
     assert open(out).read() == "ok"
+
+
+# ------------------------------------------------------------------------------------------------------------------------
+# The real engine under data parallelism, on the CPU emulation of the kernels (tests/hipemu): each rank runs forward + backward
+# of its shard and the engine's `on_grads_final(prefix)` callback — the hook the overlapped RCCL exchange hangs on — reduces that
+# prefix's arena range IMMEDIATELY.  If a range were announced before the backward had finished writing it, the contributions
+# accumulated afterwards would stay un-averaged and the result would differ from the mean of the two ranks' gradients.
+def _engine_worker(rank, world, port, out):
+    import sys
+    here = os.path.dirname(os.path.abspath(__file__))
+    sys.path.insert(0, os.path.join(here, "hipemu"))
+    sys.path.insert(0, here)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), SCOT_SIDE_STREAM="0", SCOT_TAPE="0")
+    import emu_session
+    from poseidon_amd import ops
+    from poseidon_amd.synth import synth_inputs, synth_state_dict
+    from scOT.model import ScOT
+    lib = emu_session.load_emu()
+    ws = torch.empty(32 << 20, dtype=torch.uint8)
+    ops.L, ops.stream, ops.workspace, ops.WORKSPACE_BYTES = (lambda: lib), (lambda: None), (lambda: ws), 32 << 20
+    ops.ptr = lambda t: None if t is None else t.data_ptr()
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    cfg = ScOTConfig(**dict(TINY, mlp_ratio=4.0, qkv_bias=True, p=1, channel_slice_list_normalized_loss=[0, 1, 3, 4],
+                            drop_path_rate=0.0))      # (stochastic depth would make the two steps below differ)
+    model = ScOT(cfg, compute="fp32")
+    model.load_state_dict(synth_state_dict(param_shapes(cfg), "trained"))
+    model._ensure_arena(torch.device("cpu"))
+    pv, t, lab = synth_inputs(4, 4, 4, 32, "smooth")
+    sl = slice(2 * rank, 2 * rank + 2)                       # this rank's shard of the global batch of 4
+    eng = model._engine
+
+    def step():
+        model._arena.grad.zero_()
+        loss, _, tape = eng.forward(pv[sl].contiguous(), t[sl].contiguous(), lab[sl].contiguous(), None, train=True)
+        model._prepare_grads()
+        eng.backward(tape, torch.ones(1), None)
+        return model._arena.grad.clone()
+
+    local = step()                                           # no exchange
+    both = [torch.empty_like(local) for _ in range(world)]
+    dist.all_gather(both, local)
+    expect = sum(both) / world
+    assert not torch.equal(both[0], both[1])                 # the shards really differ
+    red = GradAllReducer(model, dist, wire="fp32", chunk_mb=1)
+    ranges = {p: (s, e) for p, s, e in red.ranges_in_backward_order()}
+    seen = []
+
+    def on_final(prefix):
+        seen.append(prefix)
+        s, e = ranges[prefix]
+        red.reduce_range(s, e)
+
+    eng.on_grads_final = on_final
+    got = step()
+    assert seen == [p for p in backward_order_groups(cfg) if p in ranges], seen
+    err = float((got - expect).norm() / expect.norm())
+    bad = [n for n in model._arena.shapes
+           if not torch.allclose(model._arena.gview(n), expect[model._arena.offsets[n]:model._arena.offsets[n] + model._arena.numel(n)]
+                                 .view(model._arena.gview(n).shape), rtol=1e-5, atol=1e-7)]
+    assert err < 1e-6 and not bad, (rank, err, bad[:12], len(bad))
+    dist.barrier()
+    dist.destroy_process_group()
+    if rank == 0:
+        open(out, "w").write(f"ok {err:.2e}")
+
+
+def test_engine_ranges_are_final_when_announced(tmp_path):
+    import shutil
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "hipemu"))
+    import build_emu
+    if not (os.path.exists(build_emu.CLANG) or shutil.which(build_emu.CLANG)):
+        pytest.skip("no host clang with __bf16 vector support")
+    build_emu.build_cached()                                  # once, before the two ranks race for it
+    out = str(tmp_path / "ok")
+    mp.spawn(_engine_worker, args=(2, 31500 + (os.getpid() % 2000), out), nprocs=2, join=True)
+    assert open(out).read().startswith("ok")
