@@ -99,6 +99,9 @@ class ScOTEngine:
         # EXPERIMENTAL (csrc/mlp_fused.hip; not yet run on a GPU): fc1 → GELU → fc2 → cond-LN → residual in one launch for the
         # C = 96 / 192 stages, bf16 mode only
         self.fused_mlp = os.environ.get("SCOT_FUSED_MLP", "0") == "1" and compute == "bf16"
+        # A/B knobs for the first measurements: which channel widths and which of the four kernels take the fused path
+        self.fused_c = {int(c) for c in os.environ.get("SCOT_FUSED_C", "96,192").split(",") if c}
+        self.fused_parts = set(os.environ.get("SCOT_FUSED_PARTS", "mlp_fwd,mlp_bwd,proj_fwd,proj_bwd").split(","))
         # bf16 mode: GEMM operands must already be bf16 in HBM (gemm_fast streams raw 16-byte chunks into LDS), so the
         # weights get a bf16 shadow arena that is re-cast from the fp32 master at the start of EVERY forward (one pass,
         # inside the timed step), and every producer of a GEMM operand also writes a bf16 copy.
@@ -399,6 +402,10 @@ class ScOTEngine:
         self.run_chains(n, chain)
         return g
 
+    def use_fused(self, part: str, C: int) -> bool:
+        """csrc/mlp_fused.hip covers C = 96 / 192 (bf16 mode); SCOT_FUSED_C / SCOT_FUSED_PARTS narrow it for A/B runs."""
+        return self.fused_mlp and C in (96, 192) and C in self.fused_c and part in self.fused_parts
+
     def wgrad(self, cm, dy, x, gw, b_gelu=False, dbias=None):
         self.off_critical_path(lambda: ops.linear_wgrad(cm, dy, x, gw, b_gelu=b_gelu, dbias=dbias), dy, x)
 
@@ -453,7 +460,7 @@ class ScOTEngine:
             attn_c = attn
         dp1 = self.drop_path_scale(pre, B, 0) if train else None
         dp2 = self.drop_path_scale(pre, B, 1) if train else None
-        if self.fused_mlp and C in (96, 192):
+        if self.use_fused("proj_fwd", C):
             proj = self.new(B * L, C) if train else None
             st1 = (self.new(B * L), self.new(B * L)) if train else (None, None)
             h, h16 = self.new(B * L, C), self.new(B * L, C, dtype=self.adt)
@@ -469,7 +476,7 @@ class ScOTEngine:
             h, h16, st1 = self.norm_fwd(pre + ".layernorm_before", proj, x, L, C, cfg.layer_norm_eps, time, need_stats=train,
                                         copy=True, sample_scale=dp1)
         hid = int(cfg.mlp_ratio * C)
-        if self.fused_mlp and C in (96, 192) and hid % 128 == 0:
+        if self.use_fused("mlp_fwd", C) and hid % 128 == 0:
             u = self.new(B * L, hid, dtype=self.adt) if train else None
             gp = self.new(B * L, hid, dtype=self.adt) if train else None
             y2 = self.new(B * L, C) if train else None
@@ -581,7 +588,7 @@ class ScOTEngine:
         a = pre + ".attention.self."
         L, Lp = H * W, Hp * Wp
         hid = int(cfg.mlp_ratio * C)
-        if (self.fused_mlp and C in (96, 192) and hid % 128 == 0 and L % 64 == 0 and not self.split_ln_bwd):
+        if self.use_fused("mlp_bwd", C) and hid % 128 == 0 and L % 64 == 0 and not self.split_ln_bwd:
             # the whole dependent chain of the MLP half in one launch; the two weight gradients follow on the side stream
             d_y2 = self.new(B * L, C, dtype=adt)
             d_u = self.new(B * L, hid, dtype=adt)
@@ -607,7 +614,7 @@ class ScOTEngine:
             g = self.dgrad_into(cm, d_u, self.W(pre + ".intermediate.dense.weight"), g)
         # h = x + CLN_before(proj)
         d_attn = self.new(B * L, C, dtype=adt)
-        if self.fused_mlp and C in (96, 192) and L % 64 == 0 and not self.split_ln_bwd:
+        if self.use_fused("proj_bwd", C) and L % 64 == 0 and not self.split_ln_bwd:
             d_proj = self.new(B * L, C, dtype=adt)
             gw_w, gw_b, _, _ = self._norm_params(pre + ".layernorm_before")
             gg = self._norm_grads(pre + ".layernorm_before")
