@@ -8,7 +8,8 @@
  * Conventions: every pointer is a DEVICE pointer borrowed for the duration of the enqueue; calls only enqueue
  * work on `stream` (never allocate, never synchronise, except scot_selftest_tr); return 0 on success, <0 on
  * bad shape (-1) / dtype (-2) / unsupported configuration (-3) / launch failure (-4).
- * dtype codes: 0 = float32, 1 = bfloat16 (raw uint16).  compute codes: 0 = exact fp32 MFMA, 1 = bf16 MFMA.
+ * dtype codes: 0 = float32, 1 = the library's 16-bit operand format (raw uint16; bfloat16 or binary16, see
+ * scot_operand_format).  compute codes: 0 = exact fp32 MFMA, 1 = 16-bit MFMA, 2 = split (hi + lo) 16-bit MFMA.
  */
 #ifndef SCOT_HIP_H
 #define SCOT_HIP_H
@@ -26,6 +27,14 @@ typedef struct ihipStream_t* scot_stream_t; /* = hipStream_t */
 #define SCOT_LAYOUT_TN 2 /* C[M,N] += A[K,M]^T B[K,N] : wgrad of nn.Linear (autograd of the above)                 */
 
 int scot_abi_version(void);
+/* Format of dtype code 1 in THIS build of the library: 0 = bfloat16 (libscot_hip.so), 1 = IEEE binary16 (libscot_hip_f16.so, the
+ * same sources compiled with -DSCOT_OPERAND_FP16).  The reference computes in fp32 (ref:1318-1509); 16-bit operands are this
+ * library's choice and binary16 is the one that keeps ScOT.forward within 1e-3 of it. */
+int scot_operand_format(void);
+/* x[0..n) *= scale (fp32, in place, x 16-byte aligned); *nonfinite (optional, device int) += number of waves that saw Inf/NaN.
+ * Undoes the backward's gradient scale on the gradient arena (the role torch.cuda.amp.GradScaler.unscale_ plays for the
+ * reference's fp16 recipe, trainer.py via HF Trainer). */
+int scot_scale_inplace(float* x, size_t n, float scale, int* nonfinite, scot_stream_t stream);
 int scot_selftest_tr(scot_stream_t stream); /* 1: ds_read_b64_tr_b16 path verified & on, 0: scalar-gather fallback */
 void scot_set_use_tr(int v);
 int scot_get_use_tr(void);

@@ -25,8 +25,7 @@ template <> __device__ __forceinline__ void ld4<float>(const void* p, size_t i, 
 }
 template <> __device__ __forceinline__ void ld4<bf16_t>(const void* p, size_t i, float (&v)[4]) {
   const uint2 u = *(const uint2*)((const bf16_t*)p + i);
-  v[0] = __uint_as_float(u.x << 16); v[1] = __uint_as_float(u.x & 0xffff0000u);
-  v[2] = __uint_as_float(u.y << 16); v[3] = __uint_as_float(u.y & 0xffff0000u);
+  unpack_bf16x2(u.x, v[0], v[1]); unpack_bf16x2(u.y, v[2], v[3]);
 }
 template <typename CT> __device__ __forceinline__ void st4(void* p, size_t i, const float (&v)[4]);
 template <> __device__ __forceinline__ void st4<float>(void* p, size_t i, const float (&v)[4]) {

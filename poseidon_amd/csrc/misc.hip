@@ -823,3 +823,39 @@ extern "C" int scot_selftest_tr(hipStream_t s) {
 extern "C" void scot_set_use_tr(int v) { g_scot_use_tr = v ? 1 : 0; }
 extern "C" int scot_get_use_tr() { return g_scot_use_tr; }
 extern "C" int scot_abi_version() { return 1; }
+// Format of the 16-bit operand type this build of the library computes with: 0 = bfloat16, 1 = IEEE binary16 (common.h).
+extern "C" int scot_operand_format() {
+#if defined(SCOT_OPERAND_FP16)
+  return 1;
+#else
+  return 0;
+#endif
+}
+
+// ------------------------------------------------------------------ x *= scale over a flat fp32 range (+ non-finite count)
+// The fp16 build runs the backward on gradients multiplied by a power of two (fp16 has 5 exponent bits; engine.py picks
+// the scale from the loss normalisation) and divides the gradient arena by it afterwards — exact — with this one pass,
+// which also counts Inf/NaN so that an overflow is reported instead of silently stepping the optimizer.
+__global__ void scale_inplace_kernel(float* x, size_t n4, size_t n, float scale, int* nonfinite) {
+  int bad = 0;
+  const size_t stride = (size_t)gridDim.x * blockDim.x;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) {
+    float4 v = ((float4*)x)[i];
+    v.x *= scale; v.y *= scale; v.z *= scale; v.w *= scale;
+    bad |= !(fabsf(v.x) <= 3.4e38f) | !(fabsf(v.y) <= 3.4e38f) | !(fabsf(v.z) <= 3.4e38f) | !(fabsf(v.w) <= 3.4e38f);
+    ((float4*)x)[i] = v;
+  }
+  for (size_t i = n4 * 4 + (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+    const float v = x[i] * scale;
+    bad |= !(fabsf(v) <= 3.4e38f);
+    x[i] = v;
+  }
+  if (nonfinite != nullptr && __ballot(bad) != 0ull && (threadIdx.x & 63) == 0) atomicAdd(nonfinite, 1);
+}
+extern "C" int scot_scale_inplace(float* x, size_t n, float scale, int* nonfinite, hipStream_t s) {
+  if (n == 0) return SCOT_OK;
+  if (((uintptr_t)x) & 15) return SCOT_ERR_SHAPE;
+  size_t blocks = (n / 4 + 255) / 256; if (blocks > 4096) blocks = 4096; if (blocks == 0) blocks = 1;
+  hipLaunchKernelGGL(scale_inplace_kernel, dim3((unsigned)blocks), dim3(256), 0, s, x, n / 4, n, scale, nonfinite);
+  return scot_check_launch();
+}

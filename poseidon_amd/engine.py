@@ -17,6 +17,7 @@ from __future__ import annotations
 
 import math
 import os
+import weakref
 from typing import Dict, List, Optional
 
 import torch
@@ -37,6 +38,11 @@ def cpb_coords_table(ws: int) -> torch.Tensor:
     return tab.reshape(-1, 2).contiguous()
 
 
+class _Token:
+    """Lifetime marker of one taped forward call: alive while the caller (the autograd node) can still ask for its backward."""
+    __slots__ = ("__weakref__",)
+
+
 class ScOTEngine:
     def __init__(self, cfg, arena: Arena, compute: str = "bf16"):
         if compute not in ("bf16", "fp32", "bf16x3"):
@@ -51,6 +57,7 @@ class ScOTEngine:
         # arguments + the host-side stream/event operations between them), later steps replay the list: ~2500 launches per
         # step cost ~10 us of Python each when issued through the op wrappers, ~1.5 us when replayed.
         self.tape_mode = os.environ.get("SCOT_TAPE", "1") == "1"
+        self.stochastic = False
         self.tape_max = max(1, int(os.environ.get("SCOT_TAPE_MAX", "2")))
         self._rec = None
         self._rec_keep = None
@@ -458,8 +465,8 @@ class ScOTEngine:
             ops.copy2d(attn, attn_c, B, Hp, Wp, H, W, C)
         else:
             attn_c = attn
-        dp1 = self.drop_path_scale(pre, B, 0) if train else None
-        dp2 = self.drop_path_scale(pre, B, 1) if train else None
+        dp1 = self.drop_path_scale(pre, B, 0) if self.stochastic else None
+        dp2 = self.drop_path_scale(pre, B, 1) if self.stochastic else None
         if self.use_fused("proj_fwd", C):
             proj = self.new(B * L, C) if train else None
             st1 = (self.new(B * L), self.new(B * L)) if train else (None, None)
@@ -748,16 +755,21 @@ class ScOTEngine:
         return g
 
     # ------------------------------------------------------------------------------------------ whole model
-    def forward(self, pixel_values, time=None, labels=None, pixel_mask=None, train=True):
+    def forward(self, pixel_values, time=None, labels=None, pixel_mask=None, train=True, stochastic=None):
         """→ (loss [1] or None, prediction [B,Cout,H,W], tape or None).  Inputs: fp32 contiguous CUDA tensors.
+        `train` = keep what the backward needs; `stochastic` = draw stochastic-depth masks (the reference keys that on
+        `module.training`, HF:565-586; default: same as `train`).
 
         Training steps go through the step tape (see __init__): call 1 of a signature runs the ops directly, call 2 runs them
-        and records, later calls copy the inputs into the recorded step's input buffers and replay.  The tensors returned
-        by a replay alias the recorded step's buffers (like a hipGraph's static outputs): read them before the next step."""
-        if not (train and self.tape_mode and labels is not None and not self.stage_timing) or torch.cuda.is_current_stream_capturing():
+        and records, later calls copy the inputs into the recorded step's input buffers and replay.  A recorded step has ONE
+        set of activation buffers, so it is replayed only while no earlier forward of it still waits for its backward
+        (forward-forward-backward-backward, the reference's AR training loop trainer.py:466-490, takes the untaped path for
+        the second forward); loss and prediction are returned as fresh tensors, never as views of the recorded buffers."""
+        self.stochastic = bool(train if stochastic is None else stochastic)
+        if not (train and self.tape_mode and labels is not None and not self.stage_timing) or self._capturing():
             return self._forward(pixel_values, time, labels, pixel_mask, train)
         key = (tuple(pixel_values.shape), None if time is None else tuple(time.shape), tuple(labels.shape),
-               None if pixel_mask is None else (tuple(pixel_mask.shape), pixel_mask.dtype), torch.cuda.current_stream().cuda_stream)
+               None if pixel_mask is None else (tuple(pixel_mask.shape), pixel_mask.dtype), self._stream_id(), self.stochastic)
         ent = self._taped.get(key)
         if ent is None:
             # a recorded step pins all of its buffers (GBs): keep at most `tape_max` signatures (e.g. the full batch and the
@@ -768,13 +780,20 @@ class ScOTEngine:
             return self._forward(pixel_values, time, labels, pixel_mask, train)
         self._taped[key] = self._taped.pop(key)   # most recently used last
         ins = (pixel_values, time, labels, pixel_mask)
+        pend = ent.get("pending")
+        if pend is not None and pend() is not None:
+            # an earlier forward of this recorded step has not been differentiated yet (and its autograd node is still
+            # alive): its activations live in the recorded buffers, so this call must not touch them
+            return self._forward(pixel_values, time, labels, pixel_mask, train)
         if ent["state"] == "ready":
             for dst, src in zip(ent["in"], ins):
                 if dst is not None:
                     dst.copy_(src)
             self._replay(ent["fwd"])
             loss, pred, tape = ent["out"]
-            return loss.detach(), pred.detach(), tape
+            tok = _Token()
+            ent["pending"] = weakref.ref(tok)
+            return loss.clone(), pred.clone(), dict(_ent=ent, _tok=tok)
         if ent["state"] != "warm":        # recorded forward whose backward never ran, or a tape that was switched off
             return self._forward(pixel_values, time, labels, pixel_mask, train)
         ent["in"] = tuple(None if t is None else t.clone() for t in ins)
@@ -789,7 +808,15 @@ class ScOTEngine:
         tape["_ent"] = ent
         ent["out"] = (loss, pred, tape)
         ent["state"] = "fwd"
-        return loss.detach(), pred.detach(), tape
+        tok = _Token()
+        ent["pending"] = weakref.ref(tok)
+        return loss.clone(), pred.clone(), dict(_ent=ent, _tok=tok)
+
+    def _capturing(self):
+        return self.device.type == "cuda" and torch.cuda.is_current_stream_capturing()
+
+    def _stream_id(self):
+        return torch.cuda.current_stream().cuda_stream if self.device.type == "cuda" else 0
 
     @staticmethod
     def _replay(cmds):
@@ -804,9 +831,13 @@ class ScOTEngine:
     def backward(self, tape, dloss=None, dpred=None):
         """Accumulates every parameter gradient into the gradient arena (+=).  dloss: [1] cuda tensor or None (=1)."""
         ent = tape.get("_ent")
-        if ent is None or ent["state"] == "off":
+        if ent is None:
             return self._backward(tape, dloss, dpred)
-        if dpred is not None or torch.cuda.is_current_stream_capturing():   # not the recorded pattern: plain path, tape off
+        ent["pending"] = None
+        tape = ent["out"][2]     # the recorded step's activation records (the caller holds a per-call handle)
+        if ent["state"] == "off":
+            return self._backward(tape, dloss, dpred)
+        if dpred is not None or self._capturing():   # not the recorded pattern: plain path, tape off
             ent["state"] = "off"
             return self._backward(tape, dloss, dpred)
         if ent["state"] == "ready":

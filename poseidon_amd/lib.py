@@ -11,12 +11,17 @@ from ctypes import c_float, c_int, c_size_t, c_void_p
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libscot_hip.so")
+# The same sources built twice (build.py): the format of the 16-bit operand type is a compile-time property (csrc/common.h).
+LIB_PATHS = {"bf16": LIB_PATH, "f16": os.path.join(_HERE, "libscot_hip_f16.so")}
+OPERAND_FORMAT = {"bf16": 0, "f16": 1}
 
 P, I, F, Z = c_void_p, c_int, c_float, c_size_t
 
 # name -> argtypes (restype is int unless listed in _VOID)
 PROTOTYPES = {
     "scot_abi_version": [],
+    "scot_operand_format": [],
+    "scot_scale_inplace": [P, Z, F, P, P],
     "scot_selftest_tr": [P],
     "scot_set_use_tr": [I],
     "scot_get_use_tr": [],
@@ -57,18 +62,20 @@ PROTOTYPES = {
 }
 _VOID = {"scot_set_use_tr"}
 
-_lib = None
+_libs = {}
 
 
 class ScotLibraryError(RuntimeError):
     pass
 
 
-def load(path: str = LIB_PATH):
-    """Load (once) and type the library.  Raises if it is absent — there is no CPU/PyTorch fallback."""
-    global _lib
-    if _lib is not None:
-        return _lib
+def load(path: str = None, kind: str = "bf16"):
+    """Load (once per build) and type the library.  Raises if it is absent — there is no CPU/PyTorch fallback."""
+    if kind not in LIB_PATHS:
+        raise ValueError(f"unknown library build {kind!r}")
+    if kind in _libs:
+        return _libs[kind]
+    path = path or LIB_PATHS[kind]
     # torch bundles its own libamdhip64.so (dlopen'ed by path).  It MUST be resident before our library is loaded so
     # that our NEEDED libamdhip64.so.7 resolves (by SONAME) to the same runtime; loading ours first pulls in
     # /opt/rocm's copy as a SECOND HIP runtime whose streams/pointers are foreign to torch's.
@@ -82,7 +89,10 @@ def load(path: str = LIB_PATH):
         fn = getattr(lib, name)  # AttributeError if a declared symbol is missing
         fn.argtypes = argtypes
         fn.restype = None if name in _VOID else c_int
-    _lib = lib
+    if lib.scot_operand_format() != OPERAND_FORMAT[kind]:
+        raise ScotLibraryError(f"{path} was built for operand format {lib.scot_operand_format()}, expected {OPERAND_FORMAT[kind]} "
+                               f"({kind}); rebuild with `python -m poseidon_amd.build --force`")
+    _libs[kind] = lib
     return lib
 
 

@@ -15,12 +15,31 @@ F32, BF16, X3 = 0, 1, 2   # compute modes of scot_gemm (X3 = bf16x3: fp32 operan
 NT, NN, TN = 0, 1, 2
 
 
+_active = "bf16"   # which build of the library the calls below go to: "bf16" (libscot_hip.so) or "f16" (libscot_hip_f16.so)
+HALF = {"bf16": torch.bfloat16, "f16": torch.float16}
+
+
+def use(kind: str) -> str:
+    """Route the wrappers below to the library build whose 16-bit operand format is `kind`; returns the previous one.
+    (An engine selects its build around every forward / backward; a recorded step tape holds the functions themselves.)"""
+    global _active
+    if kind not in HALF:
+        raise ValueError(kind)
+    prev, _active = _active, kind
+    return prev
+
+
+def half_dtype() -> torch.dtype:
+    return HALF[_active]
+
+
 def dt(t: torch.Tensor) -> int:
+    """dtype code of the C ABI: 0 = float32, 1 = the active library's 16-bit operand format."""
     if t.dtype == torch.float32:
         return F32
-    if t.dtype == torch.bfloat16:
+    if t.dtype == HALF[_active]:
         return BF16
-    raise TypeError(f"unsupported dtype {t.dtype}")
+    raise TypeError(f"unsupported dtype {t.dtype} for the {_active} build of the library")
 
 
 def ptr(t: Optional[torch.Tensor]):
@@ -35,7 +54,7 @@ def stream():
     return torch.cuda.current_stream().cuda_stream
 
 
-_selftested = False
+_selftested = set()
 
 
 _recorder = None   # a list while the engine records a step tape: every C-ABI call is appended as (function, args)
@@ -67,13 +86,12 @@ def set_recorder(log):
 
 def L():
     """Library handle; runs the one-time device self test of the transposing LDS read on first use."""
-    global _selftested
-    l = _lib.load()
-    if not _selftested and torch.cuda.is_available():
+    l = _lib.load(kind=_active)
+    if _active not in _selftested and torch.cuda.is_available():
         rc = l.scot_selftest_tr(stream())
         if rc < 0:
             raise _lib.ScotLibraryError("scot_selftest_tr failed to run")
-        _selftested = True
+        _selftested.add(_active)
     if _recorder is not None:
         return _Recording(l, _recorder)
     return l
@@ -279,6 +297,11 @@ def cast(src, dst):
     """dst <- src (dtype conversion, one pass) — scot_scale_residual with no scale / residual."""
     n = src.numel()
     _lib.check(L().scot_scale_residual(ptr(src), dt(src), None, None, 0, ptr(dst), dt(dst), 1, n, stream()), "scot_scale_residual(cast)")
+
+
+def scale_inplace(x, scale: float, nonfinite=None):
+    """x (flat fp32, 16-byte aligned) *= scale; nonfinite (int32[1], optional) counts waves that saw Inf/NaN."""
+    _lib.check(L().scot_scale_inplace(ptr(x), x.numel(), float(scale), ptr(nonfinite), stream()), "scot_scale_inplace")
 
 
 def scale_residual(y, scale, resid, out, rows, N):

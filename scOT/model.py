@@ -125,7 +125,8 @@ class _ScOTFunction(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, anchor, model, pixel_values, time, labels, pixel_mask):
-        loss, pred, tape = model._engine.forward(pixel_values, time, labels, pixel_mask, train=True)
+        # activations are kept because a gradient was asked for; stochastic depth follows module.training (HF:565-586)
+        loss, pred, tape = model._engine.forward(pixel_values, time, labels, pixel_mask, train=True, stochastic=model.training)
         ctx.model, ctx.tape = model, tape
         ctx.has_loss = loss is not None
         ctx.set_materialize_grads(False)  # unused outputs arrive as None instead of zero tensors
@@ -164,6 +165,9 @@ class ScOT(nn.Module):
             raise NotImplementedError("mask tokens (bool_masked_pos) are unused by every preset and not implemented")
         if config.image_size % config.patch_size:
             raise ValueError("image_size must be a multiple of patch_size")
+        if config.hidden_dropout_prob or config.attention_probs_dropout_prob:
+            raise NotImplementedError("hidden_dropout_prob / attention_probs_dropout_prob != 0 are not implemented (every preset "
+                                      "and the training recipe use 0.0, reference train.py:247-272); refusing to ignore them silently")
         self.config = config
         self.compute = compute or os.environ.get("SCOT_COMPUTE", "bf16")
         self.num_layers_encoder = self.num_layers_decoder = len(config.depths)
@@ -315,7 +319,10 @@ class ScOT(nn.Module):
         """Attach arena slices as `.grad`.  If the grads were set to None (zero_grad(set_to_none=True)) the arena is
         cleared first, so accumulation semantics match autograd's."""
         ps = self._params
-        if ps[0].grad is None or ps[0].grad.data_ptr() != self._gviews[0].data_ptr():
+        first = next((i for i, p in enumerate(ps) if p.requires_grad), None)   # a frozen parameter's .grad is always None
+        if first is None:
+            return
+        if ps[first].grad is None or ps[first].grad.data_ptr() != self._gviews[first].data_ptr():
             self._arena.grad.zero_()
             for p, g in zip(ps, self._gviews):
                 p.grad = g if p.requires_grad else None
@@ -396,18 +403,25 @@ class ScOT(nn.Module):
             if lab is None:
                 loss = None
         else:
-            loss, pred, _ = self._engine.forward(pv, t, lab, pixel_mask, train=False)
+            loss, pred, _ = self._engine.forward(pv, t, lab, pixel_mask, train=False, stochastic=self.training)
             if loss is not None:
                 loss = loss.view(())
             if resized:
                 pred = self._upsample(pred, in_size) if in_size > cfg.image_size else self._downsample(pred, in_size)
         hs = rhs = None
-        if output_hidden_states or (output_hidden_states is None and cfg.output_hidden_states):
+        want_hs = bool(output_hidden_states or (output_hidden_states is None and cfg.output_hidden_states))
+        if want_hs or not return_dict:
             hd, he = self._engine.last_hidden
-            hs, rhs = self._hidden_tuples(hd, he, B)
+            hs, rhs, enc_hs, enc_rhs, dec_hs, dec_rhs = self._hidden_tuples(hd, he, B)
         if not return_dict:
-            out = (pred,) + ((hs,) if hs is not None else ())
+            # reference model.py:1486-1488: (prediction,) + decoder_output[1:] + encoder_outputs[1:].  In tuple mode a stage
+            # stack returns (last, all_hidden_states[, attentions]) without the reshaped copies (model.py:1087-1092, 1228-1233);
+            # the decoder gets the caller's output_hidden_states, the ENCODER always True (model.py:1371-1378), so the
+            # encoder's hidden states are always the last element
+            out = (pred,) + ((dec_hs,) if want_hs else ()) + (enc_hs,)
             return ((loss,) + out) if loss is not None else out
+        if not want_hs:
+            hs = rhs = None
         return ScOTOutput(loss=loss, output=pred, hidden_states=hs, attentions=None, reshaped_hidden_states=rhs)
 
     def _forward_resized(self, pv, t, lab, pixel_mask, in_size, want_grad):
@@ -415,7 +429,7 @@ class ScOT(nn.Module):
         if want_grad:
             _, pred = _ScOTFunction.apply(self._anchor, self, pv, t, None, None)
         else:
-            _, pred, _ = self._engine.forward(pv, t, None, None, train=False)
+            _, pred, _ = self._engine.forward(pv, t, None, None, train=False, stochastic=self.training)
         pred = self._upsample(pred, in_size) if in_size > cfg.image_size else self._downsample(pred, in_size)
         if pixel_mask is not None:
             m = pixel_mask.view(pixel_mask.shape[0], pixel_mask.shape[1], 1, 1).expand_as(pred) if pixel_mask.dim() == 2 else pixel_mask
@@ -439,7 +453,7 @@ class ScOT(nn.Module):
         dec_res = [dec[0].res] + [s.res for s in dec]
         fd, rd = shp(hd, dec_res)
         fe, re_ = shp(he, enc_res)
-        return tuple(fd + fe), tuple(rd + re_)
+        return tuple(fd + fe), tuple(rd + re_), tuple(fe), tuple(re_), tuple(fd), tuple(rd)
 
 
 def _torch_loss(pred, labels, p, groups):

@@ -32,7 +32,7 @@ def load_emu():
 def patch_ops(monkeypatch, lib, workspace_bytes=32 << 20):
     """CPU tensors go down the same wrappers for the duration of one test (the product's `ops.ptr` refuses them)."""
     ws = torch.empty(workspace_bytes, dtype=torch.uint8)
-    monkeypatch.setattr(ops, "L", lambda: lib)
+    monkeypatch.setattr(ops, "L", lambda: ops._Recording(lib, ops._recorder) if ops._recorder is not None else lib)   # step tape
     monkeypatch.setattr(ops, "ptr", lambda t: None if t is None else t.data_ptr())
     monkeypatch.setattr(ops, "stream", lambda: None)
     monkeypatch.setattr(ops, "workspace", lambda: ws)

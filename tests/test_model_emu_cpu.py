@@ -143,3 +143,41 @@ def test_engine_poseidon_T_bf16(emu, monkeypatch, fused):
     mine = {k: float(p.grad.double().norm()) for k, p in model.named_parameters()}
     dev = np.array([abs(mine[n] - r) / max(r, 1e-12) for n, r in zip(names, f["grad_norms"]) if r > 1e-7])
     assert np.median(dev) < 3e-2
+
+
+def test_step_tape_forward_forward_backward_backward(emu, monkeypatch):
+    """with the step tape on, two same-shape training forwards before their backwards (the reference's AR
+    training loop, trainer.py:466-490) must not share activation buffers.  Gradients of f(a) + f(b) with the tape on == tape off,
+    and the prediction returned for `a` is not overwritten by the forward of `b`."""
+    from scOT.model import ScOT
+    f, meta = load_fixture("tiny_trained")
+    cfg = ScOTConfig(**meta["cfg"])
+    sd = synth_state_dict(param_shapes(cfg), meta["regime"])
+    pv, t, lab, pm = fixture_inputs(meta, cfg)
+    batches = [(pv * (1.0 + 0.1 * i), t, lab + 0.05 * i) for i in range(4)]
+    res = {}
+    for tape_on in ("0", "1"):
+        monkeypatch.setenv("SCOT_TAPE", tape_on)
+        model = ScOT(cfg, compute="fp32")
+        model.load_state_dict(sd)
+        model._ensure_arena(torch.device("cpu"))
+        eng = model._engine
+        assert eng.tape_mode == (tape_on == "1")
+        model._prepare_grads()
+        for b in batches[:2]:                      # warm + record (forward and backward)
+            _, _, tp = eng.forward(b[0], b[1], b[2], None, train=True)
+            eng.backward(tp, torch.ones(1), None)
+        model._arena.grad.zero_()
+        la, pa, ta = eng.forward(*batches[2], None, train=True)     # replay (tape on)
+        pa_copy = pa.clone()
+        lb, pb, tb = eng.forward(*batches[3], None, train=True)     # must NOT reuse the recorded buffers: `ta` is pending
+        assert torch.equal(pa, pa_copy), "a later forward overwrote an earlier forward's prediction"
+        assert not torch.equal(pa, pb)
+        eng.backward(ta, torch.ones(1), None)
+        eng.backward(tb, torch.ones(1), None)
+        lc, pc, tc = eng.forward(*batches[2], None, train=True)     # the tape is free again: replay
+        eng.backward(tc, torch.full((1,), 0.5), None)
+        res[tape_on] = (float(la), float(lb), pa.clone(), pb.clone(), model._arena.grad.clone())
+    assert res["0"][0] == pytest.approx(res["1"][0], rel=1e-6) and res["0"][1] == pytest.approx(res["1"][1], rel=1e-6)
+    assert rel_l2(res["1"][2].numpy(), res["0"][2].numpy()) < 1e-6 and rel_l2(res["1"][3].numpy(), res["0"][3].numpy()) < 1e-6
+    assert rel_l2(res["1"][4].numpy(), res["0"][4].numpy()) < 1e-5
