@@ -24,7 +24,7 @@ sys.path.insert(0, ROOT)
 
 # forward GFLOP/sample F (excl. CPB) and batch-independent CPB GFLOP/step P; fwd+bwd = 3(B·F + P)
 FLOPS = {"T": (2.784, 0.139), "B": (18.286, 0.277), "L": (67.948, 0.277)}
-PEAK_TFLOPS = {"bf16": 2500.0, "fp32": 157.3, "bf16x3": 2500.0 / 3}   # bf16x3 = three bf16 MFMAs per product  # dense MFMA peaks, /opt/skills/guides/MI355X_MICROARCH.md
+PEAK_TFLOPS = {"fp16": 2500.0, "bf16": 2500.0, "fp32": 157.3, "bf16x3": 2500.0 / 3}   # bf16x3 = three bf16 MFMAs per product  # dense MFMA peaks, /opt/skills/guides/MI355X_MICROARCH.md
 
 
 def parse():
@@ -36,7 +36,7 @@ def parse():
     ap.add_argument("--batch", type=int, default=64, help="per-GPU batch")
     ap.add_argument("--size", type=int, default=128)
     ap.add_argument("--channels", type=int, default=4)
-    ap.add_argument("--compute", default="bf16", choices=["bf16", "fp32", "bf16x3"])
+    ap.add_argument("--compute", default="bf16", choices=["fp16", "bf16", "fp32", "bf16x3"])
     ap.add_argument("--no-graph", action="store_true", help="eager launches instead of one hipGraph per step")
     ap.add_argument("--graph", action="store_true", help="force hipGraph replay (default: time both in the warm-up, keep the faster)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -121,12 +121,13 @@ def dominant_kernel_probe(compute, batch, embed_dim, size):
     at its stage-0 fc1 instance  dW[4C, C] += dY[M, 4C]^T · X[M, C],  M = batch·(size/4)^2 (split-K partials + reduce pass
     included, as in the step).  Also times the runner-up (`attn_bwd_kernel`, stage 0) for reference."""
     from poseidon_amd import ops
-    cm = {"bf16": ops.BF16, "fp32": ops.F32, "bf16x3": ops.X3}[compute]
-    dt = torch.bfloat16 if compute == "bf16" else torch.float32
+    cm = {"fp16": ops.BF16, "bf16": ops.BF16, "fp32": ops.F32, "bf16x3": ops.X3}[compute]
+    ops.use("f16" if compute == "fp16" else "bf16")
+    dt = ops.half_dtype() if compute in ("fp16", "bf16") else torch.float32
     M, C = batch * (size // 4) ** 2, embed_dim
     # operands rotate through > 800 MB so that nothing is served by the 256 MB Infinity Cache, as in the real step (a loop over
     # one buffer set measured 10-120 % optimistic for these kernels)
-    nset = max(2, int(800e6 / (M * 5 * C * (2 if compute == "bf16" else 4))) + 1)
+    nset = max(2, int(800e6 / (M * 5 * C * (2 if compute in ("fp16", "bf16") else 4))) + 1)
     sets = [(torch.randn(M, 4 * C, device="cuda").to(dt), torch.randn(M, C, device="cuda").to(dt)) for _ in range(nset)]
     dw = torch.zeros(4 * C, C, device="cuda")
     it = [0]

@@ -45,8 +45,12 @@ class _Token:
 
 class ScOTEngine:
     def __init__(self, cfg, arena: Arena, compute: str = "bf16"):
-        if compute not in ("bf16", "fp32", "bf16x3"):
-            raise ValueError("compute must be 'bf16', 'fp32' or 'bf16x3'")
+        if compute not in ("fp16", "bf16", "fp32", "bf16x3"):
+            raise ValueError("compute must be 'fp16', 'bf16', 'fp32' or 'bf16x3'")
+        # "fp16" and "bf16" run the SAME kernels from two builds of the library (csrc/common.h: the format of the 16-bit operand
+        # type is a compile-time property); everything else about the two modes is identical except the backward's gradient scale
+        self.lib_kind = "f16" if compute == "fp16" else "bf16"
+        half = compute in ("fp16", "bf16")
         self.cfg = cfg
         self.stage_timing = os.environ.get("SCOT_STAGE_TIMING", "0") == "1"
         self.marks = []
@@ -68,11 +72,11 @@ class ScOTEngine:
         self.arena = arena
         # bf16x3: activations and weights stay fp32 in HBM; the GEMMs split them into hi + lo bf16 while staging into LDS and
         # run three bf16 MFMAs per K-step (≈ fp32 accuracy at the bf16 MFMA rate); so do the 16x16-window attention kernels
-        self.compute = {"bf16": ops.BF16, "fp32": ops.F32, "bf16x3": ops.X3}[compute]
+        self.compute = {"fp16": ops.BF16, "bf16": ops.BF16, "fp32": ops.F32, "bf16x3": ops.X3}[compute]
         # attention kernels' arithmetic: bf16x3 also splits inside the 16x16-window kernels (SCOT_ATTN_X3=0: exact fp32 MFMA)
-        self.acm = ops.BF16 if compute == "bf16" else (ops.X3 if (compute == "bf16x3" and os.environ.get("SCOT_ATTN_X3", "1") == "1")
+        self.acm = ops.BF16 if half else (ops.X3 if (compute == "bf16x3" and os.environ.get("SCOT_ATTN_X3", "1") == "1")
                                                       else ops.F32)
-        self.adt = torch.bfloat16 if compute == "bf16" else torch.float32
+        self.adt = ops.HALF[self.lib_kind] if half else torch.float32
         self.device = arena.data.device
         # The "trunk" (patch embed, merge, unmerge, recovery: < 2 % of the FLOPs) is the only path every output pixel's
         # signal must traverse; each bf16 GEMM on it adds ~1e-3 of relative error that nothing downstream averages out.
@@ -80,7 +84,7 @@ class ScOTEngine:
         import os as _os
         trunk32 = self.compute == ops.BF16 and _os.environ.get("SCOT_TRUNK_BF16", "0") != "1"
         self.tcm = ops.F32 if (trunk32 or self.compute != ops.BF16) else ops.BF16
-        self.tadt = torch.float32 if self.tcm == ops.F32 else torch.bfloat16
+        self.tadt = torch.float32 if self.tcm == ops.F32 else self.adt
         self.grid, self.enc, self.dec = stage_plan(cfg)
         self.drop_rates = drop_path_rates(cfg)      # per-layer stochastic-depth rate (0 for the training recipe, train.py:262)
         self.precision_probe = None                 # tools/probes: set of layer pieces run in fp32 during an inference forward
@@ -105,14 +109,20 @@ class ScOTEngine:
         self._keep = []
         # EXPERIMENTAL (csrc/mlp_fused.hip; not yet run on a GPU): fc1 → GELU → fc2 → cond-LN → residual in one launch for the
         # C = 96 / 192 stages, bf16 mode only
-        self.fused_mlp = os.environ.get("SCOT_FUSED_MLP", "0") == "1" and compute == "bf16"
+        self.fused_mlp = os.environ.get("SCOT_FUSED_MLP", "1") == "1" and half
         # A/B knobs for the first measurements: which channel widths and which of the four kernels take the fused path
         self.fused_c = {int(c) for c in os.environ.get("SCOT_FUSED_C", "96,192").split(",") if c}
         self.fused_parts = set(os.environ.get("SCOT_FUSED_PARTS", "mlp_fwd,mlp_bwd,proj_fwd,proj_bwd").split(","))
         # bf16 mode: GEMM operands must already be bf16 in HBM (gemm_fast streams raw 16-byte chunks into LDS), so the
         # weights get a bf16 shadow arena that is re-cast from the fp32 master at the start of EVERY forward (one pass,
         # inside the timed step), and every producer of a GEMM operand also writes a bf16 copy.
-        self.shadow = torch.empty(arena.size, dtype=torch.bfloat16, device=self.device) if self.compute == ops.BF16 else None
+        self.shadow = torch.empty(arena.size, dtype=self.adt, device=self.device) if self.compute == ops.BF16 else None
+        # fp16 operands have 5 exponent bits: the backward runs on gradients multiplied by a power of two chosen from the loss
+        # normalisation (d loss / d prediction = O(1 / number of output elements); see _grad_scale) and the gradient arena is
+        # divided by it afterwards (exact; scot_scale_inplace also counts non-finite values → `grad_overflow`).
+        self.scale_grads = compute == "fp16" and os.environ.get("SCOT_GRAD_SCALE", "auto") != "1"
+        self.grad_overflow = torch.zeros(1, dtype=torch.int32, device=self.device) if self.scale_grads else None
+        self.grads_are_zero = False   # set by ScOT.zero_grad / _prepare_grads: the arena needs no pre-scaling then
         self._wviews: Dict[str, torch.Tensor] = {}
         self._build_cpb_plan()
 
@@ -217,6 +227,31 @@ class ScOTEngine:
         fn()
         if self._rec is not None:
             self._rec.append((fn, None))
+
+    def tdo_dynamic(self, fn):
+        """Like tdo, for a host-side step that decides AT RUN TIME which launches to issue (so the launches themselves must not
+        be logged by the recorder: a replay calls fn again)."""
+        def run():
+            prev = ops.set_recorder(None)
+            try:
+                fn()
+            finally:
+                ops.set_recorder(prev)
+        run()
+        if self._rec is not None:
+            self._rec.append((run, None))
+
+    def _grad_scale(self, n_out: int) -> float:
+        """Power-of-two factor the fp16 backward runs under.  d loss / d prediction is O(1 / n_out) for the (relative) mean
+        losses of model.py:1424-1484, i.e. 2.4e-7 for Poseidon-B at batch 64 — a subnormal in binary16; with the scale the
+        gradient of the prediction is O(1 / mean|label|) and the 16-bit gradient tensors of the backward (dY operands) sit in
+        the middle of binary16's 30 binades."""
+        if not self.scale_grads:
+            return 1.0
+        env = os.environ.get("SCOT_GRAD_SCALE", "auto")
+        if env != "auto":
+            return float(env)
+        return float(2 ** max(0, int(math.floor(math.log2(max(1, n_out))))))
 
     def clone(self, t):
         y = self.new(*t.shape, dtype=t.dtype)
@@ -756,6 +791,21 @@ class ScOTEngine:
 
     # ------------------------------------------------------------------------------------------ whole model
     def forward(self, pixel_values, time=None, labels=None, pixel_mask=None, train=True, stochastic=None):
+        prev = ops.use(self.lib_kind)
+        try:
+            return self._forward_step(pixel_values, time, labels, pixel_mask, train, stochastic)
+        finally:
+            ops.use(prev)
+
+    def backward(self, tape, dloss=None, dpred=None):
+        prev = ops.use(self.lib_kind)
+        try:
+            return self._backward_step(tape, dloss, dpred)
+        finally:
+            ops.use(prev)
+            self.grads_are_zero = False
+
+    def _forward_step(self, pixel_values, time=None, labels=None, pixel_mask=None, train=True, stochastic=None):
         """→ (loss [1] or None, prediction [B,Cout,H,W], tape or None).  Inputs: fp32 contiguous CUDA tensors.
         `train` = keep what the backward needs; `stochastic` = draw stochastic-depth masks (the reference keys that on
         `module.training`, HF:565-586; default: same as `train`).
@@ -828,7 +878,7 @@ class ScOTEngine:
                 if rc:
                     raise RuntimeError(f"step tape: {getattr(fn, '__name__', fn)} returned {rc}")
 
-    def backward(self, tape, dloss=None, dpred=None):
+    def _backward_step(self, tape, dloss=None, dpred=None):
         """Accumulates every parameter gradient into the gradient arena (+=).  dloss: [1] cuda tensor or None (=1)."""
         ent = tape.get("_ent")
         if ent is None:
@@ -1010,6 +1060,23 @@ class ScOTEngine:
         p = cfg.patch_size
         gh, gw = self.grid
         C0, L0 = cfg.embed_dim, gh * gw
+        # gradient scale of the fp16 build (1.0 otherwise): gradients already in the arena are brought to the same scale first
+        S = self._grad_scale(B * Cout * H * W)
+        if S != 1.0:
+            def prescale():
+                if not self.grads_are_zero:
+                    ops.scale_inplace(self.arena.grad, S)
+            self.tdo_dynamic(prescale)
+            if dpred is not None:
+                dpred = self.clone(dpred.contiguous())
+                ops.scale_inplace(dpred.view(-1), S)
+            if hd["labels"] is not None:
+                dl_in = dloss
+                dloss = self.new(1)
+                if dl_in is None:
+                    self.tdo(lambda: dloss.fill_(S))
+                else:
+                    self.tdo(lambda: torch.mul(dl_in.reshape(1), S, out=dloss))
         # loss → d pred
         if hd["labels"] is not None:
             g_pred = self.new(B, Cout, H, W)
@@ -1036,8 +1103,13 @@ class ScOTEngine:
         g = self.new(B * L0, C0)
         ops.gemm(ops.NT, self.tcm, B * L0, C0, Cout * p * p, d_rc, Cout * p * p, wrec, Cout * p * p, g, C0)
         if self.on_grads_final is not None:
+            from .dp import group_ranges
+
             def done(prefix, _cb=self.on_grads_final):
                 self.join_side()   # the range's weight gradients (side stream) must be complete before its all-reduce
+                if S != 1.0:       # ... and back at scale 1
+                    for _, lo, hi in group_ranges(self.arena, [prefix]):
+                        ops.scale_inplace(self.arena.grad[lo:hi], 1.0 / S, self.grad_overflow)
                 self.tdo(lambda: _cb(prefix))
         else:
             def done(prefix):
@@ -1099,5 +1171,7 @@ class ScOTEngine:
         self.wgrad(self.tcm, d_e, emb["cols"], self.G("embeddings.patch_embeddings.projection.weight").view(C0, Cin * p * p),
                    dbias=self.G("embeddings.patch_embeddings.projection.bias"))
         self.join_side()
+        if S != 1.0 and self.on_grads_final is None:
+            ops.scale_inplace(self.arena.grad, 1.0 / S, self.grad_overflow)
         self.mark("end")
         done("embeddings.")

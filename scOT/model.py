@@ -324,6 +324,7 @@ class ScOT(nn.Module):
             return
         if ps[first].grad is None or ps[first].grad.data_ptr() != self._gviews[first].data_ptr():
             self._arena.grad.zero_()
+            self._engine.grads_are_zero = True
             for p, g in zip(ps, self._gviews):
                 p.grad = g if p.requires_grad else None
 
@@ -338,6 +339,7 @@ class ScOT(nn.Module):
     def zero_grad(self, set_to_none: bool = False):
         if self._arena is not None:
             self._arena.grad.zero_()
+            self._engine.grads_are_zero = True
             if set_to_none:
                 for p in self._params:
                     p.grad = None

@@ -14,7 +14,7 @@ CLANG = os.environ.get("HIPEMU_CXX", "/opt/rocm/lib/llvm/bin/clang++")
 DYN = re.compile(r"extern\s+__shared__\s+(?:__attribute__\(\(aligned\(\d+\)\)\)\s+)?(\w+)\s+(\w+)\[\];")
 
 
-def build(out_dir: str, sanitize: str = "", opt: str = "-O1") -> str:
+def build(out_dir: str, sanitize: str = "", opt: str = "-O1", defines=()) -> str:
     src_dir = os.path.join(out_dir, "src")
     os.makedirs(src_dir, exist_ok=True)
     units = []
@@ -27,7 +27,7 @@ def build(out_dir: str, sanitize: str = "", opt: str = "-O1") -> str:
         if dst.endswith(".hip"):
             units.append(dst)
     flags = [CLANG, "-x", "c++", "-std=c++20", opt, "-g", "-fPIC", "-pthread", "-I", HERE, "-I", src_dir, "-Wno-unused-value",
-             "-Wno-unknown-attributes"] + ([f"-fsanitize={sanitize}"] if sanitize else [])
+             "-Wno-unknown-attributes"] + [f"-D{d}" for d in defines] + ([f"-fsanitize={sanitize}"] if sanitize else [])
     if sanitize or os.environ.get("HIPEMU_THREADS") == "1":
         flags.append("-DHIPEMU_THREADS")     # work-items as OS threads: what the sanitizers can reason about
 
@@ -47,21 +47,24 @@ def build(out_dir: str, sanitize: str = "", opt: str = "-O1") -> str:
     return lib
 
 
-def build_cached(sanitize: str = "") -> str:
-    """Build under tests/hipemu/_build/<hash of sources + shim + flags> (git-ignored) and reuse it while nothing changed."""
+def build_cached(sanitize: str = "", kind: str = "bf16") -> str:
+    """Build under tests/hipemu/_build/<hash of sources + shim + flags> (git-ignored) and reuse it while nothing changed.
+    kind = "f16": the -DSCOT_OPERAND_FP16 build (libscot_hip_f16.so's twin)."""
     import hashlib
     h = hashlib.sha256()
     for path in sorted(glob.glob(os.path.join(CSRC, "*.h")) + glob.glob(os.path.join(CSRC, "*.hip")) +
                        [os.path.join(HERE, "hip", "hip_runtime.h"), os.path.abspath(__file__)]):
         h.update(open(path, "rb").read())
     h.update(sanitize.encode())
-    out = os.path.join(HERE, "_build", h.hexdigest()[:16])
+    gen = os.path.join(HERE, "_build", h.hexdigest()[:16])
+    out = os.path.join(gen, kind)
     lib = os.path.join(out, "libscot_emu.so")
     if os.path.exists(lib):
         return lib
-    import shutil
-    shutil.rmtree(os.path.join(HERE, "_build"), ignore_errors=True)   # one generation only
-    return build(out, sanitize=sanitize)
+    if not os.path.isdir(gen):
+        import shutil
+        shutil.rmtree(os.path.join(HERE, "_build"), ignore_errors=True)   # one generation only
+    return build(out, sanitize=sanitize, defines=("SCOT_OPERAND_FP16",) if kind == "f16" else ())
 
 
 if __name__ == "__main__":

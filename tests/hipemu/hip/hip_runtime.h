@@ -211,6 +211,30 @@ inline emu_f32x4 emu_mfma_f32_16x16x32_bf16(emu_bf16x8 a, emu_bf16x8 b, emu_f32x
 }
 #define __builtin_amdgcn_mfma_f32_16x16x32_bf16 emu_mfma_f32_16x16x32_bf16
 
+// v_mfma_f32_16x16x32_f16: same operand layout, IEEE binary16 elements (the -DSCOT_OPERAND_FP16 build of the kernels)
+typedef _Float16 emu_f16x8 __attribute__((ext_vector_type(8)));
+inline emu_f32x4 emu_mfma_f32_16x16x32_f16(emu_f16x8 a, emu_f16x8 b, emu_f32x4 c, int, int, int) {
+  auto& w = hipemu::wave();
+  const int l = hipemu::lane(), g = l >> 4, lc = l & 15;
+  std::memcpy(w.a[l], &a, 16);
+  std::memcpy(w.b[l], &b, 16);
+  w.bar.arrive_and_wait();
+  emu_f32x4 d = c;
+  for (int r = 0; r < 4; ++r) {
+    const int row = 4 * g + r;
+    float s = c[r];
+    for (int gg = 0; gg < 4; ++gg) {
+      const _Float16* pa = (const _Float16*)w.a[gg * 16 + row];
+      const _Float16* pb = (const _Float16*)w.b[gg * 16 + lc];
+      for (int j = 0; j < 8; ++j) s += (float)pa[j] * (float)pb[j];
+    }
+    d[r] = s;
+  }
+  w.bar.arrive_and_wait();
+  return d;
+}
+#define __builtin_amdgcn_mfma_f32_16x16x32_f16 emu_mfma_f32_16x16x32_f16
+
 // v_mfma_f32_16x16x4_f32: A lane (r, g) holds A[r][k = g], B lane (r, g) holds B[k = g][r]
 inline emu_f32x4 emu_mfma_f32_16x16x4f32(float a, float b, emu_f32x4 c, int, int, int) {
   auto& w = hipemu::wave();
@@ -277,6 +301,7 @@ inline float atomicAdd(float* p, float v) {
   while (!r.compare_exchange_weak(old, old + v)) {}
   return old;
 }
+inline int atomicAdd(int* p, int v) { return std::atomic_ref<int>(*p).fetch_add(v); }
 inline double atomicAdd(double* p, double v) {
   std::atomic_ref<double> r(*p);
   double old = r.load();

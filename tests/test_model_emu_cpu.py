@@ -81,14 +81,44 @@ def test_engine_fp32_vs_reference_fixture(emu, name):
     assert grads_global(model, f) < 1e-4
 
 
-@pytest.mark.parametrize("compute,tol_out,tol_grad", [("bf16", 5e-2, 0.7), ("bf16x3", 1e-4, 2e-3)])
+@pytest.mark.parametrize("compute,tol_out,tol_grad", [("bf16", 5e-2, 0.7), ("bf16x3", 1e-4, 2e-3), ("fp16", 5e-3, 5e-2)])
 def test_engine_reduced_precision_modes(emu, compute, tol_out, tol_grad):
+    """The 16-dim tiny model is ~4x more sensitive to operand rounding than Poseidon-T/B (contractions of length 16): fp16 gives
+    3e-3 here exactly as tools/probes/precision_sim.py predicts (bf16: 2e-2), and 7e-4..8e-4 on T/B, where the north star's 1e-3
+    is asserted (tests/test_model_gpu.py)."""
     f, meta = load_fixture("tiny_trained")
     cfg = ScOTConfig(**meta["cfg"])
     pv, t, lab, pm = fixture_inputs(meta, cfg)
     model, loss, pred = run_engine(cfg, synth_state_dict(param_shapes(cfg), meta["regime"]), pv, t, lab, pm, compute)
+    print(f"\n[{compute}] out {rel_l2(pred.numpy(), f['output']):.2e} grads {grads_global(model, f):.2e}")
     assert rel_l2(pred.numpy(), f["output"]) < tol_out
     assert grads_global(model, f) < tol_grad
+    if compute == "fp16":   # the backward ran under the power-of-two gradient scale and came back exactly, without overflow
+        assert model._engine.scale_grads and int(model._engine.grad_overflow) == 0
+
+
+def test_engine_fp16_gradient_scale_accumulates(emu):
+    """fp16 build: two backwards into the same gradient arena (gradient accumulation) — the second one finds a non-zero arena,
+    brings it to the backward's scale first and both contributions come back at scale 1: grads == 2 x the single-step grads."""
+    f, meta = load_fixture("tiny_trained")
+    cfg = ScOTConfig(**meta["cfg"])
+    pv, t, lab, pm = fixture_inputs(meta, cfg)
+    from scOT.model import ScOT
+    model = ScOT(cfg, compute="fp16")
+    model.load_state_dict(synth_state_dict(param_shapes(cfg), meta["regime"]))
+    model._ensure_arena(torch.device("cpu"))
+    eng = model._engine
+    model._prepare_grads()
+    assert eng.grads_are_zero
+    _, _, tp = eng.forward(pv, t, lab, pm, train=True)
+    eng.backward(tp, torch.ones(1), None)
+    g1 = model._arena.grad.clone()
+    assert not eng.grads_are_zero
+    _, _, tp = eng.forward(pv, t, lab, pm, train=True)
+    eng.backward(tp, torch.ones(1), None)
+    assert rel_l2(model._arena.grad.numpy(), 2.0 * g1.numpy()) < 1e-6
+    assert grads_global(model, f) > 0.5          # i.e. really 2x, not 1x
+    assert int(eng.grad_overflow) == 0
 
 
 def test_engine_window16_fast_path(emu):

@@ -109,7 +109,8 @@ def test_bf16_vs_reference_fixture(name):
 @pytest.mark.parametrize("name,compute", [("poseidonT_trained", "fp32"), ("poseidonT_hf", "fp32"), ("poseidonT_trained", "bf16"),
                                           ("poseidonT_hf", "bf16"), ("poseidonB_trained", "fp32"), ("poseidonB_trained", "bf16"),
                                           ("poseidonB_hf", "bf16"), ("poseidonT_trained", "bf16x3"), ("poseidonT_hf", "bf16x3"),
-                                          ("poseidonB_trained", "bf16x3")])
+                                          ("poseidonB_trained", "bf16x3"), ("poseidonT_trained", "fp16"), ("poseidonT_hf", "fp16"),
+                                          ("poseidonB_trained", "fp16"), ("poseidonB_hf", "fp16")])
 def test_poseidon_presets(name, compute):
     f, meta = load_fixture(name)
     cfg, model = build(meta, compute)
@@ -128,6 +129,14 @@ def test_poseidon_presets(name, compute):
         assert e_loss < 2e-5
         assert np.median(dev) < 1e-4
         grads_report(model, f, tol_each=1e-3, tol_global=1e-3)
+    elif compute == "fp16":
+        # THE north-star bound for 16-bit operands: 1e-3 output rel-L2 on both parameter regimes (binary16 operands, fp32
+        # accumulation / statistics / residual stream; predicted 7.1e-4..7.9e-4 trained-like, 1.7e-4 HF-init by
+        # tools/probes/precision_sim.py).  Gradients: the backward runs under a power-of-two gradient scale, no overflow.
+        assert e_out < 1e-3 and e_loss < 1e-3
+        assert int(model._engine.grad_overflow) == 0
+        assert np.median(dev) < 5e-3
+        grads_report(model, f, tol_each=1e9, tol_global=0.1, floor=1e-6, skip=("logit_scale",))
     elif compute == "bf16x3":
         # fp32 operands split into hi + lo bf16 (three bf16 MFMAs per product): the north star's 1e-3 bound for the bf16 path,
         # with margin — on BOTH parameter regimes

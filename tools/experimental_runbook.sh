@@ -24,6 +24,6 @@ b c192_only SCOT_FUSED_MLP=1 SCOT_FUSED_C=192
 b mlp_only SCOT_FUSED_MLP=1 SCOT_FUSED_PARTS=mlp_fwd,mlp_bwd
 b proj_only SCOT_FUSED_MLP=1 SCOT_FUSED_PARTS=proj_fwd,proj_bwd
 echo "== 4. per-kernel times with the flag on (rocprofv3 kernel trace)" | tee -a $out/summary.txt
-(cd /tmp && export TMPDIR=/tmp && SCOT_FUSED_MLP=1 timeout 300 rocprofv3 --kernel-trace --stats -d $OLDPWD/$out/prof -o fused -- python $OLDPWD/bench.py --steps 5 --warmup 2 --no-cpu-baseline > $OLDPWD/$out/prof.log 2>&1)
+(cd /tmp && export TMPDIR=/tmp && SCOT_FUSED_MLP=1 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OLDPWD/$out/prof -o fused -- python $OLDPWD/bench.py --steps 5 --warmup 2 --no-cpu-baseline > $OLDPWD/$out/prof.log 2>&1)
 f=$(ls $out/prof/*/*kernel_stats.csv $out/prof/*kernel_stats.csv 2>/dev/null | head -1)
 [ -n "$f" ] && head -25 "$f" | cut -c1-200 | tee -a $out/summary.txt
