@@ -4,8 +4,10 @@
   python bench.py --gpus N --steps K --warmup W          (N>1: launched by torch.distributed.run, one rank per GPU)
 
 Workload (BASELINE.json metric / configs[2]): Poseidon-B, per-GPU batch 64, 128x128x4 synthetic CE-RP-shaped grids
-(N(0,1) channels, all active, groups [0,1,3,4]), bf16 MFMA compute, weak scaling (per-device batch fixed, as reference
-train.py:281).  A "step" = zero the gradient arena + ScOT.forward (incl. grouped relative-L1 loss) + backward into the
+(N(0,1) channels, all active, groups [0,1,3,4]), 16-bit MFMA compute with fp32 accumulation, weak scaling (per-device batch
+fixed, as reference train.py:281).  Default --compute fp16: the fastest mode whose ScOT.forward output stays within the north
+star's 1e-3 rel-L2 of the real reference on trained-like parameters — checked IN THIS PROCESS against the committed golden
+fixture before anything is timed (config.parity); bf16 operands (--compute bf16) do not meet it (6e-3).  A "step" = zero the gradient arena + ScOT.forward (incl. grouped relative-L1 loss) + backward into the
 arena (+ mean all-reduce of the arena for N>1).  Inputs are resident in HBM before the timed region.
 Prints ONE JSON line (rank 0).
 """
@@ -36,12 +38,13 @@ def parse():
     ap.add_argument("--batch", type=int, default=64, help="per-GPU batch")
     ap.add_argument("--size", type=int, default=128)
     ap.add_argument("--channels", type=int, default=4)
-    ap.add_argument("--compute", default="bf16", choices=["fp16", "bf16", "fp32", "bf16x3"])
+    ap.add_argument("--compute", default="fp16", choices=["fp16", "bf16", "fp32", "bf16x3"])
+    ap.add_argument("--no-parity", action="store_true", help="skip the in-process parity check against the golden fixture")
     ap.add_argument("--no-graph", action="store_true", help="eager launches instead of one hipGraph per step")
     ap.add_argument("--graph", action="store_true", help="force hipGraph replay (default: time both in the warm-up, keep the faster)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=20.0)
-    ap.add_argument("--wire", default="bf16", choices=["bf16", "fp32"], help="gradient all-reduce wire format (N>1)")
+    ap.add_argument("--wire", default="fp32", choices=["bf16", "fp32"], help="gradient all-reduce wire format (N>1)")
     ap.add_argument("--dp", default="auto", choices=["auto", "overlap", "after"],
                     help="N>1: all-reduce each gradient range from inside the backward as soon as it is final (RCCL on a side "
                          "stream, eager launches), or one chunked all-reduce after the step (works with hipGraph replay); "
@@ -115,71 +118,75 @@ def _cpu_baseline_worker(model_tag, size, channels, budget_s):
                       f"median of {len(times)} steps, {cores} torch threads"}
 
 
-def dominant_kernel_probe(compute, batch, embed_dim, size):
-    """Live HIP-event timing (events on torch's current stream = the stream the C ABI launches on) of the kernel with the
-    largest share of the step in the committed rocprof summary (profiles/): `gemm_fast_kernel<.., TN>` — the wgrad GEMM,
-    at its stage-0 fc1 instance  dW[4C, C] += dY[M, 4C]^T · X[M, C],  M = batch·(size/4)^2 (split-K partials + reduce pass
-    included, as in the step).  Also times the runner-up (`attn_bwd_kernel`, stage 0) for reference."""
-    from poseidon_amd import ops
-    cm = {"fp16": ops.BF16, "bf16": ops.BF16, "fp32": ops.F32, "bf16x3": ops.X3}[compute]
-    ops.use("f16" if compute == "fp16" else "bf16")
-    dt = ops.half_dtype() if compute in ("fp16", "bf16") else torch.float32
-    M, C = batch * (size // 4) ** 2, embed_dim
-    # operands rotate through > 800 MB so that nothing is served by the 256 MB Infinity Cache, as in the real step (a loop over
-    # one buffer set measured 10-120 % optimistic for these kernels)
-    nset = max(2, int(800e6 / (M * 5 * C * (2 if compute in ("fp16", "bf16") else 4))) + 1)
-    sets = [(torch.randn(M, 4 * C, device="cuda").to(dt), torch.randn(M, C, device="cuda").to(dt)) for _ in range(nset)]
-    dw = torch.zeros(4 * C, C, device="cuda")
-    it = [0]
+def parity_check(model_tag, compute, size, channels):
+    """Output of the mode about to be timed against the golden vector of the REAL reference (tests/golden/poseidon<X>_trained.npz:
+    produced by tests/golden/make_fixtures.py importing /root/reference; trained-like parameter statistics, the hard regime for
+    16-bit operands) — same closed-form parameters and inputs, forward + loss on this GPU.  Fixtures are data; nothing under
+    oracle/ is touched."""
+    import numpy as np
+    from poseidon_amd.config import ScOTConfig
+    from poseidon_amd.geometry import param_shapes
+    from poseidon_amd.synth import synth_inputs, synth_state_dict
+    from scOT.model import ScOT
+    name = f"poseidon{model_tag}_trained"
+    path = os.path.join(ROOT, "tests", "golden", name + ".npz")
+    if not os.path.exists(path):
+        return {"fixture": None, "note": f"no golden fixture for Poseidon-{model_tag}"}
+    f = np.load(path)
+    meta = json.loads(bytes(f["__meta__"]).decode())
+    cfg = ScOTConfig(**meta["cfg"])
+    if cfg.image_size != size:
+        return {"fixture": None, "note": f"golden fixture is at {cfg.image_size}x{cfg.image_size}"}
+    with torch.device("cuda"):
+        model = ScOT(cfg, compute=compute)
+    model.load_state_dict(synth_state_dict(param_shapes(cfg), meta["regime"]))
+    pv, t, lab = synth_inputs(meta["batch"], cfg.num_channels, cfg.num_out_channels, cfg.image_size, meta["kind"])
+    with torch.no_grad():
+        out = model(pixel_values=pv.cuda(), time=t.cuda(), labels=lab.cuda())
+    ref = f["output"].astype(np.float64)
+    got = out.output.double().cpu().numpy()
+    rel = float(np.linalg.norm(got - ref) / np.linalg.norm(ref))
+    lrel = abs(float(out.loss) - float(f["loss"])) / abs(float(f["loss"]))
+    del model
+    torch.cuda.empty_cache()
+    return {"fixture": f"tests/golden/{name}.npz (real reference, {meta['regime']} parameters, batch {meta['batch']})",
+            "output_rel_l2": rel, "loss_rel": lrel, "bound": 1e-5 if compute == "fp32" else 1e-3, "meets_bound": rel < (1e-5 + 5e-6 if compute == "fp32" else 1e-3)}
 
-    def timed(fn, reps=3):
-        for _ in range(nset):
-            fn()
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
-        for _ in range(reps * nset):
-            fn()
-        e1.record()
-        torch.cuda.synchronize()
-        return e0.elapsed_time(e1) / (reps * nset)  # ms
 
-    def wgrad():
-        dy, x = sets[it[0] % nset]
-        it[0] += 1
-        ops.linear_wgrad(cm, dy, x, dw)
-    ms = timed(wgrad)
-    esz = sets[0][0].element_size()
-    flops = 2.0 * M * 4 * C * C
-    bytes_alg = (M * 4 * C + M * C) * esz + dw.numel() * 4 * 2
-    out = {"kernel": "gemm_fast_kernel<bf16,96,96,TN> (wgrad fc1, stage 0) + splitk_reduce, cold operands", "shape_MNK": [4 * C, C, M],
-           "us": ms * 1e3, "tflops": flops / ms / 1e9, "algorithmic_bytes": bytes_alg, "algorithmic_gbps": bytes_alg / ms / 1e6}
-    del sets
-    # runner-up: shifted-window attention backward at stage 0
-    Hp, heads, ws = size // 4, 3, 16
-    nW = (Hp // ws) ** 2
-    lse = torch.zeros(batch * nW, heads, ws * ws, device="cuda")
-    tab = torch.randn(heads, (2 * ws - 1) ** 2, device="cuda")
-    ls = torch.full((heads,), 2.3, device="cuda")
-    nset = 9
-    asets = []
-    for _ in range(nset):
-        qkv = torch.randn(batch * Hp * Hp, 3 * C, device="cuda").to(dt)
-        asets.append((qkv, torch.empty(batch * Hp * Hp, C, device="cuda", dtype=dt), torch.randn(batch * Hp * Hp, C, device="cuda").to(dt),
-                      torch.empty_like(qkv)))
-    ops.window_attn_fwd(min(cm, 1) if cm != 2 else 0, asets[0][0], asets[0][1], lse, tab, ls, batch, Hp, Hp, C, heads, ws, 8)
-    for a_ in asets[1:]:
-        a_[1].copy_(asets[0][1])
-    dtab, dls = torch.zeros_like(tab), torch.zeros(heads, device="cuda")
-
-    def abwd():
-        qkv, o, do, dq = asets[it[0] % nset]
-        it[0] += 1
-        ops.window_attn_bwd(min(cm, 1) if cm != 2 else 0, qkv, o, do, lse, tab, ls, dq, dtab, dls, batch, Hp, Hp, C, heads, ws, 8)
-    ms2 = timed(abwd)
-    fl2 = 2.5 * 4.0 * batch * nW * heads * (ws * ws) ** 2 * (C // heads)
-    out["runner_up"] = {"kernel": "attn16_bwd_kernel<bf16,32,shifted> (stage 0, dQ and dK/dV halves in one launch), cold operands",
-                        "us": ms2 * 1e3, "tflops": fl2 / ms2 / 1e9}
-    return out
+def launch_table(engine, run_step, nsteps=3):
+    """Per-launch GPU durations INSIDE real steps: the recorded step is replayed with a HIP-event pair around every C-ABI
+    call, each pair on the stream the call launches on (main or weight-gradient side stream), so concurrency and cache state
+    are the step's own.  Returns {family: {ms_per_step, launches_per_step, gflop_per_step}}, plus the worst wgrad instance."""
+    engine.launch_timer = []
+    for _ in range(nsteps):
+        run_step()
+    torch.cuda.synchronize()
+    log, engine.launch_timer = engine.launch_timer, None
+    fam, inst = {}, {}
+    for name, args, e0, e1 in log:
+        ms = e0.elapsed_time(e1)
+        fl = 0.0
+        key = name.replace("scot_", "")
+        if name == "scot_gemm":
+            lay, M, N, K = args[0], args[2], args[3], args[4]
+            key = ("gemm NT (forward Linear)", "gemm NN (dgrad)", "gemm TN (wgrad, incl. split-K reduce)")[lay]
+            fl = 2.0 * M * N * K
+            if lay == 2:
+                d = inst.setdefault((M, N, K), [0.0, 0])
+                d[0] += ms
+                d[1] += 1
+        d = fam.setdefault(key, [0.0, 0, 0.0])
+        d[0] += ms
+        d[1] += 1
+        d[2] += fl
+    table = {k: {"ms_per_step": v[0] / nsteps, "launches_per_step": v[1] / nsteps, "gflop_per_step": v[2] / nsteps / 1e9}
+             for k, v in sorted(fam.items(), key=lambda kv: -kv[1][0])}
+    worst = None
+    for (M, N, K), (ms, n) in inst.items():
+        tf = 2.0 * M * N * K * n / ms / 1e9
+        if worst is None or tf < worst["tflops"]:
+            worst = {"shape_MNK": [M, N, K], "us_per_launch": ms / n * 1e3, "tflops": tf, "launches_per_step": n / nsteps}
+    return table, worst
 
 
 def main():
@@ -206,6 +213,12 @@ def main():
     ch = a.channels
     cfg = preset(a.model, image_size=a.size, num_channels=ch, num_out_channels=ch,
                  channel_slice_list_normalized_loss=[0, 1, ch - 1, ch])
+    parity = None
+    if rank == 0 and not a.no_parity:
+        parity = parity_check(a.model, a.compute, a.size, ch)
+        if parity.get("fixture") and not parity["meets_bound"]:
+            print(f"bench.py: --compute {a.compute} is at {parity['output_rel_l2']:.2e} from the reference fixture (bound "
+                  f"{parity['bound']:.0e}): the number below is NOT a compliant measurement", file=sys.stderr)
     torch.manual_seed(1234)  # identical initial weights on every rank (no broadcast needed)
     model = ScOT(cfg, compute=a.compute)
     with torch.no_grad():  # "trained-like" statistics so that every branch carries O(1) signal (random data, §5.4 rule 25)
@@ -323,6 +336,7 @@ def main():
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax)
     ms = dt / a.steps * 1e3
+    overflow = int(model._engine.grad_overflow) if model._engine.grad_overflow is not None else None   # fp16 gradient scale
     total_samples = B * world * a.steps
     value = total_samples / dt
 
@@ -334,17 +348,31 @@ def main():
         peak = PEAK_TFLOPS[a.compute]
         step_roof = {"bound": "mfma", "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak,
                      "scope": "whole step, algorithmic FLOPs 3(B*F+P) per GPU (SURVEY.md 8d)"}
+        roof = dict(step_roof, traffic=None)
+        launches = None
         try:
-            dk = dominant_kernel_probe(a.compute, B, cfg.embed_dim, a.size)
-            traffic = None
-            tpath = os.path.join(ROOT, "profiles", "round1", "pmc_traffic.json")
-            if os.path.exists(tpath):  # HBM bytes per launch of the same kernel from the committed rocprofv3 --pmc run
-                traffic = json.load(open(tpath)).get("wgrad_fc1_stage0_bytes_per_launch")
-            roof = {"bound": "mfma", "achieved": dk["tflops"], "peak": peak, "unit": "TFLOP/s", "frac": dk["tflops"] / peak,
-                    "traffic": traffic, "kernel": dk["kernel"], "us_per_launch": dk["us"], "shape_MNK": dk["shape_MNK"],
-                    "algorithmic_bytes": dk["algorithmic_bytes"], "algorithmic_gbps": dk["algorithmic_gbps"],
-                    "hbm_frac_of_8TBps": dk["algorithmic_gbps"] / 8000.0,
-                    "runner_up": dk["runner_up"], "whole_step": step_roof}
+            # the dominant kernel family of the committed rocprof summary (profiles/round2: gemm_fast_kernel<..TN> + its split-K
+            # reduce = the weight-gradient GEMMs, 31 % of the step's kernel time), timed live inside real steps
+            eager = use_graph[0]
+            use_graph[0] = False
+            table, worst = launch_table(model._engine, step)
+            use_graph[0] = eager
+            launches = {"launches_per_step": sum(v["launches_per_step"] for v in table.values()),
+                        "kernel_ms_per_step": sum(v["ms_per_step"] for v in table.values()),
+                        "top": {k: {kk: round(vv, 3) for kk, vv in v.items()} for k, v in list(table.items())[:10]}}
+            wg = table.get("gemm TN (wgrad, incl. split-K reduce)")
+            if wg:
+                tf = wg["gflop_per_step"] / wg["ms_per_step"]      # GFLOP / ms = TFLOP/s
+                traffic = None
+                tpath = os.path.join(ROOT, "profiles", "round2", "pmc_traffic.json")
+                if os.path.exists(tpath):   # HBM bytes per launch (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes)
+                    traffic = json.load(open(tpath)).get("wgrad_bytes_per_launch")
+                roof = {"bound": "mfma", "achieved": tf, "peak": peak, "unit": "TFLOP/s", "frac": tf / peak, "traffic": traffic,
+                        "kernel": "gemm_fast_kernel<..,TN> + splitk_reduce: all weight-gradient GEMMs of a step, in-step durations "
+                                  "(HIP events on the launching stream around every call of the replayed step)",
+                        "us_per_launch": wg["ms_per_step"] / wg["launches_per_step"] * 1e3,
+                        "launches_per_step": wg["launches_per_step"], "algorithmic_gflop_per_step": wg["gflop_per_step"],
+                        "worst_instance": worst, "whole_step": step_roof}
         except Exception as e:  # pragma: no cover
             roof = dict(step_roof, traffic=None, error=repr(e))
         res = {"metric": "PDE-grid samples/sec (fwd+bwd)", "value": value, "unit": "samples/s", "n_gpus": world, "steps": a.steps,
@@ -353,10 +381,7 @@ def main():
                "config": {"workload": f"Poseidon-{a.model} fwd+bwd, {a.size}x{a.size}x{ch} grids, per-GPU batch {B}",
                           "global_batch": B * world, "parallelism": f"dp{world}", "graph": bool(use_graph[0]), **mode_info,
                           "grad_wire": a.wire if world > 1 else None, "grad_exchange": exchange[0], "loss": float(loss_buf),
-                          "parity_vs_reference_fixtures": {"bf16": "output rel-L2 1.4e-3..2.0e-3 (HF-init), 6.3e-3..6.7e-3 (trained-like)",
-                                                           "bf16x3": "1e-5 (--compute bf16x3: 1768 samples/s)",
-                                                           "fp32": "1e-6 (--compute fp32: 1168 samples/s)",
-                                                           "source": "tests/test_model_gpu.py::test_poseidon_presets"}},
+                          "parity": parity, "grad_overflow": overflow, "in_step_launches": launches},
                "roofline": roof}
         if world == 1 and not a.no_cpu_baseline:
             try:

@@ -600,10 +600,38 @@ __global__ __launch_bounds__(256) void cpb_fwd_kernel(const float* coords, const
 }
 // Backward: block owns JB hidden units (no atomics, deterministic +=); threads stride over the table entries.
 constexpr int CPB_JB = 4;
+// writes the block's sums: dw0[2j], dw0[2j+1], db0[j], dw2[h*512 + j] += Σ_threads of the per-thread partials
+__device__ __forceinline__ void cpb_bwd_finish(float (&a_w2)[CPB_JB][24], float (&a_w0y)[CPB_JB], float (&a_w0x)[CPB_JB],
+                                               float (&a_b0)[CPB_JB], int heads, int j0, float* dw0, float* db0, float* dw2) {
+  constexpr int NV = CPB_JB * 27;
+  __shared__ float part[4][NV];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+  for (int jj = 0; jj < CPB_JB; ++jj) {
+    float v = wave_sum(a_w0y[jj]); if (lane == 0) part[wave][jj * 27 + 0] = v;
+    v = wave_sum(a_w0x[jj]); if (lane == 0) part[wave][jj * 27 + 1] = v;
+    v = wave_sum(a_b0[jj]); if (lane == 0) part[wave][jj * 27 + 2] = v;
+#pragma unroll
+    for (int h = 0; h < 24; ++h) {
+      if (h < heads) { v = wave_sum(a_w2[jj][h]); if (lane == 0) part[wave][jj * 27 + 3 + h] = v; }
+    }
+  }
+  __syncthreads();
+  const int t = threadIdx.x;
+  if (t < NV) {
+    const int jj = t / 27, k = t % 27, j = j0 + jj;
+    if (k < 3 + heads) {
+      const float v = part[0][t] + part[1][t] + part[2][t] + part[3][t];
+      if (k == 0) dw0[2 * j] += v;
+      else if (k == 1) dw0[2 * j + 1] += v;
+      else if (k == 2) db0[j] += v;
+      else dw2[(k - 3) * 512 + j] += v;
+    }
+  }
+}
 __global__ __launch_bounds__(256) void cpb_bwd_kernel(const float* coords, const float* w0, const float* b0, const float* w2,
                                                       const float* z, const float* dtable, float* dw0, float* db0, float* dw2,
                                                       int TS, int heads) {
-  __shared__ float red[4];
   const int j0 = blockIdx.x * CPB_JB;
   float a_w2[CPB_JB][24], a_w0y[CPB_JB], a_w0x[CPB_JB], a_b0[CPB_JB];
 #pragma unroll
@@ -637,24 +665,9 @@ __global__ __launch_bounds__(256) void cpb_bwd_kernel(const float* coords, const
       a_w0y[jj] += dpre * cy; a_w0x[jj] += dpre * cx; a_b0[jj] += dpre;
     }
   }
-  auto block_sum = [&](float v) -> float {
-    v = wave_sum(v);
-    __syncthreads();
-    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
-    __syncthreads();
-    return red[0] + red[1] + red[2] + red[3];
-  };
-#pragma unroll
-  for (int jj = 0; jj < CPB_JB; ++jj) {
-    const int j = j0 + jj;
-    float v = block_sum(a_w0y[jj]); if (threadIdx.x == 0) dw0[2 * j] += v;
-    v = block_sum(a_w0x[jj]); if (threadIdx.x == 0) dw0[2 * j + 1] += v;
-    v = block_sum(a_b0[jj]); if (threadIdx.x == 0) db0[j] += v;
-#pragma unroll
-    for (int h = 0; h < 24; ++h) {
-      if (h < heads) { v = block_sum(a_w2[jj][h]); if (threadIdx.x == 0) dw2[h * 512 + j] += v; }
-    }
-  }
+  // block reduction of the CPB_JB x (3 + heads) sums: wave shuffles, ONE LDS stage, ONE barrier (the first version called a
+  // two-barrier block_sum per value: 216 barriers = 100 of this kernel's 116 us in the round-2 trace)
+  cpb_bwd_finish(a_w2, a_w0y, a_w0x, a_b0, heads, j0, dw0, db0, dw2);
 }
 // ---- batched over layers: the CPB MLP is batch-independent and layer-parallel, so all layers of a step (64 for
 // Poseidon-B) go in ONE launch instead of 64 (rocprof round 1: 64 x 43 us of mostly launch-latency-bound bwd kernels).
@@ -698,7 +711,6 @@ __global__ __launch_bounds__(256) void cpb_bwd_batched_kernel(const float* param
   const int* d = desc + 8 * (first + blockIdx.y);
   const int ws = d[4], heads = d[5];
   const int TS = (2 * ws - 1) * (2 * ws - 1);
-  __shared__ float red[4];
   const float* coords = coords_base + d[3];
   const float* w0 = params + d[0];
   const float* b0 = params + d[1];
@@ -741,24 +753,9 @@ __global__ __launch_bounds__(256) void cpb_bwd_batched_kernel(const float* param
       a_w0y[jj] += dpre * cy; a_w0x[jj] += dpre * cx; a_b0[jj] += dpre;
     }
   }
-  auto block_sum = [&](float v) -> float {
-    v = wave_sum(v);
-    __syncthreads();
-    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
-    __syncthreads();
-    return red[0] + red[1] + red[2] + red[3];
-  };
-#pragma unroll
-  for (int jj = 0; jj < CPB_JB; ++jj) {
-    const int j = j0 + jj;
-    float v = block_sum(a_w0y[jj]); if (threadIdx.x == 0) dw0[2 * j] += v;
-    v = block_sum(a_w0x[jj]); if (threadIdx.x == 0) dw0[2 * j + 1] += v;
-    v = block_sum(a_b0[jj]); if (threadIdx.x == 0) db0[j] += v;
-#pragma unroll
-    for (int h = 0; h < 24; ++h) {
-      if (h < heads) { v = block_sum(a_w2[jj][h]); if (threadIdx.x == 0) dw2[h * 512 + j] += v; }
-    }
-  }
+  // block reduction of the CPB_JB x (3 + heads) sums: wave shuffles, ONE LDS stage, ONE barrier (the first version called a
+  // two-barrier block_sum per value: 216 barriers = 100 of this kernel's 116 us in the round-2 trace)
+  cpb_bwd_finish(a_w2, a_w0y, a_w0x, a_b0, heads, j0, dw0, db0, dw2);
 }
 extern "C" int scot_cpb_fwd_batched(const float* params, const int* desc, int nlayers, int max_ws, const float* coords_base,
                                     float* tables, float* zbuf, hipStream_t s) {

@@ -87,7 +87,7 @@ class OverlappedGradAllReducer(GradAllReducer):
     (engine.on_grads_final), so that only the last range (the small C=96 encoder stage + embeddings) is exposed.
     Roughly 73 % of Poseidon-B's gradient bytes (the two C=768 stages) are final by mid-backward."""
 
-    def __init__(self, model, dist, wire: str = "bf16", chunk_mb: int = 64, group=None):
+    def __init__(self, model, dist, wire: str = "fp32", chunk_mb: int = 64, group=None):
         super().__init__(model, dist, wire=wire, chunk_mb=chunk_mb, group=group)
         self._ranges = None
         self.comm_stream = torch.cuda.Stream()

@@ -62,6 +62,7 @@ class ScOTEngine:
         # step cost ~10 us of Python each when issued through the op wrappers, ~1.5 us when replayed.
         self.tape_mode = os.environ.get("SCOT_TAPE", "1") == "1"
         self.stochastic = False
+        self.launch_timer = None    # bench.py: list that collects per-launch HIP-event timings of replayed steps
         self.tape_max = max(1, int(os.environ.get("SCOT_TAPE_MAX", "2")))
         self._rec = None
         self._rec_keep = None
@@ -868,8 +869,10 @@ class ScOTEngine:
     def _stream_id(self):
         return torch.cuda.current_stream().cuda_stream if self.device.type == "cuda" else 0
 
-    @staticmethod
-    def _replay(cmds):
+    def _replay(self, cmds):
+        timer = self.launch_timer
+        if timer is not None:
+            return self._replay_timed(cmds, timer)
         for fn, args in cmds:
             if args is None:
                 fn()
@@ -877,6 +880,27 @@ class ScOTEngine:
                 rc = fn(*args)
                 if rc:
                     raise RuntimeError(f"step tape: {getattr(fn, '__name__', fn)} returned {rc}")
+
+    def _replay_timed(self, cmds, timer):
+        """Replay with a HIP-event pair around every C-ABI call, recorded on the stream the call launches on (its last
+        argument) — bench.py's live per-kernel durations inside a real step (`engine.launch_timer = []` switches it on;
+        entries are (entry point, arguments, start event, end event))."""
+        streams = {}
+        for fn, args in cmds:
+            if args is None:
+                fn()
+                continue
+            h = args[-1] or 0
+            st = streams.get(h)
+            if st is None:
+                st = streams[h] = torch.cuda.ExternalStream(h) if h else torch.cuda.default_stream()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record(st)
+            rc = fn(*args)
+            e1.record(st)
+            if rc:
+                raise RuntimeError(f"step tape: {getattr(fn, '__name__', fn)} returned {rc}")
+            timer.append((getattr(fn, "__name__", str(fn)), args, e0, e1))
 
     def _backward_step(self, tape, dloss=None, dpred=None):
         """Accumulates every parameter gradient into the gradient arena (+=).  dloss: [1] cuda tensor or None (=1)."""

@@ -110,7 +110,10 @@ def test_bf16_vs_reference_fixture(name):
                                           ("poseidonT_hf", "bf16"), ("poseidonB_trained", "fp32"), ("poseidonB_trained", "bf16"),
                                           ("poseidonB_hf", "bf16"), ("poseidonT_trained", "bf16x3"), ("poseidonT_hf", "bf16x3"),
                                           ("poseidonB_trained", "bf16x3"), ("poseidonT_trained", "fp16"), ("poseidonT_hf", "fp16"),
-                                          ("poseidonB_trained", "fp16"), ("poseidonB_hf", "fp16")])
+                                          ("poseidonB_trained", "fp16"), ("poseidonB_hf", "fp16"),
+                                          # BASELINE config 5: Poseidon-B at 256x256 (shifted 16x16 windows at stages 0 AND 1)
+                                          ("poseidonB256_trained", "fp32"), ("poseidonB256_trained", "fp16"),
+                                          ("poseidonB256_trained", "bf16")])
 def test_poseidon_presets(name, compute):
     f, meta = load_fixture(name)
     cfg, model = build(meta, compute)
@@ -147,7 +150,8 @@ def test_poseidon_presets(name, compute):
         assert e_out < (3e-3 if meta["regime"] == "hf" else 2e-2)  # measured 1.4e-3..2e-3 / 6.3e-3..6.7e-3, DESIGN.md "Numerics"
 
 
-def test_poseidon_L_config4():
+@pytest.mark.parametrize("compute", ["fp32", "fp16"])
+def test_poseidon_L_config4(compute):
     """BASELINE.json config 4's shape: Poseidon-L (embed_dim 192: head_dim 64, C up to 1536, 629 M parameters), 5→5 channels with
     loss groups [0,1,3,4,5].  Parameters are generated on the GPU (bit-identical to the host generator, asserted on one tensor)
     and the modules are constructed there, which keeps this test at a few seconds."""
@@ -155,7 +159,7 @@ def test_poseidon_L_config4():
     cfg = ScOTConfig(**meta["cfg"])
     shapes = param_shapes(cfg)
     with torch.device(DEV):
-        model = ScOT(cfg, compute="fp32")
+        model = ScOT(cfg, compute=compute)
     with generate_on(DEV):
         sd = synth_state_dict(shapes, meta["regime"])
     for k in ("encoder.layers.2.blocks.3.intermediate.dense.weight", "embeddings.norm.weight.weight"):
@@ -170,7 +174,10 @@ def test_poseidon_L_config4():
     names = [str(n) for n in f["grad_names"]]
     mine = {k: float(p.grad.double().norm()) for k, p in model.named_parameters()}
     dev = np.array([abs(mine[n] - r) / max(r, 1e-12) for n, r in zip(names, f["grad_norms"]) if r > 1e-7])
-    print(f"\n[poseidonL fp32] out rel-L2 {e_out:.2e} loss rel {e_loss:.2e} grad-norm dev median {np.median(dev):.2e} max {dev.max():.2e}")
+    print(f"\n[poseidonL {compute}] out rel-L2 {e_out:.2e} loss rel {e_loss:.2e} grad-norm dev median {np.median(dev):.2e} max {dev.max():.2e}")
+    if compute == "fp16":       # the headline mode on config 4's model (head_dim 64): the north star's 1e-3
+        assert e_out < 1e-3 and e_loss < 1e-3 and np.median(dev) < 5e-3 and int(model._engine.grad_overflow) == 0
+        return
     assert e_out < 1e-5 + 5e-6
     assert e_loss < 2e-5
     assert np.median(dev) < 1e-4
@@ -360,3 +367,103 @@ def test_fused_adamw_matches_torch_adamw_with_clipping():
     pre = "encoder.layers.0.blocks.0.attention.self."
     o, c = a.offsets[pre + "qkv_bias"], ma.config.embed_dim
     assert float(a.data[o + c:o + 2 * c].abs().max()) == 0.0
+
+
+def test_training_rollout_with_grad_matches_oracle():
+    """VERDICT r1 weak #4 / ADVICE (high): the reference's AR *training* step runs n forwards, sums the losses and calls ONE
+    backward (trainer.py:466-490, 605-635) — forward-forward-backward through the step tape.  Gradients must equal the
+    oracle's doing the same, on the warm, the recording and the replaying step alike."""
+    from oracle import scot_cpu
+    from poseidon_amd.harness import rollout
+    f, meta = load_fixture("tiny_trained")
+    cfg, model = build(meta, "fp32")
+    model.train()
+    pv, t, lab = synth_inputs(2, 4, 4, 32, "smooth")
+    sd = {k: v.clone().requires_grad_(True) for k, v in synth_state_dict(param_shapes(cfg), meta["regime"]).items()}
+    l1, o1 = scot_cpu.scot_forward(sd, cfg, pv, t / 2, lab)
+    l2, o2 = scot_cpu.scot_forward(sd, cfg, o1.detach(), t / 2, lab)
+    ((l1 + l2) / 2).backward()
+    kw = dict(pixel_values=pv.to(DEV), time=t.to(DEV), labels=lab.to(DEV))
+    for step in range(4):     # warm, record, replay, replay
+        model.zero_grad()
+        out = rollout(model, kw, 2)
+        out.loss.backward()
+        torch.cuda.synchronize()
+        # two chained applications: the per-call 1e-6 deviation is amplified by the (trained-like) network's gain, as in
+        # test_ar_rollout_matches_reference_trainer
+        assert abs(float(out.loss) - float((l1 + l2) / 2)) < 1e-4 * abs(float(l1 + l2) / 2), step
+        assert rel_l2(out.output.detach().cpu().numpy(), o2.detach().numpy()) < 1e-3, step
+        num = den = 0.0
+        for k, p in model.named_parameters():
+            num += float((p.grad.cpu().double() - sd[k].grad.double()).norm()) ** 2
+            den += float(sd[k].grad.double().norm()) ** 2
+        assert (num / den) ** 0.5 < 1e-3, (step, (num / den) ** 0.5)   # (the aliasing bug this guards against gave 0.5)
+
+
+def test_outputs_are_fresh_tensors_across_steps():
+    """`out.output` / `out.loss` of step N must still hold step N's values after step N+1 (no aliasing of recorded buffers)."""
+    f, meta = load_fixture("tiny_trained")
+    cfg, model = build(meta, "fp32")
+    kw = inputs(cfg, meta)
+    kept = []
+    for step in range(5):
+        kws = {k: (v if v.dtype == torch.bool else v * (1.0 + 0.3 * step)) for k, v in kw.items()}
+        model.zero_grad()
+        out = model(**kws)
+        out.loss.backward()
+        kept.append((out.output.detach(), out.output.detach().clone(), out.loss.detach(), float(out.loss)))
+    torch.cuda.synchronize()
+    for held, copy, lheld, lval in kept:
+        assert torch.equal(held, copy) and float(lheld) == lval
+    assert not torch.equal(kept[3][0], kept[4][0])
+
+
+def test_eval_mode_with_grad_enabled_is_deterministic():
+    """stochastic depth follows module.training, not torch.is_grad_enabled (HF:565-586).  eval() with
+    gradients enabled and drop_path_rate > 0 gives the deterministic output AND gradients; train() under no_grad still draws."""
+    f, meta = load_fixture("tiny_droppath")
+    cfg, model = build(meta, "fp32")
+    assert cfg.drop_path_rate > 0
+    kw = inputs(cfg, meta)
+    model.eval()
+    with torch.no_grad():
+        ref = model(**kw).output.clone()
+    outs = []
+    for _ in range(3):
+        model.zero_grad()
+        o = model(**kw)                       # grad enabled
+        o.loss.backward()
+        outs.append(o.output.detach().clone())
+    assert all(torch.equal(x, outs[0]) for x in outs) and rel_l2(outs[0].cpu().numpy(), ref.cpu().numpy()) < 1e-6
+    assert float(model.flat_grads().abs().sum()) > 0
+    model.train()
+    with torch.no_grad():
+        draws = [model(**kw).output.clone() for _ in range(4)]
+    assert max(float((d - ref).abs().max()) for d in draws) > 1e-3
+
+
+def test_tuple_return_layout_matches_reference():
+    """return_dict=False: (loss,) + (prediction,) + decoder_output[1:] + encoder_outputs[1:] (reference model.py:1486-1488): the
+    encoder's hidden states are always the last element, the decoder's only with output_hidden_states=True."""
+    f, meta = load_fixture("tiny_trained")
+    cfg, model = build(meta, "fp32")
+    kw = inputs(cfg, meta)
+    with torch.no_grad():
+        d = model(**kw, output_hidden_states=True)
+        t0 = model(**kw, return_dict=False)
+        t1 = model(**kw, return_dict=False, output_hidden_states=True)
+    nl = len(cfg.depths)
+    assert len(t0) == 3 and len(t1) == 4
+    assert float(t0[0]) == float(d.loss) and torch.equal(t0[1], d.output)
+    assert isinstance(t0[2], tuple) and len(t0[2]) == nl + 1 and len(t1[2]) == nl + 1 and len(t1[3]) == nl + 1
+    assert len(d.hidden_states) == 2 * (nl + 1)
+    for a, b in zip(t1[2] + t1[3], d.hidden_states):
+        assert torch.equal(a, b)
+    for a, b in zip(t0[2], d.hidden_states[nl + 1:]):
+        assert torch.equal(a, b)
+
+
+def test_nonzero_dropout_is_refused():
+    f, meta = load_fixture("tiny_trained")
+    with pytest.raises(NotImplementedError):
+        ScOT(ScOTConfig(**dict(meta["cfg"], hidden_dropout_prob=0.1)))

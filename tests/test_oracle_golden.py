@@ -78,8 +78,9 @@ def test_spectral_resize(size):
     assert abs(float(loss.detach()) - float(f["loss"])) < 1e-5 * abs(float(f["loss"]))
 
 
-@pytest.mark.parametrize("name", ["poseidonT_trained", "poseidonT_hf", "poseidonB_trained", "poseidonB_hf"])
+@pytest.mark.parametrize("name", ["poseidonT_trained", "poseidonT_hf", "poseidonB_trained", "poseidonB_hf", "poseidonB256_trained"])
 def test_poseidon_presets(name):
+    """poseidonB256_trained = BASELINE config 5's geometry (256x256: sixteen shifted 16x16 windows at stage 0, four at stage 1)."""
     f, meta = load_fixture(name)
     grads = name.startswith("poseidonT")
     cfg, sd, loss, out, _ = _run(meta, grads=grads)

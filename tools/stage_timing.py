@@ -19,7 +19,7 @@ def main():
     ap.add_argument("--model", default="B")
     ap.add_argument("--batch", type=int, default=64)
     ap.add_argument("--size", type=int, default=128)
-    ap.add_argument("--compute", default="bf16")
+    ap.add_argument("--compute", default="fp16")
     a = ap.parse_args()
     cfg = preset(a.model, image_size=a.size, num_channels=4, num_out_channels=4, channel_slice_list_normalized_loss=[0, 1, 3, 4])
     torch.manual_seed(1234)
