@@ -163,16 +163,27 @@ def launch_table(engine, run_step, nsteps=3):
     torch.cuda.synchronize()
     log, engine.launch_timer = engine.launch_timer, None
     fam, inst = {}, {}
+    main = torch.cuda.current_stream().cuda_stream
+    chain_ms = 0.0
     for name, args, e0, e1 in log:
         ms = e0.elapsed_time(e1)
+        if (args[-1] or 0) == main:
+            chain_ms += ms
         fl = 0.0
         key = name.replace("scot_", "")
+        if name == "scot_wgrad_group":
+            key = "wgrad_group (all weight gradients of a layer, incl. grouped split-K reduce)"
+            n = args[1]
+            fl = sum(2.0 * args[2] * args[7][i] * args[8][i] for i in range(n))
+            d = inst.setdefault((tuple(args[7][i] for i in range(n)), tuple(args[8][i] for i in range(n)), args[2]), [0.0, 0, fl])
+            d[0] += ms
+            d[1] += 1
         if name == "scot_gemm":
             lay, M, N, K = args[0], args[2], args[3], args[4]
             key = ("gemm NT (forward Linear)", "gemm NN (dgrad)", "gemm TN (wgrad, incl. split-K reduce)")[lay]
             fl = 2.0 * M * N * K
             if lay == 2:
-                d = inst.setdefault((M, N, K), [0.0, 0])
+                d = inst.setdefault((M, N, K), [0.0, 0, fl])
                 d[0] += ms
                 d[1] += 1
         d = fam.setdefault(key, [0.0, 0, 0.0])
@@ -182,10 +193,15 @@ def launch_table(engine, run_step, nsteps=3):
     table = {k: {"ms_per_step": v[0] / nsteps, "launches_per_step": v[1] / nsteps, "gflop_per_step": v[2] / nsteps / 1e9}
              for k, v in sorted(fam.items(), key=lambda kv: -kv[1][0])}
     worst = None
-    for (M, N, K), (ms, n) in inst.items():
-        tf = 2.0 * M * N * K * n / ms / 1e9
-        if worst is None or tf < worst["tflops"]:
+    for (M, N, K), (ms, n, fl) in inst.items():
+        tf = fl * n / ms / 1e9
+        if n / nsteps >= 8 and (worst is None or tf < worst["tflops"]):    # a per-layer instance, not one of the few trunk GEMMs
             worst = {"shape_MNK": [M, N, K], "us_per_launch": ms / n * 1e3, "tflops": tf, "launches_per_step": n / nsteps}
+    launch_table.main_stream_ms_per_step = chain_ms / nsteps
+    launch_table.wgrad_instances = sorted(({"shape_MNK": [list(k[0]) if isinstance(k[0], tuple) else k[0], list(k[1]) if isinstance(k[1], tuple) else k[1], k[2]],
+                                            "us_per_launch": round(ms / n * 1e3, 1), "tflops": round(fl * n / ms / 1e9, 1),
+                                            "launches_per_step": n / nsteps} for k, (ms, n, fl) in inst.items()),
+                                          key=lambda d: -d["us_per_launch"] * d["launches_per_step"])[:8]
     return table, worst
 
 
@@ -359,8 +375,11 @@ def main():
             use_graph[0] = eager
             launches = {"launches_per_step": sum(v["launches_per_step"] for v in table.values()),
                         "kernel_ms_per_step": sum(v["ms_per_step"] for v in table.values()),
+                        "main_stream_ms_per_step": launch_table.main_stream_ms_per_step,
+                        "wgrad_instances": launch_table.wgrad_instances,
                         "top": {k: {kk: round(vv, 3) for kk, vv in v.items()} for k, v in list(table.items())[:10]}}
-            wg = table.get("gemm TN (wgrad, incl. split-K reduce)")
+            wg = table.get("wgrad_group (all weight gradients of a layer, incl. grouped split-K reduce)") or \
+                table.get("gemm TN (wgrad, incl. split-K reduce)")
             if wg:
                 tf = wg["gflop_per_step"] / wg["ms_per_step"]      # GFLOP / ms = TFLOP/s
                 traffic = None
@@ -368,8 +387,9 @@ def main():
                 if os.path.exists(tpath):   # HBM bytes per launch (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes)
                     traffic = json.load(open(tpath)).get("wgrad_bytes_per_launch")
                 roof = {"bound": "mfma", "achieved": tf, "peak": peak, "unit": "TFLOP/s", "frac": tf / peak, "traffic": traffic,
-                        "kernel": "gemm_fast_kernel<..,TN> + splitk_reduce: all weight-gradient GEMMs of a step, in-step durations "
-                                  "(HIP events on the launching stream around every call of the replayed step)",
+                        "kernel": "wgrad_group_kernel<96x96 | 64x64> + wgrad_group_reduce_kernel: the grouped weight-gradient GEMMs of "
+                                  "the 64 ScOTLayers, in-step durations (HIP events on the launching stream around every call of "
+                                  "the replayed step)",
                         "us_per_launch": wg["ms_per_step"] / wg["launches_per_step"] * 1e3,
                         "launches_per_step": wg["launches_per_step"], "algorithmic_gflop_per_step": wg["gflop_per_step"],
                         "worst_instance": worst, "whole_step": step_roof}

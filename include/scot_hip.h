@@ -61,6 +61,16 @@ int scot_gemm(int layout, int compute, int M, int N, int K,
  * inference form) — the fc1 form, so that no
  * later kernel re-evaluates erf; aux_mul=1: `aux` already holds that derivative and is multiplied in as is. */
 
+/* The weight gradients of one ScOTLayer in ONE launch: for i < n (n <= 8)
+ *   dW_i[M_i, N_i] += dY_i[K, M_i]^T · X_i[K, N_i],   dbias_i[M_i] += Σ_k dY_i[k, :]   (dbias / dbias_i may be NULL)
+ * i.e. the autograd of query/key/value, attention.output.dense, intermediate.dense and output.dense (HF:396-410, 502-506,
+ * 545-561) over the same K tokens.  Operands dense row-major in the 16-bit operand format, dW fp32; the arrays of pointers /
+ * sizes are HOST arrays, read before the call returns.  K is split over workgroups, partial tiles go through `workspace`
+ * (32-byte aligned device scratch, >= nsplit · Σ M_i N_i floats) and one grouped pass adds them into the gradients.
+ * compute must be 1 (16-bit MFMA); returns -3 for anything else (use scot_gemm per problem). */
+int scot_wgrad_group(int compute, int n, int K, const void* const* dY, const void* const* X, float* const* dW,
+                     float* const* dbias, const int* M, const int* N, void* workspace, size_t ws_bytes, scot_stream_t stream);
+
 /* Shifted-window cosine attention, HF:389-455 + ref:522-559 (roll/partition/mask folded into indexing).
  * qkv: [batch*Hp*Wp][3C] (q|k|v) in the compute dtype; out: [batch*Hp*Wp][C]; lse: [batch*nW][heads][ws*ws] f32;
  * bias_table: [heads][(2ws-1)^2] = 16*sigmoid(CPB MLP) from scot_cpb_fwd; logit_scale: [heads]. */

@@ -106,12 +106,15 @@ __device__ __forceinline__ void st8(void* p, int dt, size_t i, const float v[8])
 // fp32 GELU resolution for the 1e-5 parity mode) needs one exp, one rcp and a degree-5 Horner chain — and the SAME
 // exp(-x^2/2) also gives the Gaussian term of the derivative.
 __device__ __forceinline__ void gelu_terms(float x, float& cdf, float& pdf_times_sqrt2pi) {
+  // 15 VALU instructions per element (v_rcp_f32 and v_exp_f32 directly: `__frcp_rn` expands to the 11-instruction IEEE division
+  // sequence, which made this function 28 instructions and the fused MLP kernels VALU-bound on it — round-2 microbenchmarks)
   const float z = fabsf(x) * 0.70710678118654752f;
-  const float t = __frcp_rn(1.0f + 0.3275911f * z);
-  const float e = __expf(-z * z);
-  const float poly = ((((1.061405429f * t - 1.453152027f) * t + 1.421413741f) * t - 0.284496736f) * t + 0.254829592f) * t;
-  const float erf_abs = 1.0f - poly * e;                 // erf(|x|/sqrt2)
-  cdf = 0.5f * (1.0f + copysignf(erf_abs, x));           // Phi(x)
+  const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, z, 1.0f));
+  const float e = __builtin_amdgcn_exp2f(z * z * -1.4426950408889634f);      // exp(-z^2) = exp(-x^2/2)
+  // 0.5 * (A&S 7.1.26 polynomial): h = 0.5 * erfc(|x|/sqrt2) = poly * e
+  const float poly = ((((0.5307027145f * t - 0.7265760135f) * t + 0.7107068705f) * t - 0.142248368f) * t + 0.127414796f) * t;
+  const float h = fmaf(-poly, e, 0.5f);                  // 0.5 * erf(|x|/sqrt2)
+  cdf = 0.5f + copysignf(h, x);                          // Phi(x)
   pdf_times_sqrt2pi = e;                                 // exp(-x^2/2)
 }
 // 8 consecutive compute-type elements to a 16-byte aligned (LDS or global) address

@@ -32,6 +32,7 @@ struct FastArgs {
   void* C2;        // optional second output: C = gelu(v), C2 = gelu'(v)   (fc1 epilogue: value and derivative in one pass)
   int aux_mul;     // aux is multiplied in as is (it already holds gelu'(u)) instead of gelu'(aux)
   float* ws;       // TN split-K: partial tiles ws[z][M][N] (fp32), reduced by splitk_reduce_kernel
+  size_t ws_plane; // distance (floats) between the partial tiles of consecutive K slices; 0 = M·N (grouped wgrad: Σ_i M_i·N_i)
   int rmw;         // TN, single split: C += acc by the unique owner (no atomics)
 };
 
@@ -132,8 +133,17 @@ __device__ __forceinline__ void fstore_x3(bf16_t* hi, bf16_t* lo, const uint4 (&
 
 // WM x WN = arrangement of the 4 waves over the BM x BN tile (WM*WN == 4); each wave owns (BM/WM) x (BN/WN).
 // X3 (CT = bf16_t, BKT = 32): fp32 operands in memory, split into hi/lo bf16 tiles in LDS, 3 MFMAs per K-step (see fstore_x3).
+// LDS footprint of one workgroup of gemm_fast_body (operand double buffer, reused by the epilogue's C tile)
+template <typename CT, int BM, int BN, int BKT, int LAYOUT, bool X3> struct FastLds {
+  static constexpr bool A_KC = (LAYOUT != LAYOUT_TN), B_KC = (LAYOUT == LAYOUT_NT);
+  static constexpr int STAGE = (X3 ? 2 : 1) * (FTile<CT, BM, A_KC, BKT>::elems + FTile<CT, BN, B_KC, BKT>::elems);
+  static constexpr size_t AB = 2 * STAGE * sizeof(CT), C = (size_t)BM * (BN + 4) * sizeof(float) + BN * sizeof(float);
+  static constexpr size_t bytes = AB > C ? AB : C;
+};
+
+// One workgroup's share of a GEMM: output tile (by, bx), K range [bz·ksplit, (bz+1)·ksplit).  `smem`: FastLds<..>::bytes, 16-byte aligned.
 template <typename CT, int BM, int BN, int WM, int WN, int BKT, int NSET, int LAYOUT, bool X3 = false>
-__global__ __launch_bounds__(256) void gemm_fast_kernel(FastArgs p) {
+__device__ __forceinline__ void gemm_fast_body(const FastArgs& p, const int bx, const int by, const int bz, char* smem) {
   static_assert(NSET == 2 || NSET == 4, "pipeline depth");
   static_assert(WM * WN == 4, "4 waves per workgroup");
   static_assert(!X3 || (sizeof(CT) == 2 && BKT == 32), "bf16x3: bf16 tiles, one MFMA K-step per tile");
@@ -150,29 +160,11 @@ __global__ __launch_bounds__(256) void gemm_fast_kernel(FastArgs p) {
   constexpr int STAGE = (X3 ? 2 : 1) * (TA::elems + TB::elems);   // X3: [A hi][A lo][B hi][B lo]
   constexpr int BOFF = (X3 ? 2 : 1) * TA::elems;                  // offset of the B tile(s) in a stage
   constexpr int CP = BN + 4;                                  // C tile pitch (floats)
-  constexpr size_t LDS_AB = 2 * STAGE * sizeof(CT), LDS_C = (size_t)BM * CP * sizeof(float) + BN * sizeof(float);
-  constexpr size_t LDS_BYTES = LDS_AB > LDS_C ? LDS_AB : LDS_C;
-  __shared__ __attribute__((aligned(16))) char smem[LDS_BYTES];
+  static_assert(FastLds<CT, BM, BN, BKT, LAYOUT, X3>::STAGE == STAGE, "LDS sizing");
   CT* lds = (CT*)smem;
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wr = wave / WN, wc = wave % WN, g = lane >> 4;
-  // Workgroup b runs on XCD b % 8 (observed dispatch order, used for speed only).  The tiles that re-read the same streamed
-  // operand — all output tiles of one token chunk (TN), all column tiles of one row block (NT/NN) — are renumbered so that they
-  // are consecutive ON ONE XCD: its 4 MB L2 then serves the re-reads instead of the fabric (PMC: 3.1x algorithmic bytes before).
-  int bx = blockIdx.x, by = blockIdx.y, bz = blockIdx.z;
-  {
-    const int gx = gridDim.x, gy = gridDim.y, gz = gridDim.z;
-    const int G = (LAYOUT == LAYOUT_TN) ? gx * gy : gx;
-    const int NG = (LAYOUT == LAYOUT_TN) ? gz : gy * gz;
-    if (p.xcd_swizzle && NG % 8 == 0) {
-      const int L = bx + gx * (by + gy * bz);
-      const int j = L >> 3;
-      const int group = (L & 7) * (NG >> 3) + j / G, member = j % G;
-      if (LAYOUT == LAYOUT_TN) { bz = group; bx = member % gx; by = member / gx; }
-      else { by = group % gy; bz = group / gy; bx = member; }
-    }
-  }
   const int m0 = by * BM, n0 = bx * BN;
   const int kbeg = bz * p.ksplit;
   const int kend = min(p.K, kbeg + p.ksplit);
@@ -333,7 +325,7 @@ __global__ __launch_bounds__(256) void gemm_fast_kernel(FastArgs p) {
       const size_t ci = (size_t)grow * p.ldc + col;
       if (LAYOUT == LAYOUT_TN) {
         if (p.ws) {            // split-K partial tile (dense [M][N], 32-byte aligned rows since N % 8 == 0)
-          st8(p.ws + (size_t)bz * p.M * p.N, SCOT_F32, (size_t)grow * p.N + col, v);
+          st8(p.ws + (size_t)bz * (p.ws_plane ? p.ws_plane : (size_t)p.M * p.N), SCOT_F32, (size_t)grow * p.N + col, v);
         } else if (p.rmw) {    // single split: this workgroup is the only writer of the tile
           float o[8];
           ld8(p.C, SCOT_F32, ci, o);
@@ -369,6 +361,80 @@ __global__ __launch_bounds__(256) void gemm_fast_kernel(FastArgs p) {
     __syncthreads();
     if (tid < BN && n0 + tid < p.N) atomicAdd(&p.colsum_out[n0 + tid], colacc[tid]);
   }
+}
+
+template <typename CT, int BM, int BN, int WM, int WN, int BKT, int NSET, int LAYOUT, bool X3 = false>
+__global__ __launch_bounds__(256) void gemm_fast_kernel(FastArgs p) {
+  __shared__ __attribute__((aligned(16))) char smem[FastLds<CT, BM, BN, BKT, LAYOUT, X3>::bytes];
+  // Workgroup b runs on XCD b % 8 (observed dispatch order, used for speed only).  The tiles that re-read the same streamed
+  // operand — all output tiles of one token chunk (TN), all column tiles of one row block (NT/NN) — are renumbered so that they
+  // are consecutive ON ONE XCD: its 4 MB L2 then serves the re-reads instead of the fabric (PMC: 3.1x algorithmic bytes before).
+  int bx = blockIdx.x, by = blockIdx.y, bz = blockIdx.z;
+  {
+    const int gx = gridDim.x, gy = gridDim.y, gz = gridDim.z;
+    const int G = (LAYOUT == LAYOUT_TN) ? gx * gy : gx;
+    const int NG = (LAYOUT == LAYOUT_TN) ? gz : gy * gz;
+    if (p.xcd_swizzle && NG % 8 == 0) {
+      const int L = bx + gx * (by + gy * bz);
+      const int j = L >> 3;
+      const int group = (L & 7) * (NG >> 3) + j / G, member = j % G;
+      if (LAYOUT == LAYOUT_TN) { bz = group; bx = member % gx; by = member / gx; }
+      else { by = group % gy; bz = group / gy; bx = member; }
+    }
+  }
+  gemm_fast_body<CT, BM, BN, WM, WN, BKT, NSET, LAYOUT, X3>(p, bx, by, bz, smem);
+}
+
+// ------------------------------------------------------------------------------------------------------------------------
+// Grouped weight gradients: the (up to 8) wgrad GEMMs of one ScOTLayer — dW_i[M_i, N_i] += dY_i[K, M_i]^T · X_i[K, N_i], all
+// contracting over the same K tokens — in ONE launch.  Round-2 trace: 273 TN launches + 342 split-K reduce launches per step
+// were 31 % of the kernel time at 85 TF/s; a stage-0 gradient has only 4 output tiles, so each launch split K 128 ways to fill
+// the chip and moved 19 MB of partial tiles.  Together the four problems of a block have 12 tiles: 40 K slices fill the chip,
+// the partials shrink 3x, 8 launches become 2 (this kernel + one grouped reduce), and the deep stages' problems (hundreds of
+// 64x64 tiles each, no split) share one launch instead of four tail effects.
+#define SCOT_WGRAD_GROUP_MAX 8
+struct WgradProblem {
+  const void* A; const void* B; float* C; float* colsum;   // A = dY [K, M] (lda), B = X [K, N] (ldb), C = dW [M, N] (ldc, +=)
+  int M, N, lda, ldb, ldc;
+  int tiles_n, tile0;          // tiles along N; index of this problem's first tile in the group
+  unsigned ws_off;             // offset (floats) of this problem's partial tiles inside one K-slice plane of the workspace
+};
+struct WgradGroupArgs {
+  WgradProblem p[SCOT_WGRAD_GROUP_MAX];
+  int n, K, ksplit, nsplit, tiles;
+  float* ws; size_t plane;     // ws[z][plane]: partial sums of K slice z (all problems back to back); plane in floats
+  int use_tr;
+};
+
+template <typename CT, int BM, int BN, int BKT, int NSET>
+__global__ __launch_bounds__(256) void wgrad_group_kernel(WgradGroupArgs g) {
+  __shared__ __attribute__((aligned(16))) char smem[FastLds<CT, BM, BN, BKT, LAYOUT_TN, false>::bytes];
+  // all tiles of one K slice consecutively on ONE XCD (workgroup b runs on XCD b % 8: speed only): its L2 serves the re-reads of
+  // the slice's operand panels by the tiles that share them
+  int L = blockIdx.x, slice, tile;
+  if (g.nsplit % 8 == 0) {
+    const int j = L >> 3;
+    slice = (L & 7) * (g.nsplit >> 3) + j / g.tiles;
+    tile = j % g.tiles;
+  } else {
+    slice = L / g.tiles;
+    tile = L % g.tiles;
+  }
+  int q = 0;
+#pragma unroll
+  for (int i = 1; i < SCOT_WGRAD_GROUP_MAX; ++i) q += (i < g.n && tile >= g.p[i].tile0) ? 1 : 0;
+  const WgradProblem& pr = g.p[q];
+  const int local = tile - pr.tile0;
+  FastArgs a;
+  a.A = pr.A; a.B = pr.B; a.C = pr.C; a.bias = nullptr; a.colscale = nullptr; a.aux = nullptr; a.resid = nullptr;
+  a.colsum_out = pr.colsum;
+  a.M = pr.M; a.N = pr.N; a.K = g.K; a.lda = pr.lda; a.ldb = pr.ldb; a.ldc = pr.ldc; a.ldaux = 0; a.ldres = 0;
+  a.c_dt = SCOT_F32; a.aux_dt = 0; a.res_dt = 0; a.a_gelu = 0; a.b_gelu = 0; a.aux_gelu_grad = 0; a.atomic = 0;
+  a.ksplit = g.ksplit; a.use_tr = g.use_tr; a.xcd_swizzle = 0; a.C2 = nullptr; a.aux_mul = 0;
+  a.ws = g.ws ? g.ws + pr.ws_off : nullptr;     // partial tiles of slice z at ws[z·plane + ws_off ..]
+  a.ws_plane = g.plane;
+  a.rmw = g.ws ? 0 : 1;
+  gemm_fast_body<CT, BM, BN, 2, 2, BKT, NSET, LAYOUT_TN, false>(a, local % pr.tiles_n, local / pr.tiles_n, slice, smem);
 }
 
 // Σ_z ws[z][e .. e+7]: ZL consecutive lanes share one 8-float group and take every ZL-th partial (independent loads,
@@ -532,7 +598,7 @@ int scot_gemm_fast(int layout, int compute, int M, int N, int K, const void* A, 
   a.A = A; a.B = B; a.C = C; a.bias = bias; a.colscale = colscale; a.aux = aux; a.resid = resid; a.colsum_out = colsum_out;
   a.M = M; a.N = N; a.K = K; a.lda = lda; a.ldb = ldb; a.ldc = ldc; a.ldaux = ldaux; a.ldres = ldres;
   a.c_dt = c_dt; a.aux_dt = aux_dt; a.res_dt = res_dt; a.a_gelu = a_gelu; a.b_gelu = b_gelu; a.aux_gelu_grad = aux != nullptr;
-  a.use_tr = g_scot_use_tr; a.atomic = 0; a.ws = nullptr; a.rmw = 0; a.C2 = C2; a.aux_mul = aux_mul;
+  a.use_tr = g_scot_use_tr; a.atomic = 0; a.ws = nullptr; a.ws_plane = 0; a.rmw = 0; a.C2 = C2; a.aux_mul = aux_mul;
   static int xcd = -1;
   if (xcd < 0) { const char* e = getenv("SCOT_GEMM_XCD"); xcd = e ? atoi(e) : 1; }
   a.xcd_swizzle = xcd;
@@ -628,6 +694,108 @@ int scot_gemm_fast(int layout, int compute, int M, int N, int K, const void* A, 
       else if (zl == 4) hipLaunchKernelGGL(splitk_epilogue_kernel<4>, g, b, 0, stream, a, nsplit);
       else hipLaunchKernelGGL(splitk_epilogue_kernel<1>, g, b, 0, stream, a, nsplit);
     }
+    rc = scot_check_launch();
+  }
+  return rc;
+}
+
+
+// C_i[m][n] += Σ_z ws[z·plane + ws_off_i + m·N_i + n] for every problem of the group (one launch)
+template <int ZL>
+__global__ __launch_bounds__(256) void wgrad_group_reduce_kernel(WgradGroupArgs g) {
+  const size_t n8 = g.plane / 8;
+  const int zl = threadIdx.x % ZL;
+  for (size_t i = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) / ZL; i < n8; i += (size_t)gridDim.x * blockDim.x / ZL) {
+    const size_t e = i * 8;
+    int q = 0;
+#pragma unroll
+    for (int k = 1; k < SCOT_WGRAD_GROUP_MAX; ++k) q += (k < g.n && e >= g.p[k].ws_off) ? 1 : 0;
+    const WgradProblem& pr = g.p[q];
+    const size_t le = e - pr.ws_off;
+    const int m = le / pr.N, n = le % pr.N;
+    float acc[8];
+    splitk_sum<ZL>(acc, g.ws, e, g.plane, g.nsplit, zl);
+    if (zl == 0) {
+      float c[8];
+      ld8(pr.C, SCOT_F32, (size_t)m * pr.ldc + n, c);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) c[j] += acc[j];
+      st8(pr.C, SCOT_F32, (size_t)m * pr.ldc + n, c);
+    }
+  }
+}
+
+template <int BM, int BN, int BKT, int NSET>
+static int launch_wgrad_group(const WgradGroupArgs& g, hipStream_t s) {
+  hipLaunchKernelGGL((wgrad_group_kernel<bf16_t, BM, BN, BKT, NSET>), dim3((unsigned)(g.tiles * g.nsplit)), dim3(256), 0, s, g);
+  return scot_check_launch();
+}
+
+// include/scot_hip.h: scot_wgrad_group.  dY_i: [K, M_i] (16-bit operands), X_i: [K, N_i], dW_i: [M_i, N_i] fp32 (+=),
+// dbias_i: [M_i] fp32 (+= column sums of dY_i) or NULL.  All leading dimensions = the row lengths (dense).
+extern "C" int scot_wgrad_group(int compute, int n, int K, const void* const* dY, const void* const* X, float* const* dW,
+                                float* const* dbias, const int* Ms, const int* Ns, void* workspace, size_t ws_bytes,
+                                hipStream_t stream) {
+  if (n <= 0 || n > SCOT_WGRAD_GROUP_MAX || K <= 0) return SCOT_ERR_SHAPE;
+  if (compute != SCOT_BF16) return SCOT_ERR_UNSUPPORTED;     // fp32 / split modes use scot_gemm per problem
+  if (K % 8) return SCOT_ERR_UNSUPPORTED;
+  bool all96 = true;
+  for (int i = 0; i < n; ++i) {
+    if (Ms[i] <= 0 || Ns[i] <= 0) return SCOT_ERR_SHAPE;
+    if (Ms[i] % 8 || Ns[i] % 8) return SCOT_ERR_UNSUPPORTED;
+    if ((((uintptr_t)dY[i] | (uintptr_t)X[i] | (uintptr_t)dW[i]) & 15) != 0) return SCOT_ERR_UNSUPPORTED;
+    all96 = all96 && Ms[i] % 96 == 0 && Ns[i] % 96 == 0;
+  }
+  // tile policy of the single-problem path: 96x96 for the long-K gradients of the token-heavy stages, 64x64 otherwise
+  const bool t96 = all96 && K >= 8192;
+  const int bm = t96 ? 96 : 64, bn = bm, bk = 64;
+  WgradGroupArgs g;
+  g.n = n; g.K = K; g.use_tr = g_scot_use_tr;
+  int tiles = 0;
+  size_t plane = 0;
+  for (int i = 0; i < n; ++i) {
+    WgradProblem& p = g.p[i];
+    p.A = dY[i]; p.B = X[i]; p.C = dW[i]; p.colsum = dbias ? dbias[i] : nullptr;
+    p.M = Ms[i]; p.N = Ns[i]; p.lda = Ms[i]; p.ldb = Ns[i]; p.ldc = Ns[i];
+    p.tiles_n = (Ns[i] + bn - 1) / bn;
+    p.tile0 = tiles;
+    p.ws_off = (unsigned)plane;
+    tiles += p.tiles_n * ((Ms[i] + bm - 1) / bm);
+    plane += (size_t)Ms[i] * Ns[i];
+  }
+  for (int i = n; i < SCOT_WGRAD_GROUP_MAX; ++i) { g.p[i] = g.p[0]; g.p[i].tile0 = 0x7fffffff; g.p[i].ws_off = 0xffffffffu; }
+  g.tiles = tiles; g.plane = plane;
+  // K slices: enough workgroups to fill the chip (~2 per CU), at least 8 K-tiles each, a multiple of 8 so that one slice's
+  // tiles share an XCD; none when the group already has >= 256 tiles
+  static int want_wgs = -1;
+  if (want_wgs < 0) { const char* e = getenv("SCOT_WGRAD_GROUP_WGS"); want_wgs = e ? atoi(e) : 448; }
+  const long nkt = (K + bk - 1) / bk;
+  long nsplit = tiles >= 256 ? 1 : (want_wgs + tiles - 1) / tiles;
+  const long maxsplit = nkt / 8 > 0 ? nkt / 8 : 1;
+  if (nsplit > maxsplit) nsplit = maxsplit;
+  const long wsmax = (workspace && plane) ? (long)(ws_bytes / (plane * sizeof(float))) : 1;
+  if (nsplit > wsmax) nsplit = wsmax < 1 ? 1 : wsmax;
+  int per = (int)(((K + nsplit - 1) / nsplit + bk - 1) / bk * bk);
+  if (nsplit >= 8) {
+    for (int tries = 0; tries < 64 && ((K + per - 1) / per) % 8 != 0; ++tries) per += bk;
+    if (((K + per - 1) / per) % 8 != 0) per = (int)(((K + nsplit - 1) / nsplit + bk - 1) / bk * bk);
+  }
+  g.ksplit = per;
+  g.nsplit = (K + per - 1) / per;
+  g.ws = nullptr;
+  if (g.nsplit > 1) {
+    if (!workspace || (((uintptr_t)workspace) & 31) || (size_t)g.nsplit * plane * sizeof(float) > ws_bytes) return SCOT_ERR_UNSUPPORTED;
+    g.ws = (float*)workspace;
+  }
+  int rc = t96 ? launch_wgrad_group<96, 96, 64, 2>(g, stream) : launch_wgrad_group<64, 64, 64, 2>(g, stream);
+  if (rc == SCOT_OK && g.ws) {
+    const size_t n8 = plane / 8;
+    const int zl = g.nsplit >= 32 ? 8 : g.nsplit >= 4 ? 4 : 1;
+    size_t blocks = (n8 * zl + 255) / 256; if (blocks > 4096) blocks = 4096;
+    const dim3 gr((unsigned)blocks), b(256);
+    if (zl == 8) hipLaunchKernelGGL(wgrad_group_reduce_kernel<8>, gr, b, 0, stream, g);
+    else if (zl == 4) hipLaunchKernelGGL(wgrad_group_reduce_kernel<4>, gr, b, 0, stream, g);
+    else hipLaunchKernelGGL(wgrad_group_reduce_kernel<1>, gr, b, 0, stream, g);
     rc = scot_check_launch();
   }
   return rc;

@@ -70,6 +70,8 @@ class ScOTEngine:
         self.side_batch = os.environ.get("SCOT_SIDE_BATCH", "1") == "1"
         self.side_flush = os.environ.get("SCOT_SIDE_FLUSH", "block")   # block | stage: where queued weight-gradient launches fork
         self._pending = []
+        self._wgq = []                                                  # weight gradients waiting to be grouped (see wgrad)
+        self.group_wgrads = os.environ.get("SCOT_GROUP_WGRAD", "1") == "1"
         self.arena = arena
         # bf16x3: activations and weights stay fp32 in HBM; the GEMMs split them into hi + lo bf16 while staging into LDS and
         # run three bf16 MFMAs per K-step (≈ fp32 accuracy at the bf16 MFMA rate); so do the 16x16-window attention kernels
@@ -357,6 +359,8 @@ class ScOTEngine:
             ops.set_workspace_slot(prev)
 
     def flush_side(self):
+        if self._wgq:
+            self._drain_wgrads()
         if self._pending:
             fns, self._pending = self._pending, []
             self._run_side(fns)
@@ -450,7 +454,30 @@ class ScOTEngine:
         return self.fused_mlp and C in (96, 192) and C in self.fused_c and part in self.fused_parts
 
     def wgrad(self, cm, dy, x, gw, b_gelu=False, dbias=None):
-        self.off_critical_path(lambda: ops.linear_wgrad(cm, dy, x, gw, b_gelu=b_gelu, dbias=dbias), dy, x)
+        """dW += dy^T x (+ dbias): queued until the next flush_side(), where the queued problems that share a compute mode and
+        a token count — the four Linear layers of a ScOTLayer — go out as ONE grouped launch (ops.wgrad_group)."""
+        if b_gelu or not self.group_wgrads:
+            self.off_critical_path(lambda: ops.linear_wgrad(cm, dy, x, gw, b_gelu=b_gelu, dbias=dbias), dy, x)
+            return
+        self._wgq.append((cm, dy, x, gw, dbias))
+
+    def _drain_wgrads(self):
+        q, self._wgq = self._wgq, []
+        groups = {}
+        for item in q:
+            cm, dy, x, gw, dbias = item
+            key = (cm, dy.numel() // dy.shape[-1], dy.dtype, x.dtype)
+            groups.setdefault(key, []).append(item)
+        for (cm, K, _, _), items in groups.items():
+            for i in range(0, len(items), 8):
+                part = items[i:i + 8]
+
+                def run(cm=cm, part=part):
+                    if cm == ops.BF16 and len(part) > 1 and ops.wgrad_group(cm, [(dy, x, gw, db) for _, dy, x, gw, db in part]):
+                        return
+                    for _, dy, x, gw, db in part:
+                        ops.linear_wgrad(cm, dy, x, gw, dbias=db)
+                self.off_critical_path(run, *[t for it in part for t in (it[1], it[2])])
 
     def linear_bwd_params(self, wname, bname, dy, x, b_gelu=False):
         """dW += dy^T x and db += Σ dy in ONE wgrad launch (the bias sum rides on the dY tiles already in LDS)."""

@@ -156,6 +156,27 @@ def linear_wgrad(compute, dy, x, dw, b_gelu=False, dbias=None):
     gemm(TN, compute, N, K, M, dy, N, x, K, dw, K, b_gelu=b_gelu, accumulate=True, colsum_out=dbias)
 
 
+def wgrad_group(compute, problems) -> bool:
+    """The weight gradients of one ScOTLayer in ONE launch (+ one grouped split-K reduce): problems = [(dy, x, dw, dbias)], every
+    dy [K, M_i] / x [K, N_i] in the 16-bit operand format over the SAME K rows, dw [M_i, N_i] fp32 (+=), dbias [M_i] or None.
+    False = not covered (the caller launches them one by one)."""
+    import ctypes
+    n = len(problems)
+    K = problems[0][0].numel() // problems[0][0].shape[-1]
+    VP, IA = ctypes.c_void_p * n, ctypes.c_int * n
+    dys, xs, dws = VP(*[ptr(p[0]) for p in problems]), VP(*[ptr(p[1]) for p in problems]), VP(*[ptr(p[2]) for p in problems])
+    dbs = VP(*[ptr(p[3]) for p in problems])
+    Ms, Ns = IA(*[p[0].shape[-1] for p in problems]), IA(*[p[1].shape[-1] for p in problems])
+    for dy, x, dw, _ in problems:
+        if dt(dy) != BF16 or dt(x) != BF16 or dw.dtype != torch.float32 or dy.numel() // dy.shape[-1] != K or x.numel() // x.shape[-1] != K:
+            return False
+    rc = L().scot_wgrad_group(compute, n, K, dys, xs, dws, dbs, Ms, Ns, workspace().data_ptr(), WORKSPACE_BYTES, stream())
+    if rc == -3:
+        return False
+    _lib.check(rc, "scot_wgrad_group")
+    return True
+
+
 def colsum(x, out, y=None):
     M = x.numel() // x.shape[-1]
     N = x.shape[-1]

@@ -71,6 +71,8 @@ inline float __expf(float x) { return std::exp(x); }
 inline float __logf(float x) { return std::log(x); }
 #define __log2f(x) std::log2((float)(x))        /* glibc declares (but does not export) a function of this name */
 inline float emu_exp2f(float x) { return std::exp2(x); }
+inline float emu_rcpf(float x) { return 1.0f / x; }
+#define __builtin_amdgcn_rcpf emu_rcpf
 #define __builtin_amdgcn_exp2f emu_exp2f
 #define hipMemcpyDeviceToHost 2
 inline hipError_t hipMemcpyAsync(void* dst, const void* src, size_t n, int, hipStream_t) { std::memcpy(dst, src, n); return hipSuccess; }

@@ -79,6 +79,28 @@ def test_wgrad_split_k(emu):
     assert rel(db, dy.double().sum(0)) < 1e-4
 
 
+@pytest.mark.parametrize("K,dims", [(2048, [(96, 384), (384, 96), (96, 96), (288, 96)]),       # a stage-0 block: 96x96 tiles, K split
+                                    (8192, [(96, 192), (192, 96)]),                            # t96 policy needs K >= 8192: 4 tiles -> many slices
+                                    (256, [(128, 512), (512, 128), (128, 128), (384, 128)]),   # deep stage: 64x64 tiles, no split
+                                    (512, [(40, 72), (72, 40), (48, 48)])])                    # ragged tiles (Poseidon-T-like widths)
+def test_wgrad_group(emu, K, dims):
+    """scot_wgrad_group: the weight (and bias) gradients of several Linear layers over the same K tokens in one launch + one
+    grouped reduce == the single-problem launches == fp64."""
+    probs, refs = [], []
+    for i, (M, N) in enumerate(dims):
+        dy, x = rnd(K, M, dtype=torch.bfloat16, seed=10 + i), rnd(K, N, dtype=torch.bfloat16, seed=20 + i)
+        dw, db = rnd(M, N, seed=30 + i), (rnd(M, seed=40 + i) if i != 2 else None)
+        refs.append((dw.double() + dy.double().t() @ x.double(), None if db is None else db.double() + dy.double().sum(0)))
+        probs.append((dy, x, dw, db))
+    assert ops.wgrad_group(ops.BF16, probs)
+    for (dy, x, dw, db), (rw, rb) in zip(probs, refs):
+        assert rel(dw, rw) < 1e-5
+        if db is not None:
+            assert rel(db, rb) < 1e-4
+    # not covered: fp32 operands -> False, nothing written
+    assert not ops.wgrad_group(ops.F32, [(p[0].float(), p[1].float(), p[2], p[3]) for p in probs])
+
+
 @pytest.mark.parametrize("cond", [True, False])
 @pytest.mark.parametrize("xdt,B,L,C", [(torch.float32, 2, 40, 96), (torch.bfloat16, 2, 64, 192), (torch.float32, 3, 9, 20)])
 def test_cln_fwd_bwd(emu, cond, xdt, B, L, C):
