@@ -76,6 +76,22 @@ def create_optimizer(model: nn.Module, learning_rate: float, weight_decay: float
     return torch.optim.AdamW(groups, lr=learning_rate, betas=(0.9, 0.999), eps=1e-8)
 
 
+def compute_loss(model, inputs: Dict[str, torch.Tensor], return_outputs: bool = False, num_items_in_batch=None,
+                 ar_steps: Union[int, Sequence[int], None] = None, output_all_steps: bool = False):
+    """reference Trainer.compute_loss (trainer.py:605-635) without the label smoother / past-state branches no ScOT recipe uses:
+    the AR forward (`rollout`), then the loss taken from the output (dict key or tuple position 0).  `num_items_in_batch` is what
+    transformers >= 4.46 passes to compute_loss; like the reference (whose loss is already a mean) it is accepted and ignored."""
+    outputs = rollout(model, inputs, ar_steps, output_all_steps)
+    if isinstance(outputs, tuple):
+        loss = outputs[0]
+    else:
+        if outputs.loss is None:
+            raise ValueError("The model did not return a loss from the inputs, only the following keys: "
+                             f"{','.join(outputs.keys())}. For reference, the inputs it received are {','.join(inputs.keys())}.")
+        loss = outputs.loss
+    return (loss, outputs) if return_outputs else loss
+
+
 def rollout(model, inputs: Dict[str, torch.Tensor], ar_steps: Union[int, Sequence[int], None] = None,
             output_all_steps: bool = False):
     """reference Trainer._model_forward (trainer.py:452-603).  Returns the model's ScOTOutput of the last step with

@@ -242,6 +242,15 @@ class ScOT(nn.Module):
     def get_input_embeddings(self):
         return self.embeddings.patch_embeddings
 
+    def _prune_heads(self, heads_to_prune):
+        """reference model.py:1287-1291 (HF head pruning).  The q/k/v weights of a block live back to back in the parameter arena
+        and the attention kernels are compiled for head_dim = embed_dim / 3: removing heads changes both.  No Poseidon recipe
+        prunes heads; refuse instead of silently computing with the unpruned model."""
+        raise NotImplementedError("head pruning is not supported by the fused attention kernels (reference model.py:1287-1291)")
+
+    def prune_heads(self, heads_to_prune):
+        self._prune_heads(heads_to_prune)
+
     def num_parameters(self):
         return sum(p.numel() for p in self.parameters())
 

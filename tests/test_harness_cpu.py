@@ -3,6 +3,7 @@ reference Trainer), on CPU.  Rollout numerics are GPU tests (tests/test_model_gp
 import json
 import os
 
+import pytest
 import torch
 
 from conftest import GOLDEN
@@ -108,3 +109,32 @@ def test_metrics_match_reference_pins():
     assert close(out["mean_over_median_l1_error"], np.mean([pins[f"group{i}"]["median_abs"] for i in range(3)]))
     single = M.channel_group_metrics(pr[:, :1], tg[:, :1], [0, 1], full_data=True)
     assert close(single["mean_relative_l1_error"], pins["group0"]["mean_rel"]) and len(single["full_data"]) == 6
+
+
+def test_compute_loss_accepts_trainer_kwargs():
+    """reference Trainer.compute_loss (trainer.py:605-635) as called by transformers >= 4.46 (extra `num_items_in_batch`): loss from a
+    ModelOutput-like object or from tuple position 0; a missing loss raises the reference's ValueError."""
+    from types import SimpleNamespace
+    from scOT.trainer import compute_loss
+
+    class Out(SimpleNamespace):
+        def keys(self):
+            return [k for k, v in vars(self).items() if v is not None]
+
+    class M:
+        config = SimpleNamespace(use_conditioning=True, num_channels=1, num_out_channels=1)
+
+        def __init__(self, ret):
+            self.ret, self.calls = ret, 0
+
+        def __call__(self, **kw):
+            self.calls += 1
+            return self.ret
+    x = dict(pixel_values=torch.zeros(1, 1, 2, 2), time=torch.ones(1), labels=torch.zeros(1, 1, 2, 2))
+    m = M(Out(loss=torch.tensor(2.0), output=torch.zeros(1, 1, 2, 2)))
+    assert float(compute_loss(m, x, num_items_in_batch=7)) == 2.0 and m.calls == 1
+    loss, out = compute_loss(m, x, return_outputs=True, ar_steps=2)
+    assert float(loss) == 2.0 and m.calls == 3 and out is m.ret
+    assert float(compute_loss(M((torch.tensor(3.0), None)), dict(x), ar_steps=None)) == 3.0
+    with pytest.raises(ValueError, match="did not return a loss"):
+        compute_loss(M(Out(loss=None, output=torch.zeros(1, 1, 2, 2))), x)

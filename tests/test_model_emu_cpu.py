@@ -67,7 +67,7 @@ def grads_global(model, f):
     return (num / max(den, 1e-300)) ** 0.5
 
 
-TINY = ["tiny_trained", "tiny_hf", "tiny_odd", "tiny_shift3", "tiny_nocond_p2", "tiny_learnres_mask", "tiny_obstacle_mask"]
+TINY = ["tiny_trained", "tiny_hf", "tiny_odd", "tiny_shift3", "tiny_nocond_p2", "tiny_learnres_mask", "tiny_obstacle_mask", "tiny_abspos"]
 
 
 @pytest.mark.parametrize("name", TINY)

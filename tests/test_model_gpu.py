@@ -64,7 +64,7 @@ def grads_report(model, f, tol_each, tol_global, floor=1e-9, skip=()):
     return (num / max(den, 1e-300)) ** 0.5, worst
 
 
-TINY = ["tiny_trained", "tiny_hf", "tiny_odd", "tiny_shift3", "tiny_nocond_p2", "tiny_learnres_mask", "tiny_obstacle_mask",
+TINY = ["tiny_trained", "tiny_hf", "tiny_odd", "tiny_shift3", "tiny_nocond_p2", "tiny_learnres_mask", "tiny_obstacle_mask", "tiny_abspos",
         "tiny_w16"]
 
 

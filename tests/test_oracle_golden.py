@@ -36,7 +36,7 @@ def _run(meta, grads):
     return cfg, sd, loss, out, inter
 
 
-@pytest.mark.parametrize("name", ["tiny_trained", "tiny_hf", "tiny_odd", "tiny_shift3", "tiny_nocond_p2",
+@pytest.mark.parametrize("name", ["tiny_trained", "tiny_hf", "tiny_odd", "tiny_shift3", "tiny_nocond_p2", "tiny_abspos",
                                   "tiny_learnres_mask", "tiny_obstacle_mask"])
 def test_tiny_models_full_grads(name):
     f, meta = load_fixture(name)
