@@ -45,6 +45,8 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=20.0)
     ap.add_argument("--wire", default="fp32", choices=["bf16", "fp32"], help="gradient all-reduce wire format (N>1)")
+    ap.add_argument("--dp-collective", default="allreduce", choices=["allreduce", "rs_ag"],
+                    help="N>1: one all-reduce per gradient chunk, or reduce-scatter + all-gather (poseidon_amd/dp.py)")
     ap.add_argument("--dp", default="auto", choices=["auto", "overlap", "after"],
                     help="N>1: all-reduce each gradient range from inside the backward as soon as it is final (RCCL on a side "
                          "stream, eager launches), or one chunked all-reduce after the step (works with hipGraph replay); "
@@ -254,8 +256,9 @@ def main():
     tt = torch.randint(0, 8, (B,), device="cuda").float() / 10.0
     kw = dict(pixel_values=pv, time=tt, labels=lab)
 
-    after = GradAllReducer(model, dist, wire=a.wire) if dist is not None else None
-    overlapped = OverlappedGradAllReducer(model, dist, wire=a.wire) if (dist is not None and a.dp != "after") else None
+    after = GradAllReducer(model, dist, wire=a.wire, collective=a.dp_collective) if dist is not None else None
+    overlapped = (OverlappedGradAllReducer(model, dist, wire=a.wire, collective=a.dp_collective)
+                  if (dist is not None and a.dp != "after") else None)
     exchange = [None if dist is None else ("after" if a.dp != "overlap" else "overlap")]   # current mode
     loss_buf = torch.zeros((), device="cuda")
 
@@ -352,6 +355,24 @@ def main():
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax)
     ms = dt / a.steps * 1e3
+    comm = None
+    if dist is not None:   # GPU time of the gradient exchange alone (pack + collective + unpack), outside the timed region
+        if exchange[0] == "overlap":
+            overlapped.timing = []
+            for _ in range(3):
+                step()
+            torch.cuda.synchronize()
+            comm = overlapped.comm_ms() / 3
+            overlapped.timing = None
+        else:
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            torch.cuda.synchronize()
+            e0.record()
+            for _ in range(3):
+                after.allreduce()
+            e1.record()
+            torch.cuda.synchronize()
+            comm = e0.elapsed_time(e1) / 3
     overflow = int(model._engine.grad_overflow) if model._engine.grad_overflow is not None else None   # fp16 gradient scale
     total_samples = B * world * a.steps
     value = total_samples / dt
@@ -400,7 +421,9 @@ def main():
                "dtype": a.compute, "data": "synthetic",
                "config": {"workload": f"Poseidon-{a.model} fwd+bwd, {a.size}x{a.size}x{ch} grids, per-GPU batch {B}",
                           "global_batch": B * world, "parallelism": f"dp{world}", "graph": bool(use_graph[0]), **mode_info,
-                          "grad_wire": a.wire if world > 1 else None, "grad_exchange": exchange[0], "loss": float(loss_buf),
+                          "grad_wire": a.wire if dist is not None else None, "grad_exchange": exchange[0],
+                          "grad_collective": a.dp_collective if dist is not None else None, "grad_comm_ms_per_step": comm,
+                          "loss": float(loss_buf),
                           "parity": parity, "grad_overflow": overflow, "in_step_launches": launches},
                "roofline": roof}
         if world == 1 and not a.no_cpu_baseline:

@@ -35,6 +35,13 @@ int scot_operand_format(void);
  * Undoes the backward's gradient scale on the gradient arena (the role torch.cuda.amp.GradScaler.unscale_ plays for the
  * reference's fp16 recipe, trainer.py via HF Trainer). */
 int scot_scale_inplace(float* x, size_t n, float scale, int* nonfinite, scot_stream_t stream);
+/* Data-parallel wire format of the gradient arena (the exchange itself is torch.distributed's RCCL all-reduce / reduce-scatter on
+ * the buffers below; reference: DDP's fp32 bucket all-reduce via HF Trainer/accelerate, scOT/train.py):
+ *   scot_dp_pack:   wire[i] = bfloat16(scale * src[i])     (scale = 1/world: the mean is taken before the 16-bit sum)
+ *   scot_dp_unpack: dst[i]  = scale * float(wire[i])
+ * src/dst fp32 (32-byte aligned), wire bfloat16 (16-byte aligned) — bfloat16 in BOTH builds of the library. */
+int scot_dp_pack(const float* src, void* wire, size_t n, float scale, scot_stream_t stream);
+int scot_dp_unpack(const void* wire, float* dst, size_t n, float scale, scot_stream_t stream);
 int scot_selftest_tr(scot_stream_t stream); /* 1: ds_read_b64_tr_b16 path verified & on, 0: scalar-gather fallback */
 void scot_set_use_tr(int v);
 int scot_get_use_tr(void);

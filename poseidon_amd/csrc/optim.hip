@@ -109,3 +109,53 @@ extern "C" int scot_adamw_step(float* params, const float* grads, float* exp_avg
                      beta1, beta2, eps, (float)bc1, (float)(1.0 / sqrt(bc2)), clip);
   return scot_check_launch();
 }
+
+// ------------------------------------------------------------------------------------------------------------------------
+// Data-parallel wire format (poseidon_amd/dp.py): the fp32 gradient arena goes over xGMI as bfloat16 (half the bytes; the
+// reference's DDP sends fp32 — reference scOT/train.py via HF Trainer/accelerate).  One pass each way, the mean's 1/N folded in
+// (the first version used two torch elementwise kernels per chunk plus a div).  ALWAYS bfloat16 (gradient range), whatever
+// 16-bit operand format this build of the library computes with.
+typedef __bf16 wire_bf16x2_t __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ uint32_t wire_pack2(float lo, float hi) {
+  const f32x2_t v = {lo, hi};
+  return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, wire_bf16x2_t));
+}
+// wire[i] = bf16(scale · src[i])
+__global__ __launch_bounds__(256) void dp_pack_kernel(const float* __restrict__ src, uint16_t* __restrict__ wire, size_t n, float scale) {
+  const size_t n8 = n / 8, stride = (size_t)gridDim.x * 256;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n8; i += stride) {
+    const float4 a = ((const float4*)src)[2 * i], b = ((const float4*)src)[2 * i + 1];
+    ((uint4*)wire)[i] = make_uint4(wire_pack2(a.x * scale, a.y * scale), wire_pack2(a.z * scale, a.w * scale),
+                                   wire_pack2(b.x * scale, b.y * scale), wire_pack2(b.z * scale, b.w * scale));
+  }
+  for (size_t i = n8 * 8 + (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += stride)
+    wire[i] = (uint16_t)(wire_pack2(src[i] * scale, 0.f) & 0xffffu);
+}
+// dst[i] = scale · float(wire[i])
+__global__ __launch_bounds__(256) void dp_unpack_kernel(const uint16_t* __restrict__ wire, float* __restrict__ dst, size_t n, float scale) {
+  const size_t n8 = n / 8, stride = (size_t)gridDim.x * 256;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n8; i += stride) {
+    const uint4 u = ((const uint4*)wire)[i];
+    ((float4*)dst)[2 * i] = make_float4(__uint_as_float(u.x << 16) * scale, __uint_as_float(u.x & 0xffff0000u) * scale,
+                                        __uint_as_float(u.y << 16) * scale, __uint_as_float(u.y & 0xffff0000u) * scale);
+    ((float4*)dst)[2 * i + 1] = make_float4(__uint_as_float(u.z << 16) * scale, __uint_as_float(u.z & 0xffff0000u) * scale,
+                                            __uint_as_float(u.w << 16) * scale, __uint_as_float(u.w & 0xffff0000u) * scale);
+  }
+  for (size_t i = n8 * 8 + (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += stride)
+    dst[i] = __uint_as_float(((uint32_t)wire[i]) << 16) * scale;
+}
+// include/scot_hip.h: scot_dp_pack / scot_dp_unpack (src / dst 32-byte aligned, wire 16-byte aligned)
+extern "C" int scot_dp_pack(const float* src, void* wire, size_t n, float scale, hipStream_t s) {
+  if (n == 0) return SCOT_OK;
+  if ((((uintptr_t)src) & 31) || (((uintptr_t)wire) & 15)) return SCOT_ERR_SHAPE;
+  size_t blocks = (n / 8 + 255) / 256; if (blocks > 4096) blocks = 4096; if (blocks == 0) blocks = 1;
+  hipLaunchKernelGGL(dp_pack_kernel, dim3((unsigned)blocks), dim3(256), 0, s, src, (uint16_t*)wire, n, scale);
+  return scot_check_launch();
+}
+extern "C" int scot_dp_unpack(const void* wire, float* dst, size_t n, float scale, hipStream_t s) {
+  if (n == 0) return SCOT_OK;
+  if ((((uintptr_t)dst) & 31) || (((uintptr_t)wire) & 15)) return SCOT_ERR_SHAPE;
+  size_t blocks = (n / 8 + 255) / 256; if (blocks > 4096) blocks = 4096; if (blocks == 0) blocks = 1;
+  hipLaunchKernelGGL(dp_unpack_kernel, dim3((unsigned)blocks), dim3(256), 0, s, (const uint16_t*)wire, dst, n, scale);
+  return scot_check_launch();
+}

@@ -41,15 +41,27 @@ def group_ranges(arena, groups: List[str]) -> List[Tuple[str, int, int]]:
 
 
 class GradAllReducer:
-    def __init__(self, model, dist, wire: str = "fp32", chunk_mb: int = 128, group=None):
+    """wire: "fp32" (the reference's DDP semantics) or "bf16" (half the xGMI bytes: one HIP pass packs 1/N·g into bfloat16,
+    the sum runs on the 16-bit buffer, one pass unpacks — scot_dp_pack / scot_dp_unpack).
+    collective: "allreduce" (one RCCL all-reduce per chunk) or "rs_ag" (reduce-scatter + all-gather per chunk: the same ring
+    traffic, but every rank owns the mean of 1/N of each chunk between the two halves — the seam a sharded optimizer step
+    hangs on; backends without reduce_scatter_tensor (gloo, CPU tests) take the same bookkeeping through all_reduce)."""
+
+    def __init__(self, model, dist, wire: str = "fp32", chunk_mb: int = 128, group=None, collective: str = "allreduce"):
+        if wire not in ("fp32", "bf16") or collective not in ("allreduce", "rs_ag"):
+            raise ValueError("wire: fp32 | bf16; collective: allreduce | rs_ag")
         self.model = model
         self.dist = dist
         self.group = group
         self.world = dist.get_world_size(group) if dist is not None else 1
+        self.rank = dist.get_rank(group) if dist is not None else 0
         self.wire = wire
+        self.collective = collective
         self.chunk = chunk_mb * (1 << 20) // 4
         self._wire_buf: Optional[torch.Tensor] = None
+        self._pad_buf: Optional[torch.Tensor] = None
         self.comm_stream = None
+        self.bytes_on_wire = 0          # per rank, payload handed to the collectives since construction
 
     def _flat(self) -> torch.Tensor:
         return self.model.flat_grads()
@@ -60,22 +72,53 @@ class GradAllReducer:
     def ranges_in_backward_order(self):
         return group_ranges(self.model._arena, backward_order_groups(self.model.config))
 
+    def _sum(self, buf: torch.Tensor):
+        """In-place sum over ranks of `buf` (a multiple of `world` elements long when collective == "rs_ag")."""
+        self.bytes_on_wire += buf.numel() * buf.element_size()
+        if self.collective == "rs_ag":
+            shard = buf.view(self.world, -1)[self.rank]
+            if hasattr(self.dist, "reduce_scatter_tensor") and self.dist.get_backend(self.group) != "gloo":
+                self.dist.reduce_scatter_tensor(shard, buf, group=self.group)        # this rank now owns its shard's sum
+                self.dist.all_gather_into_tensor(buf, shard, group=self.group)
+            else:   # same data flow on a backend without reduce-scatter: sum, keep the own shard, gather the shards
+                self.dist.all_reduce(buf, group=self.group)
+                parts = [torch.empty_like(shard) for _ in range(self.world)]
+                self.dist.all_gather(parts, shard.clone(), group=self.group)
+                for r, pt in enumerate(parts):
+                    buf.view(self.world, -1)[r].copy_(pt)
+        else:
+            self.dist.all_reduce(buf, group=self.group)
+
     def reduce_range(self, start: int, end: int):
         """Mean all-reduce of arena[start:end] on the current stream."""
+        from . import ops
         flat = self._flat()
+        inv = 1.0 / self.world
         for s in range(start, end, self.chunk):
             e = min(end, s + self.chunk)
             seg = flat[s:e]
+            n = e - s
+            npad = (n + self.world * 8 - 1) // (self.world * 8) * (self.world * 8) if self.collective == "rs_ag" else n
             if self.wire == "bf16":
-                if self._wire_buf is None or self._wire_buf.numel() < self.chunk:
-                    self._wire_buf = torch.empty(self.chunk, dtype=torch.bfloat16, device=flat.device)
-                w = self._wire_buf[: e - s]
-                w.copy_(seg)                                   # fp32 -> bf16 (one pass)
-                self.dist.all_reduce(w, group=self.group)      # sum on the wire
-                torch.mul(w, 1.0 / self.world, out=seg)        # bf16 -> fp32 and the mean's 1/N in the same pass
+                if self._wire_buf is None or self._wire_buf.numel() < self.chunk + self.world * 8:
+                    self._wire_buf = torch.zeros(self.chunk + self.world * 8, dtype=torch.bfloat16, device=flat.device)
+                w = self._wire_buf[:npad]
+                if npad != n:
+                    w[n:].zero_()
+                ops.dp_pack(seg, w, inv)                       # fp32 -> bf16 with the mean's 1/N, one HIP pass
+                self._sum(w)                                   # sum on the wire
+                ops.dp_unpack(w, seg, 1.0)                     # bf16 -> fp32, one HIP pass
+            elif npad != n:
+                if self._pad_buf is None or self._pad_buf.numel() < self.chunk + self.world * 8:
+                    self._pad_buf = torch.zeros(self.chunk + self.world * 8, dtype=torch.float32, device=flat.device)
+                w = self._pad_buf[:npad]
+                w[n:].zero_()
+                torch.mul(seg, inv, out=w[:n])
+                self._sum(w)
+                seg.copy_(w[:n])
             else:
-                seg.div_(self.world)
-                self.dist.all_reduce(seg, group=self.group)
+                seg.mul_(inv)
+                self._sum(seg)
 
     def allreduce(self):
         flat = self._flat()
@@ -87,12 +130,13 @@ class OverlappedGradAllReducer(GradAllReducer):
     (engine.on_grads_final), so that only the last range (the small C=96 encoder stage + embeddings) is exposed.
     Roughly 73 % of Poseidon-B's gradient bytes (the two C=768 stages) are final by mid-backward."""
 
-    def __init__(self, model, dist, wire: str = "fp32", chunk_mb: int = 64, group=None):
-        super().__init__(model, dist, wire=wire, chunk_mb=chunk_mb, group=group)
+    def __init__(self, model, dist, wire: str = "fp32", chunk_mb: int = 64, group=None, collective: str = "allreduce"):
+        super().__init__(model, dist, wire=wire, chunk_mb=chunk_mb, group=group, collective=collective)
         self._ranges = None
         self.comm_stream = torch.cuda.Stream()
         self._pending = False
         self._hooked = False
+        self.timing = None      # set to [] to collect (prefix, start event, end event) per range on the comm stream
 
     def attach(self):
         self.model._engine.on_grads_final = self._on_final
@@ -116,8 +160,19 @@ class OverlappedGradAllReducer(GradAllReducer):
         ev.record()
         self.comm_stream.wait_event(ev)
         with torch.cuda.stream(self.comm_stream):
+            if self.timing is not None:
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
             self.reduce_range(rng[0], rng[1])
+            if self.timing is not None:
+                e1.record()
+                self.timing.append((prefix, e0, e1))
         self._pending = True
+
+    def comm_ms(self) -> float:
+        """GPU time the collectives (incl. pack / unpack) took on the comm stream since `timing` was last reset."""
+        t, self.timing = (self.timing or []), []
+        return sum(a.elapsed_time(b) for _, a, b in t)
 
     def finish(self):
         if self._pending:

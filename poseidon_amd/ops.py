@@ -320,6 +320,20 @@ def cast(src, dst):
     _lib.check(L().scot_scale_residual(ptr(src), dt(src), None, None, 0, ptr(dst), dt(dst), 1, n, stream()), "scot_scale_residual(cast)")
 
 
+def dp_pack(src, wire, scale: float):
+    """wire (bfloat16) <- scale * src (fp32): the gradient arena's wire format for the data-parallel exchange, one pass."""
+    if src.dtype != torch.float32 or wire.dtype != torch.bfloat16 or wire.numel() < src.numel():
+        raise TypeError("dp_pack: fp32 source, bfloat16 wire buffer of at least the same length")
+    _lib.check(L().scot_dp_pack(ptr(src), ptr(wire), src.numel(), float(scale), stream()), "scot_dp_pack")
+
+
+def dp_unpack(wire, dst, scale: float = 1.0):
+    """dst (fp32) <- scale * wire (bfloat16)."""
+    if dst.dtype != torch.float32 or wire.dtype != torch.bfloat16 or wire.numel() < dst.numel():
+        raise TypeError("dp_unpack: bfloat16 wire buffer, fp32 destination")
+    _lib.check(L().scot_dp_unpack(ptr(wire), ptr(dst), dst.numel(), float(scale), stream()), "scot_dp_unpack")
+
+
 def scale_inplace(x, scale: float, nonfinite=None):
     """x (flat fp32, 16-byte aligned) *= scale; nonfinite (int32[1], optional) counts waves that saw Inf/NaN."""
     _lib.check(L().scot_scale_inplace(ptr(x), x.numel(), float(scale), ptr(nonfinite), stream()), "scot_scale_inplace")

@@ -47,9 +47,23 @@ def test_backward_order_ranges_cover_arena():
         assert "encoder.layers.0.blocks.0.attention.self.qkv_weight" in ar.offsets
 
 
-def _worker(rank, world, port, wire, out):
+def _emu_ops():
+    """The wire pack / unpack are HIP kernels (scot_dp_pack / scot_dp_unpack): on CPU tensors they run from the emulated build."""
+    import sys
+    here = os.path.dirname(os.path.abspath(__file__))
+    sys.path.insert(0, os.path.join(here, "hipemu"))
+    import emu_session
+    from poseidon_amd import ops
+    lib = emu_session.load_emu()
+    ops.L, ops.stream = (lambda: lib), (lambda: None)
+    ops.ptr = lambda t: None if t is None else t.data_ptr()
+
+
+def _worker(rank, world, port, wire, collective, out):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
+    if wire == "bf16":
+        _emu_ops()
     dist.init_process_group("gloo", rank=rank, world_size=world)
     cfg = ScOTConfig(**TINY)
     m = _FakeModel(cfg)
@@ -57,8 +71,8 @@ def _worker(rank, world, port, wire, out):
     base = torch.arange(n, dtype=torch.float32) / n
     m._arena.grad.copy_(base * (rank + 1))           # rank r holds (r+1)*base → mean = 1.5*base
     m._arena.data.fill_(float(rank + 7))
-    red = GradAllReducer(m, dist, wire=wire, chunk_mb=1)
-    red.chunk = 1000                                  # force many chunks
+    red = GradAllReducer(m, dist, wire=wire, chunk_mb=1, collective=collective)
+    red.chunk = 1000                                  # force many chunks (1000 % (2 * 8) != 0: rs_ag pads every chunk)
     red.broadcast_parameters(src=0)
     assert float(m._arena.data.min()) == 7.0 and float(m._arena.data.max()) == 7.0
     red.allreduce()
@@ -78,11 +92,19 @@ def _worker(rank, world, port, wire, out):
         open(out, "w").write("ok")
 
 
-@pytest.mark.parametrize("wire", ["fp32", "bf16"])
-def test_two_rank_mean_allreduce(tmp_path, wire):
-    port = 29500 + (os.getpid() % 2000) + (0 if wire == "fp32" else 1)
+@pytest.mark.parametrize("wire,collective", [("fp32", "allreduce"), ("bf16", "allreduce"), ("fp32", "rs_ag"), ("bf16", "rs_ag")])
+def test_two_rank_mean_allreduce(tmp_path, wire, collective):
+    if wire == "bf16":
+        import shutil
+        import sys
+        sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "hipemu"))
+        import build_emu
+        if not (os.path.exists(build_emu.CLANG) or shutil.which(build_emu.CLANG)):
+            pytest.skip("no host clang with __bf16 vector support")
+        build_emu.build_cached()                              # once, before the two ranks race for it
+    port = 29500 + (os.getpid() % 2000) + ["fp32allreduce", "bf16allreduce", "fp32rs_ag", "bf16rs_ag"].index(wire + collective)
     out = str(tmp_path / "ok")
-    mp.spawn(_worker, args=(2, port, wire, out), nprocs=2, join=True)
+    mp.spawn(_worker, args=(2, port, wire, collective, out), nprocs=2, join=True)
     assert open(out).read() == "ok"
 
 
