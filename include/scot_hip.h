@@ -35,6 +35,11 @@ int scot_operand_format(void);
  * Undoes the backward's gradient scale on the gradient arena (the role torch.cuda.amp.GradScaler.unscale_ plays for the
  * reference's fp16 recipe, trainer.py via HF Trainer). */
 int scot_scale_inplace(float* x, size_t n, float scale, int* nonfinite, scot_stream_t stream);
+/* Second half of the spectral resize (ref:1293-1316, `_downsample` / `_upsample`: fft2 -> crop / zero-pad the centred spectrum ->
+ * ifft2 -> real part), restated as the linear map Y = Pr X Pr^T - Pi X Pi^T (P built on the host, scOT/model.py).  The first half
+ * U = X [Pr; Pi]^T is a scot_gemm (NT, compute 0); this entry does Y[b] = Pr·U[b,:,:t] - Pi·U[b,:,t:] per image.
+ * U [nimg, s, 2t], Pr / Pi [t, s], Y [nimg, t, t], all fp32; s <= 512. */
+int scot_spectral_apply(const float* U, const float* Pr, const float* Pi, float* Y, int nimg, int s, int t, scot_stream_t stream);
 /* Data-parallel wire format of the gradient arena (the exchange itself is torch.distributed's RCCL all-reduce / reduce-scatter on
  * the buffers below; reference: DDP's fp32 bucket all-reduce via HF Trainer/accelerate, scOT/train.py):
  *   scot_dp_pack:   wire[i] = bfloat16(scale * src[i])     (scale = 1/world: the mean is taken before the 16-bit sum)

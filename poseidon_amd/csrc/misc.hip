@@ -786,6 +786,44 @@ extern "C" int scot_cpb_bwd(const float* coords, const float* w0, const float* b
   return scot_check_launch();
 }
 
+// ------------------------------------------------------------------ spectral resize, second half  (model.py:1293-1316)
+// The reference resamples by FFT -> crop / zero-pad of the centred spectrum -> inverse FFT -> real part.  For real input that is
+// the LINEAR map  Y = Re(P X P^T) = Pr X Pr^T - Pi X Pi^T  with the (t x s) matrix
+//     P[m, n] = (1/s) Σ_{k = -q/2}^{q/2 - 1} exp(2 pi i k (m/t - n/s)),   q = min(s, t)
+// (built in fp64 on the host, scOT/model.py; Pi != 0 because the kept band is not symmetric: -q/2 is in, +q/2 is not).
+// First half  U = X [Pr; Pi]^T  ([nimg·s, 2t]) is an NT GEMM on the exact fp32 MFMA (scot_gemm); this kernel does the per-image
+// left multiplication  Y[b] = Pr U_r[b] - Pi U_i[b]  — 2·t·s·t FMAs per image, HBM-bound on U.
+__global__ __launch_bounds__(256) void spectral_apply_kernel(const float* __restrict__ U, const float* __restrict__ Pr,
+                                                             const float* __restrict__ Pi, float* __restrict__ Y, int s, int t) {
+  extern __shared__ float sp[];                  // [16][s] of Pr then [16][s] of Pi: the 16 output rows of this workgroup
+  const int b = blockIdx.x, m0 = blockIdx.y * 16;
+  const int ty = threadIdx.x >> 4, tx = threadIdx.x & 15;
+  for (int i = threadIdx.x; i < 16 * s; i += 256) {
+    const int m = min(m0 + i / s, t - 1), r = i % s;
+    sp[i] = Pr[(size_t)m * s + r];
+    sp[16 * s + i] = Pi[(size_t)m * s + r];
+  }
+  __syncthreads();
+  const float* Ub = U + (size_t)b * s * 2 * t;
+  const float* pr = sp + ty * s;
+  const float* pi = sp + 16 * s + ty * s;
+  for (int j0 = 0; j0 < t; j0 += 16) {
+    const int j = min(j0 + tx, t - 1);
+    float acc = 0.f;
+    for (int r = 0; r < s; ++r) {
+      acc = fmaf(pr[r], Ub[(size_t)r * 2 * t + j], acc);
+      acc = fmaf(-pi[r], Ub[(size_t)r * 2 * t + t + j], acc);
+    }
+    if (m0 + ty < t && j0 + tx < t) Y[((size_t)b * t + m0 + ty) * t + j0 + tx] = acc;
+  }
+}
+extern "C" int scot_spectral_apply(const float* U, const float* Pr, const float* Pi, float* Y, int nimg, int s, int t, hipStream_t st) {
+  if (nimg <= 0 || s <= 0 || t <= 0) return SCOT_ERR_SHAPE;
+  if ((size_t)32 * s * sizeof(float) > 64 * 1024) return SCOT_ERR_UNSUPPORTED;     // s <= 512
+  hipLaunchKernelGGL(spectral_apply_kernel, dim3(nimg, (t + 15) / 16), dim3(256), (size_t)32 * s * sizeof(float), st, U, Pr, Pi, Y, s, t);
+  return scot_check_launch();
+}
+
 // ------------------------------------------------------------------ library state / self test
 int g_scot_use_tr = 1;
 

@@ -56,6 +56,7 @@ PROTOTYPES = {
     "scot_head_finalize": [P, P, I, P, P, I, P, P, I, I, I, I, P],
     "scot_loss_finish": [P, P, I, I, P, P],
     "scot_loss_bwd": [P, P, P, I, P, P, P, I, I, P, P, I, I, I, I, P],
+    "scot_spectral_apply": [P, P, P, P, I, I, I, P],
     "scot_dp_pack": [P, P, Z, F, P],
     "scot_dp_unpack": [P, P, Z, F, P],
     "scot_optim_blocks": [Z],

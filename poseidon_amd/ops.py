@@ -320,6 +320,11 @@ def cast(src, dst):
     _lib.check(L().scot_scale_residual(ptr(src), dt(src), None, None, 0, ptr(dst), dt(dst), 1, n, stream()), "scot_scale_residual(cast)")
 
 
+def spectral_apply(U, Pr, Pi, Y, nimg: int, s: int, t: int):
+    """Y[b] = Pr · U[b, :, :t] - Pi · U[b, :, t:]  (U: [nimg, s, 2t], Pr/Pi: [t, s], Y: [nimg, t, t]; all fp32)."""
+    _lib.check(L().scot_spectral_apply(ptr(U), ptr(Pr), ptr(Pi), ptr(Y), nimg, s, t, stream()), "scot_spectral_apply")
+
+
 def dp_pack(src, wire, scale: float):
     """wire (bfloat16) <- scale * src (fp32): the gradient arena's wire format for the data-parallel exchange, one pass."""
     if src.dtype != torch.float32 or wire.dtype != torch.bfloat16 or wire.numel() < src.numel():

@@ -361,22 +361,13 @@ class ScOT(nn.Module):
     # ------------------------------------------------------------------------------------------ forward
     @staticmethod
     def _downsample(image, target_size):
-        """Spectral down-sampling (reference model.py:1293-1300); rocFFT via torch.fft, not on the timed hot path."""
-        size = image.shape[-2]
-        freqs = torch.fft.fftfreq(size, d=1 / size, device=image.device)
-        sel = torch.logical_and(freqs >= -target_size / 2, freqs <= target_size / 2 - 1)
-        hat = torch.fft.fft2(image, norm="forward")[:, :, sel, :][:, :, :, sel]
-        return torch.fft.ifft2(hat, norm="forward").real.contiguous()
+        """Spectral down-sampling (reference model.py:1293-1300) on the native kernels (see spectral_resize)."""
+        return spectral_resize(image, target_size)
 
     @staticmethod
     def _upsample(image, target_size):
         """Spectral up-sampling (reference model.py:1302-1316)."""
-        size = image.shape[-2]
-        hat = torch.fft.fftshift(torch.fft.fft2(image, norm="forward"))
-        pad = (target_size - size) // 2
-        real = nn.functional.pad(hat.real, (pad, pad, pad, pad), value=0.0)
-        imag = nn.functional.pad(hat.imag, (pad, pad, pad, pad), value=0.0)
-        return torch.fft.ifft2(torch.fft.ifftshift(torch.complex(real, imag)), norm="forward").real.contiguous()
+        return spectral_resize(image, target_size)
 
     def forward(self, pixel_values=None, time=None, bool_masked_pos=None, head_mask=None, pixel_mask=None, labels=None,
                 output_attentions=None, output_hidden_states=None, return_dict=None):
@@ -468,6 +459,80 @@ class ScOT(nn.Module):
         fd, rd = shp(hd, dec_res)
         fe, re_ = shp(he, enc_res)
         return tuple(fd + fe), tuple(rd + re_), tuple(fe), tuple(re_), tuple(fd), tuple(rd)
+
+
+# ---------------------------------------------------------------------------------------------- spectral resize
+_RESIZE_OPS = {}
+
+
+def resize_operator(s: int, t: int):
+    """The reference resamples square images by  fft2 -> crop (model.py:1293-1300) / centred zero-pad (model.py:1302-1316) of the
+    spectrum -> ifft2 -> real part, with norm="forward".  For a real image that is the linear map  Y = Re(P X P^T)  with
+
+        P[m, n] = (1/s) Σ_{k=-q/2}^{q/2-1} exp(2 pi i k (m/t - n/s)),      q = min(s, t)        (t x s, complex)
+
+    (down: the kept frequencies are fftfreq in [-t/2, t/2-1]; up: the whole source band [-s/2, s/2-1] is embedded in the centre of
+    the target spectrum).  Returns (Re P, Im P) as float64 arrays."""
+    import numpy as np
+    q = min(s, t)
+    k = np.arange(-(q // 2), q - q // 2, dtype=np.float64)
+    if q % 2:   # fftfreq of an odd size is symmetric: -(q-1)/2 .. (q-1)/2
+        k = np.arange(-(q - 1) // 2, (q - 1) // 2 + 1, dtype=np.float64)
+    m = np.arange(t, dtype=np.float64)[:, None, None] / t
+    n = np.arange(s, dtype=np.float64)[None, :, None] / s
+    ph = 2.0 * np.pi * k[None, None, :] * (m - n)
+    return np.cos(ph).sum(-1) / s, np.sin(ph).sum(-1) / s
+
+
+def _resize_mats(s: int, t: int, device):
+    key = (s, t, str(device))
+    m = _RESIZE_OPS.get(key)
+    if m is None:
+        pr, pi = resize_operator(s, t)
+        f = lambda a: torch.as_tensor(a, dtype=torch.float32).contiguous().to(device)
+        # forward: U = X [Pr; Pi]^T then Y = Pr U_r - Pi U_i;  backward (dX = Pr^T dY Pr - Pi^T dY Pi): the same with P^T
+        m = dict(cat=f(__import__("numpy").concatenate([pr, pi], 0)), pr=f(pr), pi=f(pi),
+                 catT=f(__import__("numpy").concatenate([pr.T, pi.T], 0)), prT=f(pr.T), piT=f(pi.T))
+        _RESIZE_OPS[key] = m
+    return m
+
+
+def _resize_apply(x, cat, pr, pi, s, t):
+    from poseidon_amd import ops
+    nimg = x.numel() // (s * s)
+    U = torch.empty(nimg * s, 2 * t, dtype=torch.float32, device=x.device)
+    ops.linear_fwd(ops.F32, x.reshape(nimg * s, s), cat, U)          # exact fp32 MFMA
+    Y = torch.empty(nimg, t, t, dtype=torch.float32, device=x.device)
+    ops.spectral_apply(U, pr, pi, Y, nimg, s, t)
+    return Y
+
+
+class _SpectralResize(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, image, target):
+        s = image.shape[-1]
+        if image.shape[-2] != s:
+            raise ValueError("spectral resize assumes square images (as the reference does)")
+        m = _resize_mats(s, target, image.device)
+        ctx.m, ctx.s, ctx.t = m, s, target
+        x = image.to(torch.float32).contiguous()
+        return _resize_apply(x, m["cat"], m["pr"], m["pi"], s, target).view(*image.shape[:-2], target, target)
+
+    @staticmethod
+    def backward(ctx, g):
+        m, s, t = ctx.m, ctx.s, ctx.t
+        dx = _resize_apply(g.to(torch.float32).contiguous(), m["catT"], m["prT"], m["piT"], t, s)
+        return dx.view(*g.shape[:-2], s, s), None
+
+
+def spectral_resize(image: torch.Tensor, target_size: int) -> torch.Tensor:
+    """reference ScOT._downsample / _upsample (model.py:1293-1316) as two launches of the native library: an NT GEMM on the exact
+    fp32 MFMA and scot_spectral_apply; differentiable (the adjoint is the same pair with the transposed operator)."""
+    if not image.is_cuda:
+        raise ScotLibraryError("spectral_resize needs CUDA(HIP) tensors: no CPU path exists in the product")
+    if image.shape[-1] == target_size:
+        return image
+    return _SpectralResize.apply(image, int(target_size))
 
 
 def _torch_loss(pred, labels, p, groups):

@@ -189,3 +189,20 @@ def test_fused_mlp_and_projection_forward(gpu_test_bodies, train, cond, B, L, C)
 def test_fused_mlp_and_projection_backward(gpu_test_bodies, cond, B, L, C):
     gpu_test_bodies.test_mlp_block_bwd_fused(cond, B, L, C)
     gpu_test_bodies.test_proj_cln_bwd_fused(cond, B, L, C)
+
+
+@pytest.mark.parametrize("s,t", [(32, 64), (32, 16), (64, 32), (24, 40)])
+def test_spectral_resize_native(emu, s, t):
+    """scOT.model.spectral_resize (NT GEMM on the fp32 MFMA + scot_spectral_apply) == the reference's fft2 -> crop / pad -> ifft2
+    (model.py:1293-1316, restated in oracle.scot_cpu.spectral_resize with torch.fft), forward and gradient."""
+    from oracle.scot_cpu import spectral_resize as ref_resize
+    from scOT.model import _SpectralResize
+    x = rnd(2, 3, s, s).requires_grad_(True)
+    y = _SpectralResize.apply(x, t)
+    xr = x.detach().double().requires_grad_(True)
+    yr = ref_resize(xr, t)
+    assert tuple(y.shape) == (2, 3, t, t) and rel(y.detach(), yr.detach()) < 2e-6
+    g = rnd(2, 3, t, t, seed=5)
+    y.backward(g)
+    yr.backward(g.double())
+    assert rel(x.grad, xr.grad) < 2e-6

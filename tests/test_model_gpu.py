@@ -467,3 +467,34 @@ def test_nonzero_dropout_is_refused():
     f, meta = load_fixture("tiny_trained")
     with pytest.raises(NotImplementedError):
         ScOT(ScOTConfig(**dict(meta["cfg"], hidden_dropout_prob=0.1)))
+
+
+def test_metrics_on_device_tensors_match_reference_pins():
+    """SURVEY §8(f) rank 2: the evaluation metrics run on the GPU tensors a rollout returns (only the error vectors cross PCIe);
+    same pins as the CPU test (values produced by the reference's metrics module, tests/golden/make_metrics_pins.py)."""
+    import json
+    import os
+    from conftest import GOLDEN
+    from poseidon_amd.synth import closed_form_tensor
+    from scOT import metrics as M
+    pins = json.load(open(os.path.join(GOLDEN, "metrics_pins.json")))
+    pr = torch.as_tensor(np.asarray(closed_form_tensor("metrics:pred", (6, 4, 16, 16), 1.0), dtype=np.float32)).to(DEV)
+    tg = np.asarray(closed_form_tensor("metrics:target", (6, 4, 16, 16), 1.0), dtype=np.float32)
+    tg[3] = 0.0
+    tg = torch.as_tensor(tg).to(DEV)
+
+    def close(a, b, tol=3e-6):
+        a = a.detach().cpu().numpy() if isinstance(a, torch.Tensor) else np.asarray(a)
+        a, b = np.asarray(a, dtype=np.float64), np.asarray(b, dtype=np.float64)
+        return np.all(np.abs(a - b) <= tol * np.maximum(np.abs(b), 1e-30))
+    for p in (1, 2):
+        e = M.lp_error(pr, tg, p=p)
+        assert isinstance(e, torch.Tensor) and e.is_cuda and close(e, pins[f"lp_error_p{p}"])
+        assert close(M.relative_lp_error(pr, tg, p=p), pins[f"relative_lp_error_p{p}"])
+        assert close(M.mean_relative_lp_error(pr, tg, p=p), pins[f"mean_relative_p{p}"])
+        assert close(M.median_relative_lp_error(pr, tg, p=p), pins[f"median_relative_p{p}"])
+    out = M.channel_group_metrics(pr, tg, [0, 1, 3, 4], ["rho", "uv", "p"])
+    for i, n in enumerate(["rho", "uv", "p"]):
+        g = pins[f"group{i}"]
+        assert close(out[n + "/median_relative_l1_error"], g["median_rel"]) and close(out[n + "/mean_relative_l1_error"], g["mean_rel"])
+        assert close(out[n + "/max_relative_l1_error"], g["max_rel"]) and close(out[n + "/median_l1_error"], g["median_abs"])
