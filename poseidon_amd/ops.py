@@ -135,7 +135,7 @@ def gemm(layout: int, compute: int, M: int, N: int, K: int, A, lda: int, B, ldb:
 
 
 def linear_fwd(compute, x, w, out, bias=None, a_gelu=False, gelu_deriv_out=None):
-    """out[M,N] = act(x)[M,K] @ w[N,K]^T + bias;  with gelu_deriv_out: out = gelu(.), gelu_deriv_out = gelu'(.)."""
+    """Out[M,N] = act(x)[M,K] @ w[N,K]^T + bias;  with gelu_deriv_out: out = gelu(.), gelu_deriv_out = gelu'(.)."""
     M = x.numel() // x.shape[-1]
     N, Kw = w.shape[0], w.numel() // w.shape[0]
     gemm(NT, compute, M, N, Kw, x, x.shape[-1], w, Kw, out, out.shape[-1], bias=bias, a_gelu=a_gelu, gelu_deriv_out=gelu_deriv_out)
@@ -223,7 +223,7 @@ def cln_fwd(x, resid, out, mean, rstd, time, gw_w, gw_b, bw_w, bw_b, rows, rows_
 
 def mlp_block_fwd(h16, h, w1, b1, w2, b2, out, out16, act, dact, z, mean, rstd, time, gw_w, gw_b, bw_w, bw_b, sample_scale,
                   rows, rows_per_sample, C, hid, eps) -> bool:
-    """EXPERIMENTAL fused fc1 → GELU → fc2 → cond-LN → residual (csrc/mlp_fused.hip).  False = shape not covered (the
+    """Fused fc1 → GELU → fc2 → cond-LN → residual (csrc/mlp_fused.hip).  False = shape not covered (the
     caller runs the three-kernel path); any other failure raises."""
     rc = L().scot_mlp_block_fwd(ptr(h16), ptr(h), ptr(w1), ptr(b1), ptr(w2), ptr(b2), ptr(out), ptr(out16), ptr(act), ptr(dact),
                                 ptr(z), ptr(mean), ptr(rstd), ptr(time), ptr(gw_w), ptr(gw_b), ptr(bw_w), ptr(bw_b),
@@ -236,7 +236,7 @@ def mlp_block_fwd(h16, h, w1, b1, w2, b2, out, out16, act, dact, z, mean, rstd, 
 
 def mlp_block_bwd(g, g_out, z, mean, rstd, time, gw_w, gw_b, sample_scale, dact, w1, w2, dz, du, d_gw_w, d_gw_b, d_bw_w, d_bw_b,
                   rows, rows_per_sample, C, hid) -> bool:
-    """EXPERIMENTAL fused cond-LN backward → dgrad fc2 (·gelu') → dgrad fc1 (+ g) (csrc/mlp_fused.hip).  False = not covered."""
+    """Fused cond-LN backward → dgrad fc2 (·gelu') → dgrad fc1 (+ g) (csrc/mlp_fused.hip).  False = not covered."""
     rc = L().scot_mlp_block_bwd(ptr(g), ptr(g_out), ptr(z), ptr(mean), ptr(rstd), ptr(time), ptr(gw_w), ptr(gw_b),
                                 ptr(sample_scale), ptr(dact), ptr(w1), ptr(w2), ptr(dz), ptr(du), ptr(d_gw_w), ptr(d_gw_b),
                                 ptr(d_bw_w), ptr(d_bw_b), rows, rows_per_sample, C, hid, stream())
@@ -248,7 +248,7 @@ def mlp_block_bwd(g, g_out, z, mean, rstd, time, gw_w, gw_b, sample_scale, dact,
 
 def proj_cln_fwd(a, w, bias, resid, out, out16, z, mean, rstd, time, gw_w, gw_b, bw_w, bw_b, sample_scale, rows, rows_per_sample, C,
                  eps) -> bool:
-    """EXPERIMENTAL out-projection GEMM with cond-LN + residual in its epilogue (csrc/mlp_fused.hip).  False = not covered."""
+    """Out-projection GEMM with cond-LN + residual in its epilogue (csrc/mlp_fused.hip).  False = not covered."""
     rc = L().scot_proj_cln_fwd(ptr(a), ptr(w), ptr(bias), ptr(resid), ptr(out), ptr(out16), ptr(z), ptr(mean), ptr(rstd), ptr(time),
                                ptr(gw_w), ptr(gw_b), ptr(bw_w), ptr(bw_b), ptr(sample_scale), rows, rows_per_sample, C, float(eps),
                                stream())
@@ -260,7 +260,7 @@ def proj_cln_fwd(a, w, bias, resid, out, out16, z, mean, rstd, time, gw_w, gw_b,
 
 def proj_cln_bwd(g, z, mean, rstd, time, gw_w, gw_b, sample_scale, w, dz, da, d_gw_w, d_gw_b, d_bw_w, d_bw_b, rows, rows_per_sample,
                  C) -> bool:
-    """EXPERIMENTAL cond-LN backward → dgrad of the out-projection in one launch.  False = not covered."""
+    """Cond-LN backward → dgrad of the out-projection in one launch.  False = not covered."""
     rc = L().scot_proj_cln_bwd(ptr(g), ptr(z), ptr(mean), ptr(rstd), ptr(time), ptr(gw_w), ptr(gw_b), ptr(sample_scale), ptr(w),
                                ptr(dz), ptr(da), ptr(d_gw_w), ptr(d_gw_b), ptr(d_bw_w), ptr(d_bw_b), rows, rows_per_sample, C, stream())
     if rc == -3:

@@ -1,6 +1,6 @@
 """CPU execution of HIP kernel SOURCES through tests/hipemu (a host stand-in for hip_runtime.h: the work-items of a block as fibers,
 wave64 cross-lane operations by rendezvous — see tests/hipemu/hip/hip_runtime.h).  Covers the fused block kernels of
-poseidon_amd/csrc/mlp_fused.hip, whose GPU parity tests are still gated (SCOT_EXPERIMENTAL): index algebra, LDS aliasing and
+poseidon_amd/csrc/mlp_fused.hip, (GPU parity: tests/test_kernels_gpu.py): index algebra, LDS aliasing and
 barrier placement are checked here against double-precision loops.  No GPU, no libscot_hip.so: the kernel file is compiled
 as plain C++ by the ROCm clang."""
 import os

@@ -241,8 +241,6 @@ def test_cln_fwd_bwd(cond, xdt, B, L, C):
 
 
 # ----------------------------------------------------------------------------------------------- fused MLP block (experimental)
-@pytest.mark.skipif(__import__("os").environ.get("SCOT_EXPERIMENTAL") != "1",
-                    reason="csrc/mlp_fused.hip was written without GPU time left (round 1): run with SCOT_EXPERIMENTAL=1")
 @pytest.mark.parametrize("train", [True, False])
 @pytest.mark.parametrize("cond", [True, False])
 @pytest.mark.parametrize("B,L,C", [(2, 1024, 96), (3, 200, 96), (64, 1024, 96), (2, 256, 192), (5, 72, 192)])
@@ -297,8 +295,6 @@ def test_mlp_block_fused(train, cond, B, L, C):
     assert rel(fout.view(B, L, C), ref) < 2e-3      # bf16 rounding of gelu(u) right at a rounding boundary differs from fp64's
 
 
-@pytest.mark.skipif(__import__("os").environ.get("SCOT_EXPERIMENTAL") != "1",
-                    reason="csrc/mlp_fused.hip was written without GPU time left (round 1): run with SCOT_EXPERIMENTAL=1")
 @pytest.mark.parametrize("cond", [True, False])
 @pytest.mark.parametrize("B,L,C", [(2, 1024, 96), (3, 192, 96), (64, 1024, 96), (2, 256, 192), (5, 64, 192)])
 def test_mlp_block_bwd_fused(cond, B, L, C):
@@ -356,8 +352,6 @@ def test_mlp_block_bwd_fused(cond, B, L, C):
     assert rel(fdz.float(), rdz) < 6e-3 and rel(fdu.float(), rdu) < 1e-2 and rel(fgh, rgh) < 5e-3
 
 
-@pytest.mark.skipif(__import__("os").environ.get("SCOT_EXPERIMENTAL") != "1",
-                    reason="csrc/mlp_fused.hip was written without GPU time left (round 1): run with SCOT_EXPERIMENTAL=1")
 @pytest.mark.parametrize("train", [True, False])
 @pytest.mark.parametrize("cond", [True, False])
 @pytest.mark.parametrize("B,L,C", [(2, 1024, 96), (3, 200, 96), (64, 1024, 96), (2, 256, 192), (5, 72, 192)])
@@ -390,8 +384,6 @@ def test_proj_cln_fused(train, cond, B, L, C):
         assert rel(fz, z) < 2e-5 and rel(fmean, mean) < 1e-4 and rel(frstd, rstd) < 1e-4
 
 
-@pytest.mark.skipif(__import__("os").environ.get("SCOT_EXPERIMENTAL") != "1",
-                    reason="csrc/mlp_fused.hip was written without GPU time left (round 1): run with SCOT_EXPERIMENTAL=1")
 @pytest.mark.parametrize("cond", [True, False])
 @pytest.mark.parametrize("B,L,C", [(2, 1024, 96), (3, 192, 96), (64, 1024, 96), (2, 256, 192), (5, 64, 192)])
 def test_proj_cln_bwd_fused(cond, B, L, C):
