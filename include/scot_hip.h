@@ -35,6 +35,10 @@ int scot_operand_format(void);
  * Undoes the backward's gradient scale on the gradient arena (the role torch.cuda.amp.GradScaler.unscale_ plays for the
  * reference's fp16 recipe, trainer.py via HF Trainer). */
 int scot_scale_inplace(float* x, size_t n, float scale, int* nonfinite, scot_stream_t stream);
+/* Mask tokens of ScOTEmbeddings (ref:353-359): x[r,:] = mask[r] ? token : x[r,:] in place (x fp32 [rows, C], mask uint8 [rows],
+ * token fp32 [C]); backward: d_token += Σ_r mask[r]·g[r,:], g[r,:] = 0 where mask[r]. */
+int scot_mask_tokens(float* x, const void* mask_u8, const float* token, int rows, int C, scot_stream_t stream);
+int scot_mask_tokens_bwd(float* g, const void* mask_u8, float* d_token, int rows, int C, scot_stream_t stream);
 /* Second half of the spectral resize (ref:1293-1316, `_downsample` / `_upsample`: fft2 -> crop / zero-pad the centred spectrum ->
  * ifft2 -> real part), restated as the linear map Y = Pr X Pr^T - Pi X Pi^T (P built on the host, scOT/model.py).  The first half
  * U = X [Pr; Pi]^T is a scot_gemm (NT, compute 0); this entry does Y[b] = Pr·U[b,:,:t] - Pi·U[b,:,t:] per image.

@@ -281,7 +281,7 @@ def spectral_resize(img: Tensor, target: int) -> Tensor:
 
 def scot_forward(sd: Dict[str, Tensor], cfg, pixel_values: Tensor, time: Optional[Tensor] = None,
                  labels: Optional[Tensor] = None, pixel_mask: Optional[Tensor] = None,
-                 return_intermediates: bool = False, drop_masks=None):
+                 return_intermediates: bool = False, drop_masks=None, bool_masked_pos: Optional[Tensor] = None):
     """ScOT.forward (model.py:1318-1509) → (loss or None, prediction[, intermediates])."""
     if pixel_values is None:
         raise ValueError("pixel_values cannot be None")
@@ -302,6 +302,9 @@ def scot_forward(sd: Dict[str, Tensor], cfg, pixel_values: Tensor, time: Optiona
 
     x, (gh, gw) = patch_embed(sd, pixel_values, patch)
     x = norm(sd, "embeddings.norm", x, time, 1e-5, cond)  # default eps (model.py:342)
+    if bool_masked_pos is not None:      # mask tokens (model.py:353-359)
+        m = bool_masked_pos.reshape(x.shape[0], -1, 1).to(x.dtype)
+        x = x * (1.0 - m) + sd["embeddings.mask_token"].expand(x.shape[0], x.shape[1], -1) * m
     if "embeddings.position_embeddings" in sd:
         x = x + sd["embeddings.position_embeddings"]
     inter["embeddings"] = x

@@ -32,6 +32,36 @@ extern "C" int scot_batch_sum(const void* x, int x_dt, float* out, int batch, si
   return scot_check_launch();
 }
 
+// ------------------------------------------------------------------ mask tokens (model.py:353-359, SimMIM-style masked positions)
+// forward:  x[r, :] = mask[r] ? token : x[r, :]     (== x·(1-m) + token·m for m in {0, 1}),   in place
+// backward: d_token += Σ_r mask[r]·g[r, :];  g[r, :] = mask[r] ? 0 : g[r, :],                  in place
+__global__ void mask_tokens_kernel(float* x, const uint8_t* mask, const float* token, size_t n, int C) {
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
+    if (mask[i / C]) x[i] = token[i % C];
+}
+__global__ __launch_bounds__(256) void mask_tokens_bwd_kernel(float* g, const uint8_t* mask, float* d_token, int rows, int C, int rpb) {
+  const int r0 = blockIdx.x * rpb, r1 = min(rows, r0 + rpb);
+  for (int c = threadIdx.x; c < C; c += 256) {
+    float acc = 0.f;
+    for (int r = r0; r < r1; ++r)
+      if (mask[r]) { acc += g[(size_t)r * C + c]; g[(size_t)r * C + c] = 0.f; }
+    if (acc != 0.f) atomicAdd(&d_token[c], acc);
+  }
+}
+extern "C" int scot_mask_tokens(float* x, const void* mask_u8, const float* token, int rows, int C, hipStream_t s) {
+  if (rows <= 0 || C <= 0) return SCOT_ERR_SHAPE;
+  const size_t n = (size_t)rows * C;
+  size_t blocks = (n + 255) / 256; if (blocks > 8192) blocks = 8192;
+  hipLaunchKernelGGL(mask_tokens_kernel, dim3((unsigned)blocks), dim3(256), 0, s, x, (const uint8_t*)mask_u8, token, n, C);
+  return scot_check_launch();
+}
+extern "C" int scot_mask_tokens_bwd(float* g, const void* mask_u8, float* d_token, int rows, int C, hipStream_t s) {
+  if (rows <= 0 || C <= 0) return SCOT_ERR_SHAPE;
+  const int rpb = 64;
+  hipLaunchKernelGGL(mask_tokens_bwd_kernel, dim3((rows + rpb - 1) / rpb), dim3(256), 0, s, g, (const uint8_t*)mask_u8, d_token, rows, C, rpb);
+  return scot_check_launch();
+}
+
 // ------------------------------------------------------------------ token-grid pad / crop  (model.py:480-498, 563-566)
 // dst[b,y,x,:] = (y < Hs && x < Ws) ? src[b,y,x,:] : 0    for y < Hd, x < Wd
 __global__ void copy2d_kernel(const void* src, int s_dt, void* dst, int d_dt, int B, int Hs, int Ws, int Hd, int Wd, int C) {

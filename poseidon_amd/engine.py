@@ -819,9 +819,12 @@ class ScOTEngine:
         return g
 
     # ------------------------------------------------------------------------------------------ whole model
-    def forward(self, pixel_values, time=None, labels=None, pixel_mask=None, train=True, stochastic=None):
+    def forward(self, pixel_values, time=None, labels=None, pixel_mask=None, train=True, stochastic=None, bool_masked_pos=None):
         prev = ops.use(self.lib_kind)
         try:
+            if bool_masked_pos is not None:       # masked-position pre-training inputs: not a taped signature
+                self.stochastic = bool(train if stochastic is None else stochastic)
+                return self._forward(pixel_values, time, labels, pixel_mask, train, bool_masked_pos)
             return self._forward_step(pixel_values, time, labels, pixel_mask, train, stochastic)
         finally:
             ops.use(prev)
@@ -964,7 +967,7 @@ class ScOTEngine:
         """Forget recorded steps (call after changing anything a tape bakes in: hooks, environment knobs)."""
         self._taped.clear()
 
-    def _forward(self, pixel_values, time=None, labels=None, pixel_mask=None, train=True):
+    def _forward(self, pixel_values, time=None, labels=None, pixel_mask=None, train=True, bool_masked_pos=None):
         cfg, cm = self.cfg, self.compute
         B, Cin, H, W = pixel_values.shape
         if Cin != cfg.num_channels:
@@ -989,11 +992,19 @@ class ScOTEngine:
         wemb = self.TW("embeddings.patch_embeddings.projection.weight").view(C0, Cin * p * p)
         ops.linear_fwd(self.tcm, cols, wemb, e, bias=self.P("embeddings.patch_embeddings.projection.bias"))
         x, x16, est = self.norm_fwd("embeddings.norm", e, None, L0, C0, 1e-5, time, need_stats=train, copy=True)
+        tokmask = None
+        if bool_masked_pos is not None:      # model.py:353-359: masked positions take the learned mask token
+            if "embeddings.mask_token" not in self.arena.offsets:
+                raise ValueError("bool_masked_pos needs a model built with use_mask_token=True")
+            tokmask = self.new(B * L0, dtype=torch.uint8)
+            self.tdo(lambda: tokmask.copy_(bool_masked_pos.reshape(B * L0)))
+            ops.mask_tokens(x, tokmask, self.P("embeddings.mask_token").view(-1), B * L0, C0)
+            x16 = self.to_adt(x)
         if cfg.use_absolute_embeddings:
             ops.add(x, self.P("embeddings.position_embeddings").view(-1), x, period=L0 * C0)
             x16 = self.to_adt(x)
         if train:
-            tape["emb"] = dict(cols=cols, e=e, stats=est)
+            tape["emb"] = dict(cols=cols, e=e, stats=est, tokmask=tokmask)
         hidden_enc = [x]
 
         # encoder (model.py:816-861)
@@ -1219,6 +1230,8 @@ class ScOTEngine:
         Cin = cfg.num_channels
         if cfg.use_absolute_embeddings:
             ops.batch_sum(g, self.G("embeddings.position_embeddings").view(-1), B, L0 * C0)
+        if emb.get("tokmask") is not None:
+            ops.mask_tokens_bwd(g, emb["tokmask"], self.G("embeddings.mask_token").view(-1), B * L0, C0)
         d_e = self.norm_bwd("embeddings.norm", g, emb["e"], emb["stats"], L0, C0, time, self.tadt)
         self.wgrad(self.tcm, d_e, emb["cols"], self.G("embeddings.patch_embeddings.projection.weight").view(C0, Cin * p * p),
                    dbias=self.G("embeddings.patch_embeddings.projection.bias"))

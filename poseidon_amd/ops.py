@@ -284,6 +284,16 @@ def add(a, b, out, period=None):
                "scot_add")
 
 
+def mask_tokens(x, mask_u8, token, rows, C):
+    """x[r, :] = token where mask_u8[r] (in place; reference model.py:353-359)."""
+    _lib.check(L().scot_mask_tokens(ptr(x), ptr(mask_u8), ptr(token), rows, C, stream()), "scot_mask_tokens")
+
+
+def mask_tokens_bwd(g, mask_u8, d_token, rows, C):
+    """d_token += Σ_r mask[r]·g[r, :];  g[r, :] = 0 where mask[r]  (in place)."""
+    _lib.check(L().scot_mask_tokens_bwd(ptr(g), ptr(mask_u8), ptr(d_token), rows, C, stream()), "scot_mask_tokens_bwd")
+
+
 def batch_sum(x, out, batch, period):
     _lib.check(L().scot_batch_sum(ptr(x), dt(x), ptr(out), batch, period, stream()), "scot_batch_sum")
 

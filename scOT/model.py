@@ -124,9 +124,10 @@ class _ScOTFunction(torch.autograd.Function):
     kernels directly into the gradient arena whose slices are the parameters' `.grad` (no per-tensor AccumulateGrad)."""
 
     @staticmethod
-    def forward(ctx, anchor, model, pixel_values, time, labels, pixel_mask):
+    def forward(ctx, anchor, model, pixel_values, time, labels, pixel_mask, bool_masked_pos=None):
         # activations are kept because a gradient was asked for; stochastic depth follows module.training (HF:565-586)
-        loss, pred, tape = model._engine.forward(pixel_values, time, labels, pixel_mask, train=True, stochastic=model.training)
+        loss, pred, tape = model._engine.forward(pixel_values, time, labels, pixel_mask, train=True, stochastic=model.training,
+                                                 bool_masked_pos=bool_masked_pos)
         ctx.model, ctx.tape = model, tape
         ctx.has_loss = loss is not None
         ctx.set_materialize_grads(False)  # unused outputs arrive as None instead of zero tensors
@@ -147,7 +148,7 @@ class _ScOTFunction(torch.autograd.Function):
                   else torch.zeros(1, device=model._arena.data.device))
         model._engine.backward(tape, dl, dpred)
         model._after_backward()
-        return None, None, None, None, None, None
+        return None, None, None, None, None, None, None
 
 
 class ScOT(nn.Module):
@@ -161,8 +162,6 @@ class ScOT(nn.Module):
             raise ValueError("residual_model must be 'convnext' or 'resnet'")
         if config.residual_model != "convnext":
             raise NotImplementedError("residual_model='resnet' is unused by every preset and out of scope (SURVEY.md §8a row 18)")
-        if use_mask_token:
-            raise NotImplementedError("mask tokens (bool_masked_pos) are unused by every preset and not implemented")
         if config.image_size % config.patch_size:
             raise ValueError("image_size must be a multiple of patch_size")
         if config.hidden_dropout_prob or config.attention_probs_dropout_prob:
@@ -180,10 +179,12 @@ class ScOT(nn.Module):
         grid, enc, dec = stage_plan(cfg)
 
         self.embeddings = _Holder()
-        self.embeddings.patch_embeddings = _Holder()
-        self.embeddings.patch_embeddings.projection = nn.Conv2d(cfg.num_channels, c0, kernel_size=p, stride=p)
+        if use_mask_token:      # reference model.py:323-327 (own parameters of `embeddings` register before its children)
+            self.embeddings.mask_token = nn.Parameter(torch.zeros(1, 1, c0))
         if cfg.use_absolute_embeddings:
             self.embeddings.position_embeddings = nn.Parameter(torch.zeros(1, grid[0] * grid[1], c0))
+        self.embeddings.patch_embeddings = _Holder()
+        self.embeddings.patch_embeddings.projection = nn.Conv2d(cfg.num_channels, c0, kernel_size=p, stride=p)
         self.embeddings.norm = _norm(cfg, c0)
 
         self.encoder = _Holder()
@@ -216,7 +217,8 @@ class ScOT(nn.Module):
             else nn.ModuleList([nn.Identity()]) for i, depth in enumerate(cfg.skip_connections)])
 
         self._init_weights()
-        self._shapes = param_shapes(cfg)
+        self.use_mask_token = bool(use_mask_token)
+        self._shapes = param_shapes(cfg, use_mask_token=self.use_mask_token)
         got = OrderedDict((k, tuple(v.shape)) for k, v in self.named_parameters())
         if list(got.items()) != list(self._shapes.items()):  # schema self-check
             raise AssertionError("parameter schema drifted from poseidon_amd.geometry.param_shapes")
@@ -377,8 +379,8 @@ class ScOT(nn.Module):
             raise ValueError("pixel_values cannot be None")
         if output_attentions or (output_attentions is None and cfg.output_attentions):
             raise NotImplementedError("attention probabilities are never materialised by the fused kernel")
-        if bool_masked_pos is not None:
-            raise NotImplementedError("mask tokens are not implemented")
+        if bool_masked_pos is not None and not self.use_mask_token:
+            raise ValueError("bool_masked_pos needs ScOT(config, use_mask_token=True) (reference model.py:323-327, 353-359)")
         if head_mask is not None:
             raise NotImplementedError("head_mask is not implemented")
         if not pixel_values.is_cuda:
@@ -400,15 +402,20 @@ class ScOT(nn.Module):
         if resized:
             pv = self._upsample(pv, cfg.image_size) if in_size < cfg.image_size else self._downsample(pv, cfg.image_size)
         want_grad = torch.is_grad_enabled() and any(p.requires_grad for p in self._params)
+        bmp = None
+        if bool_masked_pos is not None:
+            if resized:
+                raise ValueError("bool_masked_pos indexes the patch grid of config.image_size: no spectral resize with it")
+            bmp = bool_masked_pos.to(device=dev).reshape(B, -1).contiguous()
         if resized and (lab is not None or pixel_mask is not None):
             # reference order (model.py:1416-1484): resize the prediction back first, then mask + loss at input resolution
             loss, pred = self._forward_resized(pv, t, lab, pixel_mask, in_size, want_grad)
         elif want_grad:
-            loss, pred = _ScOTFunction.apply(self._anchor, self, pv, t, lab, pixel_mask)
+            loss, pred = _ScOTFunction.apply(self._anchor, self, pv, t, lab, pixel_mask, bmp)
             if lab is None:
                 loss = None
         else:
-            loss, pred, _ = self._engine.forward(pv, t, lab, pixel_mask, train=False, stochastic=self.training)
+            loss, pred, _ = self._engine.forward(pv, t, lab, pixel_mask, train=False, stochastic=self.training, bool_masked_pos=bmp)
             if loss is not None:
                 loss = loss.view(())
             if resized:

@@ -30,14 +30,15 @@ def emu(monkeypatch):
     return lib
 
 
-def run_engine(cfg, sd, pv, t, lab, mask, compute, grads=True, drop_masks=None):
+def run_engine(cfg, sd, pv, t, lab, mask, compute, grads=True, drop_masks=None, bool_masked_pos=None):
     from scOT.model import ScOT
-    model = ScOT(cfg, compute=compute)
+    model = ScOT(cfg, compute=compute, use_mask_token=bool_masked_pos is not None)
     model.load_state_dict(sd)
     model._ensure_arena(torch.device("cpu"))
     if drop_masks is not None:
         model._engine.drop_path_masks = drop_masks
-    loss, pred, tape = model._engine.forward(pv, t if cfg.use_conditioning else None, lab, mask, train=grads)
+    loss, pred, tape = model._engine.forward(pv, t if cfg.use_conditioning else None, lab, mask, train=grads,
+                                             bool_masked_pos=bool_masked_pos)
     if grads:
         model._prepare_grads()
         model._engine.backward(tape, torch.ones(1), None)
@@ -79,6 +80,22 @@ def test_engine_fp32_vs_reference_fixture(emu, name):
     assert rel_l2(pred.numpy(), f["output"]) < 1e-5 + 5e-6
     assert abs(float(loss) - float(f["loss"])) < 2e-5 * abs(float(f["loss"]))
     assert grads_global(model, f) < 1e-4
+
+
+def test_engine_mask_tokens(emu):
+    """use_mask_token / bool_masked_pos (reference model.py:323-327, 353-359) against the real reference's fixture."""
+    from poseidon_amd.synth import synth_token_mask
+    f, meta = load_fixture("tiny_masktoken")
+    cfg = ScOTConfig(**meta["cfg"])
+    pv, t, lab, pm = fixture_inputs(meta, cfg)
+    bmp = synth_token_mask(meta["batch"], (cfg.image_size // cfg.patch_size) ** 2)
+    sd = synth_state_dict(param_shapes(cfg, use_mask_token=True), meta["regime"])
+    model, loss, pred = run_engine(cfg, sd, pv, t, lab, pm, "fp32", bool_masked_pos=bmp)
+    assert rel_l2(pred.numpy(), f["output"]) < 1e-5 + 5e-6
+    assert abs(float(loss) - float(f["loss"])) < 2e-5 * abs(float(f["loss"]))
+    assert grads_global(model, f) < 1e-4
+    g = dict(model.named_parameters())["embeddings.mask_token"].grad
+    assert rel_l2(g.numpy(), f["grad:embeddings.mask_token"]) < 1e-4
 
 
 @pytest.mark.parametrize("compute,tol_out,tol_grad", [("bf16", 5e-2, 0.7), ("bf16x3", 1e-4, 2e-3), ("fp16", 5e-3, 5e-2)])

@@ -498,3 +498,24 @@ def test_metrics_on_device_tensors_match_reference_pins():
         g = pins[f"group{i}"]
         assert close(out[n + "/median_relative_l1_error"], g["median_rel"]) and close(out[n + "/mean_relative_l1_error"], g["mean_rel"])
         assert close(out[n + "/max_relative_l1_error"], g["max_rel"]) and close(out[n + "/median_l1_error"], g["median_abs"])
+
+
+def test_mask_tokens_match_reference():
+    """ScOT(config, use_mask_token=True) + bool_masked_pos (reference model.py:323-327, 353-359) against the real
+    reference's fixture, through the module API (output, loss, every gradient incl. the mask token's)."""
+    from poseidon_amd.synth import synth_token_mask
+    f, meta = load_fixture("tiny_masktoken")
+    cfg = ScOTConfig(**meta["cfg"])
+    model = ScOT(cfg, use_mask_token=True, compute="fp32")
+    model.load_state_dict(synth_state_dict(param_shapes(cfg, use_mask_token=True), meta["regime"]))
+    model = model.to(DEV)
+    kw = inputs(cfg, meta)
+    bmp = synth_token_mask(meta["batch"], (cfg.image_size // cfg.patch_size) ** 2).to(DEV)
+    out = model(**kw, bool_masked_pos=bmp)
+    out.loss.backward()
+    torch.cuda.synchronize()
+    assert rel_l2(out.output.detach().cpu().numpy(), f["output"]) < 1e-5 + 5e-6
+    assert abs(float(out.loss.detach()) - float(f["loss"])) < 2e-5 * abs(float(f["loss"]))
+    grads_report(model, f, tol_each=1e-3, tol_global=1e-4)
+    with pytest.raises(ValueError):
+        build(meta, "fp32")[1](**kw, bool_masked_pos=bmp)      # a model without the mask token refuses masked positions

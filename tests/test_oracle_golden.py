@@ -16,7 +16,7 @@ TOL_GRAD = 5e-4  # per tensor (cancellation-dominated tiny grads, e.g. CPB-MLP b
 
 def _run(meta, grads):
     cfg = ScOTConfig(**meta["cfg"])
-    sd = synth_state_dict(param_shapes(cfg), meta["regime"])
+    sd = synth_state_dict(param_shapes(cfg, use_mask_token=bool(meta.get("mask_token"))), meta["regime"])
     if grads:
         for v in sd.values():
             v.requires_grad_(True)
@@ -29,15 +29,19 @@ def _run(meta, grads):
     elif meta.get("with_mask"):
         pm = torch.zeros(meta["batch"], cfg.num_out_channels, dtype=torch.bool)
         pm[:, -1] = True
+    bmp = None
+    if meta.get("mask_token"):
+        from poseidon_amd.synth import synth_token_mask
+        bmp = synth_token_mask(meta["batch"], (size // cfg.patch_size) ** 2)
     loss, out, inter = scot_cpu.scot_forward(sd, cfg, pv, t if cfg.use_conditioning else None, lab, pm,
-                                             return_intermediates=True)
+                                             return_intermediates=True, bool_masked_pos=bmp)
     if grads:
         loss.backward()
     return cfg, sd, loss, out, inter
 
 
 @pytest.mark.parametrize("name", ["tiny_trained", "tiny_hf", "tiny_odd", "tiny_shift3", "tiny_nocond_p2", "tiny_abspos",
-                                  "tiny_learnres_mask", "tiny_obstacle_mask"])
+                                  "tiny_masktoken", "tiny_learnres_mask", "tiny_obstacle_mask"])
 def test_tiny_models_full_grads(name):
     f, meta = load_fixture(name)
     cfg, sd, loss, out, inter = _run(meta, grads=True)
