@@ -374,6 +374,15 @@ def main():
             torch.cuda.synchronize()
             comm = e0.elapsed_time(e1) / 3
     overflow = int(model._engine.grad_overflow) if model._engine.grad_overflow is not None else None   # fp16 gradient scale
+    table = worst = None
+    table_err = None
+    try:   # every rank steps (under DP a step contains collectives); rank 0 reports
+        eager = use_graph[0]
+        use_graph[0] = False
+        table, worst = launch_table(model._engine, step)
+        use_graph[0] = eager
+    except Exception as e:  # pragma: no cover
+        table_err = repr(e)
     total_samples = B * world * a.steps
     value = total_samples / dt
 
@@ -388,12 +397,10 @@ def main():
         roof = dict(step_roof, traffic=None)
         launches = None
         try:
-            # the dominant kernel family of the committed rocprof summary (profiles/round2: gemm_fast_kernel<..TN> + its split-K
-            # reduce = the weight-gradient GEMMs, 31 % of the step's kernel time), timed live inside real steps
-            eager = use_graph[0]
-            use_graph[0] = False
-            table, worst = launch_table(model._engine, step)
-            use_graph[0] = eager
+            # the dominant kernel family of the committed rocprof summary (profiles/round2: the grouped weight-gradient GEMMs),
+            # timed live inside real steps (launch_table above)
+            if table is None:
+                raise RuntimeError(table_err)
             launches = {"launches_per_step": sum(v["launches_per_step"] for v in table.values()),
                         "kernel_ms_per_step": sum(v["ms_per_step"] for v in table.values()),
                         "main_stream_ms_per_step": launch_table.main_stream_ms_per_step,
