@@ -19,12 +19,18 @@ from typing import List, Optional, Tuple
 import torch
 
 
-def backward_order_groups(cfg) -> List[str]:
+def backward_order_groups(cfg, skips_on_side: bool = True) -> List[str]:
+    """Name-prefix groups in the order the backward announces them final.  The ConvNeXt skip blocks' backward runs on the side
+    stream beside the encoder stages (engine.skip_side), so their range is announced after the encoder's (before it with
+    SCOT_SKIP_SIDE=0 / no side stream)."""
     nl = len(cfg.depths)
     g = ["patch_recovery."]
     g += [f"decoder.layers.{k}." for k in reversed(range(nl))]
-    g += ["residual_blocks."]
+    if not skips_on_side:
+        g += ["residual_blocks."]
     g += [f"encoder.layers.{s}." for s in reversed(range(nl))]
+    if skips_on_side:
+        g += ["residual_blocks."]
     g += ["embeddings."]
     return g
 

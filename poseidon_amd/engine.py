@@ -71,6 +71,12 @@ class ScOTEngine:
         self.side_flush = os.environ.get("SCOT_SIDE_FLUSH", "block")   # block | stage: where queued weight-gradient launches fork
         self._pending = []
         self._wgq = []                                                  # weight gradients waiting to be grouped (see wgrad)
+        self._in_side = None                                            # main stream while a side-stream task runs (see fork_task)
+        self._task_keep, self._task_keeps = [], {}
+        # ConvNeXt skip blocks off the critical path: a skip's blocks only feed the decoder stage that consumes the skip (forward)
+        # / the encoder stage that produced it (backward), so they run on the side stream beside the deep stages' latency-bound
+        # chain instead of in front of it (SCOT_SKIP_SIDE=0: in line)
+        self.skip_side = os.environ.get("SCOT_SKIP_SIDE", "1") == "1"
         self.group_wgrads = os.environ.get("SCOT_GROUP_WGRAD", "1") == "1"
         self.arena = arena
         # bf16x3: activations and weights stay fp32 in HBM; the GEMMs split them into hi + lo bf16 while staging into LDS and
@@ -215,7 +221,14 @@ class ScOTEngine:
         return y
 
     def new(self, *shape, dtype=torch.float32):
-        t = torch.empty(*shape, dtype=dtype, device=self.device)
+        if self._in_side is not None:
+            # a side-stream task that produces tensors the main chain consumes later (skip blocks): allocate from the MAIN
+            # stream's pool, so the block's reuse stays ordered with the main-stream kernels that read it after the join
+            with torch.cuda.stream(self._in_side):
+                t = torch.empty(*shape, dtype=dtype, device=self.device)
+            self._task_keep.append(t)      # ... and alive until the main stream has waited for the task (wait_task)
+        else:
+            t = torch.empty(*shape, dtype=dtype, device=self.device)
         if self._rec is not None:
             self._rec_keep.append(t)   # a recorded step owns its buffers for good: replays reuse these very addresses
         return t
@@ -333,7 +346,7 @@ class ScOTEngine:
         enqueued so far on the current stream.  `tensors` are kept alive until the join so the allocator cannot recycle
         them.  With batching (default) the launches are queued and handed over by flush_side(): ONE fork per block instead
         of one per weight gradient — hipGraph replay pays for every cross-stream edge."""
-        if not self.use_side:
+        if not self.use_side or self._in_side is not None:     # no side stream, or already running on it
             fn()
             return
         self._keep.append(tensors)
@@ -359,6 +372,39 @@ class ScOTEngine:
         finally:
             ops.set_workspace_slot(prev)
 
+    def fork_task(self, fn):
+        """Run fn() on the side stream NOW, ordered after everything enqueued so far on the current stream; returns (fn's
+        result, event recorded on the side stream after it).  The caller makes the main stream wait for the event
+        (`wait_task`) before it consumes what fn produced.  Without a side stream: fn() in line, event None."""
+        if not self.use_side:
+            return fn(), None
+        self.flush_side()
+        box = []
+        main = torch.cuda.current_stream()
+
+        def run():
+            self._in_side = main
+            try:
+                box.append(fn())
+                if self._wgq:
+                    self._drain_wgrads()     # the task's own weight gradients: same stream, right behind it
+            finally:
+                self._in_side = None
+        self._task_keep = []
+        self._run_side([run])
+        ev, side = torch.cuda.Event(), self.side
+        self.tdo(lambda: ev.record(side))
+        # temporaries of the task come from the main stream's pool: returning them before the main stream is ordered behind the
+        # task would hand memory that side-stream kernels still use to the next main-stream allocation
+        self._task_keeps[ev], self._task_keep = self._task_keep, []
+        return box[0], ev
+
+    def wait_task(self, ev):
+        if ev is not None:
+            cur = torch.cuda.current_stream()
+            self.tdo(lambda: cur.wait_event(ev))
+            self._task_keeps.pop(ev, None)
+
     def flush_side(self):
         if self._wgq:
             self._drain_wgrads()
@@ -372,6 +418,7 @@ class ScOTEngine:
             cur, side = torch.cuda.current_stream(), self.side
             self.tdo(lambda: cur.wait_stream(side))
             self._keep.clear()
+            self._task_keeps.clear()
 
     # ------------------------------------------------------------------------------------------ batch chains
     # The deep stages (8x8 / 4x4 token grids: 4096 / 1024 rows at batch 64) are chains of ~30 dependent launches per block
@@ -1009,30 +1056,49 @@ class ScOTEngine:
 
         # encoder (model.py:816-861)
         skips: List[torch.Tensor] = []
+        skip_ev = []
+        side_skips = self.skip_side and self.use_side and not self.stage_timing
+
+        def skip_blocks(i, st, s_in):
+            """ConvNeXt blocks on skip i (model.py:1388-1393) → (processed skip, per-block records)"""
+            nblk = int(cfg.skip_connections[i]) if i < len(cfg.skip_connections) else 0
+            rr = []
+            for j in range(nblk):
+                s_in, r = self.convnext_fwd(f"residual_blocks.{i}.{j}", s_in, B, st.res[0], st.res[1], st.dim, time, train)
+                rr.append(r)
+            return s_in, rr
+        res_recs = []
         for si, st in enumerate(self.enc):
             self.mark(f"fwd enc{si}")
             stage_in = x
             x, x16, recs = self.blocks_fwd(st.blocks, x, x16, B, time, train)
             skips.append(x)
             hidden_enc.append(x)
+            if side_skips:      # this skip's blocks start now, beside the rest of the encoder
+                nblk = int(cfg.skip_connections[si]) if si < len(cfg.skip_connections) else 0
+                if nblk:
+                    (skips[si], rr), ev = self.fork_task(lambda si=si, st=st, s_in=x: skip_blocks(si, st, s_in))
+                else:
+                    rr, ev = [], None
+                res_recs.append(rr)
+                skip_ev.append(ev)
             mrec = None
             if st.resample:
                 x, x16, mrec = self.merge_fwd(st, x, stage_in, B, time, train)
             if train:
                 tape["enc"].append((recs, mrec))
 
-        # ConvNeXt blocks on the skips (model.py:1388-1393)
         self.mark("fwd convnext")
-        for i, st in enumerate(self.enc):
-            nblk = int(cfg.skip_connections[i]) if i < len(cfg.skip_connections) else 0
-            rr = []
-            for j in range(nblk):
-                skips[i], r = self.convnext_fwd(f"residual_blocks.{i}.{j}", skips[i], B, st.res[0], st.res[1], st.dim, time, train)
-                rr.append(r)
-            if train:
-                tape["res"].append(rr)
+        if not side_skips:
+            for i, st in enumerate(self.enc):
+                skips[i], rr = skip_blocks(i, st, skips[i])
+                res_recs.append(rr)
+                skip_ev.append(None)
+        if train:
+            tape["res"] = res_recs
 
         # decoder (model.py:916-961, 1145-1240)
+        self.wait_task(skip_ev[-1])
         x = skips[-1]
         x16 = self.to_adt(x)
         hidden_dec = [x]
@@ -1040,6 +1106,7 @@ class ScOTEngine:
         for k, st in enumerate(self.dec):
             self.mark(f"fwd dec{k}")
             if k != 0:
+                self.wait_task(skip_ev[len(sk) - k])
                 y = self.new(x.shape[0], x.shape[1])
                 ops.add(x, sk[len(sk) - k], y)
                 x = y
@@ -1182,6 +1249,15 @@ class ScOTEngine:
         # decoder, shallow → deep
         nl = len(self.dec)
         g_skips: List[Optional[torch.Tensor]] = [None] * nl  # gradient wrt the (ConvNeXt-processed) skips
+        skip_ev = [None] * nl
+        side_skips = self.skip_side and self.use_side and not self.stage_timing
+
+        def skip_bwd(i, gi):
+            """backward of the ConvNeXt blocks on skip i: gradient wrt the encoder stage's output (in place on gi)"""
+            st_ = self.enc[i]
+            for j in reversed(range(len(tape["res"][i]))):
+                gi = self.convnext_bwd(f"residual_blocks.{i}.{j}", tape["res"][i][j], gi, B, st_.res[0], st_.res[1], st_.dim, time)
+            return gi
         for k in reversed(range(nl)):
             self.mark(f"bwd dec{k}")
             st = self.dec[k]
@@ -1192,25 +1268,30 @@ class ScOTEngine:
             self.cpb_backward_range(st.blocks)
             done(f"decoder.layers.{k}.")
             if k != 0:
-                g_skips[nl - 1 - k] = g   # x = x_prev + skip: both get g (g keeps flowing to x_prev unchanged)
+                i = nl - 1 - k
+                g_skips[i] = g   # x = x_prev + skip: both get g (g keeps flowing to x_prev unchanged)
                 g = self.clone(g)
+                if side_skips and tape["res"][i]:
+                    # this skip's gradient is only needed when the backward reaches encoder stage i: its ConvNeXt blocks go to
+                    # the side stream now, beside the deeper decoder / encoder stages
+                    g_skips[i], skip_ev[i] = self.fork_task(lambda i=i, gi=g_skips[i]: skip_bwd(i, gi))
         g_skips[nl - 1] = g  # decoder input = skips[-1]
 
-        # ConvNeXt blocks
+        # ConvNeXt blocks (in line: the deepest skip, and every skip when the side stream is off)
         self.mark("bwd convnext")
         for i in reversed(range(nl)):
-            st = self.enc[i]
-            for j in reversed(range(len(tape["res"][i]))):
-                g_skips[i] = self.convnext_bwd(f"residual_blocks.{i}.{j}", tape["res"][i][j], g_skips[i], B, st.res[0], st.res[1],
-                                               st.dim, time)
+            if skip_ev[i] is None:
+                g_skips[i] = skip_bwd(i, g_skips[i])
 
-        done("residual_blocks.")
+        if not side_skips:
+            done("residual_blocks.")
         # encoder, deep → shallow
         g = None
         for s in reversed(range(nl)):
             self.mark(f"bwd enc{s}")
             st = self.enc[s]
             recs, mrec = tape["enc"][s]
+            self.wait_task(skip_ev[s])
             if st.resample:
                 d_sum = self.merge_bwd(st, mrec, g, B, time)
                 g = g_skips[s]
@@ -1223,6 +1304,8 @@ class ScOTEngine:
                 ops.add(g, d_sum, g)
             self.cpb_backward_range(st.blocks)
             done(f"encoder.layers.{s}.")
+        if side_skips:
+            done("residual_blocks.")     # (their side-stream tasks were joined by the encoder stages that consumed them)
 
         # embeddings
         self.mark("bwd embed")

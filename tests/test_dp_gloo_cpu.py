@@ -160,7 +160,8 @@ def _engine_worker(rank, world, port, out):
 
     eng.on_grads_final = on_final
     got = step()
-    assert seen == [p for p in backward_order_groups(cfg) if p in ranges], seen
+    # (no side stream on the CPU emulation: the skip blocks' backward runs in line, before the encoder stages)
+    assert seen == [p for p in backward_order_groups(cfg, skips_on_side=False) if p in ranges], seen
     err = float((got - expect).norm() / expect.norm())
     bad = [n for n in model._arena.shapes
            if not torch.allclose(model._arena.gview(n), expect[model._arena.offsets[n]:model._arena.offsets[n] + model._arena.numel(n)]

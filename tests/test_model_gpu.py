@@ -454,7 +454,8 @@ def test_tuple_return_layout_matches_reference():
         t1 = model(**kw, return_dict=False, output_hidden_states=True)
     nl = len(cfg.depths)
     assert len(t0) == 3 and len(t1) == 4
-    assert float(t0[0]) == float(d.loss) and torch.equal(t0[1], d.output)
+    # (the loss sums are accumulated with atomics: the last bit depends on the order the workgroups arrive in)
+    assert abs(float(t0[0]) - float(d.loss)) <= 1e-6 * abs(float(d.loss)) and torch.equal(t0[1], d.output)
     assert isinstance(t0[2], tuple) and len(t0[2]) == nl + 1 and len(t1[2]) == nl + 1 and len(t1[3]) == nl + 1
     assert len(d.hidden_states) == 2 * (nl + 1)
     for a, b in zip(t1[2] + t1[3], d.hidden_states):
