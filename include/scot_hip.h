@@ -35,6 +35,12 @@ int scot_operand_format(void);
  * Undoes the backward's gradient scale on the gradient arena (the role torch.cuda.amp.GradScaler.unscale_ plays for the
  * reference's fp16 recipe, trainer.py via HF Trainer). */
 int scot_scale_inplace(float* x, size_t n, float scale, int* nonfinite, scot_stream_t stream);
+/* Batch assembly from trajectories resident in HBM (the reference's Dataset.__getitem__ + collate: scOT/problems/base.py:318-334,
+ * scOT/problems/fluids/incompressible.py:74-160, compressible.py:84-262):
+ *   pv [b,c,y,x] = a[c] * data[i_b, t1_b, src[c], y, x] + b[c],  lab[...] the same at t2_b;  src[c] < 0: constant plane b[c];
+ *   transpose: (y, x) read at (x, y).  data fp32 [n, T, nsrc, H, W]; it int32 [3, B] = trajectories, t1, t2. */
+int scot_gather_pairs(const float* data, const int* it, const int* src, const float* a, const float* b, float* pv, float* lab,
+                      int B, int C, int T, int nsrc, int H, int W, int transpose, scot_stream_t stream);
 /* Mask tokens of ScOTEmbeddings (ref:353-359): x[r,:] = mask[r] ? token : x[r,:] in place (x fp32 [rows, C], mask uint8 [rows],
  * token fp32 [C]); backward: d_token += Σ_r mask[r]·g[r,:], g[r,:] = 0 where mask[r]. */
 int scot_mask_tokens(float* x, const void* mask_u8, const float* token, int rows, int C, scot_stream_t stream);

@@ -48,6 +48,41 @@ extern "C" int scot_batch_sum(const void* x, int x_dt, float* out, int batch, si
   return scot_check_launch();
 }
 
+// ------------------------------------------------------------------ dataset batch assembly (poseidon_amd/data.py)
+// The reference builds a sample on the CPU: two slices of an HDF5 array, constant planes, (x - mean) / std per channel, optional
+// transposition (scOT/problems/fluids/*.py __getitem__), collated by the DataLoader.  Here the trajectories live in HBM
+// (data [n, T, nsrc, H, W] fp32) and ONE launch writes both tensors of a batch:
+//   pv [b, c, y, x] = a[c] * data[i_b, t1_b, src[c], y', x'] + b[c]      (src[c] < 0: the constant plane b[c])
+//   lab[b, c, y, x] = a[c] * data[i_b, t2_b, src[c], y', x'] + b[c]      (y', x') = (x, y) when transposed
+__global__ __launch_bounds__(256) void gather_pairs_kernel(const float* __restrict__ data, const int* __restrict__ it, const int* __restrict__ src,
+                                                           const float* __restrict__ a, const float* __restrict__ b, float* __restrict__ pv,
+                                                           float* __restrict__ lab, int B, int C, int T, int nsrc, int H, int W, int transpose) {
+  const int bc = blockIdx.y, bi = bc / C, c = bc % C;
+  const int i = it[bi], t1 = it[B + bi], t2 = it[2 * B + bi];
+  const int sc = src[c];
+  const float aa = a[c], bb = b[c];
+  const size_t plane = (size_t)H * W;
+  const float* p1 = data + (((size_t)i * T + t1) * nsrc + (sc < 0 ? 0 : sc)) * plane;
+  const float* p2 = data + (((size_t)i * T + t2) * nsrc + (sc < 0 ? 0 : sc)) * plane;
+  float* o1 = pv + (size_t)bc * plane;
+  float* o2 = lab + (size_t)bc * plane;
+  for (size_t e = (size_t)blockIdx.x * 256 + threadIdx.x; e < plane; e += (size_t)gridDim.x * 256) {
+    if (sc < 0) { o1[e] = bb; o2[e] = bb; continue; }
+    const size_t s = transpose ? (e % W) * (size_t)W + e / W : e;     // square planes (the reference's transpose(-2, -1))
+    o1[e] = fmaf(aa, p1[s], bb);
+    o2[e] = fmaf(aa, p2[s], bb);
+  }
+}
+extern "C" int scot_gather_pairs(const float* data, const int* it, const int* src, const float* a, const float* b, float* pv, float* lab,
+                                 int B, int C, int T, int nsrc, int H, int W, int transpose, hipStream_t s) {
+  if (B <= 0 || C <= 0 || T <= 0 || nsrc <= 0 || H <= 0 || W <= 0) return SCOT_ERR_SHAPE;
+  if (transpose && H != W) return SCOT_ERR_UNSUPPORTED;
+  const size_t plane = (size_t)H * W;
+  unsigned bx = (unsigned)((plane + 1023) / 1024); if (bx == 0) bx = 1;
+  hipLaunchKernelGGL(gather_pairs_kernel, dim3(bx, B * C), dim3(256), 0, s, data, it, src, a, b, pv, lab, B, C, T, nsrc, H, W, transpose);
+  return scot_check_launch();
+}
+
 // ------------------------------------------------------------------ mask tokens (model.py:353-359, SimMIM-style masked positions)
 // forward:  x[r, :] = mask[r] ? token : x[r, :]     (== x·(1-m) + token·m for m in {0, 1}),   in place
 // backward: d_token += Σ_r mask[r]·g[r, :];  g[r, :] = mask[r] ? 0 : g[r, :],                  in place

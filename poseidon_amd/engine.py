@@ -848,9 +848,10 @@ class ScOTEngine:
 
     def convnext_bwd(self, pre, rec, g, B, H, W, C, time):
         L = H * W
-        ops.colsum(g, self.G(pre + ".weight"), y=rec["y2"])
         d_y2 = self.new(B * L, C, dtype=self.adt)
         ops.scale_residual(g, self.P(pre + ".weight"), None, d_y2, B * L, C)
+        # layer-scale gradient Σ g·y2: reads g BEFORE the in-place `g += d_s` at the end of this function — keep it on this stream
+        ops.colsum(g, self.G(pre + ".weight"), y=rec["y2"])
         self.linear_bwd_params(pre + ".pwconv2.weight", pre + ".pwconv2.bias", d_y2, rec["u"])
         d_u = self.new(B * L, 4 * C, dtype=self.adt)
         ops.linear_dgrad(self.compute, d_y2, self.W(pre + ".pwconv2.weight"), d_u, aux=rec["gp"], aux_mul=True)
@@ -1220,10 +1221,11 @@ class ScOTEngine:
         else:
             raise RuntimeError("nothing to differentiate: no labels and no gradient for the prediction")
         # recovery head
-        ops.conv5_wgrad(g_pred, hd["img"], self.G("patch_recovery.mixup.weight"), B, Cout, H, W)
+        self.off_critical_path(lambda: ops.conv5_wgrad(g_pred, hd["img"], self.G("patch_recovery.mixup.weight"), B, Cout, H, W),
+                               g_pred, hd["img"])
         d_img = self.new(B, Cout, H, W)
         ops.conv5(g_pred, self.P("patch_recovery.mixup.weight"), d_img, B, Cout, H, W, transpose=True)
-        ops.nchw_channel_sum(d_img, self.G("patch_recovery.projection.bias"), B, Cout, H * W)
+        self.off_critical_path(lambda: ops.nchw_channel_sum(d_img, self.G("patch_recovery.projection.bias"), B, Cout, H * W), d_img)
         d_rc = self.new(B * L0, Cout * p * p, dtype=self.tadt)
         ops.patchify(d_img, d_rc, B, Cout, H, W, p)
         wrec = self.TW("patch_recovery.projection.weight").view(C0, Cout * p * p)
@@ -1241,6 +1243,17 @@ class ScOTEngine:
                     for _, lo, hi in group_ranges(self.arena, [prefix]):
                         ops.scale_inplace(self.arena.grad[lo:hi], 1.0 / S, self.grad_overflow)
                 self.tdo(lambda: _cb(prefix))
+        elif S != 1.0 and self.use_side:
+            from .dp import group_ranges
+
+            def done(prefix):
+                # fp16 build: bring each range back from the gradient scale as soon as the backward has finished writing it, on
+                # the side stream behind the range's weight gradients (one 0.24 ms pass at the very end of the step before)
+                self.flush_side()          # the range's queued weight gradients go first
+                for _, lo, hi in group_ranges(self.arena, [prefix]):
+                    seg = self.arena.grad[lo:hi]
+                    self.off_critical_path(lambda seg=seg: ops.scale_inplace(seg, 1.0 / S, self.grad_overflow))
+                self.flush_side()
         else:
             def done(prefix):
                 return None
@@ -1318,8 +1331,9 @@ class ScOTEngine:
         d_e = self.norm_bwd("embeddings.norm", g, emb["e"], emb["stats"], L0, C0, time, self.tadt)
         self.wgrad(self.tcm, d_e, emb["cols"], self.G("embeddings.patch_embeddings.projection.weight").view(C0, Cin * p * p),
                    dbias=self.G("embeddings.patch_embeddings.projection.bias"))
-        self.join_side()
-        if S != 1.0 and self.on_grads_final is None:
+        if S != 1.0 and self.on_grads_final is None and not self.use_side:
+            self.join_side()
             ops.scale_inplace(self.arena.grad, 1.0 / S, self.grad_overflow)
         self.mark("end")
         done("embeddings.")
+        self.join_side()

@@ -284,6 +284,14 @@ def add(a, b, out, period=None):
                "scot_add")
 
 
+def gather_pairs(data, it, src, a, b, pv, lab, T, nsrc, H, W, transpose):
+    """Batch assembly from HBM-resident trajectories (poseidon_amd/data.py): data [n, T, nsrc, H, W] fp32, it int32 [3, B] =
+    (trajectory, t1, t2), src int32 [C] (-1: constant plane), a / b fp32 [C]; writes pv / lab [B, C, H, W]."""
+    B, C = pv.shape[0], pv.shape[1]
+    _lib.check(L().scot_gather_pairs(ptr(data), ptr(it), ptr(src), ptr(a), ptr(b), ptr(pv), ptr(lab), B, C, T, nsrc, H, W,
+                                     int(transpose), stream()), "scot_gather_pairs")
+
+
 def mask_tokens(x, mask_u8, token, rows, C):
     """x[r, :] = token where mask_u8[r] (in place; reference model.py:353-359)."""
     _lib.check(L().scot_mask_tokens(ptr(x), ptr(mask_u8), ptr(token), rows, C, stream()), "scot_mask_tokens")

@@ -520,3 +520,25 @@ def test_mask_tokens_match_reference():
     grads_report(model, f, tol_each=1e-3, tol_global=1e-4)
     with pytest.raises(ValueError):
         build(meta, "fp32")[1](**kw, bool_masked_pos=bmp)      # a model without the mask token refuses masked positions
+
+
+def test_device_resident_dataset_batches():
+    """trajectories resident in HBM, a batch = one scot_gather_pairs launch; equals the reference-style
+    __getitem__ samples (CPU path) and feeds the model directly."""
+    from scOT.problems.base import get_dataset
+    rng = np.random.default_rng(0)
+    rd = {"data": rng.standard_normal((12, 21, 5, 32, 32)).astype(np.float32)}
+    ds = get_dataset("fluids.compressible.Riemann", which="train", num_trajectories=5, reader=rd, n_max=12, n_val=4, n_test=3)
+    ds.resolution = 32
+    dev = ds.to_device(DEV)
+    idx = [0, 7, 35, 36, 100, 179]
+    b = dev.batch(idx)
+    for k, j in enumerate(idx):
+        s = ds[j]
+        assert np.allclose(b["pixel_values"][k].cpu().numpy(), s["pixel_values"].numpy(), rtol=1e-6, atol=1e-6)
+        assert np.allclose(b["labels"][k].cpu().numpy(), s["labels"].numpy(), rtol=1e-6, atol=1e-6)
+        assert float(b["time"][k]) == pytest.approx(s["time"])
+    f, meta = load_fixture("tiny_trained")
+    cfg, model = build(meta, "fp32")              # 32x32, 4 -> 4 channels: the batch goes straight into the model
+    out = model(pixel_values=b["pixel_values"], time=b["time"], labels=b["labels"], pixel_mask=b["pixel_mask"])
+    assert bool(torch.isfinite(out.loss))
