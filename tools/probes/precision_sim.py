@@ -27,6 +27,8 @@ _orig = torch.Tensor.__matmul__
 
 
 def _mm(a, b):
+    if MODE["trunk"] and a.dim() >= 3 and MODE.get("trunk_fmt"):      # patch embed / merge / unmerge / recovery GEMMs
+        return _orig(R[MODE["trunk_fmt"]](a), R[MODE["trunk_fmt"]](b))
     if MODE["trunk"] or a.dim() < 3:
         return _orig(a, b)
     if b.dim() == 2:
@@ -74,6 +76,13 @@ def main():
     scot_cpu.attention = _site(scot_cpu.attention, "attn", after="layer")
     scot_cpu.convnext = _site(scot_cpu.convnext, "cnx")
     torch.Tensor.__matmul__ = _mm
+    if len(sys.argv) > 2 and sys.argv[2] == "trunk":
+        with torch.no_grad():
+            for tf in (None, "fp16", "bf16"):
+                MODE.update(act="fp16", w="fp16", attn="fp16", per_site={}, trunk_fmt=tf)
+                _, pred = scot_cpu.scot_forward(sd, cfg, pv, t if cfg.use_conditioning else None, lab)
+                print(f"  fp16 everywhere, trunk (patch embed / merge / unmerge / recovery) {tf or 'fp32'}: {rel_l2(pred.numpy(), f['output']):.2e}")
+        return
     if len(sys.argv) > 2 and sys.argv[2] == "sites":
         X, H = ("x", "fp16"), ("fp16", "fp16")
         cases = [("all fp16", {}), ("proj act exact", {"proj": X}), ("fc2 act exact", {"fc2": X}), ("proj+fc2 act exact", {"proj": X, "fc2": X}),
