@@ -1030,10 +1030,26 @@ class ScOTEngine:
         C0 = cfg.embed_dim
         L0 = gh * gw
         tape = dict(B=B, time=time, enc=[], dec=[], res=[]) if train else None
-        if self.shadow is not None:
-            ops.cast(self.arena.data, self.shadow)  # fp32 master weights → bf16 GEMM operands (every step)
-        ops.cpb_fwd_batched(self.arena.data, self.cpb_desc, self.cpb_nlayers, self.cpb_max_ws, self.cpb_coords, self.cpb_tables,
-                            self.cpb_z)
+        ev_cpb = ev_cast = None
+
+        def cpb_all():
+            ops.cpb_fwd_batched(self.arena.data, self.cpb_desc, self.cpb_nlayers, self.cpb_max_ws, self.cpb_coords, self.cpb_tables,
+                                self.cpb_z)
+        if self.use_side and not self.stage_timing:
+            # neither the bias tables (first used by the first attention kernel) nor the 16-bit copies of the deeper stages'
+            # weights (99 % of the arena) are needed by the embedding / stage-0 chain: both go to the side stream
+            _, ev_cpb = self.fork_task(cpb_all)
+            if self.shadow is not None:
+                split = min((o for n, o in self.arena.offsets.items() if n.startswith("encoder.layers.1.")), default=0)
+                if split > 0:
+                    ops.cast(self.arena.data[:split], self.shadow[:split])
+                    _, ev_cast = self.fork_task(lambda: ops.cast(self.arena.data[split:], self.shadow[split:]))
+                else:
+                    ops.cast(self.arena.data, self.shadow)
+        else:
+            if self.shadow is not None:
+                ops.cast(self.arena.data, self.shadow)  # fp32 master weights → 16-bit GEMM operands (every step)
+            cpb_all()
 
         # embeddings (model.py:295-366)
         cols = self.new(B * L0, Cin * p * p, dtype=self.tadt)
@@ -1071,8 +1087,11 @@ class ScOTEngine:
                 rr.append(r)
             return s_in, rr
         res_recs = []
+        self.wait_task(ev_cpb)
         for si, st in enumerate(self.enc):
             self.mark(f"fwd enc{si}")
+            if si == 1:
+                self.wait_task(ev_cast)
             stage_in = x
             x, x16, recs = self.blocks_fwd(st.blocks, x, x16, B, time, train)
             skips.append(x)
