@@ -209,7 +209,10 @@ int scot_grad_sqnorm(const float* grad, const unsigned char* map8, size_t n, flo
 int scot_clip_coef(const float* partial, int nblocks, float max_norm, float* out2 /* {coef, total_norm} */, scot_stream_t stream);
 int scot_adamw_step(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, const unsigned char* map8, size_t n,
                     const float* lr /* host[ngroups] */, const float* wd /* host[ngroups] */, int ngroups, float beta1, float beta2,
-                    float eps, int step, const float* clip /* device {coef,..} or NULL */, scot_stream_t stream);
+                    float eps, int step, const float* clip /* device {coef,..} or NULL */,
+                    const int* overflow, const int* overflow_seen /* device ints or NULL: the update is skipped when they differ
+                    (gradients that overflowed under the fp16 build's gradient scale — GradScaler.step semantics) */,
+                    scot_stream_t stream);
 
 #ifdef __cplusplus
 }

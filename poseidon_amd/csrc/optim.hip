@@ -53,7 +53,11 @@ __global__ __launch_bounds__(256) void clip_coef_kernel(const float* __restrict_
 __global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
                                                     float* __restrict__ v, const uint8_t* __restrict__ map8, size_t n8, AdamGroups grp,
                                                     float beta1, float beta2, float eps, float bc1, float rsqrt_bc2,
-                                                    const float* __restrict__ clip) {
+                                                    const float* __restrict__ clip, const int* __restrict__ overflow,
+                                                    const int* __restrict__ overflow_seen) {
+  // fp16 build: the gradient un-scale counts non-finite values; a step whose gradients overflowed is skipped (what
+  // torch.cuda.amp.GradScaler.step does for the reference's fp16 recipe) — decided on the device, no host round trip
+  if (overflow && *overflow != *overflow_seen) return;
   const float cc = clip ? clip[0] : 1.f;
   for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n8; i += (size_t)gridDim.x * 256) {
     const int gi = map8[i];
@@ -96,17 +100,18 @@ extern "C" int scot_clip_coef(const float* partial, int nblocks, float max_norm,
 }
 
 // lr / wd: HOST arrays of ngroups floats (passed to the kernel by value); step >= 1; clip: device pointer to the
-// coefficient written by scot_clip_coef, or NULL
+// coefficient written by scot_clip_coef, or NULL; overflow / overflow_seen: device ints (or NULL): the update is skipped when
+// they differ (the engine's cumulative count of non-finite gradient values vs the count at the previous step)
 extern "C" int scot_adamw_step(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, const uint8_t* map8, size_t n,
                                const float* lr, const float* wd, int ngroups, float beta1, float beta2, float eps, int step,
-                               const float* clip, hipStream_t stream) {
+                               const float* clip, const int* overflow, const int* overflow_seen, hipStream_t stream) {
   if (!params || !grads || !exp_avg || !exp_avg_sq || !map8 || n % 8 || ngroups < 1 || ngroups > OPT_MAX_GROUPS || step < 1)
     return SCOT_ERR_SHAPE;
   AdamGroups grp{};
   for (int i = 0; i < ngroups; ++i) { grp.lr[i] = lr[i]; grp.wd[i] = wd[i]; }
   const double bc1 = 1.0 - pow((double)beta1, step), bc2 = 1.0 - pow((double)beta2, step);
   hipLaunchKernelGGL(adamw_kernel, dim3(opt_blocks(n / 8)), dim3(256), 0, stream, params, grads, exp_avg, exp_avg_sq, map8, n / 8, grp,
-                     beta1, beta2, eps, (float)bc1, (float)(1.0 / sqrt(bc2)), clip);
+                     beta1, beta2, eps, (float)bc1, (float)(1.0 / sqrt(bc2)), clip, overflow, overflow ? overflow_seen : nullptr);
   return scot_check_launch();
 }
 

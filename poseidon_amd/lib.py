@@ -65,7 +65,7 @@ PROTOTYPES = {
     "scot_optim_blocks": [Z],
     "scot_grad_sqnorm": [P, P, Z, P, P],
     "scot_clip_coef": [P, I, F, P, P],
-    "scot_adamw_step": [P, P, P, P, P, Z, P, P, I, F, F, F, I, P, P],
+    "scot_adamw_step": [P, P, P, P, P, Z, P, P, I, F, F, F, I, P, P, P, P],
 }
 _VOID = {"scot_set_use_tr"}
 

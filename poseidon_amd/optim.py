@@ -72,6 +72,7 @@ class FusedAdamW(torch.optim.Optimizer):
         self._clip = torch.ones(2, device=dev)
         self.max_grad_norm = max_grad_norm
         self.step_count = 0
+        self._overflow_seen = torch.zeros(1, dtype=torch.int32, device=dev)   # engine.grad_overflow at the previous step
 
     @property
     def last_grad_norm(self) -> torch.Tensor:
@@ -96,10 +97,23 @@ class FusedAdamW(torch.optim.Optimizer):
         lr = (ctypes.c_float * ng)(*[float(g["lr"]) for g in self.param_groups])
         wd = (ctypes.c_float * ng)(*[float(g["weight_decay"]) for g in self.param_groups])
         b1, b2 = g0["betas"]
+        # fp16 compute mode: a step whose gradients overflowed under the gradient scale is skipped ON THE DEVICE (the kernel
+        # compares the engine's cumulative non-finite count with the count at the previous step), like GradScaler.step
+        eng = getattr(self.model, "_engine", None)
+        ovf = eng.grad_overflow if (eng is not None and eng.grad_overflow is not None) else None
         _lib.check(L.scot_adamw_step(arena.data.data_ptr(), arena.grad.data_ptr(), self.exp_avg.data_ptr(), self.exp_avg_sq.data_ptr(),
                                      self._map.data_ptr(), n, ctypes.cast(lr, ctypes.c_void_p), ctypes.cast(wd, ctypes.c_void_p), ng,
-                                     float(b1), float(b2), float(g0["eps"]), self.step_count, clip_ptr, st), "scot_adamw_step")
+                                     float(b1), float(b2), float(g0["eps"]), self.step_count, clip_ptr,
+                                     ovf.data_ptr() if ovf is not None else None,
+                                     self._overflow_seen.data_ptr() if ovf is not None else None, st), "scot_adamw_step")
+        if ovf is not None:
+            self._overflow_seen.copy_(ovf)
         return loss
+
+    def skipped_steps_possible(self) -> bool:
+        """True when the model computes in fp16 (steps with overflowed gradients are skipped on the device)."""
+        eng = getattr(self.model, "_engine", None)
+        return eng is not None and eng.grad_overflow is not None
 
     def zero_grad(self, set_to_none: bool = False):
         self.model.zero_grad(set_to_none=False)   # one memset of the gradient arena; .grad stay views of it

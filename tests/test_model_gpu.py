@@ -542,3 +542,32 @@ def test_device_resident_dataset_batches():
     cfg, model = build(meta, "fp32")              # 32x32, 4 -> 4 channels: the batch goes straight into the model
     out = model(pixel_values=b["pixel_values"], time=b["time"], labels=b["labels"], pixel_mask=b["pixel_mask"])
     assert bool(torch.isfinite(out.loss))
+
+
+def test_fused_adamw_skips_steps_with_overflowed_gradients():
+    """fp16 compute mode: the gradient un-scale counts non-finite values; FusedAdamW compares that count with the previous step's
+    ON THE DEVICE and leaves parameters and moments untouched when it moved (GradScaler.step semantics, no host round trip)."""
+    from scOT.trainer import FusedAdamW
+    f, meta = load_fixture("tiny_trained")
+    cfg, model = build(meta, "fp16")
+    kw = inputs(cfg, meta)
+    model(**kw).loss.backward()
+    opt = FusedAdamW(model, lr=1e-2)
+    assert opt.skipped_steps_possible()
+    p0 = model.flat_parameters().clone()
+    opt.step()                                            # a normal step moves the parameters
+    torch.cuda.synchronize()
+    p1 = model.flat_parameters().clone()
+    assert not torch.equal(p0, p1) and int(model._engine.grad_overflow) == 0
+    opt.zero_grad()
+    model(**kw).loss.backward()
+    model._engine.grad_overflow.add_(3)                   # as if the un-scale had met Inf/NaN in this backward
+    m1 = opt.exp_avg.clone()
+    opt.step()
+    torch.cuda.synchronize()
+    assert torch.equal(model.flat_parameters(), p1) and torch.equal(opt.exp_avg, m1)      # skipped
+    opt.zero_grad()
+    model(**kw).loss.backward()
+    opt.step()                                            # the count did not move again: stepping resumes
+    torch.cuda.synchronize()
+    assert not torch.equal(model.flat_parameters(), p1)
