@@ -164,6 +164,16 @@ int scot_proj_cln_bwd(const float* g, const float* z, const float* mean, const f
                       const float* gw_w, const float* gw_b, const float* sample_scale, const void* W, void* dz, void* da,
                       float* d_gw_w, float* d_gw_b, float* d_bw_w, float* d_bw_b, int M, int rows_per_sample, int C,
                       scot_stream_t stream);
+/* scot_mlp_block_bwd followed by scot_proj_cln_bwd on its g_out, for the same rows, in ONE launch (the backward of HF:533-561 +
+ * ref:566-579 and of HF:478-489 + ref:560-565 along the dependent chain): g_out is still written (the qkv dgrad accumulates
+ * into it) but not re-read.  Suffix 2 = the MLP half's norm (layernorm_after), 1 = the attention half's (layernorm_before);
+ * arguments as in the two entry points above.  C in {96, 192}, rows_per_sample % 64 == 0; returns -3 otherwise. */
+int scot_block_tail_bwd(const float* g, float* g_out, const float* z2, const float* mean2, const float* rstd2, const float* gw_w2,
+                        const float* gw_b2, const float* sscale2, const void* dact, const void* W1, const void* W2, void* dz2, void* du,
+                        float* d_gw_w2, float* d_gw_b2, float* d_bw_w2, float* d_bw_b2, const float* z1, const float* mean1,
+                        const float* rstd1, const float* gw_w1, const float* gw_b1, const float* sscale1, const void* Wo, void* dz1,
+                        void* da, float* d_gw_w1, float* d_gw_b1, float* d_bw_w1, float* d_bw_b1, const float* time, int M,
+                        int rows_per_sample, int C, int hid, scot_stream_t stream);
 
 /* Data movement */
 int scot_add(const void* a, int a_dt, const void* b, int b_dt, void* out, int out_dt, size_t n, size_t period,

@@ -103,8 +103,11 @@ template <int C> struct ClnBwdLds {
 // B operand).  The four parameter gradients are reduced over the workgroup's rows and added with one atomic per column; the
 // conditioning time must be uniform over the workgroup (rows_per_sample % (64·TT) == 0).  Ends with the atomics ISSUED but no
 // barrier after them: the caller must __syncthreads() before it overwrites `lds`.
-template <int C, int TT>
-__device__ __forceinline__ void cln_bwd_rows(Frag<bf16_t> (&dzf)[TT][C / 32], char* lds, int wg_row0, const ClnRowsBwd& p) {
+// GREG: the rows of g are already in registers (greg[tt][pp][j], same lane layout as the loads they replace) — the fused
+// block-tail backward hands the MLP half's result straight to the attention half's norm.
+template <int C, int TT, bool GREG = false>
+__device__ __forceinline__ void cln_bwd_rows(Frag<bf16_t> (&dzf)[TT][C / 32], char* lds, int wg_row0, const ClnRowsBwd& p,
+                                             const float (*greg)[C / 32][8] = nullptr) {
   constexpr int KJ = C / 32, PD = C + 8;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int prow = lane >> 2, q = lane & 3;
@@ -140,7 +143,12 @@ __device__ __forceinline__ void cln_bwd_rows(Frag<bf16_t> (&dzf)[TT][C / 32], ch
     for (int pp = 0; pp < KJ; ++pp) {
       const int col = pp * 32 + q * 8;
       float zz[8], ga[8];
-      ld8(p.g, SCOT_F32, base + col, d[pp]);
+      if (GREG) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) d[pp][j] = greg[tt][pp][j];
+      } else {
+        ld8(p.g, SCOT_F32, base + col, d[pp]);
+      }
       ld8(p.z, SCOT_F32, base + col, zz);
       gamma8(col, ga);
 #pragma unroll

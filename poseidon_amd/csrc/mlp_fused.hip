@@ -289,8 +289,16 @@ __device__ __forceinline__ Frag<bf16_t> lds_frag_ks_perm(const bf16_t* t, int pi
   return f;
 }
 
-template <int C, int HC, int TT>
-__global__ __launch_bounds__(256, 2) void mlp_bwd_fused_kernel(MlpBwdArgs p) {
+template <int C, int HC> struct MlpBwdLds {
+  static constexpr size_t WBYTES = (size_t)(HC * (C + 8) + C * (HC + 8)) * 2, PBYTES = (size_t)4 * 16 * (C + 4) * 4;
+  static constexpr size_t P1BYTES = ClnBwdLds<C>::bytes;
+  static constexpr size_t bytes = WBYTES > PBYTES ? (WBYTES > P1BYTES ? WBYTES : P1BYTES) : (PBYTES > P1BYTES ? PBYTES : P1BYTES);
+};
+
+// One workgroup's 64·TT rows of the MLP half's backward.  KEEP: the rows of g' = g + du·W1 are also returned in registers
+// (gkeep[tt][pp][j]: row row0 + 16 tt + (lane >> 2), columns 32 pp + 8 (lane & 3) + j) for the fused block tail.
+template <int C, int HC, int TT, bool KEEP>
+__device__ __forceinline__ void mlp_bwd_body(const MlpBwdArgs& p, char* smem, float (*gkeep)[C / 32][8]) {
   constexpr int KJ = C / 32, NT = C / 16, NB = HC / 32;
   constexpr int P1 = C + 8;            // W1 chunk [HC][P1]: k = hidden (rows), columns = channels
   constexpr int P2 = HC + 8;           // W2 chunk [C][P2]:  k = channels (rows), columns = hidden
@@ -298,14 +306,10 @@ __global__ __launch_bounds__(256, 2) void mlp_bwd_fused_kernel(MlpBwdArgs p) {
   constexpr int W1_EL = HC * P1, W2_EL = C * P2;
   constexpr int N1 = HC * C / 8, N2 = C * HC / 8;
   constexpr int PW1 = (N1 + 255) / 256, PW2 = (N2 + 255) / 256;
-  constexpr size_t WBYTES = (size_t)(W1_EL + W2_EL) * 2;
-  constexpr size_t PBYTES = (size_t)4 * 16 * CP * 4;
-  // one region, three lives: [dz patches | column sums] (phase 1)  ->  weight chunks (phase 2)  ->  fp32 patches (phase 3)
-  constexpr size_t P1BYTES = ClnBwdLds<C>::bytes;
-  constexpr size_t LDS_BYTES = WBYTES > PBYTES ? (WBYTES > P1BYTES ? WBYTES : P1BYTES) : (PBYTES > P1BYTES ? PBYTES : P1BYTES);
+  // one LDS region (MlpBwdLds<C, HC>::bytes), three lives: [dz patches | column sums] (phase 1) -> weight chunks (phase 2) ->
+  // fp32 patches (phase 3)
   static_assert((W1_EL * 2) % 16 == 0, "layout");
   static_assert(N1 % 256 == 0 && N2 % 256 == 0, "weight chunk pieces must divide over the 256 threads");
-  __shared__ __attribute__((aligned(16))) char smem[LDS_BYTES];
   bf16_t* W1c = (bf16_t*)smem;
   bf16_t* W2c = W1c + W1_EL;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4, lc = lane & 15;
@@ -436,10 +440,25 @@ __global__ __launch_bounds__(256, 2) void mlp_bwd_fused_kernel(MlpBwdArgs p) {
         o[0] = gi[0] + x0.x; o[1] = gi[1] + x0.y; o[2] = gi[2] + x0.z; o[3] = gi[3] + x0.w;
         o[4] = gi[4] + x1.x; o[5] = gi[5] + x1.y; o[6] = gi[6] + x1.z; o[7] = gi[7] + x1.w;
         st8(p.g_out, SCOT_F32, base + col, o);
+        if (KEEP) {
+#pragma unroll
+          for (int j = 0; j < 8; ++j) gkeep[tt][pp][j] = o[j];
+        }
       }
+    } else if (KEEP) {
+#pragma unroll
+      for (int pp = 0; pp < KJ; ++pp)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) gkeep[tt][pp][j] = 0.f;
     }
     __builtin_amdgcn_wave_barrier();
   }
+}
+
+template <int C, int HC, int TT>
+__global__ __launch_bounds__(256, 2) void mlp_bwd_fused_kernel(MlpBwdArgs p) {
+  __shared__ __attribute__((aligned(16))) char smem[MlpBwdLds<C, HC>::bytes];
+  mlp_bwd_body<C, HC, TT, false>(p, smem, nullptr);
 }
 
 extern int g_scot_use_tr;
@@ -549,22 +568,25 @@ struct ProjClnBwdArgs {
   int use_tr;
 };
 
-template <int C, int TT>
-__global__ __launch_bounds__(256, 2) void proj_cln_bwd_fused_kernel(ProjClnBwdArgs p) {
+template <int C> struct ProjBwdLds {
+  static constexpr size_t WBYTES = (size_t)96 * (C + 8) * 2, PBYTES = (size_t)4 * 16 * (C + 4) * 4, P1BYTES = ClnBwdLds<C>::bytes;
+  static constexpr size_t bytes = WBYTES > PBYTES ? (WBYTES > P1BYTES ? WBYTES : P1BYTES) : (PBYTES > P1BYTES ? PBYTES : P1BYTES);
+};
+
+// GREG: g rows come in registers (fused block tail), see cln_bwd_rows.  `smem`: ProjBwdLds<C>::bytes, dead on entry.
+template <int C, int TT, bool GREG>
+__device__ __forceinline__ void proj_cln_bwd_body(const ProjClnBwdArgs& p, char* smem, const float (*greg)[C / 32][8]) {
   constexpr int NT = C / 16, KC = 96, NKC = C / KC;
   constexpr int PW = C + 8;                        // W chunk [KC rows n][PW]: the contraction index runs over rows (K-strided)
   constexpr int NP = KC * C / 8, PWN = (NP + 255) / 256;
   constexpr int CP = C + 4;
-  constexpr size_t WBYTES = (size_t)KC * PW * 2, PBYTES = (size_t)4 * 16 * CP * 4, P1BYTES = ClnBwdLds<C>::bytes;
-  constexpr size_t LDS_BYTES = WBYTES > PBYTES ? (WBYTES > P1BYTES ? WBYTES : P1BYTES) : (PBYTES > P1BYTES ? PBYTES : P1BYTES);
-  __shared__ __attribute__((aligned(16))) char smem[LDS_BYTES];
   bf16_t* Wc = (bf16_t*)smem;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4, lc = lane & 15;
   const int wg_row0 = blockIdx.x * (64 * TT);
   const int row0 = wg_row0 + wave * (16 * TT);
 
   Frag<bf16_t> dzf[TT][C / 32];
-  cln_bwd_rows<C, TT>(dzf, smem, wg_row0, p.b);
+  cln_bwd_rows<C, TT, GREG>(dzf, smem, wg_row0, p.b, greg);
   f32x4_t Y[TT][NT];
 #pragma unroll
   for (int tt = 0; tt < TT; ++tt)
@@ -615,6 +637,36 @@ __global__ __launch_bounds__(256, 2) void proj_cln_bwd_fused_kernel(ProjClnBwdAr
     }
     __builtin_amdgcn_wave_barrier();
   }
+}
+
+template <int C, int TT>
+__global__ __launch_bounds__(256, 2) void proj_cln_bwd_fused_kernel(ProjClnBwdArgs p) {
+  __shared__ __attribute__((aligned(16))) char smem[ProjBwdLds<C>::bytes];
+  proj_cln_bwd_body<C, TT, false>(p, smem, nullptr);
+}
+
+// ------------------------------------------------------------------------------------------------------------------------
+// The whole tail of a ScOTLayer's backward in ONE launch: MLP half (cond-LN backward -> dgrad fc2 · gelu' -> dgrad fc1 -> + g) and
+// attention-output half (cond-LN backward -> projection dgrad) for the same 64·TT rows.  The gradient of the residual stream
+// between the two halves stays in registers (it is still written once: the qkv dgrad accumulates into it), which removes one
+// launch and one 4·C-byte-per-token read from the dependent chain of the token-heavy stages.
+struct TailBwdArgs { MlpBwdArgs m; ProjClnBwdArgs pj; };
+
+template <int C, int HC, int TT>
+__global__ __launch_bounds__(256, 2) void tail_bwd_fused_kernel(TailBwdArgs p) {
+  constexpr size_t LDS = MlpBwdLds<C, HC>::bytes > ProjBwdLds<C>::bytes ? MlpBwdLds<C, HC>::bytes : ProjBwdLds<C>::bytes;
+  __shared__ __attribute__((aligned(16))) char smem[LDS];
+  float gk[TT][C / 32][8];
+  mlp_bwd_body<C, HC, TT, true>(p.m, smem, gk);
+  __syncthreads();                       // the MLP half's fp32 patches are dead: the norm's dz patches take their place
+  proj_cln_bwd_body<C, TT, true>(p.pj, smem, gk);
+}
+
+template <int C, int HC, int TT>
+static int launch_tail_bwd(const TailBwdArgs& a, hipStream_t s) {
+  dim3 grid((a.m.M + 64 * TT - 1) / (64 * TT)), block(256);
+  hipLaunchKernelGGL((tail_bwd_fused_kernel<C, HC, TT>), grid, block, 0, s, a);
+  return scot_check_launch();
 }
 
 static int rows_tile_count(int C, int M, int rows_per_sample) {
@@ -673,4 +725,40 @@ extern "C" int scot_proj_cln_bwd(const float* g, const float* z, const float* me
     hipLaunchKernelGGL((proj_cln_bwd_fused_kernel<192, 1>), grid, block, 0, stream, p);
   }
   return scot_check_launch();
+}
+
+
+// include/scot_hip.h: scot_block_tail_bwd = scot_mlp_block_bwd followed by scot_proj_cln_bwd on g_out, in one launch.
+extern "C" int scot_block_tail_bwd(const float* g, float* g_out,
+                                   /* MLP half */ const float* z2, const float* mean2, const float* rstd2, const float* gw_w2,
+                                   const float* gw_b2, const float* sscale2, const void* dact, const void* W1, const void* W2, void* dz2,
+                                   void* du, float* d_gw_w2, float* d_gw_b2, float* d_bw_w2, float* d_bw_b2,
+                                   /* attention-output half */ const float* z1, const float* mean1, const float* rstd1,
+                                   const float* gw_w1, const float* gw_b1, const float* sscale1, const void* Wo, void* dz1, void* da,
+                                   float* d_gw_w1, float* d_gw_b1, float* d_bw_w1, float* d_bw_b1,
+                                   const float* time, int M, int rows_per_sample, int C, int hid, hipStream_t stream) {
+  if (M <= 0 || rows_per_sample <= 0) return SCOT_ERR_SHAPE;
+  if (C != 96 && C != 192) return SCOT_ERR_UNSUPPORTED;
+  if (mlp_chunk(C) != 64 || hid < 64 || hid % 64 != 0 || rows_per_sample % 64 != 0) return SCOT_ERR_UNSUPPORTED;
+  if (!g || !g_out || !z2 || !mean2 || !rstd2 || !gw_b2 || !dact || !W1 || !W2 || !dz2 || !du || !d_gw_b2 || !d_bw_b2 || !z1 || !mean1 ||
+      !rstd1 || !gw_b1 || !Wo || !dz1 || !da || !d_gw_b1 || !d_bw_b1)
+    return SCOT_ERR_SHAPE;
+  if ((gw_w2 == nullptr) != (d_gw_w2 == nullptr) || (d_gw_w2 == nullptr) != (d_bw_w2 == nullptr) || (gw_w1 == nullptr) != (gw_w2 == nullptr) ||
+      (gw_w1 == nullptr) != (d_gw_w1 == nullptr) || (d_gw_w1 == nullptr) != (d_bw_w1 == nullptr))
+    return SCOT_ERR_SHAPE;
+  static int tt_env = -1;
+  if (tt_env < 0) { const char* e = getenv("SCOT_MLP_TT"); tt_env = e ? atoi(e) : 0; }
+  int tt = tt_env ? tt_env : ((C == 96 && M >= 64 * 2 * 512) ? 2 : 1);
+  if (C != 96 || rows_per_sample % (64 * tt) != 0) tt = 1;
+  TailBwdArgs a;
+  a.m.g = g; a.m.g_out = g_out; a.m.z = z2; a.m.mean = mean2; a.m.rstd = rstd2; a.m.time = time; a.m.gw_w = gw_w2; a.m.gw_b = gw_b2;
+  a.m.sscale = sscale2; a.m.dact = (const bf16_t*)dact; a.m.W1 = (const bf16_t*)W1; a.m.W2 = (const bf16_t*)W2; a.m.dz = (bf16_t*)dz2;
+  a.m.du = (bf16_t*)du; a.m.d_gw_w = d_gw_w2; a.m.d_gw_b = d_gw_b2; a.m.d_bw_w = d_bw_w2; a.m.d_bw_b = d_bw_b2;
+  a.m.M = M; a.m.rows_per_sample = rows_per_sample; a.m.hid = hid; a.m.use_tr = g_scot_use_tr;
+  a.pj.W = (const bf16_t*)Wo; a.pj.da = (bf16_t*)da; a.pj.use_tr = g_scot_use_tr;
+  a.pj.b.g = g_out; a.pj.b.z = z1; a.pj.b.mean = mean1; a.pj.b.rstd = rstd1; a.pj.b.time = time; a.pj.b.gw_w = gw_w1; a.pj.b.gw_b = gw_b1;
+  a.pj.b.sscale = sscale1; a.pj.b.dz = (bf16_t*)dz1; a.pj.b.d_gw_w = d_gw_w1; a.pj.b.d_gw_b = d_gw_b1; a.pj.b.d_bw_w = d_bw_w1;
+  a.pj.b.d_bw_b = d_bw_b1; a.pj.b.M = M; a.pj.b.rows_per_sample = rows_per_sample;
+  if (C == 96) return tt == 2 ? launch_tail_bwd<96, 64, 2>(a, stream) : launch_tail_bwd<96, 64, 1>(a, stream);
+  return launch_tail_bwd<192, 64, 1>(a, stream);
 }

@@ -125,6 +125,7 @@ class ScOTEngine:
         # A/B knobs for the first measurements: which channel widths and which of the four kernels take the fused path
         self.fused_c = {int(c) for c in os.environ.get("SCOT_FUSED_C", "96,192").split(",") if c}
         self.fused_parts = set(os.environ.get("SCOT_FUSED_PARTS", "mlp_fwd,mlp_bwd,proj_fwd,proj_bwd").split(","))
+        self.fused_tail = os.environ.get("SCOT_FUSED_TAIL", "1") == "1"     # MLP-half + projection-half backward in one launch
         # bf16 mode: GEMM operands must already be bf16 in HBM (gemm_fast streams raw 16-byte chunks into LDS), so the
         # weights get a bf16 shadow arena that is re-cast from the fp32 master at the start of EVERY forward (one pass,
         # inside the timed step), and every producer of a GEMM operand also writes a bf16 copy.
@@ -708,7 +709,31 @@ class ScOTEngine:
         a = pre + ".attention.self."
         L, Lp = H * W, Hp * Wp
         hid = int(cfg.mlp_ratio * C)
-        if self.use_fused("mlp_bwd", C) and hid % 128 == 0 and L % 64 == 0 and not self.split_ln_bwd:
+        mlp_f = self.use_fused("mlp_bwd", C) and hid % 128 == 0 and L % 64 == 0 and not self.split_ln_bwd
+        proj_f = self.use_fused("proj_bwd", C) and L % 64 == 0 and not self.split_ln_bwd
+        d_attn = self.new(B * L, C, dtype=adt)
+        done_tail = False
+        if mlp_f and proj_f and self.fused_tail:
+            # both halves of the block tail in one launch: the residual-stream gradient between them stays in registers
+            d_y2, d_u, d_proj = self.new(B * L, C, dtype=adt), self.new(B * L, hid, dtype=adt), self.new(B * L, C, dtype=adt)
+            n2, g2 = self._norm_params(pre + ".layernorm_after"), self._norm_grads(pre + ".layernorm_after")
+            n1, g1 = self._norm_params(pre + ".layernorm_before"), self._norm_grads(pre + ".layernorm_before")
+            gout = g if self.inplace_g else self.new(B * L, C)
+            done_tail = ops.block_tail_bwd(
+                g, gout,
+                (rec["y2"], rec["st2"][0], rec["st2"][1], n2[0], n2[1], rec["dp"][1], rec["gp"], self.W(pre + ".intermediate.dense.weight"),
+                 self.W(pre + ".output.dense.weight"), d_y2, d_u, g2[0], g2[1], g2[2], g2[3]),
+                (rec["proj"], rec["st1"][0], rec["st1"][1], n1[0], n1[1], rec["dp"][0], self.W(pre + ".attention.output.dense.weight"),
+                 d_proj, d_attn, g1[0], g1[1], g1[2], g1[3]),
+                time if self.cond else None, B * L, L, C, hid)
+            if done_tail:
+                g = gout
+                self.linear_bwd_params(pre + ".output.dense.weight", pre + ".output.dense.bias", d_y2, rec["u"])
+                self.linear_bwd_params(pre + ".intermediate.dense.weight", pre + ".intermediate.dense.bias", d_u, rec["h16"])
+                self.linear_bwd_params(pre + ".attention.output.dense.weight", pre + ".attention.output.dense.bias", d_proj, rec["attn_c"])
+        if done_tail:
+            pass
+        elif mlp_f:
             # the whole dependent chain of the MLP half in one launch; the two weight gradients follow on the side stream
             d_y2 = self.new(B * L, C, dtype=adt)
             d_u = self.new(B * L, hid, dtype=adt)
@@ -733,8 +758,9 @@ class ScOTEngine:
             self.linear_bwd_params(pre + ".intermediate.dense.weight", pre + ".intermediate.dense.bias", d_u, rec["h16"])
             g = self.dgrad_into(cm, d_u, self.W(pre + ".intermediate.dense.weight"), g)
         # h = x + CLN_before(proj)
-        d_attn = self.new(B * L, C, dtype=adt)
-        if self.use_fused("proj_bwd", C) and L % 64 == 0 and not self.split_ln_bwd:
+        if done_tail:
+            pass
+        elif proj_f:
             d_proj = self.new(B * L, C, dtype=adt)
             gw_w, gw_b, _, _ = self._norm_params(pre + ".layernorm_before")
             gg = self._norm_grads(pre + ".layernorm_before")

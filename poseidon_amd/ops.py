@@ -246,6 +246,19 @@ def mlp_block_bwd(g, g_out, z, mean, rstd, time, gw_w, gw_b, sample_scale, dact,
     return True
 
 
+def block_tail_bwd(g, g_out, mlp, proj, time, rows, rows_per_sample, C, hid) -> bool:
+    """The tail of a ScOTLayer's backward in one launch: mlp_block_bwd then proj_cln_bwd on its result (which stays in
+    registers in between).  mlp = (z2, mean2, rstd2, gw_w2, gw_b2, sscale2, dact, w1, w2, dz2, du, d_gw_w2, d_gw_b2, d_bw_w2,
+    d_bw_b2); proj = (z1, mean1, rstd1, gw_w1, gw_b1, sscale1, wo, dz1, da, d_gw_w1, d_gw_b1, d_bw_w1, d_bw_b1).  False = not
+    covered (the caller launches the two kernels)."""
+    rc = L().scot_block_tail_bwd(ptr(g), ptr(g_out), *[ptr(t) for t in mlp], *[ptr(t) for t in proj], ptr(time), rows,
+                                 rows_per_sample, C, hid, stream())
+    if rc == -3:
+        return False
+    _lib.check(rc, "scot_block_tail_bwd")
+    return True
+
+
 def proj_cln_fwd(a, w, bias, resid, out, out16, z, mean, rstd, time, gw_w, gw_b, bw_w, bw_b, sample_scale, rows, rows_per_sample, C,
                  eps) -> bool:
     """Out-projection GEMM with cond-LN + residual in its epilogue (csrc/mlp_fused.hip).  False = not covered."""
