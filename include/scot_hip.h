@@ -174,6 +174,15 @@ int scot_block_tail_bwd(const float* g, float* g_out, const float* z2, const flo
                         const float* rstd1, const float* gw_w1, const float* gw_b1, const float* sscale1, const void* Wo, void* dz1,
                         void* da, float* d_gw_w1, float* d_gw_b1, float* d_bw_w1, float* d_bw_b1, const float* time, int M,
                         int rows_per_sample, int C, int hid, scot_stream_t stream);
+/* scot_proj_cln_fwd followed by scot_mlp_block_fwd on its output, for the same rows, in ONE launch (HF:478-489 + ref:560-565, then
+ * HF:533-561 + ref:566-579): h / h16 are written (the backward reads them) but not re-read.  Suffix 1 = attention half's norm
+ * (layernorm_before), 2 = MLP half's (layernorm_after); arguments as in the two entry points.  C in {96, 192}; -3 otherwise. */
+int scot_block_tail_fwd(const void* a, const void* Wo, const float* bo, const float* x, float* h, void* h16, float* z1, float* mean1,
+                        float* rstd1, const float* gw_w1, const float* gw_b1, const float* bw_w1, const float* bw_b1,
+                        const float* sscale1, const void* W1, const float* b1, const void* W2, const float* b2, float* out, void* out16,
+                        void* act, void* dact, float* z2, float* mean2, float* rstd2, const float* gw_w2, const float* gw_b2,
+                        const float* bw_w2, const float* bw_b2, const float* sscale2, const float* time, int M, int rows_per_sample,
+                        int C, int hid, float eps, scot_stream_t stream);
 
 /* Data movement */
 int scot_add(const void* a, int a_dt, const void* b, int b_dt, void* out, int out_dt, size_t n, size_t period,

@@ -18,8 +18,11 @@ struct ClnRowsOut {
 
 // Y[tt][nt]: accumulator tiles of the wave's rows row0 + 16 tt .. (C/D layout: row 4g + r, column 16 nt + lc).
 // patch_base: LDS, 4 waves x 16 x (C+4) floats, must be dead (the caller has passed a __syncthreads since its last use).
+// tile16 (optional): per-wave LDS tile [16·TT][C + 8] that also receives the 16-bit output rows (the fused block tail reads them
+// back as MFMA operand fragments instead of re-loading out16 from HBM); must not overlap the fp32 patches.
 template <int C, int TT>
-__device__ __forceinline__ void cln_rows_epilogue(f32x4_t (&Y)[TT][C / 16], float* patch_base, int row0, const ClnRowsOut& p) {
+__device__ __forceinline__ void cln_rows_epilogue(f32x4_t (&Y)[TT][C / 16], float* patch_base, int row0, const ClnRowsOut& p,
+                                                  bf16_t* tile16 = nullptr) {
   constexpr int KJ = C / 32, NT = C / 16, CP = C + 4;   // CP % 16 == 4: the 4 row groups of a tile write disjoint banks
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, g = lane >> 4, lc = lane & 15;
   float* Ct = patch_base + wave * 16 * CP;
@@ -77,7 +80,12 @@ __device__ __forceinline__ void cln_rows_epilogue(f32x4_t (&Y)[TT][C / 16], floa
         }
         st8(p.out, SCOT_F32, base + col, o);
         if (p.out16) st8(p.out16, SCOT_BF16, base + col, o);
+        if (tile16) store8_ct(tile16 + (tt * 16 + prow) * (C + 8) + col, o);
       }
+    } else if (tile16) {
+      const float zero[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int pp = 0; pp < KJ; ++pp) store8_ct(tile16 + (tt * 16 + prow) * (C + 8) + pp * 32 + q * 8, zero);
     }
     __builtin_amdgcn_wave_barrier();
   }

@@ -41,8 +41,15 @@ struct MlpArgs {
   float eps;
 };
 
-template <int C, int HC, int TT>
-__global__ __launch_bounds__(256, 2) void mlp_fused_kernel(MlpArgs p) {
+template <int C, int HC> struct MlpFwdLds {
+  static constexpr size_t WBYTES = (size_t)(HC * (C + 8) + C * (HC + 8)) * 2 + (size_t)256 * 4, PBYTES = (size_t)4 * 16 * (C + 4) * 4;
+  static constexpr size_t bytes = WBYTES > PBYTES ? WBYTES : PBYTES;
+};
+
+// One workgroup's 64·TT rows of the MLP half.  HTILE: the wave's token rows are read from its LDS tile `htile` ([16·TT][C + 8],
+// written by the projection half's epilogue in the fused block tail) instead of from p.h16; the tile may alias `smem`.
+template <int C, int HC, int TT, bool HTILE>
+__device__ __forceinline__ void mlp_fwd_body(const MlpArgs& p, char* smem, const bf16_t* htile) {
   constexpr int KJ = C / 32;           // K-steps of GEMM 1 (K = C)
   constexpr int NT = C / 16;           // channel tiles of GEMM 2 / of the output
   constexpr int NB = HC / 32;          // 32-hidden blocks per chunk
@@ -52,12 +59,9 @@ __global__ __launch_bounds__(256, 2) void mlp_fused_kernel(MlpArgs p) {
   constexpr int W1_EL = HC * P1, W2_EL = C * P2;
   constexpr int N1 = HC * C / 8, N2 = C * HC / 8;          // 16-byte pieces per chunk
   constexpr int PW1 = (N1 + 255) / 256, PW2 = (N2 + 255) / 256;
-  constexpr size_t WBYTES = (size_t)(W1_EL + W2_EL) * 2 + (size_t)256 * 4;      // + b1 chunk, one slot per thread (HC used)
-  constexpr size_t PBYTES = (size_t)4 * 16 * CP * 4;
-  constexpr size_t LDS_BYTES = WBYTES > PBYTES ? WBYTES : PBYTES;
+  // LDS (MlpFwdLds<C, HC>::bytes): weight chunks + b1 chunk (one slot per thread, HC used), later the epilogue's fp32 patches
   static_assert(N1 % 256 == 0 && N2 % 256 == 0, "weight chunk pieces must divide over the 256 threads");
   static_assert(HC <= 256 && C % 32 == 0 && HC % 32 == 0 && (W1_EL * 2) % 16 == 0 && ((W1_EL + W2_EL) * 2) % 16 == 0, "layout");
-  __shared__ __attribute__((aligned(16))) char smem[LDS_BYTES];
   bf16_t* W1c = (bf16_t*)smem;
   bf16_t* W2c = W1c + W1_EL;
   float* b1c = (float*)(W2c + W2_EL);
@@ -70,11 +74,17 @@ __global__ __launch_bounds__(256, 2) void mlp_fused_kernel(MlpArgs p) {
   Frag<bf16_t> hf[TT][KJ];
 #pragma unroll
   for (int tt = 0; tt < TT; ++tt) {
-    const int row = min(row0 + tt * 16 + lc, p.M - 1);
-    const bf16_t* src = p.h16 + (size_t)row * C + g * 8;
+    if (HTILE) {
 #pragma unroll
-    for (int j = 0; j < KJ; ++j) hf[tt][j].v = *(const s16x8_t*)(src + j * 32);
+      for (int j = 0; j < KJ; ++j) hf[tt][j].v = *(const s16x8_t*)(htile + (tt * 16 + lc) * (C + 8) + j * 32 + g * 8);
+    } else {
+      const int row = min(row0 + tt * 16 + lc, p.M - 1);
+      const bf16_t* src = p.h16 + (size_t)row * C + g * 8;
+#pragma unroll
+      for (int j = 0; j < KJ; ++j) hf[tt][j].v = *(const s16x8_t*)(src + j * 32);
+    }
   }
+  if (HTILE) __syncthreads();          // every wave has its rows in registers: the tile may alias the weight chunk filled next
 
   // ---- weight chunk: global -> registers (unconditional, clamped piece index) -> LDS
   u32x4_t r1[PW1], r2[PW2];
@@ -191,6 +201,12 @@ __global__ __launch_bounds__(256, 2) void mlp_fused_kernel(MlpArgs p) {
   e.bw_b = p.bw_b; e.sscale = p.sscale; e.resid = p.h; e.out = p.out; e.out16 = p.out16; e.M = p.M; e.rows_per_sample = p.rows_per_sample;
   e.eps = p.eps;
   cln_rows_epilogue<C, TT>(Y, (float*)smem, row0, e);
+}
+
+template <int C, int HC, int TT>
+__global__ __launch_bounds__(256, 2) void mlp_fused_kernel(MlpArgs p) {
+  __shared__ __attribute__((aligned(16))) char smem[MlpFwdLds<C, HC>::bytes];
+  mlp_fwd_body<C, HC, TT, false>(p, smem, nullptr);
 }
 
 // Hidden units per LDS weight chunk.  The chunk's 16-byte pieces must divide evenly over the 256 threads (HC·C/8 % 256 == 0:
@@ -508,15 +524,18 @@ struct ProjClnArgs {
   ClnRowsOut e;
 };
 
+template <int C> struct ProjFwdLds {
+  static constexpr size_t WBYTES = (size_t)C * (96 + 8) * 2, PBYTES = (size_t)4 * 16 * (C + 4) * 4;
+  static constexpr size_t bytes = WBYTES > PBYTES ? WBYTES : PBYTES;
+};
+
+// `tile16`: see cln_rows_epilogue (per-wave LDS tile of the 16-bit output rows, beyond the fp32 patches), or nullptr.
 template <int C, int TT>
-__global__ __launch_bounds__(256, 2) void proj_cln_fused_kernel(ProjClnArgs p) {
+__device__ __forceinline__ void proj_cln_fwd_body(const ProjClnArgs& p, char* smem, bf16_t* tile16) {
   constexpr int KJ = C / 32, NT = C / 16, KC = 96, NKC = C / KC;
   constexpr int PW = KC + 8;                       // W chunk [C][PW]: K-contiguous columns kc·96 .. +95 of every row
   constexpr int NP = C * KC / 8, PWN = (NP + 255) / 256;
-  constexpr size_t WBYTES = (size_t)C * PW * 2, PBYTES = (size_t)4 * 16 * (C + 4) * 4;
-  constexpr size_t LDS_BYTES = WBYTES > PBYTES ? WBYTES : PBYTES;
   static_assert(C % KC == 0, "K chunking");
-  __shared__ __attribute__((aligned(16))) char smem[LDS_BYTES];
   bf16_t* Wc = (bf16_t*)smem;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4, lc = lane & 15;
   const int row0 = (blockIdx.x * 4 + wave) * (16 * TT);
@@ -558,7 +577,39 @@ __global__ __launch_bounds__(256, 2) void proj_cln_fused_kernel(ProjClnArgs p) {
       }
   }
   __syncthreads();                                 // the epilogue patches alias the weight chunk
-  cln_rows_epilogue<C, TT>(Y, (float*)smem, row0, p.e);
+  cln_rows_epilogue<C, TT>(Y, (float*)smem, row0, p.e, tile16);
+}
+
+template <int C, int TT>
+__global__ __launch_bounds__(256, 2) void proj_cln_fused_kernel(ProjClnArgs p) {
+  __shared__ __attribute__((aligned(16))) char smem[ProjFwdLds<C>::bytes];
+  proj_cln_fwd_body<C, TT>(p, smem, nullptr);
+}
+
+// ------------------------------------------------------------------------------------------------------------------------
+// The whole tail of a ScOTLayer's forward in ONE launch: h = x + s·CLN(attn · Wo^T + bo), then out = h + s·CLN(MLP(h)), for the
+// same 64·TT rows.  h is written once (fp32 + 16-bit: the backward and the weight gradients read them) but not re-read: the MLP
+// half takes its operand rows from the LDS tile the projection half's epilogue filled, and its residual from the values the
+// same lanes just stored.
+struct TailFwdArgs { ProjClnArgs pj; MlpArgs m; };
+
+template <int C, int HC, int TT>
+__global__ __launch_bounds__(256, 2) void tail_fwd_fused_kernel(TailFwdArgs p) {
+  constexpr size_t PATCH = (size_t)4 * 16 * (C + 4) * 4, TILE = (size_t)4 * 16 * TT * (C + 8) * 2;
+  constexpr size_t A = ProjFwdLds<C>::bytes > PATCH + TILE ? ProjFwdLds<C>::bytes : PATCH + TILE;
+  constexpr size_t LDS = A > MlpFwdLds<C, HC>::bytes ? A : MlpFwdLds<C, HC>::bytes;
+  __shared__ __attribute__((aligned(16))) char smem[LDS];
+  bf16_t* tile = (bf16_t*)(smem + PATCH) + (threadIdx.x >> 6) * 16 * TT * (C + 8);
+  proj_cln_fwd_body<C, TT>(p.pj, smem, tile);
+  __builtin_amdgcn_wave_barrier();       // the tile is written and read by the same wave
+  mlp_fwd_body<C, HC, TT, true>(p.m, smem, tile);
+}
+
+template <int C, int HC, int TT>
+static int launch_tail_fwd(const TailFwdArgs& a, hipStream_t s) {
+  dim3 grid((a.m.M + 64 * TT - 1) / (64 * TT)), block(256);
+  hipLaunchKernelGGL((tail_fwd_fused_kernel<C, HC, TT>), grid, block, 0, s, a);
+  return scot_check_launch();
 }
 
 struct ProjClnBwdArgs {
@@ -761,4 +812,36 @@ extern "C" int scot_block_tail_bwd(const float* g, float* g_out,
   a.pj.b.d_bw_b = d_bw_b1; a.pj.b.M = M; a.pj.b.rows_per_sample = rows_per_sample;
   if (C == 96) return tt == 2 ? launch_tail_bwd<96, 64, 2>(a, stream) : launch_tail_bwd<96, 64, 1>(a, stream);
   return launch_tail_bwd<192, 64, 1>(a, stream);
+}
+
+
+// include/scot_hip.h: scot_block_tail_fwd = scot_proj_cln_fwd followed by scot_mlp_block_fwd on its output, in one launch.
+extern "C" int scot_block_tail_fwd(/* attention-output half */ const void* a, const void* Wo, const float* bo, const float* x, float* h,
+                                   void* h16, float* z1, float* mean1, float* rstd1, const float* gw_w1, const float* gw_b1,
+                                   const float* bw_w1, const float* bw_b1, const float* sscale1,
+                                   /* MLP half */ const void* W1, const float* b1, const void* W2, const float* b2, float* out,
+                                   void* out16, void* act, void* dact, float* z2, float* mean2, float* rstd2, const float* gw_w2,
+                                   const float* gw_b2, const float* bw_w2, const float* bw_b2, const float* sscale2,
+                                   const float* time, int M, int rows_per_sample, int C, int hid, float eps, hipStream_t stream) {
+  if (M <= 0 || rows_per_sample <= 0) return SCOT_ERR_SHAPE;
+  if (C != 96 && C != 192) return SCOT_ERR_UNSUPPORTED;
+  if (mlp_chunk(C) != 64 || hid < 64 || hid % 64 != 0) return SCOT_ERR_UNSUPPORTED;
+  if (!a || !Wo || !bo || !x || !h || !h16 || !gw_b1 || !bw_b1 || !W1 || !b1 || !W2 || !b2 || !out || !gw_b2 || !bw_b2) return SCOT_ERR_SHAPE;
+  if ((act == nullptr) != (dact == nullptr) || (mean1 == nullptr) != (rstd1 == nullptr) || (mean2 == nullptr) != (rstd2 == nullptr) ||
+      (gw_w1 == nullptr) != (bw_w1 == nullptr) || (gw_w2 == nullptr) != (bw_w2 == nullptr) || (gw_w1 == nullptr) != (gw_w2 == nullptr))
+    return SCOT_ERR_SHAPE;
+  TailFwdArgs t;
+  t.pj.a = (const bf16_t*)a; t.pj.W = (const bf16_t*)Wo;
+  t.pj.e.bias = bo; t.pj.e.z = z1; t.pj.e.mean = mean1; t.pj.e.rstd = rstd1; t.pj.e.time = time; t.pj.e.gw_w = gw_w1; t.pj.e.gw_b = gw_b1;
+  t.pj.e.bw_w = bw_w1; t.pj.e.bw_b = bw_b1; t.pj.e.sscale = sscale1; t.pj.e.resid = x; t.pj.e.out = h; t.pj.e.out16 = (bf16_t*)h16;
+  t.pj.e.M = M; t.pj.e.rows_per_sample = rows_per_sample; t.pj.e.eps = eps;
+  t.m.h16 = (const bf16_t*)h16; t.m.h = h; t.m.W1 = (const bf16_t*)W1; t.m.b1 = b1; t.m.W2 = (const bf16_t*)W2; t.m.b2 = b2;
+  t.m.out = out; t.m.out16 = (bf16_t*)out16; t.m.act = (bf16_t*)act; t.m.dact = (bf16_t*)dact; t.m.z = z2; t.m.mean = mean2; t.m.rstd = rstd2;
+  t.m.time = time; t.m.gw_w = gw_w2; t.m.gw_b = gw_b2; t.m.bw_w = bw_w2; t.m.bw_b = bw_b2; t.m.sscale = sscale2;
+  t.m.M = M; t.m.rows_per_sample = rows_per_sample; t.m.hid = hid; t.m.eps = eps;
+  static int tt_env = -1;
+  if (tt_env < 0) { const char* e = getenv("SCOT_MLP_TT"); tt_env = e ? atoi(e) : 0; }
+  const int tt = C == 96 ? (tt_env ? tt_env : (M >= 64 * 2 * 512 ? 2 : 1)) : 1;
+  if (C == 96) return tt == 2 ? launch_tail_fwd<96, 64, 2>(t, stream) : launch_tail_fwd<96, 64, 1>(t, stream);
+  return launch_tail_fwd<192, 64, 1>(t, stream);
 }

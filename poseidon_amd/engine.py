@@ -581,7 +581,30 @@ class ScOTEngine:
             attn_c = attn
         dp1 = self.drop_path_scale(pre, B, 0) if self.stochastic else None
         dp2 = self.drop_path_scale(pre, B, 1) if self.stochastic else None
-        if self.use_fused("proj_fwd", C):
+        hid = int(cfg.mlp_ratio * C)
+        proj_f = self.use_fused("proj_fwd", C)
+        mlp_f = self.use_fused("mlp_fwd", C) and hid % 128 == 0
+        done_tail = False
+        if proj_f and mlp_f and self.fused_tail and os.environ.get("SCOT_FUSED_TAIL_FWD", "1") == "1":
+            # projection + norm + residual, then MLP + norm + residual, for the same rows in one launch
+            proj = self.new(B * L, C) if train else None
+            st1 = (self.new(B * L), self.new(B * L)) if train else (None, None)
+            h, h16 = self.new(B * L, C), self.new(B * L, C, dtype=self.adt)
+            u = self.new(B * L, hid, dtype=self.adt) if train else None
+            gp = self.new(B * L, hid, dtype=self.adt) if train else None
+            y2 = self.new(B * L, C) if train else None
+            st2 = (self.new(B * L), self.new(B * L)) if train else (None, None)
+            out, out16 = self.new(B * L, C), self.new(B * L, C, dtype=self.adt)
+            n1, n2 = self._norm_params(pre + ".layernorm_before"), self._norm_params(pre + ".layernorm_after")
+            done_tail = ops.block_tail_fwd(
+                (attn_c, self.W(pre + ".attention.output.dense.weight"), self.P(pre + ".attention.output.dense.bias"), x, h, h16, proj,
+                 st1[0], st1[1], n1[0], n1[1], n1[2], n1[3], dp1),
+                (self.W(pre + ".intermediate.dense.weight"), self.P(pre + ".intermediate.dense.bias"), self.W(pre + ".output.dense.weight"),
+                 self.P(pre + ".output.dense.bias"), out, out16, u, gp, y2, st2[0], st2[1], n2[0], n2[1], n2[2], n2[3], dp2),
+                time if self.cond else None, B * L, L, C, hid, cfg.layer_norm_eps)
+        if done_tail:
+            pass
+        elif proj_f:
             proj = self.new(B * L, C) if train else None
             st1 = (self.new(B * L), self.new(B * L)) if train else (None, None)
             h, h16 = self.new(B * L, C), self.new(B * L, C, dtype=self.adt)
@@ -596,8 +619,9 @@ class ScOTEngine:
                            bias=self.P(pre + ".attention.output.dense.bias"))
             h, h16, st1 = self.norm_fwd(pre + ".layernorm_before", proj, x, L, C, cfg.layer_norm_eps, time, need_stats=train,
                                         copy=True, sample_scale=dp1)
-        hid = int(cfg.mlp_ratio * C)
-        if self.use_fused("mlp_fwd", C) and hid % 128 == 0:
+        if done_tail:
+            pass
+        elif mlp_f:
             u = self.new(B * L, hid, dtype=self.adt) if train else None
             gp = self.new(B * L, hid, dtype=self.adt) if train else None
             y2 = self.new(B * L, C) if train else None

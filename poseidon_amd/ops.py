@@ -246,6 +246,18 @@ def mlp_block_bwd(g, g_out, z, mean, rstd, time, gw_w, gw_b, sample_scale, dact,
     return True
 
 
+def block_tail_fwd(proj, mlp, time, rows, rows_per_sample, C, hid, eps) -> bool:
+    """The tail of a ScOTLayer's forward in one launch: proj_cln_fwd then mlp_block_fwd on its output rows (handed over through
+    LDS).  proj = (attn, wo, bo, x, h, h16, z1, mean1, rstd1, gw_w1, gw_b1, bw_w1, bw_b1, sscale1); mlp = (w1, b1, w2, b2, out,
+    out16, act, dact, z2, mean2, rstd2, gw_w2, gw_b2, bw_w2, bw_b2, sscale2).  False = not covered."""
+    rc = L().scot_block_tail_fwd(*[ptr(t) for t in proj], *[ptr(t) for t in mlp], ptr(time), rows, rows_per_sample, C, hid,
+                                 float(eps), stream())
+    if rc == -3:
+        return False
+    _lib.check(rc, "scot_block_tail_fwd")
+    return True
+
+
 def block_tail_bwd(g, g_out, mlp, proj, time, rows, rows_per_sample, C, hid) -> bool:
     """The tail of a ScOTLayer's backward in one launch: mlp_block_bwd then proj_cln_bwd on its result (which stays in
     registers in between).  mlp = (z2, mean2, rstd2, gw_w2, gw_b2, sscale2, dact, w1, w2, dz2, du, d_gw_w2, d_gw_b2, d_bw_w2,
