@@ -182,6 +182,7 @@ def gpu_test_bodies(emu, monkeypatch):
 def test_fused_mlp_and_projection_forward(gpu_test_bodies, train, cond, B, L, C):
     gpu_test_bodies.test_mlp_block_fused(train, cond, B, L, C)
     gpu_test_bodies.test_proj_cln_fused(train, cond, B, L, C)
+    gpu_test_bodies.test_block_tail_fwd_fused(train, cond, B, L, C)
 
 
 @pytest.mark.parametrize("cond,B,L,C", [(True, 1, 64, 96), (False, 1, 64, 192)] + full_only((False, 2, 128, 96), (True, 3, 64, 96),
@@ -189,6 +190,7 @@ def test_fused_mlp_and_projection_forward(gpu_test_bodies, train, cond, B, L, C)
 def test_fused_mlp_and_projection_backward(gpu_test_bodies, cond, B, L, C):
     gpu_test_bodies.test_mlp_block_bwd_fused(cond, B, L, C)
     gpu_test_bodies.test_proj_cln_bwd_fused(cond, B, L, C)
+    gpu_test_bodies.test_block_tail_bwd_fused(cond, B, L, C)
 
 
 @pytest.mark.parametrize("s,t", [(32, 64), (32, 16), (64, 32), (24, 40)])

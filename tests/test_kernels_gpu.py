@@ -638,3 +638,85 @@ def test_gemm_bf16x3_is_fp32_class(layout, M, N, K):
     ops.gemm(layout, ops.BF16, M, N, K, A.bfloat16(), A.shape[1], B.bfloat16(), B.shape[1], Cb, N, bias=bias, accumulate=layout == ops.TN)
     torch.cuda.synchronize()
     assert rel(Cb, ref) > 20 * e      # what the split buys
+
+
+# ----------------------------------------------------------------------------------------------- block tail (two halves, one launch)
+@pytest.mark.parametrize("train", [True, False])
+@pytest.mark.parametrize("cond", [True, False])
+@pytest.mark.parametrize("B,L,C", [(2, 1024, 96), (3, 192, 96), (64, 1024, 96), (2, 256, 192), (5, 64, 192)])
+def test_block_tail_fwd_fused(train, cond, B, L, C):
+    """scot_block_tail_fwd == scot_proj_cln_fwd followed by scot_mlp_block_fwd (the two validated launches it replaces): same
+    arithmetic in the same order, the MLP half's operand rows only travel through LDS instead of HBM — equal up to nothing."""
+    M, hid = B * L, 4 * C
+    bf = torch.bfloat16
+    a = rnd(M, C, seed=11).to(bf)
+    x = rnd(M, C, seed=12)
+    wo, bo = rnd(C, C, scale=C ** -0.5, seed=13).to(bf), rnd(C, seed=14, scale=0.2)
+    w1, b1 = rnd(hid, C, scale=C ** -0.5, seed=2).to(bf), rnd(hid, seed=3, scale=0.2)
+    w2, b2 = rnd(C, hid, scale=hid ** -0.5, seed=4).to(bf), rnd(C, seed=5, scale=0.2)
+    t = torch.rand(B, device=DEV) if cond else None
+    s1 = (torch.rand(B, device=DEV) > 0.3).float() / 0.7
+    s2 = (torch.rand(B, device=DEV) > 0.3).float() / 0.7
+    n1 = [rnd(C, seed=20, scale=0.3) if cond else None, 1 + rnd(C, seed=21, scale=0.1), rnd(C, seed=22, scale=0.1) if cond else None, rnd(C, seed=23, scale=0.1)]
+    n2 = [rnd(C, seed=6, scale=0.3) if cond else None, 1 + rnd(C, seed=7, scale=0.1), rnd(C, seed=8, scale=0.1) if cond else None, rnd(C, seed=9, scale=0.1)]
+
+    def bufs():
+        f = lambda *s, dtype=torch.float32: torch.full(s, float("nan"), device=DEV, dtype=dtype)
+        d = dict(h=f(M, C), h16=f(M, C, dtype=bf), out=f(M, C), out16=f(M, C, dtype=bf))
+        d.update(dict(z1=f(M, C), m1=f(M), r1=f(M), u=f(M, hid, dtype=bf), gp=f(M, hid, dtype=bf), z2=f(M, C), m2=f(M), r2=f(M)) if train else
+                 dict(z1=None, m1=None, r1=None, u=None, gp=None, z2=None, m2=None, r2=None))
+        return d
+    r = bufs()
+    assert ops.proj_cln_fwd(a, wo, bo, x, r["h"], r["h16"], r["z1"], r["m1"], r["r1"], t, n1[0], n1[1], n1[2], n1[3], s1, M, L, C, 1e-5)
+    assert ops.mlp_block_fwd(r["h16"], r["h"], w1, b1, w2, b2, r["out"], r["out16"], r["u"], r["gp"], r["z2"], r["m2"], r["r2"], t, n2[0], n2[1],
+                             n2[2], n2[3], s2, M, L, C, hid, 1e-5)
+    f = bufs()
+    assert ops.block_tail_fwd((a, wo, bo, x, f["h"], f["h16"], f["z1"], f["m1"], f["r1"], n1[0], n1[1], n1[2], n1[3], s1),
+                              (w1, b1, w2, b2, f["out"], f["out16"], f["u"], f["gp"], f["z2"], f["m2"], f["r2"], n2[0], n2[1], n2[2], n2[3], s2),
+                              t, M, L, C, hid, 1e-5)
+    torch.cuda.synchronize()
+    for k in r:
+        if r[k] is not None:
+            assert torch.isfinite(f[k].float()).all(), k
+            assert torch.equal(f[k], r[k]), (k, rel(f[k].float(), r[k].float()))
+
+
+@pytest.mark.parametrize("cond", [True, False])
+@pytest.mark.parametrize("B,L,C", [(2, 1024, 96), (3, 192, 96), (64, 1024, 96), (2, 256, 192), (5, 64, 192)])
+def test_block_tail_bwd_fused(cond, B, L, C):
+    """scot_block_tail_bwd == scot_mlp_block_bwd followed by scot_proj_cln_bwd on its g_out: the data tensors are equal, the
+    parameter-gradient sums (atomics) equal to accumulation order."""
+    M, hid = B * L, 4 * C
+    bf = torch.bfloat16
+    g0 = rnd(M, C, seed=31)
+    z2, z1 = rnd(M, C, seed=32), rnd(M, C, seed=33)
+    st = lambda z: (z.mean(-1).contiguous(), (1.0 / torch.sqrt(z.var(-1, unbiased=False) + 1e-5)).contiguous())
+    (m2, r2), (m1, r1) = st(z2), st(z1)
+    gp = rnd(M, hid, seed=34).to(bf)
+    w1, w2 = rnd(hid, C, scale=C ** -0.5, seed=2).to(bf), rnd(C, hid, scale=hid ** -0.5, seed=4).to(bf)
+    wo = rnd(C, C, scale=C ** -0.5, seed=13).to(bf)
+    t = torch.rand(B, device=DEV) if cond else None
+    s1 = (torch.rand(B, device=DEV) > 0.3).float() / 0.7
+    s2 = (torch.rand(B, device=DEV) > 0.3).float() / 0.7
+    gw2 = (rnd(C, seed=6, scale=0.3) if cond else None, 1 + rnd(C, seed=7, scale=0.1))
+    gw1 = (rnd(C, seed=20, scale=0.3) if cond else None, 1 + rnd(C, seed=21, scale=0.1))
+
+    def outs():
+        f = lambda *s, dtype=torch.float32: torch.full(s, float("nan"), device=DEV, dtype=dtype)
+        z = lambda: torch.zeros(C, device=DEV)
+        return dict(g=f(M, C), dz2=f(M, C, dtype=bf), du=f(M, hid, dtype=bf), dz1=f(M, C, dtype=bf), da=f(M, C, dtype=bf)), \
+            [z() if cond else None, z(), z() if cond else None, z()], [z() if cond else None, z(), z() if cond else None, z()]
+    r, rp2, rp1 = outs()
+    assert ops.mlp_block_bwd(g0, r["g"], z2, m2, r2, t, gw2[0], gw2[1], s2, gp, w1, w2, r["dz2"], r["du"], rp2[0], rp2[1], rp2[2], rp2[3], M, L, C,
+                             hid)
+    assert ops.proj_cln_bwd(r["g"], z1, m1, r1, t, gw1[0], gw1[1], s1, wo, r["dz1"], r["da"], rp1[0], rp1[1], rp1[2], rp1[3], M, L, C)
+    f, fp2, fp1 = outs()
+    assert ops.block_tail_bwd(g0, f["g"], (z2, m2, r2, gw2[0], gw2[1], s2, gp, w1, w2, f["dz2"], f["du"], fp2[0], fp2[1], fp2[2], fp2[3]),
+                              (z1, m1, r1, gw1[0], gw1[1], s1, wo, f["dz1"], f["da"], fp1[0], fp1[1], fp1[2], fp1[3]), t, M, L, C, hid)
+    torch.cuda.synchronize()
+    for k in r:
+        assert torch.isfinite(f[k].float()).all(), k
+        assert torch.equal(f[k], r[k]), (k, rel(f[k].float(), r[k].float()))
+    for a_, b_ in zip(fp2 + fp1, rp2 + rp1):
+        if a_ is not None:
+            assert rel(a_, b_) < 1e-4
