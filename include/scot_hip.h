@@ -172,8 +172,10 @@ int scot_block_tail_bwd(const float* g, float* g_out, const float* z2, const flo
                         const float* gw_b2, const float* sscale2, const void* dact, const void* W1, const void* W2, void* dz2, void* du,
                         float* d_gw_w2, float* d_gw_b2, float* d_bw_w2, float* d_bw_b2, const float* z1, const float* mean1,
                         const float* rstd1, const float* gw_w1, const float* gw_b1, const float* sscale1, const void* Wo, void* dz1,
-                        void* da, float* d_gw_w1, float* d_gw_b1, float* d_bw_w1, float* d_bw_b1, const float* time, int M,
-                        int rows_per_sample, int C, int hid, scot_stream_t stream);
+                        void* da, float* d_gw_w1, float* d_gw_b1, float* d_bw_w1, float* d_bw_b1,
+                        const void* dqkv, const void* Wqkv /* optional prologue, both or neither: g += dqkv[M,3C] · Wqkv[3C,C] in place
+                        (needs g_out == g) = the qkv projection's data gradient (HF:396-410) of the layer processed before */,
+                        const float* time, int M, int rows_per_sample, int C, int hid, scot_stream_t stream);
 /* scot_proj_cln_fwd followed by scot_mlp_block_fwd on its output, for the same rows, in ONE launch (HF:478-489 + ref:560-565, then
  * HF:533-561 + ref:566-579): h / h16 are written (the backward reads them) but not re-read.  Suffix 1 = attention half's norm
  * (layernorm_before), 2 = MLP half's (layernorm_after); arguments as in the two entry points.  C in {96, 192}; -3 otherwise. */

@@ -313,8 +313,11 @@ template <int C, int HC> struct MlpBwdLds {
 
 // One workgroup's 64·TT rows of the MLP half's backward.  KEEP: the rows of g' = g + du·W1 are also returned in registers
 // (gkeep[tt][pp][j]: row row0 + 16 tt + (lane >> 2), columns 32 pp + 8 (lane & 3) + j) for the fused block tail.
-template <int C, int HC, int TT, bool KEEP>
-__device__ __forceinline__ void mlp_bwd_body(const MlpBwdArgs& p, char* smem, float (*gkeep)[C / 32][8]) {
+// GIN: the rows of g arrive in registers (gin, same layout as gkeep: the fused qkv-dgrad prologue produced them and also stored
+// them to p.g, which phase 3 re-reads with the same lanes).
+template <int C, int HC, int TT, bool KEEP, bool GIN = false>
+__device__ __forceinline__ void mlp_bwd_body(const MlpBwdArgs& p, char* smem, float (*gkeep)[C / 32][8],
+                                             const float (*gin)[C / 32][8] = nullptr) {
   constexpr int KJ = C / 32, NT = C / 16, NB = HC / 32;
   constexpr int P1 = C + 8;            // W1 chunk [HC][P1]: k = hidden (rows), columns = channels
   constexpr int P2 = HC + 8;           // W2 chunk [C][P2]:  k = channels (rows), columns = hidden
@@ -368,7 +371,7 @@ __device__ __forceinline__ void mlp_bwd_body(const MlpBwdArgs& p, char* smem, fl
   b.dz = p.dz; b.d_gw_w = p.d_gw_w; b.d_gw_b = p.d_gw_b; b.d_bw_w = p.d_bw_w; b.d_bw_b = p.d_bw_b; b.M = p.M;
   b.rows_per_sample = p.rows_per_sample;
   Frag<bf16_t> dzf[TT][KJ];
-  cln_bwd_rows<C, TT>(dzf, smem, wg_row0, b);
+  cln_bwd_rows<C, TT, GIN>(dzf, smem, wg_row0, b, gin);
   load_chunk(0);
   __syncthreads();                                             // the dz patches and `red` alias the weight chunk
   store_chunk();
@@ -701,14 +704,105 @@ __global__ __launch_bounds__(256, 2) void proj_cln_bwd_fused_kernel(ProjClnBwdAr
 // attention-output half (cond-LN backward -> projection dgrad) for the same 64·TT rows.  The gradient of the residual stream
 // between the two halves stays in registers (it is still written once: the qkv dgrad accumulates into it), which removes one
 // launch and one 4·C-byte-per-token read from the dependent chain of the token-heavy stages.
-struct TailBwdArgs { MlpBwdArgs m; ProjClnBwdArgs pj; };
+struct TailBwdArgs {
+  MlpBwdArgs m; ProjClnBwdArgs pj;
+  const bf16_t* dqkv; const bf16_t* Wqkv;     // optional prologue: g += dqkv[M, 3C] · Wqkv[3C, C] (the qkv dgrad of the layer above)
+};
 
-template <int C, int HC, int TT>
+// The qkv projection's data gradient of the layer processed just before (HF:396-410: dx = dq Wq + dk Wk + dv Wv), as a prologue of
+// this layer's tail: g rows += dqkv rows · Wqkv — same row ownership, so the stand-alone GEMM launch and one read-modify-write
+// pass over the residual-stream gradient disappear from the chain.  Writes g in place AND returns the rows in registers.
+template <int C, int TT>
+__device__ __forceinline__ void qkv_dgrad_prologue(const bf16_t* dqkv, const bf16_t* Wqkv, float* gio, int M, char* smem, int use_tr,
+                                                   float (*gk)[C / 32][8]) {
+  constexpr int K3 = 3 * C, NT = C / 16, KC = 96, NKC = K3 / KC;
+  constexpr int PW = C + 8, NP = KC * C / 8, PWN = (NP + 255) / 256, CP = C + 4;
+  bf16_t* Wc = (bf16_t*)smem;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4, lc = lane & 15;
+  const int row0 = (blockIdx.x * 4 + wave) * (16 * TT);
+  f32x4_t Y[TT][NT];
+#pragma unroll
+  for (int tt = 0; tt < TT; ++tt)
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) Y[tt][nt] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+  u32x4_t rw[PWN];
+#pragma unroll
+  for (int kc = 0; kc < NKC; ++kc) {
+    const bf16_t* src = Wqkv + (size_t)kc * KC * C;              // KC full rows of [3C, C]: one contiguous block
+#pragma unroll
+    for (int u = 0; u < PWN; ++u) rw[u] = *(const u32x4_t*)(src + (size_t)min(tid + u * 256, NP - 1) * 8);
+    // A operand of this K chunk straight from HBM (row = token lc, k = kc·96 + 32 j + 8 g ..): per chunk, not all 3C columns at
+    // once — 18 fragments up front spilled at C = 192
+    Frag<bf16_t> af[TT][KC / 32];
+#pragma unroll
+    for (int tt = 0; tt < TT; ++tt) {
+      const bf16_t* arow = dqkv + (size_t)min(row0 + tt * 16 + lc, M - 1) * K3 + kc * KC + g * 8;
+#pragma unroll
+      for (int j = 0; j < KC / 32; ++j) af[tt][j].v = *(const s16x8_t*)(arow + j * 32);
+    }
+    if (kc) __syncthreads();                       // every wave is done with the previous chunk
+#pragma unroll
+    for (int u = 0; u < PWN; ++u) {
+      const int i = tid + u * 256;
+      if (i < NP) *(u32x4_t*)(Wc + (i / (C / 8)) * PW + (i % (C / 8)) * 8) = rw[u];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < KC / 32; ++j)
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) {
+        const Frag<bf16_t> w = lds_frag_ks(Wc, PW, nt * 16, j * 32 + g * 8, j * 32 + g * 8 + 4, lane, use_tr);
+#pragma unroll
+        for (int tt = 0; tt < TT; ++tt) mma16(Y[tt][nt], af[tt][j], w);
+      }
+  }
+  __syncthreads();                                 // the fp32 patches alias the weight chunk
+  float* Ct = (float*)smem + wave * 16 * CP;
+  const int prow = lane >> 2, q = lane & 3;
+#pragma unroll
+  for (int tt = 0; tt < TT; ++tt) {
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) Ct[(g * 4 + r) * CP + nt * 16 + lc] = Y[tt][nt][r];
+    __builtin_amdgcn_wave_barrier();
+    const int grow = row0 + tt * 16 + prow;
+#pragma unroll
+    for (int pp = 0; pp < C / 32; ++pp) {
+      const int col = pp * 32 + q * 8;
+      if (grow < M) {
+        const float4 x0 = *(const float4*)(Ct + prow * CP + col), x1 = *(const float4*)(Ct + prow * CP + col + 4);
+        float gi[8];
+        ld8(gio, SCOT_F32, (size_t)grow * C + col, gi);
+        gi[0] += x0.x; gi[1] += x0.y; gi[2] += x0.z; gi[3] += x0.w; gi[4] += x1.x; gi[5] += x1.y; gi[6] += x1.z; gi[7] += x1.w;
+        st8(gio, SCOT_F32, (size_t)grow * C + col, gi);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) gk[tt][pp][j] = gi[j];
+      } else {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) gk[tt][pp][j] = 0.f;
+      }
+    }
+    __builtin_amdgcn_wave_barrier();
+  }
+}
+
+template <int C, int HC, int TT, bool PRO>
 __global__ __launch_bounds__(256, 2) void tail_bwd_fused_kernel(TailBwdArgs p) {
-  constexpr size_t LDS = MlpBwdLds<C, HC>::bytes > ProjBwdLds<C>::bytes ? MlpBwdLds<C, HC>::bytes : ProjBwdLds<C>::bytes;
+  constexpr size_t L0 = MlpBwdLds<C, HC>::bytes > ProjBwdLds<C>::bytes ? MlpBwdLds<C, HC>::bytes : ProjBwdLds<C>::bytes;
+  constexpr size_t LDS = L0;                       // (the prologue's weight chunk + patches fit inside ProjBwdLds)
   __shared__ __attribute__((aligned(16))) char smem[LDS];
   float gk[TT][C / 32][8];
-  mlp_bwd_body<C, HC, TT, true>(p.m, smem, gk);
+  if (PRO) {
+    qkv_dgrad_prologue<C, TT>(p.dqkv, p.Wqkv, (float*)p.m.g, p.m.M, smem, p.m.use_tr, gk);
+    __syncthreads();                     // the prologue's patches are dead
+    // C = 96: the updated rows go on in registers; C = 192 (no registers to spare: 164 B/lane of scratch otherwise): the norm
+    // re-reads the rows its own lanes have just stored
+    if (C <= 96) mlp_bwd_body<C, HC, TT, true, true>(p.m, smem, gk, gk);
+    else mlp_bwd_body<C, HC, TT, true, false>(p.m, smem, gk);
+  } else {
+    mlp_bwd_body<C, HC, TT, true>(p.m, smem, gk);
+  }
   __syncthreads();                       // the MLP half's fp32 patches are dead: the norm's dz patches take their place
   proj_cln_bwd_body<C, TT, true>(p.pj, smem, gk);
 }
@@ -716,7 +810,8 @@ __global__ __launch_bounds__(256, 2) void tail_bwd_fused_kernel(TailBwdArgs p) {
 template <int C, int HC, int TT>
 static int launch_tail_bwd(const TailBwdArgs& a, hipStream_t s) {
   dim3 grid((a.m.M + 64 * TT - 1) / (64 * TT)), block(256);
-  hipLaunchKernelGGL((tail_bwd_fused_kernel<C, HC, TT>), grid, block, 0, s, a);
+  if (a.dqkv) hipLaunchKernelGGL((tail_bwd_fused_kernel<C, HC, TT, true>), grid, block, 0, s, a);
+  else hipLaunchKernelGGL((tail_bwd_fused_kernel<C, HC, TT, false>), grid, block, 0, s, a);
   return scot_check_launch();
 }
 
@@ -787,10 +882,14 @@ extern "C" int scot_block_tail_bwd(const float* g, float* g_out,
                                    /* attention-output half */ const float* z1, const float* mean1, const float* rstd1,
                                    const float* gw_w1, const float* gw_b1, const float* sscale1, const void* Wo, void* dz1, void* da,
                                    float* d_gw_w1, float* d_gw_b1, float* d_bw_w1, float* d_bw_b1,
+                                   /* optional prologue g += dqkv · Wqkv (both or neither; needs g_out == g) */ const void* dqkv,
+                                   const void* Wqkv,
                                    const float* time, int M, int rows_per_sample, int C, int hid, hipStream_t stream) {
   if (M <= 0 || rows_per_sample <= 0) return SCOT_ERR_SHAPE;
   if (C != 96 && C != 192) return SCOT_ERR_UNSUPPORTED;
   if (mlp_chunk(C) != 64 || hid < 64 || hid % 64 != 0 || rows_per_sample % 64 != 0) return SCOT_ERR_UNSUPPORTED;
+  if ((dqkv == nullptr) != (Wqkv == nullptr)) return SCOT_ERR_SHAPE;
+  if (dqkv && g_out != g) return SCOT_ERR_UNSUPPORTED;        // the prologue updates g in place
   if (!g || !g_out || !z2 || !mean2 || !rstd2 || !gw_b2 || !dact || !W1 || !W2 || !dz2 || !du || !d_gw_b2 || !d_bw_b2 || !z1 || !mean1 ||
       !rstd1 || !gw_b1 || !Wo || !dz1 || !da || !d_gw_b1 || !d_bw_b1)
     return SCOT_ERR_SHAPE;
@@ -810,6 +909,7 @@ extern "C" int scot_block_tail_bwd(const float* g, float* g_out,
   a.pj.b.g = g_out; a.pj.b.z = z1; a.pj.b.mean = mean1; a.pj.b.rstd = rstd1; a.pj.b.time = time; a.pj.b.gw_w = gw_w1; a.pj.b.gw_b = gw_b1;
   a.pj.b.sscale = sscale1; a.pj.b.dz = (bf16_t*)dz1; a.pj.b.d_gw_w = d_gw_w1; a.pj.b.d_gw_b = d_gw_b1; a.pj.b.d_bw_w = d_bw_w1;
   a.pj.b.d_bw_b = d_bw_b1; a.pj.b.M = M; a.pj.b.rows_per_sample = rows_per_sample;
+  a.dqkv = (const bf16_t*)dqkv; a.Wqkv = (const bf16_t*)Wqkv;
   if (C == 96) return tt == 2 ? launch_tail_bwd<96, 64, 2>(a, stream) : launch_tail_bwd<96, 64, 1>(a, stream);
   return launch_tail_bwd<192, 64, 1>(a, stream);
 }

@@ -126,6 +126,7 @@ class ScOTEngine:
         self.fused_c = {int(c) for c in os.environ.get("SCOT_FUSED_C", "96,192").split(",") if c}
         self.fused_parts = set(os.environ.get("SCOT_FUSED_PARTS", "mlp_fwd,mlp_bwd,proj_fwd,proj_bwd").split(","))
         self.fused_tail = os.environ.get("SCOT_FUSED_TAIL", "1") == "1"     # MLP-half + projection-half backward in one launch
+        self.fused_qkv_dgrad = os.environ.get("SCOT_FUSED_QKV_DGRAD", "1") == "1"   # ... with the previous layer's qkv dgrad as prologue
         # bf16 mode: GEMM operands must already be bf16 in HBM (gemm_fast streams raw 16-byte chunks into LDS), so the
         # weights get a bf16 shadow arena that is re-cast from the fp32 master at the start of EVERY forward (one pass,
         # inside the timed step), and every producer of a GEMM operand also writes a bf16 copy.
@@ -484,8 +485,11 @@ class ScOTEngine:
 
     def blocks_bwd(self, recs, g, B, time):
         if not (isinstance(recs, tuple) and recs[0] == "chains"):
-            for blk_rec in reversed(recs):
-                g = self.layer_bwd(blk_rec, g, B, time)
+            pend = None      # (d_qkv, Wqkv) of the layer just processed, to be applied by the next layer's fused tail as a prologue
+            n = len(recs)
+            for i, blk_rec in enumerate(reversed(recs)):
+                g, pend = self.layer_bwd(blk_rec, g, B, time, pend, defer_qkv_dgrad=(i + 1 < n))
+            assert pend is None
             self.flush_side()
             return g
         _, n, per = recs
@@ -496,7 +500,7 @@ class ScOTEngine:
         def chain(c):
             gc = gs[c]
             for blk_rec in reversed(per[c]):
-                gc = self.layer_bwd(blk_rec, gc, Bc, ts[c])   # in place on the slice of g
+                gc, _ = self.layer_bwd(blk_rec, gc, Bc, ts[c])   # in place on the slice of g
         self.run_chains(n, chain)
         return g
 
@@ -723,9 +727,11 @@ class ScOTEngine:
         out, out16, _ = self.norm_fwd(pre + ".layernorm_after", y2, h, L, C, cfg.layer_norm_eps, time, need_stats=False, copy=True)
         return out, out16, None
 
-    def layer_bwd(self, rec, g, B, time):
-        """g: fp32 [B*L, C] gradient wrt the layer output; returns the gradient wrt the layer input (the same buffer when
-        `inplace_g`)."""
+    def layer_bwd(self, rec, g, B, time, pend=None, defer_qkv_dgrad=False):
+        """g: fp32 [B*L, C] gradient wrt the layer output; returns (gradient wrt the layer input — the same buffer when
+        `inplace_g` —, pending).  pend = (d_qkv, Wqkv) of the layer processed before this one whose qkv dgrad `g += d_qkv·Wqkv`
+        has not been applied yet: the fused block tail does it as a prologue (same rows), otherwise it is launched here first.
+        defer_qkv_dgrad: leave THIS layer's qkv dgrad to the next call in the same way when that call can take it."""
         cfg, cm, adt = self.cfg, self.compute, self.adt
         blk: BlockGeom = rec["blk"]
         H, W, Hp, Wp, ws, shift, padded = rec["geom"]
@@ -735,9 +741,14 @@ class ScOTEngine:
         hid = int(cfg.mlp_ratio * C)
         mlp_f = self.use_fused("mlp_bwd", C) and hid % 128 == 0 and L % 64 == 0 and not self.split_ln_bwd
         proj_f = self.use_fused("proj_bwd", C) and L % 64 == 0 and not self.split_ln_bwd
+        tail_f = mlp_f and proj_f and self.fused_tail
+        can_prologue = tail_f and self.inplace_g and self.fused_qkv_dgrad and not padded
+        if pend is not None and not can_prologue:
+            g = self.dgrad_into(cm, pend[0], pend[1], g)
+            pend = None
         d_attn = self.new(B * L, C, dtype=adt)
         done_tail = False
-        if mlp_f and proj_f and self.fused_tail:
+        if tail_f:
             # both halves of the block tail in one launch: the residual-stream gradient between them stays in registers
             d_y2, d_u, d_proj = self.new(B * L, C, dtype=adt), self.new(B * L, hid, dtype=adt), self.new(B * L, C, dtype=adt)
             n2, g2 = self._norm_params(pre + ".layernorm_after"), self._norm_grads(pre + ".layernorm_after")
@@ -749,7 +760,10 @@ class ScOTEngine:
                  self.W(pre + ".output.dense.weight"), d_y2, d_u, g2[0], g2[1], g2[2], g2[3]),
                 (rec["proj"], rec["st1"][0], rec["st1"][1], n1[0], n1[1], rec["dp"][0], self.W(pre + ".attention.output.dense.weight"),
                  d_proj, d_attn, g1[0], g1[1], g1[2], g1[3]),
-                time if self.cond else None, B * L, L, C, hid)
+                time if self.cond else None, B * L, L, C, hid, dqkv=pend[0] if pend else None, wqkv=pend[1] if pend else None)
+            if not done_tail and pend is not None:
+                g = self.dgrad_into(cm, pend[0], pend[1], g)
+            pend = None
             if done_tail:
                 g = gout
                 self.linear_bwd_params(pre + ".output.dense.weight", pre + ".output.dense.bias", d_y2, rec["u"])
@@ -817,11 +831,15 @@ class ScOTEngine:
             g2 = g if self.inplace_g else self.new(B * L, C)
             ops.add(g, tmpc, g2)
             g = g2
+            new_pend = None
+        elif defer_qkv_dgrad and can_prologue:
+            new_pend = (d_qkv, wqkv)      # (the next layer of this stage has the same geometry: its fused tail applies it)
         else:
             g = self.dgrad_into(cm, d_qkv, wqkv, g)
+            new_pend = None
         if self.side_flush == "block":
             self.flush_side()
-        return g
+        return g, new_pend
 
     # ------------------------------------------------------------------------------------------ resampling
     def merge_fwd(self, st: StageGeom, x, stage_in, B, time, train):

@@ -258,13 +258,14 @@ def block_tail_fwd(proj, mlp, time, rows, rows_per_sample, C, hid, eps) -> bool:
     return True
 
 
-def block_tail_bwd(g, g_out, mlp, proj, time, rows, rows_per_sample, C, hid) -> bool:
+def block_tail_bwd(g, g_out, mlp, proj, time, rows, rows_per_sample, C, hid, dqkv=None, wqkv=None) -> bool:
     """The tail of a ScOTLayer's backward in one launch: mlp_block_bwd then proj_cln_bwd on its result (which stays in
     registers in between).  mlp = (z2, mean2, rstd2, gw_w2, gw_b2, sscale2, dact, w1, w2, dz2, du, d_gw_w2, d_gw_b2, d_bw_w2,
-    d_bw_b2); proj = (z1, mean1, rstd1, gw_w1, gw_b1, sscale1, wo, dz1, da, d_gw_w1, d_gw_b1, d_bw_w1, d_bw_b1).  False = not
-    covered (the caller launches the two kernels)."""
-    rc = L().scot_block_tail_bwd(ptr(g), ptr(g_out), *[ptr(t) for t in mlp], *[ptr(t) for t in proj], ptr(time), rows,
-                                 rows_per_sample, C, hid, stream())
+    d_bw_b2); proj = (z1, mean1, rstd1, gw_w1, gw_b1, sscale1, wo, dz1, da, d_gw_w1, d_gw_b1, d_bw_w1, d_bw_b1).  dqkv [rows, 3C] /
+    wqkv [3C, C] (optional): prologue g += dqkv · wqkv — the qkv dgrad of the layer processed before, in place (g_out is g).
+    False = not covered (the caller launches the kernels one by one)."""
+    rc = L().scot_block_tail_bwd(ptr(g), ptr(g_out), *[ptr(t) for t in mlp], *[ptr(t) for t in proj], ptr(dqkv), ptr(wqkv), ptr(time),
+                                 rows, rows_per_sample, C, hid, stream())
     if rc == -3:
         return False
     _lib.check(rc, "scot_block_tail_bwd")

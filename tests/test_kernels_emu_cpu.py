@@ -190,7 +190,8 @@ def test_fused_mlp_and_projection_forward(gpu_test_bodies, train, cond, B, L, C)
 def test_fused_mlp_and_projection_backward(gpu_test_bodies, cond, B, L, C):
     gpu_test_bodies.test_mlp_block_bwd_fused(cond, B, L, C)
     gpu_test_bodies.test_proj_cln_bwd_fused(cond, B, L, C)
-    gpu_test_bodies.test_block_tail_bwd_fused(cond, B, L, C)
+    gpu_test_bodies.test_block_tail_bwd_fused(cond, B, L, C, False)
+    gpu_test_bodies.test_block_tail_bwd_fused(cond, B, L, C, True)
 
 
 @pytest.mark.parametrize("s,t", [(32, 64), (32, 16), (64, 32), (24, 40)])
