@@ -183,8 +183,10 @@ int scot_block_tail_fwd(const void* a, const void* Wo, const float* bo, const fl
                         float* rstd1, const float* gw_w1, const float* gw_b1, const float* bw_w1, const float* bw_b1,
                         const float* sscale1, const void* W1, const float* b1, const void* W2, const float* b2, float* out, void* out16,
                         void* act, void* dact, float* z2, float* mean2, float* rstd2, const float* gw_w2, const float* gw_b2,
-                        const float* bw_w2, const float* bw_b2, const float* sscale2, const float* time, int M, int rows_per_sample,
-                        int C, int hid, float eps, scot_stream_t stream);
+                        const float* bw_w2, const float* bw_b2, const float* sscale2,
+                        const void* Wqkv, const float* bqkv, void* qkv /* optional epilogue (Wqkv and qkv both or neither): the NEXT
+                        layer's fused q/k/v projection qkv[M,3C] = out16 · Wqkv[3C,C]^T + bqkv (HF:396-410) on the rows just produced */,
+                        const float* time, int M, int rows_per_sample, int C, int hid, float eps, scot_stream_t stream);
 
 /* Data movement */
 int scot_add(const void* a, int a_dt, const void* b, int b_dt, void* out, int out_dt, size_t n, size_t period,

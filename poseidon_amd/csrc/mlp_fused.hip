@@ -49,7 +49,7 @@ template <int C, int HC> struct MlpFwdLds {
 // One workgroup's 64·TT rows of the MLP half.  HTILE: the wave's token rows are read from its LDS tile `htile` ([16·TT][C + 8],
 // written by the projection half's epilogue in the fused block tail) instead of from p.h16; the tile may alias `smem`.
 template <int C, int HC, int TT, bool HTILE>
-__device__ __forceinline__ void mlp_fwd_body(const MlpArgs& p, char* smem, const bf16_t* htile) {
+__device__ __forceinline__ void mlp_fwd_body(const MlpArgs& p, char* smem, const bf16_t* htile, bf16_t* otile = nullptr) {
   constexpr int KJ = C / 32;           // K-steps of GEMM 1 (K = C)
   constexpr int NT = C / 16;           // channel tiles of GEMM 2 / of the output
   constexpr int NB = HC / 32;          // 32-hidden blocks per chunk
@@ -200,7 +200,7 @@ __device__ __forceinline__ void mlp_fwd_body(const MlpArgs& p, char* smem, const
   e.bias = p.b2; e.z = p.z; e.mean = p.mean; e.rstd = p.rstd; e.time = p.time; e.gw_w = p.gw_w; e.gw_b = p.gw_b; e.bw_w = p.bw_w;
   e.bw_b = p.bw_b; e.sscale = p.sscale; e.resid = p.h; e.out = p.out; e.out16 = p.out16; e.M = p.M; e.rows_per_sample = p.rows_per_sample;
   e.eps = p.eps;
-  cln_rows_epilogue<C, TT>(Y, (float*)smem, row0, e);
+  cln_rows_epilogue<C, TT>(Y, (float*)smem, row0, e, otile);
 }
 
 template <int C, int HC, int TT>
@@ -594,24 +594,105 @@ __global__ __launch_bounds__(256, 2) void proj_cln_fused_kernel(ProjClnArgs p) {
 // same 64·TT rows.  h is written once (fp32 + 16-bit: the backward and the weight gradients read them) but not re-read: the MLP
 // half takes its operand rows from the LDS tile the projection half's epilogue filled, and its residual from the values the
 // same lanes just stored.
-struct TailFwdArgs { ProjClnArgs pj; MlpArgs m; };
+struct TailFwdArgs {
+  ProjClnArgs pj; MlpArgs m;
+  const bf16_t* Wqkv; const float* bqkv; bf16_t* qkv;    // optional epilogue: qkv[M, 3C] = out16 · Wqkv[3C, C]^T + bqkv (next layer)
+};
 
-template <int C, int HC, int TT>
+// The NEXT layer's fused q/k/v projection (HF:396-410) on the rows this workgroup has just produced: qkv = out16 · Wqkv^T + b.
+// Same row ownership as the tail, so the stand-alone QKV GEMM launch (and its re-read of out16) leaves the chain.  `tile`: the
+// wave's 16-bit output rows in LDS ([16·TT][C + 8], written by the final epilogue); the weight chunk and the patches reuse smem.
+template <int C, int TT>
+__device__ __forceinline__ void qkv_epilogue(const bf16_t* tile, const bf16_t* Wqkv, const float* bqkv, bf16_t* qkv, int M, char* smem) {
+  constexpr int KJ = C / 32, NC = 96, NCH = 3 * C / NC;          // 96 output columns per weight chunk
+  constexpr int PW = C + 8, NP = NC * C / 8, PWN = (NP + 255) / 256, CP = NC + 4;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4, lc = lane & 15;
+  const int row0 = (blockIdx.x * 4 + wave) * (16 * TT);
+  Frag<bf16_t> af[TT][KJ];
+#pragma unroll
+  for (int tt = 0; tt < TT; ++tt)
+#pragma unroll
+    for (int j = 0; j < KJ; ++j) af[tt][j].v = *(const s16x8_t*)(tile + (tt * 16 + lc) * (C + 8) + j * 32 + g * 8);
+  bf16_t* Wc = (bf16_t*)smem;                                    // [NC][PW], K-contiguous rows (= output columns)
+  float* Ct = (float*)(smem + (size_t)NC * PW * 2) + wave * 16 * CP;
+  const int prow = lane >> 2, q = lane & 3;
+  u32x4_t rw[PWN];
+#pragma unroll 1
+  for (int nc = 0; nc < NCH; ++nc) {
+    const bf16_t* src = Wqkv + (size_t)nc * NC * C;              // NC full rows: one contiguous block
+#pragma unroll
+    for (int u = 0; u < PWN; ++u) rw[u] = *(const u32x4_t*)(src + (size_t)min(tid + u * 256, NP - 1) * 8);
+    __syncthreads();                                             // the tile reads (nc = 0) / the previous chunk's reads are done
+#pragma unroll
+    for (int u = 0; u < PWN; ++u) {
+      const int i = tid + u * 256;
+      if (i < NP) *(u32x4_t*)(Wc + (i / (C / 8)) * PW + (i % (C / 8)) * 8) = rw[u];
+    }
+    __syncthreads();
+    f32x4_t Y[TT][NC / 16];
+#pragma unroll
+    for (int tt = 0; tt < TT; ++tt)
+#pragma unroll
+      for (int nt = 0; nt < NC / 16; ++nt) Y[tt][nt] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int j = 0; j < KJ; ++j)
+#pragma unroll
+      for (int nt = 0; nt < NC / 16; ++nt) {
+        const Frag<bf16_t> w = lds_frag_kc(Wc, PW, nt * 16, j * 32, lane);
+#pragma unroll
+        for (int tt = 0; tt < TT; ++tt) mma16(Y[tt][nt], af[tt][j], w);
+      }
+#pragma unroll
+    for (int tt = 0; tt < TT; ++tt) {
+#pragma unroll
+      for (int nt = 0; nt < NC / 16; ++nt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) Ct[(g * 4 + r) * CP + nt * 16 + lc] = Y[tt][nt][r];
+      __builtin_amdgcn_wave_barrier();
+      const int grow = row0 + tt * 16 + prow;
+      if (grow < M) {
+#pragma unroll
+        for (int pp = 0; pp < NC / 32; ++pp) {
+          const int col = pp * 32 + q * 8;
+          const float4 x0 = *(const float4*)(Ct + prow * CP + col), x1 = *(const float4*)(Ct + prow * CP + col + 4);
+          float o[8] = {x0.x, x0.y, x0.z, x0.w, x1.x, x1.y, x1.z, x1.w};
+          if (bqkv) {
+            float bb[8];
+            ld8(bqkv, SCOT_F32, nc * NC + col, bb);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) o[j] += bb[j];
+          }
+          st8(qkv, SCOT_BF16, (size_t)grow * (3 * C) + nc * NC + col, o);
+        }
+      }
+      __builtin_amdgcn_wave_barrier();
+    }
+  }
+}
+
+template <int C, int HC, int TT, bool QKV>
 __global__ __launch_bounds__(256, 2) void tail_fwd_fused_kernel(TailFwdArgs p) {
   constexpr size_t PATCH = (size_t)4 * 16 * (C + 4) * 4, TILE = (size_t)4 * 16 * TT * (C + 8) * 2;
   constexpr size_t A = ProjFwdLds<C>::bytes > PATCH + TILE ? ProjFwdLds<C>::bytes : PATCH + TILE;
-  constexpr size_t LDS = A > MlpFwdLds<C, HC>::bytes ? A : MlpFwdLds<C, HC>::bytes;
+  constexpr size_t QB = (size_t)96 * (C + 8) * 2 + (size_t)4 * 16 * (96 + 4) * 4;           // qkv epilogue: weight chunk + patches
+  constexpr size_t B = A > MlpFwdLds<C, HC>::bytes ? A : MlpFwdLds<C, HC>::bytes;
+  constexpr size_t LDS = (QKV && QB > B) ? QB : B;
   __shared__ __attribute__((aligned(16))) char smem[LDS];
   bf16_t* tile = (bf16_t*)(smem + PATCH) + (threadIdx.x >> 6) * 16 * TT * (C + 8);
   proj_cln_fwd_body<C, TT>(p.pj, smem, tile);
   __builtin_amdgcn_wave_barrier();       // the tile is written and read by the same wave
-  mlp_fwd_body<C, HC, TT, true>(p.m, smem, tile);
+  mlp_fwd_body<C, HC, TT, true>(p.m, smem, tile, QKV ? tile : nullptr);
+  if (QKV) {
+    __builtin_amdgcn_wave_barrier();
+    qkv_epilogue<C, TT>(tile, p.Wqkv, p.bqkv, p.qkv, p.m.M, smem);
+  }
 }
 
 template <int C, int HC, int TT>
 static int launch_tail_fwd(const TailFwdArgs& a, hipStream_t s) {
   dim3 grid((a.m.M + 64 * TT - 1) / (64 * TT)), block(256);
-  hipLaunchKernelGGL((tail_fwd_fused_kernel<C, HC, TT>), grid, block, 0, s, a);
+  if (a.qkv) hipLaunchKernelGGL((tail_fwd_fused_kernel<C, HC, TT, true>), grid, block, 0, s, a);
+  else hipLaunchKernelGGL((tail_fwd_fused_kernel<C, HC, TT, false>), grid, block, 0, s, a);
   return scot_check_launch();
 }
 
@@ -922,6 +1003,8 @@ extern "C" int scot_block_tail_fwd(/* attention-output half */ const void* a, co
                                    /* MLP half */ const void* W1, const float* b1, const void* W2, const float* b2, float* out,
                                    void* out16, void* act, void* dact, float* z2, float* mean2, float* rstd2, const float* gw_w2,
                                    const float* gw_b2, const float* bw_w2, const float* bw_b2, const float* sscale2,
+                                   /* optional: the next layer's qkv = out16 · Wqkv^T + bqkv */ const void* Wqkv, const float* bqkv,
+                                   void* qkv,
                                    const float* time, int M, int rows_per_sample, int C, int hid, float eps, hipStream_t stream) {
   if (M <= 0 || rows_per_sample <= 0) return SCOT_ERR_SHAPE;
   if (C != 96 && C != 192) return SCOT_ERR_UNSUPPORTED;
@@ -939,6 +1022,8 @@ extern "C" int scot_block_tail_fwd(/* attention-output half */ const void* a, co
   t.m.out = out; t.m.out16 = (bf16_t*)out16; t.m.act = (bf16_t*)act; t.m.dact = (bf16_t*)dact; t.m.z = z2; t.m.mean = mean2; t.m.rstd = rstd2;
   t.m.time = time; t.m.gw_w = gw_w2; t.m.gw_b = gw_b2; t.m.bw_w = bw_w2; t.m.bw_b = bw_b2; t.m.sscale = sscale2;
   t.m.M = M; t.m.rows_per_sample = rows_per_sample; t.m.hid = hid; t.m.eps = eps;
+  if ((Wqkv == nullptr) != (qkv == nullptr)) return SCOT_ERR_SHAPE;
+  t.Wqkv = (const bf16_t*)Wqkv; t.bqkv = bqkv; t.qkv = (bf16_t*)qkv;
   static int tt_env = -1;
   if (tt_env < 0) { const char* e = getenv("SCOT_MLP_TT"); tt_env = e ? atoi(e) : 0; }
   const int tt = C == 96 ? (tt_env ? tt_env : (M >= 64 * 2 * 512 ? 2 : 1)) : 1;

@@ -126,6 +126,7 @@ class ScOTEngine:
         self.fused_c = {int(c) for c in os.environ.get("SCOT_FUSED_C", "96,192").split(",") if c}
         self.fused_parts = set(os.environ.get("SCOT_FUSED_PARTS", "mlp_fwd,mlp_bwd,proj_fwd,proj_bwd").split(","))
         self.fused_tail = os.environ.get("SCOT_FUSED_TAIL", "1") == "1"     # MLP-half + projection-half backward in one launch
+        self.fused_next_qkv = os.environ.get("SCOT_FUSED_NEXT_QKV", "1") == "1"     # ... forward: the next layer's q/k/v projection as epilogue
         self.fused_qkv_dgrad = os.environ.get("SCOT_FUSED_QKV_DGRAD", "1") == "1"   # ... with the previous layer's qkv dgrad as prologue
         # bf16 mode: GEMM operands must already be bf16 in HBM (gemm_fast streams raw 16-byte chunks into LDS), so the
         # weights get a bf16 shadow arena that is re-cast from the fp32 master at the start of EVERY forward (one pass,
@@ -462,9 +463,9 @@ class ScOTEngine:
         L, C = blocks[0].res[0] * blocks[0].res[1], blocks[0].dim
         n = self.chains_for(B * L, B)
         if n == 1:
-            recs = []
-            for blk in blocks:
-                x, x16, r = self.layer_fwd(blk, x, x16, B, time, train)
+            recs, q = [], None
+            for i, blk in enumerate(blocks):
+                x, x16, r, q = self.layer_fwd(blk, x, x16, B, time, train, qkv_pre=q, next_blk=blocks[i + 1] if i + 1 < len(blocks) else None)
                 recs.append(r)
             return x, x16, recs
         Bc = B // n
@@ -472,9 +473,10 @@ class ScOTEngine:
         ts = time.view(n, Bc) if time is not None else [None] * n
 
         def chain(c):
-            xc, xc16, rc = xs[c], x16s[c], []
-            for blk in blocks:
-                xc, xc16, r = self.layer_fwd(blk, xc, xc16, Bc, ts[c], train)
+            xc, xc16, rc, q = xs[c], x16s[c], [], None
+            for i, blk in enumerate(blocks):
+                xc, xc16, r, q = self.layer_fwd(blk, xc, xc16, Bc, ts[c], train, qkv_pre=q,
+                                                next_blk=blocks[i + 1] if i + 1 < len(blocks) else None)
                 rc.append(r)
             return xc, xc16, rc
         outs = self.run_chains(n, chain)
@@ -546,8 +548,17 @@ class ScOTEngine:
             ev.record()
             self.marks.append((label, ev))
 
-    def layer_fwd(self, blk: BlockGeom, x, x16, B, time, train):
-        """reference ScOTLayer.forward (model.py:500-581) + Swinv2Attention/Intermediate/Output (HF:389-561)."""
+    def qkv_fusable(self, blk: BlockGeom):
+        """May the PREVIOUS layer's fused tail produce this layer's q/k/v projection?  Same channel count by construction (only
+        called within a stage); needs the unpadded window geometry (the projection input is then exactly the previous output rows)."""
+        H, W = blk.res
+        ws, _ = blk.window_shift()
+        return H % ws == 0 and W % ws == 0 and self.fused_next_qkv and not self.precision_probe
+
+    def layer_fwd(self, blk: BlockGeom, x, x16, B, time, train, qkv_pre=None, next_blk=None):
+        """reference ScOTLayer.forward (model.py:500-581) + Swinv2Attention/Intermediate/Output (HF:389-561).  qkv_pre: this layer's
+        q/k/v projection, already produced by the previous layer's fused tail; next_blk: the layer that follows in the same stage
+        (its projection becomes this tail's epilogue when the fused tail runs).  Returns (out, out16, rec, qkv_next or None)."""
         cfg, cm = self.cfg, self.compute
         H, W = blk.res
         C, heads = blk.dim, blk.heads
@@ -566,9 +577,13 @@ class ScOTEngine:
         bqkv = self.arena.span(a + "qkv_bias", 3 * C) if cfg.qkv_bias else None
         ex = self.precision_probe if (self.precision_probe and not train and not padded) else None
         if ex:   # tools/probes/bf16_error_sources.py: selected pieces of an inference forward in fp32 (never on the product path)
-            return self._layer_fwd_probe(blk, x, x16, B, time, ex)
-        qkv = self.new(B * Lp, 3 * C, dtype=self.adt)
-        ops.linear_fwd(cm, xp, wqkv, qkv, bias=bqkv)
+            return self._layer_fwd_probe(blk, x, x16, B, time, ex) + (None,)
+        if qkv_pre is not None:
+            assert not padded
+            qkv = qkv_pre
+        else:
+            qkv = self.new(B * Lp, 3 * C, dtype=self.adt)
+            ops.linear_fwd(cm, xp, wqkv, qkv, bias=bqkv)
         tw = blk.table_window
         if tw != ws:
             raise NotImplementedError("run-time window differs from the constructor-time CPB table window "
@@ -589,6 +604,7 @@ class ScOTEngine:
         proj_f = self.use_fused("proj_fwd", C)
         mlp_f = self.use_fused("mlp_fwd", C) and hid % 128 == 0
         done_tail = False
+        qkv_next = None
         if proj_f and mlp_f and self.fused_tail and os.environ.get("SCOT_FUSED_TAIL_FWD", "1") == "1":
             # projection + norm + residual, then MLP + norm + residual, for the same rows in one launch
             proj = self.new(B * L, C) if train else None
@@ -600,12 +616,20 @@ class ScOTEngine:
             st2 = (self.new(B * L), self.new(B * L)) if train else (None, None)
             out, out16 = self.new(B * L, C), self.new(B * L, C, dtype=self.adt)
             n1, n2 = self._norm_params(pre + ".layernorm_before"), self._norm_params(pre + ".layernorm_after")
+            nq = (None, None, None)
+            if next_blk is not None and next_blk.dim == C and self.qkv_fusable(next_blk):
+                na = next_blk.prefix + ".attention.self."
+                qkv_next = self.new(B * L, 3 * C, dtype=self.adt)
+                nq = (self.Wspan(na + "qkv_weight", 3 * C * C).view(3 * C, C),
+                      self.arena.span(na + "qkv_bias", 3 * C) if cfg.qkv_bias else None, qkv_next)
             done_tail = ops.block_tail_fwd(
                 (attn_c, self.W(pre + ".attention.output.dense.weight"), self.P(pre + ".attention.output.dense.bias"), x, h, h16, proj,
                  st1[0], st1[1], n1[0], n1[1], n1[2], n1[3], dp1),
                 (self.W(pre + ".intermediate.dense.weight"), self.P(pre + ".intermediate.dense.bias"), self.W(pre + ".output.dense.weight"),
                  self.P(pre + ".output.dense.bias"), out, out16, u, gp, y2, st2[0], st2[1], n2[0], n2[1], n2[2], n2[3], dp2),
-                time if self.cond else None, B * L, L, C, hid, cfg.layer_norm_eps)
+                time if self.cond else None, B * L, L, C, hid, cfg.layer_norm_eps, *nq)
+            if not done_tail:
+                qkv_next = None
         if done_tail:
             pass
         elif proj_f:
@@ -651,7 +675,7 @@ class ScOTEngine:
         if train:
             rec = dict(blk=blk, xp=xp, qkv=qkv, attn_p=attn, table=table, lse=lse, attn_c=attn_c, proj=proj, st1=st1, h16=h16, u=u, gp=gp,
                        y2=y2, st2=st2, geom=(H, W, Hp, Wp, ws, shift, padded), dp=(dp1, dp2))
-        return out, out16, rec
+        return out, out16, rec, qkv_next
 
     def dgrad_into(self, cm, dy, w, g):
         """g + dy·w.  In place when nothing else may still be reading g; otherwise into a fresh buffer: with the LN backward's

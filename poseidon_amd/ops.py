@@ -246,12 +246,13 @@ def mlp_block_bwd(g, g_out, z, mean, rstd, time, gw_w, gw_b, sample_scale, dact,
     return True
 
 
-def block_tail_fwd(proj, mlp, time, rows, rows_per_sample, C, hid, eps) -> bool:
+def block_tail_fwd(proj, mlp, time, rows, rows_per_sample, C, hid, eps, wqkv=None, bqkv=None, qkv=None) -> bool:
     """The tail of a ScOTLayer's forward in one launch: proj_cln_fwd then mlp_block_fwd on its output rows (handed over through
     LDS).  proj = (attn, wo, bo, x, h, h16, z1, mean1, rstd1, gw_w1, gw_b1, bw_w1, bw_b1, sscale1); mlp = (w1, b1, w2, b2, out,
-    out16, act, dact, z2, mean2, rstd2, gw_w2, gw_b2, bw_w2, bw_b2, sscale2).  False = not covered."""
-    rc = L().scot_block_tail_fwd(*[ptr(t) for t in proj], *[ptr(t) for t in mlp], ptr(time), rows, rows_per_sample, C, hid,
-                                 float(eps), stream())
+    out16, act, dact, z2, mean2, rstd2, gw_w2, gw_b2, bw_w2, bw_b2, sscale2).  wqkv [3C, C] / bqkv [3C] / qkv [rows, 3C] (optional):
+    epilogue qkv = out16 · wqkv^T + bqkv — the NEXT layer's fused q/k/v projection on the rows just produced.  False = not covered."""
+    rc = L().scot_block_tail_fwd(*[ptr(t) for t in proj], *[ptr(t) for t in mlp], ptr(wqkv), ptr(bqkv), ptr(qkv), ptr(time), rows,
+                                 rows_per_sample, C, hid, float(eps), stream())
     if rc == -3:
         return False
     _lib.check(rc, "scot_block_tail_fwd")

@@ -182,7 +182,7 @@ def gpu_test_bodies(emu, monkeypatch):
 def test_fused_mlp_and_projection_forward(gpu_test_bodies, train, cond, B, L, C):
     gpu_test_bodies.test_mlp_block_fused(train, cond, B, L, C)
     gpu_test_bodies.test_proj_cln_fused(train, cond, B, L, C)
-    gpu_test_bodies.test_block_tail_fwd_fused(train, cond, B, L, C)
+    gpu_test_bodies.test_block_tail_fwd_fused(train, cond, B, L, C, next_qkv=True)
 
 
 @pytest.mark.parametrize("cond,B,L,C", [(True, 1, 64, 96), (False, 1, 64, 192)] + full_only((False, 2, 128, 96), (True, 3, 64, 96),

@@ -644,9 +644,12 @@ def test_gemm_bf16x3_is_fp32_class(layout, M, N, K):
 @pytest.mark.parametrize("train", [True, False])
 @pytest.mark.parametrize("cond", [True, False])
 @pytest.mark.parametrize("B,L,C", [(2, 1024, 96), (3, 192, 96), (64, 1024, 96), (2, 256, 192), (5, 64, 192)])
-def test_block_tail_fwd_fused(train, cond, B, L, C):
+@pytest.mark.parametrize("next_qkv", [False, True])
+def test_block_tail_fwd_fused(train, cond, B, L, C, next_qkv):
     """scot_block_tail_fwd == scot_proj_cln_fwd followed by scot_mlp_block_fwd (the two validated launches it replaces): same
-    arithmetic in the same order, the MLP half's operand rows only travel through LDS instead of HBM — equal up to nothing."""
+    arithmetic in the same order, the MLP half's operand rows only travel through LDS instead of HBM — equal up to nothing.
+    next_qkv: the epilogue that produces the following layer's q/k/v projection == the stand-alone GEMM on out16 (fp32 sums to
+    accumulation order, then one 16-bit rounding)."""
     M, hid = B * L, 4 * C
     bf = torch.bfloat16
     a = rnd(M, C, seed=11).to(bf)
@@ -671,14 +674,24 @@ def test_block_tail_fwd_fused(train, cond, B, L, C):
     assert ops.mlp_block_fwd(r["h16"], r["h"], w1, b1, w2, b2, r["out"], r["out16"], r["u"], r["gp"], r["z2"], r["m2"], r["r2"], t, n2[0], n2[1],
                              n2[2], n2[3], s2, M, L, C, hid, 1e-5)
     f = bufs()
+    wq, bq = rnd(3 * C, C, scale=C ** -0.5, seed=41).to(bf), rnd(3 * C, seed=42, scale=0.2)
+    q = torch.full((M, 3 * C), float("nan"), device=DEV, dtype=bf) if next_qkv else None
     assert ops.block_tail_fwd((a, wo, bo, x, f["h"], f["h16"], f["z1"], f["m1"], f["r1"], n1[0], n1[1], n1[2], n1[3], s1),
                               (w1, b1, w2, b2, f["out"], f["out16"], f["u"], f["gp"], f["z2"], f["m2"], f["r2"], n2[0], n2[1], n2[2], n2[3], s2),
-                              t, M, L, C, hid, 1e-5)
+                              t, M, L, C, hid, 1e-5, *((wq, bq, q) if next_qkv else ()))
     torch.cuda.synchronize()
     for k in r:
         if r[k] is not None:
             assert torch.isfinite(f[k].float()).all(), k
             assert torch.equal(f[k], r[k]), (k, rel(f[k].float(), r[k].float()))
+    if next_qkv:
+        qr = torch.empty_like(q)
+        ops.linear_fwd(ops.BF16, r["out16"], wq, qr, bias=bq)
+        torch.cuda.synchronize()
+        assert torch.isfinite(q.float()).all()
+        ref = r["out16"].float() @ wq.float().t() + bq
+        assert rel(q.float(), ref) < 4e-3 and rel(q.float(), qr.float()) < 2e-3, (rel(q.float(), ref), rel(q.float(), qr.float()))
+        assert (q != qr).float().mean() < 0.02      # same products, fp32 sums in a different order: rare last-place flips only
 
 
 @pytest.mark.parametrize("prologue", [False, True])
