@@ -41,6 +41,11 @@ int scot_scale_inplace(float* x, size_t n, float scale, int* nonfinite, scot_str
  *   transpose: (y, x) read at (x, y).  data fp32 [n, T, nsrc, H, W]; it int32 [3, B] = trajectories, t1, t2. */
 int scot_gather_pairs(const float* data, const int* it, const int* src, const float* a, const float* b, float* pv, float* lab,
                       int B, int C, int T, int nsrc, int H, int W, int transpose, scot_stream_t stream);
+/* Transposed operand-format copies of weight matrices, converted from the fp32 master in the same pass:
+ * wt16[off + c*rows + r] = w[off + r*cols + c] for every matrix of desc (int32 [n][4], device: element offset, rows, cols, index of
+ * its first 64x64 tile; rows and cols multiples of 8; tiles = total tile count).  The data gradient of nn.Linear, dX = dY · W, then
+ * runs as the forward's NT product on W^T instead of the slower strided-operand NN product. */
+int scot_transpose_cast(const float* w, void* wt16, const int* desc, int n, int tiles, scot_stream_t stream);
 /* Mask tokens of ScOTEmbeddings (ref:353-359): x[r,:] = mask[r] ? token : x[r,:] in place (x fp32 [rows, C], mask uint8 [rows],
  * token fp32 [C]); backward: d_token += Σ_r mask[r]·g[r,:], g[r,:] = 0 where mask[r]. */
 int scot_mask_tokens(float* x, const void* mask_u8, const float* token, int rows, int C, scot_stream_t stream);

@@ -787,7 +787,11 @@ extern "C" int scot_wgrad_group(int compute, int n, int K, const void* const* dY
     if (!workspace || (((uintptr_t)workspace) & 31) || (size_t)g.nsplit * plane * sizeof(float) > ws_bytes) return SCOT_ERR_UNSUPPORTED;
     g.ws = (float*)workspace;
   }
-  int rc = t96 ? launch_wgrad_group<96, 96, 64, 2>(g, stream) : launch_wgrad_group<64, 64, 64, 2>(g, stream);
+  static int nset = -1;
+  if (nset < 0) { const char* e = getenv("SCOT_WGRAD_GROUP_NSET"); nset = e ? atoi(e) : 2; }
+  int rc;
+  if (nset == 4) rc = t96 ? launch_wgrad_group<96, 96, 64, 4>(g, stream) : launch_wgrad_group<64, 64, 64, 4>(g, stream);
+  else rc = t96 ? launch_wgrad_group<96, 96, 64, 2>(g, stream) : launch_wgrad_group<64, 64, 64, 2>(g, stream);
   if (rc == SCOT_OK && g.ws) {
     const size_t n8 = plane / 8;
     const int zl = g.nsplit >= 32 ? 8 : g.nsplit >= 4 ? 4 : 1;

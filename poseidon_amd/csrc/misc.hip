@@ -83,6 +83,45 @@ extern "C" int scot_gather_pairs(const float* data, const int* it, const int* sr
   return scot_check_launch();
 }
 
+// ------------------------------------------------------------------ transposed 16-bit weight copies for the data gradients
+// dX = dY · W with W [out, in] row-major is an "NN" product: its B operand is strided along the reduction index, and the MFMA
+// fragments then cost eight 2-byte LDS reads each instead of one 16-byte read (stages 2/3: 1.7–2.2x the time of the forward GEMM of
+// the same shape).  With W^T [in, out] kept beside the 16-bit weight copy, dX = dY · (W^T)^T is the forward's NT product.  One
+// launch per step transposes every matrix of the list while it converts from the fp32 master: wt16[off + c·rows + r] = w[off + r·cols + c].
+// desc: int32 [n][4] = {element offset (same in both arenas), rows, cols, first 64x64 tile}; rows, cols multiples of 8.
+__global__ __launch_bounds__(256) void transpose_cast_kernel(const float* __restrict__ w, bf16_t* __restrict__ wt, const int4* __restrict__ desc, int n) {
+  __shared__ __attribute__((aligned(16))) bf16_t T[64][72];
+  int lo = 0, hi = n - 1;
+  const int tile = blockIdx.x;
+  while (lo < hi) {                       // last matrix whose first tile is <= tile
+    const int mid = (lo + hi + 1) >> 1;
+    if (desc[mid].w <= tile) lo = mid; else hi = mid - 1;
+  }
+  const int4 d = desc[lo];
+  const int rows = d.y, cols = d.z, tc = (cols + 63) / 64, t = tile - d.w;
+  const int r0 = (t / tc) * 64, c0 = (t % tc) * 64;
+  const float* src = w + d.x;
+  bf16_t* dst = wt + d.x;
+#pragma unroll
+  for (int u = 0; u < 4; ++u) {
+    const int i = threadIdx.x + u * 256, r = i >> 4, c = (i & 15) * 4;
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (r0 + r < rows && c0 + c < cols) v = *(const float4*)(src + (size_t)(r0 + r) * cols + c0 + c);
+    T[c][r] = f2bf(v.x); T[c + 1][r] = f2bf(v.y); T[c + 2][r] = f2bf(v.z); T[c + 3][r] = f2bf(v.w);
+  }
+  __syncthreads();
+#pragma unroll
+  for (int u = 0; u < 2; ++u) {
+    const int i = threadIdx.x + u * 256, c = i >> 3, r = (i & 7) * 8;
+    if (c0 + c < cols && r0 + r < rows) *(uint4*)(dst + (size_t)(c0 + c) * rows + r0 + r) = *(const uint4*)&T[c][r];
+  }
+}
+extern "C" int scot_transpose_cast(const float* w, void* wt16, const int* desc, int n, int tiles, hipStream_t s) {
+  if (n <= 0 || tiles <= 0) return SCOT_ERR_SHAPE;
+  hipLaunchKernelGGL(transpose_cast_kernel, dim3(tiles), dim3(256), 0, s, w, (bf16_t*)wt16, (const int4*)desc, n);
+  return scot_check_launch();
+}
+
 // ------------------------------------------------------------------ mask tokens (model.py:353-359, SimMIM-style masked positions)
 // forward:  x[r, :] = mask[r] ? token : x[r, :]     (== x·(1-m) + token·m for m in {0, 1}),   in place
 // backward: d_token += Σ_r mask[r]·g[r, :];  g[r, :] = mask[r] ? 0 : g[r, :],                  in place

@@ -77,6 +77,8 @@ class ScOTEngine:
         # / the encoder stage that produced it (backward), so they run on the side stream beside the deep stages' latency-bound
         # chain instead of in front of it (SCOT_SKIP_SIDE=0: in line)
         self.skip_side = os.environ.get("SCOT_SKIP_SIDE", "1") == "1"
+        self.skip_lane = int(os.environ.get("SCOT_SKIP_LANE", "0"))       # backward of the skip blocks: 1 = a second side stream (measured: 21.55 vs 21.43 ms, more overlap only slows the rest)
+        self.side2 = None
         self.group_wgrads = os.environ.get("SCOT_GROUP_WGRAD", "1") == "1"
         self.arena = arena
         # bf16x3: activations and weights stay fp32 in HBM; the GEMMs split them into hi + lo bf16 while staging into LDS and
@@ -126,12 +128,21 @@ class ScOTEngine:
         self.fused_c = {int(c) for c in os.environ.get("SCOT_FUSED_C", "96,192").split(",") if c}
         self.fused_parts = set(os.environ.get("SCOT_FUSED_PARTS", "mlp_fwd,mlp_bwd,proj_fwd,proj_bwd").split(","))
         self.fused_tail = os.environ.get("SCOT_FUSED_TAIL", "1") == "1"     # MLP-half + projection-half backward in one launch
-        self.fused_next_qkv = os.environ.get("SCOT_FUSED_NEXT_QKV", "1") == "1"     # ... forward: the next layer's q/k/v projection as epilogue
-        self.fused_qkv_dgrad = os.environ.get("SCOT_FUSED_QKV_DGRAD", "1") == "1"   # ... with the previous layer's qkv dgrad as prologue
+        widths = lambda name, default: {int(c) for c in os.environ.get(name, default).split(",") if c}
+        # ... forward: the next layer's q/k/v projection as epilogue (channel widths).  Backward: the previous layer's qkv dgrad as
+        # prologue — at C = 96 only: the C = 192 prologue variant spills and costs more than the GEMM it replaces (125 vs 87 + 20 us)
+        self.fused_next_qkv = widths("SCOT_FUSED_NEXT_QKV", "96,192")
+        self.fused_qkv_dgrad = widths("SCOT_FUSED_QKV_DGRAD", "96")
         # bf16 mode: GEMM operands must already be bf16 in HBM (gemm_fast streams raw 16-byte chunks into LDS), so the
         # weights get a bf16 shadow arena that is re-cast from the fp32 master at the start of EVERY forward (one pass,
         # inside the timed step), and every producer of a GEMM operand also writes a bf16 copy.
         self.shadow = torch.empty(arena.size, dtype=self.adt, device=self.device) if self.compute == ops.BF16 else None
+        # ... and a second copy holding every weight MATRIX transposed (same offsets): the data gradients dX = dY · W then run as the
+        # forward's NT product on W^T instead of the strided-operand NN product (stages 2/3: 1.7–2.2x slower for the same shape).
+        # Filled by one launch per training forward, on the side stream (scot_transpose_cast).  SCOT_DGRAD_WT=0: NN products.
+        self.shadow_t, self._wt_names, self._wt_desc, self._wt_tiles = None, {}, None, 0
+        if self.shadow is not None and os.environ.get("SCOT_DGRAD_WT", "1") == "1":
+            self._plan_transposed_weights()
         # fp16 operands have 5 exponent bits: the backward runs on gradients multiplied by a power of two chosen from the loss
         # normalisation (d loss / d prediction = O(1 / number of output elements); see _grad_scale) and the gradient arena is
         # divided by it afterwards (exact; scot_scale_inplace also counts non-finite values → `grad_overflow`).
@@ -207,6 +218,45 @@ class ScOTEngine:
     def Wspan(self, name, numel):
         o = self.arena.offsets[name]
         return (self.shadow if self.shadow is not None else self.arena.data)[o:o + numel]
+
+    def _plan_transposed_weights(self):
+        ar = self.arena
+        mats = []
+        for name, off in ar.offsets.items():
+            if name.endswith(".qkv_weight"):
+                C = ar.shapes[name[: -len("qkv_weight")] + "query.weight"][0]
+                mats.append((name, off, 3 * C, C))
+            elif name.endswith("weight") and name in ar.shapes and len(ar.shapes[name]) == 2 and \
+                    not name.endswith(("query.weight", "key.weight", "value.weight")):
+                r, c = ar.shapes[name]
+                if r % 8 == 0 and c % 8 == 0 and min(r, c) >= 32:
+                    mats.append((name, off, r, c))
+        if not mats:
+            return
+        desc, tile = [], 0
+        for name, off, r, c in mats:
+            desc.append((off, r, c, tile))
+            tile += ((r + 63) // 64) * ((c + 63) // 64)
+            self._wt_names[name] = (off, r, c)
+        self.shadow_t = torch.zeros(ar.size, dtype=self.adt, device=self.device)
+        self._wt_desc = torch.tensor(desc, dtype=torch.int32, device=self.device)
+        self._wt_tiles = tile
+        self._wtviews = {}
+
+    def transpose_weights(self):
+        ops.transpose_cast(self.arena.data, self.shadow_t, self._wt_desc, len(self._wt_names), self._wt_tiles)
+
+    def WT(self, name, w=None):
+        """W(name)^T as a GEMM operand ([in, out], contiguous), or None when no transposed copy is kept (`w`: the operand the caller
+        is about to use — a transposed copy only stands in for the 16-bit weight copy, never for the fp32 master)."""
+        if self.shadow_t is None or name not in self._wt_names or (w is not None and w.dtype != self.adt):
+            return None
+        v = self._wtviews.get(name)
+        if v is None:
+            off, r, c = self._wt_names[name]
+            v = self.shadow_t[off:off + r * c].view(c, r)
+            self._wtviews[name] = v
+        return v
 
     def TW(self, name):
         """Trunk weight operand (fp32 master when the trunk computes in fp32)."""
@@ -360,25 +410,27 @@ class ScOTEngine:
         else:
             self._run_side([fn])
 
-    def _run_side(self, fns):
+    def _run_side(self, fns, lane=0):
         if self.side is None:
             self.side = torch.cuda.Stream(device=self.device)
-        ev, cur, side = torch.cuda.Event(), torch.cuda.current_stream(), self.side
+        if lane and self.side2 is None:
+            self.side2 = torch.cuda.Stream(device=self.device)
+        ev, cur, side = torch.cuda.Event(), torch.cuda.current_stream(), (self.side2 if lane else self.side)
 
         def fork():
             ev.record(cur)
             side.wait_event(ev)
         self.tdo(fork)
-        prev = ops.set_workspace_slot(1)
+        prev = ops.set_workspace_slot(10 if lane else 1)
         try:
-            with torch.cuda.stream(self.side):
+            with torch.cuda.stream(side):
                 for fn in fns:
                     fn()
         finally:
             ops.set_workspace_slot(prev)
 
-    def fork_task(self, fn):
-        """Run fn() on the side stream NOW, ordered after everything enqueued so far on the current stream; returns (fn's
+    def fork_task(self, fn, lane=0):
+        """Run fn() on the side stream (lane 1: the second side stream, for long small-grid work that overlaps the first) NOW, ordered after everything enqueued so far on the current stream; returns (fn's
         result, event recorded on the side stream after it).  The caller makes the main stream wait for the event
         (`wait_task`) before it consumes what fn produced.  Without a side stream: fn() in line, event None."""
         if not self.use_side:
@@ -396,8 +448,8 @@ class ScOTEngine:
             finally:
                 self._in_side = None
         self._task_keep = []
-        self._run_side([run])
-        ev, side = torch.cuda.Event(), self.side
+        self._run_side([run], lane)
+        ev, side = torch.cuda.Event(), (self.side2 if lane else self.side)
         self.tdo(lambda: ev.record(side))
         # temporaries of the task come from the main stream's pool: returning them before the main stream is ordered behind the
         # task would hand memory that side-stream kernels still use to the next main-stream allocation
@@ -420,8 +472,10 @@ class ScOTEngine:
     def join_side(self):
         self.flush_side()
         if self.use_side and self.side is not None:
-            cur, side = torch.cuda.current_stream(), self.side
+            cur, side, side2 = torch.cuda.current_stream(), self.side, self.side2
             self.tdo(lambda: cur.wait_stream(side))
+            if side2 is not None:
+                self.tdo(lambda: cur.wait_stream(side2))
             self._keep.clear()
             self._task_keeps.clear()
 
@@ -553,7 +607,7 @@ class ScOTEngine:
         called within a stage); needs the unpadded window geometry (the projection input is then exactly the previous output rows)."""
         H, W = blk.res
         ws, _ = blk.window_shift()
-        return H % ws == 0 and W % ws == 0 and self.fused_next_qkv and not self.precision_probe
+        return H % ws == 0 and W % ws == 0 and blk.dim in self.fused_next_qkv and not self.precision_probe
 
     def layer_fwd(self, blk: BlockGeom, x, x16, B, time, train, qkv_pre=None, next_blk=None):
         """reference ScOTLayer.forward (model.py:500-581) + Swinv2Attention/Intermediate/Output (HF:389-561).  qkv_pre: this layer's
@@ -677,14 +731,14 @@ class ScOTEngine:
                        y2=y2, st2=st2, geom=(H, W, Hp, Wp, ws, shift, padded), dp=(dp1, dp2))
         return out, out16, rec, qkv_next
 
-    def dgrad_into(self, cm, dy, w, g):
+    def dgrad_into(self, cm, dy, w, g, wt=None):
         """g + dy·w.  In place when nothing else may still be reading g; otherwise into a fresh buffer: with the LN backward's
         parameter-gradient half on the side stream, g (its `dout`) must stay untouched until that kernel has run."""
         if self.inplace_g:
-            ops.linear_dgrad(cm, dy, w, g, accumulate=True)
+            ops.linear_dgrad(cm, dy, w, g, accumulate=True, wt=wt)
             return g
         g2 = self.new(*g.shape)
-        ops.linear_dgrad(cm, dy, w, g2, resid=g)
+        ops.linear_dgrad(cm, dy, w, g2, resid=g, wt=wt)
         return g2
 
     def _layer_fwd_probe(self, blk, x, x16, B, time, ex):
@@ -766,9 +820,9 @@ class ScOTEngine:
         mlp_f = self.use_fused("mlp_bwd", C) and hid % 128 == 0 and L % 64 == 0 and not self.split_ln_bwd
         proj_f = self.use_fused("proj_bwd", C) and L % 64 == 0 and not self.split_ln_bwd
         tail_f = mlp_f and proj_f and self.fused_tail
-        can_prologue = tail_f and self.inplace_g and self.fused_qkv_dgrad and not padded
+        can_prologue = tail_f and self.inplace_g and C in self.fused_qkv_dgrad and not padded
         if pend is not None and not can_prologue:
-            g = self.dgrad_into(cm, pend[0], pend[1], g)
+            g = self.dgrad_into(cm, pend[0], pend[1], g, wt=pend[2])
             pend = None
         d_attn = self.new(B * L, C, dtype=adt)
         done_tail = False
@@ -786,7 +840,7 @@ class ScOTEngine:
                  d_proj, d_attn, g1[0], g1[1], g1[2], g1[3]),
                 time if self.cond else None, B * L, L, C, hid, dqkv=pend[0] if pend else None, wqkv=pend[1] if pend else None)
             if not done_tail and pend is not None:
-                g = self.dgrad_into(cm, pend[0], pend[1], g)
+                g = self.dgrad_into(cm, pend[0], pend[1], g, wt=pend[2])
             pend = None
             if done_tail:
                 g = gout
@@ -815,10 +869,11 @@ class ScOTEngine:
             # y2 = gelu(u) W2^T + b2
             self.linear_bwd_params(pre + ".output.dense.weight", pre + ".output.dense.bias", d_y2, rec["u"])   # rec["u"] = gelu(u)
             d_u = self.new(B * L, hid, dtype=adt)
-            ops.linear_dgrad(cm, d_y2, self.W(pre + ".output.dense.weight"), d_u, aux=rec["gp"], aux_mul=True)
+            ops.linear_dgrad(cm, d_y2, self.W(pre + ".output.dense.weight"), d_u, aux=rec["gp"], aux_mul=True,
+                             wt=self.WT(pre + ".output.dense.weight"))
             # u = h W1^T + b1
             self.linear_bwd_params(pre + ".intermediate.dense.weight", pre + ".intermediate.dense.bias", d_u, rec["h16"])
-            g = self.dgrad_into(cm, d_u, self.W(pre + ".intermediate.dense.weight"), g)
+            g = self.dgrad_into(cm, d_u, self.W(pre + ".intermediate.dense.weight"), g, wt=self.WT(pre + ".intermediate.dense.weight"))
         # h = x + CLN_before(proj)
         if done_tail:
             pass
@@ -834,7 +889,8 @@ class ScOTEngine:
         else:
             d_proj = self.norm_bwd(pre + ".layernorm_before", g, rec["proj"], rec["st1"], L, C, time, adt, sample_scale=rec["dp"][0])
             self.linear_bwd_params(pre + ".attention.output.dense.weight", pre + ".attention.output.dense.bias", d_proj, rec["attn_c"])
-            ops.linear_dgrad(cm, d_proj, self.W(pre + ".attention.output.dense.weight"), d_attn)
+            ops.linear_dgrad(cm, d_proj, self.W(pre + ".attention.output.dense.weight"), d_attn,
+                             wt=self.WT(pre + ".attention.output.dense.weight"))
         if padded:
             d_attn_p = self.new(B * Lp, C, dtype=adt)
             ops.copy2d(d_attn, d_attn_p, B, H, W, Hp, Wp, C)
@@ -849,7 +905,7 @@ class ScOTEngine:
         self.wgrad(cm, d_qkv, rec["xp"], gwqkv, dbias=self.arena.span(a + "qkv_bias", 3 * C, grad=True) if cfg.qkv_bias else None)
         if padded:
             tmp = self.new(B * Lp, C)
-            ops.linear_dgrad(cm, d_qkv, wqkv, tmp)
+            ops.linear_dgrad(cm, d_qkv, wqkv, tmp, wt=self.WT(a + "qkv_weight"))
             tmpc = self.new(B * L, C)
             ops.copy2d(tmp, tmpc, B, Hp, Wp, H, W, C)
             g2 = g if self.inplace_g else self.new(B * L, C)
@@ -857,9 +913,9 @@ class ScOTEngine:
             g = g2
             new_pend = None
         elif defer_qkv_dgrad and can_prologue:
-            new_pend = (d_qkv, wqkv)      # (the next layer of this stage has the same geometry: its fused tail applies it)
+            new_pend = (d_qkv, wqkv, self.WT(a + "qkv_weight"))      # (the next layer of this stage has the same geometry: its fused tail applies it)
         else:
-            g = self.dgrad_into(cm, d_qkv, wqkv, g)
+            g = self.dgrad_into(cm, d_qkv, wqkv, g, wt=self.WT(a + "qkv_weight"))
             new_pend = None
         if self.side_flush == "block":
             self.flush_side()
@@ -885,7 +941,8 @@ class ScOTEngine:
         d_r = self.norm_bwd(st.prefix + ".downsample.norm", g, rec["r"], rec["stats"], H2 * W2, 2 * C, time, self.tadt)
         self.wgrad(self.tcm, d_r, rec["cat"], self.G(st.prefix + ".downsample.reduction.weight"))
         d_cat = self.new(B * H2 * W2, 4 * C)
-        ops.linear_dgrad(self.tcm, d_r, self.TW(st.prefix + ".downsample.reduction.weight"), d_cat)
+        ops.linear_dgrad(self.tcm, d_r, self.TW(st.prefix + ".downsample.reduction.weight"), d_cat,
+                         wt=self.WT(st.prefix + ".downsample.reduction.weight", self.TW(st.prefix + ".downsample.reduction.weight")))
         d_sum = self.new(B * H * W, C)
         ops.depth_to_space(d_cat, d_sum, B, H, W, H2, W2, C, 0)
         return d_sum
@@ -913,13 +970,15 @@ class ScOTEngine:
         g16 = self.to_tadt(g)
         self.wgrad(self.tcm, g16, rec["n"], self.G(st.prefix + ".upsample.mixup.weight"))
         d_n = self.new(B * oh * ow, C // 2, dtype=self.tadt)
-        ops.linear_dgrad(self.tcm, g16, self.TW(st.prefix + ".upsample.mixup.weight"), d_n)
+        ops.linear_dgrad(self.tcm, g16, self.TW(st.prefix + ".upsample.mixup.weight"), d_n,
+                         wt=self.WT(st.prefix + ".upsample.mixup.weight", self.TW(st.prefix + ".upsample.mixup.weight")))
         d_sh = self.norm_bwd(st.prefix + ".upsample.norm", d_n, rec["sh"], rec["stats"], oh * ow, C // 2, time, self.tadt)
         d_up = self.new(B * h * w, 2 * C, dtype=self.tadt)
         ops.space_to_depth(d_sh, None, d_up, B, oh, ow, C // 2, 1)
         self.wgrad(self.tcm, d_up, rec["x"], self.G(st.prefix + ".upsample.upsample.weight"))
         gx = self.new(B * h * w, C)
-        ops.linear_dgrad(self.tcm, d_up, self.TW(st.prefix + ".upsample.upsample.weight"), gx)
+        ops.linear_dgrad(self.tcm, d_up, self.TW(st.prefix + ".upsample.upsample.weight"), gx,
+                         wt=self.WT(st.prefix + ".upsample.upsample.weight", self.TW(st.prefix + ".upsample.upsample.weight")))
         return gx
 
     # ------------------------------------------------------------------------------------------ ConvNeXt skip block
@@ -948,10 +1007,10 @@ class ScOTEngine:
         ops.colsum(g, self.G(pre + ".weight"), y=rec["y2"])
         self.linear_bwd_params(pre + ".pwconv2.weight", pre + ".pwconv2.bias", d_y2, rec["u"])
         d_u = self.new(B * L, 4 * C, dtype=self.adt)
-        ops.linear_dgrad(self.compute, d_y2, self.W(pre + ".pwconv2.weight"), d_u, aux=rec["gp"], aux_mul=True)
+        ops.linear_dgrad(self.compute, d_y2, self.W(pre + ".pwconv2.weight"), d_u, aux=rec["gp"], aux_mul=True, wt=self.WT(pre + ".pwconv2.weight"))
         self.linear_bwd_params(pre + ".pwconv1.weight", pre + ".pwconv1.bias", d_u, rec["n"])
         d_n = self.new(B * L, C, dtype=self.adt)
-        ops.linear_dgrad(self.compute, d_u, self.W(pre + ".pwconv1.weight"), d_n)
+        ops.linear_dgrad(self.compute, d_u, self.W(pre + ".pwconv1.weight"), d_n, wt=self.WT(pre + ".pwconv1.weight"))
         d_dw = self.norm_bwd(pre + ".norm", d_n, rec["dw"], rec["stats"], L, C, time, torch.float32)
         self.off_critical_path(lambda: ops.dwconv7_wgrad(d_dw, rec["s"], self.G(pre + ".dwconv.weight"), self.G(pre + ".dwconv.bias"),
                                                          B, H, W, C), d_dw, rec["s"])
@@ -1133,14 +1192,24 @@ class ScOTEngine:
             _, ev_cpb = self.fork_task(cpb_all)
             if self.shadow is not None:
                 split = min((o for n, o in self.arena.offsets.items() if n.startswith("encoder.layers.1.")), default=0)
+                want_t = train and self.shadow_t is not None
+
+                def rest():
+                    ops.cast(self.arena.data[split:], self.shadow[split:])
+                    if want_t:
+                        self.transpose_weights()        # first read by the backward
                 if split > 0:
                     ops.cast(self.arena.data[:split], self.shadow[:split])
-                    _, ev_cast = self.fork_task(lambda: ops.cast(self.arena.data[split:], self.shadow[split:]))
+                    _, ev_cast = self.fork_task(rest)
                 else:
                     ops.cast(self.arena.data, self.shadow)
+                    if want_t:
+                        self.transpose_weights()
         else:
             if self.shadow is not None:
                 ops.cast(self.arena.data, self.shadow)  # fp32 master weights → 16-bit GEMM operands (every step)
+                if train and self.shadow_t is not None:
+                    self.transpose_weights()
             cpb_all()
 
         # embeddings (model.py:295-366)
@@ -1400,7 +1469,7 @@ class ScOTEngine:
                 if side_skips and tape["res"][i]:
                     # this skip's gradient is only needed when the backward reaches encoder stage i: its ConvNeXt blocks go to
                     # the side stream now, beside the deeper decoder / encoder stages
-                    g_skips[i], skip_ev[i] = self.fork_task(lambda i=i, gi=g_skips[i]: skip_bwd(i, gi))
+                    g_skips[i], skip_ev[i] = self.fork_task(lambda i=i, gi=g_skips[i]: skip_bwd(i, gi), lane=self.skip_lane)
         g_skips[nl - 1] = g  # decoder input = skips[-1]
 
         # ConvNeXt blocks (in line: the deepest skip, and every skip when the side stream is off)

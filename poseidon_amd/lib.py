@@ -37,6 +37,7 @@ PROTOTYPES = {
     "scot_mlp_block_fwd": [P, P, P, P, P, P, P, P, P, P, P, P, P, P, P, P, P, P, P, I, I, I, I, F, P],
     "scot_mlp_block_bwd": [P, P, P, P, P, P, P, P, P, P, P, P, P, P, P, P, P, P, I, I, I, I, P],
     "scot_block_tail_bwd": [P] * 33 + [I, I, I, I, P],
+    "scot_transpose_cast": [P, P, P, I, I, P],
     "scot_block_tail_fwd": [P] * 34 + [I, I, I, I, F, P],
     "scot_proj_cln_fwd": [P, P, P, P, P, P, P, P, P, P, P, P, P, P, P, I, I, I, F, P],
     "scot_proj_cln_bwd": [P, P, P, P, P, P, P, P, P, P, P, P, P, P, P, I, I, I, P],

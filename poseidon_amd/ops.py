@@ -141,12 +141,24 @@ def linear_fwd(compute, x, w, out, bias=None, a_gelu=False, gelu_deriv_out=None)
     gemm(NT, compute, M, N, Kw, x, x.shape[-1], w, Kw, out, out.shape[-1], bias=bias, a_gelu=a_gelu, gelu_deriv_out=gelu_deriv_out)
 
 
-def linear_dgrad(compute, dy, w, dx, accumulate=False, aux=None, aux_mul=False, resid=None):
-    """dx[M,K] (+)= dy[M,N] @ w[N,K]  (* gelu'(aux), or * aux when aux_mul);  resid: dx = resid + ... (out of place)."""
+def linear_dgrad(compute, dy, w, dx, accumulate=False, aux=None, aux_mul=False, resid=None, wt=None):
+    """dx[M,K] (+)= dy[M,N] @ w[N,K]  (* gelu'(aux), or * aux when aux_mul);  resid: dx = resid + ... (out of place).
+    wt: w^T [K, N] (see transpose_cast) — the same product as the forward's NT GEMM, whose operands are both contiguous along the
+    reduction index."""
     M = dy.numel() // dy.shape[-1]
     N, K = w.shape[0], w.numel() // w.shape[0]
-    gemm(NN, compute, M, K, N, dy, dy.shape[-1], w, K, dx, dx.shape[-1], aux=aux, ldaux=aux.shape[-1] if aux is not None else 0,
-         accumulate=accumulate, aux_mul=aux_mul, resid=resid, ldres=resid.shape[-1] if resid is not None else 0)
+    kw = dict(aux=aux, ldaux=aux.shape[-1] if aux is not None else 0, accumulate=accumulate, aux_mul=aux_mul, resid=resid,
+              ldres=resid.shape[-1] if resid is not None else 0)
+    if wt is not None:
+        gemm(NT, compute, M, K, N, dy, dy.shape[-1], wt, N, dx, dx.shape[-1], **kw)
+    else:
+        gemm(NN, compute, M, K, N, dy, dy.shape[-1], w, K, dx, dx.shape[-1], **kw)
+
+
+def transpose_cast(w, wt16, desc, n: int, tiles: int):
+    """wt16 (operand format) <- per-matrix transposes of the fp32 arena w; desc int32 [n, 4] on the device (offset, rows, cols,
+    first tile) — scot_transpose_cast."""
+    _lib.check(L().scot_transpose_cast(ptr(w), ptr(wt16), ptr(desc), n, tiles, stream()), "scot_transpose_cast")
 
 
 def linear_wgrad(compute, dy, x, dw, b_gelu=False, dbias=None):

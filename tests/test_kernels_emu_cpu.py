@@ -209,3 +209,7 @@ def test_spectral_resize_native(emu, s, t):
     y.backward(g)
     yr.backward(g.double())
     assert rel(x.grad, xr.grad) < 2e-6
+
+
+def test_transposed_weight_copies(gpu_test_bodies):
+    gpu_test_bodies.test_transpose_cast_and_dgrad_nt()

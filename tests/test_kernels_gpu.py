@@ -747,3 +747,33 @@ def test_block_tail_bwd_fused(cond, B, L, C, prologue):
     for a_, b_ in zip(fp2 + fp1, rp2 + rp1):
         if a_ is not None:
             assert rel(a_, b_) < 1e-4
+
+
+# ----------------------------------------------------------------------------------------------- transposed weight copies
+def test_transpose_cast_and_dgrad_nt():
+    """scot_transpose_cast: per-matrix transposes of an fp32 arena in the operand format (ragged 64x64 tiles included); a data
+    gradient through the transposed copy (NT product) equals the NN product on the plain copy to fp32 accumulation order."""
+    mats = [(96, 288), (288, 96), (384, 1536), (40, 72), (768, 192)]
+    offs, cur = [], 0
+    for r, c in mats:
+        offs.append(cur)
+        cur += (r * c + 63) // 64 * 64 + 64
+    arena = rnd(cur, seed=3)
+    desc, tile = [], 0
+    for (r, c), o in zip(mats, offs):
+        desc.append((o, r, c, tile))
+        tile += ((r + 63) // 64) * ((c + 63) // 64)
+    wt = torch.full((cur,), float("nan"), device=DEV, dtype=torch.bfloat16)
+    ops.transpose_cast(arena, wt, torch.tensor(desc, dtype=torch.int32, device=DEV), len(mats), tile)
+    torch.cuda.synchronize()
+    for (r, c), o in zip(mats, offs):
+        ref = arena[o:o + r * c].view(r, c).to(torch.bfloat16).t().contiguous()
+        assert torch.equal(wt[o:o + r * c].view(c, r), ref), (r, c)
+    r, c = mats[2]
+    w16 = arena[offs[2]:offs[2] + r * c].view(r, c).to(torch.bfloat16)
+    dy = rnd(512, r, seed=5).to(torch.bfloat16)
+    a, b = torch.empty(512, c, device=DEV), torch.empty(512, c, device=DEV)
+    ops.linear_dgrad(ops.BF16, dy, w16, a)
+    ops.linear_dgrad(ops.BF16, dy, w16, b, wt=wt[offs[2]:offs[2] + r * c].view(c, r))
+    torch.cuda.synchronize()
+    assert rel(b, a) < 1e-6 and rel(b, dy.float() @ w16.float()) < 1e-5
