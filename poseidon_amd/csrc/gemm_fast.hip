@@ -661,8 +661,10 @@ int scot_gemm_fast(int layout, int compute, int M, int N, int K, const void* A, 
     // per CU): split K over more workgroups, partial sums through the workspace, epilogue in the reduce pass.
     // Measured: pays from K >= 1536 (24 K-tiles); at K = 768 the extra pass costs more than it hides.
     static int nt_split = -1;
-    if (nt_split < 0) { const char* e = getenv("SCOT_GEMM_NT_SPLIT"); nt_split = e ? atoi(e) : 1; }
-    if (nt_split && !colsum_out && workspace && (((uintptr_t)workspace & 31) == 0) && tiles < 512 && nkt >= 24) {
+    if (nt_split < 0) { const char* e = getenv("SCOT_GEMM_NT_SPLIT"); nt_split = e ? atoi(e) : 0; }
+    static int split_nkt = -1;
+    if (split_nkt < 0) { const char* e = getenv("SCOT_GEMM_NT_SPLIT_NKT"); split_nkt = e ? atoi(e) : 24; }
+    if (nt_split && !colsum_out && workspace && (((uintptr_t)workspace & 31) == 0) && tiles < 512 && nkt >= split_nkt) {
       long want = (1024 + tiles - 1) / tiles;
       long maxs = nkt / 4;
       long wsmax = (long)(ws_bytes / ((size_t)M * N * sizeof(float)));
