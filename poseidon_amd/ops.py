@@ -72,8 +72,10 @@ class _Recording:
         log = self._log
 
         def call(*args):
-            log.append((fn, args))
-            return fn(*args)
+            rc = fn(*args)
+            if rc != -3:      # SCOT_ERR_UNSUPPORTED = "not covered, nothing launched": the caller falls back, the replay must not re-ask
+                log.append((fn, args))
+            return rc
         return call
 
 

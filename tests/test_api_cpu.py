@@ -105,3 +105,20 @@ def test_c_abi_exports_every_declared_symbol():
     for name in declared:
         assert getattr(f16, name) is not None
     assert f16.scot_abi_version() == 1 and f16.scot_operand_format() == 1
+
+
+def test_step_tape_skips_calls_the_library_declined():
+    """A C-ABI call that answers SCOT_ERR_UNSUPPORTED launched nothing and its caller falls back to other launches: the recorded step
+    must hold the fallback launches only (a replayed -3 would otherwise abort every later step)."""
+    from poseidon_amd import ops
+
+    class FakeLib:
+        def scot_covered(self, *a):
+            return 0
+
+        def scot_declined(self, *a):
+            return -3
+    log = []
+    rec = ops._Recording(FakeLib(), log)
+    assert rec.scot_declined(1, 2) == -3 and rec.scot_covered(3) == 0
+    assert [(f.__name__, a) for f, a in log] == [("scot_covered", (3,))]
