@@ -772,7 +772,13 @@ extern "C" int scot_wgrad_group(int compute, int n, int K, const void* const* dY
   static int want_wgs = -1;
   if (want_wgs < 0) { const char* e = getenv("SCOT_WGRAD_GROUP_WGS"); want_wgs = e ? atoi(e) : 448; }
   const long nkt = (K + bk - 1) / bk;
-  long nsplit = tiles >= 256 ? 1 : (want_wgs + tiles - 1) / tiles;
+  // mid-sized groups (stage 2: 432 tiles x 64 K-tiles = 1.7 workgroups per CU walking a long serial K loop): two K slices
+  // (SCOT_WGRAD_GROUP_MID_WGS=864) run 66 instead of 85 us alone — and cost the step 0.2 ms: beside the main chain a wider
+  // side-stream kernel takes more from the chain's latency-bound kernels than it gains.  Off by default.
+  static int mid_wgs = -1;
+  if (mid_wgs < 0) { const char* e = getenv("SCOT_WGRAD_GROUP_MID_WGS"); mid_wgs = e ? atoi(e) : 0; }
+  long nsplit = tiles >= 1024 ? 1 : tiles >= 256 ? (mid_wgs + tiles / 2) / tiles : (want_wgs + tiles - 1) / tiles;
+  if (nsplit < 1) nsplit = 1;
   const long maxsplit = nkt / 8 > 0 ? nkt / 8 : 1;
   if (nsplit > maxsplit) nsplit = maxsplit;
   const long wsmax = (workspace && plane) ? (long)(ws_bytes / (plane * sizeof(float))) : 1;

@@ -133,6 +133,7 @@ def test_cln_fwd_bwd(emu, cond, xdt, B, L, C):
 ATTN = [  # compute, B, Hp, Wp, C, heads, ws, shift
     (ops.BF16, 1, 16, 16, 32, 1, 16, 0),     # 16x16-window fast path, one window, head_dim 32
     (ops.BF16, 1, 32, 32, 32, 1, 16, 8),     # ... shifted: all mask regions (4 windows)
+    (ops.BF16, 1, 16, 16, 32, 2, 16, 0),     # ... head_dim 16 (one-pass backward with a single feature block)
     (ops.BF16, 2, 8, 8, 32, 2, 4, 2),        # general kernels, N = 16, shifted
     (ops.F32, 1, 7, 7, 16, 1, 7, 0),         # general kernels, N = 49 (ragged tiles), exact fp32 MFMA
 ] + full_only((ops.X3, 1, 16, 16, 16, 1, 16, 0))   # 16x16 fast path with hi/lo split operands, head_dim 16

@@ -63,6 +63,27 @@ def main():
         gemm_case(ops.NN, M, 4 * C, C, tag=f"dgrad fc2 s{s}")
         gemm_case(ops.TN, 4 * C, C, M, tag=f"wgrad fc1 s{s}")
         gemm_case(ops.TN, C, 4 * C, M, tag=f"wgrad fc2 s{s}")
+    # grouped weight gradients of one ScOTLayer (fc2, fc1, out-projection, qkv), cold operands
+    for s_, (L, C) in (list(enumerate([(1024, 96), (256, 192), (64, 384), (16, 768)])) if only == "wgroup" else []):
+        K = B * L
+        nb = max(2, int(1.2e9 // (K * 12 * C * 2)))     # rotate through > 1 GB of operands
+        bf = torch.bfloat16
+        sets = []
+        for _ in range(nb):
+            dy = [torch.randn(K, n, device="cuda").to(bf) for n in (C, 4 * C, C, 3 * C)]
+            x = [torch.randn(K, n, device="cuda").to(bf) for n in (4 * C, C, C, C)]
+            sets.append((dy, x))
+        dw = [torch.zeros(m, n, device="cuda") for m, n in ((C, 4 * C), (4 * C, C), (C, C), (3 * C, C))]
+        db = [torch.zeros(m, device="cuda") for m in (C, 4 * C, C, 3 * C)]
+        it = [0]
+
+        def run_g():
+            dy, x = sets[it[0] % nb]
+            it[0] += 1
+            assert ops.wgrad_group(ops.BF16, [(dy[i], x[i], dw[i], db[i]) for i in range(4)])
+        us = timeit(run_g, reps=30)
+        fl = 2.0 * K * 12 * C * C
+        print(f"wgrad_group s{s_} K={K} C={C}: {us:7.1f} us  {fl/us/1e6:6.1f} TF/s  {K * 12 * C * 2 / us / 1e6:5.2f} TB/s of operands")
     # CLN
     for L, C in ([(1024, 96), (256, 192), (64, 384), (16, 768)] if only == "cln" else [] if only else [(1024, 96), (256, 192), (16, 768)]):
         rows = B * L
@@ -78,7 +99,7 @@ def main():
         us = timeit(lambda: ops.cln_bwd(out, x, mean, rstd, t, ps[0], ps[1], dx, gr[0], gr[1], gr[2], gr[3], rows, L, C))
         print(f"cln_bwd rows={rows} C={C}: {us:7.1f} us  {(2*4+2)*rows*C/us/1e3:6.0f} GB/s")
     # attention
-    for (Hp, C, heads, ws, shift) in ([(32, 96, 3, 16, 8)] if only == "attn" else [(4, 768, 24, 4, 0), (8, 384, 12, 8, 0)] if only == "attn3" else [] if only else
+    for (Hp, C, heads, ws, shift) in ([(32, 96, 3, 16, 8)] if only == "attn" else [(32, 96, 3, 16, 8), (32, 96, 3, 16, 0), (16, 192, 6, 16, 0)] if only == "attn16" else [(4, 768, 24, 4, 0), (8, 384, 12, 8, 0)] if only == "attn3" else [] if only else
                                       [(32, 96, 3, 16, 8), (16, 192, 6, 16, 0), (8, 384, 12, 8, 0), (4, 768, 24, 4, 0)]):
         Lp = Hp * Hp
         qkv = torch.randn(B * Lp, 3 * C, device="cuda").to(torch.bfloat16)
