@@ -15,6 +15,14 @@ def short(name):
 
 def main():
     rows = list(csv.DictReader(open(sys.argv[1])))
+    if "--total" in sys.argv:      # counter sum over ALL dispatches, and per training step (a step = one cpb_fwd_batched dispatch)
+        steps = max(1, sum(1 for r in rows if "cpb_fwd_batched" in r["Kernel_Name"]))
+        tot = defaultdict(float)
+        for r in rows:
+            tot[r["Counter_Name"]] += float(r["Counter_Value"])
+        for k, v in tot.items():
+            print(f"{k}: total {v:.1f} over {len(rows)} dispatches, {steps} steps -> {v / steps:.1f} per step")
+        return
     agg = defaultdict(lambda: [0, 0.0])
     for r in rows:
         k = (short(r["Kernel_Name"]), r.get("Grid_Size", ""), r["Counter_Name"])

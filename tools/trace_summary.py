@@ -1,6 +1,6 @@
 """Aggregate a rocprofv3 kernel_trace.csv by (kernel, grid): calls, average and total time, plus busy/idle totals.
 
-usage: python tools/trace_summary.py <kernel_trace.csv> [steps] > summary.txt
+usage: python tools/trace_summary.py <kernel_trace.csv> [steps | auto] > summary.txt
 """
 import csv
 import re
@@ -17,8 +17,11 @@ def short(name):
 
 def main():
     path = sys.argv[1]
-    steps = int(sys.argv[2]) if len(sys.argv) > 2 else 1
     rows = list(csv.DictReader(open(path)))
+    if len(sys.argv) > 2 and sys.argv[2] == "auto":     # one cpb_fwd_batched dispatch per training forward
+        steps = max(1, sum(1 for r in rows if "cpb_fwd_batched" in r["Kernel_Name"]))
+    else:
+        steps = int(sys.argv[2]) if len(sys.argv) > 2 else 1
     agg = defaultdict(lambda: [0, 0.0])
     spans = []
     for r in rows:
