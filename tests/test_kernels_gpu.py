@@ -165,11 +165,21 @@ ATTN_CASES = [  # B, Hp, Wp, C, heads, ws, shift
 ]
 
 
-@pytest.mark.parametrize("compute", [ops.F32, ops.BF16, ops.X3])
+@pytest.mark.parametrize("compute", [ops.F32, ops.BF16, ops.X3, "f16"])
 @pytest.mark.parametrize("case", ATTN_CASES)
 def test_window_attention_fwd_bwd(compute, case):
+    """"f16": the 16-bit kernels in the binary16 build of the library (the product's default operand format)."""
+    f16 = compute == "f16"
+    prev = ops.use("f16" if f16 else "bf16")
+    try:
+        _window_attention_fwd_bwd(ops.BF16 if f16 else compute, case, torch.float16 if f16 else torch.bfloat16)
+    finally:
+        ops.use(prev)
+
+
+def _window_attention_fwd_bwd(compute, case, half):
     B, Hp, Wp, C, heads, ws, shift = case
-    cdt = torch.bfloat16 if compute == ops.BF16 else torch.float32     # bf16x3 keeps fp32 tensors and splits inside the kernel
+    cdt = half if compute == ops.BF16 else torch.float32     # bf16x3 keeps fp32 tensors and splits inside the kernel
     L, TS, N = Hp * Wp, (2 * ws - 1) ** 2, ws * ws
     qkv = rnd(B, L, 3 * C, dtype=cdt)
     table = (16 * torch.sigmoid(rnd(heads, TS, seed=1))).contiguous()
@@ -190,8 +200,12 @@ def test_window_attention_fwd_bwd(compute, case):
     l64 = ls.double().requires_grad_(True)
     ref = _attn_ref(q64, t64, l64, B, Hp, Wp, C, heads, ws, shift)
     ref.backward(dout.double())
-    tol_o, tol_g = (2e-5, 5e-5) if compute == ops.F32 else (5e-5, 2e-4) if compute == ops.X3 else (2e-2, 4e-2)
-    tol_ls = 2e-4 if compute == ops.F32 else 2e-3 if compute == ops.X3 else 0.15  # Σ_k dS = 0: d logit_scale is a heavily cancelling sum
+    # 16-bit operands: q/k (normalised), P and dS are rounded to the operand format inside the kernel.  Measured over these cases on
+    # MI355X (tools/probes/attn_err_probe.py): bf16 out <= 5.3e-3, dqkv <= 7.8e-3, dtab <= 6.4e-3, dls <= 5.9e-2; binary16 out <= 6.4e-4,
+    # dqkv <= 1.1e-3, dtab <= 7.8e-4, dls <= 8.4e-3 — bounds at ~1.5-2x of that
+    t16 = ((1.2e-3, 2e-3), 2e-2) if half == torch.float16 else ((8e-3, 1.2e-2), 0.1)
+    tol_o, tol_g = (2e-5, 5e-5) if compute == ops.F32 else (5e-5, 2e-4) if compute == ops.X3 else t16[0]
+    tol_ls = 2e-4 if compute == ops.F32 else 2e-3 if compute == ops.X3 else t16[1]  # Σ_k dS = 0: d logit_scale is a heavily cancelling sum
     assert rel(out, ref.detach()) < tol_o, "out"
     assert rel(dqkv, q64.grad) < tol_g, "dqkv"
     assert rel(dtab, t64.grad) < tol_g, "dbias_table"

@@ -138,8 +138,10 @@ def test_poseidon_presets(name, compute):
         # tools/probes/precision_sim.py).  Gradients: the backward runs under a power-of-two gradient scale, no overflow.
         assert e_out < 1e-3 and e_loss < 1e-3
         assert int(model._engine.grad_overflow) == 0
-        assert np.median(dev) < 5e-3
-        grads_report(model, f, tol_each=1e9, tol_global=0.1, floor=1e-6, skip=("logit_scale",))
+        assert np.median(dev) < 1.5e-3         # measured 3.8e-4 .. 6.0e-4
+        # stored full gradients, global rel-L2: measured 1.1e-3 (T) / 2.6e-3 (B) / 1.6e-3 (B@256²) trained-like, 3e-4 / 1e-4 HF-init
+        g, worst = grads_report(model, f, tol_each=1e9, tol_global=6e-3, floor=1e-6, skip=("logit_scale",))
+        print(f"[{name} fp16] stored gradients: global rel-L2 {g:.2e}, worst {worst}")
     elif compute == "bf16x3":
         # fp32 operands split into hi + lo bf16 (three bf16 MFMAs per product): the north star's 1e-3 bound for the bf16 path,
         # with margin — on BOTH parameter regimes
