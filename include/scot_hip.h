@@ -41,6 +41,12 @@ int scot_scale_inplace(float* x, size_t n, float scale, int* nonfinite, scot_str
  *   transpose: (y, x) read at (x, y).  data fp32 [n, T, nsrc, H, W]; it int32 [3, B] = trajectories, t1, t2. */
 int scot_gather_pairs(const float* data, const int* it, const int* src, const float* a, const float* b, float* pv, float* lab,
                       int B, int C, int T, int nsrc, int H, int W, int transpose, scot_stream_t stream);
+/* One tensor of a batch with its own recipe (readers whose inputs and labels differ, static or analytic extra channels:
+ * scOT/problems/elliptic/*.py, wave/acoustic.py, reaction_diffusion/allen_cahn.py, fluids/incompressible.py:149-243 KolmogorovFlow,
+ * fluids/compressible.py:8-53 Airfoil):  out[b,c] = a[c] * P + b[c] with P = data[traj[b], tidx[b], src[c]] (src >= 0), nothing
+ * (src = -1: the constant b[c]) or the fixed plane planes[-2 - src[c]] ([*, H, W] fp32; may be NULL when unused). */
+int scot_gather_planes(const float* data, const int* traj, const int* tidx, const int* src, const float* a, const float* b,
+                       const float* planes, float* out, int B, int C, int T, int nsrc, int H, int W, int transpose, scot_stream_t stream);
 /* Transposed operand-format copies of weight matrices, converted from the fp32 master in the same pass:
  * wt16[off + c*rows + r] = w[off + r*cols + c] for every matrix of desc (int32 [n][4], device: element offset, rows, cols, index of
  * its first 64x64 tile; rows and cols multiples of 8; tiles = total tile count).  The data gradient of nn.Linear, dX = dY · W, then

@@ -83,6 +83,37 @@ extern "C" int scot_gather_pairs(const float* data, const int* it, const int* sr
   return scot_check_launch();
 }
 
+// One tensor of a batch with its own recipe (datasets whose inputs and labels differ: steady problems, extra static or analytic
+// channels — scOT/problems/{elliptic,wave,reaction_diffusion}/*.py, KolmogorovFlow, Airfoil):
+//   out[b, c, y, x] = a[c] * P[y', x'] + b[c],   P = data[traj_b, t_b, src[c]]  (src >= 0),  the constant 0 (src = -1: out = b[c]),
+//   or the fixed plane planes[-2 - src[c]] (not transposed: it is defined on the output grid)
+__global__ __launch_bounds__(256) void gather_planes_kernel(const float* __restrict__ data, const int* __restrict__ traj, const int* __restrict__ tidx,
+                                                            const int* __restrict__ src, const float* __restrict__ a, const float* __restrict__ b,
+                                                            const float* __restrict__ planes, float* __restrict__ out, int B, int C, int T,
+                                                            int nsrc, int H, int W, int transpose) {
+  const int bc = blockIdx.y, bi = bc / C, c = bc % C;
+  const int sc = src[c];
+  const float aa = a[c], bb = b[c];
+  const size_t plane = (size_t)H * W;
+  const float* p = sc >= 0 ? data + (((size_t)traj[bi] * T + tidx[bi]) * nsrc + sc) * plane : sc <= -2 ? planes + (size_t)(-2 - sc) * plane : nullptr;
+  float* o = out + (size_t)bc * plane;
+  const bool tr = transpose && sc >= 0;
+  for (size_t e = (size_t)blockIdx.x * 256 + threadIdx.x; e < plane; e += (size_t)gridDim.x * 256) {
+    if (!p) { o[e] = bb; continue; }
+    const size_t s = tr ? (e % W) * (size_t)W + e / W : e;
+    o[e] = fmaf(aa, p[s], bb);
+  }
+}
+extern "C" int scot_gather_planes(const float* data, const int* traj, const int* tidx, const int* src, const float* a, const float* b,
+                                  const float* planes, float* out, int B, int C, int T, int nsrc, int H, int W, int transpose, hipStream_t s) {
+  if (B <= 0 || C <= 0 || T <= 0 || nsrc <= 0 || H <= 0 || W <= 0) return SCOT_ERR_SHAPE;
+  if (transpose && H != W) return SCOT_ERR_UNSUPPORTED;
+  const size_t plane = (size_t)H * W;
+  unsigned bx = (unsigned)((plane + 1023) / 1024); if (bx == 0) bx = 1;
+  hipLaunchKernelGGL(gather_planes_kernel, dim3(bx, B * C), dim3(256), 0, s, data, traj, tidx, src, a, b, planes, out, B, C, T, nsrc, H, W, transpose);
+  return scot_check_launch();
+}
+
 // ------------------------------------------------------------------ transposed 16-bit weight copies for the data gradients
 // dX = dY · W with W [out, in] row-major is an "NN" product: its B operand is strided along the reduction index, and the MFMA
 // fragments then cost eight 2-byte LDS reads each instead of one 16-byte read (stages 2/3: 1.7–2.2x the time of the forward GEMM of

@@ -10,8 +10,11 @@ What is mirrored (reference `scOT/problems/base.py`, `scOT/problems/fluids/*.py`
   * `get_dataset(name)` — name -> dataset + default time settings (".out" variants: 10 steps), ".tracer" (base.py:15-160);
   * per-dataset sample = channels of one array at t1 / t2, constant planes (incompressible density 1 / pressure 0), per-channel
     (x - mean) / std, a mean-pressure shift, transposition (shear layer), time = (t2 - t1) / T (fluids/incompressible.py:74-160,
-    fluids/compressible.py:56-262).  Covered: the fluids family (NS-*, CE-*, GCE-RT, CE-RM) — the datasets of BASELINE.json's
-    configs; the wave / elliptic / reaction-diffusion / forced-NS / airfoil readers are not restated (ValueError).
+    fluids/compressible.py:56-262).  Covered: every reader of the reference — the fluids family (NS-*, CE-*, GCE-RT, CE-RM: the
+    datasets of BASELINE.json's configs), forced NS (FNS-KF: analytic forcing plane, `just_velocities`), the steady airfoil (SE-AF:
+    element-wise pixel mask), wave (Wave-Layer / Wave-Gauss: a static wave-speed channel passed through to the labels), Allen-Cahn,
+    Poisson and Helmholtz (time-independent; ".time" wraps them with time = 1.0, base.py:372-395).  `...gravity.Blast` is named by
+    the reference's registry but has no reader there (ImportError in the reference): ValueError here.
 The index machinery is pinned against the reference's own base classes (tests/golden/make_dataset_pins.py); the per-dataset
 recipes are restated from the reference's readers, which need h5py to import and are therefore unpinned here (tests compare the
 HIP batch with a numpy evaluation of the recipe).
@@ -106,16 +109,28 @@ class TimePairs:
 # ------------------------------------------------------------------------------------------------ per-dataset recipes
 @dataclass
 class Channel:
-    """One output channel: `(plane - mean) / std` with plane = array channel `src` (minus `shift`) or the constant `const`."""
+    """One output channel: `(plane - mean) / std` with plane = a slice of array `key` (minus `shift`), the constant `const`, or a
+    fixed `plane`.  layout — how array `key` is indexed for trajectory i at time index t:
+      "ntc": arr[i, t, src]   (fluids: [n, T, C, H, W])        "nt": arr[i, t]   ([n, T, H, W]: wave, Allen-Cahn)
+      "n":   arr[i]           ([n, H, W]: static in time)       "nk": arr[i, src] ([n, 2, H, W]: the airfoil's two planes)
+      "s":   arr[i] scalar    (Helmholtz boundary value, broadcast over the plane)"""
     src: Optional[int] = None
     const: float = 0.0
     mean: float = 0.0
     std: float = 1.0
     shift: float = 0.0
+    key: Optional[str] = None          # None: the spec's main array
+    layout: str = "ntc"
+    plane: Optional[np.ndarray] = None  # fixed [H, W] plane (already normalised): KolmogorovFlow's forcing
+
+    def is_array(self) -> bool:
+        return self.plane is None and (self.src is not None or self.layout in ("nt", "n", "s"))
 
     def affine(self) -> Tuple[float, float]:
-        """out = a * x + b   (x = the array value; constant channels: a = 0)"""
-        if self.src is None:
+        """out = a * x + b   (x = the array value / the fixed plane; constant channels: a = 0)"""
+        if self.plane is not None:
+            return 1.0, 0.0
+        if not self.is_array():
             return 0.0, (self.const - self.mean) / self.std
         return 1.0 / self.std, -(self.shift + self.mean) / self.std
 
@@ -135,6 +150,10 @@ class DatasetSpec:
     resolution: int = 128
     transpose: bool = False
     defaults: Dict[str, int] = field(default_factory=lambda: dict(max_num_time_steps=7, time_step_size=2))
+    labels: Optional[List[Channel]] = None     # None: the input recipe evaluated at t2
+    steady: bool = False                       # time-independent: one sample per trajectory, no "time" key (unless ".time"-wrapped)
+    has_pixel_mask: bool = True                # the fluids readers return a per-channel pixel_mask; the others none
+    input_mask_value: Optional[float] = None   # airfoil: pixel_mask = (input == value) element-wise, labels there set to it
 
 
 # reference scOT/problems/fluids/normalization_constants.py (mean / std of [rho, u, v, p], tracer)
@@ -160,7 +179,7 @@ def _compressible(file: str, mean_pressure: float) -> DatasetSpec:
     return DatasetSpec(file, "data", 10000, 120, 240, ch, "[rho],[u,v],[p]", [False] * 4, _NS["time"], 20)
 
 
-def _spec(name: str) -> Tuple[DatasetSpec, Dict[str, int]]:
+def _spec(name: str, just_velocities: bool = False) -> Tuple[DatasetSpec, Dict[str, int]]:
     """name -> (recipe, default time settings)   (reference base.py:15-160)"""
     tracer = "tracer" in name
     out = "out" in name          # (the reference tests the substring, base.py:80,118)
@@ -175,9 +194,20 @@ def _spec(name: str) -> Tuple[DatasetSpec, Dict[str, int]]:
                 spec = _incompressible(file, n_max, tracer, transpose=key == "ShearLayer")
                 break
         else:
-            raise ValueError(f"Unknown dataset {name}")
+            if "forcing" in name and "KolmogorovFlow" in name:
+                if tracer:
+                    raise ValueError("KolmogorovFlow does not have a tracer")
+                spec = _kolmogorov(just_velocities)
+            else:
+                raise ValueError(f"Unknown dataset {name}")
         dflt = dict(max_num_time_steps=10 if out else 7, time_step_size=2)
     elif "fluids.compressible" in name:
+        if "gravity" in name and "Blast" in name:
+            raise ValueError(f"{name}: the reference's registry names fluids.compressible.Blast but ships no such reader")
+        if "steady" in name:
+            if "steady.Airfoil" not in name or out:
+                raise ValueError(f"Unknown dataset {name}")
+            return _airfoil(), dict(max_num_time_steps=1, time_step_size=1)
         if "gravity" in name and "RayleighTaylor" in name:
             # fluids/compressible.py:114-188: channels 0:4 and 5 (gravitational potential) of `solution`
             mean = [0.8970493, 4.0316996e-13, -1.3858967e-13, 0.7133829, -1.7055787]
@@ -203,9 +233,78 @@ def _spec(name: str) -> Tuple[DatasetSpec, Dict[str, int]]:
             else:
                 raise ValueError(f"Unknown dataset {name}")
             dflt = dict(max_num_time_steps=10 if out else 7, time_step_size=2)
+    elif "elliptic" in name:
+        if ".out" in name:
+            raise NotImplementedError(f"Unknown dataset {name}")
+        if "elliptic.poisson" in name:
+            if "Gaussians" not in name:
+                raise ValueError(f"Unknown dataset {name}")
+            # elliptic/poisson.py:15-50
+            spec = DatasetSpec("/Poisson-Gauss.nc", "source", 20000, 120, 240,
+                               [Channel(key="source", layout="n", mean=0.014822142414492256, std=4.755138816607612)], "[u]", [False], 1.0, 0,
+                               labels=[Channel(key="solution", layout="n", mean=0.0005603458434937093, std=0.02401226126952699)],
+                               steady=True, has_pixel_mask=False)
+        elif "elliptic.Helmholtz" in name:
+            # elliptic/helmholtz.py:9-49: inputs [a - 1, bc·1], labels (u - mean) / std; per-sample groups "Sample_<i>" in the file
+            spec = DatasetSpec("/Helmholtz.h5", "a", 19675, 128, 512,
+                               [Channel(key="a", layout="n", shift=1.0), Channel(key="bc", layout="s")], "[u]", [False], 1.0, 0,
+                               labels=[Channel(key="u", layout="n", mean=0.11523915668552, std=0.8279975746000605)],
+                               steady=True, has_pixel_mask=False)
+        else:
+            raise ValueError(f"Unknown dataset {name}")
+        dflt = dict(max_num_time_steps=1, time_step_size=1)
+    elif "wave" in name:
+        # wave/acoustic.py:6-125: [u(t), c] -> [u(t'), c]; the wave speed c is static and is ALSO the second label channel
+        if "wave.Layer" in name:
+            k = dict(mean=0.03467443221585092, std=0.10442421752963911, mean_c=3498.5644380917424, std_c=647.843958567462, time=20.0)
+            file, steps = "/Wave-Layer.nc", 10 if out else 7
+        elif "wave.Gaussians" in name:
+            if out:
+                raise ValueError(f"Unknown dataset {name}")
+            k = dict(mean=0.0334376316, std=0.1171879068, mean_c=2618.4593933, std_c=601.51658913, time=15.0)
+            file, steps = "/Wave-Gauss.nc", 7
+        else:
+            raise ValueError(f"Unknown dataset {name}")
+        ch = [Channel(key="solution", layout="nt", mean=k["mean"], std=k["std"]), Channel(key="c", layout="n", mean=k["mean_c"], std=k["std_c"])]
+        spec = DatasetSpec(file, "solution", 10512, 60, 240, ch, "[u],[c]", [False, False], k["time"], int(k["time"]), has_pixel_mask=False)
+        dflt = dict(max_num_time_steps=steps, time_step_size=2)
+    elif "reaction_diffusion" in name:
+        if "reaction_diffusion.AllenCahn" not in name:
+            raise ValueError(f"Unknown dataset {name}")   # (the reference falls through to an UnboundLocalError here)
+        # reaction_diffusion/allen_cahn.py:6-53
+        spec = DatasetSpec("/ACE.nc", "solution", 15000, 60, 240, [Channel(key="solution", layout="nt", mean=0.002484262, std=0.65351176)],
+                           "[u]", [False], 19.0, 19, has_pixel_mask=False)
+        dflt = dict(max_num_time_steps=9 if out else 7, time_step_size=2)
     else:
-        raise ValueError(f"Unknown dataset {name} (this front-end restates the fluids family only)")
+        raise ValueError(f"Unknown dataset {name}")
     return spec, dflt
+
+
+def _kolmogorov(just_velocities: bool) -> DatasetSpec:
+    """fluids/incompressible.py:149-243: forced NS — velocity from `solution`, density 1 / pressure 0 planes, and the (fixed,
+    normalised) forcing 0.1 sin(2 pi (x + y)) on linspace(0, 1, 128)^2 as an extra channel of inputs AND labels."""
+    m, s = list(_NS["mean"]), list(_NS["std"])
+    m[1], m[2], s[1], s[2] = -2.2424793e-13, 4.1510376e-12, 0.22017328, 0.22078253
+    R = 128
+    xs = np.linspace(0.0, 1.0, R, dtype=np.float32)          # (torch.linspace(0, 1, R) in fp32)
+    X, Y = np.meshgrid(xs, xs, indexing="ij")
+    f = (np.float32(0.1) * np.sin(np.float32(2.0 * np.pi) * (X + Y))).astype(np.float32)
+    forcing = ((f - np.float32(-1.2996679288335145e-09)) / np.float32(0.0707106739282608)).astype(np.float32)
+    vel = [Channel(src=0, key="solution", mean=m[1], std=s[1]), Channel(src=1, key="solution", mean=m[2], std=s[2])]
+    if just_velocities:
+        ch, desc, mask = vel + [Channel(plane=forcing)], "[u,v],[g]", [False, False, False]
+    else:
+        ch = [Channel(const=1.0, mean=m[0], std=s[0])] + vel + [Channel(const=0.0, mean=m[3], std=s[3]), Channel(plane=forcing)]
+        desc, mask = "[rho],[u,v],[p],[g]", [False, False, False, True, False]
+    return DatasetSpec("/FNS-KF.nc", "solution", 20000, 120, 240, ch, desc, mask, _NS["time"], 20)
+
+
+def _airfoil() -> DatasetSpec:
+    """fluids/compressible.py:8-53: steady flow around an airfoil — input = plane 0 of `solution` (1 inside the body), label =
+    plane 1 normalised; pixel_mask = (input == 1) element-wise and the label is set to 1 there."""
+    return DatasetSpec("/SE-AF.nc", "solution", 10869, 120, 240, [Channel(src=0, key="solution", layout="nk")], "[rho]", [False], 1.0, 0,
+                       labels=[Channel(src=1, key="solution", layout="nk", mean=0.92984116, std=0.10864315)], steady=True,
+                       has_pixel_mask=False, input_mask_value=1.0)
 
 
 def open_reader(path: str):
@@ -220,99 +319,235 @@ def open_reader(path: str):
     return h5py.File(path, "r")
 
 
+class _SampleGroups:
+    """The Helmholtz file keeps one group per sample ("Sample_<i>" with datasets a, bc, u: elliptic/helmholtz.py:33-45); this view
+    indexes it like the other readers: view[key][i]."""
+
+    class _Key:
+        def __init__(self, reader, key):
+            self.reader, self.key = reader, key
+
+        def __getitem__(self, i):
+            return np.asarray(self.reader["Sample_" + str(int(i))][self.key])
+
+    def __init__(self, reader):
+        self.reader = reader
+
+    def __getitem__(self, key):
+        return _SampleGroups._Key(self.reader, key)
+
+
+def _downsample(image: torch.Tensor, target: int) -> torch.Tensor:
+    """the readers' own spectral downsampling (fluids/incompressible.py:75-83; the twin of ScOT._downsample), CPU path"""
+    image = image.unsqueeze(0)
+    n = image.shape[-2]
+    freqs = torch.fft.fftfreq(n, d=1 / n)
+    sel = torch.logical_and(freqs >= -target / 2, freqs <= target / 2 - 1)
+    hat = torch.fft.fft2(image, norm="forward")[:, :, sel, :][:, :, :, sel]
+    return torch.fft.ifft2(hat, norm="forward").real.squeeze(0)
+
+
 # ------------------------------------------------------------------------------------------------ datasets
 class PDEDataset(torch.utils.data.Dataset):
-    """A time-dependent fluids dataset with the reference's sample dict; `to_device()` gives the HBM-resident twin."""
+    """One dataset of the reference's registry with the reference's sample dict; `to_device()` gives the HBM-resident twin."""
 
     def __init__(self, name: str, which: str = "train", num_trajectories: int = -1, data_path: str = "./data", reader=None,
                  max_num_time_steps: Optional[int] = None, time_step_size: Optional[int] = None,
                  fix_input_to_time_step: Optional[int] = None, allowed_time_transitions: Optional[Sequence[int]] = None,
-                 n_max: Optional[int] = None, n_val: Optional[int] = None, n_test: Optional[int] = None, **_):
-        spec, dflt = _spec(name)
+                 n_max: Optional[int] = None, n_val: Optional[int] = None, n_test: Optional[int] = None,
+                 just_velocities: bool = False, resolution: Optional[int] = None, **_):
+        spec, dflt = _spec(name, just_velocities)
+        if just_velocities:
+            if "fluids.incompressible" not in name:
+                raise TypeError("just_velocities is an option of the incompressible readers")
+            if "KolmogorovFlow" not in name:     # fluids/incompressible.py:44-63: drop the constant density / pressure planes
+                keep = [k for k, c in enumerate(spec.channels) if c.is_array()]
+                spec.channels = [spec.channels[k] for k in keep]
+                spec.pixel_mask = [False] * len(keep)
+                spec.label_description = "[u,v]" + (",[tracer]" if "tracer" in name else "")
+        if resolution is not None:
+            if "fluids.incompressible" not in name or "KolmogorovFlow" in name:
+                raise TypeError("resolution is an option of the incompressible readers")
+            if resolution > 128:
+                raise ValueError("Resolution must be <= 128")
+        self.res = resolution
         self.name, self.spec, self.which = name, spec, which
-        steps = max_num_time_steps if max_num_time_steps is not None else dflt["max_num_time_steps"]
-        dt = time_step_size if time_step_size is not None else dflt["time_step_size"]
-        if steps * dt > spec.max_time_index:
-            raise ValueError(f"max_num_time_steps * time_step_size must be <= {spec.max_time_index} for {name}")
-        self.pairs = TimePairs(steps, dt, fix_input_to_time_step, allowed_time_transitions)
+        self.time_wrapped = spec.steady and ".time" in name          # base.py:372-395: time = 1.0
+        self.steady = spec.steady
+        if spec.steady:
+            self.pairs = TimePairs(1, 1)
+            self.pairs.multiplier = 1
+        else:
+            steps = max_num_time_steps if max_num_time_steps is not None else dflt["max_num_time_steps"]
+            dt = time_step_size if time_step_size is not None else dflt["time_step_size"]
+            if steps * dt > spec.max_time_index:
+                raise ValueError(f"max_num_time_steps * time_step_size must be <= {spec.max_time_index} for {name}")
+            self.pairs = TimePairs(steps, dt, fix_input_to_time_step, allowed_time_transitions)
         # (n_max / n_val / n_test overrides: subsets of a dataset, e.g. for tests; defaults = the reference's sizes)
         self.n_max, self.n_val, self.n_test = n_max or spec.n_max, n_val or spec.n_val, n_test or spec.n_test
         self.trajectories, self.start, self.num_trajectories = resolve_split(which, num_trajectories, self.n_max, self.n_val, self.n_test)
         self.length = self.trajectories * self.pairs.multiplier
         self.resolution = spec.resolution
         self.input_dim = len(spec.channels)
+        self.label_channels = spec.labels if spec.labels is not None else spec.channels
         self.label_description = spec.label_description
         self.output_dim = spec.label_description.count(",") + 1
         self.printable_channel_description, self.channel_slice_list = channel_lists(spec.label_description)
-        self.pixel_mask = torch.tensor(spec.pixel_mask)
+        self.pixel_mask = torch.tensor(spec.pixel_mask) if spec.has_pixel_mask else None
         self.reader = reader if reader is not None else open_reader(os.path.join(data_path, spec.file.lstrip("/")))
+        if "Helmholtz" in name and "a" not in getattr(self.reader, "keys", lambda: [])():
+            self.reader = _SampleGroups(self.reader)
 
     def __len__(self) -> int:
         return self.length
 
-    def _planes(self, i: int, t: int) -> torch.Tensor:
-        arr = self.reader[self.spec.key]
-        out = []
-        for c in self.spec.channels:
-            if c.src is None:
-                x = torch.full((self.resolution, self.resolution), float(c.const), dtype=torch.float32)
-            else:
-                x = torch.from_numpy(np.asarray(arr[i + self.start, t, c.src:c.src + 1])).type(torch.float32)
-                x = x.reshape(self.resolution, self.resolution)
-                if self.spec.transpose:
-                    x = x.transpose(-2, -1)
-                if c.shift:
-                    x = x - c.shift
-            out.append((x - c.mean) / c.std)
-        return torch.stack(out, 0)
+    def _plane(self, c: Channel, i: int, t: Optional[int]) -> torch.Tensor:
+        R = self.resolution
+        if c.plane is not None:
+            return torch.from_numpy(np.asarray(c.plane, dtype=np.float32))
+        if not c.is_array():
+            return (torch.full((R, R), float(c.const), dtype=torch.float32) - c.mean) / c.std
+        arr = self.reader[c.key or self.spec.key]
+        j = i + self.start
+        if c.layout == "ntc":
+            x = arr[j, t, c.src:c.src + 1]
+        elif c.layout == "nt":
+            x = arr[j, t]
+        elif c.layout == "nk":
+            x = arr[j, c.src]
+        elif c.layout == "n":
+            x = arr[j]
+        else:   # "s": one number per sample
+            x = np.full((R, R), float(np.asarray(arr[j])), dtype=np.float32)
+        x = torch.from_numpy(np.asarray(x)).type(torch.float32).reshape(R, R)
+        if self.spec.transpose:
+            x = x.transpose(-2, -1)
+        if c.shift:
+            x = x - c.shift
+        return (x - c.mean) / c.std
+
+    def _planes(self, channels, i: int, t: Optional[int]) -> torch.Tensor:
+        return torch.stack([self._plane(c, i, t) for c in channels], 0)
 
     def __getitem__(self, idx: int) -> Dict:
+        if self.steady:
+            pv, lab = self._planes(self.spec.channels, idx, None), self._planes(self.label_channels, idx, None)
+            out = {"pixel_values": pv, "labels": lab}
+            if self.spec.input_mask_value is not None:      # airfoil: element-wise mask (1, H, W); the label is 1 inside the body
+                mask = pv == self.spec.input_mask_value
+                lab[mask] = self.spec.input_mask_value
+                out["pixel_mask"] = mask
+            if self.time_wrapped:
+                out["time"] = 1.0
+            return out
         i, t, t1, t2 = self.pairs(idx)
-        return {"pixel_values": self._planes(i, t1), "labels": self._planes(i, t2), "time": t / self.spec.time_const,
-                "pixel_mask": self.pixel_mask}
+        pv, lab = self._planes(self.spec.channels, i, t1), self._planes(self.label_channels, i, t2)
+        if self.res is not None:
+            pv, lab = _downsample(pv, self.res), _downsample(lab, self.res)
+        out = {"pixel_values": pv, "labels": lab, "time": t / self.spec.time_const}
+        if self.pixel_mask is not None:
+            out["pixel_mask"] = self.pixel_mask
+        return out
 
     def to_device(self, device="cuda", trajectories: Optional[int] = None) -> "DeviceTrajectories":
         return DeviceTrajectories(self, device, trajectories)
 
 
 class DeviceTrajectories:
-    """This split's trajectories resident in HBM; `batch(indices)` -> the collated dict of a reference batch in one launch."""
+    """This split's trajectories resident in HBM; `batch(indices)` -> the collated dict of a reference batch in one launch (two when
+    inputs and labels follow different recipes).  Every array a recipe reads becomes a source plane of ONE resident tensor
+    data[n, T, nsrc, H, W] (planes that are static in time are repeated along T; steady datasets have T = 1)."""
 
     def __init__(self, ds: PDEDataset, device="cuda", trajectories: Optional[int] = None):
         self.ds = ds
+        spec = ds.spec
         n = ds.trajectories if trajectories is None else min(trajectories, ds.trajectories)
-        arr = ds.reader[ds.spec.key]
-        self.nsrc = max(c.src for c in ds.spec.channels if c.src is not None) + 1
-        host = np.ascontiguousarray(np.asarray(arr[ds.start:ds.start + n, :, 0:self.nsrc], dtype=np.float32))
-        self.data = torch.from_numpy(host).to(device)                       # [n, T, nsrc, H, W]
-        self.n, self.T = n, host.shape[1]
-        ab = [c.affine() for c in ds.spec.channels]
-        self.src = torch.tensor([-1 if c.src is None else c.src for c in ds.spec.channels], dtype=torch.int32, device=device)
-        self.a = torch.tensor([x[0] for x in ab], dtype=torch.float32, device=device)
-        self.b = torch.tensor([x[1] for x in ab], dtype=torch.float32, device=device)
-        self.pixel_mask = ds.pixel_mask.to(device)
+        R = ds.resolution
+        main = ds.reader[spec.key]
+        self.T = 1 if spec.steady else int(np.asarray(main[ds.start]).shape[0])
+        sources, planes = [], []
+
+        def source_of(c: Channel) -> int:
+            if c.plane is not None:
+                planes.append(np.asarray(c.plane, dtype=np.float32))
+                return -1 - len(planes)                   # -2 - p: fixed plane p
+            if not c.is_array():
+                return -1
+            k = (c.key or spec.key, c.layout, c.src if c.layout in ("ntc", "nk") else None)
+            if k not in sources:
+                sources.append(k)
+            return sources.index(k)
+        self.symmetric = spec.labels is None
+        src_in = [source_of(c) for c in spec.channels]
+        src_lab = src_in if self.symmetric else [source_of(c) for c in ds.label_channels]
+        self.nsrc = max(1, len(sources))
+        host = np.zeros((n, self.T, self.nsrc, R, R), dtype=np.float32)
+        for q, (key, layout, src) in enumerate(sources):
+            arr = ds.reader[key]
+            if layout == "ntc":
+                host[:, :, q] = np.asarray(arr[ds.start:ds.start + n, :, src], dtype=np.float32).reshape(n, self.T, R, R)
+            elif layout == "nt":
+                host[:, :, q] = np.asarray(arr[ds.start:ds.start + n], dtype=np.float32).reshape(n, self.T, R, R)
+            else:
+                for j in range(n):
+                    x = arr[ds.start + j, src] if layout == "nk" else arr[ds.start + j]
+                    host[j, :, q] = np.asarray(x, dtype=np.float32).reshape((1, 1) if layout == "s" else (R, R))
+        self.data = torch.from_numpy(host).to(device)
+        self.n = n
+        self.planes = torch.from_numpy(np.stack(planes)).to(device) if planes else None
+
+        def recipe(channels, srcs):
+            ab = [c.affine() for c in channels]
+            return (torch.tensor(srcs, dtype=torch.int32, device=device), torch.tensor([x[0] for x in ab], dtype=torch.float32, device=device),
+                    torch.tensor([x[1] for x in ab], dtype=torch.float32, device=device))
+        self.rin = recipe(spec.channels, src_in)
+        self.rlab = self.rin if self.symmetric else recipe(ds.label_channels, src_lab)
+        self.pixel_mask = ds.pixel_mask.to(device) if ds.pixel_mask is not None else None
 
     def __len__(self) -> int:
         return self.n * self.ds.pairs.multiplier
 
     def batch(self, indices) -> Dict[str, torch.Tensor]:
         from . import ops
+        ds = self.ds
         idx = np.asarray(indices, dtype=np.int64)
-        i, t1, t2 = self.ds.pairs.arrays(idx)
+        if ds.steady:
+            i, t1, t2 = idx, np.zeros_like(idx), np.zeros_like(idx)
+        else:
+            i, t1, t2 = ds.pairs.arrays(idx)
         if idx.size == 0 or i.max() >= self.n or t2.max() >= self.T:
             raise IndexError("sample index outside the resident trajectories")
         dev = self.data.device
         it = torch.from_numpy(np.stack([i, t1, t2], 0).astype(np.int32)).to(dev)
-        B, C, R = idx.size, len(self.ds.spec.channels), self.ds.resolution
-        pv = torch.empty(B, C, R, R, dtype=torch.float32, device=dev)
-        lab = torch.empty_like(pv)
-        ops.gather_pairs(self.data, it, self.src, self.a, self.b, pv, lab, self.T, self.nsrc, R, R, bool(self.ds.spec.transpose))
-        time = torch.from_numpy(((t2 - t1) / self.ds.spec.time_const).astype(np.float32)).to(dev)
-        return {"pixel_values": pv, "labels": lab, "time": time, "pixel_mask": self.pixel_mask.unsqueeze(0).expand(B, -1)}
+        B, R = idx.size, ds.resolution
+        pv = torch.empty(B, len(ds.spec.channels), R, R, dtype=torch.float32, device=dev)
+        lab = torch.empty(B, len(ds.label_channels), R, R, dtype=torch.float32, device=dev)
+        tr = bool(ds.spec.transpose)
+        if self.symmetric and self.planes is None:
+            ops.gather_pairs(self.data, it, *self.rin, pv, lab, self.T, self.nsrc, R, R, tr)
+        else:
+            ops.gather_planes(self.data, it[0], it[1], *self.rin, self.planes, pv, self.T, self.nsrc, R, R, tr)
+            ops.gather_planes(self.data, it[0], it[2], *self.rlab, self.planes, lab, self.T, self.nsrc, R, R, tr)
+        out = {"pixel_values": pv, "labels": lab}
+        if ds.spec.input_mask_value is not None:
+            mask = pv == ds.spec.input_mask_value
+            lab.masked_fill_(mask, ds.spec.input_mask_value)
+            out["pixel_mask"] = mask
+        if not ds.steady:
+            if ds.res is not None:
+                from scOT.model import spectral_resize
+                out["pixel_values"], out["labels"] = spectral_resize(pv, ds.res), spectral_resize(lab, ds.res)
+            out["time"] = torch.from_numpy(((t2 - t1) / ds.spec.time_const).astype(np.float32)).to(dev)
+        elif ds.time_wrapped:
+            out["time"] = torch.ones(B, dtype=torch.float32, device=dev)
+        if self.pixel_mask is not None:
+            out["pixel_mask"] = self.pixel_mask.unsqueeze(0).expand(B, -1)
+        return out
 
 
 def get_dataset(dataset, **kwargs):
-    """reference `get_dataset` (base.py:15-160) for the fluids family; a list of names -> torch ConcatDataset."""
+    """reference `get_dataset` (base.py:15-160): name -> dataset (".out": more time steps, ".tracer", ".time": a time-independent
+    dataset with time = 1.0); a list of names -> torch ConcatDataset."""
     if isinstance(dataset, (list, tuple)):
         return torch.utils.data.ConcatDataset([get_dataset(d, **kwargs) for d in dataset])
     return PDEDataset(dataset, **kwargs)

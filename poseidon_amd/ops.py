@@ -333,6 +333,14 @@ def gather_pairs(data, it, src, a, b, pv, lab, T, nsrc, H, W, transpose):
                                      int(transpose), stream()), "scot_gather_pairs")
 
 
+def gather_planes(data, traj, tidx, src, a, b, planes, out, T, nsrc, H, W, transpose):
+    """One tensor of a batch from HBM-resident trajectories with its own recipe (poseidon_amd/data.py): traj / tidx int32 [B], src int32
+    [C] (-1: constant plane, -2 - p: fixed plane p of `planes` [P, H, W]), a / b fp32 [C]; writes out [B, C, H, W]."""
+    B, C = out.shape[0], out.shape[1]
+    _lib.check(L().scot_gather_planes(ptr(data), ptr(traj), ptr(tidx), ptr(src), ptr(a), ptr(b), ptr(planes), ptr(out), B, C, T, nsrc,
+                                      H, W, int(transpose), stream()), "scot_gather_planes")
+
+
 def mask_tokens(x, mask_u8, token, rows, C):
     """x[r, :] = token where mask_u8[r] (in place; reference model.py:353-359)."""
     _lib.check(L().scot_mask_tokens(ptr(x), ptr(mask_u8), ptr(token), rows, C, stream()), "scot_mask_tokens")

@@ -1,3 +1,3 @@
-"""scOT.problems.base — the reference module's import path (reference scOT/problems/base.py:15) for the dataset selector of the
-fluids family; implementation and the HBM-resident batch assembly: poseidon_amd/data.py."""
+"""scOT.problems.base — the reference module's import path (reference scOT/problems/base.py:15) for the dataset selector (every reader
+of the reference's registry); implementation and the HBM-resident batch assembly: poseidon_amd/data.py."""
 from poseidon_amd.data import DeviceTrajectories, PDEDataset, TimePairs, channel_lists, get_dataset, resolve_split  # noqa: F401

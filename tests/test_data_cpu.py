@@ -70,8 +70,108 @@ def test_incompressible_recipe_and_defaults():
     assert np.allclose(sl[3]["pixel_values"][1].numpy(), (v[i + 5, t1, 0].T - 0.0) / 0.391, rtol=1e-6, atol=1e-6)
     with pytest.raises(ValueError):
         _mk("fluids.incompressible.Gaussians.tracer", rd)
+    # just_velocities (incompressible.py:44-63): the two velocity channels only, "[u,v]", mask [F, F]
+    jv = _mk("fluids.incompressible.Sines", rd, just_velocities=True)
+    i, t, t1, t2 = jv.pairs(7)
+    assert jv.input_dim == 2 and jv.channel_slice_list == [0, 2] and jv.pixel_mask.tolist() == [False, False]
+    assert np.allclose(jv[7]["labels"].numpy(), v[i + 5, t2, 0:2] / np.array([0.391, 0.356])[:, None, None], rtol=1e-6, atol=1e-6)
     with pytest.raises(ValueError):
-        _mk("wave.Layer", rd)
+        _mk("fluids.compressible.gravity.Blast", rd)      # named by the reference's registry, but no such reader exists there
+    with pytest.raises(ValueError):
+        _mk("nonsense.Dataset", rd)
+
+
+def test_incompressible_resolution_option():
+    """`resolution=` (incompressible.py:66-83, 141-143): samples spectrally downsampled by the readers' own fft2 -> crop -> ifft2."""
+    rng = np.random.default_rng(3)
+    rd = {"velocity": rng.standard_normal((12, 21, 2, 128, 128)).astype(np.float32)}
+    ds = D.get_dataset("fluids.incompressible.Sines", which="val", num_trajectories=3, reader=rd, n_max=12, n_val=4, n_test=3, resolution=64)
+    s = ds[5]
+    assert s["pixel_values"].shape == (4, 64, 64) and s["labels"].shape == (4, 64, 64)
+    i, t, t1, t2 = ds.pairs(5)
+    full = torch.from_numpy(rd["velocity"][i + 5, t1, 0]) / 0.391
+    assert float(s["pixel_values"][1].mean()) == pytest.approx(float(full.mean()), abs=1e-6)      # the mean (k = 0) survives the crop
+    assert float(s["pixel_values"][0].std()) < 1e-6                                                 # a constant plane stays constant
+    with pytest.raises(ValueError):
+        D.get_dataset("fluids.incompressible.Sines", which="val", num_trajectories=3, reader=rd, n_max=12, n_val=4, n_test=3, resolution=256)
+
+
+def test_forced_and_steady_fluids_recipes():
+    """fluids/incompressible.py:149-243 (KolmogorovFlow: own velocity constants, analytic forcing channel in inputs AND labels) and
+    fluids/compressible.py:8-53 (Airfoil: element-wise mask, label 1 inside the body, no time)."""
+    rng = np.random.default_rng(4)
+    rd = {"solution": rng.standard_normal((12, 21, 2, 128, 128)).astype(np.float32)}
+    kw = dict(which="val", num_trajectories=3, n_max=12, n_val=4, n_test=3)
+    ds = D.get_dataset("fluids.incompressible.forcing.KolmogorovFlow", reader=rd, **kw)
+    assert ds.channel_slice_list == [0, 1, 3, 4, 5] and ds.pixel_mask.tolist() == [False, False, False, True, False] and ds.input_dim == 5
+    i, t, t1, t2 = ds.pairs(40)
+    s = ds[40]
+    xs = torch.linspace(0, 1, 128)
+    X, Y = torch.meshgrid(xs, xs, indexing="ij")
+    forcing = ((0.1 * torch.sin(2.0 * np.pi * (X + Y))) - (-1.2996679288335145e-09)) / 0.0707106739282608
+    assert np.allclose(s["pixel_values"][4].numpy(), forcing.numpy(), atol=2e-6) and torch.equal(s["labels"][4], s["pixel_values"][4])
+    assert np.allclose(s["labels"][1].numpy(), (rd["solution"][i + 5, t2, 0] - (-2.2424793e-13)) / 0.22017328, rtol=1e-6, atol=1e-6)
+    assert np.allclose(s["labels"][2].numpy(), (rd["solution"][i + 5, t2, 1] - 4.1510376e-12) / 0.22078253, rtol=1e-6, atol=1e-6)
+    assert np.allclose(s["pixel_values"][0].numpy(), (1 - 0.80) / 0.31) and s["time"] == pytest.approx(t / 20.0)
+    jv = D.get_dataset("fluids.incompressible.forcing.KolmogorovFlow", reader=rd, just_velocities=True, **kw)
+    assert jv.label_description == "[u,v],[g]" and jv.input_dim == 3 and jv.pixel_mask.tolist() == [False, False, False]
+    body = (rng.random((12, 1, 128, 128)) > 0.7).astype(np.float32)
+    af = D.get_dataset("fluids.compressible.steady.Airfoil", reader={"solution": np.concatenate([body, rng.standard_normal((12, 1, 128, 128)).astype(np.float32)], 1)}, **kw)
+    s = af[2]
+    assert len(af) == 4 and set(s) == {"pixel_values", "labels", "pixel_mask"} and s["pixel_mask"].shape == (1, 128, 128)
+    want = (af.reader["solution"][2 + 5, 1] - 0.92984116) / 0.10864315
+    want = np.where(body[2 + 5, 0] == 1, 1.0, want)
+    assert np.array_equal(s["pixel_values"][0].numpy(), body[2 + 5, 0]) and np.allclose(s["labels"][0].numpy(), want, rtol=1e-6, atol=1e-6)
+    with pytest.raises(ValueError):
+        D.get_dataset("fluids.compressible.steady.Airfoil.out", reader={"solution": body}, **kw)
+
+
+def test_wave_reaction_diffusion_and_elliptic_recipes():
+    """wave/acoustic.py (static wave speed c is input channel 1 AND label channel 1), reaction_diffusion/allen_cahn.py, elliptic/poisson.py,
+    elliptic/helmholtz.py (inputs [a - 1, bc], per-sample groups), `.time` wrapper (base.py:372-395), defaults of base.py:121-157."""
+    rng = np.random.default_rng(5)
+    R, kw = 16, dict(which="val", num_trajectories=3, n_max=12, n_val=4, n_test=3)
+
+    def mk(name, reader, **k2):
+        ds = D.get_dataset(name, reader=reader, **kw, **k2)
+        ds.resolution = R
+        return ds
+    wave = {"solution": rng.standard_normal((12, 21, R, R)).astype(np.float32), "c": (3000 + 500 * rng.standard_normal((12, R, R))).astype(np.float32)}
+    ds = mk("wave.Layer", wave)
+    i, t, t1, t2 = ds.pairs(50)
+    s = ds[50]
+    assert set(s) == {"pixel_values", "labels", "time"} and ds.channel_slice_list == [0, 1, 2] and ds.output_dim == 2
+    c = (wave["c"][i + 5] - 3498.5644380917424) / 647.843958567462
+    assert np.allclose(s["pixel_values"][0].numpy(), (wave["solution"][i + 5, t1] - 0.03467443221585092) / 0.10442421752963911, rtol=1e-6, atol=1e-6)
+    assert np.allclose(s["labels"][0].numpy(), (wave["solution"][i + 5, t2] - 0.03467443221585092) / 0.10442421752963911, rtol=1e-6, atol=1e-6)
+    assert np.allclose(s["pixel_values"][1].numpy(), c, rtol=1e-5, atol=1e-5) and torch.equal(s["labels"][1], s["pixel_values"][1])
+    assert s["time"] == pytest.approx(t / 20.0) and mk("wave.Layer.out", wave).pairs.max_num_time_steps == 10
+    g = mk("wave.Gaussians", wave)
+    assert g.spec.time_const == 15.0 and g.spec.channels[1].mean == 2618.4593933 and g.spec.file == "/Wave-Gauss.nc"
+    with pytest.raises(ValueError):
+        mk("wave.Gaussians.out", wave)
+    with pytest.raises(ValueError):
+        mk("wave.Gaussians", wave, max_num_time_steps=8, time_step_size=2)     # 16 > 15 (acoustic.py:69)
+    ac = mk("reaction_diffusion.AllenCahn", {"solution": wave["solution"][:, :20]})
+    i, t, t1, t2 = ac.pairs(9)
+    assert np.allclose(ac[9]["labels"][0].numpy(), (wave["solution"][i + 5, t2] - 0.002484262) / 0.65351176, rtol=1e-6, atol=1e-6)
+    assert ac[9]["time"] == pytest.approx(t / 19.0) and mk("reaction_diffusion.AllenCahn.out", {"solution": wave["solution"]}).pairs.max_num_time_steps == 9
+    po = mk("elliptic.poisson.Gaussians", {"source": wave["c"], "solution": wave["solution"][:, 0]})
+    s = po[1]
+    assert len(po) == 4 and set(s) == {"pixel_values", "labels"}
+    assert np.allclose(s["pixel_values"][0].numpy(), (wave["c"][1 + 5] - 0.014822142414492256) / 4.755138816607612, rtol=1e-6, atol=1e-6)
+    assert np.allclose(s["labels"][0].numpy(), (wave["solution"][1 + 5, 0] - 0.0005603458434937093) / 0.02401226126952699, rtol=1e-6, atol=1e-6)
+    assert mk("elliptic.poisson.Gaussians.time", {"source": wave["c"], "solution": wave["solution"][:, 0]})[1]["time"] == 1.0
+    bc = rng.standard_normal(12).astype(np.float32)
+    groups = {f"Sample_{j}": {"a": wave["c"][j], "bc": np.float32(bc[j]), "u": wave["solution"][j, 3]} for j in range(12)}   # the file's layout
+    for reader in (groups, {"a": wave["c"], "bc": bc, "u": wave["solution"][:, 3]}):
+        he = mk("elliptic.Helmholtz.time", reader)
+        s = he[2]
+        assert np.allclose(s["pixel_values"][0].numpy(), wave["c"][2 + 5] - 1, rtol=1e-6) and np.allclose(s["pixel_values"][1].numpy(), bc[2 + 5])
+        assert np.allclose(s["labels"][0].numpy(), (wave["solution"][2 + 5, 3] - 0.11523915668552) / 0.8279975746000605, rtol=1e-6, atol=1e-6)
+        assert s["time"] == 1.0 and he.input_dim == 2 and he.output_dim == 1
+    with pytest.raises(NotImplementedError):
+        mk("elliptic.Helmholtz.out", groups)
 
 
 def test_compressible_recipes():
@@ -91,6 +191,49 @@ def test_compressible_recipes():
     assert [c.src for c in rt.spec.channels] == [0, 1, 2, 3, 5]
     with pytest.raises(ValueError):
         _mk("fluids.compressible.gravity.RayleighTaylor", _fake("solution", 12, 11, 6), max_num_time_steps=6, time_step_size=2)
+
+
+def _family_reader(name, R):
+    rng = np.random.default_rng(11)
+    f = lambda *s: rng.standard_normal(s).astype(np.float32)
+    if name.startswith("wave"):
+        return {"solution": f(12, 21, R, R), "c": f(12, R, R)}
+    if "AllenCahn" in name:
+        return {"solution": f(12, 20, R, R)}
+    if "poisson" in name:
+        return {"source": f(12, R, R), "solution": f(12, R, R)}
+    if "Helmholtz" in name:
+        return {"a": f(12, R, R), "bc": f(12), "u": f(12, R, R)}
+    if "Airfoil" in name:
+        return {"solution": np.concatenate([(rng.random((12, 1, R, R)) > 0.6).astype(np.float32), f(12, 1, R, R)], 1)}
+    return {"solution": f(12, 21, 2, R, R)}
+
+
+@pytest.mark.parametrize("name", ["wave.Layer", "reaction_diffusion.AllenCahn", "elliptic.poisson.Gaussians", "elliptic.Helmholtz.time",
+                                  "fluids.compressible.steady.Airfoil", "fluids.incompressible.forcing.KolmogorovFlow"])
+def test_device_batch_matches_getitem_other_families(name, monkeypatch):
+    """DeviceTrajectories.batch through scot_gather_planes (one launch per tensor: inputs and labels follow different recipes, static
+    / analytic / scalar source planes) == the collated __getitem__ samples, for every non-fluids family."""
+    sys.path.insert(0, os.path.join(HERE, "hipemu"))
+    import emu_session
+    emu_session.patch_ops(monkeypatch, emu_session.load_emu())
+    R = 128 if "Kolmogorov" in name else 16
+    ds = D.get_dataset(name, which="val", num_trajectories=3, reader=_family_reader(name, R), n_max=12, n_val=4, n_test=3)
+    ds.resolution = R
+    dev = ds.to_device("cpu")
+    idx = [0, 3, 1] if ds.steady else [0, 5, 36, 71, 143, 100]
+    got = dev.batch(idx)
+    for k, j in enumerate(idx):
+        s = ds[j]
+        assert set(got) == set(s)
+        assert np.allclose(got["pixel_values"][k].numpy(), s["pixel_values"].numpy(), rtol=1e-6, atol=1e-6)
+        assert np.allclose(got["labels"][k].numpy(), s["labels"].numpy(), rtol=1e-6, atol=1e-6)
+        if "time" in s:
+            assert float(got["time"][k]) == pytest.approx(s["time"])
+        if "pixel_mask" in s:
+            assert torch.equal(got["pixel_mask"][k].cpu(), s["pixel_mask"])
+    with pytest.raises(IndexError):
+        dev.batch([len(dev)])
 
 
 @pytest.mark.parametrize("name,key,C", [("fluids.incompressible.PiecewiseConstants.tracer", "velocity", 3),

@@ -546,6 +546,49 @@ def test_device_resident_dataset_batches():
     assert bool(torch.isfinite(out.loss))
 
 
+@pytest.mark.parametrize("name", ["wave.Layer", "elliptic.Helmholtz.time", "fluids.compressible.steady.Airfoil",
+                                  "fluids.incompressible.forcing.KolmogorovFlow"])
+def test_device_resident_batches_other_families(name):
+    """The non-fluids readers on the GPU: scot_gather_planes (static, scalar and analytic source planes; inputs and labels with
+    different recipes) == the reference-style __getitem__ samples; the incompressible readers' `resolution=` through the native
+    spectral resize."""
+    from scOT.problems.base import get_dataset
+    rng = np.random.default_rng(1)
+    R = 128 if "Kolmogorov" in name else 32
+    f = lambda *s: rng.standard_normal(s).astype(np.float32)
+    rd = {"wave.Layer": lambda: {"solution": f(12, 21, R, R), "c": f(12, R, R)},
+          "elliptic.Helmholtz.time": lambda: {"a": f(12, R, R), "bc": f(12), "u": f(12, R, R)},
+          "fluids.compressible.steady.Airfoil": lambda: {"solution": np.concatenate([(rng.random((12, 1, R, R)) > 0.6).astype(np.float32), f(12, 1, R, R)], 1)},
+          "fluids.incompressible.forcing.KolmogorovFlow": lambda: {"solution": f(12, 21, 2, R, R)}}[name]()
+    ds = get_dataset(name, which="train", num_trajectories=5, reader=rd, n_max=12, n_val=4, n_test=3)
+    ds.resolution = R
+    dev = ds.to_device(DEV)
+    idx = [0, 4, 2] if ds.steady else [0, 7, 35, 36, 100, 179]
+    b = dev.batch(idx)
+    for k, j in enumerate(idx):
+        s = ds[j]
+        assert set(b) == set(s)
+        assert np.allclose(b["pixel_values"][k].cpu().numpy(), s["pixel_values"].numpy(), rtol=1e-6, atol=1e-6)
+        assert np.allclose(b["labels"][k].cpu().numpy(), s["labels"].numpy(), rtol=1e-6, atol=1e-6)
+        if "time" in s:
+            assert float(b["time"][k]) == pytest.approx(s["time"])
+        if "pixel_mask" in s:
+            assert torch.equal(b["pixel_mask"][k].cpu(), s["pixel_mask"])
+
+
+def test_device_resident_batches_downsampled():
+    from scOT.problems.base import get_dataset
+    rng = np.random.default_rng(2)
+    rd = {"velocity": rng.standard_normal((12, 21, 2, 128, 128)).astype(np.float32)}
+    ds = get_dataset("fluids.incompressible.Sines", which="train", num_trajectories=5, reader=rd, n_max=12, n_val=4, n_test=3, resolution=64)
+    b = ds.to_device(DEV).batch([3, 40])
+    for k, j in enumerate([3, 40]):
+        s = ds[j]
+        assert b["pixel_values"].shape[-2:] == (64, 64)
+        assert np.allclose(b["pixel_values"][k].cpu().numpy(), s["pixel_values"].numpy(), rtol=1e-4, atol=2e-5)
+        assert np.allclose(b["labels"][k].cpu().numpy(), s["labels"].numpy(), rtol=1e-4, atol=2e-5)
+
+
 def test_fused_adamw_skips_steps_with_overflowed_gradients():
     """fp16 compute mode: the gradient un-scale counts non-finite values; FusedAdamW compares that count with the previous step's
     ON THE DEVICE and leaves parameters and moments untouched when it moved (GradScaler.step semantics, no host round trip)."""
