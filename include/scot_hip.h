@@ -35,6 +35,14 @@ int scot_operand_format(void);
  * Undoes the backward's gradient scale on the gradient arena (the role torch.cuda.amp.GradScaler.unscale_ plays for the
  * reference's fp16 recipe, trainer.py via HF Trainer). */
 int scot_scale_inplace(float* x, size_t n, float scale, int* nonfinite, scot_stream_t stream);
+/* Local power-of-two rescale of a gradient branch behind a tiny per-channel scale (ConvNeXt layer scale, model.py:191-195,212-213)
+ * in the binary16 build — all factors stay on the device:
+ *   scot_pow2_rescale: out2[0] = c = 2^k (k >= 0) with max|v|·c in (1/2, 1], out2[1] = 1/c;
+ *   scot_colscale_dev: out[r,c] = g[r,c] * gamma[c] * mul[0]  (out: fp32 or the 16-bit operand format; C % 8 == 0);
+ *   scot_axpy_dev:     dst += alpha[0] * src  (fp32; clear_src: src = 0 afterwards). */
+int scot_pow2_rescale(const float* v, int n, float* out2, scot_stream_t stream);
+int scot_colscale_dev(const float* g, const float* gamma, const float* mul, void* out, int out_dt, int rows, int C, scot_stream_t stream);
+int scot_axpy_dev(float* dst, float* src, size_t n, const float* alpha, int clear_src, scot_stream_t stream);
 /* Batch assembly from trajectories resident in HBM (the reference's Dataset.__getitem__ + collate: scOT/problems/base.py:318-334,
  * scOT/problems/fluids/incompressible.py:74-160, compressible.py:84-262):
  *   pv [b,c,y,x] = a[c] * data[i_b, t1_b, src[c], y, x] + b[c],  lab[...] the same at t2_b;  src[c] < 0: constant plane b[c];

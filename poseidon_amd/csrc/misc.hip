@@ -1051,6 +1051,72 @@ extern "C" int scot_operand_format() {
 // The fp16 build runs the backward on gradients multiplied by a power of two (fp16 has 5 exponent bits; engine.py picks
 // the scale from the loss normalisation) and divides the gradient arena by it afterwards — exact — with this one pass,
 // which also counts Inf/NaN so that an overflow is reported instead of silently stepping the optimizer.
+// ------------------------------------------------------------------ local power-of-two rescale of a gradient branch (fp16 build)
+// A branch that ends in a tiny per-channel scale (ConvNeXt layer scale, 1e-6 at initialisation: model.py:191-195, 212-213) receives
+// gradients ~2^-20 below the rest of the network; under the backward's one global scale they flush to zero in binary16.  The branch's
+// backward therefore runs on (g ⊙ γ)·c with c = the power of two that brings max|γ| into (1/2, 1], its parameter gradients
+// accumulate in a scratch copy of their arena range, and `scot_axpy_dev` adds scratch / c into the arena (and d_input / c into the
+// residual-stream gradient).  c lives on the DEVICE (computed from γ every step): no host round trip, nothing step-dependent in the
+// recorded launches.
+__global__ __launch_bounds__(256) void pow2_rescale_kernel(const float* __restrict__ v, int n, float* __restrict__ out2) {
+  __shared__ float red[4];
+  float m = 0.f;
+  for (int i = threadIdx.x; i < n; i += 256) m = fmaxf(m, fabsf(v[i]));
+  m = wave_max(m);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    m = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+    int e = 0;
+    if (m > 0.f && m < 3.0e38f) { (void)frexpf(m, &e); e = -e; }      // m = f·2^-e' with f in [1/2, 1): c = 2^e
+    e = e < 0 ? 0 : (e > 40 ? 40 : e);                                    // never scale a branch DOWN; 2^40 is plenty
+    out2[0] = ldexpf(1.0f, e);
+    out2[1] = ldexpf(1.0f, -e);
+  }
+}
+extern "C" int scot_pow2_rescale(const float* v, int n, float* out2, hipStream_t s) {
+  if (n <= 0) return SCOT_ERR_SHAPE;
+  hipLaunchKernelGGL(pow2_rescale_kernel, dim3(1), dim3(256), 0, s, v, n, out2);
+  return scot_check_launch();
+}
+// out[r, c] (16-bit operand format or fp32) = g[r, c] * gamma[c] * mul[0]
+__global__ __launch_bounds__(256) void colscale_dev_kernel(const float* __restrict__ g, const float* __restrict__ gamma, const float* __restrict__ mul,
+                                                           void* __restrict__ out, int out_dt, size_t n8, int C) {
+  const float m = mul[0];
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n8; i += (size_t)gridDim.x * 256) {
+    const size_t e = i * 8;
+    const int c = (int)(e % C);
+    float x[8], w[8];
+    ld8(g, SCOT_F32, e, x);
+    ld8(gamma, SCOT_F32, c, w);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) x[j] = x[j] * w[j] * m;
+    st8(out, out_dt, e, x);
+  }
+}
+extern "C" int scot_colscale_dev(const float* g, const float* gamma, const float* mul, void* out, int out_dt, int rows, int C, hipStream_t s) {
+  if (rows <= 0 || C <= 0) return SCOT_ERR_SHAPE;
+  if (C % 8 || ((((uintptr_t)g | (uintptr_t)out | (uintptr_t)gamma) & 15) != 0) || (out_dt & ~1)) return SCOT_ERR_UNSUPPORTED;
+  const size_t n8 = (size_t)rows * C / 8;
+  size_t blocks = (n8 + 255) / 256; if (blocks > 8192) blocks = 8192;
+  hipLaunchKernelGGL(colscale_dev_kernel, dim3((unsigned)blocks), dim3(256), 0, s, g, gamma, mul, out, out_dt, n8, C);
+  return scot_check_launch();
+}
+// dst[i] += alpha[0] * src[i];  clear_src: src[i] = 0 afterwards (a scratch accumulator hands over and is ready for the next step)
+__global__ __launch_bounds__(256) void axpy_dev_kernel(float* __restrict__ dst, float* __restrict__ src, size_t n, const float* __restrict__ alpha, int clear_src) {
+  const float a = alpha[0];
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+    dst[i] = fmaf(a, src[i], dst[i]);
+    if (clear_src) src[i] = 0.f;
+  }
+}
+extern "C" int scot_axpy_dev(float* dst, float* src, size_t n, const float* alpha, int clear_src, hipStream_t s) {
+  if (n == 0) return SCOT_OK;
+  size_t blocks = (n + 255) / 256; if (blocks > 8192) blocks = 8192;
+  hipLaunchKernelGGL(axpy_dev_kernel, dim3((unsigned)blocks), dim3(256), 0, s, dst, src, n, alpha, clear_src);
+  return scot_check_launch();
+}
+
 __global__ void scale_inplace_kernel(float* x, size_t n4, size_t n, float scale, int* nonfinite) {
   int bad = 0;
   const size_t stride = (size_t)gridDim.x * blockDim.x;

@@ -149,6 +149,11 @@ class ScOTEngine:
         self.scale_grads = compute == "fp16" and os.environ.get("SCOT_GRAD_SCALE", "auto") != "1"
         self.grad_overflow = torch.zeros(1, dtype=torch.int32, device=self.device) if self.scale_grads else None
         self.grads_are_zero = False   # set by ScOT.zero_grad / _prepare_grads: the arena needs no pre-scaling then
+        # ... and one global scale cannot also lift the gradients of a branch behind a ~1e-6 layer scale (2^-20 below the rest):
+        # the ConvNeXt skip blocks run their backward under an extra, device-side power of two (convnext_bwd)
+        self._gredirect, self._ls = None, {}
+        if self.scale_grads and os.environ.get("SCOT_LS_RESCALE", "1") == "1":
+            self._plan_layer_scale_rescale()
         self._wviews: Dict[str, torch.Tensor] = {}
         self._build_cpb_plan()
 
@@ -202,7 +207,27 @@ class ScOTEngine:
         return self.arena.view(name)
 
     def G(self, name):
-        return self.arena.gview(name)
+        r = self._gredirect.get(name) if self._gredirect is not None else None
+        return r if r is not None else self.arena.gview(name)
+
+    def _plan_layer_scale_rescale(self):
+        """fp16 mode: every ConvNeXt skip block gets a scratch copy of its range of the gradient arena and a device-side pair
+        (c, 1/c); see convnext_bwd and csrc/misc.hip (scot_pow2_rescale)."""
+        ar = self.arena
+        blocks = {}
+        for name in ar.shapes:
+            if name.startswith("residual_blocks.") and name.count(".") >= 3:
+                blocks.setdefault(".".join(name.split(".")[:3]), []).append(name)
+        for pre, names in blocks.items():
+            if pre + ".weight" not in names or pre + ".pwconv2.weight" not in names:
+                continue        # not a ConvNeXt block
+            lo = min(ar.offsets[n] for n in names)
+            hi = max(ar.offsets[n] + ar.numel(n) for n in names)
+            if any(lo <= o < hi for n, o in ar.offsets.items() if n in ar.shapes and not n.startswith(pre + ".")):
+                continue        # (cannot happen with the registration-order layout: a block's parameters are contiguous)
+            scratch = torch.zeros(hi - lo, dtype=torch.float32, device=self.device)
+            views = {n: scratch[ar.offsets[n] - lo: ar.offsets[n] - lo + ar.numel(n)].view(ar.shapes[n]) for n in names if n != pre + ".weight"}
+            self._ls[pre] = dict(lo=lo, hi=hi, scratch=scratch, views=views, cs=torch.ones(2, dtype=torch.float32, device=self.device))
 
     def W(self, name):
         """Weight `name` as a GEMM operand (compute dtype)."""
@@ -1001,10 +1026,25 @@ class ScOTEngine:
 
     def convnext_bwd(self, pre, rec, g, B, H, W, C, time):
         L = H * W
+        ls = self._ls.get(pre) if C % 8 == 0 else None
         d_y2 = self.new(B * L, C, dtype=self.adt)
-        ops.scale_residual(g, self.P(pre + ".weight"), None, d_y2, B * L, C)
+        if ls is not None:
+            # binary16 operands: the branch's gradients are (g ⊙ γ)·c with c = 2^k bringing max|γ| into (1/2, 1]; its parameter
+            # gradients go to the block's scratch range and are handed to the arena divided by c at the end (all on the device)
+            ops.pow2_rescale(self.P(pre + ".weight"), ls["cs"])
+            ops.colscale_dev(g, self.P(pre + ".weight"), ls["cs"][0:1], d_y2, B * L, C)
+            self._gredirect = ls["views"]
+        else:
+            ops.scale_residual(g, self.P(pre + ".weight"), None, d_y2, B * L, C)
+        try:
+            return self._convnext_bwd_chain(pre, rec, g, d_y2, B, H, W, C, time, ls)
+        finally:
+            self._gredirect = None
+
+    def _convnext_bwd_chain(self, pre, rec, g, d_y2, B, H, W, C, time, ls):
+        L = H * W
         # layer-scale gradient Σ g·y2: reads g BEFORE the in-place `g += d_s` at the end of this function — keep it on this stream
-        ops.colsum(g, self.G(pre + ".weight"), y=rec["y2"])
+        ops.colsum(g, self.arena.gview(pre + ".weight"), y=rec["y2"])
         self.linear_bwd_params(pre + ".pwconv2.weight", pre + ".pwconv2.bias", d_y2, rec["u"])
         d_u = self.new(B * L, 4 * C, dtype=self.adt)
         ops.linear_dgrad(self.compute, d_y2, self.W(pre + ".pwconv2.weight"), d_u, aux=rec["gp"], aux_mul=True, wt=self.WT(pre + ".pwconv2.weight"))
@@ -1016,7 +1056,14 @@ class ScOTEngine:
                                                          B, H, W, C), d_dw, rec["s"])
         d_s = self.new(B * L, C)
         ops.dwconv7(d_dw, self.P(pre + ".dwconv.weight"), None, d_s, B, H, W, C, flip=True)
-        ops.add(g, d_s, g)
+        if ls is None:
+            ops.add(g, d_s, g)
+            return g
+        ops.axpy_dev(g, d_s, ls["cs"][1:2])
+        # scratch / c -> the arena, behind every kernel that accumulated into the scratch (weight gradients: side stream)
+        self._drain_wgrads()
+        dst = self.arena.grad[ls["lo"]:ls["hi"]]
+        self.off_critical_path(lambda: ops.axpy_dev(dst, ls["scratch"], ls["cs"][1:2], clear_src=True))
         return g
 
     # ------------------------------------------------------------------------------------------ whole model

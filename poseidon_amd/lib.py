@@ -45,6 +45,9 @@ PROTOTYPES = {
     "scot_add": [P, I, P, I, P, I, Z, Z, P],
     "scot_batch_sum": [P, I, P, I, Z, P],
     "scot_gather_pairs": [P, P, P, P, P, P, P, I, I, I, I, I, I, I, P],
+    "scot_pow2_rescale": [P, I, P, P],
+    "scot_colscale_dev": [P, P, P, P, I, I, I, P],
+    "scot_axpy_dev": [P, P, Z, P, I, P],
     "scot_gather_planes": [P, P, P, P, P, P, P, P, I, I, I, I, I, I, I, P],
     "scot_mask_tokens": [P, P, P, I, I, P],
     "scot_mask_tokens_bwd": [P, P, P, I, I, P],

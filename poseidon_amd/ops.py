@@ -333,6 +333,21 @@ def gather_pairs(data, it, src, a, b, pv, lab, T, nsrc, H, W, transpose):
                                      int(transpose), stream()), "scot_gather_pairs")
 
 
+def pow2_rescale(v, out2):
+    """out2[0] = c = 2^k >= 1 with max|v|·c in (1/2, 1], out2[1] = 1/c (device-side; see csrc/misc.hip)."""
+    _lib.check(L().scot_pow2_rescale(ptr(v), v.numel(), ptr(out2), stream()), "scot_pow2_rescale")
+
+
+def colscale_dev(g, gamma, mul, out, rows, C):
+    """out[r, c] = g[r, c] * gamma[c] * mul[0]  (mul: device scalar)."""
+    _lib.check(L().scot_colscale_dev(ptr(g), ptr(gamma), ptr(mul), ptr(out), dt(out), rows, C, stream()), "scot_colscale_dev")
+
+
+def axpy_dev(dst, src, alpha, clear_src=False):
+    """dst += alpha[0] * src (fp32; alpha: device scalar); clear_src: src zeroed in the same pass."""
+    _lib.check(L().scot_axpy_dev(ptr(dst), ptr(src), dst.numel(), ptr(alpha), int(clear_src), stream()), "scot_axpy_dev")
+
+
 def gather_planes(data, traj, tidx, src, a, b, planes, out, T, nsrc, H, W, transpose):
     """One tensor of a batch from HBM-resident trajectories with its own recipe (poseidon_amd/data.py): traj / tidx int32 [B], src int32
     [C] (-1: constant plane, -2 - p: fixed plane p of `planes` [P, H, W]), a / b fp32 [C]; writes out [B, C, H, W]."""

@@ -114,6 +114,36 @@ def test_engine_reduced_precision_modes(emu, compute, tol_out, tol_grad):
         assert model._engine.scale_grads and int(model._engine.grad_overflow) == 0
 
 
+def test_engine_fp16_layer_scale_branch_gradients(emu, monkeypatch):
+    """HF-init regime (ConvNeXt layer scale 1e-6): the skip blocks' branch gradients sit ~2^-20 below the rest and flush to zero in
+    binary16 under the one global gradient scale; with the device-side local power of two (scot_pow2_rescale / colscale_dev / axpy_dev)
+    every parameter of those blocks gets its gradient — also when the arena is accumulated into twice."""
+    f, meta = load_fixture("tiny_hf")
+    cfg = ScOTConfig(**meta["cfg"])
+    pv, t, lab, pm = fixture_inputs(meta, cfg)
+    sd = synth_state_dict(param_shapes(cfg), meta["regime"])
+
+    def branch_errors(model):
+        out = {}
+        for k, p in model.named_parameters():
+            if k.startswith("residual_blocks.") and not k.endswith(".weight") or k.endswith(("dwconv.weight", "pwconv1.weight", "pwconv2.weight")):
+                if k.startswith("residual_blocks.") and "grad:" + k in f.files and np.linalg.norm(f["grad:" + k]) > 0:
+                    out[k] = rel_l2(p.grad.numpy(), f["grad:" + k])
+        return out
+    model, loss, pred = run_engine(cfg, sd, pv, t, lab, pm, "fp16")
+    assert model._engine._ls and int(model._engine.grad_overflow) == 0
+    errs = branch_errors(model)
+    assert len(errs) >= 8 and max(errs.values()) < 5e-2, errs
+    g1 = model._arena.grad.clone()
+    eng = model._engine
+    _, _, tp = eng.forward(pv, t, lab, pm, train=True)          # accumulate a second, identical backward: exactly 2x
+    eng.backward(tp, torch.ones(1), None)
+    assert rel_l2(model._arena.grad.numpy(), 2.0 * g1.numpy()) < 1e-6
+    monkeypatch.setenv("SCOT_LS_RESCALE", "0")                  # what the rescale is for: without it those gradients are lost
+    model0, _, _ = run_engine(cfg, sd, pv, t, lab, pm, "fp16")
+    assert not model0._engine._ls and max(branch_errors(model0).values()) > 0.5
+
+
 def test_engine_fp16_gradient_scale_accumulates(emu):
     """fp16 build: two backwards into the same gradient arena (gradient accumulation) — the second one finds a non-zero arena,
     brings it to the backward's scale first and both contributions come back at scale 1: grads == 2 x the single-step grads."""
