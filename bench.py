@@ -130,7 +130,7 @@ def parity_check(model_tag, compute, size, channels):
     from poseidon_amd.geometry import param_shapes
     from poseidon_amd.synth import synth_inputs, synth_state_dict
     from scOT.model import ScOT
-    name = f"poseidon{model_tag}_trained"
+    name = f"poseidon{model_tag}{size if size != 128 else ''}_trained"      # (poseidonB256_trained: BASELINE config 5)
     path = os.path.join(ROOT, "tests", "golden", name + ".npz")
     if not os.path.exists(path):
         return {"fixture": None, "note": f"no golden fixture for Poseidon-{model_tag}"}
