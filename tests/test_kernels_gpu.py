@@ -32,14 +32,14 @@ def test_selftest_tr():
 
 
 # ----------------------------------------------------------------------------------------------- GEMM
-@pytest.mark.parametrize("compute", [ops.F32, ops.BF16])
-@pytest.mark.parametrize("layout", [ops.NT, ops.NN, ops.TN])
-@pytest.mark.parametrize("mixed", [False, True])  # False: operands in the compute dtype (gemm_fast); True: fp32 B (generic)
-@pytest.mark.parametrize("M,N,K", [(304, 96, 96), (1024, 288, 96), (257, 130, 72), (4096, 384, 96), (64, 64, 3072),
-                                   (1024, 768, 768), (65536, 96, 384), (520, 64, 40)])
+GEMM_SHAPES = [(304, 96, 96), (1024, 288, 96), (257, 130, 72), (4096, 384, 96), (64, 64, 3072), (1024, 768, 768), (65536, 96, 384), (520, 64, 40)]
+# mixed = False: operands in the compute dtype (gemm_fast); True: fp32 B beside 16-bit A (generic kernel; exists in the 16-bit mode only)
+GEMM_CASES = [(c, l, mx, *sh) for c in (ops.F32, ops.BF16) for l in (ops.NT, ops.NN, ops.TN) for mx in (False, True) for sh in GEMM_SHAPES
+              if not (mx and (c == ops.F32 or sh[0] > 5000))]
+
+
+@pytest.mark.parametrize("compute,layout,mixed,M,N,K", GEMM_CASES)
 def test_gemm_layouts(compute, layout, mixed, M, N, K):
-    if mixed and (compute == ops.F32 or M > 5000):
-        pytest.skip("mixed-dtype operands only exist in bf16 mode")
     adt = torch.float32 if compute == ops.F32 else torch.bfloat16
     bdt = torch.float32 if mixed else adt
     if layout == ops.NT:
