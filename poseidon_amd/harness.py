@@ -8,7 +8,8 @@
     layer-scale `weight` decay; `embeddings.norm.*` go to the embeddings group, not the time-embedding group.
   * `rollout` — autoregressive evaluation/training forward of `Trainer._model_forward` (reference trainer.py:452-603):
     int n: time/n, n model calls feeding `output.detach()` back (+ pass-through of the extra input channels when
-    num_channels > num_out_channels), loss averaged, or all steps stacked on dim 1; list: time = lead_time * i per step.
+    num_channels > num_out_channels), loss averaged, or all steps stacked on dim 1 (outputs, and the hidden states /
+    reshaped hidden states / attentions of every step when the model returns them); list: time = lead_time * i per step.
 """
 from __future__ import annotations
 
@@ -110,6 +111,7 @@ def rollout(model, inputs: Dict[str, torch.Tensor], ar_steps: Union[int, Sequenc
     else:
         raise ValueError("num_ar_steps must be an integer or a list of integers.")
     outs, losses, loss = [], [], 0
+    hidden, reshaped, attn = [], [], []
     outputs = None
     for i in schedule:
         if lead is not None:
@@ -119,6 +121,13 @@ def rollout(model, inputs: Dict[str, torch.Tensor], ar_steps: Union[int, Sequenc
             outs.append(outputs.output.detach())
             if lead is not None:
                 outs.append(outputs.output.detach())  # duplicated append of the reference's list branch (trainer.py:540-543)
+            # per-step hidden states / attentions, stacked over the steps below (trainer.py:472-479, 509-520, 544-551, 584-595)
+            if getattr(outputs, "hidden_states", None) is not None:
+                hidden.append(outputs.hidden_states)
+            if getattr(outputs, "attentions", None) is not None:
+                attn.append(outputs.attentions)
+            if getattr(outputs, "reshaped_hidden_states", None) is not None:
+                reshaped.append(outputs.reshaped_hidden_states)
             if outputs.loss is not None:
                 losses.append(outputs.loss)
         elif outputs.loss is not None:
@@ -131,6 +140,12 @@ def rollout(model, inputs: Dict[str, torch.Tensor], ar_steps: Union[int, Sequenc
         outputs.output = torch.stack(outs, dim=1)
         if losses:  # reference: dim 0 (int mode), dim 1 (list mode; only valid for non-scalar losses)
             outputs.loss = torch.stack(losses, dim=1 if (lead is not None and losses[0].dim() > 0) else 0)
+        if hidden:
+            outputs.hidden_states = [torch.stack(hs, dim=1) for hs in zip(*hidden)]
+        if attn:
+            outputs.attentions = [torch.stack(a, dim=1) for a in zip(*attn)]
+        if reshaped:
+            outputs.reshaped_hidden_states = [torch.stack(r, dim=1) for r in zip(*reshaped)]
     else:
         outputs.loss = loss / len(schedule)
     return outputs

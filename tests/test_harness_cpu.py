@@ -138,3 +138,32 @@ def test_compute_loss_accepts_trainer_kwargs():
     assert float(compute_loss(M((torch.tensor(3.0), None)), dict(x), ar_steps=None)) == 3.0
     with pytest.raises(ValueError, match="did not return a loss"):
         compute_loss(M(Out(loss=None, output=torch.zeros(1, 1, 2, 2))), x)
+
+
+def test_rollout_stacks_hidden_states_over_steps():
+    """reference Trainer._model_forward with output_all_steps (trainer.py:472-479, 509-520 / 544-551, 584-595): the hidden states,
+    reshaped hidden states and attentions of every AR step are collected and stacked on dim 1, layer by layer; the list mode
+    appends each OUTPUT twice (the reference's duplicated append) but the hidden states once."""
+    from types import SimpleNamespace
+    from poseidon_amd.harness import rollout
+
+    class M:
+        config = SimpleNamespace(use_conditioning=True, num_channels=1, num_out_channels=1)
+
+        def __init__(self):
+            self.calls = 0
+
+        def __call__(self, pixel_values, time, **kw):
+            self.calls += 1
+            k = float(self.calls)
+            return SimpleNamespace(loss=torch.tensor(k), output=pixel_values + 1, hidden_states=(torch.full((2, 3), k), torch.full((2, 5), 10 * k)),
+                                   reshaped_hidden_states=(torch.full((2, 1, 3), k),), attentions=None)
+    x = dict(pixel_values=torch.zeros(2, 1, 2, 2), time=torch.ones(2))
+    o = rollout(M(), x, 3, output_all_steps=True)
+    assert o.output.shape == (2, 3, 1, 2, 2) and o.loss.tolist() == [1.0, 2.0, 3.0]
+    assert [tuple(h.shape) for h in o.hidden_states] == [(2, 3, 3), (2, 3, 5)] and o.hidden_states[1][0, :, 0].tolist() == [10.0, 20.0, 30.0]
+    assert tuple(o.reshaped_hidden_states[0].shape) == (2, 3, 1, 3) and o.attentions is None
+    o = rollout(M(), x, [1, 2], output_all_steps=True)
+    assert o.output.shape == (2, 4, 1, 2, 2) and tuple(o.hidden_states[0].shape) == (2, 2, 3)
+    o = rollout(M(), x, 2)                 # without output_all_steps: the last step's hidden states, the mean loss
+    assert float(o.loss) == 1.5 and tuple(o.hidden_states[0].shape) == (2, 3)
