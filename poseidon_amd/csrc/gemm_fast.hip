@@ -770,7 +770,7 @@ extern "C" int scot_wgrad_group(int compute, int n, int K, const void* const* dY
   // K slices: enough workgroups to fill the chip (~2 per CU), at least 8 K-tiles each, a multiple of 8 so that one slice's
   // tiles share an XCD; none when the group already has >= 256 tiles
   static int want_wgs = -1;
-  if (want_wgs < 0) { const char* e = getenv("SCOT_WGRAD_GROUP_WGS"); want_wgs = e ? atoi(e) : 448; }
+  if (want_wgs < 0) { const char* e = getenv("SCOT_WGRAD_GROUP_WGS"); want_wgs = e ? atoi(e) : 256; }   // in-step optimum: 192-256 (448 filled the chip better alone and cost the chain 0.1 ms; 128 makes the side stream the wall)
   const long nkt = (K + bk - 1) / bk;
   // mid-sized groups (stage 2: 432 tiles x 64 K-tiles = 1.7 workgroups per CU walking a long serial K loop): two K slices
   // (SCOT_WGRAD_GROUP_MID_WGS=864) run 66 instead of 85 us alone — and cost the step 0.2 ms: beside the main chain a wider

@@ -214,3 +214,8 @@ def test_spectral_resize_native(emu, s, t):
 
 def test_transposed_weight_copies(gpu_test_bodies):
     gpu_test_bodies.test_transpose_cast_and_dgrad_nt()
+
+
+@pytest.mark.parametrize("H,W,C,B", [(16, 16, 96, 2), (5, 5, 24, 2)])
+def test_depthwise_conv7(gpu_test_bodies, H, W, C, B):
+    gpu_test_bodies.test_dwconv7(H, W, C, B)

@@ -517,9 +517,8 @@ def test_reductions_and_scale_residual():
 
 
 # ----------------------------------------------------------------------------------------------- stencils
-@pytest.mark.parametrize("H,W,C", [(16, 16, 96), (5, 5, 24)])
-def test_dwconv7(H, W, C):
-    B = 2
+@pytest.mark.parametrize("H,W,C,B", [(16, 16, 96, 2), (5, 5, 24, 2), (40, 40, 64, 24)])   # last: 25 tiles in 16 groups (2 tiles per wgrad workgroup, idle tail groups)
+def test_dwconv7(H, W, C, B):
     x = rnd(B, H, W, C)
     w, bias = rnd(C, 1, 7, 7, seed=1, scale=0.2), rnd(C, seed=2)
     y = torch.empty(B, H, W, C, device=DEV)
