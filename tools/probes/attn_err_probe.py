@@ -1,5 +1,7 @@
 import sys, math, torch
-sys.path.insert(0, "/root/repo"); sys.path.insert(0, "/root/repo/tests")
+import os
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import test_kernels_gpu as T
 from poseidon_amd import ops
 rel, rnd, DEV = T.rel, T.rnd, T.DEV

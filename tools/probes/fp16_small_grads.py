@@ -3,7 +3,9 @@
 import sys
 import numpy as np
 import torch
-sys.path.insert(0, "/root/repo"); sys.path.insert(0, "/root/repo/tests")
+import os
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import test_model_gpu as T
 for name in sys.argv[1:] or ["poseidonT_hf", "poseidonB_hf"]:
     f, meta = T.load_fixture(name)
