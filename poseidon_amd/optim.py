@@ -54,6 +54,9 @@ class FusedAdamW(torch.optim.Optimizer):
 
     def __init__(self, model, lr: float, weight_decay: float = 0.0, betas=(0.9, 0.999), eps: float = 1e-8,
                  max_grad_norm: Optional[float] = None, **group_kw):
+        p0 = next(model.parameters(), None)
+        if p0 is not None and p0.is_cuda and hasattr(model, "_ensure_arena"):
+            model._ensure_arena(p0.device)      # (the flat parameter / gradient arenas are otherwise created by the first forward)
         if getattr(model, "_arena", None) is None or not model._arena.data.is_cuda:
             raise RuntimeError("FusedAdamW needs a ScOT model that lives on the GPU (call .to('cuda') first)")
         groups = optimizer_param_groups(model, weight_decay, return_names=True, **group_kw)

@@ -636,8 +636,7 @@ def test_short_training_run_fp16_tracks_fp32(regime_fixture, lr, tol):
     for compute in ("fp32", "fp16"):
         cfg, model = build(meta, compute)
         kw = inputs(cfg, meta)
-        model(**kw).loss.backward()           # (materialises the parameter / gradient arenas the optimiser steps on)
-        opt = FusedAdamW(model, lr=lr, weight_decay=0.01, max_grad_norm=5.0)
+        opt = FusedAdamW(model, lr=lr, weight_decay=0.01, max_grad_norm=5.0)      # (before any forward: creates the arenas itself)
         losses = []
         for _ in range(12):
             opt.zero_grad()
