@@ -274,6 +274,26 @@ __global__ void patchify_kernel(const float* img, void* cols, int c_dt, int B, i
     st1(cols, c_dt, row * (Cc * p * p) + (ci * p + y % p) * p + x % p, v);
   }
 }
+// p = 4, no padding: one workgroup per (b, gy) strip of gw tokens.  The strip's 4·Cc image-row segments are read as whole rows
+// (W floats each, coalesced) and its gw·16·Cc im2col floats leave as ONE contiguous block; the 4x4 re-tiling happens in LDS.
+// (The element-wise kernel above writes 16-byte pieces 256 bytes apart: 106 us for a 64 x 4 x 128² batch; this one ~10x less.)
+__global__ __launch_bounds__(256) void patchify4_kernel(const float* __restrict__ img, void* __restrict__ cols, int c_dt, int Cc, int H, int W, int gh, int gw) {
+  extern __shared__ __attribute__((aligned(16))) float strip[];          // [gw][16·Cc + 4]
+  const int b = blockIdx.x / gh, gy = blockIdx.x % gh, K = 16 * Cc, P = K + 4, nseg = 4 * Cc;
+  for (int idx = threadIdx.x; idx < nseg * gw; idx += 256) {
+    const int seg = idx / gw, q = idx % gw, ci = seg >> 2, i = seg & 3;
+    const float4 v = *(const float4*)(img + (((size_t)b * Cc + ci) * H + gy * 4 + i) * W + q * 4);
+    *(float4*)(strip + q * P + seg * 4) = v;
+  }
+  __syncthreads();
+  const size_t row0 = ((size_t)b * gh + gy) * gw;
+  for (int idx = threadIdx.x; idx < gw * (K / 8); idx += 256) {
+    const int q = idx / (K / 8), k8 = (idx % (K / 8)) * 8;
+    const float4 a = *(const float4*)(strip + q * P + k8), c = *(const float4*)(strip + q * P + k8 + 4);
+    const float o[8] = {a.x, a.y, a.z, a.w, c.x, c.y, c.z, c.w};
+    st8(cols, c_dt, (row0 + q) * K + k8, o);
+  }
+}
 // img[b,co,y,x] = cols[(b,y/p,x/p)][co*p*p + (y%p)*p + x%p] + bias[co]   for y < H, x < W (crop, model.py:632-637)
 __global__ void unpatchify_kernel(const void* cols, int c_dt, const float* bias, float* img, int B, int Cc, int H, int W,
                                   int gh, int gw, int p) {
@@ -290,6 +310,11 @@ extern "C" int scot_patchify(const float* img, void* cols, int c_dt, int B, int 
   const int gh = (H + p - 1) / p, gw = (W + p - 1) / p;
   const size_t n = (size_t)B * Cc * gh * p * gw * p;
   if (n == 0) return SCOT_ERR_SHAPE;
+  const size_t lds = (size_t)gw * (16 * Cc + 4) * sizeof(float);
+  if (p == 4 && H == gh * 4 && W == gw * 4 && (((uintptr_t)img | (uintptr_t)cols) & 15) == 0 && lds <= 64 * 1024) {
+    hipLaunchKernelGGL(patchify4_kernel, dim3((unsigned)(B * gh)), dim3(256), lds, s, img, cols, c_dt, Cc, H, W, gh, gw);
+    return scot_check_launch();
+  }
   size_t blocks = (n + 255) / 256; if (blocks > 16384) blocks = 16384;
   hipLaunchKernelGGL(patchify_kernel, dim3((unsigned)blocks), dim3(256), 0, s, img, cols, c_dt, B, Cc, H, W, gh, gw, p);
   return scot_check_launch();
@@ -623,8 +648,76 @@ __global__ __launch_bounds__(256) void conv5_kernel(const float* in, const float
     for (int o = 0; o < 8; ++o) if (o < Cc) out[(((size_t)b * Cc + o) * H + y) * W + x] = acc[o];
   }
 }
+// LDS-tiled version: workgroup = 8 rows x 128 columns of one sample, all channels; the haloed input tile (Cc x 12 x 132) and the
+// weights sit in LDS, a thread produces 4 consecutive pixels of every output channel (the per-pixel kernel above re-read each
+// input 25x through L1 and fetched one LDS weight per multiply-add: 88 us for a 64 x 4 x 128² batch).
+constexpr int C5T_R = 8, C5T_W = 128;
+template <int CC>
+__global__ __launch_bounds__(256) void conv5_tiled_kernel(const float* __restrict__ in, const float* __restrict__ w, float* __restrict__ out,
+                                                          int H, int W, int transpose) {
+  constexpr int TH = C5T_R + 4, TW = C5T_W + 4;
+  __shared__ __attribute__((aligned(16))) float tile[CC * TH * TW];
+  __shared__ float ws[CC * CC * 25];
+  const int b = blockIdx.z, y0 = blockIdx.y * C5T_R, x0 = blockIdx.x * C5T_W;
+  for (int i = threadIdx.x; i < CC * CC * 25; i += 256) {
+    const int k = i % 25, c = (i / 25) % CC, o = i / (25 * CC);
+    ws[i] = transpose ? w[((size_t)c * CC + o) * 25 + (24 - k)] : w[((size_t)o * CC + c) * 25 + k];
+  }
+  for (int i = threadIdx.x; i < CC * TH * TW; i += 256) {
+    const int xx = i % TW, r = (i / TW) % TH, c = i / (TW * TH);
+    const int y = y0 + r - 2, x = x0 + xx - 2;
+    tile[i] = (y >= 0 && y < H && x >= 0 && x < W) ? in[(((size_t)b * CC + c) * H + y) * W + x] : 0.f;
+  }
+  __syncthreads();
+  const int ry = threadIdx.x >> 5, xq = (threadIdx.x & 31) * 4;
+  float acc[CC][4];
+#pragma unroll
+  for (int o = 0; o < CC; ++o)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[o][j] = 0.f;
+#pragma unroll
+  for (int c = 0; c < CC; ++c)
+#pragma unroll
+    for (int ki = 0; ki < 5; ++ki) {
+      const float* row = tile + ((size_t)c * TH + ry + ki) * TW + xq;
+      const float4 a = *(const float4*)row, d = *(const float4*)(row + 4);
+      const float v[8] = {a.x, a.y, a.z, a.w, d.x, d.y, d.z, d.w};
+#pragma unroll
+      for (int kj = 0; kj < 5; ++kj)
+#pragma unroll
+        for (int o = 0; o < CC; ++o) {
+          const float wv = ws[(o * CC + c) * 25 + ki * 5 + kj];
+#pragma unroll
+          for (int j = 0; j < 4; ++j) acc[o][j] = fmaf(v[j + kj], wv, acc[o][j]);
+        }
+    }
+  const int y = y0 + ry, x = x0 + xq;
+  if (y < H && x < W) {
+#pragma unroll
+    for (int o = 0; o < CC; ++o) {
+      float* op = out + (((size_t)b * CC + o) * H + y) * W + x;
+      if (x + 3 < W && (W & 3) == 0) *(float4*)op = make_float4(acc[o][0], acc[o][1], acc[o][2], acc[o][3]);
+      else
+        for (int j = 0; j < 4 && x + j < W; ++j) op[j] = acc[o][j];
+    }
+  }
+}
+template <int CC> static int launch_conv5_tiled(const float* in, const float* w, float* out, int B, int H, int W, int transpose, hipStream_t s) {
+  hipLaunchKernelGGL((conv5_tiled_kernel<CC>), dim3((W + C5T_W - 1) / C5T_W, (H + C5T_R - 1) / C5T_R, B), dim3(256), 0, s, in, w, out, H, W, transpose);
+  return scot_check_launch();
+}
 extern "C" int scot_conv5(const float* in, const float* w, float* out, int B, int Cc, int H, int W, int transpose, hipStream_t s) {
   if (Cc <= 0 || Cc > 8) return SCOT_ERR_UNSUPPORTED;
+  if ((((uintptr_t)in | (uintptr_t)out) & 15) == 0 && B <= 65535) {
+    switch (Cc) {       // (the LDS tile is Cc x 12 x 132 floats: instantiated for the channel counts of the reference's datasets)
+      case 1: return launch_conv5_tiled<1>(in, w, out, B, H, W, transpose, s);
+      case 2: return launch_conv5_tiled<2>(in, w, out, B, H, W, transpose, s);
+      case 3: return launch_conv5_tiled<3>(in, w, out, B, H, W, transpose, s);
+      case 4: return launch_conv5_tiled<4>(in, w, out, B, H, W, transpose, s);
+      case 5: return launch_conv5_tiled<5>(in, w, out, B, H, W, transpose, s);
+      default: break;
+    }
+  }
   const size_t n = (size_t)B * H * W;
   size_t blocks = (n + 255) / 256; if (blocks > 16384) blocks = 16384;
   hipLaunchKernelGGL(conv5_kernel, dim3((unsigned)blocks), dim3(256), 0, s, in, w, out, B, Cc, H, W, transpose);

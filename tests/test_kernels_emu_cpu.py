@@ -219,3 +219,13 @@ def test_transposed_weight_copies(gpu_test_bodies):
 @pytest.mark.parametrize("H,W,C,B", [(16, 16, 96, 2), (5, 5, 24, 2)])
 def test_depthwise_conv7(gpu_test_bodies, H, W, C, B):
     gpu_test_bodies.test_dwconv7(H, W, C, B)
+
+
+@pytest.mark.parametrize("H,W,Cc", [(16, 16, 3), (18, 14, 3), (32, 64, 4)])
+def test_patchify_strip_kernel(gpu_test_bodies, H, W, Cc):
+    gpu_test_bodies.test_patchify_unpatchify(H, W, Cc, torch.float32)
+
+
+@pytest.mark.parametrize("Cc,H,W", [(4, 32, 32), (5, 13, 10), (1, 20, 132)])
+def test_conv5_tiled(gpu_test_bodies, Cc, H, W):
+    gpu_test_bodies.test_conv5(Cc, H, W)

@@ -472,16 +472,19 @@ def test_space_depth(H, W):
     assert torch.equal(back, mref)
 
 
-@pytest.mark.parametrize("H,W", [(16, 16), (18, 14)])
-def test_patchify_unpatchify(H, W):
-    B, Cc, p = 2, 3, 4
+@pytest.mark.parametrize("H,W,Cc,cdt", [(16, 16, 3, torch.float32), (18, 14, 3, torch.float32), (128, 128, 4, torch.float32),
+                                        (64, 32, 5, torch.bfloat16)])     # unpadded p = 4 grids take the LDS-staged strip kernel
+def test_patchify_unpatchify(H, W, Cc, cdt):
+    B, p = 2, 4
     img = rnd(B, Cc, H, W)
     gh, gw = (H + p - 1) // p, (W + p - 1) // p
-    cols = torch.empty(B * gh * gw, Cc * p * p, device=DEV)
+    cols = torch.full((B * gh * gw, Cc * p * p), float("nan"), device=DEV, dtype=cdt)
     ops.patchify(img, cols, B, Cc, H, W, p)
     padded = torch.nn.functional.pad(img, (0, gw * p - W, 0, gh * p - H))
     ref = padded.view(B, Cc, gh, p, gw, p).permute(0, 2, 4, 1, 3, 5).reshape(B * gh * gw, Cc * p * p)
-    assert torch.equal(cols, ref)
+    assert torch.equal(cols, ref.to(cdt))
+    if cdt != torch.float32:
+        return
     bias = rnd(Cc, seed=1)
     back = torch.empty(B, Cc, H, W, device=DEV)
     ops.unpatchify(cols, bias, back, B, Cc, H, W, gh, gw, p)
@@ -538,7 +541,7 @@ def test_dwconv7(H, W, C, B):
     assert rel(db, b64.grad) < 1e-5
 
 
-@pytest.mark.parametrize("Cc,H,W", [(4, 32, 32), (5, 13, 10)])
+@pytest.mark.parametrize("Cc,H,W", [(4, 32, 32), (5, 13, 10), (4, 128, 128), (1, 20, 132), (6, 9, 9)])   # tiled kernel: Cc <= 5 (ragged tiles, 2 column tiles); 6: per-pixel fallback
 def test_conv5(Cc, H, W):
     B = 2
     x, w = rnd(B, Cc, H, W), rnd(Cc, Cc, 5, 5, seed=1, scale=0.2)
