@@ -175,7 +175,7 @@ template <typename CT, typename MT, int HD, bool NORM, bool X3>
 __device__ __forceinline__ void w16_stage(CT* tile, const void* src, int ld, int col, const W16Tok& T, int tid) {
   constexpr int CPR = ((HD + 31) / 32) * 4;
 #pragma unroll 2
-  for (int c = tid; c < W16::NP * CPR; c += 256) {
+  for (int c = tid; c < W16::NP * CPR; c += blockDim.x) {
     const int n = c / CPR, ch = c % CPR;
     float v[8];
 #pragma unroll
@@ -377,14 +377,14 @@ __device__ __forceinline__ void attn16_bwd_dq_body(const AttnArgs& p) {
   CT* Y = X + TE;               // V
   float* tab2 = (float*)(Y + TE);
   double* dtab = (double*)(tab2 + W16::TSP);   // ds_add_f64 is full rate on gfx950, ds_add_f32 is not (see attention.hip)
-  float* red = (float*)(dtab + W16::TSP);      // [4]
+  float* red = (float*)(dtab + W16::TSP);      // [waves <= 8]
 
   const int win = blockIdx.x, h = blockIdx.y;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int ld = 3 * p.C, g = lane >> 4, lc = lane & 15;
   const W16Tok tokf(p, win);
 
-  for (int i = tid; i < W16::TS; i += 256) { tab2[i] = p.bias_table[h * W16::TS + i] * kLog2e; dtab[i] = 0.0; }
+  for (int i = tid; i < W16::TS; i += blockDim.x) { tab2[i] = p.bias_table[h * W16::TS + i] * kLog2e; dtab[i] = 0.0; }
   w16_stage<CT, MT, HD, true, X3>(X, p.qkv, ld, p.C + h * HD, tokf, tid);
   w16_stage<CT, MT, HD, false, X3>(Y, p.qkv, ld, 2 * p.C + h * HD, tokf, tid);
   __syncthreads();
@@ -403,7 +403,7 @@ __device__ __forceinline__ void attn16_bwd_dq_body(const AttnArgs& p) {
   float dls = 0.f;
 
 #pragma nounroll
-  for (int qb = wave; qb < 16; qb += 4) {
+  for (int qb = wave; qb < 16; qb += (int)(blockDim.x >> 6)) {
     const int q = qb * 16 + lc;
     const int tokq = tokf(q);
     float accD = 0.f, accB = 0.f;
@@ -483,8 +483,12 @@ __device__ __forceinline__ void attn16_bwd_dq_body(const AttnArgs& p) {
   dls = wave_sum(dls);
   if (lane == 0) red[wave] = dls;
   __syncthreads();
-  for (int i = tid; i < W16::TS; i += 256) atomicAdd(&p.dbias_table[h * W16::TS + i], (float)dtab[i]);
-  if (tid == 0 && p.logit_scale[h] <= 4.605170185988092f) atomicAdd(&p.dlogit_scale[h], (red[0] + red[1] + red[2] + red[3]) * scale);
+  for (int i = tid; i < W16::TS; i += blockDim.x) atomicAdd(&p.dbias_table[h * W16::TS + i], (float)dtab[i]);
+  if (tid == 0 && p.logit_scale[h] <= 4.605170185988092f) {
+    float r = 0.f;
+    for (int wv = 0; wv < (int)(blockDim.x >> 6); ++wv) r += red[wv];
+    atomicAdd(&p.dlogit_scale[h], r * scale);
+  }
 }
 
 // ================================================================================================= backward: dK, dV
@@ -505,12 +509,12 @@ __device__ __forceinline__ void attn16_bwd_dkv_body(const AttnArgs& p) {
   const int ld = 3 * p.C, g = lane >> 4, lc = lane & 15;
 
   const W16Tok tokf(p, win);
-  for (int i = tid; i < NP; i += 256) nlse2[i] = -p.lse[((size_t)win * p.heads + h) * NP + i] * kLog2e;
-  for (int i = tid; i < W16::TS; i += 256) tab2[i] = p.bias_table[h * W16::TS + i] * kLog2e;
+  for (int i = tid; i < NP; i += blockDim.x) nlse2[i] = -p.lse[((size_t)win * p.heads + h) * NP + i] * kLog2e;
+  for (int i = tid; i < W16::TS; i += blockDim.x) tab2[i] = p.bias_table[h * W16::TS + i] * kLog2e;
   w16_stage<CT, MT, HD, true, X3>(X, p.qkv, ld, h * HD, tokf, tid);
   // dO -> LDS and delta[n] = Σ_d dO[n][d]·O[n][d] in the same pass (CPR lanes per row)
 #pragma unroll
-  for (int c = tid; c < NP * CPR; c += 256) {
+  for (int c = tid; c < NP * CPR; c += blockDim.x) {
     const int n = c / CPR, d8 = (c % CPR) * 8;
     float v[8], o[8];
 #pragma unroll
@@ -542,7 +546,7 @@ __device__ __forceinline__ void attn16_bwd_dkv_body(const AttnArgs& p) {
   const float* dlg = delta + g * 4;
 
 #pragma nounroll
-  for (int kb = wave; kb < 16; kb += 4) {
+  for (int kb = wave; kb < 16; kb += (int)(blockDim.x >> 6)) {
     const int tokk = tokf(kb * 16 + lc);
     FragX<CT, X3> kf[KS], vf[KS];
     row_frag<CT, MT, HD, X3>(kf, p.qkv, (size_t)tokk * ld + p.C + h * HD, true, lane);
@@ -605,6 +609,12 @@ __global__ __launch_bounds__(256, 2) void attn16_bwd_kernel(AttnArgs p) {
   if (blockIdx.z == 0) attn16_bwd_dq_body<CT, HD, SHIFTED, X3>(p);
   else attn16_bwd_dkv_body<CT, HD, SHIFTED, X3>(p);
 }
+// the same bodies with 8 waves per (window, head): two query / key rows per wave instead of four (half the serial chain per workgroup)
+template <typename CT, int HD, bool SHIFTED, bool X3>
+__global__ __launch_bounds__(512) void attn16_bwd_kernel_w8(AttnArgs p) {
+  if (blockIdx.z == 0) attn16_bwd_dq_body<CT, HD, SHIFTED, X3>(p);
+  else attn16_bwd_dkv_body<CT, HD, SHIFTED, X3>(p);
+}
 
 // ================================================================================================= host side
 template <typename CT, int HD, bool SHIFTED, bool X3>
@@ -612,7 +622,7 @@ static int launch_w16(const AttnArgs& a, int nwin, bool bwd, hipStream_t s) {
   constexpr int NP = W16::NP;
   const size_t tiles = (X3 ? 4 : 2) * Tile16<CT, HD>::elems * sizeof(CT);     // bf16x3: a hi and a lo tile per operand
   const size_t sh_fwd = tiles + W16::TSP * sizeof(float);
-  const size_t sh_dq = tiles + W16::TSP * (sizeof(float) + sizeof(double)) + 4 * sizeof(float);
+  const size_t sh_dq = tiles + W16::TSP * (sizeof(float) + sizeof(double)) + 8 * sizeof(float);
   const size_t sh_dkv = tiles + (W16::TSP + 2 * NP) * sizeof(float);
   dim3 grid(nwin, a.heads), block(256);
   if (!bwd) {
@@ -623,6 +633,13 @@ static int launch_w16(const AttnArgs& a, int nwin, bool bwd, hipStream_t s) {
     const size_t sh_b = sh_dq > sh_dkv ? sh_dq : sh_dkv;
     if (sh_b > 160 * 1024) return SCOT_ERR_UNSUPPORTED;
     if (sh_b > 64 * 1024) (void)hipFuncSetAttribute((const void*)attn16_bwd_kernel<CT, HD, SHIFTED, X3>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh_b);
+    static int w8 = -1;
+    if (w8 < 0) { const char* e = getenv("SCOT_ATTN16_BWD_WAVES"); w8 = (e && atoi(e) == 8) ? 1 : 0; }
+    if (w8 && !X3 && sizeof(CT) == 2) {
+      if (sh_b > 64 * 1024) (void)hipFuncSetAttribute((const void*)attn16_bwd_kernel_w8<CT, HD, SHIFTED, X3>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh_b);
+      hipLaunchKernelGGL((attn16_bwd_kernel_w8<CT, HD, SHIFTED, X3>), dim3(nwin, a.heads, 2), dim3(512), sh_b, s, a);
+      return scot_check_launch();
+    }
     hipLaunchKernelGGL((attn16_bwd_kernel<CT, HD, SHIFTED, X3>), dim3(nwin, a.heads, 2), block, sh_b, s, a);
   }
   return scot_check_launch();
