@@ -19,7 +19,11 @@ import os
 import sys
 import time
 
-import torch
+# before the HIP runtime initialises (see poseidon_amd/__init__.py): enough hardware queues for the chain, the weight-gradient stream
+# AND an RCCL communicator's streams — with the default 4 the step loses its stream overlap as soon as a process group exists
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+
+import torch  # noqa: E402
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
@@ -47,10 +51,10 @@ def parse():
     ap.add_argument("--wire", default="fp32", choices=["bf16", "fp32"], help="gradient all-reduce wire format (N>1)")
     ap.add_argument("--dp-collective", default="allreduce", choices=["allreduce", "rs_ag"],
                     help="N>1: one all-reduce per gradient chunk, or reduce-scatter + all-gather (poseidon_amd/dp.py)")
-    ap.add_argument("--dp", default="auto", choices=["auto", "overlap", "after"],
+    ap.add_argument("--dp", default="auto", choices=["auto", "overlap", "after", "none"],
                     help="N>1: all-reduce each gradient range from inside the backward as soon as it is final (RCCL on a side "
                          "stream, eager launches), or one chunked all-reduce after the step (works with hipGraph replay); "
-                         "auto: time both in the warm-up, keep the faster")
+                         "auto: time both in the warm-up, keep the faster; none: no exchange (diagnostic: what the process group costs)")
     ap.add_argument("--_cpu-worker", dest="cpu_worker", action="store_true", help=argparse.SUPPRESS)
     return ap.parse_args()
 
@@ -259,7 +263,7 @@ def main():
     after = GradAllReducer(model, dist, wire=a.wire, collective=a.dp_collective) if dist is not None else None
     overlapped = (OverlappedGradAllReducer(model, dist, wire=a.wire, collective=a.dp_collective)
                   if (dist is not None and a.dp != "after") else None)
-    exchange = [None if dist is None else ("after" if a.dp != "overlap" else "overlap")]   # current mode
+    exchange = [None if (dist is None or a.dp == "none") else ("after" if a.dp != "overlap" else "overlap")]   # current mode
     loss_buf = torch.zeros((), device="cuda")
 
     def compute_step():
@@ -317,7 +321,7 @@ def main():
             tg, te = float(tt2[0]), float(tt2[1])
         use_graph[0] = tg <= te
         mode_info = {"probe_graph_ms": tg * 1e3, "probe_eager_ms": te * 1e3, "eager_cpu_enqueue_ms": te_enq * 1e3}
-    if dist is not None and a.dp == "auto":
+    if dist is not None and a.dp == "auto" and exchange[0] is not None:
         # gradient exchange: one chunked all-reduce after the step vs range all-reduces launched from inside the backward
         ug = use_graph[0]
         t_after, _ = probe(ug)
@@ -356,7 +360,7 @@ def main():
         dt = float(tmax)
     ms = dt / a.steps * 1e3
     comm = None
-    if dist is not None:   # GPU time of the gradient exchange alone (pack + collective + unpack), outside the timed region
+    if dist is not None and exchange[0] is not None:   # GPU time of the gradient exchange alone (pack + collective + unpack), outside the timed region
         if exchange[0] == "overlap":
             overlapped.timing = []
             for _ in range(3):

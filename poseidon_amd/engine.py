@@ -1466,12 +1466,28 @@ class ScOTEngine:
         if self.on_grads_final is not None:
             from .dp import group_ranges
 
+            def announce(prefix, _cb=self.on_grads_final):
+                # the callback runs with the SIDE stream current: what it enqueues (dp.py: an event the comm stream waits for) is
+                # ordered behind the range's weight gradients and un-scale without the main chain ever waiting for them
+                with torch.cuda.stream(self.side):
+                    _cb(prefix)
+
             def done(prefix, _cb=self.on_grads_final):
-                self.join_side()   # the range's weight gradients (side stream) must be complete before its all-reduce
-                if S != 1.0:       # ... and back at scale 1
+                if not self.use_side:
+                    if S != 1.0:       # back at scale 1 before the range goes on the wire
+                        for _, lo, hi in group_ranges(self.arena, [prefix]):
+                            ops.scale_inplace(self.arena.grad[lo:hi], 1.0 / S, self.grad_overflow)
+                    self.tdo(lambda: _cb(prefix))
+                    return
+                # side stream (forked behind everything the main chain has enqueued so far, i.e. behind the range's last
+                # main-stream gradient kernel): the range's queued weight gradients, its un-scale, then the announcement
+                self.flush_side()
+                if S != 1.0:
                     for _, lo, hi in group_ranges(self.arena, [prefix]):
-                        ops.scale_inplace(self.arena.grad[lo:hi], 1.0 / S, self.grad_overflow)
-                self.tdo(lambda: _cb(prefix))
+                        seg = self.arena.grad[lo:hi]
+                        self.off_critical_path(lambda seg=seg: ops.scale_inplace(seg, 1.0 / S, self.grad_overflow))
+                self.off_critical_path(lambda: self.tdo(lambda: announce(prefix)))
+                self.flush_side()
         elif S != 1.0 and self.use_side:
             from .dp import group_ranges
 

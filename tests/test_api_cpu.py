@@ -122,3 +122,16 @@ def test_step_tape_skips_calls_the_library_declined():
     rec = ops._Recording(FakeLib(), log)
     assert rec.scot_declined(1, 2) == -3 and rec.scot_covered(3) == 0
     assert [(f.__name__, a) for f, a in log] == [("scot_covered", (3,))]
+
+
+def test_package_import_reserves_hardware_queues():
+    """Importing the package (before the HIP runtime starts) asks for 8 hardware queues unless the user chose a number: with the
+    default 4, an RCCL communicator's streams push the engine's two streams onto one queue (27.1 vs 21.0 ms/step measured)."""
+    import subprocess
+    import sys
+    code = "import os; os.environ.pop('GPU_MAX_HW_QUEUES', None); import poseidon_amd; print(os.environ['GPU_MAX_HW_QUEUES'])"
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    assert out.stdout.strip() == "8", out.stderr[-500:]
+    code = "import os; os.environ['GPU_MAX_HW_QUEUES'] = '6'; import poseidon_amd; print(os.environ['GPU_MAX_HW_QUEUES'])"
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    assert out.stdout.strip() == "6"
