@@ -1474,6 +1474,7 @@ class ScOTEngine:
 
             def done(prefix, _cb=self.on_grads_final):
                 if not self.use_side:
+                    self.flush_side()  # (no side stream: the range's queued weight gradients run here, in line)
                     if S != 1.0:       # back at scale 1 before the range goes on the wire
                         for _, lo, hi in group_ranges(self.arena, [prefix]):
                             ops.scale_inplace(self.arena.grad[lo:hi], 1.0 / S, self.grad_overflow)
