@@ -111,7 +111,7 @@ class ScOTEngine:
         # Weight gradients are off the backward's critical path (nothing downstream reads dW): they are launched on a
         # second HIP stream, forked from / joined into the main stream with events, so that the (latency-bound) wgrad GEMMs
         # fill the CUs the dgrad / LN / attention chain leaves idle.  SCOT_SIDE_STREAM=0 serialises everything.
-        self.use_side = os.environ.get("SCOT_SIDE_STREAM", "1") != "0"
+        self.use_side = os.environ.get("SCOT_SIDE_STREAM", "1") != "0" and torch.device(self.device).type == "cuda"
         # LN backward split across the streams (SCOT_SPLIT_LN_BWD=1): dx on the dependent chain, the four parameter gradients
         # on the side stream; the residual-stream gradient is then never updated in place (its readers on the side stream may
         # still be pending).  Measured 25.96 vs 25.04 ms/step: the second pass over dout and x costs more than the chain

@@ -53,6 +53,19 @@ class ScOTOutput:
     def __contains__(self, k):
         return k in self.keys()
 
+    def items(self):
+        return [(k, getattr(self, k)) for k in self.keys()]
+
+    def values(self):
+        return [getattr(self, k) for k in self.keys()]
+
+
+def _require_hip(t: torch.Tensor) -> None:
+    """The hot path is HIP-only: no CPU fallback exists in the product.  (tests/hipemu, which executes the kernel sources on the
+    host, replaces this check together with `ops.ptr` for the duration of a test.)"""
+    if not t.is_cuda:
+        raise ScotLibraryError("ScOT.forward needs CUDA(HIP) tensors: the hot path is HIP-only (no CPU fallback)")
+
 
 # ---------------------------------------------------------------------------------------------- parameter containers
 class LayerNorm(nn.LayerNorm):
@@ -383,8 +396,7 @@ class ScOT(nn.Module):
             raise ValueError("bool_masked_pos needs ScOT(config, use_mask_token=True) (reference model.py:323-327, 353-359)")
         if head_mask is not None:
             raise NotImplementedError("head_mask is not implemented")
-        if not pixel_values.is_cuda:
-            raise ScotLibraryError("ScOT.forward needs CUDA(HIP) tensors: the hot path is HIP-only (no CPU fallback)")
+        _require_hip(pixel_values)
         dev = pixel_values.device
         self._ensure_arena(dev)
         pv = pixel_values.to(torch.float32).contiguous()

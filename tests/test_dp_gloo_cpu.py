@@ -3,6 +3,7 @@
 parameter broadcast, and that the backward-order ranges are contiguous, disjoint and cover every parameter."""
 import os
 
+import numpy as np
 import pytest
 import torch
 import torch.distributed as dist
@@ -184,3 +185,80 @@ def test_engine_ranges_are_final_when_announced(tmp_path):
     out = str(tmp_path / "ok")
     mp.spawn(_engine_worker, args=(2, 31500 + (os.getpid() % 2000), out), nprocs=2, join=True)
     assert open(out).read().startswith("ok")
+
+
+# ------------------------------------------------------------------------------------------------------------------------
+# The training driver (poseidon_amd/train.py) under data parallelism: two ranks, the epoch's permutation sharded
+# DistributedSampler-style, the mean gradient exchanged after every step -> both replicas hold the SAME parameters after
+# training (DDP's invariant), they differ from what either rank would have learnt alone, and evaluation / prediction return the
+# whole dataset in order on every rank.
+def _trainer_worker(rank, world, port, out):
+    import sys
+    here = os.path.dirname(os.path.abspath(__file__))
+    sys.path.insert(0, os.path.join(here, "hipemu"))
+    sys.path.insert(0, here)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), SCOT_SIDE_STREAM="0")
+    import emu_session
+    import scOT.model as M
+    from poseidon_amd import ops
+    from poseidon_amd.synth import synth_state_dict
+    from scOT.trainer import Trainer, TrainingArguments
+    from test_trainer_emu_cpu import Samples
+    lib = emu_session.load_emu()
+    ws = torch.empty(32 << 20, dtype=torch.uint8)
+    ops.L, ops.stream, ops.workspace, ops.WORKSPACE_BYTES = (lambda: ops._Recording(lib, ops._recorder) if ops._recorder is not None else lib), \
+        (lambda: None), (lambda: ws), 32 << 20
+    ops.ptr = lambda t: None if t is None else t.data_ptr()
+    M._require_hip = lambda t: None
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    cfg = ScOTConfig(**dict(TINY, mlp_ratio=4.0, qkv_bias=True, p=1, channel_slice_list_normalized_loss=[0, 1, 3, 4], drop_path_rate=0.0))
+    sd = synth_state_dict(param_shapes(cfg), "trained")
+
+    def fit(use_dist):
+        model = M.ScOT(cfg, compute="fp32")
+        model.load_state_dict(sd)
+        if rank == 1 and use_dist:          # a replica that starts elsewhere: the trainer broadcasts rank 0's weights first
+            with torch.no_grad():
+                for p in model.parameters():
+                    p.add_(0.01)
+        tr = Trainer(model, TrainingArguments(per_device_train_batch_size=2, per_device_eval_batch_size=2, num_train_epochs=1, learning_rate=1e-3,
+                                              lr_scheduler_type="linear", logging_steps=1, max_grad_norm=5.0, dp_exchange="after"),
+                     train_dataset=Samples(7, cfg, 0), eval_dataset=Samples(5, cfg, 1))
+        if not use_dist:
+            tr.dist, tr.world, tr.rank = None, 1, 0
+        return tr, tr.train()
+
+    tr, res = fit(True)
+    assert res.global_step == 2                      # 7 samples -> 4 per rank (one wrapped) -> 2 batches of 2
+    flat = tr.model.flat_parameters().clone()
+    both = [torch.empty_like(flat) for _ in range(world)]
+    dist.all_gather(both, flat)
+    assert torch.equal(both[0], both[1])             # replicas in lock-step
+    losses = [h["loss"] for h in tr.state["log_history"] if "loss" in h]
+    gathered = [None, None]
+    dist.all_gather_object(gathered, losses)
+    assert gathered[0] == gathered[1]                # the logged loss is the mean over the ranks
+    ev = tr.evaluate()
+    pr = tr.predict(Samples(5, cfg, 1), metric_key_prefix="t")
+    assert pr.predictions.shape == (5, 4, 32, 32) and pr.metrics["t_loss"] == pytest.approx(ev["eval_loss"], rel=1e-6)
+    solo_tr, _ = fit(False)                          # the same recipe without the exchange, on this process alone
+    single = solo_tr.predict(Samples(5, cfg, 1), metric_key_prefix="t")
+    assert single.predictions.shape == pr.predictions.shape and np.array_equal(single.label_ids, pr.label_ids)   # gathered back in dataset order
+    assert not torch.equal(solo_tr.model.flat_parameters(), flat)
+    dist.barrier()
+    dist.destroy_process_group()
+    if rank == 0:
+        open(out, "w").write("ok")
+
+
+def test_trainer_two_ranks_stay_in_lock_step(tmp_path):
+    import shutil
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "hipemu"))
+    import build_emu
+    if not (os.path.exists(build_emu.CLANG) or shutil.which(build_emu.CLANG)):
+        pytest.skip("no host clang with __bf16 vector support")
+    build_emu.build_cached()
+    out = str(tmp_path / "ok")
+    mp.spawn(_trainer_worker, args=(2, 33500 + (os.getpid() % 2000), out), nprocs=2, join=True)
+    assert open(out).read() == "ok"

@@ -2,6 +2,8 @@
 (b) the CPU oracle on the same closed-form inputs.  compute='fp32' must meet the 1e-5 class bound; compute='bf16'
 is reported against the north-star 1e-3 on both parameter regimes (bf16 GEMM operands alone put the
 reference itself at 6e-3..2e-2 on trained-like weights, so the trained-regime bound asserted here is looser)."""
+import math
+
 import numpy as np
 import pytest
 import torch
@@ -688,3 +690,35 @@ def test_grad_ranges_are_final_when_announced(compute):
     finally:
         eng.on_grads_final = None
         eng.reset_tapes()
+
+
+def test_trainer_on_device_resident_dataset():
+    """The driver with the reference trainer's surface on the GPU: fused arena-wide AdamW (reference's four parameter groups), cosine
+    schedule, batches gathered from HBM-resident trajectories, evaluation through the reference-style sample dicts."""
+    from scOT.problems.base import get_dataset
+    from scOT.trainer import FusedAdamW, Trainer, TrainingArguments
+    rng = np.random.default_rng(0)
+    x = rng.standard_normal((12, 21, 5, 32, 32)).astype(np.float32)
+    rd = {"data": np.cumsum(0.2 * x, axis=1).astype(np.float32)}            # trajectories with some temporal structure
+    kw = dict(reader=rd, n_max=12, n_val=3, n_test=3, max_num_time_steps=3, time_step_size=2)
+    train = get_dataset("fluids.compressible.Riemann", which="train", num_trajectories=6, **kw)
+    val = get_dataset("fluids.compressible.Riemann", which="val", num_trajectories=6, **kw)
+    for d in (train, val):
+        d.resolution = 32
+    f, meta = load_fixture("tiny_trained")
+    cfg, model = build(meta, "fp16")
+    args = TrainingArguments(per_device_train_batch_size=8, per_device_eval_batch_size=8, num_train_epochs=2, learning_rate=1e-3,
+                             learning_rate_embedding_recovery=5e-4, weight_decay=0.01, lr_scheduler_type="cosine", warmup_ratio=0.1,
+                             logging_steps=1, max_grad_norm=5.0)
+    tr = Trainer(model=model, args=args, train_dataset=train.to_device(DEV), eval_dataset=val,
+                 compute_metrics=lambda p: {"l1": float(np.abs(p.predictions - p.label_ids).mean())})
+    before = tr.evaluate()
+    out = tr.train()
+    after = tr.evaluate()
+    assert isinstance(tr.optimizer, FusedAdamW) and len(tr.optimizer.param_groups) == 3
+    steps = 2 * math.ceil(len(train) / 8)
+    assert out.global_step == steps and len([h for h in tr.state["log_history"] if "grad_norm" in h]) == steps
+    assert after["eval_loss"] < before["eval_loss"] and after["eval_l1"] < before["eval_l1"] and int(model._engine.grad_overflow) == 0
+    tr.set_ar_steps([1, 1])
+    p = tr.predict(val, metric_key_prefix="")
+    assert p.predictions.shape == (len(val), 4, 32, 32) and np.isfinite(p.metrics["_loss"])
