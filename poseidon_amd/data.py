@@ -545,9 +545,23 @@ class DeviceTrajectories:
         return out
 
 
+class _TimeDependent(type(PDEDataset)):
+    def __instancecheck__(cls, obj):
+        return isinstance(obj, PDEDataset) and (not obj.steady or obj.time_wrapped)
+
+
+class BaseDataset(PDEDataset):
+    """reference base.py:163-285 as a type: every dataset of the registry is one (`isinstance(ds, BaseDataset)`)"""
+
+
+class BaseTimeDataset(PDEDataset, metaclass=_TimeDependent):
+    """reference base.py:288-369 / 372-395 as a type: `isinstance(ds, BaseTimeDataset)` is how the reference's drivers ask whether
+    samples carry a `time` (train.py:227-231, inference.py:74,224) — true for the time-dependent readers and for `.time`-wrapped ones."""
+
+
 def get_dataset(dataset, **kwargs):
     """reference `get_dataset` (base.py:15-160): name -> dataset (".out": more time steps, ".tracer", ".time": a time-independent
     dataset with time = 1.0); a list of names -> torch ConcatDataset."""
     if isinstance(dataset, (list, tuple)):
         return torch.utils.data.ConcatDataset([get_dataset(d, **kwargs) for d in dataset])
-    return PDEDataset(dataset, **kwargs)
+    return BaseDataset(dataset, **kwargs)

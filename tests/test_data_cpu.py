@@ -254,3 +254,21 @@ def test_device_batch_matches_getitem(name, key, C, monkeypatch):
         assert float(got["time"][k]) == pytest.approx(s["time"]) and got["pixel_mask"][k].tolist() == s["pixel_mask"].tolist()
     with pytest.raises(IndexError):
         dev.batch([len(dev)])
+
+
+def test_reference_type_names_and_size_helpers():
+    """What the reference's drivers import besides get_dataset: `BaseTimeDataset` for their `time_involved` isinstance checks
+    (train.py:227-231, inference.py:74) and the two parameter counters of scOT/utils.py."""
+    from scOT.problems.base import BaseDataset, BaseTimeDataset, get_dataset
+    from scOT.utils import get_num_parameters, get_num_parameters_no_embed
+    rng = np.random.default_rng(0)
+    f = lambda *s: rng.standard_normal(s).astype(np.float32)
+    kw = dict(which="val", num_trajectories=3, n_max=12, n_val=4, n_test=3)
+    wave = get_dataset("wave.Layer", reader={"solution": f(12, 21, 16, 16), "c": f(12, 16, 16)}, **kw)
+    po = {"source": f(12, 16, 16), "solution": f(12, 16, 16)}
+    steady, wrapped = get_dataset("elliptic.poisson.Gaussians", reader=po, **kw), get_dataset("elliptic.poisson.Gaussians.time", reader=po, **kw)
+    assert all(isinstance(d, BaseDataset) for d in (wave, steady, wrapped))
+    assert isinstance(wave, BaseTimeDataset) and isinstance(wrapped, BaseTimeDataset) and not isinstance(steady, BaseTimeDataset)
+    m = torch.nn.ModuleDict({"embeddings": torch.nn.Linear(3, 2), "body": torch.nn.Linear(2, 2), "patch_recovery": torch.nn.Linear(2, 1)})
+    m["body"].bias.requires_grad_(False)
+    assert get_num_parameters(m) == 8 + 4 + 3 and get_num_parameters_no_embed(m) == 4
