@@ -121,6 +121,10 @@ int scot_window_attn_fwd(int compute, const void* qkv, void* out, float* lse, co
 int scot_window_attn_bwd(int compute, const void* qkv, const void* out_fwd, const void* dout, const float* lse, const float* bias_table,
                          const float* logit_scale, void* dqkv, float* dbias_table, float* dlogit_scale, int batch,
                          int Hp, int Wp, int C, int heads, int ws, int shift, scot_stream_t stream);
+/* Attention probabilities of one block, [batch·nW, heads, N, N] fp32, recomputed from qkv and the forward's log-sum-exp — what
+ * `output_attentions=True` returns (HF:443-455; the fused kernels never store them).  head_dim <= 64, N·head_dim·4 <= 64 KB. */
+int scot_window_attn_probs(const void* qkv, int qkv_dt, const float* lse, const float* bias_table, const float* logit_scale,
+                           float* probs, int batch, int Hp, int Wp, int C, int heads, int ws, int shift, scot_stream_t stream);
 
 /* Continuous relative position bias MLP, HF:376-378,418-428 (coords table HF:457-476 is passed in). */
 int scot_cpb_fwd(const float* coords, const float* w0, const float* b0, const float* w2, float* table, float* z, int ws,

@@ -116,8 +116,9 @@ def gelu(x: Tensor) -> Tensor:
     return 0.5 * x * (1.0 + torch.erf(x * 0.7071067811865476))
 
 
-def attention(sd, prefix: str, xw: Tensor, heads: int, ws: int, mask: Optional[Tensor]) -> Tensor:
-    """Swinv2SelfAttention + SelfOutput on windows xw [Bw, N, C] (HF:389-455, 502-506)."""
+def attention(sd, prefix: str, xw: Tensor, heads: int, ws: int, mask: Optional[Tensor], attn_sink: Optional[list] = None) -> Tensor:
+    """Swinv2SelfAttention + SelfOutput on windows xw [Bw, N, C] (HF:389-455, 502-506).  attn_sink: receives the attention
+    probabilities [Bw, heads, N, N] (what `output_attentions=True` returns, HF:443-455)."""
     bw, n, c = xw.shape
     d = c // heads
     p = prefix + ".self."
@@ -145,12 +146,14 @@ def attention(sd, prefix: str, xw: Tensor, heads: int, ws: int, mask: Optional[T
         s = s.view(bw // nw, nw, heads, n, n) + 2.0 * mask.view(1, nw, 1, n, n)  # added twice (HF:433-436)
         s = s.view(bw, heads, n, n)
     pr = torch.softmax(s, dim=-1)
+    if attn_sink is not None:
+        attn_sink.append(pr)
     o = (pr @ v).transpose(1, 2).reshape(bw, n, c)
     return o @ sd[prefix + ".output.dense.weight"].t() + sd[prefix + ".output.dense.bias"]
 
 
 def scot_layer(sd, prefix: str, x: Tensor, hw: Tuple[int, int], time, heads: int, target_window: int,
-               target_shift: int, eps: float, cond: bool, drop_masks=None) -> Tensor:
+               target_shift: int, eps: float, cond: bool, drop_masks=None, attn_sink: Optional[list] = None) -> Tensor:
     """ScOTLayer.forward (model.py:500-581) — res-post-norm.  drop_masks: {(prefix, 0|1): [B] mask/keep_prob} =
     Swinv2DropPath (HF:565-586) on the two normed branches (model.py:570,574) with the random draw supplied."""
     h, w = hw
@@ -166,7 +169,7 @@ def scot_layer(sd, prefix: str, x: Tensor, hw: Tuple[int, int], time, heads: int
     nw, n = idx.shape
     xw = xg.reshape(b, hp * wp, c)[:, idx.reshape(-1)].reshape(b * nw, n, c)
     mask = shift_mask(hp, wp, ws, shift)
-    aw = attention(sd, prefix + ".attention", xw, heads, ws, mask)
+    aw = attention(sd, prefix + ".attention", xw, heads, ws, mask, attn_sink)
     out = torch.zeros(b, hp * wp, c, dtype=x.dtype)
     out[:, idx.reshape(-1)] = aw.reshape(b, nw * n, c)
     out = out.view(b, hp, wp, c)[:, :h, :w].reshape(b, l, c)
@@ -281,8 +284,11 @@ def spectral_resize(img: Tensor, target: int) -> Tensor:
 
 def scot_forward(sd: Dict[str, Tensor], cfg, pixel_values: Tensor, time: Optional[Tensor] = None,
                  labels: Optional[Tensor] = None, pixel_mask: Optional[Tensor] = None,
-                 return_intermediates: bool = False, drop_masks=None, bool_masked_pos: Optional[Tensor] = None):
-    """ScOT.forward (model.py:1318-1509) → (loss or None, prediction[, intermediates])."""
+                 return_intermediates: bool = False, drop_masks=None, bool_masked_pos: Optional[Tensor] = None,
+                 output_attentions: bool = False):
+    """ScOT.forward (model.py:1318-1509) → (loss or None, prediction[, intermediates]).  output_attentions: intermediates["attentions"]
+    = the attention probabilities of every stage's LAST block, decoder stages first (model.py:859-860, 959-960, 1084-1085, 1225-1226,
+    1497-1501) — implies return_intermediates."""
     if pixel_values is None:
         raise ValueError("pixel_values cannot be None")
     image_size = _get(cfg, "image_size")
@@ -295,6 +301,9 @@ def scot_forward(sd: Dict[str, Tensor], cfg, pixel_values: Tensor, time: Optiona
     skips_cfg = list(_get(cfg, "skip_connections"))
     nl = len(depths)
     inter = {}
+    enc_attn: List[Tensor] = []
+    dec_attn: List[Tensor] = []
+    return_intermediates = return_intermediates or output_attentions
 
     in_size = pixel_values.shape[2]
     if in_size != image_size:
@@ -316,7 +325,8 @@ def scot_forward(sd: Dict[str, Tensor], cfg, pixel_values: Tensor, time: Optiona
         stage_in = x
         for i in range(depths[s]):
             cw, cs = ctor_window_shift(gh // (2 ** s), window, 0 if i % 2 == 0 else window // 2)
-            x = scot_layer(sd, f"encoder.layers.{s}.blocks.{i}", x, hw, time, heads[s], cw, cs, eps, cond, drop_masks)
+            x = scot_layer(sd, f"encoder.layers.{s}.blocks.{i}", x, hw, time, heads[s], cw, cs, eps, cond, drop_masks,
+                           enc_attn if (output_attentions and i == depths[s] - 1) else None)
         skip_states.append(x)  # hidden_states_before_downsampling
         inter[f"enc{s}"] = x
         if s < nl - 1:
@@ -342,7 +352,8 @@ def scot_forward(sd: Dict[str, Tensor], cfg, pixel_values: Tensor, time: Optiona
         for j in range(depth):
             i = depth - 1 - j  # blocks are built for i in reversed(range(depth)) (model.py:885-902)
             cw, cs = ctor_window_shift(gh // (2 ** i_layer), window, 0 if i % 2 == 0 else window // 2)
-            x = scot_layer(sd, f"decoder.layers.{k}.blocks.{j}", x, hw, time, heads[i_layer], cw, cs, eps, cond, drop_masks)
+            x = scot_layer(sd, f"decoder.layers.{k}.blocks.{j}", x, hw, time, heads[i_layer], cw, cs, eps, cond, drop_masks,
+                           dec_attn if (output_attentions and j == depth - 1) else None)
         inter[f"dec{k}"] = x
         if i_layer > 0:
             up = (gh // (2 ** (i_layer - 1)), gw // (2 ** (i_layer - 1)))
@@ -360,6 +371,8 @@ def scot_forward(sd: Dict[str, Tensor], cfg, pixel_values: Tensor, time: Optiona
     loss = None
     if labels is not None:
         loss = scot_loss(pred, labels, _get(cfg, "p", 1), _get(cfg, "channel_slice_list_normalized_loss"))
+    if output_attentions:
+        inter["attentions"] = tuple(dec_attn) + tuple(enc_attn)
     if return_intermediates:
         return loss, pred, inter
     return loss, pred

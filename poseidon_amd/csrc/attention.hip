@@ -510,6 +510,55 @@ extern "C" int scot_window_attn_fwd(int compute, const void* qkv, void* out, flo
                               : dispatch_hd<float>(a, C / heads, nwin, false, stream);
 }
 
+// ------------------------------------------------------------------ attention probabilities (`output_attentions=True`, HF:443-455)
+// The fused kernels never materialise the softmax; a caller that asks for it gets it from this separate, simple kernel: workgroup
+// = (window, head), thread = query; the window's normalised keys sit in LDS as fp32 (every thread reads the same key row: a
+// broadcast), P[q][k] = exp(cos(q, k)·scale + bias(q - k) + mask(q, k) - lse[q]) with the forward's log-sum-exp.  Off the hot path.
+__global__ __launch_bounds__(256) void attn_probs_kernel(AttnArgs p, int qkv_dt, float* __restrict__ probs, int HD) {
+  extern __shared__ __attribute__((aligned(16))) float kn[];      // [N][HD]
+  const int win = blockIdx.x, h = blockIdx.y, tid = threadIdx.x;
+  const int N = p.ws * p.ws, ld = 3 * p.C, TW = 2 * p.ws - 1;
+  for (int i = tid; i < N; i += blockDim.x) {
+    const size_t base = (size_t)win_token(p, win, i) * ld + p.C + h * HD;
+    float ss = 0.f;
+    for (int d = 0; d < HD; ++d) { const float v = ld1(p.qkv, qkv_dt, base + d); kn[i * HD + d] = v; ss += v * v; }
+    const float r = 1.0f / fmaxf(sqrtf(ss), 1e-12f);
+    for (int d = 0; d < HD; ++d) kn[i * HD + d] *= r;
+  }
+  __syncthreads();
+  const float scale = __expf(fminf(p.logit_scale[h], 4.605170185988092f));
+  for (int q = tid; q < N; q += blockDim.x) {
+    float qv[64];
+    const size_t base = (size_t)win_token(p, win, q) * ld + h * HD;
+    float ss = 0.f;
+    for (int d = 0; d < HD; ++d) { qv[d] = ld1(p.qkv, qkv_dt, base + d); ss += qv[d] * qv[d]; }
+    const float r = scale / fmaxf(sqrtf(ss), 1e-12f);
+    const float lse = p.lse[((size_t)win * p.heads + h) * N + q];
+    const int rq = win_region(p, win, q), qy = q / p.ws, qx = q % p.ws;
+    float* out = probs + (((size_t)win * p.heads + h) * N + q) * N;
+    for (int k = 0; k < N; ++k) {
+      float dot = 0.f;
+      for (int d = 0; d < HD; ++d) dot = fmaf(qv[d], kn[k * HD + d], dot);
+      float sv = dot * r + p.bias_table[h * TW * TW + (qy - k / p.ws + p.ws - 1) * TW + (qx - k % p.ws + p.ws - 1)];
+      if (win_region(p, win, k) != rq) sv -= 200.0f;               // the -100 mask, added twice (HF:433-436)
+      out[k] = __expf(sv - lse);
+    }
+  }
+}
+extern "C" int scot_window_attn_probs(const void* qkv, int qkv_dt, const float* lse, const float* bias_table, const float* logit_scale,
+                                      float* probs, int batch, int Hp, int Wp, int C, int heads, int ws, int shift, hipStream_t stream) {
+  AttnArgs a{};
+  const int rc = fill_args(a, batch, Hp, Wp, C, heads, ws, shift);
+  if (rc) return rc;
+  const int HD = C / heads, N = ws * ws;
+  if (HD > 64 || (qkv_dt & ~1)) return SCOT_ERR_UNSUPPORTED;
+  const size_t sh = (size_t)N * HD * sizeof(float);
+  if (sh > 64 * 1024) return SCOT_ERR_UNSUPPORTED;
+  a.qkv = qkv; a.lse = (float*)lse; a.bias_table = bias_table; a.logit_scale = logit_scale;
+  hipLaunchKernelGGL(attn_probs_kernel, dim3(batch * a.nw_per_img, heads), dim3(256), sh, stream, a, qkv_dt, probs, HD);
+  return scot_check_launch();
+}
+
 extern "C" int scot_window_attn_bwd(int compute, const void* qkv, const void* out_fwd, const void* dout, const float* lse,
                                     const float* bias_table, const float* logit_scale, void* dqkv,
                                     float* dbias_table, float* dlogit_scale, int batch, int Hp, int Wp, int C,

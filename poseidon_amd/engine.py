@@ -149,6 +149,7 @@ class ScOTEngine:
         self.scale_grads = compute == "fp16" and os.environ.get("SCOT_GRAD_SCALE", "auto") != "1"
         self.grad_overflow = torch.zeros(1, dtype=torch.int32, device=self.device) if self.scale_grads else None
         self.grads_are_zero = False   # set by ScOT.zero_grad / _prepare_grads: the arena needs no pre-scaling then
+        self.collect_attn, self.attn_sink = False, []   # output_attentions: one probability tensor per stage (encoder stages first)
         # ... and one global scale cannot also lift the gradients of a branch behind a ~1e-6 layer scale (2^-20 below the rest):
         # the ConvNeXt skip blocks run their backward under an extra, device-side power of two (convnext_bwd)
         self._gredirect, self._ls = None, {}
@@ -512,7 +513,7 @@ class ScOTEngine:
     # serialised, everything else they accumulate into is atomic.
     def chains_for(self, rows: int, B: int) -> int:
         n = self.chains
-        if n <= 1 or rows > self.chain_rows or B % n:
+        if n <= 1 or rows > self.chain_rows or B % n or self.collect_attn:
             return 1
         return n
 
@@ -544,7 +545,9 @@ class ScOTEngine:
         if n == 1:
             recs, q = [], None
             for i, blk in enumerate(blocks):
-                x, x16, r, q = self.layer_fwd(blk, x, x16, B, time, train, qkv_pre=q, next_blk=blocks[i + 1] if i + 1 < len(blocks) else None)
+                last = i + 1 == len(blocks)
+                x, x16, r, q = self.layer_fwd(blk, x, x16, B, time, train, qkv_pre=q, next_blk=None if last else blocks[i + 1],
+                                              want_attn=self.collect_attn and last)      # (a stage returns its LAST block's, ref:859-860)
                 recs.append(r)
             return x, x16, recs
         Bc = B // n
@@ -634,7 +637,7 @@ class ScOTEngine:
         ws, _ = blk.window_shift()
         return H % ws == 0 and W % ws == 0 and blk.dim in self.fused_next_qkv and not self.precision_probe
 
-    def layer_fwd(self, blk: BlockGeom, x, x16, B, time, train, qkv_pre=None, next_blk=None):
+    def layer_fwd(self, blk: BlockGeom, x, x16, B, time, train, qkv_pre=None, next_blk=None, want_attn=False):
         """reference ScOTLayer.forward (model.py:500-581) + Swinv2Attention/Intermediate/Output (HF:389-561).  qkv_pre: this layer's
         q/k/v projection, already produced by the previous layer's fused tail; next_blk: the layer that follows in the same stage
         (its projection becomes this tail's epilogue when the fused tail runs).  Returns (out, out16, rec, qkv_next or None)."""
@@ -672,6 +675,10 @@ class ScOTEngine:
         nW = (Hp // ws) * (Wp // ws)
         lse = self.new(B * nW, heads, ws * ws)
         ops.window_attn_fwd(self.acm, qkv, attn, lse, table, self.P(a + "logit_scale"), B, Hp, Wp, C, heads, ws, shift)
+        if want_attn:     # output_attentions: the probabilities are recomputed from qkv and lse by a separate kernel, into fresh memory
+            probs = torch.empty(B * nW, heads, ws * ws, ws * ws, dtype=torch.float32, device=self.device)
+            ops.window_attn_probs(qkv, lse, table, self.P(a + "logit_scale"), probs, B, Hp, Wp, C, heads, ws, shift)
+            self.attn_sink.append(probs)
         if padded:
             attn_c = self.new(B * L, C, dtype=self.adt)
             ops.copy2d(attn, attn_c, B, Hp, Wp, H, W, C)
@@ -1096,7 +1103,7 @@ class ScOTEngine:
         (forward-forward-backward-backward, the reference's AR training loop trainer.py:466-490, takes the untaped path for
         the second forward); loss and prediction are returned as fresh tensors, never as views of the recorded buffers."""
         self.stochastic = bool(train if stochastic is None else stochastic)
-        if not (train and self.tape_mode and labels is not None and not self.stage_timing) or self._capturing():
+        if not (train and self.tape_mode and labels is not None and not self.stage_timing and not self.collect_attn) or self._capturing():
             return self._forward(pixel_values, time, labels, pixel_mask, train)
         key = (tuple(pixel_values.shape), None if time is None else tuple(time.shape), tuple(labels.shape),
                None if pixel_mask is None else (tuple(pixel_mask.shape), pixel_mask.dtype), self._stream_id(), self.stochastic)
@@ -1228,6 +1235,7 @@ class ScOTEngine:
         C0 = cfg.embed_dim
         L0 = gh * gw
         tape = dict(B=B, time=time, enc=[], dec=[], res=[]) if train else None
+        self.attn_sink = []
         ev_cpb = ev_cast = None
 
         def cpb_all():

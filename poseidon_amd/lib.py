@@ -28,6 +28,7 @@ PROTOTYPES = {
     "scot_gemm": [I, I, I, I, I, P, I, I, I, P, I, I, I, P, I, I, P, P, P, I, I, P, I, I, I, P, P, Z, I, P, P],
     "scot_wgrad_group": [I, I, I, P, P, P, P, P, P, P, Z, P],
     "scot_window_attn_fwd": [I, P, P, P, P, P, I, I, I, I, I, I, I, P],
+    "scot_window_attn_probs": [P, I, P, P, P, P, I, I, I, I, I, I, I, P],
     "scot_window_attn_bwd": [I, P, P, P, P, P, P, P, P, P, I, I, I, I, I, I, I, P],
     "scot_cpb_fwd": [P, P, P, P, P, P, I, I, P],
     "scot_cpb_bwd": [P, P, P, P, P, P, P, P, P, I, I, P],

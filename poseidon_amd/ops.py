@@ -202,6 +202,12 @@ def window_attn_fwd(compute, qkv, out, lse, bias_table, logit_scale, batch, Hp, 
                                         C, heads, ws, shift, stream()), "scot_window_attn_fwd")
 
 
+def window_attn_probs(qkv, lse, bias_table, logit_scale, probs, batch, Hp, Wp, C, heads, ws, shift):
+    """probs [batch·nW, heads, N, N] fp32 <- the block's attention probabilities, from qkv and the forward's lse (output_attentions)."""
+    _lib.check(L().scot_window_attn_probs(ptr(qkv), dt(qkv), ptr(lse), ptr(bias_table), ptr(logit_scale), ptr(probs), batch, Hp, Wp, C,
+                                          heads, ws, shift, stream()), "scot_window_attn_probs")
+
+
 def window_attn_bwd(compute, qkv, out_fwd, dout, lse, bias_table, logit_scale, dqkv, dbias_table, dlogit_scale, batch, Hp, Wp, C,
                     heads, ws, shift):
     _lib.check(L().scot_window_attn_bwd(compute, ptr(qkv), ptr(out_fwd), ptr(dout), ptr(lse), ptr(bias_table), ptr(logit_scale), ptr(dqkv),

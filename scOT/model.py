@@ -390,8 +390,7 @@ class ScOT(nn.Module):
         return_dict = return_dict if return_dict is not None else cfg.use_return_dict
         if pixel_values is None:
             raise ValueError("pixel_values cannot be None")
-        if output_attentions or (output_attentions is None and cfg.output_attentions):
-            raise NotImplementedError("attention probabilities are never materialised by the fused kernel")
+        want_attn = bool(output_attentions or (output_attentions is None and getattr(cfg, "output_attentions", False)))
         if bool_masked_pos is not None and not self.use_mask_token:
             raise ValueError("bool_masked_pos needs ScOT(config, use_mask_token=True) (reference model.py:323-327, 353-359)")
         if head_mask is not None:
@@ -419,6 +418,7 @@ class ScOT(nn.Module):
             if resized:
                 raise ValueError("bool_masked_pos indexes the patch grid of config.image_size: no spectral resize with it")
             bmp = bool_masked_pos.to(device=dev).reshape(B, -1).contiguous()
+        self._engine.collect_attn = want_attn     # (read by the engine during this call only; reset below)
         if resized and (lab is not None or pixel_mask is not None):
             # reference order (model.py:1416-1484): resize the prediction back first, then mask + loss at input resolution
             loss, pred = self._forward_resized(pv, t, lab, pixel_mask, in_size, want_grad)
@@ -432,21 +432,30 @@ class ScOT(nn.Module):
                 loss = loss.view(())
             if resized:
                 pred = self._upsample(pred, in_size) if in_size > cfg.image_size else self._downsample(pred, in_size)
+        self._engine.collect_attn = False
         hs = rhs = None
         want_hs = bool(output_hidden_states or (output_hidden_states is None and cfg.output_hidden_states))
         if want_hs or not return_dict:
             hd, he = self._engine.last_hidden
             hs, rhs, enc_hs, enc_rhs, dec_hs, dec_rhs = self._hidden_tuples(hd, he, B)
+        enc_at = dec_at = None
+        if want_attn:
+            # one probability tensor [B·nW, heads, N, N] per stage (its last block: reference model.py:859-860, 959-960), collected in
+            # execution order: the encoder's stages, then the decoder's
+            sink, nl = self._engine.attn_sink, len(cfg.depths)
+            enc_at, dec_at = tuple(sink[:nl]), tuple(sink[nl:])
+            self._engine.attn_sink = []
         if not return_dict:
             # reference model.py:1486-1488: (prediction,) + decoder_output[1:] + encoder_outputs[1:].  In tuple mode a stage
             # stack returns (last, all_hidden_states[, attentions]) without the reshaped copies (model.py:1087-1092, 1228-1233);
             # the decoder gets the caller's output_hidden_states, the ENCODER always True (model.py:1371-1378), so the
-            # encoder's hidden states are always the last element
-            out = (pred,) + ((dec_hs,) if want_hs else ()) + (enc_hs,)
+            # encoder's hidden states are always present
+            out = (pred,) + ((dec_hs,) if want_hs else ()) + ((dec_at,) if want_attn else ()) + (enc_hs,) + ((enc_at,) if want_attn else ())
             return ((loss,) + out) if loss is not None else out
         if not want_hs:
             hs = rhs = None
-        return ScOTOutput(loss=loss, output=pred, hidden_states=hs, attentions=None, reshaped_hidden_states=rhs)
+        return ScOTOutput(loss=loss, output=pred, hidden_states=hs, attentions=(dec_at + enc_at) if want_attn else None,
+                          reshaped_hidden_states=rhs)
 
     def _forward_resized(self, pv, t, lab, pixel_mask, in_size, want_grad):
         cfg = self.config

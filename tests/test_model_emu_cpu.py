@@ -258,3 +258,32 @@ def test_step_tape_forward_forward_backward_backward(emu, monkeypatch):
     assert res["0"][0] == pytest.approx(res["1"][0], rel=1e-6) and res["0"][1] == pytest.approx(res["1"][1], rel=1e-6)
     assert rel_l2(res["1"][2].numpy(), res["0"][2].numpy()) < 1e-6 and rel_l2(res["1"][3].numpy(), res["0"][3].numpy()) < 1e-6
     assert rel_l2(res["1"][4].numpy(), res["0"][4].numpy()) < 1e-5
+
+
+def test_output_attentions_match_reference(emu, monkeypatch):
+    """`output_attentions=True` (tests/golden/make_attentions_fixture.py, real reference): `ScOTOutput.attentions` = the attention
+    probabilities of every stage's last block, decoder stages first — recomputed from qkv and the forward's log-sum-exp by
+    scot_window_attn_probs; the positional tuple of `return_dict=False` carries them behind each stack's hidden states."""
+    import scOT.model as M
+    monkeypatch.setattr(M, "_require_hip", lambda t: None)
+    f, meta = load_fixture("tiny_attentions")
+    cfg = ScOTConfig(**meta["cfg"])
+    model = M.ScOT(cfg, compute="fp32")
+    model.load_state_dict(synth_state_dict(param_shapes(cfg), meta["regime"]))
+    model.eval()
+    pv, t, lab = synth_inputs(meta["batch"], cfg.num_channels, cfg.num_out_channels, cfg.image_size, meta["kind"])
+    with torch.no_grad():
+        out = model(pixel_values=pv, time=t, labels=lab, output_attentions=True)
+        tup = model(pixel_values=pv, time=t, labels=lab, output_attentions=True, output_hidden_states=True, return_dict=False)
+        plain = model(pixel_values=pv, time=t, labels=lab)
+    assert plain.attentions is None and len(out.attentions) == meta["n_attn"]
+    for i, a in enumerate(out.attentions):
+        ref = f[f"attn:{i}"]
+        assert tuple(a.shape) == ref.shape and float((a - torch.from_numpy(ref)).abs().max()) < 3e-5, i
+        assert float((a.sum(-1) - 1).abs().max()) < 1e-5
+    assert rel_l2(out.output.numpy(), f["output"]) < 1e-5
+    assert [(-1 if torch.is_tensor(x) else len(x)) for x in tup] == f["tuple_layout"].tolist()
+    model.train()                                  # with gradients (the untaped training path), attentions are collected too
+    o2 = model(pixel_values=pv, time=t, labels=lab, output_attentions=True)
+    o2.loss.backward()
+    assert len(o2.attentions) == 4 and float((o2.attentions[1] - out.attentions[1]).abs().max()) < 1e-6

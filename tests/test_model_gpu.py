@@ -722,3 +722,36 @@ def test_trainer_on_device_resident_dataset():
     tr.set_ar_steps([1, 1])
     p = tr.predict(val, metric_key_prefix="")
     assert p.predictions.shape == (len(val), 4, 32, 32) and np.isfinite(p.metrics["_loss"])
+
+
+@pytest.mark.parametrize("compute,tol", [("fp32", 3e-5), ("fp16", 2e-2)])     # (fp16 on the 16-wide toy model: 6.5e-3 measured at the deepest stage)
+def test_output_attentions_match_reference(compute, tol):
+    """`output_attentions=True` against the real reference (tests/golden/make_attentions_fixture.py): one probability tensor per stage
+    (its last block), decoder stages first; the `return_dict=False` tuple carries them behind each stack's hidden states."""
+    f, meta = load_fixture("tiny_attentions")
+    cfg, model = build(meta, compute)
+    model.eval()
+    kw = inputs(cfg, meta)
+    with torch.no_grad():
+        out = model(**kw, output_attentions=True)
+        tup = model(**kw, output_attentions=True, output_hidden_states=True, return_dict=False)
+    assert len(out.attentions) == meta["n_attn"]
+    for i, a in enumerate(out.attentions):
+        ref = torch.from_numpy(f[f"attn:{i}"]).to(a.device)
+        assert tuple(a.shape) == tuple(ref.shape) and float((a - ref).abs().max()) < tol, (i, float((a - ref).abs().max()))
+    assert [(-1 if torch.is_tensor(x) else len(x)) for x in tup] == f["tuple_layout"].tolist()
+
+
+def test_output_attentions_on_16x16_windows():
+    """Poseidon-T (16x16 windows: the fast-path kernels' log-sum-exp, shifted windows at stage 0): every row of every returned
+    probability tensor sums to 1 in the default fp16 mode."""
+    f, meta = load_fixture("poseidonT_trained")
+    cfg, model = build(meta, "fp16")
+    model.eval()
+    with torch.no_grad():
+        out = model(**inputs(cfg, meta), output_attentions=True)
+    assert len(out.attentions) == 2 * len(cfg.depths)
+    assert tuple(out.attentions[-len(cfg.depths)].shape) == (meta["batch"] * 4, cfg.num_heads[0], 256, 256)     # encoder stage 0: 2x2 windows of 16x16
+    for a in out.attentions:
+        assert float((a.sum(-1) - 1).abs().max()) < 2e-2 and float(a.min()) >= 0
+    assert rel_l2(out.output.detach().cpu().numpy(), f["output"]) < 1e-3

@@ -166,3 +166,19 @@ def test_drop_path_rate_schedule():
     mine = drop_path_rates(ScOTConfig(**meta["cfg"]))
     for k, r in pins["tiny"]["layers"].items():
         assert abs(mine[k] - r) < 1e-6, (k, mine[k], r)
+
+
+def test_oracle_attention_probabilities_match_reference():
+    """output_attentions (tests/golden/make_attentions_fixture.py, real reference): one [B·nW, heads, N, N] tensor per stage — its LAST
+    block's softmax — decoder stages first."""
+    f, meta = load_fixture("tiny_attentions")
+    cfg = ScOTConfig(**meta["cfg"])
+    sd = synth_state_dict(param_shapes(cfg), meta["regime"])
+    pv, t, lab = synth_inputs(meta["batch"], cfg.num_channels, cfg.num_out_channels, cfg.image_size, meta["kind"])
+    loss, pred, inter = scot_cpu.scot_forward(sd, cfg, pv, t, lab, output_attentions=True)
+    att = inter["attentions"]
+    assert len(att) == meta["n_attn"] == 4
+    for i, a in enumerate(att):
+        ref = f[f"attn:{i}"]
+        assert tuple(a.shape) == ref.shape and float((a - torch.from_numpy(ref)).abs().max()) < 3e-5, i      # (probabilities up to 1 in fp32, deep in the model: measured 6.5e-6)
+    assert rel_l2(pred.detach().numpy(), f["output"]) < 2e-6
