@@ -55,6 +55,8 @@ def parse():
                     help="N>1: all-reduce each gradient range from inside the backward as soon as it is final (RCCL on a side "
                          "stream, eager launches), or one chunked all-reduce after the step (works with hipGraph replay); "
                          "auto: time both in the warm-up, keep the faster; none: no exchange (diagnostic: what the process group costs)")
+    ap.add_argument("--launch-dump", default=None, help="write every launch of the replayed steps (entry point, integer arguments, "
+                                                        "stream, start/end in ms since the step's first launch) to this JSON file")
     ap.add_argument("--_cpu-worker", dest="cpu_worker", action="store_true", help=argparse.SUPPRESS)
     return ap.parse_args()
 
@@ -159,7 +161,7 @@ def parity_check(model_tag, compute, size, channels):
             "output_rel_l2": rel, "loss_rel": lrel, "bound": 1e-5 if compute == "fp32" else 1e-3, "meets_bound": rel < (1e-5 + 5e-6 if compute == "fp32" else 1e-3)}
 
 
-def launch_table(engine, run_step, nsteps=3):
+def launch_table(engine, run_step, nsteps=3, dump=None):
     """Per-launch GPU durations INSIDE real steps: the recorded step is replayed with a HIP-event pair around every C-ABI
     call, each pair on the stream the call launches on (main or weight-gradient side stream), so concurrency and cache state
     are the step's own.  Returns {family: {ms_per_step, launches_per_step, gflop_per_step}}, plus the worst wgrad instance."""
@@ -171,6 +173,13 @@ def launch_table(engine, run_step, nsteps=3):
     fam, inst = {}, {}
     main = torch.cuda.current_stream().cuda_stream
     chain_ms = 0.0
+    if dump and log:
+        # tools/launch_summary.py groups these by (entry point, shape arguments, stream): the per-stage view of the chain
+        rows, first = [], log[0][2]
+        for name, args, e0, e1 in log:
+            ints = [int(x) for x in args if isinstance(x, int) and not isinstance(x, bool) and -(1 << 31) < x < (1 << 31)]
+            rows.append([name, ints, int((args[-1] or 0) == main), round(first.elapsed_time(e0), 4), round(e0.elapsed_time(e1), 4)])
+        json.dump({"nsteps": nsteps, "rows": rows}, open(dump, "w"))
     for name, args, e0, e1 in log:
         ms = e0.elapsed_time(e1)
         if (args[-1] or 0) == main:
@@ -383,7 +392,7 @@ def main():
     try:   # every rank steps (under DP a step contains collectives); rank 0 reports
         eager = use_graph[0]
         use_graph[0] = False
-        table, worst = launch_table(model._engine, step)
+        table, worst = launch_table(model._engine, step, dump=a.launch_dump if rank == 0 else None)
         use_graph[0] = eager
     except Exception as e:  # pragma: no cover
         table_err = repr(e)

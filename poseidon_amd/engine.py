@@ -80,6 +80,11 @@ class ScOTEngine:
         self.skip_lane = int(os.environ.get("SCOT_SKIP_LANE", "0"))       # backward of the skip blocks: 1 = a second side stream (measured: 21.55 vs 21.43 ms, more overlap only slows the rest)
         self.side2 = None
         self.group_wgrads = os.environ.get("SCOT_GROUP_WGRAD", "1") == "1"
+        # TIMING-ONLY what-if switches (results are wrong with any of them set; tools/gpu_whatif.sh): "noact" = the fused forward tail
+        # does not store gelu(u) / gelu'(u) (the backward reads a stale dummy), "nomlpwgrad" = the fc1 / fc2 weight gradients of the
+        # fused stages are skipped, "nocast" = the 16-bit weight copies are made once and never refreshed
+        self.whatif = {w for w in os.environ.get("SCOT_WHATIF", "").split(",") if w}
+        self._whatif_dummy = {}
         self.arena = arena
         # bf16x3: activations and weights stay fp32 in HBM; the GEMMs split them into hi + lo bf16 while staging into LDS and
         # run three bf16 MFMAs per K-step (≈ fp32 accuracy at the bf16 MFMA rate); so do the 16x16-window attention kernels
@@ -698,6 +703,10 @@ class ScOTEngine:
             h, h16 = self.new(B * L, C), self.new(B * L, C, dtype=self.adt)
             u = self.new(B * L, hid, dtype=self.adt) if train else None
             gp = self.new(B * L, hid, dtype=self.adt) if train else None
+            u_st, gp_st = u, gp
+            if train and "noact" in self.whatif:
+                u_st = gp_st = None
+                u = gp = self._whatif_dummy.setdefault((B * L, hid), torch.ones(B * L, hid, dtype=self.adt, device=self.device))
             y2 = self.new(B * L, C) if train else None
             st2 = (self.new(B * L), self.new(B * L)) if train else (None, None)
             out, out16 = self.new(B * L, C), self.new(B * L, C, dtype=self.adt)
@@ -712,7 +721,7 @@ class ScOTEngine:
                 (attn_c, self.W(pre + ".attention.output.dense.weight"), self.P(pre + ".attention.output.dense.bias"), x, h, h16, proj,
                  st1[0], st1[1], n1[0], n1[1], n1[2], n1[3], dp1),
                 (self.W(pre + ".intermediate.dense.weight"), self.P(pre + ".intermediate.dense.bias"), self.W(pre + ".output.dense.weight"),
-                 self.P(pre + ".output.dense.bias"), out, out16, u, gp, y2, st2[0], st2[1], n2[0], n2[1], n2[2], n2[3], dp2),
+                 self.P(pre + ".output.dense.bias"), out, out16, u_st, gp_st, y2, st2[0], st2[1], n2[0], n2[1], n2[2], n2[3], dp2),
                 time if self.cond else None, B * L, L, C, hid, cfg.layer_norm_eps, *nq)
             if not done_tail:
                 qkv_next = None
@@ -876,8 +885,9 @@ class ScOTEngine:
             pend = None
             if done_tail:
                 g = gout
-                self.linear_bwd_params(pre + ".output.dense.weight", pre + ".output.dense.bias", d_y2, rec["u"])
-                self.linear_bwd_params(pre + ".intermediate.dense.weight", pre + ".intermediate.dense.bias", d_u, rec["h16"])
+                if "nomlpwgrad" not in self.whatif:
+                    self.linear_bwd_params(pre + ".output.dense.weight", pre + ".output.dense.bias", d_y2, rec["u"])
+                    self.linear_bwd_params(pre + ".intermediate.dense.weight", pre + ".intermediate.dense.bias", d_u, rec["h16"])
                 self.linear_bwd_params(pre + ".attention.output.dense.weight", pre + ".attention.output.dense.bias", d_proj, rec["attn_c"])
         if done_tail:
             pass
@@ -1241,7 +1251,12 @@ class ScOTEngine:
         def cpb_all():
             ops.cpb_fwd_batched(self.arena.data, self.cpb_desc, self.cpb_nlayers, self.cpb_max_ws, self.cpb_coords, self.cpb_tables,
                                 self.cpb_z)
-        if self.use_side and not self.stage_timing:
+        if "nocast" in self.whatif and self.shadow is not None and getattr(self, "_whatif_cast_done", False):
+            if self.use_side and not self.stage_timing:
+                _, ev_cpb = self.fork_task(cpb_all)
+            else:
+                cpb_all()
+        elif self.use_side and not self.stage_timing:
             # neither the bias tables (first used by the first attention kernel) nor the 16-bit copies of the deeper stages'
             # weights (99 % of the arena) are needed by the embedding / stage-0 chain: both go to the side stream
             _, ev_cpb = self.fork_task(cpb_all)
@@ -1267,6 +1282,7 @@ class ScOTEngine:
                     self.transpose_weights()
             cpb_all()
 
+        self._whatif_cast_done = True
         # embeddings (model.py:295-366)
         cols = self.new(B * L0, Cin * p * p, dtype=self.tadt)
         ops.patchify(pixel_values, cols, B, Cin, H, W, p)

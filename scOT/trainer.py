@@ -5,5 +5,6 @@ gradient arena, HBM-resident datasets), plus the harness pieces they are built f
 from poseidon_amd.harness import (compute_loss, conditional_norm_parameter_names, create_optimizer,  # noqa: F401
                                   decay_parameter_names, optimizer_param_groups, rollout)
 from poseidon_amd.optim import FusedAdamW  # noqa: F401  (arena-wide AdamW + grad-norm clip: 3 launches per step)
-from poseidon_amd.train import EvalPrediction, PredictionOutput, TrainOutput, Trainer, TrainingArguments, lr_lambda  # noqa: F401
+from poseidon_amd.train import (EarlyStoppingCallback, EvalPrediction, PredictionOutput, TrainerCallback, TrainerControl,  # noqa: F401
+                                TrainerState, TrainOutput, Trainer, TrainingArguments, checkpoints_in, lr_lambda)
 from scOT.model import ConditionalLayerNorm, LayerNorm  # noqa: F401

@@ -108,3 +108,171 @@ def test_trainer_trains_evaluates_and_predicts(emu, tmp_path):
     assert ar.predictions.shape == pred.predictions.shape and np.isfinite(ar.metrics["test_loss"]) and ar.metrics["test_loss"] != after["eval_loss"]
     tr.save_model()
     assert os.path.exists(os.path.join(str(tmp_path), "config.json"))
+
+
+def _reference_style_arguments(TrainingArguments, ckpt_dir, config, SEED=0, CPU_CORES=0, run_name=None, resume=False):
+    """The reference driver's `TrainingArguments(...)` call (reference scOT/train.py:277-323), keyword for keyword."""
+    return TrainingArguments(
+        output_dir=ckpt_dir,
+        overwrite_output_dir=True,
+        evaluation_strategy="epoch",
+        per_device_train_batch_size=config["batch_size"],
+        per_device_eval_batch_size=config["batch_size"],
+        eval_accumulation_steps=16,
+        max_grad_norm=config["max_grad_norm"],
+        num_train_epochs=config["num_epochs"],
+        optim="adamw_torch",
+        learning_rate=config["lr"],
+        learning_rate_embedding_recovery=None,
+        learning_rate_time_embedding=None,
+        weight_decay=config["weight_decay"],
+        adam_beta1=0.9,
+        adam_beta2=0.999,
+        adam_epsilon=1e-8,
+        lr_scheduler_type=config["lr_scheduler"],
+        warmup_ratio=config["warmup_ratio"],
+        log_level="passive",
+        logging_strategy="steps",
+        logging_steps=5,
+        logging_nan_inf_filter=False,
+        save_strategy="epoch",
+        save_total_limit=1,
+        seed=SEED,
+        fp16=False,
+        dataloader_num_workers=CPU_CORES,
+        load_best_model_at_end=True,
+        metric_for_best_model="loss",
+        greater_is_better=False,
+        dataloader_pin_memory=True,
+        gradient_checkpointing=False,
+        auto_find_batch_size=False,
+        full_determinism=False,
+        torch_compile=False,
+        report_to="wandb",
+        run_name=run_name,
+    )
+
+
+def test_reference_call_sites_run_unchanged(emu, tmp_path):
+    """reference scOT/train.py:277-328, 400-410: TrainingArguments with all of its HF keywords, EarlyStoppingCallback,
+    Trainer(..., callbacks=[...]), train(resume_from_checkpoint=...), save_model(dir) — per-epoch evaluation + checkpoint, rotation
+    that keeps the best, best model restored at the end, early stopping, resume."""
+    from scOT.model import ScOT
+    from scOT.trainer import EarlyStoppingCallback, Trainer, TrainingArguments, checkpoints_in
+    f, meta = load_fixture("tiny_trained")
+    cfg = ScOTConfig(**meta["cfg"])
+    sd0 = synth_state_dict(param_shapes(cfg), meta["regime"])
+    train_dataset, eval_dataset = Samples(8, cfg, 0), Samples(4, cfg, 1)
+    config = dict(batch_size=4, max_grad_norm=5.0, num_epochs=3, lr=2e-3, weight_decay=0.01, lr_scheduler="cosine", warmup_ratio=0.1,
+                  early_stopping_patience=5)
+    ckpt_dir = str(tmp_path / "run")
+    with pytest.warns(UserWarning, match="report_to='wandb'"):
+        train_config = _reference_style_arguments(TrainingArguments, ckpt_dir, config)
+    assert train_config.ignored == {"report_to": "wandb"} and train_config.eval_strategy == "epoch"
+    early_stopping = EarlyStoppingCallback(early_stopping_patience=config["early_stopping_patience"], early_stopping_threshold=0.0)
+    model = ScOT(cfg, compute="fp32")
+    model.load_state_dict(sd0)
+    events = []
+
+    class Spy:
+        def on_epoch_end(self, args, state, control, **kw):
+            events.append(("epoch_end", state.global_step))
+
+        def on_save(self, args, state, control, **kw):
+            events.append(("save", state.global_step))
+
+        def on_evaluate(self, args, state, control, metrics=None, **kw):
+            events.append(("eval", round(metrics["eval_loss"], 6)))
+
+    def compute_metrics(eval_preds):
+        return {"mean_relative_l1_error": float(np.abs(eval_preds.predictions - eval_preds.label_ids).sum() / np.abs(eval_preds.label_ids).sum())}
+    trainer = Trainer(
+        model=model,
+        args=train_config,
+        train_dataset=train_dataset,
+        eval_dataset=eval_dataset,
+        compute_metrics=compute_metrics,
+        callbacks=[early_stopping],
+    )
+    trainer.add_callback(Spy())
+    out = trainer.train(resume_from_checkpoint=False)
+    trainer.save_model(train_config.output_dir)
+    assert out.global_step == 6 and [e[0] for e in events] == ["epoch_end", "eval", "save"] * 3
+    evals = [e[1] for e in events if e[0] == "eval"]
+    st = trainer.state
+    assert st.best_metric == pytest.approx(min(evals)) and st.best_model_checkpoint.endswith(f"checkpoint-{2 * (1 + evals.index(min(evals)))}")
+    left = checkpoints_in(ckpt_dir)
+    assert st.best_model_checkpoint in left and len(left) <= 2 and left[-1].endswith("checkpoint-6")    # save_total_limit=1 + best kept
+    assert os.path.exists(os.path.join(left[-1], "optimizer.pt")) and os.path.exists(os.path.join(left[-1], "trainer_state.json"))
+    assert os.path.exists(os.path.join(ckpt_dir, "config.json"))
+    # load_best_model_at_end: the model now holds the best checkpoint's weights
+    from safetensors.torch import load_file
+    best = load_file(os.path.join(st.best_model_checkpoint, "model.safetensors"))
+    got = model.state_dict()
+    assert all(torch.equal(got[k].cpu(), v) for k, v in best.items())
+
+    # resume: a fresh model + trainer continue from the last checkpoint (step 6 of 6 -> nothing left to do, state restored)
+    model2 = ScOT(cfg, compute="fp32")
+    model2.load_state_dict(sd0)
+    with pytest.warns(UserWarning):
+        args2 = _reference_style_arguments(TrainingArguments, ckpt_dir, dict(config, num_epochs=4))
+    tr2 = Trainer(model=model2, args=args2, train_dataset=train_dataset, eval_dataset=eval_dataset, compute_metrics=compute_metrics,
+                  callbacks=[EarlyStoppingCallback(early_stopping_patience=1, early_stopping_threshold=1e9)])
+    out2 = tr2.train(resume_from_checkpoint=True)
+    # resumed at step 6 (epoch 3 of 4); one more epoch runs; the absurd threshold makes that evaluation "no improvement": patience 1 -> stop
+    assert out2.global_step == 8 and tr2.state.global_step == 8 and tr2.optimizer.state_dict() is not None
+    assert any(h.get("step") == 5 for h in tr2.state["log_history"])       # the restored log history precedes the new entries
+    with pytest.raises(ValueError, match="No valid checkpoint"):
+        Trainer(model=model2, args=_quiet(lambda: _reference_style_arguments(TrainingArguments, str(tmp_path / "empty"), config)),
+                train_dataset=train_dataset, eval_dataset=eval_dataset).train(resume_from_checkpoint=True)
+
+
+def _quiet(fn):
+    import warnings
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        return fn()
+
+
+def test_early_stopping_stops_and_hf_callback_plugs_in(emu, tmp_path):
+    from scOT.model import ScOT
+    from scOT.trainer import EarlyStoppingCallback, Trainer, TrainingArguments
+    f, meta = load_fixture("tiny_trained")
+    cfg = ScOTConfig(**meta["cfg"])
+    train_dataset, eval_dataset = Samples(4, cfg, 0), Samples(2, cfg, 1)
+
+    def run(cb, lr):
+        model = ScOT(cfg, compute="fp32")
+        model.load_state_dict(synth_state_dict(param_shapes(cfg), meta["regime"]))
+        args = TrainingArguments(output_dir=str(tmp_path / f"r{lr}"), evaluation_strategy="epoch", save_strategy="epoch", num_train_epochs=6,
+                                 per_device_train_batch_size=2, per_device_eval_batch_size=2, learning_rate=lr, lr_scheduler_type="constant",
+                                 load_best_model_at_end=True, metric_for_best_model="loss", greater_is_better=False, logging_steps=1,
+                                 save_total_limit=1, max_grad_norm=0.0)
+        tr = Trainer(model=model, args=args, train_dataset=train_dataset, eval_dataset=eval_dataset, callbacks=[cb])
+        return tr.train(), tr
+    # lr = 0: the evaluation loss never improves -> stop after `patience` evaluations without improvement (first one sets the best)
+    out, tr = run(EarlyStoppingCallback(early_stopping_patience=2), 0.0)
+    assert out.global_step == 2 * 3 and tr.control.should_training_stop
+    try:
+        from transformers import EarlyStoppingCallback as HFEarlyStopping
+    except Exception:
+        return
+    out, tr = run(HFEarlyStopping(early_stopping_patience=2), 0.0)
+    assert out.global_step == 2 * 3
+
+
+def test_gradient_accumulation_steps_on_short_epoch(emu, tmp_path):
+    """HF semantics: an optimizer step at every `acc`-th micro-batch AND at the epoch's last one (3 batches, acc 2 -> 2 steps per epoch)."""
+    from scOT.model import ScOT
+    from scOT.trainer import Trainer, TrainingArguments
+    f, meta = load_fixture("tiny_trained")
+    cfg = ScOTConfig(**meta["cfg"])
+    model = ScOT(cfg, compute="fp32")
+    model.load_state_dict(synth_state_dict(param_shapes(cfg), meta["regime"]))
+    args = TrainingArguments(output_dir=str(tmp_path), per_device_train_batch_size=2, num_train_epochs=2, gradient_accumulation_steps=2,
+                             learning_rate=1e-3, logging_steps=1, save_strategy="no")
+    out = Trainer(model=model, args=args, train_dataset=Samples(6, cfg, 0)).train()
+    assert out.global_step == 4
+    args = TrainingArguments(output_dir=str(tmp_path), per_device_train_batch_size=2, num_train_epochs=1, gradient_accumulation_steps=8,
+                             learning_rate=1e-3, logging_steps=1, save_strategy="no")
+    assert Trainer(model=model, args=args, train_dataset=Samples(6, cfg, 0)).train().global_step == 1     # fewer batches than acc: still one step
