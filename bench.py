@@ -225,17 +225,34 @@ def main():
     if a.cpu_worker:
         print(json.dumps(_cpu_baseline_worker(a.model, a.size, a.channels, a.cpu_seconds)), flush=True)
         return
+    if a.gpus > 1 and "RANK" not in os.environ and "WORLD_SIZE" not in os.environ:
+        # `python bench.py --gpus N` by itself: become the launcher — one rank per GPU under torch.distributed.run (RCCL over xGMI),
+        # rank 0 prints the one JSON line (the reference launches its driver the same way: `accelerate launch`, README.md:50-57)
+        import socket
+        import subprocess
+        have = torch.cuda.device_count()
+        if have < a.gpus:
+            raise SystemExit(f"bench.py: --gpus {a.gpus} but only {have} GPU(s) are visible")
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            port = sk.getsockname()[1]
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={a.gpus}", "--master-addr", "127.0.0.1",
+               "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+        raise SystemExit(subprocess.call(cmd))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != a.gpus and world > 1:
-        raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}")
+    if world != a.gpus:
+        raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}: launch as `python bench.py --gpus N` (self-launching) or under "
+                         "`python -m torch.distributed.run --nproc-per-node N bench.py --gpus N`")
     torch.cuda.set_device(local)
     dist = None
     if world > 1 or "RANK" in os.environ:   # under torchrun the collective path is exercised even with one rank
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
+        if dist.get_world_size() != a.gpus:
+            raise SystemExit(f"RCCL process group has {dist.get_world_size()} ranks, --gpus {a.gpus}")
 
     from poseidon_amd.config import preset
     from poseidon_amd.dp import GradAllReducer, OverlappedGradAllReducer

@@ -35,6 +35,9 @@ int scot_operand_format(void);
  * Undoes the backward's gradient scale on the gradient arena (the role torch.cuda.amp.GradScaler.unscale_ plays for the
  * reference's fp16 recipe, trainer.py via HF Trainer). */
 int scot_scale_inplace(float* x, size_t n, float scale, int* nonfinite, scot_stream_t stream);
+/* The same with the factor read from the device (x *= *scale_dev): the fp16 build's DYNAMIC gradient scale — a recorded step holds
+ * the address, scot_optim_finish changes the value between steps. */
+int scot_scale_inplace_dev(float* x, size_t n, const float* scale_dev, int* nonfinite, scot_stream_t stream);
 /* Local power-of-two rescale of a gradient branch behind a tiny per-channel scale (ConvNeXt layer scale, model.py:191-195,212-213)
  * in the binary16 build — all factors stay on the device:
  *   scot_pow2_rescale: out2[0] = c = 2^k (k >= 0) with max|v|·c in (1/2, 1], out2[1] = 1/c;
@@ -102,6 +105,11 @@ int scot_gemm(int layout, int compute, int M, int N, int K,
  * inference form) — the fc1 form, so that no
  * later kernel re-evaluates erf; aux_mul=1: `aux` already holds that derivative and is multiplied in as is. */
 
+/* Scratch the call above would use with these dimensions (dense operands in the compute mode's operand type; TN: fp32 result with
+ * accumulate = 1): bytes of split-K partial tiles, 0 when it runs unsplit.  scot_gemm adapts to a SMALLER workspace (fewer K slices,
+ * fp32 atomics without any) — this is the size at which nothing is clipped.  SURVEY.md §8(b): `scot_<op>_workspace_bytes(dims…)`. */
+size_t scot_gemm_workspace_bytes(int layout, int compute, int M, int N, int K);
+
 /* The weight gradients of one ScOTLayer in ONE launch: for i < n (n <= 8)
  *   dW_i[M_i, N_i] += dY_i[K, M_i]^T · X_i[K, N_i],   dbias_i[M_i] += Σ_k dY_i[k, :]   (dbias / dbias_i may be NULL)
  * i.e. the autograd of query/key/value, attention.output.dense, intermediate.dense and output.dense (HF:396-410, 502-506,
@@ -111,6 +119,9 @@ int scot_gemm(int layout, int compute, int M, int N, int K,
  * compute must be 1 (16-bit MFMA); returns -3 for anything else (use scot_gemm per problem). */
 int scot_wgrad_group(int compute, int n, int K, const void* const* dY, const void* const* X, float* const* dW,
                      float* const* dbias, const int* M, const int* N, void* workspace, size_t ws_bytes, scot_stream_t stream);
+/* nsplit · Σ M_i N_i · 4 bytes for the K split scot_wgrad_group chooses for these shapes (0: unsplit, or shapes it does not cover).
+ * With less it splits less; with none and a split wanted it returns -3. */
+size_t scot_wgrad_group_workspace_bytes(int n, int K, const int* M, const int* N);
 
 /* Shifted-window cosine attention, HF:389-455 + ref:522-559 (roll/partition/mask folded into indexing).
  * qkv: [batch*Hp*Wp][3C] (q|k|v) in the compute dtype; out: [batch*Hp*Wp][C]; lse: [batch*nW][heads][ws*ws] f32;
@@ -252,13 +263,20 @@ int scot_loss_bwd(const float* pred, const float* labels, const unsigned char* m
  * not a parameter (alignment padding, the key-bias slot of the fused qkv bias).  n = arena size in floats (multiple of 8). */
 int scot_optim_blocks(size_t n);                       /* floats of `partial` scratch scot_grad_sqnorm needs */
 int scot_grad_sqnorm(const float* grad, const unsigned char* map8, size_t n, float* partial, scot_stream_t stream);
-int scot_clip_coef(const float* partial, int nblocks, float max_norm, float* out2 /* {coef, total_norm} */, scot_stream_t stream);
+int scot_clip_coef(const float* partial, int nblocks, float max_norm /* <= 0: no clipping */,
+                   float* out3 /* {coef, total_norm, 1 if the norm is not finite else 0} */, scot_stream_t stream);
+/* clip: the three floats of scot_clip_coef (NULL: no clipping, no skip) — the update is SKIPPED when clip[2] != 0 (gradients that
+ * overflowed under the fp16 build's gradient scale; GradScaler.step semantics, decided on the device from the norm of the REDUCED
+ * gradient, so every data-parallel rank decides alike).  step_state: device int[2] {steps applied, steps skipped}: Adam's step number
+ * is applied + 1 (NULL: `step`).  shadow16 (optional): n elements in the library's 16-bit operand format, receives the updated
+ * parameters in the same pass (the GEMM operand copy the next forward reads). */
 int scot_adamw_step(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, const unsigned char* map8, size_t n,
                     const float* lr /* host[ngroups] */, const float* wd /* host[ngroups] */, int ngroups, float beta1, float beta2,
-                    float eps, int step, const float* clip /* device {coef,..} or NULL */,
-                    const int* overflow, const int* overflow_seen /* device ints or NULL: the update is skipped when they differ
-                    (gradients that overflowed under the fp16 build's gradient scale — GradScaler.step semantics) */,
-                    scot_stream_t stream);
+                    float eps, int step, const float* clip, const int* step_state, void* shadow16, scot_stream_t stream);
+/* After scot_adamw_step: step_state[0 or 1] += 1; with scale_state {S, 1/S, clean steps} and interval > 0 the gradient scale of the
+ * fp16 build follows torch.cuda.amp.GradScaler: S *= backoff after a skipped step, S *= growth after `interval` applied steps. */
+int scot_optim_finish(int* step_state, const float* clip, float* scale_state, float growth, float backoff, int interval,
+                      float max_scale, scot_stream_t stream);
 
 #ifdef __cplusplus
 }

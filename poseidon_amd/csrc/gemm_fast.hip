@@ -581,10 +581,14 @@ extern int g_scot_use_tr;
 
 // Returns SCOT_ERR_UNSUPPORTED when the call does not qualify (the caller then uses the generic kernel).
 
-int scot_gemm_fast(int layout, int compute, int M, int N, int K, const void* A, int a_dt, int lda, int a_gelu,
-                   const void* B, int b_dt, int ldb, int b_gelu, void* C, int c_dt, int ldc, const float* bias,
-                   const float* colscale, const void* aux, int aux_dt, int ldaux, const void* resid, int res_dt, int ldres,
-                   int accumulate, float* colsum_out, void* workspace, size_t ws_bytes, int aux_mul, void* C2, hipStream_t stream) {
+// `query` != NULL: plan only — the tile / split policy below runs against an unlimited workspace and *query receives the bytes it
+// would use; nothing is launched (scot_gemm_workspace_bytes: one policy, two readers).
+static int gemm_fast_impl(int layout, int compute, int M, int N, int K, const void* A, int a_dt, int lda, int a_gelu,
+                          const void* B, int b_dt, int ldb, int b_gelu, void* C, int c_dt, int ldc, const float* bias,
+                          const float* colscale, const void* aux, int aux_dt, int ldaux, const void* resid, int res_dt, int ldres,
+                          int accumulate, float* colsum_out, void* workspace, size_t ws_bytes, int aux_mul, void* C2, hipStream_t stream,
+                          size_t* query) {
+  if (query) { *query = 0; workspace = (void*)(uintptr_t)64; ws_bytes = (size_t)1 << 60; }
   const bool x3 = compute == SCOT_BF16X3;
   const int want = compute == SCOT_BF16 ? SCOT_BF16 : SCOT_F32;   // bf16x3 keeps its operands in fp32
   const int epc = compute == SCOT_BF16 ? 8 : 4;
@@ -679,6 +683,10 @@ int scot_gemm_fast(int layout, int compute, int M, int N, int K, const void* A, 
       }
     }
   }
+  if (query) {
+    *query = a.ws ? (size_t)nsplit * M * N * sizeof(float) : 0;
+    return SCOT_OK;
+  }
   int rc = x3 ? flaunch_x3(tile, a, layout, nsplit, stream)
               : compute == SCOT_BF16 ? flaunch_tile<bf16_t>(tile, a, layout, nsplit, stream) : flaunch_tile<float>(tile, a, layout, nsplit, stream);
   if (rc == SCOT_OK && a.ws) {
@@ -701,6 +709,26 @@ int scot_gemm_fast(int layout, int compute, int M, int N, int K, const void* A, 
   return rc;
 }
 
+
+int scot_gemm_fast(int layout, int compute, int M, int N, int K, const void* A, int a_dt, int lda, int a_gelu,
+                   const void* B, int b_dt, int ldb, int b_gelu, void* C, int c_dt, int ldc, const float* bias,
+                   const float* colscale, const void* aux, int aux_dt, int ldaux, const void* resid, int res_dt, int ldres,
+                   int accumulate, float* colsum_out, void* workspace, size_t ws_bytes, int aux_mul, void* C2, hipStream_t stream) {
+  return gemm_fast_impl(layout, compute, M, N, K, A, a_dt, lda, a_gelu, B, b_dt, ldb, b_gelu, C, c_dt, ldc, bias, colscale, aux, aux_dt,
+                        ldaux, resid, res_dt, ldres, accumulate, colsum_out, workspace, ws_bytes, aux_mul, C2, stream, nullptr);
+}
+
+// include/scot_hip.h: scot_gemm_workspace_bytes — dense operands (leading dimensions = row lengths) in the compute mode's
+// operand type, fp32 result for TN (accumulate) / 16-bit otherwise; 0 = the call would not touch the workspace.
+extern "C" size_t scot_gemm_workspace_bytes(int layout, int compute, int M, int N, int K) {
+  const int dt = compute == SCOT_BF16 ? SCOT_BF16 : SCOT_F32;
+  const int lda = layout == LAYOUT_TN ? M : K, ldb = layout == LAYOUT_NT ? K : N;
+  void* al = (void*)(uintptr_t)64;
+  size_t q = 0;
+  const int rc = gemm_fast_impl(layout, compute, M, N, K, al, dt, lda, 0, al, dt, ldb, 0, al, layout == LAYOUT_TN ? SCOT_F32 : dt, N, nullptr,
+                                nullptr, nullptr, 0, 0, nullptr, 0, 0, layout == LAYOUT_TN ? 1 : 0, nullptr, nullptr, 0, 0, nullptr, nullptr, &q);
+  return rc == SCOT_OK ? q : 0;
+}
 
 // C_i[m][n] += Σ_z ws[z·plane + ws_off_i + m·N_i + n] for every problem of the group (one launch)
 template <int ZL>
@@ -735,9 +763,10 @@ static int launch_wgrad_group(const WgradGroupArgs& g, hipStream_t s) {
 
 // include/scot_hip.h: scot_wgrad_group.  dY_i: [K, M_i] (16-bit operands), X_i: [K, N_i], dW_i: [M_i, N_i] fp32 (+=),
 // dbias_i: [M_i] fp32 (+= column sums of dY_i) or NULL.  All leading dimensions = the row lengths (dense).
-extern "C" int scot_wgrad_group(int compute, int n, int K, const void* const* dY, const void* const* X, float* const* dW,
-                                float* const* dbias, const int* Ms, const int* Ns, void* workspace, size_t ws_bytes,
-                                hipStream_t stream) {
+static int wgrad_group_impl(int compute, int n, int K, const void* const* dY, const void* const* X, float* const* dW,
+                            float* const* dbias, const int* Ms, const int* Ns, void* workspace, size_t ws_bytes,
+                            hipStream_t stream, size_t* query) {
+  if (query) { *query = 0; workspace = (void*)(uintptr_t)64; ws_bytes = (size_t)1 << 60; }
   if (n <= 0 || n > SCOT_WGRAD_GROUP_MAX || K <= 0) return SCOT_ERR_SHAPE;
   if (compute != SCOT_BF16) return SCOT_ERR_UNSUPPORTED;     // fp32 / split modes use scot_gemm per problem
   if (K % 8) return SCOT_ERR_UNSUPPORTED;
@@ -745,7 +774,7 @@ extern "C" int scot_wgrad_group(int compute, int n, int K, const void* const* dY
   for (int i = 0; i < n; ++i) {
     if (Ms[i] <= 0 || Ns[i] <= 0) return SCOT_ERR_SHAPE;
     if (Ms[i] % 8 || Ns[i] % 8) return SCOT_ERR_UNSUPPORTED;
-    if ((((uintptr_t)dY[i] | (uintptr_t)X[i] | (uintptr_t)dW[i]) & 15) != 0) return SCOT_ERR_UNSUPPORTED;
+    if (!query && (((uintptr_t)dY[i] | (uintptr_t)X[i] | (uintptr_t)dW[i]) & 15) != 0) return SCOT_ERR_UNSUPPORTED;
     all96 = all96 && Ms[i] % 96 == 0 && Ns[i] % 96 == 0;
   }
   // tile policy of the single-problem path: 96x96 for the long-K gradients of the token-heavy stages, 64x64 otherwise
@@ -757,7 +786,7 @@ extern "C" int scot_wgrad_group(int compute, int n, int K, const void* const* dY
   size_t plane = 0;
   for (int i = 0; i < n; ++i) {
     WgradProblem& p = g.p[i];
-    p.A = dY[i]; p.B = X[i]; p.C = dW[i]; p.colsum = dbias ? dbias[i] : nullptr;
+    p.A = query ? nullptr : dY[i]; p.B = query ? nullptr : X[i]; p.C = query ? nullptr : dW[i]; p.colsum = (dbias && !query) ? dbias[i] : nullptr;
     p.M = Ms[i]; p.N = Ns[i]; p.lda = Ms[i]; p.ldb = Ns[i]; p.ldc = Ns[i];
     p.tiles_n = (Ns[i] + bn - 1) / bn;
     p.tile0 = tiles;
@@ -795,6 +824,10 @@ extern "C" int scot_wgrad_group(int compute, int n, int K, const void* const* dY
     if (!workspace || (((uintptr_t)workspace) & 31) || (size_t)g.nsplit * plane * sizeof(float) > ws_bytes) return SCOT_ERR_UNSUPPORTED;
     g.ws = (float*)workspace;
   }
+  if (query) {
+    *query = g.nsplit > 1 ? (size_t)g.nsplit * plane * sizeof(float) : 0;
+    return SCOT_OK;
+  }
   static int nset = -1;
   if (nset < 0) { const char* e = getenv("SCOT_WGRAD_GROUP_NSET"); nset = e ? atoi(e) : 2; }
   int rc;
@@ -811,4 +844,17 @@ extern "C" int scot_wgrad_group(int compute, int n, int K, const void* const* dY
     rc = scot_check_launch();
   }
   return rc;
+}
+
+extern "C" int scot_wgrad_group(int compute, int n, int K, const void* const* dY, const void* const* X, float* const* dW,
+                                float* const* dbias, const int* Ms, const int* Ns, void* workspace, size_t ws_bytes,
+                                hipStream_t stream) {
+  return wgrad_group_impl(compute, n, K, dY, X, dW, dbias, Ms, Ns, workspace, ws_bytes, stream, nullptr);
+}
+
+// include/scot_hip.h: scot_wgrad_group_workspace_bytes (0: no split, or the shapes are not covered by the grouped kernel)
+extern "C" size_t scot_wgrad_group_workspace_bytes(int n, int K, const int* Ms, const int* Ns) {
+  size_t q = 0;
+  const int rc = wgrad_group_impl(SCOT_BF16, n, K, nullptr, nullptr, nullptr, nullptr, Ms, Ns, nullptr, 0, nullptr, &q);
+  return rc == SCOT_OK ? q : 0;
 }

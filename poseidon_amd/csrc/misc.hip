@@ -1218,7 +1218,10 @@ extern "C" int scot_axpy_dev(float* dst, float* src, size_t n, const float* alph
   return scot_check_launch();
 }
 
-__global__ void scale_inplace_kernel(float* x, size_t n4, size_t n, float scale, int* nonfinite) {
+// scale_dev (optional): the factor lives on the device (the fp16 build's dynamic gradient scale: a recorded step must not bake a
+// value in) and multiplies `scale`
+__global__ void scale_inplace_kernel(float* x, size_t n4, size_t n, float scale, int* nonfinite, const float* scale_dev) {
+  if (scale_dev) scale *= *scale_dev;
   int bad = 0;
   const size_t stride = (size_t)gridDim.x * blockDim.x;
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) {
@@ -1238,6 +1241,14 @@ extern "C" int scot_scale_inplace(float* x, size_t n, float scale, int* nonfinit
   if (n == 0) return SCOT_OK;
   if (((uintptr_t)x) & 15) return SCOT_ERR_SHAPE;
   size_t blocks = (n / 4 + 255) / 256; if (blocks > 4096) blocks = 4096; if (blocks == 0) blocks = 1;
-  hipLaunchKernelGGL(scale_inplace_kernel, dim3((unsigned)blocks), dim3(256), 0, s, x, n / 4, n, scale, nonfinite);
+  hipLaunchKernelGGL(scale_inplace_kernel, dim3((unsigned)blocks), dim3(256), 0, s, x, n / 4, n, scale, nonfinite, (const float*)nullptr);
+  return scot_check_launch();
+}
+// include/scot_hip.h: scot_scale_inplace_dev — x *= *scale_dev (a device float), counting non-finite results as above
+extern "C" int scot_scale_inplace_dev(float* x, size_t n, const float* scale_dev, int* nonfinite, hipStream_t s) {
+  if (n == 0) return SCOT_OK;
+  if ((((uintptr_t)x) & 15) || !scale_dev) return SCOT_ERR_SHAPE;
+  size_t blocks = (n / 4 + 255) / 256; if (blocks > 4096) blocks = 4096; if (blocks == 0) blocks = 1;
+  hipLaunchKernelGGL(scale_inplace_kernel, dim3((unsigned)blocks), dim3(256), 0, s, x, n / 4, n, 1.0f, nonfinite, scale_dev);
   return scot_check_launch();
 }

@@ -7,7 +7,12 @@
 // (poseidon_amd/arena.py), so a step is three launches over it:
 //   scot_grad_sqnorm  per-block partial sums of g² (parameters only: `map8` marks padding / non-parameter regions),
 //   scot_clip_coef    total norm and min(1, max_norm / (norm + 1e-6)),
-//   scot_adamw_step   p, m, v updated in place in one pass (28 bytes per parameter), group hyper-parameters by value.
+//   scot_adamw_step   p, m, v updated in place in one pass (28 bytes per parameter), group hyper-parameters by value; the same
+//                     pass writes the 16-bit operand copy of the new weights the forward's GEMMs read (+2 bytes per parameter:
+//                     the engine then has nothing to cast at the start of the next step),
+//   scot_optim_finish step counters and the fp16 build's dynamic gradient scale (GradScaler semantics), one thread.
+// A step whose gradient norm is not finite (overflow under the fp16 gradient scale) is skipped ON THE DEVICE by every rank alike:
+// the norm is taken from the REDUCED gradient, so data-parallel replicas cannot disagree about it.
 // torch.optim.AdamW arithmetic, in its order (torch/optim/adamw.py, single-tensor path):
 //   p *= 1 - lr·wd;  m += (g - m)(1 - β1);  v = β2·v + (1 - β2)·g²;  p -= (lr / bc1) · m / (sqrt(v)/sqrt(bc2) + eps).
 #include "common.h"
@@ -33,7 +38,7 @@ __global__ __launch_bounds__(256) void grad_sqnorm_kernel(const float* __restric
   if (threadIdx.x == 0) partial[blockIdx.x] = red[0] + red[1] + red[2] + red[3];
 }
 
-// out[0] = clip coefficient, out[1] = total norm
+// out[0] = clip coefficient (1 when max_norm <= 0), out[1] = total norm, out[2] = 1 if the norm is not finite (else 0)
 __global__ __launch_bounds__(256) void clip_coef_kernel(const float* __restrict__ partial, int nblocks, float max_norm, float* out) {
   __shared__ double red[4];
   double acc = 0.0;
@@ -45,19 +50,25 @@ __global__ __launch_bounds__(256) void clip_coef_kernel(const float* __restrict_
   if (threadIdx.x == 0) {
     const float norm = (float)sqrt(red[0] + red[1] + red[2] + red[3]);
     const float coef = max_norm / (norm + 1e-6f);   // torch.nn.utils.clip_grad_norm_: clamped to 1
-    out[0] = coef < 1.f ? coef : 1.f;
+    out[0] = (max_norm > 0.f && coef < 1.f) ? coef : 1.f;
     out[1] = norm;
+    out[2] = (fabsf(norm) <= 3.4e38f) ? 0.f : 1.f;
   }
 }
 
 __global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
                                                     float* __restrict__ v, const uint8_t* __restrict__ map8, size_t n8, AdamGroups grp,
                                                     float beta1, float beta2, float eps, float bc1, float rsqrt_bc2,
-                                                    const float* __restrict__ clip, const int* __restrict__ overflow,
-                                                    const int* __restrict__ overflow_seen) {
-  // fp16 build: the gradient un-scale counts non-finite values; a step whose gradients overflowed is skipped (what
-  // torch.cuda.amp.GradScaler.step does for the reference's fp16 recipe) — decided on the device, no host round trip
-  if (overflow && *overflow != *overflow_seen) return;
+                                                    const float* __restrict__ clip, const int* __restrict__ step_state,
+                                                    bf16_t* __restrict__ shadow16) {
+  // a step whose (reduced) gradient norm is not finite is skipped (what torch.cuda.amp.GradScaler.step does) — decided on the
+  // device, no host round trip, identically on every data-parallel rank
+  if (clip && clip[2] != 0.f) return;
+  if (step_state) {   // bias corrections from the number of steps actually APPLIED (skipped steps do not advance Adam's clock)
+    const double t = (double)(step_state[0] + 1);
+    bc1 = (float)(1.0 - pow((double)beta1, t));
+    rsqrt_bc2 = (float)(1.0 / sqrt(1.0 - pow((double)beta2, t)));
+  }
   const float cc = clip ? clip[0] : 1.f;
   for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n8; i += (size_t)gridDim.x * 256) {
     const int gi = map8[i];
@@ -76,6 +87,21 @@ __global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, const
       pv[j] -= step * (mv[j] / denom);
     }
     st8(p, SCOT_F32, i * 8, pv); st8(m, SCOT_F32, i * 8, mv); st8(v, SCOT_F32, i * 8, vv);
+    if (shadow16) st8(shadow16, SCOT_BF16, i * 8, pv);
+  }
+}
+
+// step_state: {steps applied, steps skipped}; scale_state (optional): {S, 1/S, clean steps since S last changed}
+__global__ void optim_finish_kernel(int* step_state, const float* clip, float* scale_state, float growth, float backoff, int interval,
+                                    float max_scale) {
+  if (threadIdx.x != 0) return;
+  const bool inf = clip && clip[2] != 0.f;
+  if (inf) step_state[1] += 1; else step_state[0] += 1;
+  if (scale_state && interval > 0) {
+    float S = scale_state[0], clean = scale_state[2];
+    if (inf) { S *= backoff; if (S < 1.f) S = 1.f; clean = 0.f; }
+    else if (++clean >= (float)interval) { S *= growth; if (S > max_scale) S = max_scale; clean = 0.f; }
+    scale_state[0] = S; scale_state[1] = 1.f / S; scale_state[2] = clean;
   }
 }
 
@@ -99,19 +125,32 @@ extern "C" int scot_clip_coef(const float* partial, int nblocks, float max_norm,
   return scot_check_launch();
 }
 
-// lr / wd: HOST arrays of ngroups floats (passed to the kernel by value); step >= 1; clip: device pointer to the
-// coefficient written by scot_clip_coef, or NULL; overflow / overflow_seen: device ints (or NULL): the update is skipped when
-// they differ (the engine's cumulative count of non-finite gradient values vs the count at the previous step)
+// lr / wd: HOST arrays of ngroups floats (passed to the kernel by value); clip: the 3 floats written by scot_clip_coef (or NULL:
+// no clipping, no skip); step_state: device int[2] {applied, skipped} — Adam's step number is applied + 1, read on the device — or
+// NULL: `step` (>= 1) is used; shadow16 (optional, 16-byte aligned, n elements): the library's 16-bit operand copy of the
+// updated parameters, written in the same pass.
 extern "C" int scot_adamw_step(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, const uint8_t* map8, size_t n,
                                const float* lr, const float* wd, int ngroups, float beta1, float beta2, float eps, int step,
-                               const float* clip, const int* overflow, const int* overflow_seen, hipStream_t stream) {
-  if (!params || !grads || !exp_avg || !exp_avg_sq || !map8 || n % 8 || ngroups < 1 || ngroups > OPT_MAX_GROUPS || step < 1)
+                               const float* clip, const int* step_state, void* shadow16, hipStream_t stream) {
+  if (!params || !grads || !exp_avg || !exp_avg_sq || !map8 || n % 8 || ngroups < 1 || ngroups > OPT_MAX_GROUPS || (!step_state && step < 1))
     return SCOT_ERR_SHAPE;
+  if (((uintptr_t)shadow16) & 15) return SCOT_ERR_SHAPE;
+  if (step < 1) step = 1;
   AdamGroups grp{};
   for (int i = 0; i < ngroups; ++i) { grp.lr[i] = lr[i]; grp.wd[i] = wd[i]; }
   const double bc1 = 1.0 - pow((double)beta1, step), bc2 = 1.0 - pow((double)beta2, step);
   hipLaunchKernelGGL(adamw_kernel, dim3(opt_blocks(n / 8)), dim3(256), 0, stream, params, grads, exp_avg, exp_avg_sq, map8, n / 8, grp,
-                     beta1, beta2, eps, (float)bc1, (float)(1.0 / sqrt(bc2)), clip, overflow, overflow ? overflow_seen : nullptr);
+                     beta1, beta2, eps, (float)bc1, (float)(1.0 / sqrt(bc2)), clip, step_state, (bf16_t*)shadow16);
+  return scot_check_launch();
+}
+
+// After scot_adamw_step: step_state[0] += 1 (applied) or step_state[1] += 1 (skipped: clip[2] != 0), and — when scale_state is
+// given and interval > 0 — torch.cuda.amp.GradScaler's update of the gradient scale: S *= backoff on a skipped step, S *= growth
+// after `interval` applied steps in a row; scale_state = {S, 1/S, clean steps}, S kept within [1, max_scale].
+extern "C" int scot_optim_finish(int* step_state, const float* clip, float* scale_state, float growth, float backoff, int interval,
+                                 float max_scale, hipStream_t stream) {
+  if (!step_state) return SCOT_ERR_SHAPE;
+  hipLaunchKernelGGL(optim_finish_kernel, dim3(1), dim3(64), 0, stream, step_state, clip, scale_state, growth, backoff, interval, max_scale);
   return scot_check_launch();
 }
 

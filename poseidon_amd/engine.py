@@ -82,7 +82,7 @@ class ScOTEngine:
         self.group_wgrads = os.environ.get("SCOT_GROUP_WGRAD", "1") == "1"
         # TIMING-ONLY what-if switches (results are wrong with any of them set; tools/gpu_whatif.sh): "noact" = the fused forward tail
         # does not store gelu(u) / gelu'(u) (the backward reads a stale dummy), "nomlpwgrad" = the fc1 / fc2 weight gradients of the
-        # fused stages are skipped, "nocast" = the 16-bit weight copies are made once and never refreshed
+        # fused stages are skipped
         self.whatif = {w for w in os.environ.get("SCOT_WHATIF", "").split(",") if w}
         self._whatif_dummy = {}
         self.arena = arena
@@ -153,6 +153,11 @@ class ScOTEngine:
         # divided by it afterwards (exact; scot_scale_inplace also counts non-finite values → `grad_overflow`).
         self.scale_grads = compute == "fp16" and os.environ.get("SCOT_GRAD_SCALE", "auto") != "1"
         self.grad_overflow = torch.zeros(1, dtype=torch.int32, device=self.device) if self.scale_grads else None
+        # {S, 1/S, applied steps since S last changed}: ON THE DEVICE, so that a recorded step never bakes a value in and the optimizer
+        # (scot_optim_finish: torch.cuda.amp.GradScaler's rule — halve after an overflowed step, double after N clean ones) can change
+        # it between steps.  Initialised from the loss normalisation by the first training forward (_init_grad_scale).
+        self.scale_state = torch.tensor([1.0, 1.0, 0.0, 0.0], dtype=torch.float32, device=self.device) if self.scale_grads else None
+        self._scale_ready = False
         self.grads_are_zero = False   # set by ScOT.zero_grad / _prepare_grads: the arena needs no pre-scaling then
         self.collect_attn, self.attn_sink = False, []   # output_attentions: one probability tensor per stage (encoder stages first)
         # ... and one global scale cannot also lift the gradients of a branch behind a ~1e-6 layer scale (2^-20 below the rest):
@@ -161,6 +166,11 @@ class ScOTEngine:
         if self.scale_grads and os.environ.get("SCOT_LS_RESCALE", "1") == "1":
             self._plan_layer_scale_rescale()
         self._wviews: Dict[str, torch.Tensor] = {}
+        # 16-bit weight copies are refreshed only when the fp32 master changed: `weights_version()` (set by ScOT: in-place edits of
+        # the parameters / the arena and the fused optimizer's steps all move it) is compared with the version the copies were made
+        # from.  None (an engine built by hand): refresh at every forward.  The fused AdamW writes the copies itself.
+        self.weights_version = None
+        self._shadow_v = self._shadow_t_v = object()
         self._build_cpb_plan()
 
     def _build_cpb_plan(self):
@@ -345,7 +355,7 @@ class ScOTEngine:
             self._rec.append((run, None))
 
     def _grad_scale(self, n_out: int) -> float:
-        """Power-of-two factor the fp16 backward runs under.  d loss / d prediction is O(1 / n_out) for the (relative) mean
+        """INITIAL power-of-two factor the fp16 backward runs under.  d loss / d prediction is O(1 / n_out) for the (relative) mean
         losses of model.py:1424-1484, i.e. 2.4e-7 for Poseidon-B at batch 64 — a subnormal in binary16; with the scale the
         gradient of the prediction is O(1 / mean|label|) and the 16-bit gradient tensors of the backward (dY operands) sit in
         the middle of binary16's 30 binades."""
@@ -355,6 +365,17 @@ class ScOTEngine:
         if env != "auto":
             return float(env)
         return float(2 ** max(0, int(math.floor(math.log2(max(1, n_out))))))
+
+    def _init_grad_scale(self, n_out: int):
+        """first training forward: scale_state <- the automatic choice (later changes are the optimizer's, on the device)"""
+        if self.scale_grads and not self._scale_ready:
+            S = self._grad_scale(n_out)
+            self.scale_state.copy_(torch.tensor([S, 1.0 / S, 0.0, 0.0]))
+            self._scale_ready = True
+
+    def grad_scale_value(self) -> float:
+        """current gradient scale (a host read: synchronises)"""
+        return float(self.scale_state[0]) if self.scale_grads else 1.0
 
     def clone(self, t):
         y = self.new(*t.shape, dtype=t.dtype)
@@ -1084,9 +1105,38 @@ class ScOTEngine:
         return g
 
     # ------------------------------------------------------------------------------------------ whole model
+    def refresh_weight_copies(self, train: bool):
+        """fp32 master weights -> 16-bit GEMM operands (+ the transposed copies the data gradients read), when the master changed
+        since the copies were made.  Never part of a recorded step: whether it runs is decided per call."""
+        if self.shadow is None:
+            return
+        v = self.weights_version() if self.weights_version is not None else None
+        need = v is None or v != self._shadow_v
+        need_t = train and self.shadow_t is not None and (v is None or v != self._shadow_t_v)
+        if not (need or need_t):
+            return
+        prev = ops.set_recorder(None)
+        try:
+            if need:
+                ops.cast(self.arena.data, self.shadow)
+                self._shadow_v = v
+            if need_t:
+                self.transpose_weights()
+                self._shadow_t_v = v
+        finally:
+            ops.set_recorder(prev)
+
+    def weight_copies_are_current(self, v):
+        """the optimizer has just written both copies from master weights whose version is `v`"""
+        self._shadow_v = v
+        if self.shadow_t is not None:
+            self._shadow_t_v = v
+
     def forward(self, pixel_values, time=None, labels=None, pixel_mask=None, train=True, stochastic=None, bool_masked_pos=None):
         prev = ops.use(self.lib_kind)
         try:
+            if not self._capturing():
+                self.refresh_weight_copies(train)
             if bool_masked_pos is not None:       # masked-position pre-training inputs: not a taped signature
                 self.stochastic = bool(train if stochastic is None else stochastic)
                 return self._forward(pixel_values, time, labels, pixel_mask, train, bool_masked_pos)
@@ -1245,44 +1295,18 @@ class ScOTEngine:
         C0 = cfg.embed_dim
         L0 = gh * gw
         tape = dict(B=B, time=time, enc=[], dec=[], res=[]) if train else None
+        if train:
+            self._init_grad_scale(B * cfg.num_out_channels * H * W)
         self.attn_sink = []
-        ev_cpb = ev_cast = None
+        ev_cpb = None
 
         def cpb_all():
             ops.cpb_fwd_batched(self.arena.data, self.cpb_desc, self.cpb_nlayers, self.cpb_max_ws, self.cpb_coords, self.cpb_tables,
                                 self.cpb_z)
-        if "nocast" in self.whatif and self.shadow is not None and getattr(self, "_whatif_cast_done", False):
-            if self.use_side and not self.stage_timing:
-                _, ev_cpb = self.fork_task(cpb_all)
-            else:
-                cpb_all()
-        elif self.use_side and not self.stage_timing:
-            # neither the bias tables (first used by the first attention kernel) nor the 16-bit copies of the deeper stages'
-            # weights (99 % of the arena) are needed by the embedding / stage-0 chain: both go to the side stream
-            _, ev_cpb = self.fork_task(cpb_all)
-            if self.shadow is not None:
-                split = min((o for n, o in self.arena.offsets.items() if n.startswith("encoder.layers.1.")), default=0)
-                want_t = train and self.shadow_t is not None
-
-                def rest():
-                    ops.cast(self.arena.data[split:], self.shadow[split:])
-                    if want_t:
-                        self.transpose_weights()        # first read by the backward
-                if split > 0:
-                    ops.cast(self.arena.data[:split], self.shadow[:split])
-                    _, ev_cast = self.fork_task(rest)
-                else:
-                    ops.cast(self.arena.data, self.shadow)
-                    if want_t:
-                        self.transpose_weights()
+        if self.use_side and not self.stage_timing:
+            _, ev_cpb = self.fork_task(cpb_all)     # the bias tables are first used by the first attention kernel: side stream
         else:
-            if self.shadow is not None:
-                ops.cast(self.arena.data, self.shadow)  # fp32 master weights → 16-bit GEMM operands (every step)
-                if train and self.shadow_t is not None:
-                    self.transpose_weights()
             cpb_all()
-
-        self._whatif_cast_done = True
         # embeddings (model.py:295-366)
         cols = self.new(B * L0, Cin * p * p, dtype=self.tadt)
         ops.patchify(pixel_values, cols, B, Cin, H, W, p)
@@ -1322,8 +1346,6 @@ class ScOTEngine:
         self.wait_task(ev_cpb)
         for si, st in enumerate(self.enc):
             self.mark(f"fwd enc{si}")
-            if si == 1:
-                self.wait_task(ev_cast)
             stage_in = x
             x, x16, recs = self.blocks_fwd(st.blocks, x, x16, B, time, train)
             skips.append(x)
@@ -1445,22 +1467,24 @@ class ScOTEngine:
         gh, gw = self.grid
         C0, L0 = cfg.embed_dim, gh * gw
         # gradient scale of the fp16 build (1.0 otherwise): gradients already in the arena are brought to the same scale first
-        S = self._grad_scale(B * Cout * H * W)
-        if S != 1.0:
+        scaled = self.scale_grads
+        if scaled:
+            S_dev, Sinv_dev = self.scale_state[0:1], self.scale_state[1:2]
+
             def prescale():
                 if not self.grads_are_zero:
-                    ops.scale_inplace(self.arena.grad, S)
+                    ops.scale_inplace_dev(self.arena.grad, S_dev)
             self.tdo_dynamic(prescale)
             if dpred is not None:
                 dpred = self.clone(dpred.contiguous())
-                ops.scale_inplace(dpred.view(-1), S)
+                ops.scale_inplace_dev(dpred.view(-1), S_dev)
             if hd["labels"] is not None:
                 dl_in = dloss
                 dloss = self.new(1)
                 if dl_in is None:
-                    self.tdo(lambda: dloss.fill_(S))
+                    self.tdo(lambda: dloss.copy_(S_dev))
                 else:
-                    self.tdo(lambda: torch.mul(dl_in.reshape(1), S, out=dloss))
+                    self.tdo(lambda: torch.mul(dl_in.reshape(1), S_dev, out=dloss))
         # loss → d pred
         if hd["labels"] is not None:
             g_pred = self.new(B, Cout, H, W)
@@ -1499,21 +1523,23 @@ class ScOTEngine:
             def done(prefix, _cb=self.on_grads_final):
                 if not self.use_side:
                     self.flush_side()  # (no side stream: the range's queued weight gradients run here, in line)
-                    if S != 1.0:       # back at scale 1 before the range goes on the wire
+                    if scaled:         # back at scale 1 before the range goes on the wire
                         for _, lo, hi in group_ranges(self.arena, [prefix]):
-                            ops.scale_inplace(self.arena.grad[lo:hi], 1.0 / S, self.grad_overflow)
-                    self.tdo(lambda: _cb(prefix))
+                            ops.scale_inplace_dev(self.arena.grad[lo:hi], Sinv_dev, self.grad_overflow)
+                    # (the callback launches through ops — pack / collective / unpack: with the recorder left on, those launches would
+                    # be logged IN ADDITION to the callback itself and a replayed step would run them twice)
+                    self.tdo_dynamic(lambda: _cb(prefix))
                     return
                 # side stream (forked behind everything the main chain has enqueued so far, i.e. behind the range's last
                 # main-stream gradient kernel): the range's queued weight gradients, its un-scale, then the announcement
                 self.flush_side()
-                if S != 1.0:
+                if scaled:
                     for _, lo, hi in group_ranges(self.arena, [prefix]):
                         seg = self.arena.grad[lo:hi]
-                        self.off_critical_path(lambda seg=seg: ops.scale_inplace(seg, 1.0 / S, self.grad_overflow))
-                self.off_critical_path(lambda: self.tdo(lambda: announce(prefix)))
+                        self.off_critical_path(lambda seg=seg: ops.scale_inplace_dev(seg, Sinv_dev, self.grad_overflow))
+                self.off_critical_path(lambda: self.tdo_dynamic(lambda: announce(prefix)))
                 self.flush_side()
-        elif S != 1.0 and self.use_side:
+        elif scaled and self.use_side:
             from .dp import group_ranges
 
             def done(prefix):
@@ -1522,7 +1548,7 @@ class ScOTEngine:
                 self.flush_side()          # the range's queued weight gradients go first
                 for _, lo, hi in group_ranges(self.arena, [prefix]):
                     seg = self.arena.grad[lo:hi]
-                    self.off_critical_path(lambda seg=seg: ops.scale_inplace(seg, 1.0 / S, self.grad_overflow))
+                    self.off_critical_path(lambda seg=seg: ops.scale_inplace_dev(seg, Sinv_dev, self.grad_overflow))
                 self.flush_side()
         else:
             def done(prefix):
@@ -1601,9 +1627,9 @@ class ScOTEngine:
         d_e = self.norm_bwd("embeddings.norm", g, emb["e"], emb["stats"], L0, C0, time, self.tadt)
         self.wgrad(self.tcm, d_e, emb["cols"], self.G("embeddings.patch_embeddings.projection.weight").view(C0, Cin * p * p),
                    dbias=self.G("embeddings.patch_embeddings.projection.bias"))
-        if S != 1.0 and self.on_grads_final is None and not self.use_side:
+        if scaled and self.on_grads_final is None and not self.use_side:
             self.join_side()
-            ops.scale_inplace(self.arena.grad, 1.0 / S, self.grad_overflow)
+            ops.scale_inplace_dev(self.arena.grad, Sinv_dev, self.grad_overflow)
         self.mark("end")
         done("embeddings.")
         self.join_side()

@@ -22,11 +22,14 @@ PROTOTYPES = {
     "scot_abi_version": [],
     "scot_operand_format": [],
     "scot_scale_inplace": [P, Z, F, P, P],
+    "scot_scale_inplace_dev": [P, Z, P, P, P],
     "scot_selftest_tr": [P],
     "scot_set_use_tr": [I],
     "scot_get_use_tr": [],
     "scot_gemm": [I, I, I, I, I, P, I, I, I, P, I, I, I, P, I, I, P, P, P, I, I, P, I, I, I, P, P, Z, I, P, P],
     "scot_wgrad_group": [I, I, I, P, P, P, P, P, P, P, Z, P],
+    "scot_gemm_workspace_bytes": [I, I, I, I, I],
+    "scot_wgrad_group_workspace_bytes": [I, I, P, P],
     "scot_window_attn_fwd": [I, P, P, P, P, P, I, I, I, I, I, I, I, P],
     "scot_window_attn_probs": [P, I, P, P, P, P, I, I, I, I, I, I, I, P],
     "scot_window_attn_bwd": [I, P, P, P, P, P, P, P, P, P, I, I, I, I, I, I, I, P],
@@ -74,8 +77,14 @@ PROTOTYPES = {
     "scot_grad_sqnorm": [P, P, Z, P, P],
     "scot_clip_coef": [P, I, F, P, P],
     "scot_adamw_step": [P, P, P, P, P, Z, P, P, I, F, F, F, I, P, P, P, P],
+    "scot_optim_finish": [P, P, P, F, F, I, F, P],
 }
 _VOID = {"scot_set_use_tr"}
+_SIZE = {"scot_gemm_workspace_bytes", "scot_wgrad_group_workspace_bytes"}      # return size_t
+
+
+def restype(name):
+    return None if name in _VOID else (c_size_t if name in _SIZE else c_int)
 
 _libs = {}
 
@@ -103,7 +112,7 @@ def load(path: str = None, kind: str = "bf16"):
     for name, argtypes in PROTOTYPES.items():
         fn = getattr(lib, name)  # AttributeError if a declared symbol is missing
         fn.argtypes = argtypes
-        fn.restype = None if name in _VOID else c_int
+        fn.restype = restype(name)
     if lib.scot_operand_format() != OPERAND_FORMAT[kind]:
         raise ScotLibraryError(f"{path} was built for operand format {lib.scot_operand_format()}, expected {OPERAND_FORMAT[kind]} "
                                f"({kind}); rebuild with `python -m poseidon_amd.build --force`")

@@ -100,7 +100,8 @@ def L():
 
 
 _workspace = {}
-WORKSPACE_BYTES = 96 << 20
+_retired = []                   # outgrown scratch buffers: kept alive (launches already enqueued may still use them)
+WORKSPACE_MIN_BYTES = 8 << 20
 
 
 _slot = 0
@@ -114,24 +115,42 @@ def set_workspace_slot(slot: int) -> int:
     return prev
 
 
-def workspace():
-    """Per-(device, slot) scratch for split-K partial tiles (allocated once, on first eager use; the C ABI never allocates)."""
+def workspace(need: int = 0):
+    """Per-(device, slot) scratch for split-K partial tiles, sized by the library's own `scot_*_workspace_bytes` answers for the
+    shapes actually launched (grown to the next power of two on first need; the C ABI never allocates).  A recorded step tape holds
+    the address it was recorded with: growth only happens on a shape's first (eager, unrecorded) call."""
     key = (torch.cuda.current_device(), _slot)
     w = _workspace.get(key)
-    if w is None:
-        w = torch.empty(WORKSPACE_BYTES, dtype=torch.uint8, device=f"cuda:{key[0]}")
+    if w is None or w.numel() < need:
+        size = WORKSPACE_MIN_BYTES
+        while size < need:
+            size *= 2
+        if w is not None:
+            _retired.append(w)
+        w = torch.empty(size, dtype=torch.uint8, device=f"cuda:{key[0]}")
         _workspace[key] = w
     return w
+
+
+def _raw():
+    """the library itself, never the recording proxy (size queries are not launches)"""
+    l = L()
+    return l._lib if isinstance(l, _Recording) else l
+
+
+def _gemm_ws(layout, compute, M, N, K):
+    return workspace(int(_raw().scot_gemm_workspace_bytes(layout, compute, M, N, K)))
 
 
 def gemm(layout: int, compute: int, M: int, N: int, K: int, A, lda: int, B, ldb: int, C, ldc: int, *, bias=None,
          colscale=None, aux=None, ldaux: int = 0, resid=None, ldres: int = 0, a_gelu: bool = False, b_gelu: bool = False,
          accumulate: bool = False, colsum_out=None, aux_mul: bool = False, gelu_deriv_out=None) -> None:
     """scot_gemm — see include/scot_hip.h."""
+    ws = _gemm_ws(layout, compute, M, N, K)
     rc = L().scot_gemm(layout, compute, M, N, K, ptr(A), dt(A), lda, int(a_gelu), ptr(B), dt(B), ldb, int(b_gelu),
                        ptr(C), dt(C), ldc, ptr(bias), ptr(colscale), ptr(aux), dt(aux) if aux is not None else 0, ldaux,
                        ptr(resid), dt(resid) if resid is not None else 0, ldres, int(accumulate), ptr(colsum_out),
-                       workspace().data_ptr(), WORKSPACE_BYTES,
+                       ws.data_ptr(), ws.numel(),
                        int(aux_mul), ptr(gelu_deriv_out), stream())
     _lib.check(rc, "scot_gemm")
 
@@ -184,7 +203,8 @@ def wgrad_group(compute, problems) -> bool:
     for dy, x, dw, _ in problems:
         if dt(dy) != BF16 or dt(x) != BF16 or dw.dtype != torch.float32 or dy.numel() // dy.shape[-1] != K or x.numel() // x.shape[-1] != K:
             return False
-    rc = L().scot_wgrad_group(compute, n, K, dys, xs, dws, dbs, Ms, Ns, workspace().data_ptr(), WORKSPACE_BYTES, stream())
+    ws = workspace(int(_raw().scot_wgrad_group_workspace_bytes(n, K, Ms, Ns)))
+    rc = L().scot_wgrad_group(compute, n, K, dys, xs, dws, dbs, Ms, Ns, ws.data_ptr(), ws.numel(), stream())
     if rc == -3:
         return False
     _lib.check(rc, "scot_wgrad_group")
@@ -321,7 +341,7 @@ def cln_bwd(dout, x, mean, rstd, time, gw_w, gw_b, dx, d_gw_w, d_gw_b, d_bw_w, d
     """mode 0: dx and parameter gradients; 1: dx only; 2: parameter gradients only (dx may be None)."""
     _lib.check(L().scot_cln_bwd(ptr(dout), dt(dout), ptr(x), dt(x), ptr(mean), ptr(rstd), ptr(time), ptr(gw_w), ptr(gw_b),
                                 ptr(dx), dt(dx) if dx is not None else 0, ptr(d_gw_w), ptr(d_gw_b), ptr(d_bw_w), ptr(d_bw_b), ptr(d_xbias), rows,
-                                rows_per_sample, C, workspace().data_ptr(), WORKSPACE_BYTES, ptr(sample_scale), int(mode),
+                                rows_per_sample, C, workspace().data_ptr(), workspace().numel(), ptr(sample_scale), int(mode),
                                 stream()), "scot_cln_bwd")
 
 
@@ -430,6 +450,11 @@ def dp_unpack(wire, dst, scale: float = 1.0):
 def scale_inplace(x, scale: float, nonfinite=None):
     """x (flat fp32, 16-byte aligned) *= scale; nonfinite (int32[1], optional) counts waves that saw Inf/NaN."""
     _lib.check(L().scot_scale_inplace(ptr(x), x.numel(), float(scale), ptr(nonfinite), stream()), "scot_scale_inplace")
+
+
+def scale_inplace_dev(x, scale_dev, nonfinite=None):
+    """x *= scale_dev[0] (a 1-element fp32 device tensor: the fp16 build's dynamic gradient scale or its reciprocal)"""
+    _lib.check(L().scot_scale_inplace_dev(ptr(x), x.numel(), ptr(scale_dev), ptr(nonfinite), stream()), "scot_scale_inplace_dev")
 
 
 def scale_residual(y, scale, resid, out, rows, N):

@@ -72,10 +72,12 @@ class FusedAdamW(torch.optim.Optimizer):
         self.exp_avg_sq = torch.zeros_like(arena.data)
         self._nblocks = int(ops.L().scot_optim_blocks(arena.size))
         self._partial = torch.empty(self._nblocks, device=dev)
-        self._clip = torch.ones(2, device=dev)
+        self._clip = torch.tensor([1.0, 0.0, 0.0], device=dev)        # {clip coefficient, gradient norm, 1 if the norm is not finite}
+        self._step_state = torch.zeros(2, dtype=torch.int32, device=dev)   # {steps applied, steps skipped}: Adam's clock lives on the device
         self.max_grad_norm = max_grad_norm
-        self.step_count = 0
-        self._overflow_seen = torch.zeros(1, dtype=torch.int32, device=dev)   # engine.grad_overflow at the previous step
+        self.step_count = 0             # calls of step() (applied + skipped)
+        # fp16 compute mode: torch.cuda.amp.GradScaler's schedule for the engine's gradient scale
+        self.growth_factor, self.backoff_factor, self.growth_interval, self.max_scale = 2.0, 0.5, 2000, float(2 ** 30)
 
     @property
     def last_grad_norm(self) -> torch.Tensor:
@@ -86,32 +88,53 @@ class FusedAdamW(torch.optim.Optimizer):
         loss = closure() if closure is not None else None
         arena = self.model._arena
         n = arena.size
-        st = ops.stream()
-        L = ops.L()
-        clip_ptr = None
-        if self.max_grad_norm is not None:
-            _lib.check(L.scot_grad_sqnorm(arena.grad.data_ptr(), self._map.data_ptr(), n, self._partial.data_ptr(), st), "scot_grad_sqnorm")
-            _lib.check(L.scot_clip_coef(self._partial.data_ptr(), self._nblocks, float(self.max_grad_norm), self._clip.data_ptr(), st),
-                       "scot_clip_coef")
-            clip_ptr = self._clip.data_ptr()
-        self.step_count += 1
-        g0 = self.param_groups[0]
-        ng = len(self.param_groups)
-        lr = (ctypes.c_float * ng)(*[float(g["lr"]) for g in self.param_groups])
-        wd = (ctypes.c_float * ng)(*[float(g["weight_decay"]) for g in self.param_groups])
-        b1, b2 = g0["betas"]
-        # fp16 compute mode: a step whose gradients overflowed under the gradient scale is skipped ON THE DEVICE (the kernel
-        # compares the engine's cumulative non-finite count with the count at the previous step), like GradScaler.step
         eng = getattr(self.model, "_engine", None)
-        ovf = eng.grad_overflow if (eng is not None and eng.grad_overflow is not None) else None
-        _lib.check(L.scot_adamw_step(arena.data.data_ptr(), arena.grad.data_ptr(), self.exp_avg.data_ptr(), self.exp_avg_sq.data_ptr(),
-                                     self._map.data_ptr(), n, ctypes.cast(lr, ctypes.c_void_p), ctypes.cast(wd, ctypes.c_void_p), ng,
-                                     float(b1), float(b2), float(g0["eps"]), self.step_count, clip_ptr,
-                                     ovf.data_ptr() if ovf is not None else None,
-                                     self._overflow_seen.data_ptr() if ovf is not None else None, st), "scot_adamw_step")
-        if ovf is not None:
-            self._overflow_seen.copy_(ovf)
+        fp16 = eng is not None and eng.scale_state is not None
+        prev = ops.use(eng.lib_kind) if eng is not None else None       # (the 16-bit copy is written in the engine's operand format)
+        try:
+            st = ops.stream()
+            L = ops.L()
+            clip_ptr = None
+            if self.max_grad_norm is not None or fp16:
+                # the norm of the (reduced) gradient: clipping, and — in the fp16 build — the overflow test every rank answers alike
+                _lib.check(L.scot_grad_sqnorm(arena.grad.data_ptr(), self._map.data_ptr(), n, self._partial.data_ptr(), st), "scot_grad_sqnorm")
+                _lib.check(L.scot_clip_coef(self._partial.data_ptr(), self._nblocks, float(self.max_grad_norm or 0.0), self._clip.data_ptr(), st),
+                           "scot_clip_coef")
+                clip_ptr = self._clip.data_ptr()
+            self.step_count += 1
+            g0 = self.param_groups[0]
+            ng = len(self.param_groups)
+            lr = (ctypes.c_float * ng)(*[float(g["lr"]) for g in self.param_groups])
+            wd = (ctypes.c_float * ng)(*[float(g["weight_decay"]) for g in self.param_groups])
+            b1, b2 = g0["betas"]
+            shadow = eng.shadow if (eng is not None and eng.shadow is not None) else None
+            _lib.check(L.scot_adamw_step(arena.data.data_ptr(), arena.grad.data_ptr(), self.exp_avg.data_ptr(), self.exp_avg_sq.data_ptr(),
+                                         self._map.data_ptr(), n, ctypes.cast(lr, ctypes.c_void_p), ctypes.cast(wd, ctypes.c_void_p), ng,
+                                         float(b1), float(b2), float(g0["eps"]), self.step_count, clip_ptr, self._step_state.data_ptr(),
+                                         shadow.data_ptr() if shadow is not None else None, st), "scot_adamw_step")
+            _lib.check(L.scot_optim_finish(self._step_state.data_ptr(), clip_ptr, eng.scale_state.data_ptr() if fp16 else None,
+                                           float(self.growth_factor), float(self.backoff_factor),
+                                           int(self.growth_interval) if fp16 else 0, float(self.max_scale), st), "scot_optim_finish")
+            self.model.mark_weights_dirty()
+            if shadow is not None:
+                if eng.shadow_t is not None:
+                    eng.transpose_weights()         # the data gradients' W^T operands, from the new master weights
+                eng.weight_copies_are_current(self.model._weights_version())
+        finally:
+            if prev is not None:
+                ops.use(prev)
         return loss
+
+    def skipped_steps(self) -> int:
+        """optimizer steps skipped on the device so far (non-finite gradient norm under the fp16 gradient scale); a host read"""
+        return int(self._step_state[1])
+
+    def applied_steps(self) -> int:
+        return int(self._step_state[0])
+
+    def loss_scale_value(self) -> float:
+        eng = getattr(self.model, "_engine", None)
+        return eng.grad_scale_value() if eng is not None else 1.0
 
     def skipped_steps_possible(self) -> bool:
         """True when the model computes in fp16 (steps with overflowed gradients are skipped on the device)."""
@@ -123,7 +146,9 @@ class FusedAdamW(torch.optim.Optimizer):
 
     def state_dict(self) -> Dict:
         sd = super().state_dict()
-        sd["fused"] = dict(step=self.step_count, exp_avg=self.exp_avg, exp_avg_sq=self.exp_avg_sq)
+        eng = getattr(self.model, "_engine", None)
+        sd["fused"] = dict(step=self.step_count, exp_avg=self.exp_avg, exp_avg_sq=self.exp_avg_sq, step_state=self._step_state,
+                           scale_state=eng.scale_state if (eng is not None and eng.scale_state is not None) else None)
         return sd
 
     def load_state_dict(self, sd):
@@ -133,3 +158,11 @@ class FusedAdamW(torch.optim.Optimizer):
             self.step_count = int(fused["step"])
             self.exp_avg.copy_(fused["exp_avg"])
             self.exp_avg_sq.copy_(fused["exp_avg_sq"])
+            if fused.get("step_state") is not None:
+                self._step_state.copy_(fused["step_state"])
+            else:
+                self._step_state.copy_(torch.tensor([self.step_count, 0], dtype=torch.int32))
+            eng = getattr(self.model, "_engine", None)
+            if fused.get("scale_state") is not None and eng is not None and eng.scale_state is not None:
+                eng.scale_state.copy_(fused["scale_state"])
+                eng._scale_ready = True

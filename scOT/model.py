@@ -236,6 +236,7 @@ class ScOT(nn.Module):
         if list(got.items()) != list(self._shapes.items()):  # schema self-check
             raise AssertionError("parameter schema drifted from poseidon_amd.geometry.param_shapes")
         self._arena: Optional[Arena] = None
+        self._explicit_version = 0
         self._engine: Optional[ScOTEngine] = None
         self._anchor = None
         self._grad_hooks = []
@@ -332,9 +333,21 @@ class ScOT(nn.Module):
                 p.grad = None
         self._arena = ar
         self._engine = ScOTEngine(self.config, ar, self.compute)
+        self._engine.weights_version = self._weights_version
         self._anchor = torch.zeros(1, device=device, requires_grad=True)
         self._params = [p for _, p in params]
         self._gviews = [ar.gview(n) for n, _ in params]
+
+    def _weights_version(self):
+        """Moves whenever the fp32 master weights may have changed: in-place torch ops on a parameter (optimizers, load_state_dict,
+        `p.add_()` under no_grad) or on the flat arena (DP broadcast) bump torch's version counters; kernels that write through raw
+        pointers (the fused AdamW) and code that writes through `p.data` call `mark_weights_dirty()`.  The engine re-casts its
+        16-bit weight copies only when this value differs from the one they were made from."""
+        return (sum(p._version for p in self._params), self._arena.data._version, self._explicit_version)
+
+    def mark_weights_dirty(self):
+        """Tell the engine the parameters were modified behind torch's back (writes through `p.data`, foreign kernels)."""
+        self._explicit_version += 1
 
     def flat_parameters(self) -> torch.Tensor:
         return self._arena.data

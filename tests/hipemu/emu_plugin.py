@@ -17,11 +17,11 @@ def pytest_configure(config):
     import emu_session
     from poseidon_amd import ops
     lib = emu_session.load_emu()
-    ws = torch.empty(ops.WORKSPACE_BYTES, dtype=torch.uint8)
+    ws = torch.empty(96 << 20, dtype=torch.uint8)
     ops.L = lambda: lib
     ops.ptr = lambda t: None if t is None else t.data_ptr()
     ops.stream = lambda: None
-    ops.workspace = lambda: ws
+    ops.workspace = lambda need=0: ws
     torch.cuda.synchronize = lambda *a, **k: None
     os.environ["SCOT_EXPERIMENTAL"] = "1"
 

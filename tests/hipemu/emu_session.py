@@ -22,7 +22,7 @@ def load_emu(kind="bf16"):
         for name, argtypes in scot_lib.PROTOTYPES.items():
             fn = getattr(lib, name)          # every symbol of the C ABI must exist in the emulated build too
             fn.argtypes = argtypes
-            fn.restype = None if name in scot_lib._VOID else ctypes.c_int
+            fn.restype = scot_lib.restype(name)
         # the emulated transposing LDS read must satisfy the kernels' own self test (the contract validated on the GPU)
         assert lib.scot_selftest_tr(None) >= 0 and lib.scot_get_use_tr() == 1
         assert lib.scot_operand_format() == scot_lib.OPERAND_FORMAT[kind]
@@ -41,5 +41,4 @@ def patch_ops(monkeypatch, lib, workspace_bytes=32 << 20):
     monkeypatch.setattr(ops, "L", L)
     monkeypatch.setattr(ops, "ptr", lambda t: None if t is None else t.data_ptr())
     monkeypatch.setattr(ops, "stream", lambda: None)
-    monkeypatch.setattr(ops, "workspace", lambda: ws)
-    monkeypatch.setattr(ops, "WORKSPACE_BYTES", workspace_bytes)
+    monkeypatch.setattr(ops, "workspace", lambda need=0: ws)

@@ -107,6 +107,24 @@ def test_c_abi_exports_every_declared_symbol():
     assert f16.scot_abi_version() == 1 and f16.scot_operand_format() == 1
 
 
+def test_workspace_queries_answer_without_a_gpu():
+    """SURVEY.md §8(b) `scot_<op>_workspace_bytes(dims…)`: the split policy of the launching entry points, asked without launching.
+    Poseidon-B at batch 64: the stage-0 / stage-1 grouped weight gradients split K (partial tiles), the deep stages run unsplit."""
+    import ctypes
+    lib = scotlib.load()
+    IA = ctypes.c_int * 4
+    need = [lib.scot_wgrad_group_workspace_bytes(4, K, IA(C, 4 * C, C, 3 * C), IA(4 * C, C, C, C))
+            for K, C in ((65536, 96), (16384, 192), (4096, 384), (1024, 768))]
+    plane = [12 * C * C * 4 for C in (96, 192, 384, 768)]          # Σ M_i N_i floats of a layer's four weight gradients
+    assert need[0] > 0 and need[0] % plane[0] == 0 and need[1] > 0 and need[1] % plane[1] == 0 and need[2:] == [0, 0]
+    assert 8 <= need[0] // plane[0] <= 128                          # nsplit: enough K slices to fill the chip, >= 8 K-tiles each
+    tn = lib.scot_gemm_workspace_bytes(2, 1, 96, 384, 65536)        # one long-K weight gradient alone (TN)
+    assert tn > 0 and tn % (96 * 384 * 4) == 0
+    assert lib.scot_gemm_workspace_bytes(0, 1, 1024, 768, 3072) == 0      # forward GEMMs run unsplit by default
+    assert lib.scot_gemm_workspace_bytes(2, 1, 96, 384, 7) == 0            # a shape the fast path declines: no scratch either
+    assert lib.scot_wgrad_group_workspace_bytes(0, 1024, IA(), IA()) == 0
+
+
 def test_step_tape_skips_calls_the_library_declined():
     """A C-ABI call that answers SCOT_ERR_UNSUPPORTED launched nothing and its caller falls back to other launches: the recorded step
     must hold the fallback launches only (a replayed -3 would otherwise abort every later step)."""

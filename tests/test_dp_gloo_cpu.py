@@ -126,7 +126,7 @@ def _engine_worker(rank, world, port, out):
     from scOT.model import ScOT
     lib = emu_session.load_emu()
     ws = torch.empty(32 << 20, dtype=torch.uint8)
-    ops.L, ops.stream, ops.workspace, ops.WORKSPACE_BYTES = (lambda: lib), (lambda: None), (lambda: ws), 32 << 20
+    ops.L, ops.stream, ops.workspace = (lambda: lib), (lambda: None), (lambda need=0: ws)
     ops.ptr = lambda t: None if t is None else t.data_ptr()
     dist.init_process_group("gloo", rank=rank, world_size=world)
     cfg = ScOTConfig(**dict(TINY, mlp_ratio=4.0, qkv_bias=True, p=1, channel_slice_list_normalized_loss=[0, 1, 3, 4],
@@ -188,6 +188,89 @@ def test_engine_ranges_are_final_when_announced(tmp_path):
 
 
 # ------------------------------------------------------------------------------------------------------------------------
+# The same hook through the STEP TAPE with the bf16 wire (round-2 advisor finding): the exchange's pack / unpack launches go through
+# `ops`, so while a step is being recorded they must not be logged next to the callback that issues them — a replayed step would
+# otherwise pack / sum / unpack every range twice (gradient = mean / N).  Steps 1 (direct), 2 (recorded), 3-5 (replayed) must all
+# equal the fp32 mean of the two ranks' stand-alone gradients to bf16 rounding.
+def _taped_bf16_worker(rank, world, port, out):
+    import sys
+    here = os.path.dirname(os.path.abspath(__file__))
+    sys.path.insert(0, os.path.join(here, "hipemu"))
+    sys.path.insert(0, here)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), SCOT_SIDE_STREAM="0", SCOT_TAPE="1")
+    import emu_session
+    from poseidon_amd import ops
+    from poseidon_amd.synth import synth_inputs, synth_state_dict
+    from scOT.model import ScOT
+    lib = emu_session.load_emu()
+    ws = torch.empty(32 << 20, dtype=torch.uint8)
+    ops.L = lambda: ops._Recording(lib, ops._recorder) if ops._recorder is not None else lib
+    ops.stream, ops.workspace = (lambda: None), (lambda need=0: ws)
+    ops.ptr = lambda t: None if t is None else t.data_ptr()
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    cfg = ScOTConfig(**dict(TINY, mlp_ratio=4.0, qkv_bias=True, p=1, channel_slice_list_normalized_loss=[0, 1, 3, 4], drop_path_rate=0.0))
+    model = ScOT(cfg, compute="fp32")
+    model.load_state_dict(synth_state_dict(param_shapes(cfg), "trained"))
+    model._ensure_arena(torch.device("cpu"))
+    eng = model._engine
+    assert eng.tape_mode
+
+    def step(k):
+        pv, t, lab = synth_inputs(4, 4, 4, 32, "smooth")
+        pv = pv * (1.0 + 0.1 * k)                              # different data every step (a replay must not reuse step 2's numbers)
+        sl = slice(2 * rank, 2 * rank + 2)
+        model._arena.grad.zero_()
+        loss, _, tape = eng.forward(pv[sl].contiguous(), t[sl].contiguous(), lab[sl].contiguous(), None, train=True)
+        model._prepare_grads()
+        eng.backward(tape, torch.ones(1), None)
+        return model._arena.grad.clone()
+
+    expect = []
+    for k in range(5):                                         # reference: no hook, fp32 mean over ranks after the step
+        g = step(k)
+        both = [torch.empty_like(g) for _ in range(world)]
+        dist.all_gather(both, g)
+        expect.append(sum(both) / world)
+    eng.reset_tapes()
+    red = GradAllReducer(model, dist, wire="bf16", chunk_mb=1)
+    ranges = {p: (s, e) for p, s, e in red.ranges_in_backward_order()}
+    calls = []
+
+    def on_final(prefix):
+        calls.append(prefix)
+        s, e = ranges[prefix]
+        red.reduce_range(s, e)
+
+    eng.on_grads_final = on_final
+    errs = []
+    for k in range(5):
+        n0 = len(calls)
+        got = step(k)
+        assert len(calls) - n0 == len(ranges)                 # every range announced exactly once per step, replayed steps included
+        errs.append(float((got - expect[k]).norm() / expect[k].norm()))
+    states = [e["state"] for e in eng._taped.values()]
+    assert states == ["ready"], states                         # steps 3-5 really were replays
+    assert max(errs) < 6e-3, (rank, errs)                      # bf16 wire: 2^-9 per element; the double exchange was off by 2x
+    dist.barrier()
+    dist.destroy_process_group()
+    if rank == 0:
+        open(out, "w").write("ok " + " ".join(f"{e:.1e}" for e in errs))
+
+
+def test_taped_step_with_bf16_wire_exchanges_each_range_once(tmp_path):
+    import shutil
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "hipemu"))
+    import build_emu
+    if not (os.path.exists(build_emu.CLANG) or shutil.which(build_emu.CLANG)):
+        pytest.skip("no host clang with __bf16 vector support")
+    build_emu.build_cached()
+    out = str(tmp_path / "ok")
+    mp.spawn(_taped_bf16_worker, args=(2, 33500 + (os.getpid() % 2000), out), nprocs=2, join=True)
+    assert open(out).read().startswith("ok")
+
+
+# ------------------------------------------------------------------------------------------------------------------------
 # The training driver (poseidon_amd/train.py) under data parallelism: two ranks, the epoch's permutation sharded
 # DistributedSampler-style, the mean gradient exchanged after every step -> both replicas hold the SAME parameters after
 # training (DDP's invariant), they differ from what either rank would have learnt alone, and evaluation / prediction return the
@@ -206,8 +289,8 @@ def _trainer_worker(rank, world, port, out):
     from test_trainer_emu_cpu import Samples
     lib = emu_session.load_emu()
     ws = torch.empty(32 << 20, dtype=torch.uint8)
-    ops.L, ops.stream, ops.workspace, ops.WORKSPACE_BYTES = (lambda: ops._Recording(lib, ops._recorder) if ops._recorder is not None else lib), \
-        (lambda: None), (lambda: ws), 32 << 20
+    ops.L, ops.stream, ops.workspace = (lambda: ops._Recording(lib, ops._recorder) if ops._recorder is not None else lib), \
+        (lambda: None), (lambda need=0: ws)
     ops.ptr = lambda t: None if t is None else t.data_ptr()
     M._require_hip = lambda t: None
     dist.init_process_group("gloo", rank=rank, world_size=world)

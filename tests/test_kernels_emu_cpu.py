@@ -229,3 +229,63 @@ def test_patchify_strip_kernel(gpu_test_bodies, H, W, Cc):
 @pytest.mark.parametrize("Cc,H,W", [(4, 32, 32), (5, 13, 10), (1, 20, 132)])
 def test_conv5_tiled(gpu_test_bodies, Cc, H, W):
     gpu_test_bodies.test_conv5(Cc, H, W)
+
+
+def test_optimizer_kernels_skip_clock_scale_and_operand_copy(emu):
+    """csrc/optim.hip on the CPU: scot_clip_coef's non-finite flag, scot_adamw_step (torch.optim.AdamW arithmetic, Adam's clock read
+    from the device, skip on a non-finite norm, 16-bit operand copy of the new weights in the same pass), scot_optim_finish
+    (GradScaler's scale schedule) and scot_scale_inplace_dev (the scale read from the device)."""
+    import ctypes
+    import numpy as np
+    L = ops.L()
+    n = 64 * 24
+    g0 = torch.Generator().manual_seed(0)
+    p = torch.randn(n, generator=g0)
+    ref = p.clone().requires_grad_(True)
+    topt = torch.optim.AdamW([ref], lr=1e-2, weight_decay=0.1, betas=(0.9, 0.999), eps=1e-8)
+    m, v = torch.zeros(n), torch.zeros(n)
+    map8 = torch.zeros(n // 8, dtype=torch.uint8)
+    map8[-2:] = 255                                               # alignment padding: never stepped, never copied
+    nblk = int(L.scot_optim_blocks(n))
+    partial, clip = torch.empty(nblk), torch.tensor([1.0, 0.0, 0.0])
+    step_state = torch.zeros(2, dtype=torch.int32)
+    scale_state = torch.tensor([1024.0, 1.0 / 1024.0, 0.0, 0.0])
+    shadow = torch.full((n,), -7.0, dtype=torch.bfloat16)
+    lr, wd = (ctypes.c_float * 1)(1e-2), (ctypes.c_float * 1)(0.1)
+
+    def step(grad, host_step):
+        assert L.scot_grad_sqnorm(grad.data_ptr(), map8.data_ptr(), n, partial.data_ptr(), None) == 0
+        assert L.scot_clip_coef(partial.data_ptr(), nblk, 0.0, clip.data_ptr(), None) == 0
+        assert L.scot_adamw_step(p.data_ptr(), grad.data_ptr(), m.data_ptr(), v.data_ptr(), map8.data_ptr(), n, ctypes.cast(lr, ctypes.c_void_p),
+                                 ctypes.cast(wd, ctypes.c_void_p), 1, 0.9, 0.999, 1e-8, host_step, clip.data_ptr(), step_state.data_ptr(),
+                                 shadow.data_ptr(), None) == 0
+        assert L.scot_optim_finish(step_state.data_ptr(), clip.data_ptr(), scale_state.data_ptr(), 2.0, 0.5, 2, float(2 ** 20), None) == 0
+
+    grads = [torch.randn(n, generator=g0) for _ in range(4)]
+    live = slice(0, n - 16)
+    for k, g in enumerate(grads[:2]):
+        step(g, k + 1)
+        ref.grad = g.clone()
+        topt.step()
+    assert clip.tolist()[0] == 1.0 and clip.tolist()[2] == 0.0 and abs(clip[1].item() - grads[1][live].norm().item()) < 1e-3
+    assert torch.allclose(p[live], ref.detach()[live], rtol=1e-6, atol=1e-7) and step_state.tolist() == [2, 0]
+    assert torch.equal(shadow[live], p[live].to(torch.bfloat16)) and torch.all(shadow[n - 16:] == -7.0)      # padding untouched
+    assert scale_state.tolist()[:3] == [2048.0, 1.0 / 2048.0, 0.0]                                           # two clean steps: doubled
+    bad = grads[2].clone()
+    bad[5] = float("nan")
+    p_before, m_before, sh_before = p.clone(), m.clone(), shadow.clone()
+    step(bad, 99)                                                  # the host's step number is ignored: the device clock rules
+    assert clip[2].item() == 1.0 and torch.equal(p, p_before) and torch.equal(m, m_before) and torch.equal(shadow, sh_before)
+    assert step_state.tolist() == [2, 1] and scale_state.tolist()[:3] == [1024.0, 1.0 / 1024.0, 0.0]
+    step(grads[3], 99)                                             # resumes as Adam step 3 (bias correction of the third APPLIED step)
+    ref.grad = grads[3].clone()
+    topt.step()
+    assert torch.allclose(p[live], ref.detach()[live], rtol=1e-6, atol=1e-7) and step_state.tolist() == [3, 1]
+    # the device-resident scale: x *= *scale, non-finite results counted
+    x = torch.arange(1, 41, dtype=torch.float32)
+    cnt = torch.zeros(1, dtype=torch.int32)
+    ops.scale_inplace_dev(x, scale_state[1:2], cnt)
+    assert torch.equal(x, torch.arange(1, 41, dtype=torch.float32) / 1024.0) and int(cnt) == 0
+    x[3] = float("inf")
+    ops.scale_inplace_dev(x, scale_state[0:1], cnt)
+    assert int(cnt) == 1 and np.isinf(x[3].item())

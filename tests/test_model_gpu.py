@@ -14,6 +14,7 @@ from conftest import load_fixture, rel_l2  # noqa: E402
 from poseidon_amd.config import ScOTConfig  # noqa: E402
 from poseidon_amd.geometry import param_shapes  # noqa: E402
 from poseidon_amd.synth import apply_obstacle, generate_on, synth_inputs, synth_obstacle_mask, synth_state_dict  # noqa: E402
+from poseidon_amd import ops  # noqa: E402
 from scOT.model import ScOT  # noqa: E402
 
 DEV = "cuda"
@@ -596,33 +597,109 @@ def test_device_resident_batches_downsampled():
         assert np.allclose(b["labels"][k].cpu().numpy(), s["labels"].numpy(), rtol=1e-4, atol=2e-5)
 
 
-def test_fused_adamw_skips_steps_with_overflowed_gradients():
-    """fp16 compute mode: the gradient un-scale counts non-finite values; FusedAdamW compares that count with the previous step's
-    ON THE DEVICE and leaves parameters and moments untouched when it moved (GradScaler.step semantics, no host round trip)."""
+def test_fused_adamw_skips_overflowed_steps_and_adapts_the_gradient_scale():
+    """fp16 compute mode: a step whose (reduced) gradient norm is not finite leaves parameters and moments untouched, does not
+    advance Adam's clock, and halves the engine's gradient scale; N clean steps in a row double it (torch.cuda.amp.GradScaler's
+    rule) — all ON THE DEVICE (scot_clip_coef / scot_adamw_step / scot_optim_finish), no host round trip in step()."""
     from scOT.trainer import FusedAdamW
     f, meta = load_fixture("tiny_trained")
     cfg, model = build(meta, "fp16")
     kw = inputs(cfg, meta)
     model(**kw).loss.backward()
     opt = FusedAdamW(model, lr=1e-2)
-    assert opt.skipped_steps_possible()
+    opt.growth_interval = 2
+    eng = model._engine
+    S0 = eng.grad_scale_value()
+    assert S0 == 2.0 ** int(np.floor(np.log2(kw["labels"].numel()))) and opt.loss_scale_value() == S0
     p0 = model.flat_parameters().clone()
     opt.step()                                            # a normal step moves the parameters
     torch.cuda.synchronize()
     p1 = model.flat_parameters().clone()
-    assert not torch.equal(p0, p1) and int(model._engine.grad_overflow) == 0
+    assert not torch.equal(p0, p1) and int(eng.grad_overflow) == 0 and (opt.applied_steps(), opt.skipped_steps()) == (1, 0)
     opt.zero_grad()
     model(**kw).loss.backward()
-    model._engine.grad_overflow.add_(3)                   # as if the un-scale had met Inf/NaN in this backward
+    model.flat_grads()[model._arena.offsets["embeddings.norm.bias.bias"]] = float("inf")     # as an overflow in the 16-bit backward leaves it
     m1 = opt.exp_avg.clone()
     opt.step()
     torch.cuda.synchronize()
     assert torch.equal(model.flat_parameters(), p1) and torch.equal(opt.exp_avg, m1)      # skipped
+    assert (opt.applied_steps(), opt.skipped_steps()) == (1, 1) and eng.grad_scale_value() == S0 / 2
+    for k in range(2):                                    # two clean steps in a row: the scale is doubled again
+        opt.zero_grad()
+        out = model(**kw)
+        out.loss.backward()
+        opt.step()
+    torch.cuda.synchronize()
+    assert not torch.equal(model.flat_parameters(), p1) and (opt.applied_steps(), opt.skipped_steps()) == (3, 1)
+    assert eng.grad_scale_value() == S0 and int(eng.grad_overflow) == 0
+    # the gradients of a step are the same at any (power-of-two) scale: halving the scale by hand changes nothing but round-off
     opt.zero_grad()
     model(**kw).loss.backward()
-    opt.step()                                            # the count did not move again: stepping resumes
-    torch.cuda.synchronize()
-    assert not torch.equal(model.flat_parameters(), p1)
+    g_full = model.flat_grads().clone()
+    eng.scale_state.copy_(torch.tensor([S0 / 4, 4 / S0, 0.0, 0.0]))
+    opt.zero_grad()
+    model(**kw).loss.backward()
+    assert float((model.flat_grads() - g_full).norm() / g_full.norm()) < 2e-3
+    # a checkpoint carries the clock and the scale
+    sd = opt.state_dict()
+    assert sd["fused"]["step_state"].tolist() == [3, 1] and float(sd["fused"]["scale_state"][0]) == S0 / 4
+
+
+def test_weight_copies_follow_the_master_weights():
+    """The 16-bit operand copies of the weights are refreshed only when the fp32 master changed: (a) in-place edits through torch
+    (version counters) and `mark_weights_dirty()` are seen by the next forward, (b) the fused AdamW writes the copies itself —
+    the forward after it issues no cast and still computes with the new weights."""
+    from scOT.trainer import FusedAdamW
+    f, meta = load_fixture("tiny_trained")
+    cfg, model = build(meta, "fp16")
+    kw = inputs(cfg, meta)
+    eng_casts = []
+    real_cast = ops.cast
+
+    def counting_cast(src, dst):
+        eng_casts.append(src.numel())
+        return real_cast(src, dst)
+    ops.cast = counting_cast
+    try:
+        with torch.no_grad():
+            y0 = model(**kw).output.clone()
+            n0 = len(eng_casts)
+            y1 = model(**kw).output.clone()
+            assert len(eng_casts) == n0 and torch.equal(y0, y1)                  # unchanged weights: no cast
+            name = "patch_recovery.projection.bias"
+            dict(model.named_parameters())[name].add_(0.5)                        # in-place edit through torch
+            y2 = model(**kw).output.clone()
+            assert len(eng_casts) > n0 and float((y2 - y1).abs().mean()) > 0.1
+            w = dict(model.named_parameters())["encoder.layers.0.blocks.0.output.dense.weight"]
+            w.data.mul_(1.5)                                                       # behind torch's back ...
+            n1 = len(eng_casts)
+            model.mark_weights_dirty()                                             # ... so the engine has to be told
+            y3 = model(**kw).output.clone()
+            assert len(eng_casts) > n1 and not torch.equal(y3, y2)
+        model(**kw).loss.backward()
+        opt = FusedAdamW(model, lr=1e-2)
+        n2 = len(eng_casts)
+        opt.step()
+        eng = model._engine
+        torch.cuda.synchronize()
+        # the optimizer's copy == a fresh cast of the new master weights, for every parameter; transposed copies too
+        fresh = torch.empty_like(eng.shadow)
+        real_cast(eng.arena.data, fresh)
+        for nme in ("encoder.layers.0.blocks.0.output.dense.weight", "embeddings.norm.weight.bias", "decoder.layers.1.blocks.1.attention.self.value.weight"):
+            o, k = eng.arena.offsets[nme], eng.arena.numel(nme)
+            assert torch.equal(eng.shadow[o:o + k], fresh[o:o + k])
+        wn = "encoder.layers.0.blocks.0.output.dense.weight"
+        assert torch.equal(eng.WT(wn), eng.W(wn).t().contiguous())
+        with torch.no_grad():
+            y4 = model(**kw).output.clone()
+        assert len(eng_casts) == n2 and not torch.equal(y4, y3)                   # no cast after the fused step, new weights in use
+        model2_sd = {k: v.clone() for k, v in model.state_dict().items()}
+    finally:
+        ops.cast = real_cast
+    cfg2, fresh_model = build(meta, "fp16")
+    fresh_model.load_state_dict(model2_sd)
+    with torch.no_grad():
+        assert torch.equal(fresh_model(**kw).output, y4)                          # == a model that casts everything from scratch
 
 
 @pytest.mark.parametrize("regime_fixture,lr,tol", [("tiny_trained", 1e-4, 1e-2), ("tiny_hf", 2e-3, 1e-4)])
