@@ -163,8 +163,16 @@ int scot_cln_bwd(const void* dout, int dout_dt, const void* x, int x_dt, const f
                  const float* time, const float* gw_w, const float* gw_b, void* dx, int dx_dt, float* d_gw_w,
                  float* d_gw_b, float* d_bw_w, float* d_bw_b, float* d_xbias, int rows, int rows_per_sample, int C,
                  void* workspace, size_t ws_bytes, const float* sample_scale, int mode, scot_stream_t stream);
-/* out2: optional second copy of the output in the next GEMM's operand dtype; d_xbias: optional += Σ_rows dx;
- * workspace: optional scratch for per-block column sums (avoids 4·C same-address atomics per block). */
+/* out2: optional second copy of the output in the next GEMM's operand dtype; d_xbias: optional += Σ_rows dx.
+ * mode 3 (the deep stages' small row counts: rows <= 8192, C % 64 == 0, 128 <= C <= 1536): dx as in mode 1, every wave owning ONE
+ * pass of rows, plus the block's partial parameter-gradient sums written to `workspace` (>= scot_cln_bwd_workspace_bytes, 16-byte
+ * aligned; d_* unused, may be NULL) — no atomics on the dependent chain.  scot_cln_bwd_finish adds the partials into the four (two
+ * without conditioning) parameter gradients, which must be contiguous [weight.weight | weight.bias | bias.weight | bias.bias] as they
+ * are in the parameter arena; it may run on any stream ordered behind the mode-3 call (the engine: its weight-gradient stream).
+ * Returns -3 where the form does not apply (workspace query: 0). */
+size_t scot_cln_bwd_workspace_bytes(int rows, int rows_per_sample, int C, int conditional);
+int scot_cln_bwd_finish(const void* partial, int rows, int rows_per_sample, int C, float* d_gw_w, float* d_gw_b, float* d_bw_w,
+                        float* d_bw_b, scot_stream_t stream);
 
 /* EXPERIMENTAL (off unless SCOT_FUSED_MLP=1; see poseidon_amd/csrc/mlp_fused.hip) — the MLP half of a ScOTLayer in one launch:
  *   z = gelu(h16·W1^T + b1)·W2^T + b2   (Swinv2Intermediate + Swinv2Output, HF modeling_swinv2.py:533-561)

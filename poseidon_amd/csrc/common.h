@@ -72,6 +72,20 @@ template <typename CT> struct ct_traits;
 template <> struct ct_traits<float> { static constexpr int dtype = SCOT_F32; static constexpr int kpad = 4; };
 template <> struct ct_traits<bf16_t> { static constexpr int dtype = SCOT_BF16; static constexpr int kpad = 8; };
 
+// ---- ablation hooks (tools/ablate_kernels.py builds extra copies of ONE source with -DSCOT_ABL=<bits>; the product never defines it).
+// TIMING ONLY — results are garbage: 1 = st8 stores nothing (values kept alive), 2 = gelu_terms is two multiplies, 4 = ld8 loads
+// nothing, 8 = no MFMA (and, dead-code-eliminated with it, no fragment reads), 16 = __syncthreads is a no-op, 32 = no global atomics,
+// 64 = mlp_fused.hip: gelu'(u) is not loaded, 128 = mlp_fused.hip: du is not stored.
+#ifndef SCOT_ABL
+#define SCOT_ABL 0
+#endif
+#if SCOT_ABL & 16
+#define __syncthreads() __builtin_amdgcn_wave_barrier()
+#endif
+#if SCOT_ABL & 32
+#define atomicAdd(p, v) asm volatile("" ::"v"(v))
+#endif
+
 // ---- runtime-dtype global memory access (dtype is wave-uniform → scalar branch) ----------------------------
 __device__ __forceinline__ float ld1(const void* p, int dt, size_t i) {
   return dt == SCOT_F32 ? ((const float*)p)[i] : bf2f(((const bf16_t*)p)[i]);
@@ -81,6 +95,10 @@ __device__ __forceinline__ void st1(void* p, int dt, size_t i, float v) {
 }
 // 8 consecutive elements; caller guarantees 16-byte alignment of element i (f32: 32-byte span, two 16 B loads)
 __device__ __forceinline__ void ld8(const void* p, int dt, size_t i, float v[8]) {
+#if SCOT_ABL & 4
+  for (int j = 0; j < 8; ++j) v[j] = 1.0f + (float)(i & 7);
+  return;
+#endif
   if (dt == SCOT_F32) {
     const float4 a = *(const float4*)((const float*)p + i);
     const float4 b = *(const float4*)((const float*)p + i + 4);
@@ -91,6 +109,10 @@ __device__ __forceinline__ void ld8(const void* p, int dt, size_t i, float v[8])
   }
 }
 __device__ __forceinline__ void st8(void* p, int dt, size_t i, const float v[8]) {
+#if SCOT_ABL & 1
+  asm volatile("" ::"v"(v[0]), "v"(v[1]), "v"(v[2]), "v"(v[3]), "v"(v[4]), "v"(v[5]), "v"(v[6]), "v"(v[7]));
+  return;
+#endif
   if (dt == SCOT_F32) {
     *(float4*)((float*)p + i) = make_float4(v[0], v[1], v[2], v[3]);
     *(float4*)((float*)p + i + 4) = make_float4(v[4], v[5], v[6], v[7]);
@@ -106,6 +128,10 @@ __device__ __forceinline__ void st8(void* p, int dt, size_t i, const float v[8])
 // fp32 GELU resolution for the 1e-5 parity mode) needs one exp, one rcp and a degree-5 Horner chain — and the SAME
 // exp(-x^2/2) also gives the Gaussian term of the derivative.
 __device__ __forceinline__ void gelu_terms(float x, float& cdf, float& pdf_times_sqrt2pi) {
+#if SCOT_ABL & 2
+  cdf = 0.5f * x; pdf_times_sqrt2pi = 0.25f * x;
+  return;
+#endif
   // 15 VALU instructions per element (v_rcp_f32 and v_exp_f32 directly: `__frcp_rn` expands to the 11-instruction IEEE division
   // sequence, which made this function 28 instructions and the fused MLP kernels VALU-bound on it — round-2 microbenchmarks)
   const float z = fabsf(x) * 0.70710678118654752f;
@@ -167,6 +193,9 @@ template <> __device__ __forceinline__ Frag<bf16_t> frag_from_f32<bf16_t>(const 
 }
 
 __device__ __forceinline__ void mma16(f32x4_t& c, const Frag<bf16_t>& a, const Frag<bf16_t>& b) {
+#if SCOT_ABL & 8
+  return;
+#endif
 #if defined(SCOT_OPERAND_FP16)
   c = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(bf16x8_t, a.v), __builtin_bit_cast(bf16x8_t, b.v), c, 0, 0, 0);
 #else

@@ -394,7 +394,11 @@ __device__ __forceinline__ void mlp_bwd_body(const MlpBwdArgs& p, char* smem, fl
     for (int tt = 0; tt < TT; ++tt)
 #pragma unroll
       for (int blk = 0; blk < NB; ++blk)
+#if SCOT_ABL & 64
+        gpv[tt][blk] = (s16x8_t){15360, 15360, 15360, 15360, 15360, 15360, 15360, 15360};
+#else
         gpv[tt][blk] = *(const s16x8_t*)(p.dact + (size_t)min(rowt[tt], p.M - 1) * HID + (size_t)c * HC + blk * 32 + g * 8);
+#endif
 #pragma unroll
     for (int blk = 0; blk < NB; ++blk) {
       f32x4_t U[TT][2];
@@ -418,7 +422,11 @@ __device__ __forceinline__ void mlp_bwd_body(const MlpBwdArgs& p, char* smem, fl
 #pragma unroll
           for (int r = 0; r < 4; ++r) dv[4 * ts + r] = U[tt][ts][r] * bf2f((bf16_t)gpv[tt][blk][4 * ts + r]);
         af[tt] = frag_from_f32<bf16_t>(dv);
+#if SCOT_ABL & 128
+        asm volatile("" ::"v"(af[tt].v));
+#else
         if (rowt[tt] < p.M) *(s16x8_t*)(p.du + (size_t)rowt[tt] * HID + (size_t)c * HC + blk * 32 + g * 8) = af[tt].v;
+#endif
       }
 #pragma unroll
       for (int nt = 0; nt < NT; ++nt) {

@@ -171,8 +171,15 @@ extern "C" int scot_cln_bwd(const void* dout, int dout_dt, const void* x, int x_
                             int rows_per_sample, int C, void* workspace, size_t ws_bytes, const float* sample_scale, int mode,
                             hipStream_t stream) {
   if (rows <= 0 || C <= 0 || rows_per_sample <= 0 || rows % rows_per_sample) return SCOT_ERR_SHAPE;
-  if (mode < 0 || mode > 2 || (mode == 2 && d_xbias)) return SCOT_ERR_SHAPE;
-  if (!gw_b || (mode != 1 && (!d_gw_b || !d_bw_b || (gw_w && (!d_gw_w || !d_bw_w)))) || (gw_w && !time)) return SCOT_ERR_SHAPE;
+  if (mode < 0 || mode > 3 || (mode == 2 && d_xbias)) return SCOT_ERR_SHAPE;
+  if (!gw_b || ((mode == 0 || mode == 2) && (!d_gw_b || !d_bw_b || (gw_w && (!d_gw_w || !d_bw_w)))) || (gw_w && !time)) return SCOT_ERR_SHAPE;
+  if (mode == 3) {   // dx + per-block partials into `workspace` (scot_cln_bwd_workspace_bytes), finished by scot_cln_bwd_finish; fast path only
+    ClnFastArgs f{};
+    f.dout = dout; f.dout_dt = dout_dt; f.x = x; f.x_dt = x_dt; f.mean = (float*)mean; f.rstd = (float*)rstd; f.time = time;
+    f.gw_w = gw_w; f.gw_b = gw_b; f.dx = dx; f.dx_dt = dx_dt; f.d_xbias = d_xbias;
+    f.rows = rows; f.rows_per_sample = rows_per_sample; f.C = C; f.sscale = sample_scale; f.mode = 3;
+    return scot_cln_bwd_fast(f, workspace, ws_bytes, stream);
+  }
   {
     ClnFastArgs f{};
     f.dout = dout; f.dout_dt = dout_dt; f.x = x; f.x_dt = x_dt; f.mean = (float*)mean; f.rstd = (float*)rstd; f.time = time;
@@ -193,4 +200,27 @@ extern "C" int scot_cln_bwd(const void* dout, int dout_dt, const void* x, int x_
   int rc = scot_check_launch();
   if (rc == SCOT_OK && d_xbias && mode != 2) rc = scot_colsum(dx, dx_dt, nullptr, 0, d_xbias, rows, C, C, stream);
   return rc;
+}
+
+// include/scot_hip.h: scot_cln_bwd_workspace_bytes / scot_cln_bwd_finish (mode 3 of scot_cln_bwd)
+int scot_cln_bwd_finish_launch(const float* partial, int nblk, int ncol, float* out, hipStream_t s);
+extern "C" size_t scot_cln_bwd_workspace_bytes(int rows, int rows_per_sample, int C, int conditional) {
+  int blocks, rpb;
+  if (!scot_cln_bwd_partial_plan(rows, rows_per_sample, C, &blocks, &rpb)) return 0;
+  return (size_t)blocks * (conditional ? 4 : 2) * C * sizeof(float);
+}
+extern "C" int scot_cln_bwd_finish(const void* partial, int rows, int rows_per_sample, int C, float* d_gw_w, float* d_gw_b,
+                                   float* d_bw_w, float* d_bw_b, hipStream_t stream) {
+  int blocks, rpb;
+  if (!partial || !d_gw_b || !d_bw_b || (d_gw_w == nullptr) != (d_bw_w == nullptr)) return SCOT_ERR_SHAPE;
+  if (!scot_cln_bwd_partial_plan(rows, rows_per_sample, C, &blocks, &rpb)) return SCOT_ERR_UNSUPPORTED;
+  if (d_gw_w) {
+    // [t·dγ | dγ | t·dβ | dβ] lands on [weight.weight | weight.bias | bias.weight | bias.bias]: contiguous in the parameter arena
+    // (C % 64 == 0: every tensor starts on a 64-float boundary); four launches when a caller keeps them apart
+    if (d_gw_b == d_gw_w + C && d_bw_w == d_gw_w + 2 * C && d_bw_b == d_gw_w + 3 * C)
+      return scot_cln_bwd_finish_launch((const float*)partial, blocks, 4 * C, d_gw_w, stream);
+    return SCOT_ERR_UNSUPPORTED;
+  }
+  if (d_bw_b == d_gw_b + C) return scot_cln_bwd_finish_launch((const float*)partial, blocks, 2 * C, d_gw_b, stream);
+  return SCOT_ERR_UNSUPPORTED;
 }

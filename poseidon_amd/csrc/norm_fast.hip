@@ -66,7 +66,12 @@ __global__ __launch_bounds__(256) void cln_fwd_fast_kernel(ClnFastArgs p) {
 }
 
 // MODE 0: dx and the parameter gradients;  1: dx only (the dependent chain's half: a pure stream, no reductions over rows);
-// 2: parameter gradients only (no row statistics needed: Σ dout·xhat, Σ dout) — the engine runs this half on the side stream.
+// 2: parameter gradients only (no row statistics needed: Σ dout·xhat, Σ dout) — the engine runs this half on the side stream;
+// 3: dx + the block's partial column sums written to p.partial (no atomics): the small-row-count form of the deep stages
+// (1024 / 4096 rows at batch 64), where mode 0 left 64-256 blocks walking 4-8 rows each one HBM round trip after the other and
+// ending in 5·C global atomics — 16-20 us of pure latency on the dependent chain, 69 times per step.  Here every wave owns ONE
+// pass of rows (all loads of the kernel in flight at once), and the cross-block reduction is a second tiny launch that the engine
+// puts on the side stream (scot_cln_bwd_finish): nothing downstream on the chain reads parameter gradients.
 // NWV = waves per block (4 or 8).  Every block ends in 4-5 global atomics per column, so with many rows (stages 0/1) twice the
 // waves per block = half the blocks = half the atomics at the same number of rows per wave.
 template <int LPR, int CPL, int MODE, int NWV>
@@ -75,7 +80,9 @@ __global__ __launch_bounds__(NWV * 64) void cln_bwd_fast_kernel(ClnFastArgs p) {
   constexpr int NCOL = LPR * CPL * 8;      // columns covered (>= C)
   // [copy][dgamma | dbeta | dxsum][j][chunk] for column chunk*8 + j (chunk-major within j: the lanes of one access hit
   // consecutive banks); waves 0-3 combine into copy 0, waves 4-7 into copy 1
-  __shared__ float red[NWV / 4][3][NCOL];
+  // (MODE 3 parks the four waves' sums side by side instead: [4][dγ | dβ][NCOL] in the same LDS)
+  __shared__ float red_raw[MODE == 3 ? 4 * 2 * NCOL : (NWV / 4) * 3 * NCOL];
+  float (*red)[3][NCOL] = (float (*)[3][NCOL])red_raw;
   constexpr int NCH = NCOL / 8;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int sub = lane / LPR, l = lane % LPR;
@@ -173,6 +180,33 @@ __global__ __launch_bounds__(NWV * 64) void cln_bwd_fast_kernel(ClnFastArgs p) {
         ag[i][j] += __shfl_xor(ag[i][j], o, 64); ab[i][j] += __shfl_xor(ab[i][j], o, 64); ax[i][j] += __shfl_xor(ax[i][j], o, 64);
       }
     }
+  if (MODE == 3) {
+    // one barrier: every wave parks its column sums in its own LDS slice, the first C threads add the four
+    float (*part)[2][NCOL] = (float (*)[2][NCOL])red_raw;
+    if (sub == 0) {
+#pragma unroll
+      for (int i = 0; i < CPL; ++i)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          const int c = j * NCH + l + i * LPR;
+          part[wave][0][c] = ag[i][j]; part[wave][1][c] = ab[i][j];
+        }
+    }
+    __syncthreads();
+    for (int c = threadIdx.x; c < C; c += 256) {
+      const int k = (c & 7) * NCH + (c >> 3);
+      const float dg = part[0][0][k] + part[1][0][k] + part[2][0][k] + part[3][0][k];
+      const float db = part[0][1][k] + part[1][1][k] + part[2][1][k] + part[3][1][k];
+      if (p.gw_w) {
+        float* row = p.partial + (size_t)blockIdx.x * 4 * C;
+        row[c] = t * dg; row[C + c] = dg; row[2 * C + c] = t * db; row[3 * C + c] = db;
+      } else {
+        float* row = p.partial + (size_t)blockIdx.x * 2 * C;
+        row[c] = dg; row[C + c] = db;
+      }
+    }
+    return;
+  }
   float (*rc)[NCOL] = red[wave >> 2];
   for (int w = 0; w < 4; ++w) {
     if ((wave & 3) == w && sub == 0) {
@@ -204,7 +238,8 @@ template <int LPR, int CPL> static void launch_fwd(const ClnFastArgs& a, hipStre
 }
 template <int LPR, int CPL> static void launch_bwd(const ClnFastArgs& a, hipStream_t s) {
   const dim3 grid((a.rows / a.rows_per_sample) * a.chunks_per_sample);
-  if (a.mode == 1) hipLaunchKernelGGL((cln_bwd_fast_kernel<LPR, CPL, 1, 4>), grid, dim3(256), 0, s, a);
+  if (a.mode == 3) hipLaunchKernelGGL((cln_bwd_fast_kernel<LPR, CPL, 3, 4>), grid, dim3(256), 0, s, a);
+  else if (a.mode == 1) hipLaunchKernelGGL((cln_bwd_fast_kernel<LPR, CPL, 1, 4>), grid, dim3(256), 0, s, a);
   else if (a.mode == 2) hipLaunchKernelGGL((cln_bwd_fast_kernel<LPR, CPL, 2, 4>), grid, dim3(256), 0, s, a);
   else if (a.nwv == 8) hipLaunchKernelGGL((cln_bwd_fast_kernel<LPR, CPL, 0, 8>), grid, dim3(512), 0, s, a);
   else hipLaunchKernelGGL((cln_bwd_fast_kernel<LPR, CPL, 0, 4>), grid, dim3(256), 0, s, a);
@@ -232,10 +267,58 @@ int scot_cln_fwd_fast(ClnFastArgs a, hipStream_t s) {
   CLN_DISPATCH(launch_fwd)
   return scot_check_launch();
 }
+// mode 3: one pass of rows per wave; applies to the small, wide norms of the deep stages (few rows: the partial matrix stays small)
+bool scot_cln_bwd_partial_plan(int rows, int rows_per_sample, int C, int* blocks, int* rpb) {
+  if (C % 64 || C < 128 || C > 1536 || rows > 8192 || rows <= 0 || rows_per_sample <= 0 || rows % rows_per_sample) return false;
+  int lpr = 1;
+  while (lpr < 64 && lpr * 8 < C) lpr <<= 1;
+  const int rows_per_pass = 4 * (64 / lpr);
+  const int r = rows_per_sample < rows_per_pass ? rows_per_sample : rows_per_pass;
+  const int cps = (rows_per_sample + r - 1) / r;
+  *blocks = (rows / rows_per_sample) * cps;
+  *rpb = r;
+  return true;
+}
+
+// out[j] += Σ_b partial[b][j]  (j < ncol): the cross-block half of mode 3.  grid (ceil(ncol / 64), slices), 64 columns x 4 block lanes
+__global__ __launch_bounds__(256) void cln_partial_reduce_kernel(const float* __restrict__ partial, int nblk, int ncol, float* __restrict__ out) {
+  __shared__ float red[4][64];
+  const int cx = threadIdx.x & 63, ry = threadIdx.x >> 6;
+  const int col = blockIdx.x * 64 + cx;
+  const int per = (nblk + gridDim.y - 1) / gridDim.y;
+  const int b0 = blockIdx.y * per, b1 = min(nblk, b0 + per);
+  float acc = 0.f;
+  if (col < ncol)
+    for (int b = b0 + ry; b < b1; b += 4) acc += partial[(size_t)b * ncol + col];
+  red[ry][cx] = acc;
+  __syncthreads();
+  if (ry == 0 && col < ncol) atomicAdd(&out[col], red[0][cx] + red[1][cx] + red[2][cx] + red[3][cx]);
+}
+
+int scot_cln_bwd_finish_launch(const float* partial, int nblk, int ncol, float* out, hipStream_t s) {
+  int slices = nblk / 32;
+  if (slices < 1) slices = 1;
+  if (slices > 16) slices = 16;
+  hipLaunchKernelGGL(cln_partial_reduce_kernel, dim3((ncol + 63) / 64, slices), dim3(256), 0, s, partial, nblk, ncol, out);
+  return scot_check_launch();
+}
+
 int scot_cln_bwd_fast(ClnFastArgs a, void* workspace, size_t ws_bytes, hipStream_t s) {
   if (a.C % 8 || !aligned16(a.x) || !aligned16(a.dout) || !aligned16(a.dx) || !aligned16(a.gw_w) || !aligned16(a.gw_b))
     return SCOT_ERR_UNSUPPORTED;
   if (a.mode == 2 && a.d_xbias) return SCOT_ERR_UNSUPPORTED;   // Σ dx needs dx
+  if (a.mode == 3) {
+    int blocks, rpb;
+    if (a.d_xbias || !scot_cln_bwd_partial_plan(a.rows, a.rows_per_sample, a.C, &blocks, &rpb)) return SCOT_ERR_UNSUPPORTED;
+    const size_t need = (size_t)blocks * (a.gw_w ? 4 : 2) * a.C * sizeof(float);
+    if (!workspace || (((uintptr_t)workspace) & 15) || ws_bytes < need) return SCOT_ERR_SHAPE;
+    a.partial = (float*)workspace;
+    a.nwv = 4;
+    a.rpb = rpb;
+    a.chunks_per_sample = (a.rows_per_sample + rpb - 1) / rpb;
+    CLN_DISPATCH(launch_bwd)
+    return scot_check_launch();
+  }
   // rows per block: enough blocks to cover the chip (SCOT_CLN_BLOCKS, default 256: every block ends in 5·C global atomics) but at least two
   // passes of the four waves, at most 128 rows; SCOT_CLN_RPB pins it
   static int rpb_env = -1, blocks_env = -1;

@@ -80,6 +80,7 @@ class ScOTEngine:
         self.skip_lane = int(os.environ.get("SCOT_SKIP_LANE", "0"))       # backward of the skip blocks: 1 = a second side stream (measured: 21.55 vs 21.43 ms, more overlap only slows the rest)
         self.side2 = None
         self.group_wgrads = os.environ.get("SCOT_GROUP_WGRAD", "1") == "1"
+        self.cln_partial = os.environ.get("SCOT_CLN_PARTIAL", "1") == "1"     # small-row-count LN backward through partial sums (A/B switch)
         # TIMING-ONLY what-if switches (results are wrong with any of them set; tools/gpu_whatif.sh): "noact" = the fused forward tail
         # does not store gelu(u) / gelu'(u) (the backward reads a stale dummy), "nomlpwgrad" = the fc1 / fc2 weight gradients of the
         # fused stages are skipped
@@ -422,6 +423,15 @@ class ScOTEngine:
         gw_w, gw_b, _, _ = self._norm_params(prefix)
         g = self._norm_grads(prefix)
         t = time if self.cond else None
+        nf = ops.cln_bwd_partial_floats(rows, rows_per_sample, C, self.cond) if self.cln_partial else 0
+        if nf and not self.split_ln_bwd and self._norm_grads_contiguous(prefix, C):
+            # the deep stages' norms (1024 / 4096 rows): dx on the chain with every row's loads in flight at once, the cross-block
+            # sums of the parameter gradients through a small partial matrix finished on the weight-gradient stream
+            part = self.new(nf)
+            ops.cln_bwd(dout, x, stats[0], stats[1], t, gw_w, gw_b, dx, None, None, None, None, rows, rows_per_sample, C,
+                        sample_scale=sample_scale, mode=3, partial=part)
+            self.off_critical_path(lambda: ops.cln_bwd_finish(part, rows, rows_per_sample, C, g[0], g[1], g[2], g[3]), part)
+            return dx
         if self.use_side and self.split_ln_bwd:
             # the dependent chain only needs dx (a pure stream); the column reductions for the four parameter gradients
             # re-read dout and x on the side stream, where the weight-gradient GEMMs already run
@@ -433,6 +443,12 @@ class ScOTEngine:
             ops.cln_bwd(dout, x, stats[0], stats[1], t, gw_w, gw_b, dx, g[0], g[1], g[2], g[3], rows, rows_per_sample, C,
                         sample_scale=sample_scale)
         return dx
+
+    def _norm_grads_contiguous(self, prefix, C) -> bool:
+        """the norm's parameter gradients back to back in the gradient arena (what scot_cln_bwd_finish adds its column sums into)"""
+        g = self._norm_grads(prefix)
+        ptrs = [t.data_ptr() for t in g if t is not None]
+        return all(b - a == 4 * C for a, b in zip(ptrs, ptrs[1:]))
 
     def drop_path_scale(self, prefix: str, B: int, which: int):
         """Swinv2DropPath (HF:565-586): per-sample keep mask / keep_prob for one residual branch of one layer, or None

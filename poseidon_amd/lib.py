@@ -46,6 +46,8 @@ PROTOTYPES = {
     "scot_proj_cln_fwd": [P, P, P, P, P, P, P, P, P, P, P, P, P, P, P, I, I, I, F, P],
     "scot_proj_cln_bwd": [P, P, P, P, P, P, P, P, P, P, P, P, P, P, P, I, I, I, P],
     "scot_cln_bwd": [P, I, P, I, P, P, P, P, P, P, I, P, P, P, P, P, I, I, I, P, Z, P, I, P],
+    "scot_cln_bwd_workspace_bytes": [I, I, I, I],
+    "scot_cln_bwd_finish": [P, I, I, I, P, P, P, P, P],
     "scot_add": [P, I, P, I, P, I, Z, Z, P],
     "scot_batch_sum": [P, I, P, I, Z, P],
     "scot_gather_pairs": [P, P, P, P, P, P, P, I, I, I, I, I, I, I, P],
@@ -80,7 +82,7 @@ PROTOTYPES = {
     "scot_optim_finish": [P, P, P, F, F, I, F, P],
 }
 _VOID = {"scot_set_use_tr"}
-_SIZE = {"scot_gemm_workspace_bytes", "scot_wgrad_group_workspace_bytes"}      # return size_t
+_SIZE = {"scot_gemm_workspace_bytes", "scot_wgrad_group_workspace_bytes", "scot_cln_bwd_workspace_bytes"}      # return size_t
 
 
 def restype(name):
@@ -99,7 +101,7 @@ def load(path: str = None, kind: str = "bf16"):
         raise ValueError(f"unknown library build {kind!r}")
     if kind in _libs:
         return _libs[kind]
-    path = path or LIB_PATHS[kind]
+    path = path or os.environ.get("SCOT_LIB_" + kind.upper()) or LIB_PATHS[kind]      # (SCOT_LIB_F16 / SCOT_LIB_BF16: tools/ablate_kernels.py)
     # torch bundles its own libamdhip64.so (dlopen'ed by path).  It MUST be resident before our library is loaded so
     # that our NEEDED libamdhip64.so.7 resolves (by SONAME) to the same runtime; loading ours first pulls in
     # /opt/rocm's copy as a SECOND HIP runtime whose streams/pointers are foreign to torch's.

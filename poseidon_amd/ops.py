@@ -337,12 +337,28 @@ def proj_cln_bwd(g, z, mean, rstd, time, gw_w, gw_b, sample_scale, w, dz, da, d_
 
 
 def cln_bwd(dout, x, mean, rstd, time, gw_w, gw_b, dx, d_gw_w, d_gw_b, d_bw_w, d_bw_b, rows, rows_per_sample, C, d_xbias=None,
-            sample_scale=None, mode=0):
-    """mode 0: dx and parameter gradients; 1: dx only; 2: parameter gradients only (dx may be None)."""
+            sample_scale=None, mode=0, partial=None):
+    """mode 0: dx and parameter gradients; 1: dx only; 2: parameter gradients only (dx may be None); 3: dx + per-block partial sums
+    of the parameter gradients into `partial` (fp32, cln_bwd_partial_floats long), finished by cln_bwd_finish."""
+    if mode == 3:
+        wsp, wsn = partial.data_ptr(), partial.numel() * partial.element_size()
+    else:
+        wsp, wsn = None, 0
     _lib.check(L().scot_cln_bwd(ptr(dout), dt(dout), ptr(x), dt(x), ptr(mean), ptr(rstd), ptr(time), ptr(gw_w), ptr(gw_b),
                                 ptr(dx), dt(dx) if dx is not None else 0, ptr(d_gw_w), ptr(d_gw_b), ptr(d_bw_w), ptr(d_bw_b), ptr(d_xbias), rows,
-                                rows_per_sample, C, workspace().data_ptr(), workspace().numel(), ptr(sample_scale), int(mode),
+                                rows_per_sample, C, wsp, wsn, ptr(sample_scale), int(mode),
                                 stream()), "scot_cln_bwd")
+
+
+def cln_bwd_partial_floats(rows, rows_per_sample, C, conditional) -> int:
+    """floats of scratch mode 3 of cln_bwd writes for these dimensions (0: the form does not apply)"""
+    return int(_raw().scot_cln_bwd_workspace_bytes(rows, rows_per_sample, C, int(bool(conditional)))) // 4
+
+
+def cln_bwd_finish(partial, rows, rows_per_sample, C, d_gw_w, d_gw_b, d_bw_w, d_bw_b):
+    """parameter gradients += the per-block partial sums of a mode-3 cln_bwd"""
+    _lib.check(L().scot_cln_bwd_finish(ptr(partial), rows, rows_per_sample, C, ptr(d_gw_w), ptr(d_gw_b), ptr(d_bw_w), ptr(d_bw_b), stream()),
+               "scot_cln_bwd_finish")
 
 
 def add(a, b, out, period=None):

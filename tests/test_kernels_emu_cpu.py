@@ -102,7 +102,8 @@ def test_wgrad_group(emu, K, dims):
 
 
 @pytest.mark.parametrize("cond", [True, False])
-@pytest.mark.parametrize("xdt,B,L,C", [(torch.float32, 2, 40, 96), (torch.bfloat16, 2, 64, 192), (torch.float32, 3, 9, 20)])
+@pytest.mark.parametrize("xdt,B,L,C", [(torch.float32, 2, 40, 96), (torch.bfloat16, 2, 64, 192), (torch.float32, 3, 9, 20), (torch.float32, 3, 16, 768),
+                                       (torch.float32, 2, 6, 384)])
 def test_cln_fwd_bwd(emu, cond, xdt, B, L, C):
     x, res, t = rnd(B, L, C, dtype=xdt), rnd(B, L, C, seed=1), torch.rand(B)
     gw_w, gw_b, bw_w, bw_b = rnd(C, seed=2, scale=0.3), 1 + rnd(C, seed=3, scale=0.1), rnd(C, seed=4, scale=0.1), rnd(C, seed=5, scale=0.1)
@@ -128,6 +129,22 @@ def test_cln_fwd_bwd(emu, cond, xdt, B, L, C):
     assert rel(dx, x64.grad) < (1e-4 if xdt == torch.float32 else 1e-2)
     for i in ([0, 1, 2, 3] if cond else [1, 3]):
         assert rel(grads[i], ps[i].grad) < 1e-4, i
+
+    # mode 3 (the deep stages' form): dx + per-block partial sums, finished into CONTIGUOUS parameter gradients by a second launch
+    nf = ops.cln_bwd_partial_floats(B * L, L, C, cond)
+    assert (nf > 0) == (C % 64 == 0 and 128 <= C <= 1536 and B * L <= 8192)
+    if nf:
+        part = torch.full((nf,), float("nan"))
+        dx3 = torch.empty(B, L, C, dtype=xdt)
+        flat = torch.zeros(4 * C) + 0.25                      # += semantics: starts non-zero
+        g3 = [flat[i * C:(i + 1) * C] for i in range(4)] if cond else [None, flat[0:C], None, flat[C:2 * C]]
+        ops.cln_bwd(dout, x, mean, rstd, t if cond else None, gw_w if cond else None, gw_b, dx3, None, None, None, None, B * L, L, C,
+                    sample_scale=sc, mode=3, partial=part)
+        ops.cln_bwd_finish(part, B * L, L, C, g3[0], g3[1], g3[2], g3[3])
+        pass
+        assert torch.equal(dx3, dx) or rel(dx3, dx) < 1e-6
+        for i in ([0, 1, 2, 3] if cond else [1, 3]):
+            assert rel(g3[i] - 0.25, ps[i].grad) < 1e-4, i
 
 
 ATTN = [  # compute, B, Hp, Wp, C, heads, ws, shift

@@ -216,7 +216,8 @@ def _window_attention_fwd_bwd(compute, case, half):
 # ----------------------------------------------------------------------------------------------- CLN
 @pytest.mark.parametrize("cond", [True, False])
 @pytest.mark.parametrize("xdt", [torch.float32, torch.bfloat16])
-@pytest.mark.parametrize("B,L,C", [(3, 64, 96), (2, 16, 768), (2, 9, 20), (2, 300, 48), (2, 1024, 192), (2, 5, 1536), (3, 33, 16)])
+@pytest.mark.parametrize("B,L,C", [(3, 64, 96), (2, 16, 768), (2, 9, 20), (2, 300, 48), (2, 1024, 192), (2, 5, 1536), (3, 33, 16), (64, 16, 768),
+                                   (64, 64, 384), (5, 6, 128)])
 def test_cln_fwd_bwd(cond, xdt, B, L, C):
     x = rnd(B, L, C, dtype=xdt)
     res = rnd(B, L, C, seed=1)
@@ -252,6 +253,22 @@ def test_cln_fwd_bwd(cond, xdt, B, L, C):
     assert rel(dxb, x64.grad.sum((0, 1))) < (2e-3 if xdt == torch.float32 else 5e-2)
     for i in ([0, 1, 2, 3] if cond else [1, 3]):
         assert rel(grads[i], ps[i].grad) < 1e-4, i
+
+    # mode 3 (the deep stages' form): dx + per-block partial sums, finished into CONTIGUOUS parameter gradients by a second launch
+    nf = ops.cln_bwd_partial_floats(B * L, L, C, cond)
+    assert (nf > 0) == (C % 64 == 0 and 128 <= C <= 1536 and B * L <= 8192)
+    if nf:
+        part = torch.full((nf,), float("nan"), device=DEV)
+        dx3 = torch.empty(B, L, C, dtype=xdt, device=DEV)
+        flat = torch.zeros(4 * C, device=DEV) + 0.25                      # += semantics: starts non-zero
+        g3 = [flat[i * C:(i + 1) * C] for i in range(4)] if cond else [None, flat[0:C], None, flat[C:2 * C]]
+        ops.cln_bwd(dout, x, mean, rstd, t if cond else None, gw_w if cond else None, gw_b, dx3, None, None, None, None, B * L, L, C,
+                    sample_scale=None, mode=3, partial=part)
+        ops.cln_bwd_finish(part, B * L, L, C, g3[0], g3[1], g3[2], g3[3])
+        torch.cuda.synchronize()
+        assert torch.equal(dx3, dx) or rel(dx3, dx) < 1e-6
+        for i in ([0, 1, 2, 3] if cond else [1, 3]):
+            assert rel(g3[i] - 0.25, ps[i].grad) < 1e-4, i
 
 
 # ----------------------------------------------------------------------------------------------- fused MLP block (experimental)
@@ -793,3 +810,41 @@ def test_transpose_cast_and_dgrad_nt():
     ops.linear_dgrad(ops.BF16, dy, w16, b, wt=wt[offs[2]:offs[2] + r * c].view(c, r))
     torch.cuda.synchronize()
     assert rel(b, a) < 1e-6 and rel(b, dy.float() @ w16.float()) < 1e-5
+
+
+# ----------------------------------------------------------------------------------------------- grouped weight gradients
+# scot_wgrad_group is the kernel bench.py's `roofline` is quoted on: pinned here DIRECTLY on the MI355X (round 2 only covered it on the
+# CPU emulation and through whole-model gradients): the four weight gradients of a ScOTLayer (fc2, fc1, out-projection, qkv) at every
+# Poseidon-B stage shape, a ragged token count, shapes off the 96-tile path, both operand formats; reference = fp64 dY^T X on the
+# operands as stored (16-bit), i.e. what is bounded is the kernel's own error (fp32 MFMA accumulation + split-K partial sums).
+WGROUP_CASES = [(65536, 96), (16384, 192), (4096, 384), (1024, 768), (2008, 96), (4104, 64), (1000, 40), (1004, 32)]
+
+
+@pytest.mark.parametrize("kind", ["f16", "bf16"])
+@pytest.mark.parametrize("K,C", WGROUP_CASES)
+def test_wgrad_group_direct(kind, K, C):
+    prev = ops.use(kind)
+    try:
+        hd = ops.half_dtype()
+        dims = [(C, 4 * C), (4 * C, C), (C, C), (3 * C, C)]            # (M_i, N_i) of fc2, fc1, proj, qkv: dW_i [M_i, N_i]
+        dys = [rnd(K, m, dtype=hd, scale=0.5, seed=10 + i) for i, (m, _) in enumerate(dims)]
+        xs = [rnd(K, n, dtype=hd, seed=20 + i) for i, (_, n) in enumerate(dims)]
+        dws0 = [rnd(m, n, seed=30 + i) for i, (m, n) in enumerate(dims)]                       # += semantics: start from non-zero
+        dbs0 = [rnd(m, seed=40 + i) for i, (m, _) in enumerate(dims)]
+        dws, dbs = [t.clone() for t in dws0], [t.clone() for t in dbs0]
+        ok = ops.wgrad_group(ops.BF16, [(dy, x, dw, db) for dy, x, dw, db in zip(dys, xs, dws, dbs)])
+        if not ok:     # shapes the grouped kernel declines go through the per-problem path (same contract)
+            for dy, x, dw, db in zip(dys, xs, dws, dbs):
+                ops.linear_wgrad(ops.BF16, dy, x, dw, dbias=db)
+        torch.cuda.synchronize()
+        assert ok == (C % 8 == 0 and K % 8 == 0)
+        worst = 0.0
+        for dy, x, dw0, dw, db0, db in zip(dys, xs, dws0, dws, dbs0, dbs):
+            ref = dy.double().t() @ x.double()
+            e = rel(dw.double() - dw0.double(), ref)
+            worst = max(worst, e)
+            assert e < 1e-6, (K, C, tuple(dw.shape), e)               # measured on MI355X (round 3): 9.5e-8 .. 4.1e-7 over all cases
+            assert rel(db.double() - db0.double(), dy.double().sum(0)) < 2e-6
+        print(f"wgrad_group {kind} K={K} C={C}: worst rel-L2 {worst:.2e}")
+    finally:
+        ops.use(prev)

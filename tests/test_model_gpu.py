@@ -143,7 +143,9 @@ def test_poseidon_presets(name, compute):
         assert int(model._engine.grad_overflow) == 0
         assert np.median(dev) < 1.5e-3         # measured 3.8e-4 .. 6.0e-4
         # stored full gradients, global rel-L2: measured 1.1e-3 (T) / 2.6e-3 (B) / 1.6e-3 (B@256²) trained-like, 3e-4 / 1e-4 HF-init
-        g, worst = grads_report(model, f, tol_each=1e9, tol_global=6e-3, floor=1e-6, skip=("logit_scale",))
+        # per tensor (round 3, MI355X): worst 2.9e-2 (T trained: a key.weight) / 2.8e-3 (B trained) / 5.1e-3 (B@256²) / 4.3e-2 (B HF-init: the last
+        # layer of a bias MLP); tensors whose true gradient is round-off in the reference itself (|g| < 1e-6 absolute) fall under `floor`
+        g, worst = grads_report(model, f, tol_each=8e-2, tol_global=6e-3, floor=1e-6, skip=("logit_scale",))
         print(f"[{name} fp16] stored gradients: global rel-L2 {g:.2e}, worst {worst}")
         # the ConvNeXt skip blocks' branch gradients (behind the layer scale: 1e-6 in the HF-init regime, ~2^-20 below the rest)
         # survive binary16 through the device-side local power-of-two rescale (engine.convnext_bwd)
@@ -657,7 +659,8 @@ def test_weight_copies_follow_the_master_weights():
     real_cast = ops.cast
 
     def counting_cast(src, dst):
-        eng_casts.append(src.numel())
+        if src.numel() == model._arena.size:        # the weight arena (activations are cast through the same entry point)
+            eng_casts.append(src.numel())
         return real_cast(src, dst)
     ops.cast = counting_cast
     try:
@@ -684,11 +687,13 @@ def test_weight_copies_follow_the_master_weights():
         torch.cuda.synchronize()
         # the optimizer's copy == a fresh cast of the new master weights, for every parameter; transposed copies too
         fresh = torch.empty_like(eng.shadow)
+        prev_kind = ops.use(eng.lib_kind)
         real_cast(eng.arena.data, fresh)
+        ops.use(prev_kind)
         for nme in ("encoder.layers.0.blocks.0.output.dense.weight", "embeddings.norm.weight.bias", "decoder.layers.1.blocks.1.attention.self.value.weight"):
             o, k = eng.arena.offsets[nme], eng.arena.numel(nme)
             assert torch.equal(eng.shadow[o:o + k], fresh[o:o + k])
-        wn = "encoder.layers.0.blocks.0.output.dense.weight"
+        wn = next(n for n in eng._wt_names if not n.endswith("qkv_weight"))        # (matrices of at least 32 x 32 keep a transposed copy)
         assert torch.equal(eng.WT(wn), eng.W(wn).t().contiguous())
         with torch.no_grad():
             y4 = model(**kw).output.clone()
