@@ -209,26 +209,51 @@ int scot_proj_cln_bwd(const float* g, const float* z, const float* mean, const f
 /* scot_mlp_block_bwd followed by scot_proj_cln_bwd on its g_out, for the same rows, in ONE launch (the backward of HF:533-561 +
  * ref:566-579 and of HF:478-489 + ref:560-565 along the dependent chain): g_out is still written (the qkv dgrad accumulates
  * into it) but not re-read.  Suffix 2 = the MLP half's norm (layernorm_after), 1 = the attention half's (layernorm_before);
- * arguments as in the two entry points above.  C in {96, 192}, rows_per_sample % 64 == 0; returns -3 otherwise. */
-int scot_block_tail_bwd(const float* g, float* g_out, const float* z2, const float* mean2, const float* rstd2, const float* gw_w2,
+ * arguments as in the two entry points above.  C in {96, 192}, rows_per_sample % 64 == 0; returns -3 otherwise.
+ * Round 3 — the form without 4C-wide tensors in HBM: dact == NULL makes the kernel RECOMPUTE gelu'(u) from u = h16·W1^T + b1
+ * (h16 [M, C] 16-bit and b1 [hid] then required); du == NULL: the product dz2·W2 ⊙ gelu'(u) is not stored (scot_wgrad_mlp recomputes
+ * it); z_dt: dtype of z1 / z2 (0 = fp32, 1 = the 16-bit operand format); partial2 / partial1 (both or neither): instead of 4·C
+ * atomics per workgroup and norm, the workgroup's column sums go to row `workgroup` of a [scot_block_tail_workgroups()][4·Cp]
+ * matrix ([t·dγ | dγ | t·dβ | dβ], each Cp = C rounded up to a multiple of 64 floats wide with a zero pad — the stride of the four
+ * tensors in the parameter arena; [2·Cp] = [dγ | dβ] without conditioning) that scot_partial_colsum adds into the parameter
+ * gradients on any stream ordered behind this call; the d_* pointers are then unused. */
+int scot_block_tail_bwd(const float* g, float* g_out, const void* z2, const float* mean2, const float* rstd2, const float* gw_w2,
                         const float* gw_b2, const float* sscale2, const void* dact, const void* W1, const void* W2, void* dz2, void* du,
-                        float* d_gw_w2, float* d_gw_b2, float* d_bw_w2, float* d_bw_b2, const float* z1, const float* mean1,
+                        float* d_gw_w2, float* d_gw_b2, float* d_bw_w2, float* d_bw_b2, const void* z1, const float* mean1,
                         const float* rstd1, const float* gw_w1, const float* gw_b1, const float* sscale1, const void* Wo, void* dz1,
                         void* da, float* d_gw_w1, float* d_gw_b1, float* d_bw_w1, float* d_bw_b1,
                         const void* dqkv, const void* Wqkv /* optional prologue, both or neither: g += dqkv[M,3C] · Wqkv[3C,C] in place
                         (needs g_out == g) = the qkv projection's data gradient (HF:396-410) of the layer processed before */,
+                        const void* h16, const float* b1, int z_dt, float* partial2, float* partial1,
                         const float* time, int M, int rows_per_sample, int C, int hid, scot_stream_t stream);
+int scot_block_tail_workgroups(int M, int rows_per_sample, int C);      /* rows of partial2 / partial1 (0: shapes not covered) */
+int scot_partial_colsum(const float* partial, int nblk, int ncol, float* out, scot_stream_t stream);   /* out[j] += Σ_b partial[b][j] */
+/* the same for n <= 32 matrices in ONE launch (HOST arrays of device pointers / sizes, read before the call returns): the engine
+ * finishes a whole stage's norm backwards (scot_cln_bwd mode 3, scot_block_tail_bwd partial rows) with it */
+int scot_partial_colsum_batch(int n, const float* const* partial, const int* nblk, const int* ncol, float* const* out,
+                              scot_stream_t stream);
 /* scot_proj_cln_fwd followed by scot_mlp_block_fwd on its output, for the same rows, in ONE launch (HF:478-489 + ref:560-565, then
  * HF:533-561 + ref:566-579): h / h16 are written (the backward reads them) but not re-read.  Suffix 1 = attention half's norm
- * (layernorm_before), 2 = MLP half's (layernorm_after); arguments as in the two entry points.  C in {96, 192}; -3 otherwise. */
-int scot_block_tail_fwd(const void* a, const void* Wo, const float* bo, const float* x, float* h, void* h16, float* z1, float* mean1,
+ * (layernorm_before), 2 = MLP half's (layernorm_after); arguments as in the two entry points.  C in {96, 192}; -3 otherwise.
+ * act / dact NULL (and z / statistics given): training without the 4C-wide saves (the backward recomputes, see above); z_dt: dtype
+ * z1 / z2 are stored in (0 = fp32, 1 = 16-bit: only the norm backward's x-hat reads them). */
+int scot_block_tail_fwd(const void* a, const void* Wo, const float* bo, const float* x, float* h, void* h16, void* z1, float* mean1,
                         float* rstd1, const float* gw_w1, const float* gw_b1, const float* bw_w1, const float* bw_b1,
                         const float* sscale1, const void* W1, const float* b1, const void* W2, const float* b2, float* out, void* out16,
-                        void* act, void* dact, float* z2, float* mean2, float* rstd2, const float* gw_w2, const float* gw_b2,
+                        void* act, void* dact, void* z2, float* mean2, float* rstd2, const float* gw_w2, const float* gw_b2,
                         const float* bw_w2, const float* bw_b2, const float* sscale2,
                         const void* Wqkv, const float* bqkv, void* qkv /* optional epilogue (Wqkv and qkv both or neither): the NEXT
                         layer's fused q/k/v projection qkv[M,3C] = out16 · Wqkv[3C,C]^T + bqkv (HF:396-410) on the rows just produced */,
-                        const float* time, int M, int rows_per_sample, int C, int hid, float eps, scot_stream_t stream);
+                        int z_dt, const float* time, int M, int rows_per_sample, int C, int hid, float eps, scot_stream_t stream);
+
+/* The fc1 / fc2 weight and bias gradients of a ScOTLayer's MLP WITHOUT gelu(u), gelu'(u), du in HBM (csrc/wgrad_mlp.hip; autograd of
+ * HF:545-548, 558-561): per token slice and hidden chunk the kernel recomputes u = h16·W1^T + b1 and dz·W2 and feeds gelu(u) / du from
+ * registers into dW2 += dz^T·gelu(u), dW1 += du^T·h16 (+ both bias gradients).  h16, dz [M, C] 16-bit; W1 [hid, C]; W2T [hid, C] = W2^T;
+ * dW1 [hid, C] | db1 [hid] | dW2 [C, hid] | db2 [C] must be CONTIGUOUS in this order (the gradient arena's layout); workspace >=
+ * scot_wgrad_mlp_workspace_bytes, 32-byte aligned.  C in {96, 192}, hid = 4C; -3 otherwise. */
+size_t scot_wgrad_mlp_workspace_bytes(int M, int C, int hid);
+int scot_wgrad_mlp(const void* h16, const void* dz, const void* W1, const float* b1, const void* W2T, float* dW1, float* db1, float* dW2,
+                   float* db2, int M, int C, int hid, void* workspace, size_t ws_bytes, scot_stream_t stream);
 
 /* Data movement */
 int scot_add(const void* a, int a_dt, const void* b, int b_dt, void* out, int out_dt, size_t n, size_t period,

@@ -8,7 +8,8 @@
 
 struct ClnRowsOut {
   const float* bias;                    // [C] bias of the GEMM that produced the accumulators
-  float* z; float* mean; float* rstd;   // training: pre-norm rows [M, C] and their statistics [M]   (NULL in inference)
+  void* z; int z_dt;                    // training: pre-norm rows [M, C] (fp32, or 16-bit: only the backward's x-hat reads them)
+  float* mean; float* rstd;             // ... and their statistics [M]   (all NULL in inference)
   const float* time; const float* gw_w; const float* gw_b; const float* bw_w; const float* bw_b; const float* sscale;
   const float* resid;                   // [M, C] fp32 residual stream
   float* out; bf16_t* out16;            // [M, C]
@@ -67,7 +68,7 @@ __device__ __forceinline__ void cln_rows_epilogue(f32x4_t (&Y)[TT][C / 16], floa
 #pragma unroll
       for (int pp = 0; pp < KJ; ++pp) {
         const int col = pp * 32 + q * 8;
-        if (p.z) st8(p.z, SCOT_F32, base + col, v[pp]);
+        if (p.z) st8(p.z, p.z_dt, base + col, v[pp]);
         float gw[8], gb[8], bw[8], bbv[8], res[8], o[8];
         ld8(p.gw_b, SCOT_F32, col, gb); ld8(p.bw_b, SCOT_F32, col, bbv);
         if (p.gw_w) { ld8(p.gw_w, SCOT_F32, col, gw); ld8(p.bw_w, SCOT_F32, col, bw); }
@@ -93,10 +94,13 @@ __device__ __forceinline__ void cln_rows_epilogue(f32x4_t (&Y)[TT][C / 16], floa
 
 struct ClnRowsBwd {
   const float* g;                        // [M, C] gradient wrt the block output (fp32 residual stream gradient)
-  const float* z; const float* mean; const float* rstd;
+  const void* z; int z_dt; const float* mean; const float* rstd;
   const float* time; const float* gw_w; const float* gw_b; const float* sscale;
   bf16_t* dz;                            // [M, C] gradient wrt the pre-norm rows (the weight-gradient GEMM reads it)
   float* d_gw_w; float* d_gw_b; float* d_bw_w; float* d_bw_b;
+  float* partial;                        // optional: [workgroups][4·Cp] ([t·dγ | dγ | t·dβ | dβ], each Cp = C rounded up to 64 floats wide, the
+                                         // pad zero: the stride of the four tensors in the parameter arena; 2·Cp without conditioning)
+                                         // receives the workgroup's column sums instead of 4·C global atomics (scot_partial_colsum)
   int M, rows_per_sample;
 };
 
@@ -157,7 +161,7 @@ __device__ __forceinline__ void cln_bwd_rows(Frag<bf16_t> (&dzf)[TT][C / 32], ch
       } else {
         ld8(p.g, SCOT_F32, base + col, d[pp]);
       }
-      ld8(p.z, SCOT_F32, base + col, zz);
+      ld8(p.z, p.z_dt, base + col, zz);
       gamma8(col, ga);
 #pragma unroll
       for (int j = 0; j < 8; ++j) {
@@ -204,12 +208,28 @@ __device__ __forceinline__ void cln_bwd_rows(Frag<bf16_t> (&dzf)[TT][C / 32], ch
       }
   }
   __syncthreads();
+  constexpr int CP = (C + 63) / 64 * 64;
+  if (p.partial && tid >= C && tid < CP) {       // the pad columns of the partial row
+    float* row = p.partial + (size_t)blockIdx.x * (p.gw_w ? 4 : 2) * CP;
+    row[tid] = 0.f; row[CP + tid] = 0.f;
+    if (p.gw_w) { row[2 * CP + tid] = 0.f; row[3 * CP + tid] = 0.f; }
+  }
   if (tid < C) {
     float dg = 0.f, db = 0.f;
 #pragma unroll
     for (int w = 0; w < 4; ++w) { dg += red[(w * 2 + 0) * C + tid]; db += red[(w * 2 + 1) * C + tid]; }
-    if (p.d_gw_w) { atomicAdd(&p.d_gw_w[tid], t * dg); atomicAdd(&p.d_bw_w[tid], t * db); }
-    atomicAdd(&p.d_gw_b[tid], dg);
-    atomicAdd(&p.d_bw_b[tid], db);
+    if (p.partial) {
+      if (p.gw_w) {
+        float* row = p.partial + (size_t)blockIdx.x * 4 * CP;
+        row[tid] = t * dg; row[CP + tid] = dg; row[2 * CP + tid] = t * db; row[3 * CP + tid] = db;
+      } else {
+        float* row = p.partial + (size_t)blockIdx.x * 2 * CP;
+        row[tid] = dg; row[CP + tid] = db;
+      }
+    } else {
+      if (p.d_gw_w) { atomicAdd(&p.d_gw_w[tid], t * dg); atomicAdd(&p.d_bw_w[tid], t * db); }
+      atomicAdd(&p.d_gw_b[tid], dg);
+      atomicAdd(&p.d_bw_b[tid], db);
+    }
   }
 }

@@ -35,7 +35,7 @@ struct MlpArgs {
   const bf16_t* W2; const float* b2;
   float* out; bf16_t* out16;
   bf16_t* act; bf16_t* dact;
-  float* z; float* mean; float* rstd;
+  void* z; int z_dt; float* mean; float* rstd;
   const float* time; const float* gw_w; const float* gw_b; const float* bw_w; const float* bw_b; const float* sscale;
   int M, rows_per_sample, hid;
   float eps;
@@ -165,12 +165,12 @@ __device__ __forceinline__ void mlp_fwd_body(const MlpArgs& p, char* smem, const
             dv[4 * t + r] = cdf + x * 0.3989422804014327f * e;
           }
         af[tt] = frag_from_f32<bf16_t>(av);
-        if (p.act) {
+        if (p.act || p.dact) {        // (either, both or neither: the round-3 backward needs gelu'(u) at most)
           const int row = row0 + tt * 16 + lc;
           if (row < p.M) {
             const size_t o = (size_t)row * HID + (size_t)c * HC + blk * 32 + g * 8;
-            *(s16x8_t*)(p.act + o) = af[tt].v;
-            *(s16x8_t*)(p.dact + o) = frag_from_f32<bf16_t>(dv).v;
+            if (p.act) *(s16x8_t*)(p.act + o) = af[tt].v;
+            if (p.dact) *(s16x8_t*)(p.dact + o) = frag_from_f32<bf16_t>(dv).v;
           }
         }
       }
@@ -197,7 +197,7 @@ __device__ __forceinline__ void mlp_fwd_body(const MlpArgs& p, char* smem, const
   // ---- epilogue: + b2, layer norm over the row, conditional affine, DropPath scale, residual.  The weight chunk is dead
   // (barrier above): each wave stages one 16-row tile at a time in its own patch and re-reads it row-contiguously.
   ClnRowsOut e;
-  e.bias = p.b2; e.z = p.z; e.mean = p.mean; e.rstd = p.rstd; e.time = p.time; e.gw_w = p.gw_w; e.gw_b = p.gw_b; e.bw_w = p.bw_w;
+  e.bias = p.b2; e.z = p.z; e.z_dt = p.z_dt; e.mean = p.mean; e.rstd = p.rstd; e.time = p.time; e.gw_w = p.gw_w; e.gw_b = p.gw_b; e.bw_w = p.bw_w;
   e.bw_b = p.bw_b; e.sscale = p.sscale; e.resid = p.h; e.out = p.out; e.out16 = p.out16; e.M = p.M; e.rows_per_sample = p.rows_per_sample;
   e.eps = p.eps;
   cln_rows_epilogue<C, TT>(Y, (float*)smem, row0, e, otile);
@@ -244,7 +244,7 @@ extern "C" int scot_mlp_block_fwd(const void* h16, const float* h, const void* W
     return SCOT_ERR_SHAPE;
   MlpArgs a;
   a.h16 = (const bf16_t*)h16; a.h = h; a.W1 = (const bf16_t*)W1; a.b1 = b1; a.W2 = (const bf16_t*)W2; a.b2 = b2;
-  a.out = out; a.out16 = (bf16_t*)out16; a.act = (bf16_t*)act; a.dact = (bf16_t*)dact; a.z = z; a.mean = mean; a.rstd = rstd;
+  a.out = out; a.out16 = (bf16_t*)out16; a.act = (bf16_t*)act; a.dact = (bf16_t*)dact; a.z = z; a.z_dt = SCOT_F32; a.mean = mean; a.rstd = rstd;
   a.time = time; a.gw_w = gw_w; a.gw_b = gw_b; a.bw_w = bw_w; a.bw_b = bw_b; a.sscale = sample_scale;
   a.M = M; a.rows_per_sample = rows_per_sample; a.hid = hid; a.eps = eps;
   static int tt_env = -1;
@@ -273,11 +273,13 @@ extern "C" int scot_mlp_block_fwd(const void* h16, const float* h, const void* W
 // t (the conditioning time) must be uniform over a workgroup's rows: rows_per_sample % (64·TT) == 0.
 struct MlpBwdArgs {
   const float* g; float* g_out;
-  const float* z; const float* mean; const float* rstd;
+  const void* z; int z_dt; const float* mean; const float* rstd;
   const float* time; const float* gw_w; const float* gw_b; const float* sscale;
   const bf16_t* dact; const bf16_t* W1; const bf16_t* W2;
-  bf16_t* dz; bf16_t* du;
+  bf16_t* dz; bf16_t* du;                 // du may be NULL (the recomputing weight-gradient kernel does not read it)
   float* d_gw_w; float* d_gw_b; float* d_bw_w; float* d_bw_b;
+  float* partial;                         // see ClnRowsBwd::partial
+  const bf16_t* h16; const float* b1;     // RECOMP (dact == NULL): gelu'(u) is recomputed from u = h16·W1^T + b1 instead of loaded
   int M, rows_per_sample, hid, use_tr;
 };
 
@@ -309,13 +311,18 @@ template <int C, int HC> struct MlpBwdLds {
   static constexpr size_t WBYTES = (size_t)(HC * (C + 8) + C * (HC + 8)) * 2, PBYTES = (size_t)4 * 16 * (C + 4) * 4;
   static constexpr size_t P1BYTES = ClnBwdLds<C>::bytes;
   static constexpr size_t bytes = WBYTES > PBYTES ? (WBYTES > P1BYTES ? WBYTES : P1BYTES) : (PBYTES > P1BYTES ? PBYTES : P1BYTES);
+  // RECOMP: the workgroup's 64·TT rows of h16 stay in LDS BEHIND the region above for the whole hidden loop ([64·TT][C + 8])
+  static constexpr size_t htile_bytes(int TT) { return (size_t)64 * TT * (C + 8) * 2; }
 };
 
 // One workgroup's 64·TT rows of the MLP half's backward.  KEEP: the rows of g' = g + du·W1 are also returned in registers
 // (gkeep[tt][pp][j]: row row0 + 16 tt + (lane >> 2), columns 32 pp + 8 (lane & 3) + j) for the fused block tail.
 // GIN: the rows of g arrive in registers (gin, same layout as gkeep: the fused qkv-dgrad prologue produced them and also stored
 // them to p.g, which phase 3 re-reads with the same lanes).
-template <int C, int HC, int TT, bool KEEP, bool GIN = false>
+// RECOMP: gelu'(u) of the forward is not read from HBM (p.dact) but recomputed: u = h16·W1^T + b1 on the W1 chunk that is in LDS for
+// the data gradient anyway (read K-contiguously here, with the row permutation 8a+4t+b of the forward's fragment convention applied
+// at the read), bit-identical to the forward's u, and the derivative is rounded to 16 bits exactly as the forward used to store it.
+template <int C, int HC, int TT, bool KEEP, bool GIN = false, bool RECOMP = false>
 __device__ __forceinline__ void mlp_bwd_body(const MlpBwdArgs& p, char* smem, float (*gkeep)[C / 32][8],
                                              const float (*gin)[C / 32][8] = nullptr) {
   constexpr int KJ = C / 32, NT = C / 16, NB = HC / 32;
@@ -367,11 +374,23 @@ __device__ __forceinline__ void mlp_bwd_body(const MlpBwdArgs& p, char* smem, fl
 
   // ---- phase 1: dz = CLN_bwd(s·g) in the row-contiguous layout (4 lanes per row), parameter-gradient column sums
   ClnRowsBwd b;
-  b.g = p.g; b.z = p.z; b.mean = p.mean; b.rstd = p.rstd; b.time = p.time; b.gw_w = p.gw_w; b.gw_b = p.gw_b; b.sscale = p.sscale;
-  b.dz = p.dz; b.d_gw_w = p.d_gw_w; b.d_gw_b = p.d_gw_b; b.d_bw_w = p.d_bw_w; b.d_bw_b = p.d_bw_b; b.M = p.M;
+  b.g = p.g; b.z = p.z; b.z_dt = p.z_dt; b.mean = p.mean; b.rstd = p.rstd; b.time = p.time; b.gw_w = p.gw_w; b.gw_b = p.gw_b; b.sscale = p.sscale;
+  b.dz = p.dz; b.d_gw_w = p.d_gw_w; b.d_gw_b = p.d_gw_b; b.d_bw_w = p.d_bw_w; b.d_bw_b = p.d_bw_b; b.partial = p.partial; b.M = p.M;
   b.rows_per_sample = p.rows_per_sample;
   Frag<bf16_t> dzf[TT][KJ];
   cln_bwd_rows<C, TT, GIN>(dzf, smem, wg_row0, b, gin);
+  // RECOMP: the wave's token rows of h16 — B operands of u^T = W1·h^T (column = token lc, k = 32 j + 8 g ..) — parked in the wave's own
+  // LDS tile behind the weight chunks (24 registers per lane for the whole hidden loop otherwise: the kernel is at the 256-register cap)
+  bf16_t* Hw = (bf16_t*)(smem + MlpBwdLds<C, HC>::bytes) + wave * 16 * TT * (C + 8);
+  if (RECOMP) {
+#pragma unroll
+    for (int tt = 0; tt < TT; ++tt) {
+      const bf16_t* src = p.h16 + (size_t)min(row0 + tt * 16 + lc, p.M - 1) * C + g * 8;
+#pragma unroll
+      for (int j = 0; j < KJ; ++j) *(s16x8_t*)(Hw + (tt * 16 + lc) * (C + 8) + j * 32 + g * 8) = *(const s16x8_t*)(src + j * 32);
+    }
+    __builtin_amdgcn_wave_barrier();       // written and read by the same wave only
+  }
   load_chunk(0);
   __syncthreads();                                             // the dz patches and `red` alias the weight chunk
   store_chunk();
@@ -389,18 +408,58 @@ __device__ __forceinline__ void mlp_bwd_body(const MlpBwdArgs& p, char* smem, fl
 
   auto multiply_chunk = [&](int c) {
     // gelu'(u) of this chunk for the lane's token and its 8 hidden units per block: in flight during the first MFMAs
-    s16x8_t gpv[TT][NB];
+    s16x8_t gpv[RECOMP ? 1 : TT][RECOMP ? 1 : NB];
+    if (!RECOMP) {
 #pragma unroll
-    for (int tt = 0; tt < TT; ++tt)
+      for (int tt = 0; tt < TT; ++tt)
 #pragma unroll
-      for (int blk = 0; blk < NB; ++blk)
+        for (int blk = 0; blk < NB; ++blk)
 #if SCOT_ABL & 64
-        gpv[tt][blk] = (s16x8_t){15360, 15360, 15360, 15360, 15360, 15360, 15360, 15360};
+          gpv[RECOMP ? 0 : tt][RECOMP ? 0 : blk] = (s16x8_t){15360, 15360, 15360, 15360, 15360, 15360, 15360, 15360};
 #else
-        gpv[tt][blk] = *(const s16x8_t*)(p.dact + (size_t)min(rowt[tt], p.M - 1) * HID + (size_t)c * HC + blk * 32 + g * 8);
+          gpv[RECOMP ? 0 : tt][RECOMP ? 0 : blk] = *(const s16x8_t*)(p.dact + (size_t)min(rowt[tt], p.M - 1) * HID + (size_t)c * HC + blk * 32 + g * 8);
 #endif
+    }
 #pragma unroll
     for (int blk = 0; blk < NB; ++blk) {
+      // RECOMP first, on its own: u^T of this block -> gelu'(u) packed to 16 bits (the value the forward used to store), so that
+      // neither the recomputation's accumulators nor the GELU's temporaries are live beside the data-gradient product below
+      s16x8_t gpr[RECOMP ? TT : 1];
+      if (RECOMP) {
+        f32x4_t R[TT][2];
+#pragma unroll
+        for (int tt = 0; tt < TT; ++tt) { R[tt][0] = (f32x4_t){0.f, 0.f, 0.f, 0.f}; R[tt][1] = (f32x4_t){0.f, 0.f, 0.f, 0.f}; }
+#pragma unroll
+        for (int j = 0; j < KJ; ++j)
+#pragma unroll
+          for (int ts = 0; ts < 2; ++ts) {
+            // A operand: W1 rows (hidden units 8a + 4 ts + b of the block for lane 4a + b), 8 consecutive channels: K-contiguous
+            Frag<bf16_t> w;
+            w.v = *(const s16x8_t*)(W1c + (blk * 32 + ((lc >> 2) << 3) + ts * 4 + (lc & 3)) * P1 + j * 32 + g * 8);
+#pragma unroll
+            for (int tt = 0; tt < TT; ++tt) {
+              Frag<bf16_t> hfr;
+              hfr.v = *(const s16x8_t*)(Hw + (tt * 16 + lc) * (C + 8) + j * 32 + g * 8);
+              mma16(R[tt][ts], w, hfr);
+            }
+          }
+        const float4 ba = *(const float4*)(p.b1 + (size_t)c * HC + blk * 32 + g * 8), bb = *(const float4*)(p.b1 + (size_t)c * HC + blk * 32 + g * 8 + 4);
+        const float b1v[8] = {ba.x, ba.y, ba.z, ba.w, bb.x, bb.y, bb.z, bb.w};
+#pragma unroll
+        for (int tt = 0; tt < TT; ++tt) {
+          float dg[8];
+#pragma unroll
+          for (int ts = 0; ts < 2; ++ts)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              const float x = R[tt][ts][r] + b1v[4 * ts + r];
+              float cdf, e;
+              gelu_terms(x, cdf, e);
+              dg[4 * ts + r] = cdf + x * 0.3989422804014327f * e;
+            }
+          gpr[RECOMP ? tt : 0] = frag_from_f32<bf16_t>(dg).v;
+        }
+      }
       f32x4_t U[TT][2];
 #pragma unroll
       for (int tt = 0; tt < TT; ++tt) { U[tt][0] = (f32x4_t){0.f, 0.f, 0.f, 0.f}; U[tt][1] = (f32x4_t){0.f, 0.f, 0.f, 0.f}; }
@@ -420,12 +479,13 @@ __device__ __forceinline__ void mlp_bwd_body(const MlpBwdArgs& p, char* smem, fl
 #pragma unroll
         for (int ts = 0; ts < 2; ++ts)
 #pragma unroll
-          for (int r = 0; r < 4; ++r) dv[4 * ts + r] = U[tt][ts][r] * bf2f((bf16_t)gpv[tt][blk][4 * ts + r]);
+          for (int r = 0; r < 4; ++r)
+            dv[4 * ts + r] = U[tt][ts][r] * bf2f((bf16_t)(RECOMP ? gpr[RECOMP ? tt : 0][4 * ts + r] : gpv[RECOMP ? 0 : tt][RECOMP ? 0 : blk][4 * ts + r]));
         af[tt] = frag_from_f32<bf16_t>(dv);
 #if SCOT_ABL & 128
         asm volatile("" ::"v"(af[tt].v));
 #else
-        if (rowt[tt] < p.M) *(s16x8_t*)(p.du + (size_t)rowt[tt] * HID + (size_t)c * HC + blk * 32 + g * 8) = af[tt].v;
+        if (p.du && rowt[tt] < p.M) *(s16x8_t*)(p.du + (size_t)rowt[tt] * HID + (size_t)c * HC + blk * 32 + g * 8) = af[tt].v;
 #endif
       }
 #pragma unroll
@@ -515,7 +575,8 @@ extern "C" int scot_mlp_block_bwd(const float* g, float* g_out, const float* z, 
   if (rows_per_sample % (64 * tt) != 0) tt = 1;
   if (rows_per_sample % 64 != 0) return SCOT_ERR_UNSUPPORTED;      // the conditioning time must be uniform per workgroup
   MlpBwdArgs a;
-  a.g = g; a.g_out = g_out; a.z = z; a.mean = mean; a.rstd = rstd; a.time = time; a.gw_w = gw_w; a.gw_b = gw_b; a.sscale = sample_scale;
+  a.g = g; a.g_out = g_out; a.z = z; a.z_dt = SCOT_F32; a.mean = mean; a.rstd = rstd; a.time = time; a.gw_w = gw_w; a.gw_b = gw_b; a.sscale = sample_scale;
+  a.partial = nullptr; a.h16 = nullptr; a.b1 = nullptr;
   a.dact = (const bf16_t*)dact; a.W1 = (const bf16_t*)W1; a.W2 = (const bf16_t*)W2; a.dz = (bf16_t*)dz; a.du = (bf16_t*)du;
   a.d_gw_w = d_gw_w; a.d_gw_b = d_gw_b; a.d_bw_w = d_bw_w; a.d_bw_b = d_bw_b;
   a.M = M; a.rows_per_sample = rows_per_sample; a.hid = hid; a.use_tr = g_scot_use_tr;
@@ -876,21 +937,22 @@ __device__ __forceinline__ void qkv_dgrad_prologue(const bf16_t* dqkv, const bf1
   }
 }
 
-template <int C, int HC, int TT, bool PRO>
+template <int C, int HC, int TT, bool PRO, bool RECOMP>
 __global__ __launch_bounds__(256, 2) void tail_bwd_fused_kernel(TailBwdArgs p) {
   constexpr size_t L0 = MlpBwdLds<C, HC>::bytes > ProjBwdLds<C>::bytes ? MlpBwdLds<C, HC>::bytes : ProjBwdLds<C>::bytes;
-  constexpr size_t LDS = L0;                       // (the prologue's weight chunk + patches fit inside ProjBwdLds)
+  constexpr size_t L1 = MlpBwdLds<C, HC>::bytes + (RECOMP ? MlpBwdLds<C, HC>::htile_bytes(TT) : 0);
+  constexpr size_t LDS = L0 > L1 ? L0 : L1;        // (the prologue's weight chunk + patches fit inside ProjBwdLds)
   __shared__ __attribute__((aligned(16))) char smem[LDS];
   float gk[TT][C / 32][8];
   if (PRO) {
     qkv_dgrad_prologue<C, TT>(p.dqkv, p.Wqkv, (float*)p.m.g, p.m.M, smem, p.m.use_tr, gk);
     __syncthreads();                     // the prologue's patches are dead
-    // C = 96: the updated rows go on in registers; C = 192 (no registers to spare: 164 B/lane of scratch otherwise): the norm
-    // re-reads the rows its own lanes have just stored
-    if (C <= 96) mlp_bwd_body<C, HC, TT, true, true>(p.m, smem, gk, gk);
-    else mlp_bwd_body<C, HC, TT, true, false>(p.m, smem, gk);
+    // C = 96 without recomputation: the updated rows go on in registers; otherwise (no registers to spare) the norm re-reads the
+    // rows its own lanes have just stored
+    if (C <= 96 && !RECOMP) mlp_bwd_body<C, HC, TT, true, true, RECOMP>(p.m, smem, gk, gk);
+    else mlp_bwd_body<C, HC, TT, true, false, RECOMP>(p.m, smem, gk);
   } else {
-    mlp_bwd_body<C, HC, TT, true>(p.m, smem, gk);
+    mlp_bwd_body<C, HC, TT, true, false, RECOMP>(p.m, smem, gk);
   }
   __syncthreads();                       // the MLP half's fp32 patches are dead: the norm's dz patches take their place
   proj_cln_bwd_body<C, TT, true>(p.pj, smem, gk);
@@ -899,8 +961,13 @@ __global__ __launch_bounds__(256, 2) void tail_bwd_fused_kernel(TailBwdArgs p) {
 template <int C, int HC, int TT>
 static int launch_tail_bwd(const TailBwdArgs& a, hipStream_t s) {
   dim3 grid((a.m.M + 64 * TT - 1) / (64 * TT)), block(256);
-  if (a.dqkv) hipLaunchKernelGGL((tail_bwd_fused_kernel<C, HC, TT, true>), grid, block, 0, s, a);
-  else hipLaunchKernelGGL((tail_bwd_fused_kernel<C, HC, TT, false>), grid, block, 0, s, a);
+  if (a.m.dact == nullptr) {     // gelu'(u) recomputed in the kernel
+    if (a.dqkv) hipLaunchKernelGGL((tail_bwd_fused_kernel<C, HC, TT, true, true>), grid, block, 0, s, a);
+    else hipLaunchKernelGGL((tail_bwd_fused_kernel<C, HC, TT, false, true>), grid, block, 0, s, a);
+  } else {
+    if (a.dqkv) hipLaunchKernelGGL((tail_bwd_fused_kernel<C, HC, TT, true, false>), grid, block, 0, s, a);
+    else hipLaunchKernelGGL((tail_bwd_fused_kernel<C, HC, TT, false, false>), grid, block, 0, s, a);
+  }
   return scot_check_launch();
 }
 
@@ -923,7 +990,7 @@ extern "C" int scot_proj_cln_fwd(const void* a, const void* W, const float* bias
   if ((mean == nullptr) != (rstd == nullptr) || (gw_w == nullptr) != (bw_w == nullptr)) return SCOT_ERR_SHAPE;
   ProjClnArgs p;
   p.a = (const bf16_t*)a; p.W = (const bf16_t*)W;
-  p.e.bias = bias; p.e.z = z; p.e.mean = mean; p.e.rstd = rstd; p.e.time = time; p.e.gw_w = gw_w; p.e.gw_b = gw_b; p.e.bw_w = bw_w;
+  p.e.bias = bias; p.e.z = z; p.e.z_dt = SCOT_F32; p.e.mean = mean; p.e.rstd = rstd; p.e.time = time; p.e.gw_w = gw_w; p.e.gw_b = gw_b; p.e.bw_w = bw_w;
   p.e.bw_b = bw_b; p.e.sscale = sample_scale; p.e.resid = resid; p.e.out = out; p.e.out16 = (bf16_t*)out16; p.e.M = M;
   p.e.rows_per_sample = rows_per_sample; p.e.eps = eps;
   const int tt = rows_tile_count(C, M, 64 * 2);    // no per-workgroup uniformity needed in the forward
@@ -948,7 +1015,7 @@ extern "C" int scot_proj_cln_bwd(const float* g, const float* z, const float* me
   if ((gw_w == nullptr) != (d_gw_w == nullptr) || (d_gw_w == nullptr) != (d_bw_w == nullptr)) return SCOT_ERR_SHAPE;
   ProjClnBwdArgs p;
   p.W = (const bf16_t*)W; p.da = (bf16_t*)da; p.use_tr = g_scot_use_tr;
-  p.b.g = g; p.b.z = z; p.b.mean = mean; p.b.rstd = rstd; p.b.time = time; p.b.gw_w = gw_w; p.b.gw_b = gw_b; p.b.sscale = sample_scale;
+  p.b.g = g; p.b.z = z; p.b.z_dt = SCOT_F32; p.b.partial = nullptr; p.b.mean = mean; p.b.rstd = rstd; p.b.time = time; p.b.gw_w = gw_w; p.b.gw_b = gw_b; p.b.sscale = sample_scale;
   p.b.dz = (bf16_t*)dz; p.b.d_gw_w = d_gw_w; p.b.d_gw_b = d_gw_b; p.b.d_bw_w = d_bw_w; p.b.d_bw_b = d_bw_b; p.b.M = M;
   p.b.rows_per_sample = rows_per_sample;
   const int tt = C == 96 ? rows_tile_count(C, M, rows_per_sample) : 1;
@@ -963,41 +1030,70 @@ extern "C" int scot_proj_cln_bwd(const float* g, const float* z, const float* me
 }
 
 
+// Rows a workgroup of the block tail owns at (C, M, rows_per_sample) — the geometry both directions use; the backward's partial-sum
+// scratch is one row of 4C (2C without conditioning) floats per workgroup and per norm.
+static int tail_rows_per_wg(int C, int M, int rows_per_sample) {
+  static int tt_env = -1;
+  if (tt_env < 0) { const char* e = getenv("SCOT_MLP_TT"); tt_env = e ? atoi(e) : 0; }
+  int tt = tt_env ? tt_env : ((C == 96 && M >= 64 * 2 * 512) ? 2 : 1);
+  if (C != 96 || rows_per_sample % (64 * tt) != 0) tt = 1;
+  return 64 * tt;
+}
+extern "C" int scot_block_tail_workgroups(int M, int rows_per_sample, int C) {
+  if (M <= 0 || rows_per_sample <= 0 || (C != 96 && C != 192)) return 0;
+  const int r = tail_rows_per_wg(C, M, rows_per_sample);
+  return (M + r - 1) / r;
+}
+
+// out[j] += Σ_b partial[b][j]: finishes the per-workgroup column sums of scot_block_tail_bwd / scot_cln_bwd mode 3 (norm_fast.hip)
+int scot_cln_bwd_finish_launch(const float* partial, int nblk, int ncol, float* out, hipStream_t s);
+extern "C" int scot_partial_colsum(const float* partial, int nblk, int ncol, float* out, hipStream_t stream) {
+  if (!partial || !out || nblk <= 0 || ncol <= 0) return SCOT_ERR_SHAPE;
+  return scot_cln_bwd_finish_launch(partial, nblk, ncol, out, stream);
+}
+
 // include/scot_hip.h: scot_block_tail_bwd = scot_mlp_block_bwd followed by scot_proj_cln_bwd on g_out, in one launch.
 extern "C" int scot_block_tail_bwd(const float* g, float* g_out,
-                                   /* MLP half */ const float* z2, const float* mean2, const float* rstd2, const float* gw_w2,
+                                   /* MLP half */ const void* z2, const float* mean2, const float* rstd2, const float* gw_w2,
                                    const float* gw_b2, const float* sscale2, const void* dact, const void* W1, const void* W2, void* dz2,
                                    void* du, float* d_gw_w2, float* d_gw_b2, float* d_bw_w2, float* d_bw_b2,
-                                   /* attention-output half */ const float* z1, const float* mean1, const float* rstd1,
+                                   /* attention-output half */ const void* z1, const float* mean1, const float* rstd1,
                                    const float* gw_w1, const float* gw_b1, const float* sscale1, const void* Wo, void* dz1, void* da,
                                    float* d_gw_w1, float* d_gw_b1, float* d_bw_w1, float* d_bw_b1,
                                    /* optional prologue g += dqkv · Wqkv (both or neither; needs g_out == g) */ const void* dqkv,
                                    const void* Wqkv,
+                                   /* recompute form (dact == NULL): u = h16·W1^T + b1 */ const void* h16, const float* b1,
+                                   /* dtype of z1 / z2 */ int z_dt,
+                                   /* optional per-workgroup column sums instead of atomics: [workgroups][4C | 2C] each */ float* partial2,
+                                   float* partial1,
                                    const float* time, int M, int rows_per_sample, int C, int hid, hipStream_t stream) {
   if (M <= 0 || rows_per_sample <= 0) return SCOT_ERR_SHAPE;
   if (C != 96 && C != 192) return SCOT_ERR_UNSUPPORTED;
   if (mlp_chunk(C) != 64 || hid < 64 || hid % 64 != 0 || rows_per_sample % 64 != 0) return SCOT_ERR_UNSUPPORTED;
   if ((dqkv == nullptr) != (Wqkv == nullptr)) return SCOT_ERR_SHAPE;
   if (dqkv && g_out != g) return SCOT_ERR_UNSUPPORTED;        // the prologue updates g in place
-  if (!g || !g_out || !z2 || !mean2 || !rstd2 || !gw_b2 || !dact || !W1 || !W2 || !dz2 || !du || !d_gw_b2 || !d_bw_b2 || !z1 || !mean1 ||
-      !rstd1 || !gw_b1 || !Wo || !dz1 || !da || !d_gw_b1 || !d_bw_b1)
+  if (z_dt != SCOT_F32 && z_dt != SCOT_BF16) return SCOT_ERR_DTYPE;
+  if ((dact == nullptr) && (!h16 || !b1)) return SCOT_ERR_SHAPE;       // nothing to take gelu'(u) from
+  if ((partial2 == nullptr) != (partial1 == nullptr)) return SCOT_ERR_SHAPE;
+  const bool atomics = partial2 == nullptr;
+  if (!g || !g_out || !z2 || !mean2 || !rstd2 || !gw_b2 || !W1 || !W2 || !dz2 || !z1 || !mean1 || !rstd1 || !gw_b1 || !Wo || !dz1 || !da)
     return SCOT_ERR_SHAPE;
-  if ((gw_w2 == nullptr) != (d_gw_w2 == nullptr) || (d_gw_w2 == nullptr) != (d_bw_w2 == nullptr) || (gw_w1 == nullptr) != (gw_w2 == nullptr) ||
-      (gw_w1 == nullptr) != (d_gw_w1 == nullptr) || (d_gw_w1 == nullptr) != (d_bw_w1 == nullptr))
+  if (atomics && (!d_gw_b2 || !d_bw_b2 || !d_gw_b1 || !d_bw_b1)) return SCOT_ERR_SHAPE;
+  if (atomics && ((gw_w2 == nullptr) != (d_gw_w2 == nullptr) || (d_gw_w2 == nullptr) != (d_bw_w2 == nullptr) ||
+                  (gw_w1 == nullptr) != (d_gw_w1 == nullptr) || (d_gw_w1 == nullptr) != (d_bw_w1 == nullptr)))
     return SCOT_ERR_SHAPE;
-  static int tt_env = -1;
-  if (tt_env < 0) { const char* e = getenv("SCOT_MLP_TT"); tt_env = e ? atoi(e) : 0; }
-  int tt = tt_env ? tt_env : ((C == 96 && M >= 64 * 2 * 512) ? 2 : 1);
-  if (C != 96 || rows_per_sample % (64 * tt) != 0) tt = 1;
+  if ((gw_w1 == nullptr) != (gw_w2 == nullptr)) return SCOT_ERR_SHAPE;
+  const int tt = tail_rows_per_wg(C, M, rows_per_sample) / 64;
   TailBwdArgs a;
-  a.m.g = g; a.m.g_out = g_out; a.m.z = z2; a.m.mean = mean2; a.m.rstd = rstd2; a.m.time = time; a.m.gw_w = gw_w2; a.m.gw_b = gw_b2;
+  a.m.g = g; a.m.g_out = g_out; a.m.z = z2; a.m.z_dt = z_dt; a.m.mean = mean2; a.m.rstd = rstd2; a.m.time = time; a.m.gw_w = gw_w2; a.m.gw_b = gw_b2;
   a.m.sscale = sscale2; a.m.dact = (const bf16_t*)dact; a.m.W1 = (const bf16_t*)W1; a.m.W2 = (const bf16_t*)W2; a.m.dz = (bf16_t*)dz2;
-  a.m.du = (bf16_t*)du; a.m.d_gw_w = d_gw_w2; a.m.d_gw_b = d_gw_b2; a.m.d_bw_w = d_bw_w2; a.m.d_bw_b = d_bw_b2;
+  a.m.du = (bf16_t*)du; a.m.d_gw_w = d_gw_w2; a.m.d_gw_b = d_gw_b2; a.m.d_bw_w = d_bw_w2; a.m.d_bw_b = d_bw_b2; a.m.partial = partial2;
+  a.m.h16 = (const bf16_t*)h16; a.m.b1 = b1;
   a.m.M = M; a.m.rows_per_sample = rows_per_sample; a.m.hid = hid; a.m.use_tr = g_scot_use_tr;
   a.pj.W = (const bf16_t*)Wo; a.pj.da = (bf16_t*)da; a.pj.use_tr = g_scot_use_tr;
-  a.pj.b.g = g_out; a.pj.b.z = z1; a.pj.b.mean = mean1; a.pj.b.rstd = rstd1; a.pj.b.time = time; a.pj.b.gw_w = gw_w1; a.pj.b.gw_b = gw_b1;
+  a.pj.b.g = g_out; a.pj.b.z = z1; a.pj.b.z_dt = z_dt; a.pj.b.mean = mean1; a.pj.b.rstd = rstd1; a.pj.b.time = time; a.pj.b.gw_w = gw_w1; a.pj.b.gw_b = gw_b1;
   a.pj.b.sscale = sscale1; a.pj.b.dz = (bf16_t*)dz1; a.pj.b.d_gw_w = d_gw_w1; a.pj.b.d_gw_b = d_gw_b1; a.pj.b.d_bw_w = d_bw_w1;
-  a.pj.b.d_bw_b = d_bw_b1; a.pj.b.M = M; a.pj.b.rows_per_sample = rows_per_sample;
+  a.pj.b.d_bw_b = d_bw_b1; a.pj.b.partial = partial1; a.pj.b.M = M; a.pj.b.rows_per_sample = rows_per_sample;
   a.dqkv = (const bf16_t*)dqkv; a.Wqkv = (const bf16_t*)Wqkv;
   if (C == 96) return tt == 2 ? launch_tail_bwd<96, 64, 2>(a, stream) : launch_tail_bwd<96, 64, 1>(a, stream);
   return launch_tail_bwd<192, 64, 1>(a, stream);
@@ -1006,28 +1102,30 @@ extern "C" int scot_block_tail_bwd(const float* g, float* g_out,
 
 // include/scot_hip.h: scot_block_tail_fwd = scot_proj_cln_fwd followed by scot_mlp_block_fwd on its output, in one launch.
 extern "C" int scot_block_tail_fwd(/* attention-output half */ const void* a, const void* Wo, const float* bo, const float* x, float* h,
-                                   void* h16, float* z1, float* mean1, float* rstd1, const float* gw_w1, const float* gw_b1,
+                                   void* h16, void* z1, float* mean1, float* rstd1, const float* gw_w1, const float* gw_b1,
                                    const float* bw_w1, const float* bw_b1, const float* sscale1,
                                    /* MLP half */ const void* W1, const float* b1, const void* W2, const float* b2, float* out,
-                                   void* out16, void* act, void* dact, float* z2, float* mean2, float* rstd2, const float* gw_w2,
+                                   void* out16, void* act, void* dact, void* z2, float* mean2, float* rstd2, const float* gw_w2,
                                    const float* gw_b2, const float* bw_w2, const float* bw_b2, const float* sscale2,
                                    /* optional: the next layer's qkv = out16 · Wqkv^T + bqkv */ const void* Wqkv, const float* bqkv,
                                    void* qkv,
+                                   /* dtype of z1 / z2: fp32, or the 16-bit operand format (only the backward's x-hat reads them) */ int z_dt,
                                    const float* time, int M, int rows_per_sample, int C, int hid, float eps, hipStream_t stream) {
   if (M <= 0 || rows_per_sample <= 0) return SCOT_ERR_SHAPE;
   if (C != 96 && C != 192) return SCOT_ERR_UNSUPPORTED;
   if (mlp_chunk(C) != 64 || hid < 64 || hid % 64 != 0) return SCOT_ERR_UNSUPPORTED;
+  if (z_dt != SCOT_F32 && z_dt != SCOT_BF16) return SCOT_ERR_DTYPE;
   if (!a || !Wo || !bo || !x || !h || !h16 || !gw_b1 || !bw_b1 || !W1 || !b1 || !W2 || !b2 || !out || !gw_b2 || !bw_b2) return SCOT_ERR_SHAPE;
-  if ((act == nullptr) != (dact == nullptr) || (mean1 == nullptr) != (rstd1 == nullptr) || (mean2 == nullptr) != (rstd2 == nullptr) ||
+  if ((act != nullptr && dact == nullptr) || (mean1 == nullptr) != (rstd1 == nullptr) || (mean2 == nullptr) != (rstd2 == nullptr) ||
       (gw_w1 == nullptr) != (bw_w1 == nullptr) || (gw_w2 == nullptr) != (bw_w2 == nullptr) || (gw_w1 == nullptr) != (gw_w2 == nullptr))
     return SCOT_ERR_SHAPE;
   TailFwdArgs t;
   t.pj.a = (const bf16_t*)a; t.pj.W = (const bf16_t*)Wo;
-  t.pj.e.bias = bo; t.pj.e.z = z1; t.pj.e.mean = mean1; t.pj.e.rstd = rstd1; t.pj.e.time = time; t.pj.e.gw_w = gw_w1; t.pj.e.gw_b = gw_b1;
+  t.pj.e.bias = bo; t.pj.e.z = z1; t.pj.e.z_dt = z_dt; t.pj.e.mean = mean1; t.pj.e.rstd = rstd1; t.pj.e.time = time; t.pj.e.gw_w = gw_w1; t.pj.e.gw_b = gw_b1;
   t.pj.e.bw_w = bw_w1; t.pj.e.bw_b = bw_b1; t.pj.e.sscale = sscale1; t.pj.e.resid = x; t.pj.e.out = h; t.pj.e.out16 = (bf16_t*)h16;
   t.pj.e.M = M; t.pj.e.rows_per_sample = rows_per_sample; t.pj.e.eps = eps;
   t.m.h16 = (const bf16_t*)h16; t.m.h = h; t.m.W1 = (const bf16_t*)W1; t.m.b1 = b1; t.m.W2 = (const bf16_t*)W2; t.m.b2 = b2;
-  t.m.out = out; t.m.out16 = (bf16_t*)out16; t.m.act = (bf16_t*)act; t.m.dact = (bf16_t*)dact; t.m.z = z2; t.m.mean = mean2; t.m.rstd = rstd2;
+  t.m.out = out; t.m.out16 = (bf16_t*)out16; t.m.act = (bf16_t*)act; t.m.dact = (bf16_t*)dact; t.m.z = z2; t.m.z_dt = z_dt; t.m.mean = mean2; t.m.rstd = rstd2;
   t.m.time = time; t.m.gw_w = gw_w2; t.m.gw_b = gw_b2; t.m.bw_w = bw_w2; t.m.bw_b = bw_b2; t.m.sscale = sscale2;
   t.m.M = M; t.m.rows_per_sample = rows_per_sample; t.m.hid = hid; t.m.eps = eps;
   if ((Wqkv == nullptr) != (qkv == nullptr)) return SCOT_ERR_SHAPE;

@@ -295,6 +295,45 @@ __global__ __launch_bounds__(256) void cln_partial_reduce_kernel(const float* __
   if (ry == 0 && col < ncol) atomicAdd(&out[col], red[0][cx] + red[1][cx] + red[2][cx] + red[3][cx]);
 }
 
+// Up to 32 partial matrices in ONE launch (blockIdx.z picks the matrix): the finishing pass of a whole stage's norm backwards.  Every
+// such pass used to be its own 10-14 us launch on the weight-gradient stream — which is as busy as the main chain during the backward.
+struct PartialBatch { const float* partial[32]; float* out[32]; int nblk[32]; int ncol[32]; };
+__global__ __launch_bounds__(256) void cln_partial_reduce_batch_kernel(PartialBatch b) {
+  __shared__ float red[4][64];
+  const int k = blockIdx.z;
+  const float* __restrict__ partial = b.partial[k];
+  const int nblk = b.nblk[k], ncol = b.ncol[k];
+  const int cx = threadIdx.x & 63, ry = threadIdx.x >> 6;
+  const int col = blockIdx.x * 64 + cx;
+  if (blockIdx.x * 64 >= ncol) return;                    // (whole workgroup: the grid is sized for the widest matrix)
+  const int per = (nblk + gridDim.y - 1) / gridDim.y;
+  const int b0 = blockIdx.y * per, b1 = min(nblk, b0 + per);
+  float acc = 0.f;
+  if (col < ncol)
+    for (int r = b0 + ry; r < b1; r += 4) acc += partial[(size_t)r * ncol + col];
+  red[ry][cx] = acc;
+  __syncthreads();
+  if (ry == 0 && col < ncol && b0 < b1) atomicAdd(&b.out[k][col], red[0][cx] + red[1][cx] + red[2][cx] + red[3][cx]);
+}
+extern "C" int scot_partial_colsum_batch(int n, const float* const* partial, const int* nblk, const int* ncol, float* const* out,
+                                         hipStream_t s) {
+  if (n <= 0 || n > 32 || !partial || !nblk || !ncol || !out) return SCOT_ERR_SHAPE;
+  PartialBatch b;
+  int maxcol = 0, maxblk = 0;
+  for (int i = 0; i < n; ++i) {
+    if (!partial[i] || !out[i] || nblk[i] <= 0 || ncol[i] <= 0) return SCOT_ERR_SHAPE;
+    b.partial[i] = partial[i]; b.out[i] = out[i]; b.nblk[i] = nblk[i]; b.ncol[i] = ncol[i];
+    if (ncol[i] > maxcol) maxcol = ncol[i];
+    if (nblk[i] > maxblk) maxblk = nblk[i];
+  }
+  for (int i = n; i < 32; ++i) { b.partial[i] = nullptr; b.out[i] = nullptr; b.nblk[i] = 0; b.ncol[i] = 0; }
+  int slices = maxblk / 64;
+  if (slices < 1) slices = 1;
+  if (slices > 8) slices = 8;
+  hipLaunchKernelGGL(cln_partial_reduce_batch_kernel, dim3((maxcol + 63) / 64, slices, n), dim3(256), 0, s, b);
+  return scot_check_launch();
+}
+
 int scot_cln_bwd_finish_launch(const float* partial, int nblk, int ncol, float* out, hipStream_t s) {
   int slices = nblk / 32;
   if (slices < 1) slices = 1;

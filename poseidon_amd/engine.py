@@ -71,6 +71,7 @@ class ScOTEngine:
         self.side_flush = os.environ.get("SCOT_SIDE_FLUSH", "block")   # block | stage: where queued weight-gradient launches fork
         self._pending = []
         self._wgq = []                                                  # weight gradients waiting to be grouped (see wgrad)
+        self._finq = []                                                 # per-workgroup partial sums of norm backwards waiting for their column sums (see finish_partials)
         self._in_side = None                                            # main stream while a side-stream task runs (see fork_task)
         self._task_keep, self._task_keeps = [], {}
         # ConvNeXt skip blocks off the critical path: a skip's blocks only feed the decoder stage that consumes the skip (forward)
@@ -81,11 +82,13 @@ class ScOTEngine:
         self.side2 = None
         self.group_wgrads = os.environ.get("SCOT_GROUP_WGRAD", "1") == "1"
         self.cln_partial = os.environ.get("SCOT_CLN_PARTIAL", "1") == "1"     # small-row-count LN backward through partial sums (A/B switch)
-        # TIMING-ONLY what-if switches (results are wrong with any of them set; tools/gpu_whatif.sh): "noact" = the fused forward tail
-        # does not store gelu(u) / gelu'(u) (the backward reads a stale dummy), "nomlpwgrad" = the fc1 / fc2 weight gradients of the
-        # fused stages are skipped
-        self.whatif = {w for w in os.environ.get("SCOT_WHATIF", "").split(",") if w}
-        self._whatif_dummy = {}
+        # the fused layer tail WITHOUT 4C-wide tensors in HBM (round 3): the forward stores neither gelu(u) nor gelu'(u) and keeps the
+        # pre-norm rows as 16-bit, the backward recomputes gelu'(u) and does not store du, scot_wgrad_mlp recomputes both for the
+        # fc1 / fc2 weight gradients, the norms' parameter gradients go through per-workgroup partial rows instead of atomics
+        self.lean_tail = os.environ.get("SCOT_LEAN_TAIL", "1") == "1"
+        # ... gelu'(u): "store" = the forward still writes it (16-bit, 8·C bytes per token) and the backward tail loads it; "recompute" =
+        # the backward tail recomputes it from h16 (one more C x 4C product per row tile at the 256-register cap: measured slower)
+        self.lean_dact = os.environ.get("SCOT_LEAN_DACT", "store")
         self.arena = arena
         # bf16x3: activations and weights stay fp32 in HBM; the GEMMs split them into hi + lo bf16 while staging into LDS and
         # run three bf16 MFMAs per K-step (≈ fp32 accuracy at the bf16 MFMA rate); so do the 16x16-window attention kernels
@@ -167,6 +170,7 @@ class ScOTEngine:
         if self.scale_grads and os.environ.get("SCOT_LS_RESCALE", "1") == "1":
             self._plan_layer_scale_rescale()
         self._wviews: Dict[str, torch.Tensor] = {}
+        self._lean_cache: Dict[tuple, bool] = {}
         # 16-bit weight copies are refreshed only when the fp32 master changed: `weights_version()` (set by ScOT: in-place edits of
         # the parameters / the arena and the fused optimizer's steps all move it) is compared with the version the copies were made
         # from.  None (an engine built by hand): refresh at every forward.  The fused AdamW writes the copies itself.
@@ -430,7 +434,8 @@ class ScOTEngine:
             part = self.new(nf)
             ops.cln_bwd(dout, x, stats[0], stats[1], t, gw_w, gw_b, dx, None, None, None, None, rows, rows_per_sample, C,
                         sample_scale=sample_scale, mode=3, partial=part)
-            self.off_critical_path(lambda: ops.cln_bwd_finish(part, rows, rows_per_sample, C, g[0], g[1], g[2], g[3]), part)
+            ncol = (4 if self.cond else 2) * C
+            self._finq.append((part, nf // ncol, ncol, next(t_ for t_ in g if t_ is not None)))
             return dx
         if self.use_side and self.split_ln_bwd:
             # the dependent chain only needs dx (a pure stream); the column reductions for the four parameter gradients
@@ -444,11 +449,28 @@ class ScOTEngine:
                         sample_scale=sample_scale)
         return dx
 
+    def _lean_ok(self, pre, rows, rows_per_sample, C, hid) -> bool:
+        """may this ScOTLayer's tail run in the form that keeps no 4C-wide tensor (see `lean_tail`)?  Needs the fused tail in both
+        directions, the transposed 16-bit copy of W2, and the gradient arena's contiguous [W1 | b1 | W2 | b2] and norm layouts."""
+        key = (pre, rows, rows_per_sample)
+        ok = self._lean_cache.get(key)
+        if ok is None:
+            w2 = pre + ".output.dense.weight"
+            ok = (self.use_fused("mlp_bwd", C) and self.use_fused("proj_bwd", C) and self.use_fused("mlp_fwd", C) and self.use_fused("proj_fwd", C)
+                  and self.fused_tail and hid == 4 * C and hid % 128 == 0 and rows_per_sample % 64 == 0 and not self.split_ln_bwd
+                  and self.WT(w2, self.W(w2)) is not None and ops.tail_workgroups(rows, rows_per_sample, C) > 0)
+            if ok:
+                gs = [self.arena.gview(pre + n) for n in (".intermediate.dense.weight", ".intermediate.dense.bias", ".output.dense.weight", ".output.dense.bias")]
+                ok = all(b.data_ptr() == a.data_ptr() + 4 * a.numel() for a, b in zip(gs, gs[1:]))
+                ok = ok and self._norm_grads_contiguous(pre + ".layernorm_before", C) and self._norm_grads_contiguous(pre + ".layernorm_after", C)
+            self._lean_cache[key] = ok
+        return ok
+
     def _norm_grads_contiguous(self, prefix, C) -> bool:
         """the norm's parameter gradients back to back in the gradient arena (what scot_cln_bwd_finish adds its column sums into)"""
         g = self._norm_grads(prefix)
         ptrs = [t.data_ptr() for t in g if t is not None]
-        return all(b - a == 4 * C for a, b in zip(ptrs, ptrs[1:]))
+        return all(b - a == 4 * ((C + 63) // 64 * 64) for a, b in zip(ptrs, ptrs[1:]))      # (every arena tensor starts on a 64-float boundary)
 
     def drop_path_scale(self, prefix: str, B: int, which: int):
         """Swinv2DropPath (HF:565-586): per-sample keep mask / keep_prob for one residual branch of one layer, or None
@@ -530,6 +552,14 @@ class ScOTEngine:
             self.tdo(lambda: cur.wait_event(ev))
             self._task_keeps.pop(ev, None)
 
+    def finish_partials(self):
+        """The queued partial-sum matrices of norm backwards (one row per workgroup) -> column sums into the parameter gradients, up to
+        32 matrices per launch, on the weight-gradient stream.  Called at stage boundaries: one launch for a stage's 16 norms."""
+        q, self._finq = self._finq, []
+        for i in range(0, len(q), 32):
+            part = q[i:i + 32]
+            self.off_critical_path(lambda part=part: ops.partial_colsum_batch(part), *[p[0] for p in part])
+
     def flush_side(self):
         if self._wgq:
             self._drain_wgrads()
@@ -538,6 +568,7 @@ class ScOTEngine:
             self._run_side(fns)
 
     def join_side(self):
+        self.finish_partials()
         self.flush_side()
         if self.use_side and self.side is not None:
             cur, side, side2 = torch.cuda.current_stream(), self.side, self.side2
@@ -616,6 +647,7 @@ class ScOTEngine:
             for i, blk_rec in enumerate(reversed(recs)):
                 g, pend = self.layer_bwd(blk_rec, g, B, time, pend, defer_qkv_dgrad=(i + 1 < n))
             assert pend is None
+            self.finish_partials()
             self.flush_side()
             return g
         _, n, per = recs
@@ -732,19 +764,18 @@ class ScOTEngine:
         proj_f = self.use_fused("proj_fwd", C)
         mlp_f = self.use_fused("mlp_fwd", C) and hid % 128 == 0
         done_tail = False
+        lean_used = False
         qkv_next = None
         if proj_f and mlp_f and self.fused_tail and os.environ.get("SCOT_FUSED_TAIL_FWD", "1") == "1":
             # projection + norm + residual, then MLP + norm + residual, for the same rows in one launch
-            proj = self.new(B * L, C) if train else None
+            lean = train and self.lean_tail and self._lean_ok(pre, B * L, L, C, hid)
+            zdt = self.adt if lean else torch.float32        # pre-norm rows: only the norm backward's x-hat reads them
+            proj = self.new(B * L, C, dtype=zdt) if train else None
             st1 = (self.new(B * L), self.new(B * L)) if train else (None, None)
             h, h16 = self.new(B * L, C), self.new(B * L, C, dtype=self.adt)
-            u = self.new(B * L, hid, dtype=self.adt) if train else None
-            gp = self.new(B * L, hid, dtype=self.adt) if train else None
-            u_st, gp_st = u, gp
-            if train and "noact" in self.whatif:
-                u_st = gp_st = None
-                u = gp = self._whatif_dummy.setdefault((B * L, hid), torch.ones(B * L, hid, dtype=self.adt, device=self.device))
-            y2 = self.new(B * L, C) if train else None
+            u = self.new(B * L, hid, dtype=self.adt) if (train and not lean) else None
+            gp = self.new(B * L, hid, dtype=self.adt) if (train and (not lean or self.lean_dact == "store")) else None
+            y2 = self.new(B * L, C, dtype=zdt) if train else None
             st2 = (self.new(B * L), self.new(B * L)) if train else (None, None)
             out, out16 = self.new(B * L, C), self.new(B * L, C, dtype=self.adt)
             n1, n2 = self._norm_params(pre + ".layernorm_before"), self._norm_params(pre + ".layernorm_after")
@@ -758,9 +789,12 @@ class ScOTEngine:
                 (attn_c, self.W(pre + ".attention.output.dense.weight"), self.P(pre + ".attention.output.dense.bias"), x, h, h16, proj,
                  st1[0], st1[1], n1[0], n1[1], n1[2], n1[3], dp1),
                 (self.W(pre + ".intermediate.dense.weight"), self.P(pre + ".intermediate.dense.bias"), self.W(pre + ".output.dense.weight"),
-                 self.P(pre + ".output.dense.bias"), out, out16, u_st, gp_st, y2, st2[0], st2[1], n2[0], n2[1], n2[2], n2[3], dp2),
-                time if self.cond else None, B * L, L, C, hid, cfg.layer_norm_eps, *nq)
+                 self.P(pre + ".output.dense.bias"), out, out16, u, gp, y2, st2[0], st2[1], n2[0], n2[1], n2[2], n2[3], dp2),
+                time if self.cond else None, B * L, L, C, hid, cfg.layer_norm_eps, *nq, z16=lean)
+            lean_used = lean
             if not done_tail:
+                if lean:
+                    raise RuntimeError("scot_block_tail_fwd rejected a shape the engine selected it for")
                 qkv_next = None
         if done_tail:
             pass
@@ -806,7 +840,7 @@ class ScOTEngine:
         rec = None
         if train:
             rec = dict(blk=blk, xp=xp, qkv=qkv, attn_p=attn, table=table, lse=lse, attn_c=attn_c, proj=proj, st1=st1, h16=h16, u=u, gp=gp,
-                       y2=y2, st2=st2, geom=(H, W, Hp, Wp, ws, shift, padded), dp=(dp1, dp2))
+                       y2=y2, st2=st2, geom=(H, W, Hp, Wp, ws, shift, padded), dp=(dp1, dp2), lean=bool(done_tail and lean_used))
         return out, out16, rec, qkv_next
 
     def dgrad_into(self, cm, dy, w, g, wt=None):
@@ -904,7 +938,43 @@ class ScOTEngine:
             pend = None
         d_attn = self.new(B * L, C, dtype=adt)
         done_tail = False
-        if tail_f:
+        lean = bool(rec.get("lean"))
+        if lean:
+            # the tail without 4C-wide tensors: gelu'(u) recomputed from h16, du never stored, the norms' parameter gradients as
+            # per-workgroup partial rows; on the weight-gradient stream: the partial rows' column sums, the fc1 / fc2 gradients with
+            # gelu(u) / du recomputed (scot_wgrad_mlp), the out-projection's (and, below, the qkv projection's) through the grouped GEMM
+            if not (tail_f and self.inplace_g):
+                raise RuntimeError("the forward kept no gelu(u) / gelu'(u) for this layer, but the backward's fused tail is switched off")
+            d_y2, d_proj = self.new(B * L, C, dtype=adt), self.new(B * L, C, dtype=adt)
+            n2, n1 = self._norm_params(pre + ".layernorm_after"), self._norm_params(pre + ".layernorm_before")
+            g2, g1 = self._norm_grads(pre + ".layernorm_after"), self._norm_grads(pre + ".layernorm_before")
+            nwg, ncol = ops.tail_workgroups(B * L, L, C), (4 if self.cond else 2) * ((C + 63) // 64 * 64)
+            part2, part1 = self.new(nwg, ncol), self.new(nwg, ncol)
+            w1n, w2n = pre + ".intermediate.dense.weight", pre + ".output.dense.weight"
+            b1 = self.P(pre + ".intermediate.dense.bias")
+            if not ops.block_tail_bwd(
+                    g, g,
+                    (rec["y2"], rec["st2"][0], rec["st2"][1], n2[0], n2[1], rec["dp"][1], rec["gp"], self.W(w1n), self.W(w2n), d_y2, None,
+                     None, None, None, None),
+                    (rec["proj"], rec["st1"][0], rec["st1"][1], n1[0], n1[1], rec["dp"][0], self.W(pre + ".attention.output.dense.weight"),
+                     d_proj, d_attn, None, None, None, None),
+                    time if self.cond else None, B * L, L, C, hid, dqkv=pend[0] if pend else None, wqkv=pend[1] if pend else None,
+                    h16=rec["h16"], b1=b1, z16=True, partial2=part2, partial1=part1):
+                raise RuntimeError("scot_block_tail_bwd rejected a shape the engine selected it for")
+            pend = None
+            done_tail = True
+            first2, first1 = next(t for t in g2 if t is not None), next(t for t in g1 if t is not None)
+            h16r, w2t = rec["h16"], self.WT(w2n, self.W(w2n))
+            gW1, gb1, gW2, gb2 = self.G(w1n), self.G(pre + ".intermediate.dense.bias"), self.G(w2n), self.G(pre + ".output.dense.bias")
+
+            self._finq += [(part2, nwg, ncol, first2), (part1, nwg, ncol, first1)]
+
+            def side():
+                if not ops.wgrad_mlp(h16r, d_y2, self.W(w1n), b1, w2t, gW1, gb1, gW2, gb2):
+                    raise RuntimeError("scot_wgrad_mlp rejected a shape the engine selected it for")
+            self.off_critical_path(side, h16r, d_y2)
+            self.linear_bwd_params(pre + ".attention.output.dense.weight", pre + ".attention.output.dense.bias", d_proj, rec["attn_c"])
+        elif tail_f:
             # both halves of the block tail in one launch: the residual-stream gradient between them stays in registers
             d_y2, d_u, d_proj = self.new(B * L, C, dtype=adt), self.new(B * L, hid, dtype=adt), self.new(B * L, C, dtype=adt)
             n2, g2 = self._norm_params(pre + ".layernorm_after"), self._norm_grads(pre + ".layernorm_after")
@@ -922,9 +992,8 @@ class ScOTEngine:
             pend = None
             if done_tail:
                 g = gout
-                if "nomlpwgrad" not in self.whatif:
-                    self.linear_bwd_params(pre + ".output.dense.weight", pre + ".output.dense.bias", d_y2, rec["u"])
-                    self.linear_bwd_params(pre + ".intermediate.dense.weight", pre + ".intermediate.dense.bias", d_u, rec["h16"])
+                self.linear_bwd_params(pre + ".output.dense.weight", pre + ".output.dense.bias", d_y2, rec["u"])
+                self.linear_bwd_params(pre + ".intermediate.dense.weight", pre + ".intermediate.dense.bias", d_u, rec["h16"])
                 self.linear_bwd_params(pre + ".attention.output.dense.weight", pre + ".attention.output.dense.bias", d_proj, rec["attn_c"])
         if done_tail:
             pass
@@ -1114,7 +1183,8 @@ class ScOTEngine:
             ops.add(g, d_s, g)
             return g
         ops.axpy_dev(g, d_s, ls["cs"][1:2])
-        # scratch / c -> the arena, behind every kernel that accumulated into the scratch (weight gradients: side stream)
+        # scratch / c -> the arena, behind every kernel that accumulated into the scratch (weight gradients, the norm's partial sums)
+        self.finish_partials()
         self._drain_wgrads()
         dst = self.arena.grad[ls["lo"]:ls["hi"]]
         self.off_critical_path(lambda: ops.axpy_dev(dst, ls["scratch"], ls["cs"][1:2], clear_src=True))
@@ -1569,6 +1639,11 @@ class ScOTEngine:
         else:
             def done(prefix):
                 return None
+        _range_done = done
+
+        def done(prefix):       # a range is only final once the queued partial sums of its norms have been added in
+            self.finish_partials()
+            _range_done(prefix)
         done("patch_recovery.")
 
         # decoder, shallow → deep

@@ -40,9 +40,14 @@ PROTOTYPES = {
     "scot_cln_fwd": [P, I, P, I, P, I, P, I, P, P, P, P, P, P, P, I, I, I, F, P, P],
     "scot_mlp_block_fwd": [P, P, P, P, P, P, P, P, P, P, P, P, P, P, P, P, P, P, P, I, I, I, I, F, P],
     "scot_mlp_block_bwd": [P, P, P, P, P, P, P, P, P, P, P, P, P, P, P, P, P, P, I, I, I, I, P],
-    "scot_block_tail_bwd": [P] * 33 + [I, I, I, I, P],
+    "scot_block_tail_bwd": [P] * 32 + [P, P, I, P, P, P, I, I, I, I, P],
+    "scot_block_tail_workgroups": [I, I, I],
+    "scot_partial_colsum": [P, I, I, P, P],
+    "scot_partial_colsum_batch": [I, P, P, P, P, P],
+    "scot_wgrad_mlp_workspace_bytes": [I, I, I],
+    "scot_wgrad_mlp": [P, P, P, P, P, P, P, P, P, I, I, I, P, Z, P],
     "scot_transpose_cast": [P, P, P, I, I, P],
-    "scot_block_tail_fwd": [P] * 34 + [I, I, I, I, F, P],
+    "scot_block_tail_fwd": [P] * 33 + [I, P, I, I, I, I, F, P],
     "scot_proj_cln_fwd": [P, P, P, P, P, P, P, P, P, P, P, P, P, P, P, I, I, I, F, P],
     "scot_proj_cln_bwd": [P, P, P, P, P, P, P, P, P, P, P, P, P, P, P, I, I, I, P],
     "scot_cln_bwd": [P, I, P, I, P, P, P, P, P, P, I, P, P, P, P, P, I, I, I, P, Z, P, I, P],
@@ -82,7 +87,7 @@ PROTOTYPES = {
     "scot_optim_finish": [P, P, P, F, F, I, F, P],
 }
 _VOID = {"scot_set_use_tr"}
-_SIZE = {"scot_gemm_workspace_bytes", "scot_wgrad_group_workspace_bytes", "scot_cln_bwd_workspace_bytes"}      # return size_t
+_SIZE = {"scot_gemm_workspace_bytes", "scot_wgrad_group_workspace_bytes", "scot_cln_bwd_workspace_bytes", "scot_wgrad_mlp_workspace_bytes"}      # return size_t
 
 
 def restype(name):

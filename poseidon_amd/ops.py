@@ -286,30 +286,71 @@ def mlp_block_bwd(g, g_out, z, mean, rstd, time, gw_w, gw_b, sample_scale, dact,
     return True
 
 
-def block_tail_fwd(proj, mlp, time, rows, rows_per_sample, C, hid, eps, wqkv=None, bqkv=None, qkv=None) -> bool:
+def block_tail_fwd(proj, mlp, time, rows, rows_per_sample, C, hid, eps, wqkv=None, bqkv=None, qkv=None, z16: bool = False) -> bool:
     """The tail of a ScOTLayer's forward in one launch: proj_cln_fwd then mlp_block_fwd on its output rows (handed over through
     LDS).  proj = (attn, wo, bo, x, h, h16, z1, mean1, rstd1, gw_w1, gw_b1, bw_w1, bw_b1, sscale1); mlp = (w1, b1, w2, b2, out,
     out16, act, dact, z2, mean2, rstd2, gw_w2, gw_b2, bw_w2, bw_b2, sscale2).  wqkv [3C, C] / bqkv [3C] / qkv [rows, 3C] (optional):
-    epilogue qkv = out16 · wqkv^T + bqkv — the NEXT layer's fused q/k/v projection on the rows just produced.  False = not covered."""
-    rc = L().scot_block_tail_fwd(*[ptr(t) for t in proj], *[ptr(t) for t in mlp], ptr(wqkv), ptr(bqkv), ptr(qkv), ptr(time), rows,
-                                 rows_per_sample, C, hid, float(eps), stream())
+    epilogue qkv = out16 · wqkv^T + bqkv — the NEXT layer's fused q/k/v projection on the rows just produced.  z16: z1 / z2 are
+    16-bit tensors (only the norm backward's x-hat reads them).  act / dact None with z / statistics given = training without the
+    4C-wide saves (block_tail_bwd recomputes).  False = not covered."""
+    rc = L().scot_block_tail_fwd(*[ptr(t) for t in proj], *[ptr(t) for t in mlp], ptr(wqkv), ptr(bqkv), ptr(qkv), BF16 if z16 else F32,
+                                 ptr(time), rows, rows_per_sample, C, hid, float(eps), stream())
     if rc == -3:
         return False
     _lib.check(rc, "scot_block_tail_fwd")
     return True
 
 
-def block_tail_bwd(g, g_out, mlp, proj, time, rows, rows_per_sample, C, hid, dqkv=None, wqkv=None) -> bool:
+def block_tail_bwd(g, g_out, mlp, proj, time, rows, rows_per_sample, C, hid, dqkv=None, wqkv=None, h16=None, b1=None, z16: bool = False,
+                   partial2=None, partial1=None) -> bool:
     """The tail of a ScOTLayer's backward in one launch: mlp_block_bwd then proj_cln_bwd on its result (which stays in
     registers in between).  mlp = (z2, mean2, rstd2, gw_w2, gw_b2, sscale2, dact, w1, w2, dz2, du, d_gw_w2, d_gw_b2, d_bw_w2,
     d_bw_b2); proj = (z1, mean1, rstd1, gw_w1, gw_b1, sscale1, wo, dz1, da, d_gw_w1, d_gw_b1, d_bw_w1, d_bw_b1).  dqkv [rows, 3C] /
     wqkv [3C, C] (optional): prologue g += dqkv · wqkv — the qkv dgrad of the layer processed before, in place (g_out is g).
-    False = not covered (the caller launches the kernels one by one)."""
-    rc = L().scot_block_tail_bwd(ptr(g), ptr(g_out), *[ptr(t) for t in mlp], *[ptr(t) for t in proj], ptr(dqkv), ptr(wqkv), ptr(time),
-                                 rows, rows_per_sample, C, hid, stream())
+    dact None: gelu'(u) is recomputed from h16 / b1; du None: not stored; z16: z1 / z2 are 16-bit; partial2 / partial1
+    ([tail_workgroups, 4C | 2C] fp32): the norms' parameter-gradient column sums per workgroup instead of atomics (partial_colsum
+    finishes them).  False = not covered (the caller launches the kernels one by one)."""
+    rc = L().scot_block_tail_bwd(ptr(g), ptr(g_out), *[ptr(t) for t in mlp], *[ptr(t) for t in proj], ptr(dqkv), ptr(wqkv), ptr(h16), ptr(b1),
+                                 BF16 if z16 else F32, ptr(partial2), ptr(partial1), ptr(time), rows, rows_per_sample, C, hid, stream())
     if rc == -3:
         return False
     _lib.check(rc, "scot_block_tail_bwd")
+    return True
+
+
+def tail_workgroups(rows, rows_per_sample, C) -> int:
+    """workgroups of block_tail_fwd / _bwd at these dimensions = rows of the backward's partial-sum matrices (0: not covered)"""
+    return int(_raw().scot_block_tail_workgroups(rows, rows_per_sample, C))
+
+
+def partial_colsum(partial, nblk, ncol, out):
+    """out[j] += Σ_b partial[b][j]"""
+    _lib.check(L().scot_partial_colsum(ptr(partial), nblk, ncol, ptr(out), stream()), "scot_partial_colsum")
+
+
+def partial_colsum_batch(items):
+    """items = [(partial, nblk, ncol, out)], at most 32: out_i[j] += Σ_b partial_i[b][j], one launch"""
+    import ctypes
+    n = len(items)
+    VP, IA = ctypes.c_void_p * n, ctypes.c_int * n
+    _lib.check(L().scot_partial_colsum_batch(n, VP(*[ptr(i[0]) for i in items]), IA(*[i[1] for i in items]), IA(*[i[2] for i in items]),
+                                             VP(*[ptr(i[3]) for i in items]), stream()), "scot_partial_colsum_batch")
+
+
+def wgrad_mlp(h16, dz, w1, b1, w2t, dW1, db1, dW2, db2) -> bool:
+    """fc1 / fc2 weight + bias gradients of a ScOTLayer's MLP with gelu(u), gelu'(u), du recomputed on the fly (csrc/wgrad_mlp.hip).
+    dW1 | db1 | dW2 | db2 contiguous (the gradient arena's layout).  False = not covered."""
+    M, C = h16.numel() // h16.shape[-1], h16.shape[-1]
+    hid = w1.shape[0]
+    need = int(_raw().scot_wgrad_mlp_workspace_bytes(M, C, hid))
+    if need == 0:
+        return False
+    ws = workspace(need)
+    rc = L().scot_wgrad_mlp(ptr(h16), ptr(dz), ptr(w1), ptr(b1), ptr(w2t), ptr(dW1), ptr(db1), ptr(dW2), ptr(db2), M, C, hid,
+                            ws.data_ptr(), ws.numel(), stream())
+    if rc == -3:
+        return False
+    _lib.check(rc, "scot_wgrad_mlp")
     return True
 
 

@@ -212,6 +212,11 @@ def test_fused_mlp_and_projection_backward(gpu_test_bodies, cond, B, L, C):
     gpu_test_bodies.test_block_tail_bwd_fused(cond, B, L, C, True)
 
 
+@pytest.mark.parametrize("cond,B,L,C,prologue", [(True, 1, 64, 96, True), (False, 1, 64, 192, False), (True, 3, 64, 96, False), (True, 2, 64, 192, True)])
+def test_block_tail_lean_forms(gpu_test_bodies, cond, B, L, C, prologue):
+    gpu_test_bodies.test_block_tail_lean_forms(cond, B, L, C, prologue)
+
+
 @pytest.mark.parametrize("s,t", [(32, 64), (32, 16), (64, 32), (24, 40)])
 def test_spectral_resize_native(emu, s, t):
     """scOT.model.spectral_resize (NT GEMM on the fp32 MFMA + scot_spectral_apply) == the reference's fft2 -> crop / pad -> ifft2

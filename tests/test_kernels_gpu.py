@@ -848,3 +848,97 @@ def test_wgrad_group_direct(kind, K, C):
         print(f"wgrad_group {kind} K={K} C={C}: worst rel-L2 {worst:.2e}")
     finally:
         ops.use(prev)
+
+
+# ----------------------------------------------------------------------------------------------- the layer tail without 4C-wide tensors in HBM
+@pytest.mark.parametrize("prologue", [False, True])
+@pytest.mark.parametrize("cond", [True, False])
+@pytest.mark.parametrize("B,L,C", [(2, 1024, 96), (3, 192, 96), (64, 1024, 96), (2, 256, 192), (5, 64, 192)])
+def test_block_tail_lean_forms(cond, B, L, C, prologue):
+    """Round 3: forward tail that stores neither gelu(u) nor gelu'(u) (z1 / z2 as 16-bit), backward tail that RECOMPUTES gelu'(u) from
+    h16, does not store du and hands its norms' parameter-gradient column sums over as per-workgroup partial rows, and scot_wgrad_mlp,
+    which recomputes gelu(u) / du for the fc1 / fc2 weight gradients — against the round-2 forms of the same entry points (which store
+    and re-read those tensors) on the same inputs."""
+    M, hid = B * L, 4 * C
+    bf = torch.bfloat16
+    a, x = rnd(M, C, seed=11).to(bf), rnd(M, C, seed=12)
+    wo, bo = rnd(C, C, scale=C ** -0.5, seed=13).to(bf), rnd(C, seed=14, scale=0.2)
+    w1, b1 = rnd(hid, C, scale=C ** -0.5, seed=2).to(bf), rnd(hid, seed=3, scale=0.2)
+    w2, b2 = rnd(C, hid, scale=hid ** -0.5, seed=4).to(bf), rnd(C, seed=5, scale=0.2)
+    t = torch.rand(B, device=DEV) if cond else None
+    n1 = [rnd(C, seed=20, scale=0.3) if cond else None, 1 + rnd(C, seed=21, scale=0.1), rnd(C, seed=22, scale=0.1) if cond else None, rnd(C, seed=23, scale=0.1)]
+    n2 = [rnd(C, seed=6, scale=0.3) if cond else None, 1 + rnd(C, seed=7, scale=0.1), rnd(C, seed=8, scale=0.1) if cond else None, rnd(C, seed=9, scale=0.1)]
+    f = lambda *s, dtype=torch.float32: torch.full(s, float("nan"), device=DEV, dtype=dtype)
+
+    # ---- forward: round-2 form (everything stored, fp32 z) vs lean form
+    o = dict(h=f(M, C), h16=f(M, C, dtype=bf), z1=f(M, C), m1=f(M), r1=f(M), out=f(M, C), out16=f(M, C, dtype=bf), act=f(M, hid, dtype=bf),
+             dact=f(M, hid, dtype=bf), z2=f(M, C), m2=f(M), r2=f(M))
+    assert ops.block_tail_fwd((a, wo, bo, x, o["h"], o["h16"], o["z1"], o["m1"], o["r1"], n1[0], n1[1], n1[2], n1[3], None),
+                              (w1, b1, w2, b2, o["out"], o["out16"], o["act"], o["dact"], o["z2"], o["m2"], o["r2"], n2[0], n2[1], n2[2], n2[3], None),
+                              t, M, L, C, hid, 1e-5)
+    n = dict(h=f(M, C), h16=f(M, C, dtype=bf), z1=f(M, C, dtype=bf), m1=f(M), r1=f(M), out=f(M, C), out16=f(M, C, dtype=bf), z2=f(M, C, dtype=bf),
+             m2=f(M), r2=f(M))
+    assert ops.block_tail_fwd((a, wo, bo, x, n["h"], n["h16"], n["z1"], n["m1"], n["r1"], n1[0], n1[1], n1[2], n1[3], None),
+                              (w1, b1, w2, b2, n["out"], n["out16"], None, None, n["z2"], n["m2"], n["r2"], n2[0], n2[1], n2[2], n2[3], None),
+                              t, M, L, C, hid, 1e-5, z16=True)
+    torch.cuda.synchronize()
+    for k in ("h", "h16", "m1", "r1", "out", "out16", "m2", "r2"):
+        assert torch.equal(n[k], o[k]), k
+    assert torch.equal(n["z1"], o["z1"].to(bf)) and torch.equal(n["z2"], o["z2"].to(bf))
+
+    # ---- backward: round-2 form (gelu'(u) loaded, du stored, atomics) vs lean forms
+    g0 = rnd(M, C, seed=31)
+    dqkv = wqkv = None
+    if prologue:
+        dqkv, wqkv = rnd(M, 3 * C, seed=41).to(bf), rnd(3 * C, C, scale=(3 * C) ** -0.5, seed=42).to(bf)
+    zc = lambda: torch.zeros(C, device=DEV)
+
+    def run(lean_z, recomp, partials):
+        g = g0.clone()
+        outs = dict(dz2=f(M, C, dtype=bf), du=None if recomp else f(M, hid, dtype=bf), dz1=f(M, C, dtype=bf), da=f(M, C, dtype=bf))
+        Cp = (C + 63) // 64 * 64      # [gw_w | gw_b | bw_w | bw_b] ([gw_b | bw_b] without conditioning) at the parameter arena's stride
+        flat2, flat1 = torch.zeros(4 * Cp, device=DEV), torch.zeros(4 * Cp, device=DEV)
+        if cond:
+            p2, p1 = [flat2[i * Cp:i * Cp + C] for i in range(4)], [flat1[i * Cp:i * Cp + C] for i in range(4)]
+        else:
+            p2, p1 = [None, flat2[0:C], None, flat2[Cp:Cp + C]], [None, flat1[0:C], None, flat1[Cp:Cp + C]]
+        nwg = ops.tail_workgroups(M, L, C)
+        ncol = (4 if cond else 2) * Cp
+        part2 = f(nwg, ncol) if partials else None
+        part1 = f(nwg, ncol) if partials else None
+        z2_, z1_ = (n["z2"], n["z1"]) if lean_z else (o["z2"], o["z1"])
+        assert ops.block_tail_bwd(g, g, (z2_, o["m2"], o["r2"], n2[0], n2[1], None, None if recomp else o["dact"], w1, w2, outs["dz2"], outs["du"],
+                                         p2[0], p2[1], p2[2], p2[3]),
+                                  (z1_, o["m1"], o["r1"], n1[0], n1[1], None, wo, outs["dz1"], outs["da"], p1[0], p1[1], p1[2], p1[3]),
+                                  t, M, L, C, hid, dqkv=dqkv, wqkv=wqkv, h16=o["h16"] if recomp else None, b1=b1 if recomp else None, z16=lean_z,
+                                  partial2=part2, partial1=part1)
+        if partials:
+            ops.partial_colsum(part2, nwg, ncol, flat2)
+            ops.partial_colsum(part1, nwg, ncol, flat1)
+        torch.cuda.synchronize()
+        outs["g"] = g
+        return outs, flat2, flat1
+    assert ops.tail_workgroups(M, L, C) == (M + (128 if (C == 96 and M >= 65536 and L % 128 == 0) else 64) - 1) // (128 if (C == 96 and M >= 65536 and L % 128 == 0) else 64)
+    r, r2f, r1f = run(False, False, False)
+    # (1) recomputation + partial sums, fp32 z: the same values (the recomputed u is the forward's u bit for bit, gelu' rounded alike)
+    c, c2f, c1f = run(False, True, True)
+    for k in ("g", "dz2", "dz1", "da"):
+        assert torch.isfinite(c[k].float()).all(), k
+        assert torch.equal(c[k], r[k]), (k, rel(c[k].float(), r[k].float()))
+    assert rel(c2f, r2f) < 1e-4 and rel(c1f, r1f) < 1e-4
+    # (2) + 16-bit z1 / z2: x-hat carries one 16-bit rounding (2^-9 bf16 / 2^-12 binary16)
+    e, e2f, e1f = run(True, True, True)
+    tol = 1.5e-2 if ops.half_dtype() == torch.bfloat16 else 2e-3
+    for k in ("g", "dz2", "dz1", "da"):
+        assert rel(e[k].float(), r[k].float()) < tol, (k, rel(e[k].float(), r[k].float()))
+    assert rel(e2f, r2f) < tol and rel(e1f, r1f) < tol
+
+    # ---- fc1 / fc2 weight gradients with everything recomputed vs the GEMMs on the stored tensors
+    gW = torch.zeros(2 * hid * C + hid + C, device=DEV) + 0.125           # [W1 | b1 | W2 | b2] contiguous, += semantics
+    dW1, db1, dW2, db2 = gW[:hid * C].view(hid, C), gW[hid * C:hid * C + hid], gW[hid * C + hid:2 * hid * C + hid].view(C, hid), gW[2 * hid * C + hid:]
+    w2t = w2.t().contiguous()
+    assert ops.wgrad_mlp(o["h16"], r["dz2"], w1, b1, w2t, dW1, db1, dW2, db2)
+    torch.cuda.synchronize()
+    du, act, dz2, h16 = r["du"].double(), o["act"].double(), r["dz2"].double(), o["h16"].double()
+    assert rel(dW1 - 0.125, du.t() @ h16) < 2e-4 and rel(db1 - 0.125, du.sum(0)) < 2e-4
+    assert rel(dW2 - 0.125, dz2.t() @ act) < 2e-4 and rel(db2 - 0.125, dz2.sum(0)) < 2e-4

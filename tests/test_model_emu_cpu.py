@@ -205,6 +205,38 @@ def test_engine_fused_block_kernels(emu, monkeypatch):
     assert abs(res["1"][0] - res["0"][0]) < 5e-3 * abs(res["0"][0])
 
 
+def test_engine_lean_layer_tail(emu, monkeypatch):
+    """Round 3: the ScOTLayer tail that keeps no 4C-wide tensor for the backward (forward stores neither gelu(u) nor gelu'(u), 16-bit
+    pre-norm rows; backward recomputes gelu'(u), stores no du, per-workgroup partial sums instead of atomics; scot_wgrad_mlp recomputes
+    gelu(u) / du) inside the engine, default fp16 mode, C = 96 / 192 — against the round-2 form of the same kernels: identical forward,
+    gradients equal up to the 16-bit rounding of the pre-norm rows."""
+    cfg = ScOTConfig(image_size=64, patch_size=4, num_channels=4, num_out_channels=4, embed_dim=96, depths=[2, 1], num_heads=[3, 6],
+                     skip_connections=[1, 0], window_size=16, mlp_ratio=4.0, qkv_bias=True, drop_path_rate=0.0, hidden_act="gelu", p=1,
+                     channel_slice_list_normalized_loss=[0, 1, 3, 4], residual_model="convnext", use_conditioning=True,
+                     learn_residual=False)
+    sd = synth_state_dict(param_shapes(cfg), "trained")
+    pv, t, lab = synth_inputs(2, 4, 4, 64, "smooth")
+    res = {}
+    for flag in ("0", "1"):
+        monkeypatch.setenv("SCOT_LEAN_TAIL", flag)
+        from scOT.model import ScOT
+        model = ScOT(cfg, compute="fp16")
+        model.load_state_dict(sd)
+        model._ensure_arena(torch.device("cpu"))
+        eng = model._engine
+        loss, pred, tape = eng.forward(pv, t, lab, None, train=True)
+        recs = [r for st in tape["enc"] + tape["dec"] for r in st[0]]
+        assert all(bool(r["lean"]) == (flag == "1") for r in recs) and len(recs) == 6
+        assert all((r["u"] is None and r["y2"].dtype == torch.float16) == (flag == "1") for r in recs)
+        model._prepare_grads()
+        eng.backward(tape, torch.ones(1), None)
+        res[flag] = (float(loss), pred.clone(), model._arena.grad.clone(), int(eng.grad_overflow))
+    assert res["1"][0] == res["0"][0] and torch.equal(res["1"][1], res["0"][1])           # the forward does not change
+    e = rel_l2(res["1"][2].numpy(), res["0"][2].numpy())
+    print(f"\n[lean tail] gradient arena, lean vs round-2 form: rel-L2 {e:.2e}")
+    assert e < 2e-3 and res["1"][3] == 0 and res["0"][3] == 0
+
+
 @pytest.mark.skipif(not FULL, reason="~3 min of emulated MFMA arithmetic: SCOT_EMU_FULL=1")
 @pytest.mark.parametrize("fused", ["0", "1"])
 def test_engine_poseidon_T_bf16(emu, monkeypatch, fused):

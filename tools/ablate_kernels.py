@@ -13,9 +13,11 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 OUT = os.path.join(ROOT, "tools", "_abl")
 CSRC = os.path.join(ROOT, "poseidon_amd", "csrc")
 VARIANTS = [0, 1, 2, 8, 16, 1 | 2, 1 | 2 | 8, 1 | 2 | 8 | 16, 1 | 2 | 4 | 8 | 16]
+if os.environ.get("ABL_SET") == "wm":
+    VARIANTS = [0, 2, 8, 16, 2 | 8, 2 | 8 | 16]
 if os.environ.get("ABL_SET") == "bwd2":
     VARIANTS = [0, 32, 64, 128, 64 | 128, 32 | 64 | 128, 1 | 4 | 32 | 64 | 128, 1 | 2 | 4 | 8 | 16 | 32 | 64 | 128]
-SRC = "mlp_fused.hip"
+SRC = os.environ.get("ABL_SRC", "mlp_fused.hip")
 
 
 def build():
@@ -102,6 +104,13 @@ def worker(which):
 
 
 def run(which):
+    if which == "wm":
+        for v in VARIANTS:
+            for wgs in ("256", "512", "128"):
+                env = dict(os.environ, SCOT_LIB_F16=os.path.join(OUT, f"libscot_abl_{v}.so"), SCOT_WGRAD_MLP_WGS=wgs)
+                out = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "bench_wgrad_mlp.py")], env=env, capture_output=True, text=True, timeout=300)
+                print(f"abl={v:3d} {out.stdout.strip() or out.stderr[-300:]}", flush=True)
+        return
     names = {1: "nostore", 2: "nogelu", 4: "noload", 8: "nomfma", 16: "nobarrier", 32: "noatomic", 64: "nodact", 128: "nodu"}
     for v in VARIANTS:
         env = dict(os.environ, SCOT_LIB_F16=os.path.join(OUT, f"libscot_abl_{v}.so"))
