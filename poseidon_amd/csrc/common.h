@@ -75,7 +75,7 @@ template <> struct ct_traits<bf16_t> { static constexpr int dtype = SCOT_BF16; s
 // ---- ablation hooks (tools/ablate_kernels.py builds extra copies of ONE source with -DSCOT_ABL=<bits>; the product never defines it).
 // TIMING ONLY — results are garbage: 1 = st8 stores nothing (values kept alive), 2 = gelu_terms is two multiplies, 4 = ld8 loads
 // nothing, 8 = no MFMA (and, dead-code-eliminated with it, no fragment reads), 16 = __syncthreads is a no-op, 32 = no global atomics,
-// 64 = mlp_fused.hip: gelu'(u) is not loaded, 128 = mlp_fused.hip: du is not stored.
+// 64 = mlp_fused.hip: gelu'(u) is not loaded, 128 = mlp_fused.hip: du is not stored, 256 = v_exp_f32 is the identity.
 #ifndef SCOT_ABL
 #define SCOT_ABL 0
 #endif
@@ -84,6 +84,9 @@ template <> struct ct_traits<bf16_t> { static constexpr int dtype = SCOT_BF16; s
 #endif
 #if SCOT_ABL & 32
 #define atomicAdd(p, v) asm volatile("" ::"v"(v))
+#endif
+#if SCOT_ABL & 256
+#define __builtin_amdgcn_exp2f(x) (x)
 #endif
 
 // ---- runtime-dtype global memory access (dtype is wave-uniform → scalar branch) ----------------------------

@@ -134,17 +134,23 @@ __device__ __forceinline__ void fstore_x3(bf16_t* hi, bf16_t* lo, const uint4 (&
 // WM x WN = arrangement of the 4 waves over the BM x BN tile (WM*WN == 4); each wave owns (BM/WM) x (BN/WN).
 // X3 (CT = bf16_t, BKT = 32): fp32 operands in memory, split into hi/lo bf16 tiles in LDS, 3 MFMAs per K-step (see fstore_x3).
 // LDS footprint of one workgroup of gemm_fast_body (operand double buffer, reused by the epilogue's C tile)
-template <typename CT, int BM, int BN, int BKT, int LAYOUT, bool X3> struct FastLds {
+template <typename CT, int BM, int BN, int BKT, int LAYOUT, bool X3, int KG = 1> struct FastLds {
   static constexpr bool A_KC = (LAYOUT != LAYOUT_TN), B_KC = (LAYOUT == LAYOUT_NT);
   static constexpr int STAGE = (X3 ? 2 : 1) * (FTile<CT, BM, A_KC, BKT>::elems + FTile<CT, BN, B_KC, BKT>::elems);
-  static constexpr size_t AB = 2 * STAGE * sizeof(CT), C = (size_t)BM * (BN + 4) * sizeof(float) + BN * sizeof(float);
+  static constexpr size_t AB = (size_t)KG * 2 * STAGE * sizeof(CT), C = (size_t)KG * BM * (BN + 4) * sizeof(float) + BN * sizeof(float);
   static constexpr size_t bytes = AB > C ? AB : C;
 };
 
 // One workgroup's share of a GEMM: output tile (by, bx), K range [bz·ksplit, (bz+1)·ksplit).  `smem`: FastLds<..>::bytes, 16-byte aligned.
-template <typename CT, int BM, int BN, int WM, int WN, int BKT, int NSET, int LAYOUT, bool X3 = false>
+// KG = 2: the workgroup has EIGHT waves in two groups of four; group g walks the K-tiles g, g + 2, ... of the same output tile with its
+// own LDS double buffer and accumulators, and the two partial tiles meet in LDS before the epilogue.  For small grids with a long
+// contraction (the deep stages' weight gradients: 432 workgroups x 64 K-tiles at 4096 tokens) the serial K loop — one exposed
+// load -> LDS -> barrier -> MFMA round trip per tile, at one or two workgroups per CU — is what the launch costs; this halves its
+// trip count and doubles the loads in flight per CU without a second pass over partial sums in HBM.
+template <typename CT, int BM, int BN, int WM, int WN, int BKT, int NSET, int LAYOUT, bool X3 = false, int KG = 1>
 __device__ __forceinline__ void gemm_fast_body(const FastArgs& p, const int bx, const int by, const int bz, char* smem) {
   static_assert(NSET == 2 || NSET == 4, "pipeline depth");
+  static_assert(KG == 1 || (KG == 2 && !X3), "K groups: plain 16-bit or fp32 operands");
   static_assert(WM * WN == 4, "4 waves per workgroup");
   static_assert(!X3 || (sizeof(CT) == 2 && BKT == 32), "bf16x3: bf16 tiles, one MFMA K-step per tile");
   constexpr bool A_KC = (LAYOUT != LAYOUT_TN);
@@ -160,10 +166,11 @@ __device__ __forceinline__ void gemm_fast_body(const FastArgs& p, const int bx, 
   constexpr int STAGE = (X3 ? 2 : 1) * (TA::elems + TB::elems);   // X3: [A hi][A lo][B hi][B lo]
   constexpr int BOFF = (X3 ? 2 : 1) * TA::elems;                  // offset of the B tile(s) in a stage
   constexpr int CP = BN + 4;                                  // C tile pitch (floats)
-  static_assert(FastLds<CT, BM, BN, BKT, LAYOUT, X3>::STAGE == STAGE, "LDS sizing");
-  CT* lds = (CT*)smem;
+  static_assert(FastLds<CT, BM, BN, BKT, LAYOUT, X3, KG>::STAGE == STAGE, "LDS sizing");
+  const int kg = KG > 1 ? (int)(threadIdx.x >> 8) : 0;            // K group of this wave quartet
+  CT* lds = (CT*)smem + (size_t)kg * 2 * STAGE;
 
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x & 255, lane = tid & 63, wave = tid >> 6;
   const int wr = wave / WN, wc = wave % WN, g = lane >> 4;
   const int m0 = by * BM, n0 = bx * BN;
   const int kbeg = bz * p.ksplit;
@@ -194,12 +201,14 @@ __device__ __forceinline__ void gemm_fast_body(const FastArgs& p, const int bx, 
       fstore<CT, BN, B_KC, BKT>(st + BOFF, b, k0, kend, tid);
     }
   };
+  // K-tile j of THIS group starts at kofs(j) (KG = 1: consecutive tiles)
+  auto kofs = [&](int j) { return kbeg + (kg + KG * j) * BK; };
 #pragma unroll
   for (int u = 0; u < NSET; ++u) {   // unconditional: fload clamps its addresses, fstore zero-fills tiles past kend
-    fload<MT, BM, A_KC, BKT>(ra[u], A, p.lda, m0, p.M, kbeg + u * BK, kend, tid);
-    fload<MT, BN, B_KC, BKT>(rb[u], B, p.ldb, n0, p.N, kbeg + u * BK, kend, tid);
+    fload<MT, BM, A_KC, BKT>(ra[u], A, p.lda, m0, p.M, kofs(u), kend, tid);
+    fload<MT, BN, B_KC, BKT>(rb[u], B, p.ldb, n0, p.N, kofs(u), kend, tid);
   }
-  stage_store(lds, ra[0], rb[0], kbeg);
+  stage_store(lds, ra[0], rb[0], kofs(0));
   __syncthreads();
 
   auto frag_a = [&](const CT* As, int i, int kk) {
@@ -255,16 +264,16 @@ __device__ __forceinline__ void gemm_fast_body(const FastArgs& p, const int bx, 
   // their tiles are zero-filled by fstore and add nothing): with `if (tile exists)` around the loads the compiler cannot count
   // the loads in flight and falls back to s_waitcnt vmcnt(0) before every LDS store — i.e. no prefetch at all.  The trip
   // count is rounded up to a multiple of NSET for the same reason.
-  const int nk_pad = (nk + NSET - 1) / NSET * NSET;
+  const int nk_pad = ((nk + KG - 1) / KG + NSET - 1) / NSET * NSET;    // tiles per group (the same trip count in both: barriers)
   for (int t = 0; t < nk_pad; t += NSET) {
 #pragma unroll
     for (int u = 0; u < NSET; ++u) {
       const int tt = t + u;
       // set u held tile tt (already in LDS buffer u&1): refill it with tile tt+NSET
-      fload<MT, BM, A_KC, BKT>(ra[u], A, p.lda, m0, p.M, kbeg + (tt + NSET) * BK, kend, tid);
-      fload<MT, BN, B_KC, BKT>(rb[u], B, p.ldb, n0, p.N, kbeg + (tt + NSET) * BK, kend, tid);
+      fload<MT, BM, A_KC, BKT>(ra[u], A, p.lda, m0, p.M, kofs(tt + NSET), kend, tid);
+      fload<MT, BN, B_KC, BKT>(rb[u], B, p.ldb, n0, p.N, kofs(tt + NSET), kend, tid);
       compute(lds + (u & 1) * STAGE);
-      stage_store(lds + ((u + 1) & 1) * STAGE, ra[(u + 1) % NSET], rb[(u + 1) % NSET], kbeg + (tt + 1) * BK);
+      stage_store(lds + ((u + 1) & 1) * STAGE, ra[(u + 1) % NSET], rb[(u + 1) % NSET], kofs(tt + 1));
       __syncthreads();
     }
   }
@@ -272,23 +281,27 @@ __device__ __forceinline__ void gemm_fast_body(const FastArgs& p, const int bx, 
   if (LAYOUT == LAYOUT_TN && p.colsum_out && bx == 0 && tid < BM && m0 + tid < p.M) atomicAdd(&p.colsum_out[m0 + tid], bsum);
 
   // ---- epilogue through LDS
-  float* Cs = (float*)smem;
-  float* colacc = Cs + BM * CP;
+  float* Cs = (float*)smem;               // KG partial tiles back to back: group g fills Cs + g·BM·CP
+  float* colacc = Cs + KG * BM * CP;
+  {
+    float* Cg = Cs + kg * BM * CP;
 #pragma unroll
-  for (int i = 0; i < MI; ++i)
+    for (int i = 0; i < MI; ++i)
 #pragma unroll
-    for (int j = 0; j < NI; ++j)
+      for (int j = 0; j < NI; ++j)
 #pragma unroll
-      for (int r = 0; r < 4; ++r)
-        Cs[(wr * WROWS + i * 16 + g * 4 + r) * CP + wc * WCOLS + j * 16 + (lane & 15)] = acc[i][j][r];
+        for (int r = 0; r < 4; ++r)
+          Cg[(wr * WROWS + i * 16 + g * 4 + r) * CP + wc * WCOLS + j * 16 + (lane & 15)] = acc[i][j][r];
+  }
   const bool want_colsum = (LAYOUT != LAYOUT_TN) && p.colsum_out != nullptr;
-  if (want_colsum && tid < BN) colacc[tid] = 0.f;
+  const int etid = threadIdx.x;           // epilogue: all 256·KG threads share the rows of the tile
+  if (want_colsum && etid < BN) colacc[etid] = 0.f;
   __syncthreads();
 
   constexpr int CPRW = BN / 8;            // 8-column chunks per tile row
-  constexpr int RPP = 256 / CPRW;         // rows per pass; threads >= RPP*CPRW idle (BN = 96: 252 of 256 active)
-  const int cc = tid % CPRW;              // constant per thread over the row loop
-  const bool ep_active = tid < RPP * CPRW;
+  constexpr int RPP = (256 * KG) / CPRW;  // rows per pass; threads >= RPP*CPRW idle (BN = 96: 252 of 256 active)
+  const int cc = etid % CPRW;             // constant per thread over the row loop
+  const bool ep_active = etid < RPP * CPRW;
   const int col = n0 + cc * 8;
   float csum[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
   float bv[8], sv[8];
@@ -299,12 +312,16 @@ __device__ __forceinline__ void gemm_fast_body(const FastArgs& p, const int bx, 
     sv[j] = (p.colscale && ok) ? p.colscale[col + j] : 1.f;
   }
   if (col < p.N && ep_active) {
-    for (int row = tid / CPRW; row < BM; row += RPP) {
+    for (int row = etid / CPRW; row < BM; row += RPP) {
       const int grow = m0 + row;
       if (grow >= p.M) break;
       float v[8];
       const float4 a = *(const float4*)(Cs + row * CP + cc * 8), b = *(const float4*)(Cs + row * CP + cc * 8 + 4);
       v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
+      if constexpr (KG == 2) {
+        const float4 a2 = *(const float4*)(Cs + BM * CP + row * CP + cc * 8), b2 = *(const float4*)(Cs + BM * CP + row * CP + cc * 8 + 4);
+        v[0] += a2.x; v[1] += a2.y; v[2] += a2.z; v[3] += a2.w; v[4] += b2.x; v[5] += b2.y; v[6] += b2.z; v[7] += b2.w;
+      }
       const bool partial = (LAYOUT != LAYOUT_TN) && p.ws != nullptr;
       if (!partial) {
 #pragma unroll
@@ -359,13 +376,13 @@ __device__ __forceinline__ void gemm_fast_body(const FastArgs& p, const int bx, 
   }
   if (want_colsum) {
     __syncthreads();
-    if (tid < BN && n0 + tid < p.N) atomicAdd(&p.colsum_out[n0 + tid], colacc[tid]);
+    if (etid < BN && n0 + etid < p.N) atomicAdd(&p.colsum_out[n0 + etid], colacc[etid]);
   }
 }
 
-template <typename CT, int BM, int BN, int WM, int WN, int BKT, int NSET, int LAYOUT, bool X3 = false>
-__global__ __launch_bounds__(256) void gemm_fast_kernel(FastArgs p) {
-  __shared__ __attribute__((aligned(16))) char smem[FastLds<CT, BM, BN, BKT, LAYOUT, X3>::bytes];
+template <typename CT, int BM, int BN, int WM, int WN, int BKT, int NSET, int LAYOUT, bool X3 = false, int KG = 1>
+__global__ __launch_bounds__(256 * KG) void gemm_fast_kernel(FastArgs p) {
+  __shared__ __attribute__((aligned(16))) char smem[FastLds<CT, BM, BN, BKT, LAYOUT, X3, KG>::bytes];
   // Workgroup b runs on XCD b % 8 (observed dispatch order, used for speed only).  The tiles that re-read the same streamed
   // operand — all output tiles of one token chunk (TN), all column tiles of one row block (NT/NN) — are renumbered so that they
   // are consecutive ON ONE XCD: its 4 MB L2 then serves the re-reads instead of the fabric (PMC: 3.1x algorithmic bytes before).
@@ -382,7 +399,7 @@ __global__ __launch_bounds__(256) void gemm_fast_kernel(FastArgs p) {
       else { by = group % gy; bz = group / gy; bx = member; }
     }
   }
-  gemm_fast_body<CT, BM, BN, WM, WN, BKT, NSET, LAYOUT, X3>(p, bx, by, bz, smem);
+  gemm_fast_body<CT, BM, BN, WM, WN, BKT, NSET, LAYOUT, X3, KG>(p, bx, by, bz, smem);
 }
 
 // ------------------------------------------------------------------------------------------------------------------------
@@ -406,9 +423,9 @@ struct WgradGroupArgs {
   int use_tr;
 };
 
-template <typename CT, int BM, int BN, int BKT, int NSET>
-__global__ __launch_bounds__(256) void wgrad_group_kernel(WgradGroupArgs g) {
-  __shared__ __attribute__((aligned(16))) char smem[FastLds<CT, BM, BN, BKT, LAYOUT_TN, false>::bytes];
+template <typename CT, int BM, int BN, int BKT, int NSET, int KG = 1>
+__global__ __launch_bounds__(256 * KG) void wgrad_group_kernel(WgradGroupArgs g) {
+  __shared__ __attribute__((aligned(16))) char smem[FastLds<CT, BM, BN, BKT, LAYOUT_TN, false, KG>::bytes];
   // all tiles of one K slice consecutively on ONE XCD (workgroup b runs on XCD b % 8: speed only): its L2 serves the re-reads of
   // the slice's operand panels by the tiles that share them
   int L = blockIdx.x, slice, tile;
@@ -434,7 +451,7 @@ __global__ __launch_bounds__(256) void wgrad_group_kernel(WgradGroupArgs g) {
   a.ws = g.ws ? g.ws + pr.ws_off : nullptr;     // partial tiles of slice z at ws[z·plane + ws_off ..]
   a.ws_plane = g.plane;
   a.rmw = g.ws ? 0 : 1;
-  gemm_fast_body<CT, BM, BN, 2, 2, BKT, NSET, LAYOUT_TN, false>(a, local % pr.tiles_n, local / pr.tiles_n, slice, smem);
+  gemm_fast_body<CT, BM, BN, 2, 2, BKT, NSET, LAYOUT_TN, false, KG>(a, local % pr.tiles_n, local / pr.tiles_n, slice, smem);
 }
 
 // Σ_z ws[z][e .. e+7]: ZL consecutive lanes share one 8-float group and take every ZL-th partial (independent loads,
@@ -755,9 +772,9 @@ __global__ __launch_bounds__(256) void wgrad_group_reduce_kernel(WgradGroupArgs 
   }
 }
 
-template <int BM, int BN, int BKT, int NSET>
+template <int BM, int BN, int BKT, int NSET, int KG = 1>
 static int launch_wgrad_group(const WgradGroupArgs& g, hipStream_t s) {
-  hipLaunchKernelGGL((wgrad_group_kernel<bf16_t, BM, BN, BKT, NSET>), dim3((unsigned)(g.tiles * g.nsplit)), dim3(256), 0, s, g);
+  hipLaunchKernelGGL((wgrad_group_kernel<bf16_t, BM, BN, BKT, NSET, KG>), dim3((unsigned)(g.tiles * g.nsplit)), dim3(256 * KG), 0, s, g);
   return scot_check_launch();
 }
 
@@ -830,8 +847,12 @@ static int wgrad_group_impl(int compute, int n, int K, const void* const* dY, co
   }
   static int nset = -1;
   if (nset < 0) { const char* e = getenv("SCOT_WGRAD_GROUP_NSET"); nset = e ? atoi(e) : 2; }
+  // unsplit 64x64-tile groups (the deep stages: 432 / 1728 tiles walking 64 / 16 K-tiles each): two K groups per workgroup
+  static int kg_env = -1;
+  if (kg_env < 0) { const char* e = getenv("SCOT_WGRAD_GROUP_KG"); kg_env = e ? atoi(e) : 2; }   // (measured: stage 2 84.5 -> 62.5 us alone, step -0.12 ms; SCOT_WGRAD_GROUP_KG=1: four waves)
   int rc;
-  if (nset == 4) rc = t96 ? launch_wgrad_group<96, 96, 64, 4>(g, stream) : launch_wgrad_group<64, 64, 64, 4>(g, stream);
+  if (!t96 && g.nsplit == 1 && kg_env == 2 && nkt >= 4) rc = launch_wgrad_group<64, 64, 64, 2, 2>(g, stream);
+  else if (nset == 4) rc = t96 ? launch_wgrad_group<96, 96, 64, 4>(g, stream) : launch_wgrad_group<64, 64, 64, 4>(g, stream);
   else rc = t96 ? launch_wgrad_group<96, 96, 64, 2>(g, stream) : launch_wgrad_group<64, 64, 64, 2>(g, stream);
   if (rc == SCOT_OK && g.ws) {
     const size_t n8 = plane / 8;

@@ -13,6 +13,9 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 OUT = os.path.join(ROOT, "tools", "_abl")
 CSRC = os.path.join(ROOT, "poseidon_amd", "csrc")
 VARIANTS = [0, 1, 2, 8, 16, 1 | 2, 1 | 2 | 8, 1 | 2 | 8 | 16, 1 | 2 | 4 | 8 | 16]
+KIND = os.environ.get("ABL_KIND", "f16")          # operand format of the variants (attention micro-benchmarks use bf16 tensors)
+if os.environ.get("ABL_SET") == "attn":
+    VARIANTS = [0, 8, 16, 256, 32, 8 | 256, 8 | 16 | 32 | 256]
 if os.environ.get("ABL_SET") == "wm":
     VARIANTS = [0, 2, 8, 16, 2 | 8, 2 | 8 | 16]
 if os.environ.get("ABL_SET") == "bwd2":
@@ -28,10 +31,11 @@ def build():
     procs = []
     for v in VARIANTS:
         obj = os.path.join(OUT, f"{SRC[:-4]}_{v}.o")
-        procs.append((v, obj, subprocess.Popen([b.HIPCC, *b.FLAGS, "-DSCOT_OPERAND_FP16", f"-DSCOT_ABL={v}", "-c", os.path.join(CSRC, SRC), "-o", obj])))
+        defs = ["-DSCOT_OPERAND_FP16"] if KIND == "f16" else []
+        procs.append((v, obj, subprocess.Popen([b.HIPCC, *b.FLAGS, *defs, f"-DSCOT_ABL={v}", "-c", os.path.join(CSRC, SRC), "-o", obj])))
     for v, obj, p in procs:
         assert p.wait() == 0, v
-        others = [os.path.join(CSRC, s.replace(".hip", ".f16.o")) for s in b.SOURCES if s != SRC]
+        others = [os.path.join(CSRC, s.replace(".hip", ".f16.o" if KIND == "f16" else ".o")) for s in b.SOURCES if s != SRC]
         subprocess.check_call([b.HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", obj, *others, "-o", os.path.join(OUT, f"libscot_abl_{v}.so")])
         os.remove(obj)
     print("built", len(VARIANTS), "variants in", OUT)
@@ -104,6 +108,15 @@ def worker(which):
 
 
 def run(which):
+    if which == "attn":
+        names = {8: "nomfma", 16: "nobarrier", 256: "noexp", 32: "noatomic"}
+        for v in VARIANTS:
+            env = dict(os.environ, SCOT_LIB_BF16=os.path.join(OUT, f"libscot_abl_{v}.so"), BK_COLD="1")
+            label = "+".join(n for b_, n in names.items() if v & b_) or "full"
+            out = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "bench_kernels.py"), "attn16"], env=env, capture_output=True, text=True, timeout=300)
+            lines = [l.split(":", 1)[1].strip() for l in out.stdout.splitlines() if l.startswith("attn cold")]
+            print(f"{label:34s} " + " | ".join(lines) + (out.stderr[-200:] if not lines else ""), flush=True)
+        return
     if which == "wm":
         for v in VARIANTS:
             for wgs in ("256", "512", "128"):
