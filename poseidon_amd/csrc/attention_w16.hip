@@ -483,7 +483,13 @@ __device__ __forceinline__ void attn16_bwd_dq_body(const AttnArgs& p) {
   dls = wave_sum(dls);
   if (lane == 0) red[wave] = dls;
   __syncthreads();
-  for (int i = tid; i < W16::TS; i += blockDim.x) atomicAdd(&p.dbias_table[h * W16::TS + i], (float)dtab[i]);
+  // (every (window, head) workgroup of a head flushes the same 961 addresses: start each one somewhere else so that concurrent
+  // workgroups do not queue up on the same L2 atomic unit in lockstep)
+  for (int i = tid; i < W16::TS; i += blockDim.x) {
+    int k = i + (int)(blockIdx.x % 31) * 31;
+    k = k >= W16::TS ? k - W16::TS : k;
+    atomicAdd(&p.dbias_table[h * W16::TS + k], (float)dtab[k]);
+  }
   if (tid == 0 && p.logit_scale[h] <= 4.605170185988092f) {
     float r = 0.f;
     for (int wv = 0; wv < (int)(blockDim.x >> 6); ++wv) r += red[wv];
