@@ -54,9 +54,6 @@ class ScOTEngine:
         self.cfg = cfg
         self.stage_timing = os.environ.get("SCOT_STAGE_TIMING", "0") == "1"
         self.marks = []
-        self.chains = int(os.environ.get("SCOT_CHAINS", "1"))            # batch slices walking a deep stage concurrently
-        self.chain_rows = int(os.environ.get("SCOT_CHAIN_ROWS", "4096"))  # ... for stages with at most this many token rows
-        self._chain_streams = []
         # step tape: the second training step with a given input signature is recorded (every C-ABI launch with its final
         # arguments + the host-side stream/event operations between them), later steps replay the list: ~2500 launches per
         # step cost ~10 us of Python each when issued through the op wrappers, ~1.5 us when replayed.
@@ -67,8 +64,6 @@ class ScOTEngine:
         self._rec = None
         self._rec_keep = None
         self._taped = {}
-        self.side_batch = os.environ.get("SCOT_SIDE_BATCH", "1") == "1"
-        self.side_flush = os.environ.get("SCOT_SIDE_FLUSH", "block")   # block | stage: where queued weight-gradient launches fork
         self._pending = []
         self._wgq = []                                                  # weight gradients waiting to be grouped (see wgrad)
         self._finq = []                                                 # per-workgroup partial sums of norm backwards waiting for their column sums (see finish_partials)
@@ -78,8 +73,6 @@ class ScOTEngine:
         # / the encoder stage that produced it (backward), so they run on the side stream beside the deep stages' latency-bound
         # chain instead of in front of it (SCOT_SKIP_SIDE=0: in line)
         self.skip_side = os.environ.get("SCOT_SKIP_SIDE", "1") == "1"
-        self.skip_lane = int(os.environ.get("SCOT_SKIP_LANE", "0"))       # backward of the skip blocks: 1 = a second side stream (measured: 21.55 vs 21.43 ms, more overlap only slows the rest)
-        self.side2 = None
         self.group_wgrads = os.environ.get("SCOT_GROUP_WGRAD", "1") == "1"
         self.cln_partial = os.environ.get("SCOT_CLN_PARTIAL", "1") == "1"     # small-row-count LN backward through partial sums (A/B switch)
         # the fused layer tail WITHOUT 4C-wide tensors in HBM (round 3): the forward stores neither gelu(u) nor gelu'(u) and keeps the
@@ -121,21 +114,12 @@ class ScOTEngine:
         # second HIP stream, forked from / joined into the main stream with events, so that the (latency-bound) wgrad GEMMs
         # fill the CUs the dgrad / LN / attention chain leaves idle.  SCOT_SIDE_STREAM=0 serialises everything.
         self.use_side = os.environ.get("SCOT_SIDE_STREAM", "1") != "0" and torch.device(self.device).type == "cuda"
-        # LN backward split across the streams (SCOT_SPLIT_LN_BWD=1): dx on the dependent chain, the four parameter gradients
-        # on the side stream; the residual-stream gradient is then never updated in place (its readers on the side stream may
-        # still be pending).  Measured 25.96 vs 25.04 ms/step: the second pass over dout and x costs more than the chain
-        # gains, so it is off by default.
-        self.split_ln_bwd = os.environ.get("SCOT_SPLIT_LN_BWD", "0") == "1" and self.use_side and self.chains <= 1
-        self.inplace_g = not self.split_ln_bwd
         self.side = None
         self._keep = []
         # csrc/mlp_fused.hip (validated and measured on MI355X in round 2: 23.7 vs 24.9 ms/step): fc1 → GELU → fc2 → cond-LN →
         # residual in one launch (and its backward chain, and the projection + LN pair) for the C = 96 / 192 stages of the 16-bit
         # modes; SCOT_FUSED_MLP=0 restores the layer-by-layer launches
         self.fused_mlp = os.environ.get("SCOT_FUSED_MLP", "1") == "1" and half
-        # A/B knobs for the first measurements: which channel widths and which of the four kernels take the fused path
-        self.fused_c = {int(c) for c in os.environ.get("SCOT_FUSED_C", "96,192").split(",") if c}
-        self.fused_parts = set(os.environ.get("SCOT_FUSED_PARTS", "mlp_fwd,mlp_bwd,proj_fwd,proj_bwd").split(","))
         self.fused_tail = os.environ.get("SCOT_FUSED_TAIL", "1") == "1"     # MLP-half + projection-half backward in one launch
         widths = lambda name, default: {int(c) for c in os.environ.get(name, default).split(",") if c}
         # ... forward: the next layer's q/k/v projection as epilogue (channel widths).  Backward: the previous layer's qkv dgrad as
@@ -428,7 +412,7 @@ class ScOTEngine:
         g = self._norm_grads(prefix)
         t = time if self.cond else None
         nf = ops.cln_bwd_partial_floats(rows, rows_per_sample, C, self.cond) if self.cln_partial else 0
-        if nf and not self.split_ln_bwd and self._norm_grads_contiguous(prefix, C):
+        if nf and self._norm_grads_contiguous(prefix, C):
             # the deep stages' norms (1024 / 4096 rows): dx on the chain with every row's loads in flight at once, the cross-block
             # sums of the parameter gradients through a small partial matrix finished on the weight-gradient stream
             part = self.new(nf)
@@ -437,16 +421,8 @@ class ScOTEngine:
             ncol = (4 if self.cond else 2) * C
             self._finq.append((part, nf // ncol, ncol, next(t_ for t_ in g if t_ is not None)))
             return dx
-        if self.use_side and self.split_ln_bwd:
-            # the dependent chain only needs dx (a pure stream); the column reductions for the four parameter gradients
-            # re-read dout and x on the side stream, where the weight-gradient GEMMs already run
-            ops.cln_bwd(dout, x, stats[0], stats[1], t, gw_w, gw_b, dx, g[0], g[1], g[2], g[3], rows, rows_per_sample, C,
-                        sample_scale=sample_scale, mode=1)
-            self.off_critical_path(lambda: ops.cln_bwd(dout, x, stats[0], stats[1], t, gw_w, gw_b, None, g[0], g[1], g[2], g[3], rows,
-                                                       rows_per_sample, C, sample_scale=sample_scale, mode=2), dout, x)
-        else:
-            ops.cln_bwd(dout, x, stats[0], stats[1], t, gw_w, gw_b, dx, g[0], g[1], g[2], g[3], rows, rows_per_sample, C,
-                        sample_scale=sample_scale)
+        ops.cln_bwd(dout, x, stats[0], stats[1], t, gw_w, gw_b, dx, g[0], g[1], g[2], g[3], rows, rows_per_sample, C,
+                    sample_scale=sample_scale)
         return dx
 
     def _lean_ok(self, pre, rows, rows_per_sample, C, hid) -> bool:
@@ -457,7 +433,7 @@ class ScOTEngine:
         if ok is None:
             w2 = pre + ".output.dense.weight"
             ok = (self.use_fused("mlp_bwd", C) and self.use_fused("proj_bwd", C) and self.use_fused("mlp_fwd", C) and self.use_fused("proj_fwd", C)
-                  and self.fused_tail and hid == 4 * C and hid % 128 == 0 and rows_per_sample % 64 == 0 and not self.split_ln_bwd
+                  and self.fused_tail and hid == 4 * C and hid % 128 == 0 and rows_per_sample % 64 == 0
                   and self.WT(w2, self.W(w2)) is not None and ops.tail_workgroups(rows, rows_per_sample, C) > 0)
             if ok:
                 gs = [self.arena.gview(pre + n) for n in (".intermediate.dense.weight", ".intermediate.dense.bias", ".output.dense.weight", ".output.dense.bias")]
@@ -489,29 +465,23 @@ class ScOTEngine:
     def off_critical_path(self, fn, *tensors):
         """Run fn() (kernel launches that only WRITE parameter gradients) on the side stream, ordered after everything
         enqueued so far on the current stream.  `tensors` are kept alive until the join so the allocator cannot recycle
-        them.  With batching (default) the launches are queued and handed over by flush_side(): ONE fork per block instead
-        of one per weight gradient — hipGraph replay pays for every cross-stream edge."""
+        them.  The launches are queued and handed over by flush_side(): ONE fork per block instead of one per weight gradient."""
         if not self.use_side or self._in_side is not None:     # no side stream, or already running on it
             fn()
             return
         self._keep.append(tensors)
-        if self.side_batch:
-            self._pending.append(fn)
-        else:
-            self._run_side([fn])
+        self._pending.append(fn)
 
-    def _run_side(self, fns, lane=0):
+    def _run_side(self, fns):
         if self.side is None:
             self.side = torch.cuda.Stream(device=self.device)
-        if lane and self.side2 is None:
-            self.side2 = torch.cuda.Stream(device=self.device)
-        ev, cur, side = torch.cuda.Event(), torch.cuda.current_stream(), (self.side2 if lane else self.side)
+        ev, cur, side = torch.cuda.Event(), torch.cuda.current_stream(), self.side
 
         def fork():
             ev.record(cur)
             side.wait_event(ev)
         self.tdo(fork)
-        prev = ops.set_workspace_slot(10 if lane else 1)
+        prev = ops.set_workspace_slot(1)
         try:
             with torch.cuda.stream(side):
                 for fn in fns:
@@ -519,8 +489,8 @@ class ScOTEngine:
         finally:
             ops.set_workspace_slot(prev)
 
-    def fork_task(self, fn, lane=0):
-        """Run fn() on the side stream (lane 1: the second side stream, for long small-grid work that overlaps the first) NOW, ordered after everything enqueued so far on the current stream; returns (fn's
+    def fork_task(self, fn):
+        """Run fn() on the side stream NOW, ordered after everything enqueued so far on the current stream; returns (fn's
         result, event recorded on the side stream after it).  The caller makes the main stream wait for the event
         (`wait_task`) before it consumes what fn produced.  Without a side stream: fn() in line, event None."""
         if not self.use_side:
@@ -538,8 +508,8 @@ class ScOTEngine:
             finally:
                 self._in_side = None
         self._task_keep = []
-        self._run_side([run], lane)
-        ev, side = torch.cuda.Event(), (self.side2 if lane else self.side)
+        self._run_side([run])
+        ev, side = torch.cuda.Event(), self.side
         self.tdo(lambda: ev.record(side))
         # temporaries of the task come from the main stream's pool: returning them before the main stream is ordered behind the
         # task would hand memory that side-stream kernels still use to the next main-stream allocation
@@ -571,100 +541,34 @@ class ScOTEngine:
         self.finish_partials()
         self.flush_side()
         if self.use_side and self.side is not None:
-            cur, side, side2 = torch.cuda.current_stream(), self.side, self.side2
+            cur, side = torch.cuda.current_stream(), self.side
             self.tdo(lambda: cur.wait_stream(side))
-            if side2 is not None:
-                self.tdo(lambda: cur.wait_stream(side2))
             self._keep.clear()
             self._task_keeps.clear()
 
-    # ------------------------------------------------------------------------------------------ batch chains
-    # The deep stages (8x8 / 4x4 token grids: 4096 / 1024 rows at batch 64) are chains of ~30 dependent launches per block
-    # that each move a few MB: every launch costs its ~10 us latency floor whatever it computes.  Samples are independent,
-    # so the batch is cut into `n` slices that walk the stage on `n` streams at once (hipGraph: parallel branches); the
-    # slices' weight-gradient launches all go to the one side stream, which keeps their read-modify-write of a gradient
-    # serialised, everything else they accumulate into is atomic.
-    def chains_for(self, rows: int, B: int) -> int:
-        n = self.chains
-        if n <= 1 or rows > self.chain_rows or B % n or self.collect_attn:
-            return 1
-        return n
-
-    def run_chains(self, n, fn):
-        """fn(c) for c in range(n), each on its own stream forked from (and joined back into) the current stream."""
-        if len(self._chain_streams) < n:
-            self._chain_streams += [torch.cuda.Stream(device=self.device) for _ in range(n - len(self._chain_streams))]
-        cur = torch.cuda.current_stream()
-        ev = torch.cuda.Event()
-        self.tdo(lambda: ev.record(cur))
-        outs = []
-        for c in range(n):
-            st = self._chain_streams[c]
-            self.tdo(lambda st=st: st.wait_event(ev))
-            prev = ops.set_workspace_slot(2 + c)
-            try:
-                with torch.cuda.stream(st):
-                    outs.append(fn(c))
-            finally:
-                ops.set_workspace_slot(prev)
-        for c in range(n):
-            self.tdo(lambda st=self._chain_streams[c]: cur.wait_stream(st))
-        return outs
-
     def blocks_fwd(self, blocks, x, x16, B, time, train):
-        """The ScOTLayers of one stage → (x, x16, recs); recs is a list of per-block records, or ("chains", n, [lists])."""
-        L, C = blocks[0].res[0] * blocks[0].res[1], blocks[0].dim
-        n = self.chains_for(B * L, B)
-        if n == 1:
-            recs, q = [], None
-            for i, blk in enumerate(blocks):
-                last = i + 1 == len(blocks)
-                x, x16, r, q = self.layer_fwd(blk, x, x16, B, time, train, qkv_pre=q, next_blk=None if last else blocks[i + 1],
-                                              want_attn=self.collect_attn and last)      # (a stage returns its LAST block's, ref:859-860)
-                recs.append(r)
-            return x, x16, recs
-        Bc = B // n
-        xs, x16s = x.view(n, Bc * L, C), x16.view(n, Bc * L, C)
-        ts = time.view(n, Bc) if time is not None else [None] * n
-
-        def chain(c):
-            xc, xc16, rc, q = xs[c], x16s[c], [], None
-            for i, blk in enumerate(blocks):
-                xc, xc16, r, q = self.layer_fwd(blk, xc, xc16, Bc, ts[c], train, qkv_pre=q,
-                                                next_blk=blocks[i + 1] if i + 1 < len(blocks) else None)
-                rc.append(r)
-            return xc, xc16, rc
-        outs = self.run_chains(n, chain)
-        x, x16 = self.new(B * L, C), self.new(B * L, C, dtype=self.adt)
-        self.tdo(lambda: torch.cat([o[0] for o in outs], out=x))
-        self.tdo(lambda: torch.cat([o[1] for o in outs], out=x16))
-        return x, x16, ("chains", n, [o[2] for o in outs])
+        """The ScOTLayers of one stage → (x, x16, recs); recs is the list of per-block records."""
+        recs, q = [], None
+        for i, blk in enumerate(blocks):
+            last = i + 1 == len(blocks)
+            x, x16, r, q = self.layer_fwd(blk, x, x16, B, time, train, qkv_pre=q, next_blk=None if last else blocks[i + 1],
+                                          want_attn=self.collect_attn and last)      # (a stage returns its LAST block's, ref:859-860)
+            recs.append(r)
+        return x, x16, recs
 
     def blocks_bwd(self, recs, g, B, time):
-        if not (isinstance(recs, tuple) and recs[0] == "chains"):
-            pend = None      # (d_qkv, Wqkv) of the layer just processed, to be applied by the next layer's fused tail as a prologue
-            n = len(recs)
-            for i, blk_rec in enumerate(reversed(recs)):
-                g, pend = self.layer_bwd(blk_rec, g, B, time, pend, defer_qkv_dgrad=(i + 1 < n))
-            assert pend is None
-            self.finish_partials()
-            self.flush_side()
-            return g
-        _, n, per = recs
-        Bc = B // n
-        gs = g.view(n, g.shape[0] // n, g.shape[1])
-        ts = time.view(n, Bc) if time is not None else [None] * n
-
-        def chain(c):
-            gc = gs[c]
-            for blk_rec in reversed(per[c]):
-                gc, _ = self.layer_bwd(blk_rec, gc, Bc, ts[c])   # in place on the slice of g
-        self.run_chains(n, chain)
+        pend = None      # (d_qkv, Wqkv) of the layer just processed, to be applied by the next layer's fused tail as a prologue
+        n = len(recs)
+        for i, blk_rec in enumerate(reversed(recs)):
+            g, pend = self.layer_bwd(blk_rec, g, B, time, pend, defer_qkv_dgrad=(i + 1 < n))
+        assert pend is None
+        self.finish_partials()
+        self.flush_side()
         return g
 
     def use_fused(self, part: str, C: int) -> bool:
-        """csrc/mlp_fused.hip covers C = 96 / 192 (bf16 mode); SCOT_FUSED_C / SCOT_FUSED_PARTS narrow it for A/B runs."""
-        return self.fused_mlp and C in (96, 192) and C in self.fused_c and part in self.fused_parts
+        """csrc/mlp_fused.hip covers C = 96 / 192 in the 16-bit modes"""
+        return self.fused_mlp and C in (96, 192)
 
     def wgrad(self, cm, dy, x, gw, b_gelu=False, dbias=None):
         """dW += dy^T x (+ dbias): queued until the next flush_side(), where the queued problems that share a compute mode and
@@ -766,7 +670,7 @@ class ScOTEngine:
         done_tail = False
         lean_used = False
         qkv_next = None
-        if proj_f and mlp_f and self.fused_tail and os.environ.get("SCOT_FUSED_TAIL_FWD", "1") == "1":
+        if proj_f and mlp_f and self.fused_tail:
             # projection + norm + residual, then MLP + norm + residual, for the same rows in one launch
             lean = train and self.lean_tail and self._lean_ok(pre, B * L, L, C, hid)
             zdt = self.adt if lean else torch.float32        # pre-norm rows: only the norm backward's x-hat reads them
@@ -844,14 +748,9 @@ class ScOTEngine:
         return out, out16, rec, qkv_next
 
     def dgrad_into(self, cm, dy, w, g, wt=None):
-        """g + dy·w.  In place when nothing else may still be reading g; otherwise into a fresh buffer: with the LN backward's
-        parameter-gradient half on the side stream, g (its `dout`) must stay untouched until that kernel has run."""
-        if self.inplace_g:
-            ops.linear_dgrad(cm, dy, w, g, accumulate=True, wt=wt)
-            return g
-        g2 = self.new(*g.shape)
-        ops.linear_dgrad(cm, dy, w, g2, resid=g, wt=wt)
-        return g2
+        """g += dy·w, in place (every reader of g launched so far is on the same stream)"""
+        ops.linear_dgrad(cm, dy, w, g, accumulate=True, wt=wt)
+        return g
 
     def _layer_fwd_probe(self, blk, x, x16, B, time, ex):
         """Inference forward of one ScOTLayer with chosen pieces in fp32 (ex: set of 'qkv', 'attn', 'proj', 'mlp'): measures
@@ -918,8 +817,8 @@ class ScOTEngine:
         return out, out16, None
 
     def layer_bwd(self, rec, g, B, time, pend=None, defer_qkv_dgrad=False):
-        """g: fp32 [B*L, C] gradient wrt the layer output; returns (gradient wrt the layer input — the same buffer when
-        `inplace_g` —, pending).  pend = (d_qkv, Wqkv) of the layer processed before this one whose qkv dgrad `g += d_qkv·Wqkv`
+        """g: fp32 [B*L, C] gradient wrt the layer output; returns (gradient wrt the layer input — the same buffer —,
+        pending).  pend = (d_qkv, Wqkv) of the layer processed before this one whose qkv dgrad `g += d_qkv·Wqkv`
         has not been applied yet: the fused block tail does it as a prologue (same rows), otherwise it is launched here first.
         defer_qkv_dgrad: leave THIS layer's qkv dgrad to the next call in the same way when that call can take it."""
         cfg, cm, adt = self.cfg, self.compute, self.adt
@@ -929,10 +828,10 @@ class ScOTEngine:
         a = pre + ".attention.self."
         L, Lp = H * W, Hp * Wp
         hid = int(cfg.mlp_ratio * C)
-        mlp_f = self.use_fused("mlp_bwd", C) and hid % 128 == 0 and L % 64 == 0 and not self.split_ln_bwd
-        proj_f = self.use_fused("proj_bwd", C) and L % 64 == 0 and not self.split_ln_bwd
+        mlp_f = self.use_fused("mlp_bwd", C) and hid % 128 == 0 and L % 64 == 0
+        proj_f = self.use_fused("proj_bwd", C) and L % 64 == 0
         tail_f = mlp_f and proj_f and self.fused_tail
-        can_prologue = tail_f and self.inplace_g and C in self.fused_qkv_dgrad and not padded
+        can_prologue = tail_f and C in self.fused_qkv_dgrad and not padded
         if pend is not None and not can_prologue:
             g = self.dgrad_into(cm, pend[0], pend[1], g, wt=pend[2])
             pend = None
@@ -943,7 +842,7 @@ class ScOTEngine:
             # the tail without 4C-wide tensors: gelu'(u) recomputed from h16, du never stored, the norms' parameter gradients as
             # per-workgroup partial rows; on the weight-gradient stream: the partial rows' column sums, the fc1 / fc2 gradients with
             # gelu(u) / du recomputed (scot_wgrad_mlp), the out-projection's (and, below, the qkv projection's) through the grouped GEMM
-            if not (tail_f and self.inplace_g):
+            if not tail_f:
                 raise RuntimeError("the forward kept no gelu(u) / gelu'(u) for this layer, but the backward's fused tail is switched off")
             d_y2, d_proj = self.new(B * L, C, dtype=adt), self.new(B * L, C, dtype=adt)
             n2, n1 = self._norm_params(pre + ".layernorm_after"), self._norm_params(pre + ".layernorm_before")
@@ -979,7 +878,7 @@ class ScOTEngine:
             d_y2, d_u, d_proj = self.new(B * L, C, dtype=adt), self.new(B * L, hid, dtype=adt), self.new(B * L, C, dtype=adt)
             n2, g2 = self._norm_params(pre + ".layernorm_after"), self._norm_grads(pre + ".layernorm_after")
             n1, g1 = self._norm_params(pre + ".layernorm_before"), self._norm_grads(pre + ".layernorm_before")
-            gout = g if self.inplace_g else self.new(B * L, C)
+            gout = g
             done_tail = ops.block_tail_bwd(
                 g, gout,
                 (rec["y2"], rec["st2"][0], rec["st2"][1], n2[0], n2[1], rec["dp"][1], rec["gp"], self.W(pre + ".intermediate.dense.weight"),
@@ -1003,7 +902,7 @@ class ScOTEngine:
             d_u = self.new(B * L, hid, dtype=adt)
             gw_w, gw_b, _, _ = self._norm_params(pre + ".layernorm_after")
             gg = self._norm_grads(pre + ".layernorm_after")
-            g2 = g if self.inplace_g else self.new(B * L, C)
+            g2 = g
             if not ops.mlp_block_bwd(g, g2, rec["y2"], rec["st2"][0], rec["st2"][1], time if self.cond else None, gw_w, gw_b,
                                      rec["dp"][1], rec["gp"], self.W(pre + ".intermediate.dense.weight"),
                                      self.W(pre + ".output.dense.weight"), d_y2, d_u, gg[0], gg[1], gg[2], gg[3], B * L, L, C, hid):
@@ -1056,7 +955,7 @@ class ScOTEngine:
             ops.linear_dgrad(cm, d_qkv, wqkv, tmp, wt=self.WT(a + "qkv_weight"))
             tmpc = self.new(B * L, C)
             ops.copy2d(tmp, tmpc, B, Hp, Wp, H, W, C)
-            g2 = g if self.inplace_g else self.new(B * L, C)
+            g2 = g
             ops.add(g, tmpc, g2)
             g = g2
             new_pend = None
@@ -1065,8 +964,7 @@ class ScOTEngine:
         else:
             g = self.dgrad_into(cm, d_qkv, wqkv, g, wt=self.WT(a + "qkv_weight"))
             new_pend = None
-        if self.side_flush == "block":
-            self.flush_side()
+        self.flush_side()
         return g, new_pend
 
     # ------------------------------------------------------------------------------------------ resampling
@@ -1674,7 +1572,7 @@ class ScOTEngine:
                 if side_skips and tape["res"][i]:
                     # this skip's gradient is only needed when the backward reaches encoder stage i: its ConvNeXt blocks go to
                     # the side stream now, beside the deeper decoder / encoder stages
-                    g_skips[i], skip_ev[i] = self.fork_task(lambda i=i, gi=g_skips[i]: skip_bwd(i, gi), lane=self.skip_lane)
+                    g_skips[i], skip_ev[i] = self.fork_task(lambda i=i, gi=g_skips[i]: skip_bwd(i, gi))
         g_skips[nl - 1] = g  # decoder input = skips[-1]
 
         # ConvNeXt blocks (in line: the deepest skip, and every skip when the side stream is off)
