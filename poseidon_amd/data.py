@@ -395,7 +395,7 @@ class PDEDataset(torch.utils.data.Dataset):
         self.printable_channel_description, self.channel_slice_list = channel_lists(spec.label_description)
         self.pixel_mask = torch.tensor(spec.pixel_mask) if spec.has_pixel_mask else None
         self.reader = reader if reader is not None else open_reader(os.path.join(data_path, spec.file.lstrip("/")))
-        if "Helmholtz" in name and "a" not in getattr(self.reader, "keys", lambda: [])():
+        if "elliptic.Helmholtz" in name and "a" not in getattr(self.reader, "keys", lambda: [])():
             self.reader = _SampleGroups(self.reader)
 
     def __len__(self) -> int:

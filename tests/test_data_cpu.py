@@ -272,3 +272,80 @@ def test_reference_type_names_and_size_helpers():
     m = torch.nn.ModuleDict({"embeddings": torch.nn.Linear(3, 2), "body": torch.nn.Linear(2, 2), "patch_recovery": torch.nn.Linear(2, 1)})
     m["body"].bias.requires_grad_(False)
     assert get_num_parameters(m) == 8 + 4 + 3 and get_num_parameters_no_embed(m) == 4
+
+
+# ---------------------------------------------------------------------------------------------------------------------------
+# recipes pinned to the reference's own readers (tests/golden/make_dataset_recipe_pins.py ran /root/reference/scOT/problems/** on
+# tests/golden/synth_h5.py's synthetic files; the same files are regenerated here from their seed)
+def _recipe_pins():
+    import json
+    return json.load(open(os.path.join(os.path.dirname(__file__), "golden", "dataset_recipe_pins.json")))
+
+
+def _synth_reader(ds_name):
+    sys.path.insert(0, os.path.join(os.path.dirname(__file__), "golden"))
+    import synth_h5
+    spec, _ = D._spec(ds_name.replace(".time", ""))
+    return synth_h5, synth_h5.SynthFile(spec.file)
+
+
+def check_against_pin(pin, sample_of, tol=2e-6):
+    """sample_of(dataset, idx) -> the sample dict (CPU reader or one row of a device batch)"""
+    sys.path.insert(0, os.path.join(os.path.dirname(__file__), "golden"))
+    import synth_h5
+    if "raises" in pin:
+        with pytest.raises((ValueError, AssertionError, TypeError, NotImplementedError)):
+            D.get_dataset(pin["name"], which=pin["which"], num_trajectories=pin["num_trajectories"], reader={}, **pin["kw"])
+        return
+    _, reader = _synth_reader(pin["name"])
+    ds = D.get_dataset(pin["name"], which=pin["which"], num_trajectories=pin["num_trajectories"], reader=reader, **pin["kw"])
+    assert len(ds) == pin["length"] and ds.input_dim == pin["input_dim"] and ds.output_dim == pin["output_dim"]
+    assert list(ds.channel_slice_list) == pin["channel_slice_list"] and ds.start == pin["start"]
+    for idx, want in zip(pin["idx"], pin["samples"]):
+        got = sample_of(ds, idx)
+        assert set(got) == set(want), (pin["name"], set(got), set(want))
+        for k, w in want.items():
+            if k in ("pixel_values", "labels"):
+                g = synth_h5.summary(got[k].detach().cpu().numpy())
+                assert g["shape"] == w["shape"], (pin["name"], k)
+                n = float(np.prod(w["shape"]))
+                for m in ("sum", "abs", "wsum"):
+                    assert abs(g[m] - w[m]) <= tol * (w["abs"] + n) * (16 if m == "wsum" else 1), (pin["name"], pin["kw"], k, m, g[m], w[m])
+                np.testing.assert_allclose(g["sub"], w["sub"], rtol=1e-5, atol=1e-5, err_msg=f"{pin['name']} {k}")
+            elif k == "pixel_mask":
+                m = got[k].detach().cpu().numpy()
+                assert list(m.shape) == w["shape"] and int(m.sum()) == w["count"] and str(got[k].dtype) == w["dtype"]
+                if w["values"] is not None:
+                    assert m.astype(int).tolist() == w["values"]
+                else:
+                    assert abs(synth_h5.summary(m.astype(np.float32))["wsum"] - w["wsum"]) < 1e-6
+            else:
+                assert abs(float(got[k]) - w) < 1e-7, (pin["name"], k)
+
+
+@pytest.mark.parametrize("pin", _recipe_pins(), ids=lambda p: f"{p['name']}-{p['which']}" + ("-" + "_".join(p["kw"]) if p["kw"] else ""))
+def test_recipes_match_the_reference_readers(pin):
+    check_against_pin(pin, lambda ds, i: ds[i])
+
+
+def device_rows(ds, idx, device):
+    """one row of a DeviceTrajectories batch in the shape of a __getitem__ sample"""
+    b = ds.to_device(device).batch([idx])
+    out = {}
+    for k, v in b.items():
+        out[k] = v[0] if k != "time" else float(v[0])
+    return out
+
+
+_DEVICE_PIN_NAMES = ("fluids.incompressible.ShearLayer", "fluids.compressible.steady.Airfoil", "wave.Gaussians", "elliptic.Helmholtz.time",
+                     "fluids.incompressible.forcing.KolmogorovFlow")      # (the emulator runs one host thread per lane: the GPU test covers every pin)
+
+
+@pytest.mark.parametrize("pin", [p for p in _recipe_pins() if p["name"] in _DEVICE_PIN_NAMES and p["which"] == "test" and not p["kw"]],
+                         ids=lambda p: p["name"])
+def test_device_batches_match_the_reference_readers_emulated(pin, monkeypatch):
+    """the HBM-resident twin (scot_gather_pairs / scot_gather_planes on the CPU emulation) against the same pins"""
+    sys.path.insert(0, os.path.join(HERE, "hipemu"))
+    import emu_session
+    emu_session.patch_ops(monkeypatch, emu_session.load_emu())
+    check_against_pin(pin, lambda ds, i: device_rows(ds, i, "cpu"))

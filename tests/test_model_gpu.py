@@ -586,6 +586,22 @@ def test_device_resident_batches_other_families(name):
             assert torch.equal(b["pixel_mask"][k].cpu(), s["pixel_mask"])
 
 
+def _recipe_pins_for_device():
+    import json
+    pins = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "dataset_recipe_pins.json")))
+    # (the "val" pins take the whole validation split: 120 synthetic trajectories to generate per dataset — train / test pins cover the recipes)
+    return [p for p in pins if p["which"] in ("train", "test") and "raises" not in p]
+
+
+@pytest.mark.parametrize("pin", _recipe_pins_for_device(), ids=lambda p: f"{p['name']}-{p['which']}" + ("-" + "_".join(p["kw"]) if p["kw"] else ""))
+def test_device_batches_match_the_reference_readers(pin):
+    """HBM-resident batches (scot_gather_pairs / scot_gather_planes, native spectral resize) against the pins the reference's own
+    readers produced on the same synthetic files (tests/golden/make_dataset_recipe_pins.py)."""
+    import test_data_cpu as T
+    tol = 2e-6 if "resolution" not in pin["kw"] else 5e-5
+    T.check_against_pin(pin, lambda ds, i: T.device_rows(ds, i, DEV), tol=tol)
+
+
 def test_device_resident_batches_downsampled():
     from scOT.problems.base import get_dataset
     rng = np.random.default_rng(2)
