@@ -307,15 +307,56 @@ def _airfoil() -> DatasetSpec:
                        has_pixel_mask=False, input_mask_value=1.0)
 
 
+class NpyDirectory:
+    """A dataset file exported as one `.npy` per array (`<dir>/<key>.npy`): every array is memory-mapped on first use, so a sample
+    read touches only the pages of its own planes — the numpy-only twin of an HDF5 file for hosts without h5py."""
+
+    def __init__(self, directory: str):
+        self.directory = directory
+        self._maps: Dict[str, np.ndarray] = {}
+
+    def keys(self):
+        return sorted(f[:-4] for f in os.listdir(self.directory) if f.endswith(".npy"))
+
+    def __contains__(self, key):
+        return os.path.exists(os.path.join(self.directory, key + ".npy"))
+
+    def __getitem__(self, key):
+        if key not in self._maps:
+            path = os.path.join(self.directory, key + ".npy")
+            if not os.path.exists(path):
+                raise KeyError(f"{key} (no {path})")
+            self._maps[key] = np.load(path, mmap_mode="r")
+        return self._maps[key]
+
+
+def export_npy(reader, keys: Sequence[str], directory: str) -> None:
+    """write arrays `keys` of an open reader (h5py file, dict, …) as `<directory>/<key>.npy` for NpyDirectory"""
+    os.makedirs(directory, exist_ok=True)
+    for k in keys:
+        np.save(os.path.join(directory, k + ".npy"), np.asarray(reader[k]))
+
+
 def open_reader(path: str):
-    """`.nc` / `.h5` files need h5py (HDF5 / netCDF-4), `.npz` / `.npy` work with numpy alone."""
-    if path.endswith((".npz", ".npy")):
-        r = np.load(path, mmap_mode="r")
-        return r if path.endswith(".npz") else {"data": r, "solution": r, "velocity": r}
+    """`.nc` / `.h5` files need h5py (HDF5 / netCDF-4).  numpy-only alternatives, tried first: `<path>` itself when it is a `.npy`
+    (one memory-mapped array answering every key), a `.npz`, or a directory of per-array `.npy` files (NpyDirectory); and for a
+    `.nc` / `.h5` name, an export of it lying beside it (`<stem>.npy`, `<stem>.npz`, `<stem>/`)."""
+    stem = os.path.splitext(path)[0]
+    for cand in ((path,) if path.endswith((".npy", ".npz")) or os.path.isdir(path) else (path, stem, stem + ".npy", stem + ".npz")):
+        if os.path.isdir(cand):
+            return NpyDirectory(cand)
+        if cand.endswith(".npy") and os.path.exists(cand):
+            r = np.load(cand, mmap_mode="r")
+            return {"data": r, "solution": r, "velocity": r}
+        if cand.endswith(".npz") and os.path.exists(cand):
+            return np.load(cand)
+        if cand == path and os.path.exists(cand):
+            break
     try:
         import h5py
     except ImportError as e:   # pragma: no cover - environment dependent
-        raise ImportError(f"reading {path} needs h5py (not installed here); pass reader={{key: array}} or a .npz/.npy file") from e
+        raise ImportError(f"reading {path} needs h5py (not installed here); pass reader={{key: array}}, or export the arrays with "
+                          f"poseidon_amd.data.export_npy to {stem}/ (one .npy per array), {stem}.npy or {stem}.npz") from e
     return h5py.File(path, "r")
 
 
@@ -419,7 +460,7 @@ class PDEDataset(torch.utils.data.Dataset):
             x = arr[j]
         else:   # "s": one number per sample
             x = np.full((R, R), float(np.asarray(arr[j])), dtype=np.float32)
-        x = torch.from_numpy(np.asarray(x)).type(torch.float32).reshape(R, R)
+        x = torch.from_numpy(np.array(x, dtype=np.float32)).reshape(R, R)      # (a copy: memory-mapped sources are read-only)
         if self.spec.transpose:
             x = x.transpose(-2, -1)
         if c.shift:

@@ -349,3 +349,30 @@ def test_device_batches_match_the_reference_readers_emulated(pin, monkeypatch):
     import emu_session
     emu_session.patch_ops(monkeypatch, emu_session.load_emu())
     check_against_pin(pin, lambda ds, i: device_rows(ds, i, "cpu"))
+
+
+def test_numpy_file_readers(tmp_path):
+    """`.npy` (memory-mapped), `.npz` and per-array `.npy` directories stand in for the HDF5 files: get_dataset(data_path=...) finds an
+    export lying beside the name the reference opens (fluids/incompressible.py:36-38) and yields the same samples as the arrays."""
+    rng = np.random.default_rng(5)
+    vel = rng.standard_normal((12, 21, 3, 128, 128)).astype(np.float32)
+    kw = dict(which="val", num_trajectories=3, n_max=12, n_val=4, n_test=3)
+    want = D.get_dataset("fluids.incompressible.Sines", reader={"velocity": vel}, **kw)[17]
+    a, b, c = tmp_path / "a", tmp_path / "b", tmp_path / "c"
+    for d in (a, b, c):
+        d.mkdir()
+    np.save(a / "NS-Sines.npy", vel)
+    np.savez(b / "NS-Sines.npz", velocity=vel)
+    D.export_npy({"velocity": vel}, ["velocity"], str(c / "NS-Sines"))
+    for d in (a, b, c):
+        ds = D.get_dataset("fluids.incompressible.Sines", data_path=str(d), **kw)
+        got = ds[17]
+        assert torch.equal(got["pixel_values"], want["pixel_values"]) and torch.equal(got["labels"], want["labels"]) and got["time"] == want["time"]
+    assert isinstance(D.open_reader(str(a / "NS-Sines.nc"))["velocity"], np.memmap)
+    assert isinstance(D.open_reader(str(c / "NS-Sines.nc"))["velocity"], np.memmap)
+    wave = {"solution": rng.standard_normal((12, 21, 128, 128)).astype(np.float32), "c": rng.standard_normal((12, 128, 128)).astype(np.float32)}
+    D.export_npy(wave, ["solution", "c"], str(c / "Wave-Layer"))
+    w0, w1 = D.get_dataset("wave.Layer", reader=wave, **kw)[5], D.get_dataset("wave.Layer", data_path=str(c), **kw)[5]
+    assert torch.equal(w0["pixel_values"], w1["pixel_values"]) and torch.equal(w0["labels"], w1["labels"])
+    with pytest.raises((ImportError, OSError)):
+        D.get_dataset("fluids.incompressible.Gaussians", data_path=str(c), **kw)     # nothing exported under that name, no h5py
