@@ -409,6 +409,22 @@ def main():
             torch.cuda.synchronize()
             comm = e0.elapsed_time(e1) / 3
     overflow = int(model._engine.grad_overflow) if model._engine.grad_overflow is not None else None   # fp16 gradient scale
+    # forward / backward split of the step on the GPU's clock: three events on the main stream around the two halves of a few extra
+    # steps (the backward's last act is the main stream's wait for the weight-gradient stream, so its end covers both streams)
+    phase = None
+    if not use_graph[0]:
+        ev = [[torch.cuda.Event(enable_timing=True) for _ in range(3)] for _ in range(5)]
+        for e in ev:
+            model.zero_grad()
+            e[0].record()
+            out = model(**kw)
+            e[1].record()
+            out.loss.backward()
+            e[2].record()
+            if exchange[0] == "after":
+                after.allreduce()
+        torch.cuda.synchronize()
+        phase = {"forward_ms": sorted(e[0].elapsed_time(e[1]) for e in ev)[2], "backward_ms": sorted(e[1].elapsed_time(e[2]) for e in ev)[2]}
     table = worst = None
     table_err = None
     try:   # every rank steps (under DP a step contains collectives); rank 0 reports
@@ -474,7 +490,7 @@ def main():
                           "grad_wire": a.wire if dist is not None else None, "grad_exchange": exchange[0],
                           "grad_collective": a.dp_collective if dist is not None else None, "grad_comm_ms_per_step": comm,
                           "loss": float(loss_buf),
-                          "parity": parity, "grad_overflow": overflow, "in_step_launches": launches},
+                          "parity": parity, "grad_overflow": overflow, "phases": phase, "in_step_launches": launches},
                "roofline": roof}
         if world == 1 and not a.no_cpu_baseline:
             try:

@@ -2,7 +2,10 @@
 (b) the CPU oracle on the same closed-form inputs.  compute='fp32' must meet the 1e-5 class bound; compute='bf16'
 is reported against the north-star 1e-3 on both parameter regimes (bf16 GEMM operands alone put the
 reference itself at 6e-3..2e-2 on trained-like weights, so the trained-regime bound asserted here is looser)."""
+import json
 import math
+import os
+import sys
 
 import numpy as np
 import pytest
@@ -587,7 +590,6 @@ def test_device_resident_batches_other_families(name):
 
 
 def _recipe_pins_for_device():
-    import json
     pins = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "dataset_recipe_pins.json")))
     # (the "val" pins take the whole validation split: 120 synthetic trajectories to generate per dataset — train / test pins cover the recipes)
     return [p for p in pins if p["which"] in ("train", "test") and "raises" not in p]
@@ -597,6 +599,7 @@ def _recipe_pins_for_device():
 def test_device_batches_match_the_reference_readers(pin):
     """HBM-resident batches (scot_gather_pairs / scot_gather_planes, native spectral resize) against the pins the reference's own
     readers produced on the same synthetic files (tests/golden/make_dataset_recipe_pins.py)."""
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
     import test_data_cpu as T
     tol = 2e-6 if "resolution" not in pin["kw"] else 5e-5
     T.check_against_pin(pin, lambda ds, i: T.device_rows(ds, i, DEV), tol=tol)
