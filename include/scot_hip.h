@@ -147,8 +147,10 @@ int scot_cpb_bwd(const float* coords, const float* w0, const float* b0, const fl
  * (int32, offsets in floats from params / coords_base / tables / zbuf; grads uses the params offsets). */
 int scot_cpb_fwd_batched(const float* params, const int* desc, int nlayers, int max_ws, const float* coords_base,
                          float* tables, float* zbuf, scot_stream_t stream);
-int scot_cpb_bwd_batched(const float* params, const int* desc, int first, int count, const float* coords_base,
-                         const float* zbuf, const float* dtables, float* grads, scot_stream_t stream);
+/* backward of layers first .. first + count - 1; max_ws / max_heads: the largest window size and head count among them (sizes the
+ * launch's LDS: the table-gradient tile of a layer is staged once per workgroup) */
+int scot_cpb_bwd_batched(const float* params, const int* desc, int first, int count, int max_ws, int max_heads,
+                         const float* coords_base, const float* zbuf, const float* dtables, float* grads, scot_stream_t stream);
 
 /* ConditionalLayerNorm / LayerNorm (+ fused residual), ref:135-160, res-post-norm ref:570,574.
  * sample_scale (optional, one float per sample): out = resid + s_b * norm(x) — Swinv2DropPath (HF:565-586) on the normed

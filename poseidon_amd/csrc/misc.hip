@@ -987,8 +987,18 @@ __global__ __launch_bounds__(256) void cpb_fwd_batched_kernel(const float* param
     __syncthreads();
   }
 }
+// Backward, all layers of a stage in one launch (round 3).  The work is a pair of tiny GEMMs per layer — dW2[h][j] = Σ_e dz[e][h]·hid[e][j]
+// and dh[e][j] = Σ_h dz[e][h]·W2[h][j] over TS <= 961 table entries, <= 24 heads and 512 hidden units — that sits on the weight-gradient
+// stream beside a saturated backward, so what it costs the step is its CU·time.  One workgroup = (layer, 16 hidden units): dz[e][h]
+// (the sigmoid's derivative times the table gradient) is formed ONCE per workgroup into LDS instead of once per thread and hidden
+// unit, the 256 threads are 16 hidden units x 16 entry groups (each lane keeps its unit's W0 / b0 / W2 column in registers and walks
+// TS / 16 entries), and the 16 groups' partial sums meet in LDS: no atomics, the workgroup owns its units' gradients (+=).
+// Before: 1024 workgroups per launch at 162 registers, each re-deriving dz for 4 units and folding 108 values with wave shuffles
+// (78 us per launch in step, 0.4 ms of step time for a batch-independent operation).
+constexpr int CPB_BJ = 16, CPB_BG = 16;
 __global__ __launch_bounds__(256) void cpb_bwd_batched_kernel(const float* params, const int* desc, int first, const float* coords_base,
                                                               const float* zbuf, const float* dtables, float* grads) {
+  extern __shared__ __attribute__((aligned(16))) float cpb_sm[];
   const int* d = desc + 8 * (first + blockIdx.y);
   const int ws = d[4], heads = d[5];
   const int TS = (2 * ws - 1) * (2 * ws - 1);
@@ -1001,42 +1011,53 @@ __global__ __launch_bounds__(256) void cpb_bwd_batched_kernel(const float* param
   float* dw0 = grads + d[0];
   float* db0 = grads + d[1];
   float* dw2 = grads + d[2];
-  const int j0 = blockIdx.x * CPB_JB;
-  float a_w2[CPB_JB][24], a_w0y[CPB_JB], a_w0x[CPB_JB], a_b0[CPB_JB];
-#pragma unroll
-  for (int jj = 0; jj < CPB_JB; ++jj) {
-    a_w0y[jj] = a_w0x[jj] = a_b0[jj] = 0.f;
-#pragma unroll
-    for (int h = 0; h < 24; ++h) a_w2[jj][h] = 0.f;
+  float* dz = cpb_sm;                       // [TS][heads]
+  float* cs = dz + TS * heads;              // [TS][2]
+  const int tid = threadIdx.x;
+  for (int i = tid; i < TS * heads; i += 256) {
+    const int e = i / heads, h = i - e * heads;
+    const float sg = 1.0f / (1.0f + __expf(-z[i]));
+    dz[i] = dtable[(size_t)h * TS + e] * 16.0f * sg * (1.0f - sg);
   }
-  for (int e = threadIdx.x; e < TS; e += 256) {
-    const float cy = coords[2 * e], cx = coords[2 * e + 1];
-    float dz[24];
+  for (int i = tid; i < 2 * TS; i += 256) cs[i] = coords[i];
+  __syncthreads();
+  const int jl = tid & (CPB_BJ - 1), eg = tid / CPB_BJ, j = blockIdx.x * CPB_BJ + jl;
+  const float w0y = w0[2 * j], w0x = w0[2 * j + 1], bb = b0[j];
+  float w2r[24], a_w2[24];
+#pragma unroll
+  for (int h = 0; h < 24; ++h) { w2r[h] = h < heads ? w2[h * 512 + j] : 0.f; a_w2[h] = 0.f; }
+  float a_y = 0.f, a_x = 0.f, a_b = 0.f;
+  for (int e = eg; e < TS; e += CPB_BG) {
+    const float cy = cs[2 * e], cx = cs[2 * e + 1];
+    const float pre = w0y * cy + w0x * cx + bb;
+    const float hid = fmaxf(pre, 0.f);
+    const float* dze = dz + e * heads;
+    float dh = 0.f;
 #pragma unroll
     for (int h = 0; h < 24; ++h) {
-      dz[h] = 0.f;
-      if (h < heads) {
-        const float sg = 1.0f / (1.0f + __expf(-z[(size_t)e * heads + h]));
-        dz[h] = dtable[(size_t)h * TS + e] * 16.0f * sg * (1.0f - sg);
-      }
+      if (h < heads) { const float v = dze[h]; a_w2[h] = fmaf(v, hid, a_w2[h]); dh = fmaf(v, w2r[h], dh); }
     }
-#pragma unroll
-    for (int jj = 0; jj < CPB_JB; ++jj) {
-      const int j = j0 + jj;
-      const float pre = w0[2 * j] * cy + w0[2 * j + 1] * cx + b0[j];
-      const float hid = fmaxf(pre, 0.f);
-      float dh = 0.f;
-#pragma unroll
-      for (int h = 0; h < 24; ++h) {
-        if (h < heads) { a_w2[jj][h] += dz[h] * hid; dh += dz[h] * w2[h * 512 + j]; }
-      }
-      const float dpre = pre > 0.f ? dh : 0.f;
-      a_w0y[jj] += dpre * cy; a_w0x[jj] += dpre * cx; a_b0[jj] += dpre;
-    }
+    const float dpre = pre > 0.f ? dh : 0.f;
+    a_y = fmaf(dpre, cy, a_y); a_x = fmaf(dpre, cx, a_x); a_b += dpre;
   }
-  // block reduction of the CPB_JB x (3 + heads) sums: wave shuffles, ONE LDS stage, ONE barrier (the first version called a
-  // two-barrier block_sum per value: 216 barriers = 100 of this kernel's 116 us in the round-2 trace)
-  cpb_bwd_finish(a_w2, a_w0y, a_w0x, a_b0, heads, j0, dw0, db0, dw2);
+  __syncthreads();                          // dz is dead: the partial sums take its place, red[group][value][unit]
+  float* red = cpb_sm;
+  constexpr int NV = 27;
+  red[(eg * NV + 0) * CPB_BJ + jl] = a_y; red[(eg * NV + 1) * CPB_BJ + jl] = a_x; red[(eg * NV + 2) * CPB_BJ + jl] = a_b;
+#pragma unroll
+  for (int h = 0; h < 24; ++h) red[(eg * NV + 3 + h) * CPB_BJ + jl] = a_w2[h];
+  __syncthreads();
+  for (int t = tid; t < NV * CPB_BJ; t += 256) {
+    const int k = t / CPB_BJ, jj = t % CPB_BJ, jo = blockIdx.x * CPB_BJ + jj;
+    if (k >= 3 + heads) continue;
+    float v = 0.f;
+#pragma unroll
+    for (int g = 0; g < CPB_BG; ++g) v += red[(g * NV + k) * CPB_BJ + jj];
+    if (k == 0) dw0[2 * jo] += v;
+    else if (k == 1) dw0[2 * jo + 1] += v;
+    else if (k == 2) db0[jo] += v;
+    else dw2[(k - 3) * 512 + jo] += v;
+  }
 }
 extern "C" int scot_cpb_fwd_batched(const float* params, const int* desc, int nlayers, int max_ws, const float* coords_base,
                                     float* tables, float* zbuf, hipStream_t s) {
@@ -1045,10 +1066,16 @@ extern "C" int scot_cpb_fwd_batched(const float* params, const int* desc, int nl
   hipLaunchKernelGGL(cpb_fwd_batched_kernel, dim3(TS, nlayers), dim3(256), 0, s, params, desc, coords_base, tables, zbuf);
   return scot_check_launch();
 }
-extern "C" int scot_cpb_bwd_batched(const float* params, const int* desc, int first, int count, const float* coords_base,
-                                    const float* zbuf, const float* dtables, float* grads, hipStream_t s) {
-  if (count <= 0) return SCOT_ERR_SHAPE;
-  hipLaunchKernelGGL(cpb_bwd_batched_kernel, dim3(512 / CPB_JB, count), dim3(256), 0, s, params, desc, first, coords_base, zbuf,
+extern "C" int scot_cpb_bwd_batched(const float* params, const int* desc, int first, int count, int max_ws, int max_heads,
+                                    const float* coords_base, const float* zbuf, const float* dtables, float* grads, hipStream_t s) {
+  if (count <= 0 || max_ws <= 0 || max_heads <= 0 || max_heads > 24) return SCOT_ERR_SHAPE;
+  const int TS = (2 * max_ws - 1) * (2 * max_ws - 1);
+  size_t sh = (size_t)TS * (max_heads + 2) * sizeof(float);            // dz + coordinates of the largest layer of the range
+  const size_t red = (size_t)CPB_BG * 27 * CPB_BJ * sizeof(float);     // ... reused by the partial sums
+  if (sh < red) sh = red;
+  if (sh > 160 * 1024) return SCOT_ERR_UNSUPPORTED;
+  if (sh > 64 * 1024) (void)hipFuncSetAttribute((const void*)cpb_bwd_batched_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh);
+  hipLaunchKernelGGL(cpb_bwd_batched_kernel, dim3(512 / CPB_BJ, count), dim3(256), sh, s, params, desc, first, coords_base, zbuf,
                      dtables, grads);
   return scot_check_launch();
 }

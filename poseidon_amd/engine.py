@@ -203,7 +203,8 @@ class ScOTEngine:
         parameter gradients): ~100 us per call that nothing downstream waits for -> side stream."""
         if blocks:
             first, n = self.cpb_index[blocks[0].prefix], len(blocks)
-            self.off_critical_path(lambda: ops.cpb_bwd_batched(self.arena.data, self.cpb_desc, first, n, self.cpb_coords, self.cpb_z,
+            mw, mh = max(b.window_shift()[0] for b in blocks), max(b.heads for b in blocks)
+            self.off_critical_path(lambda: ops.cpb_bwd_batched(self.arena.data, self.cpb_desc, first, n, mw, mh, self.cpb_coords, self.cpb_z,
                                                                self.cpb_dtables, self.arena.grad))
             self.flush_side()
 

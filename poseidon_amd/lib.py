@@ -36,7 +36,7 @@ PROTOTYPES = {
     "scot_cpb_fwd": [P, P, P, P, P, P, I, I, P],
     "scot_cpb_bwd": [P, P, P, P, P, P, P, P, P, I, I, P],
     "scot_cpb_fwd_batched": [P, P, I, I, P, P, P, P],
-    "scot_cpb_bwd_batched": [P, P, I, I, P, P, P, P, P],
+    "scot_cpb_bwd_batched": [P, P, I, I, I, I, P, P, P, P, P],
     "scot_cln_fwd": [P, I, P, I, P, I, P, I, P, P, P, P, P, P, P, I, I, I, F, P, P],
     "scot_mlp_block_fwd": [P, P, P, P, P, P, P, P, P, P, P, P, P, P, P, P, P, P, P, I, I, I, I, F, P],
     "scot_mlp_block_bwd": [P, P, P, P, P, P, P, P, P, P, P, P, P, P, P, P, P, P, I, I, I, I, P],

@@ -249,9 +249,9 @@ def cpb_fwd_batched(params, desc, nlayers, max_ws, coords, tables, zbuf):
                "scot_cpb_fwd_batched")
 
 
-def cpb_bwd_batched(params, desc, first, count, coords, zbuf, dtables, grads):
-    _lib.check(L().scot_cpb_bwd_batched(ptr(params), ptr(desc), first, count, ptr(coords), ptr(zbuf), ptr(dtables), ptr(grads),
-                                        stream()), "scot_cpb_bwd_batched")
+def cpb_bwd_batched(params, desc, first, count, max_ws, max_heads, coords, zbuf, dtables, grads):
+    _lib.check(L().scot_cpb_bwd_batched(ptr(params), ptr(desc), first, count, max_ws, max_heads, ptr(coords), ptr(zbuf), ptr(dtables),
+                                        ptr(grads), stream()), "scot_cpb_bwd_batched")
 
 
 def cln_fwd(x, resid, out, mean, rstd, time, gw_w, gw_b, bw_w, bw_b, rows, rows_per_sample, C, eps, out2=None, sample_scale=None):

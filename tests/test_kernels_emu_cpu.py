@@ -234,6 +234,10 @@ def test_spectral_resize_native(emu, s, t):
     assert rel(x.grad, xr.grad) < 2e-6
 
 
+def test_cpb_batched_layers(gpu_test_bodies):
+    gpu_test_bodies.test_cpb_batched_layers()
+
+
 def test_transposed_weight_copies(gpu_test_bodies):
     gpu_test_bodies.test_transpose_cast_and_dgrad_nt()
 

@@ -644,6 +644,53 @@ def test_cpb(ws, heads):
         assert rel(a, b.grad) < 1e-4
 
 
+def test_cpb_batched_layers():
+    """scot_cpb_fwd_batched / scot_cpb_bwd_batched (all layers of a range in one launch; the backward stages a layer's table-gradient
+    tile once per workgroup and owns its hidden units' gradients) against fp64 autograd of HF:376-378, 418-428 per layer, mixed window
+    sizes and head counts, `+=` into gradients that already hold values."""
+    layers = [(16, 3), (16, 6), (8, 12), (4, 24), (7, 2)]
+    coords, coff, cur = [], {}, 0
+    for ws in sorted({w for w, _ in layers}):
+        r = torch.arange(-(ws - 1), ws, dtype=torch.float32)
+        tab = torch.stack(torch.meshgrid(r, r, indexing="ij"), -1) / max(ws - 1, 1) * 8
+        c = (torch.sign(tab) * torch.log2(tab.abs() + 1) / 3).reshape(-1)
+        coff[ws] = cur
+        cur += c.numel()
+        coords.append(c)
+    coords = torch.cat(coords).to(DEV)
+    desc, off, toff = [], 0, 0
+    for ws, heads in layers:
+        ts = (2 * ws - 1) ** 2
+        desc += [off, off + 1024, off + 1536, coff[ws], ws, heads, toff, toff]
+        off += 1536 + heads * 512
+        toff += heads * ts
+    params = rnd(off, scale=0.3)
+    dtab = rnd(toff, seed=5)
+    tables, z = torch.empty(toff, device=DEV), torch.empty(toff, device=DEV)
+    grads = rnd(off, seed=9, scale=0.1)
+    g0 = grads.clone()
+    d = torch.tensor(desc, dtype=torch.int32).to(DEV)
+    ops.cpb_fwd_batched(params, d, len(layers), 16, coords, tables, z)
+    ops.cpb_bwd_batched(params, d, 1, len(layers) - 1, 16, 24, coords, z, dtab, grads)       # layers 1.. of the list
+    torch.cuda.synchronize()
+    assert torch.equal(grads[:desc[8]], g0[:desc[8]])                                          # layer 0 is outside the range
+    for li, (ws, heads) in enumerate(layers):
+        o, ts = desc[8 * li], (2 * ws - 1) ** 2
+        w0 = params[o:o + 1024].view(512, 2).double().requires_grad_(True)
+        b0 = params[o + 1024:o + 1536].double().requires_grad_(True)
+        w2 = params[o + 1536:o + 1536 + heads * 512].view(heads, 512).double().requires_grad_(True)
+        cs = coords[coff[ws]:coff[ws] + 2 * ts].view(ts, 2).double()
+        ref = 16 * torch.sigmoid(torch.relu(cs @ w0.t() + b0) @ w2.t()).t()
+        t0 = desc[8 * li + 6]
+        assert rel(tables[t0:t0 + heads * ts].view(heads, ts), ref.detach()) < 1e-5
+        if li == 0:
+            continue
+        ref.backward(dtab[t0:t0 + heads * ts].view(heads, ts).double())
+        got = (grads - g0)[o:o + 1536 + heads * 512]
+        want = torch.cat([w0.grad.reshape(-1), b0.grad, w2.grad.reshape(-1)])
+        assert rel(got, want) < 1e-4, (ws, heads)
+
+
 # ----------------------------------------------------------------------------------------------- bf16x3 GEMM
 @pytest.mark.parametrize("layout,M,N,K", [(ops.NT, 4096, 288, 96), (ops.NT, 1024, 96, 384), (ops.NN, 2048, 96, 384), (ops.NN, 1000, 384, 96),
                                           (ops.TN, 384, 96, 8192), (ops.TN, 96, 288, 4100 // 4 * 4), (ops.NT, 300, 72, 40)])
