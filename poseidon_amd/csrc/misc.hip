@@ -450,20 +450,52 @@ __global__ void dwconv7_kernel(const void* x, int x_dt, const float* w, const fl
 // (channel-contiguous: every LDS access is conflict-free and every HBM access is a full 128-byte line); each thread produces
 // a row of 8 outputs for one channel with its 49 weights in registers.
 constexpr int DW_T = 8, DW_H = DW_T + 6, DW_C = 32;
-__global__ __launch_bounds__(256) void dwconv7_tiled_kernel(const void* x, int x_dt, const float* w, const float* bias, void* y, int y_dt,
+template <typename T> struct DwVec4 { T v[4]; };
+// The element type of x is a template parameter and every pass of the tile load has a constant trip count: all loads of the tile go
+// out before the first LDS store (the rolled loop the compiler made of `for (p = ty; p < 196; p += 8)` — "loop not unrolled" — was
+// 25 dependent global round trips per workgroup).  VEC (C % 4 == 0): four consecutive channels per lane, 32 positions per pass: 7
+// loads of 16 / 8 bytes per thread instead of 25 of 4 / 2.
+template <typename TX, bool VEC>
+__global__ __launch_bounds__(256) void dwconv7_tiled_kernel(const TX* __restrict__ x, const float* w, const float* bias, void* y, int y_dt,
                                                             int B, int H, int W, int C, int flip, int tiles_x) {
-  __shared__ float tile[DW_H * DW_H * DW_C];
+  __shared__ __attribute__((aligned(16))) float tile[DW_H * DW_H * DW_C];
   const int c = blockIdx.y * DW_C + (threadIdx.x & 31), ty = threadIdx.x >> 5, b = blockIdx.z;
   const int y0 = (blockIdx.x / tiles_x) * DW_T, x0 = (blockIdx.x % tiles_x) * DW_T;
   const bool cv = c < C;
-  // fully unrolled (25 passes): the loads of all passes go out before the first LDS store — rolled up, every pass was a
-  // dependent global round trip (≈40 us of latency per workgroup for 100 KB)
+  if constexpr (VEC) {
+    constexpr int NP = (DW_H * DW_H + 31) / 32;
+    const int lq = (threadIdx.x & 7) * 4, pr = threadIdx.x >> 3, cl = blockIdx.y * DW_C + lq;
+    const bool clv = cl < C;
+    DwVec4<TX> r[NP];
 #pragma unroll
-  for (int p = ty; p < DW_H * DW_H; p += 8) {
-    const int sy = y0 + p / DW_H - 3, sx = x0 + p % DW_H - 3;
-    float v = 0.f;
-    if (cv && sy >= 0 && sy < H && sx >= 0 && sx < W) v = ld1(x, x_dt, (((size_t)b * H + sy) * W + sx) * C + c);
-    tile[p * DW_C + (threadIdx.x & 31)] = v;
+    for (int i = 0; i < NP; ++i) {
+      const int p = pr + 32 * i;
+      const int sy = y0 + p / DW_H - 3, sx = x0 + p % DW_H - 3;
+      const bool ok = clv && p < DW_H * DW_H && sy >= 0 && sy < H && sx >= 0 && sx < W;
+      const DwVec4<TX> v = *(const DwVec4<TX>*)(x + (((size_t)b * H + min(max(sy, 0), H - 1)) * W + min(max(sx, 0), W - 1)) * C + (clv ? cl : 0));
+      r[i] = ok ? v : DwVec4<TX>{};
+    }
+#pragma unroll
+    for (int i = 0; i < NP; ++i) {
+      const int p = pr + 32 * i;
+      if (p < DW_H * DW_H) *(float4*)(tile + p * DW_C + lq) = make_float4(from_ct(r[i].v[0]), from_ct(r[i].v[1]), from_ct(r[i].v[2]), from_ct(r[i].v[3]));
+    }
+  } else {
+    constexpr int NP = (DW_H * DW_H + 7) / 8;
+    TX r[NP];
+#pragma unroll
+    for (int i = 0; i < NP; ++i) {
+      const int p = ty + 8 * i;
+      const int sy = y0 + p / DW_H - 3, sx = x0 + p % DW_H - 3;
+      const bool ok = cv && p < DW_H * DW_H && sy >= 0 && sy < H && sx >= 0 && sx < W;
+      const TX v = x[(((size_t)b * H + min(max(sy, 0), H - 1)) * W + min(max(sx, 0), W - 1)) * C + (cv ? c : 0)];
+      r[i] = ok ? v : TX(0);
+    }
+#pragma unroll
+    for (int i = 0; i < NP; ++i) {
+      const int p = ty + 8 * i;
+      if (p < DW_H * DW_H) tile[p * DW_C + (threadIdx.x & 31)] = from_ct(r[i]);
+    }
   }
   float wr[49];
 #pragma unroll
@@ -499,7 +531,6 @@ __global__ __launch_bounds__(256) void dwconv7_tiled_kernel(const void* x, int x
 // the three 34 — the kernel waits for its 2- / 4-byte loads (a 14 x 14 halo per 8 x 8 outputs: every input is fetched three times).
 // VEC (C % 4 == 0): a lane fetches FOUR consecutive channels of a position (16 / 8 bytes), 32 positions per pass of the workgroup:
 // 9 wide loads per thread and tile instead of 33 narrow ones.
-template <typename T> struct DwVec4 { T v[4]; };
 template <typename TX, typename TG, bool VEC>
 __global__ __launch_bounds__(256) void dwconv7_wgrad_tiled_kernel(const TG* __restrict__ dy, const TX* __restrict__ x, float* dw, float* db,
                                                                   int B, int H, int W, int C) {
@@ -601,8 +632,12 @@ extern "C" int scot_dwconv7(const void* x, int x_dt, const float* w, const float
   const size_t n = (size_t)B * H * W * C;
   if (n == 0) return SCOT_ERR_SHAPE;
   const int tx = (W + DW_T - 1) / DW_T, ty = (H + DW_T - 1) / DW_T;
-  hipLaunchKernelGGL(dwconv7_tiled_kernel, dim3(tx * ty, (C + DW_C - 1) / DW_C, B), dim3(256), 0, s, x, x_dt, w, bias, y, y_dt, B, H, W,
-                     C, flip, tx);
+  const dim3 grid(tx * ty, (C + DW_C - 1) / DW_C, B), block(256);
+  const bool vec = C % 4 == 0 && (((uintptr_t)x) & 15) == 0;
+#define SCOT_DWF(TXT, V) hipLaunchKernelGGL((dwconv7_tiled_kernel<TXT, V>), grid, block, 0, s, (const TXT*)x, w, bias, y, y_dt, B, H, W, C, flip, tx)
+  if (x_dt == SCOT_F32) { if (vec) SCOT_DWF(float, true); else SCOT_DWF(float, false); }
+  else { if (vec) SCOT_DWF(bf16_t, true); else SCOT_DWF(bf16_t, false); }
+#undef SCOT_DWF
   return scot_check_launch();
 }
 // weight/bias grad: dw[c][ki][kj] += Σ dy[b,y,x,c]·x[b,y+ki-3,x+kj-3,c];  db[c] += Σ dy.   thread = channel, block = 64
