@@ -44,7 +44,7 @@ class _Token:
 
 
 class ScOTEngine:
-    def __init__(self, cfg, arena: Arena, compute: str = "bf16"):
+    def __init__(self, cfg, arena: Arena, compute: str = "fp16"):
         if compute not in ("fp16", "bf16", "fp32", "bf16x3"):
             raise ValueError("compute must be 'fp16', 'bf16', 'fp32' or 'bf16x3'")
         # "fp16" and "bf16" run the SAME kernels from two builds of the library (csrc/common.h: the format of the 16-bit operand

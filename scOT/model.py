@@ -270,6 +270,17 @@ class ScOT(nn.Module):
     def num_parameters(self):
         return sum(p.numel() for p in self.parameters())
 
+    def push_to_hub(self, repo_id: str, **kwargs):
+        """HF `PreTrainedModel.push_to_hub` (reference train.py:413): the checkpoint directory `save_pretrained` writes, uploaded with
+        huggingface_hub (needs network and credentials; nothing of it runs on the GPU path)."""
+        import tempfile
+        from huggingface_hub import HfApi
+        api = HfApi(token=kwargs.pop("token", None))
+        api.create_repo(repo_id, exist_ok=True, private=kwargs.pop("private", None))
+        with tempfile.TemporaryDirectory() as d:
+            self.save_pretrained(d, safe_serialization=kwargs.pop("safe_serialization", True))
+            return api.upload_folder(repo_id=repo_id, folder_path=d, commit_message=kwargs.pop("commit_message", "Upload model"))
+
     def save_pretrained(self, save_directory: str, safe_serialization: bool = True, **_):
         os.makedirs(save_directory, exist_ok=True)
         self.config.save_pretrained(save_directory)
@@ -285,8 +296,21 @@ class ScOT(nn.Module):
                         ignore_mismatched_sizes: bool = False, compute: Optional[str] = None, **kwargs):
         path = pretrained_model_name_or_path
         if not os.path.isdir(path):
-            raise FileNotFoundError(f"{path}: only local HF checkpoint directories are supported (no network here); "
-                                    "download `camlab-ethz/Poseidon-*` and pass the directory")
+            # a hub id (reference train.py:331-333: "camlab-ethz/Poseidon-B"): resolved through huggingface_hub — from its local cache
+            # first, from the network when there is one (`local_files_only` / `cache_dir` / `revision` / `token` are passed on)
+            try:
+                from huggingface_hub import snapshot_download
+                hub_kw = {k: kwargs[k] for k in ("cache_dir", "revision", "token", "local_files_only") if k in kwargs}
+                try:
+                    path = snapshot_download(path, allow_patterns=["*.json", "*.safetensors", "*.bin"], **{"local_files_only": True, **hub_kw})
+                except Exception:
+                    if hub_kw.get("local_files_only"):
+                        raise
+                    path = snapshot_download(path, allow_patterns=["*.json", "*.safetensors", "*.bin"], **hub_kw)
+            except Exception as e:
+                raise FileNotFoundError(f"{pretrained_model_name_or_path}: neither a checkpoint directory nor a hub repository that "
+                                        f"huggingface_hub can resolve here ({type(e).__name__}: {e}); download `camlab-ethz/Poseidon-*` "
+                                        "and pass the directory") from e
         if config is None:
             config = ScOTConfig.from_pretrained(path)
         model = cls(config, compute=compute)

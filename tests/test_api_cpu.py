@@ -153,3 +153,29 @@ def test_package_import_reserves_hardware_queues():
     code = "import os; os.environ['GPU_MAX_HW_QUEUES'] = '6'; import poseidon_amd; print(os.environ['GPU_MAX_HW_QUEUES'])"
     out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
     assert out.stdout.strip() == "6"
+
+
+def test_from_pretrained_resolves_hub_ids_through_the_local_cache(tmp_path, monkeypatch):
+    """`ScOT.from_pretrained("camlab-ethz/Poseidon-B")` (reference train.py:331-333): a hub id goes through huggingface_hub — its local
+    cache first; with no cache entry and no network the error names both options instead of computing anything."""
+    import huggingface_hub
+    from scOT.model import ScOT
+    cfg = ScOTConfig(image_size=16, patch_size=4, num_channels=2, num_out_channels=2, embed_dim=8, depths=[1], num_heads=[1],
+                     skip_connections=[0], window_size=4, mlp_ratio=2.0)
+    ckpt = tmp_path / "snap"
+    ScOT(cfg).save_pretrained(str(ckpt))
+    seen = {}
+
+    def fake_snapshot(repo_id, **kw):
+        seen.update(repo_id=repo_id, **kw)
+        return str(ckpt)
+    monkeypatch.setattr(huggingface_hub, "snapshot_download", fake_snapshot)
+    m = ScOT.from_pretrained("camlab-ethz/Poseidon-X")
+    assert seen["repo_id"] == "camlab-ethz/Poseidon-X" and seen["local_files_only"] is True
+    assert m.config.embed_dim == 8 and not m._load_report["missing"]
+
+    def no_network(repo_id, **kw):
+        raise OSError("offline")
+    monkeypatch.setattr(huggingface_hub, "snapshot_download", no_network)
+    with pytest.raises(FileNotFoundError, match="neither a checkpoint directory nor a hub repository"):
+        ScOT.from_pretrained("camlab-ethz/Poseidon-X")
