@@ -653,6 +653,8 @@ static int gemm_fast_impl(int layout, int compute, int M, int N, int K, const vo
     for (int i = 0; i < 4; ++i) { const char* e = getenv(names[i]); ov[i] = e ? atoi(e) : -1; }
   }
   int tile = ov[layout] >= 0 ? ov[layout] : (ov[3] >= 0 ? ov[3] : -1);
+  static int deep = -1;
+  if (deep < 0) { const char* e = getenv("SCOT_GEMM_DEEP"); deep = e ? atoi(e) : 1; }   // in step: 19.76 -> 19.59 ms (SCOT_GEMM_DEEP=0: off)
   if (tile < 0) {
     tile = 0;   // policy (see DESIGN.md §3 for the measurements behind it)
     // wgrad with a long token dimension (stages 0/1): 96x96 (cold-cache sweep: 25.6 vs 38.5 us at stage 1); with K <= 4096
@@ -660,6 +662,9 @@ static int gemm_fast_impl(int layout, int compute, int M, int N, int K, const vo
     if ((compute == SCOT_BF16 || x3) && layout == LAYOUT_TN && M % 96 == 0 && N % 96 == 0 && K >= 8192) tile = 4;
     else if ((compute == SCOT_BF16 || x3) && N == 96) tile = 2;   // one 64x96 column tile: the A operand streams once (64x64 would read it twice)
     else if (compute == SCOT_BF16 && layout != LAYOUT_TN && K <= 128) tile = 6;   // K = 96: BK = 32 halves LDS -> more workgroups/CU (-12 %)
+    // small grids walking a long contraction (stage 3: fc2 forward, fc1 / qkv data gradients — 192 workgroups x 36-48 K-tiles): four
+    // register sets of loads in flight instead of two (26.4 -> 22.4 / 24.5 -> 21.7 us alone; shorter contractions lose to the padded trip count)
+    else if (compute == SCOT_BF16 && layout != LAYOUT_TN && K >= 36 * 64 && (long)((M + 63) / 64) * ((N + 63) / 64) <= 512 && deep) tile = 8;
   }
   if (x3 && tile != 2 && tile != 4) tile = 0;                     // bf16x3 instantiates 64x64, 64x96, 96x96
   if (compute == SCOT_F32 && tile != 0 && tile != 3) tile = 0;    // fp32 instantiates 64x64 and 128x128 only
