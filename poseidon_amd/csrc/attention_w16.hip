@@ -269,6 +269,20 @@ __device__ __forceinline__ void row_frag(FragX<CT, X3> (&f)[(HD + 31) / 32], con
 }
 
 // ================================================================================================= forward
+// Which (window, head, half) a workgroup of the 1-D grid works on.  The heads of a window read interleaved 64-byte segments of the same
+// qkv / O / dO rows (two heads per 128-byte line) and the backward's two halves read the same rows again, so the `members` =
+// heads x halves workgroups of ONE window are placed back to back ON ONE XCD (workgroup L runs on XCD L % 8: observed dispatch order,
+// used for speed only): its L2 then serves the shared lines and the second half's re-read.  With (window, head, half) as grid
+// (x, y, z) those workgroups were nwin apart in dispatch order and every line came from HBM two to four times (PMC, round 3: 152 MB
+// fetched per stage-0 backward launch for 63 MB of inputs).
+__device__ __forceinline__ void w16_block(const AttnArgs& p, int halves, int& win, int& h, int& half) {
+  const int L = blockIdx.x, members = p.heads * halves, nwin = (int)gridDim.x / members;
+  int m;
+  if ((nwin & 7) == 0) { const int j = L >> 3; win = (j / members) * 8 + (L & 7); m = j % members; }
+  else { win = L / members; m = L % members; }
+  h = m % p.heads; half = m / p.heads;
+}
+
 template <typename CT, int HD, bool SHIFTED, bool X3>
 __global__ __launch_bounds__(256, 2) void attn16_fwd_kernel(AttnArgs p) {
   using MT = typename std::conditional<X3, float, CT>::type;   // element type of q/k/v/out in memory
@@ -278,7 +292,8 @@ __global__ __launch_bounds__(256, 2) void attn16_fwd_kernel(AttnArgs p) {
   CT* Vs = Kn + TE;
   float* tab2 = (float*)(Vs + TE);
 
-  const int win = blockIdx.x, h = blockIdx.y;
+  int win, h, half_;
+  w16_block(p, 1, win, h, half_);
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int ld = 3 * p.C, g = lane >> 4, lc = lane & 15;
   const W16Tok tokf(p, win);
@@ -379,7 +394,8 @@ __device__ __forceinline__ void attn16_bwd_dq_body(const AttnArgs& p) {
   double* dtab = (double*)(tab2 + W16::TSP);   // ds_add_f64 is full rate on gfx950, ds_add_f32 is not (see attention.hip)
   float* red = (float*)(dtab + W16::TSP);      // [waves <= 8]
 
-  const int win = blockIdx.x, h = blockIdx.y;
+  int win, h, half_;
+  w16_block(p, 2, win, h, half_);
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int ld = 3 * p.C, g = lane >> 4, lc = lane & 15;
   const W16Tok tokf(p, win);
@@ -486,7 +502,7 @@ __device__ __forceinline__ void attn16_bwd_dq_body(const AttnArgs& p) {
   // (every (window, head) workgroup of a head flushes the same 961 addresses: start each one somewhere else so that concurrent
   // workgroups do not queue up on the same L2 atomic unit in lockstep)
   for (int i = tid; i < W16::TS; i += blockDim.x) {
-    int k = i + (int)(blockIdx.x % 31) * 31;
+    int k = i + (win % 31) * 31;
     k = k >= W16::TS ? k - W16::TS : k;
     atomicAdd(&p.dbias_table[h * W16::TS + k], (float)dtab[k]);
   }
@@ -510,7 +526,8 @@ __device__ __forceinline__ void attn16_bwd_dkv_body(const AttnArgs& p) {
   float* nlse2 = tab2 + W16::TSP;   // [NP]  -lse * log2 e
   float* delta = nlse2 + NP;        // [NP]
 
-  const int win = blockIdx.x, h = blockIdx.y;
+  int win, h, half_;
+  w16_block(p, 2, win, h, half_);
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int ld = 3 * p.C, g = lane >> 4, lc = lane & 15;
 
@@ -612,13 +629,17 @@ __device__ __forceinline__ void attn16_bwd_dkv_body(const AttnArgs& p) {
 // the dK/dV workgroups fill the CUs as the dQ ones drain.
 template <typename CT, int HD, bool SHIFTED, bool X3>
 __global__ __launch_bounds__(256, 2) void attn16_bwd_kernel(AttnArgs p) {
-  if (blockIdx.z == 0) attn16_bwd_dq_body<CT, HD, SHIFTED, X3>(p);
+  int win, h, half;
+  w16_block(p, 2, win, h, half);
+  if (half == 0) attn16_bwd_dq_body<CT, HD, SHIFTED, X3>(p);
   else attn16_bwd_dkv_body<CT, HD, SHIFTED, X3>(p);
 }
 // the same bodies with 8 waves per (window, head): two query / key rows per wave instead of four (half the serial chain per workgroup)
 template <typename CT, int HD, bool SHIFTED, bool X3>
 __global__ __launch_bounds__(512) void attn16_bwd_kernel_w8(AttnArgs p) {
-  if (blockIdx.z == 0) attn16_bwd_dq_body<CT, HD, SHIFTED, X3>(p);
+  int win, h, half;
+  w16_block(p, 2, win, h, half);
+  if (half == 0) attn16_bwd_dq_body<CT, HD, SHIFTED, X3>(p);
   else attn16_bwd_dkv_body<CT, HD, SHIFTED, X3>(p);
 }
 
@@ -630,7 +651,7 @@ static int launch_w16(const AttnArgs& a, int nwin, bool bwd, hipStream_t s) {
   const size_t sh_fwd = tiles + W16::TSP * sizeof(float);
   const size_t sh_dq = tiles + W16::TSP * (sizeof(float) + sizeof(double)) + 8 * sizeof(float);
   const size_t sh_dkv = tiles + (W16::TSP + 2 * NP) * sizeof(float);
-  dim3 grid(nwin, a.heads), block(256);
+  dim3 grid(nwin * a.heads), block(256);       // 1-D: w16_block() maps a workgroup to its (window, head[, half])
   if (!bwd) {
     if (sh_fwd > 160 * 1024) return SCOT_ERR_UNSUPPORTED;
     if (sh_fwd > 64 * 1024) (void)hipFuncSetAttribute((const void*)attn16_fwd_kernel<CT, HD, SHIFTED, X3>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh_fwd);
@@ -643,10 +664,10 @@ static int launch_w16(const AttnArgs& a, int nwin, bool bwd, hipStream_t s) {
     if (w8 < 0) { const char* e = getenv("SCOT_ATTN16_BWD_WAVES"); w8 = (e && atoi(e) == 8) ? 1 : 0; }
     if (w8 && !X3 && sizeof(CT) == 2) {
       if (sh_b > 64 * 1024) (void)hipFuncSetAttribute((const void*)attn16_bwd_kernel_w8<CT, HD, SHIFTED, X3>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh_b);
-      hipLaunchKernelGGL((attn16_bwd_kernel_w8<CT, HD, SHIFTED, X3>), dim3(nwin, a.heads, 2), dim3(512), sh_b, s, a);
+      hipLaunchKernelGGL((attn16_bwd_kernel_w8<CT, HD, SHIFTED, X3>), dim3(nwin * a.heads * 2), dim3(512), sh_b, s, a);
       return scot_check_launch();
     }
-    hipLaunchKernelGGL((attn16_bwd_kernel<CT, HD, SHIFTED, X3>), dim3(nwin, a.heads, 2), block, sh_b, s, a);
+    hipLaunchKernelGGL((attn16_bwd_kernel<CT, HD, SHIFTED, X3>), dim3(nwin * a.heads * 2), block, sh_b, s, a);
   }
   return scot_check_launch();
 }
