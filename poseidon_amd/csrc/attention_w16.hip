@@ -634,15 +634,6 @@ __global__ __launch_bounds__(256, 2) void attn16_bwd_kernel(AttnArgs p) {
   if (half == 0) attn16_bwd_dq_body<CT, HD, SHIFTED, X3>(p);
   else attn16_bwd_dkv_body<CT, HD, SHIFTED, X3>(p);
 }
-// the same bodies with 8 waves per (window, head): two query / key rows per wave instead of four (half the serial chain per workgroup)
-template <typename CT, int HD, bool SHIFTED, bool X3>
-__global__ __launch_bounds__(512) void attn16_bwd_kernel_w8(AttnArgs p) {
-  int win, h, half;
-  w16_block(p, 2, win, h, half);
-  if (half == 0) attn16_bwd_dq_body<CT, HD, SHIFTED, X3>(p);
-  else attn16_bwd_dkv_body<CT, HD, SHIFTED, X3>(p);
-}
-
 // ================================================================================================= host side
 template <typename CT, int HD, bool SHIFTED, bool X3>
 static int launch_w16(const AttnArgs& a, int nwin, bool bwd, hipStream_t s) {
@@ -660,13 +651,6 @@ static int launch_w16(const AttnArgs& a, int nwin, bool bwd, hipStream_t s) {
     const size_t sh_b = sh_dq > sh_dkv ? sh_dq : sh_dkv;
     if (sh_b > 160 * 1024) return SCOT_ERR_UNSUPPORTED;
     if (sh_b > 64 * 1024) (void)hipFuncSetAttribute((const void*)attn16_bwd_kernel<CT, HD, SHIFTED, X3>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh_b);
-    static int w8 = -1;
-    if (w8 < 0) { const char* e = getenv("SCOT_ATTN16_BWD_WAVES"); w8 = (e && atoi(e) == 8) ? 1 : 0; }
-    if (w8 && !X3 && sizeof(CT) == 2) {
-      if (sh_b > 64 * 1024) (void)hipFuncSetAttribute((const void*)attn16_bwd_kernel_w8<CT, HD, SHIFTED, X3>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh_b);
-      hipLaunchKernelGGL((attn16_bwd_kernel_w8<CT, HD, SHIFTED, X3>), dim3(nwin * a.heads * 2), dim3(512), sh_b, s, a);
-      return scot_check_launch();
-    }
     hipLaunchKernelGGL((attn16_bwd_kernel<CT, HD, SHIFTED, X3>), dim3(nwin * a.heads * 2), block, sh_b, s, a);
   }
   return scot_check_launch();

@@ -514,42 +514,6 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restr
   }
 }
 
-// NT/NN split-K: C = epilogue(Σ_z ws[z])  — same epilogue as the GEMM kernels (bias, column scale, gelu' / aux, residual, dual GELU)
-template <int ZL>
-__global__ __launch_bounds__(256) void splitk_epilogue_kernel(FastArgs p, int nsplit) {
-  const size_t n8 = (size_t)p.M * p.N / 8;
-  const int zl = threadIdx.x % ZL;
-  for (size_t i = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) / ZL; i < n8; i += (size_t)gridDim.x * blockDim.x / ZL) {
-    const size_t e = i * 8;
-    const int m = e / p.N, n = e % p.N;
-    float v[8], t[8];
-    splitk_sum<ZL>(v, p.ws, e, (size_t)p.M * p.N, nsplit, zl);
-    if (zl != 0) continue;
-#pragma unroll
-    for (int j = 0; j < 8; ++j) v[j] = (v[j] + (p.bias ? p.bias[n + j] : 0.f)) * (p.colscale ? p.colscale[n + j] : 1.f);
-    if (p.aux_gelu_grad) {
-      ld8(p.aux, p.aux_dt, (size_t)m * p.ldaux + n, t);
-#pragma unroll
-      for (int j = 0; j < 8; ++j) v[j] *= p.aux_mul ? t[j] : gelu_grad_f(t[j]);
-    }
-    if (p.resid) {
-      ld8(p.resid, p.res_dt, (size_t)m * p.ldres + n, t);
-#pragma unroll
-      for (int j = 0; j < 8; ++j) v[j] += t[j];
-    }
-    const size_t ci = (size_t)m * p.ldc + n;
-    if (p.C2) {
-      float gv[8], gd[8];
-#pragma unroll
-      for (int j = 0; j < 8; ++j) { float cdf, ee; gelu_terms(v[j], cdf, ee); gv[j] = v[j] * cdf; gd[j] = cdf + v[j] * 0.3989422804014327f * ee; }
-      st8(p.C, p.c_dt, ci, gv);
-      if (p.C2 != p.C) st8(p.C2, p.c_dt, ci, gd);
-    } else {
-      st8(p.C, p.c_dt, ci, v);
-    }
-  }
-}
-
 template <typename CT, int BM, int BN, int WM, int WN, int BKT = FT<CT>::BK, int NSET = 2>
 static int flaunch_layout(const FastArgs& a, int layout, int nsplit, hipStream_t s) {
   dim3 grid((a.N + BN - 1) / BN, (a.M + BM - 1) / BM, nsplit), block(256);
@@ -702,27 +666,8 @@ static int gemm_fast_impl(int layout, int compute, int M, int N, int K, const vo
       if (resid != nullptr) return SCOT_ERR_UNSUPPORTED;
       a.resid = C; a.res_dt = c_dt; a.ldres = ldc;
     }
-    // small grids with a long contraction (stage-3 fc2 / dgrad: 192 workgroups x 48 K-tiles = one latency-bound workgroup
-    // per CU): split K over more workgroups, partial sums through the workspace, epilogue in the reduce pass.
-    // Measured: pays from K >= 1536 (24 K-tiles); at K = 768 the extra pass costs more than it hides.
-    static int nt_split = -1;
-    if (nt_split < 0) { const char* e = getenv("SCOT_GEMM_NT_SPLIT"); nt_split = e ? atoi(e) : 0; }
-    static int split_nkt = -1;
-    if (split_nkt < 0) { const char* e = getenv("SCOT_GEMM_NT_SPLIT_NKT"); split_nkt = e ? atoi(e) : 24; }
-    if (nt_split && !colsum_out && workspace && (((uintptr_t)workspace & 31) == 0) && tiles < 512 && nkt >= split_nkt) {
-      long want = (1024 + tiles - 1) / tiles;
-      long maxs = nkt / 4;
-      long wsmax = (long)(ws_bytes / ((size_t)M * N * sizeof(float)));
-      long ns = want < maxs ? want : maxs;
-      if (ns > wsmax) ns = wsmax;
-      if (ns >= 2) {
-        int per = (int)((K + ns - 1) / ns);
-        per = ((per + bk - 1) / bk) * bk;
-        a.ksplit = per;
-        nsplit = (K + per - 1) / per;
-        a.ws = (float*)workspace;
-      }
-    }
+    // (NT / NN products are never split along K: partial sums through the workspace + an epilogue pass were measured slower in step
+    // in rounds 2 and 3 for every deep-stage shape; the long-K small-grid case takes the four-register-set pipeline instead, above)
   }
   if (query) {
     *query = a.ws ? (size_t)nsplit * M * N * sizeof(float) : 0;
@@ -735,16 +680,10 @@ static int gemm_fast_impl(int layout, int compute, int M, int N, int K, const vo
     const int zl = (nsplit >= 64 && layout == LAYOUT_TN) ? 32 : nsplit >= 16 ? 8 : nsplit >= 4 ? 4 : 1;
     size_t blocks = (n8 * zl + 255) / 256; if (blocks > 4096) blocks = 4096;
     const dim3 g((unsigned)blocks), b(256);
-    if (layout == LAYOUT_TN) {
-      if (zl == 32) hipLaunchKernelGGL(splitk_reduce_kernel<32>, g, b, 0, stream, a.ws, (float*)C, M, N, ldc, nsplit);
-      else if (zl == 8) hipLaunchKernelGGL(splitk_reduce_kernel<8>, g, b, 0, stream, a.ws, (float*)C, M, N, ldc, nsplit);
-      else if (zl == 4) hipLaunchKernelGGL(splitk_reduce_kernel<4>, g, b, 0, stream, a.ws, (float*)C, M, N, ldc, nsplit);
-      else hipLaunchKernelGGL(splitk_reduce_kernel<1>, g, b, 0, stream, a.ws, (float*)C, M, N, ldc, nsplit);
-    } else {
-      if (zl == 8) hipLaunchKernelGGL(splitk_epilogue_kernel<8>, g, b, 0, stream, a, nsplit);
-      else if (zl == 4) hipLaunchKernelGGL(splitk_epilogue_kernel<4>, g, b, 0, stream, a, nsplit);
-      else hipLaunchKernelGGL(splitk_epilogue_kernel<1>, g, b, 0, stream, a, nsplit);
-    }
+    if (zl == 32) hipLaunchKernelGGL(splitk_reduce_kernel<32>, g, b, 0, stream, a.ws, (float*)C, M, N, ldc, nsplit);      // (only TN products split K)
+    else if (zl == 8) hipLaunchKernelGGL(splitk_reduce_kernel<8>, g, b, 0, stream, a.ws, (float*)C, M, N, ldc, nsplit);
+    else if (zl == 4) hipLaunchKernelGGL(splitk_reduce_kernel<4>, g, b, 0, stream, a.ws, (float*)C, M, N, ldc, nsplit);
+    else hipLaunchKernelGGL(splitk_reduce_kernel<1>, g, b, 0, stream, a.ws, (float*)C, M, N, ldc, nsplit);
     rc = scot_check_launch();
   }
   return rc;
@@ -842,12 +781,9 @@ static int wgrad_group_impl(int compute, int n, int K, const void* const* dY, co
   static int want_wgs = -1;
   if (want_wgs < 0) { const char* e = getenv("SCOT_WGRAD_GROUP_WGS"); want_wgs = e ? atoi(e) : 256; }   // in-step optimum: 192-256 (448 filled the chip better alone and cost the chain 0.1 ms; 128 makes the side stream the wall)
   const long nkt = (K + bk - 1) / bk;
-  // mid-sized groups (stage 2: 432 tiles x 64 K-tiles = 1.7 workgroups per CU walking a long serial K loop): two K slices
-  // (SCOT_WGRAD_GROUP_MID_WGS=864) run 66 instead of 85 us alone — and cost the step 0.2 ms: beside the main chain a wider
-  // side-stream kernel takes more from the chain's latency-bound kernels than it gains.  Off by default.
-  static int mid_wgs = -1;
-  if (mid_wgs < 0) { const char* e = getenv("SCOT_WGRAD_GROUP_MID_WGS"); mid_wgs = e ? atoi(e) : 0; }
-  long nsplit = tiles >= 1024 ? 1 : tiles >= 256 ? (mid_wgs + tiles / 2) / tiles : (want_wgs + tiles - 1) / tiles;
+  // (groups with >= 256 tiles — the deep stages — are never split: two K slices for the 432-tile stage-2 group run 66 instead of 85 us
+  // alone and cost the step 0.2 ms; the eight-wave workgroups below halve its serial K loop without a second pass)
+  long nsplit = tiles >= 256 ? 1 : (want_wgs + tiles - 1) / tiles;
   if (nsplit < 1) nsplit = 1;
   const long maxsplit = nkt / 8 > 0 ? nkt / 8 : 1;
   if (nsplit > maxsplit) nsplit = maxsplit;
@@ -869,14 +805,11 @@ static int wgrad_group_impl(int compute, int n, int K, const void* const* dY, co
     *query = g.nsplit > 1 ? (size_t)g.nsplit * plane * sizeof(float) : 0;
     return SCOT_OK;
   }
-  static int nset = -1;
-  if (nset < 0) { const char* e = getenv("SCOT_WGRAD_GROUP_NSET"); nset = e ? atoi(e) : 2; }
   // unsplit 64x64-tile groups (the deep stages: 432 / 1728 tiles walking 64 / 16 K-tiles each): two K groups per workgroup
   static int kg_env = -1;
   if (kg_env < 0) { const char* e = getenv("SCOT_WGRAD_GROUP_KG"); kg_env = e ? atoi(e) : 2; }   // (measured: stage 2 84.5 -> 62.5 us alone, step -0.12 ms; SCOT_WGRAD_GROUP_KG=1: four waves)
   int rc;
   if (!t96 && g.nsplit == 1 && kg_env == 2 && nkt >= 4) rc = launch_wgrad_group<64, 64, 64, 2, 2>(g, stream);
-  else if (nset == 4) rc = t96 ? launch_wgrad_group<96, 96, 64, 4>(g, stream) : launch_wgrad_group<64, 64, 64, 4>(g, stream);
   else rc = t96 ? launch_wgrad_group<96, 96, 64, 2>(g, stream) : launch_wgrad_group<64, 64, 64, 2>(g, stream);
   if (rc == SCOT_OK && g.ws) {
     const size_t n8 = plane / 8;
