@@ -298,7 +298,7 @@ def main():
     loss_buf = torch.zeros((), device="cuda")
 
     def compute_step():
-        model.zero_grad()
+        model.zero_grad(overlap=True)      # as poseidon_amd.train.Trainer does: the gradient arena's fill runs beside the forward
         out = model(**kw)
         out.loss.backward()
         loss_buf.copy_(out.loss.detach())
@@ -415,7 +415,7 @@ def main():
     if not use_graph[0]:
         ev = [[torch.cuda.Event(enable_timing=True) for _ in range(3)] for _ in range(5)]
         for e in ev:
-            model.zero_grad()
+            model.zero_grad(overlap=True)
             e[0].record()
             out = model(**kw)
             e[1].record()

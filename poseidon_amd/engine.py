@@ -74,6 +74,7 @@ class ScOTEngine:
         # chain instead of in front of it (SCOT_SKIP_SIDE=0: in line)
         self.skip_side = os.environ.get("SCOT_SKIP_SIDE", "1") == "1"
         self.group_wgrads = os.environ.get("SCOT_GROUP_WGRAD", "1") == "1"
+        self.grad_fill_event = None       # ScOT.zero_grad(overlap=True): recorded behind the gradient arena's fill on the side stream
         self.cln_partial = os.environ.get("SCOT_CLN_PARTIAL", "1") == "1"     # small-row-count LN backward through partial sums (A/B switch)
         # the fused layer tail WITHOUT 4C-wide tensors in HBM (round 3): the forward stores neither gelu(u) nor gelu'(u) and keeps the
         # pre-norm rows as 16-bit, the backward recomputes gelu'(u) and does not store du, scot_wgrad_mlp recomputes both for the
@@ -473,9 +474,13 @@ class ScOTEngine:
         self._keep.append(tensors)
         self._pending.append(fn)
 
-    def _run_side(self, fns):
+    def side_stream(self):
         if self.side is None:
             self.side = torch.cuda.Stream(device=self.device)
+        return self.side
+
+    def _run_side(self, fns):
+        self.side_stream()
         ev, cur, side = torch.cuda.Event(), torch.cuda.current_stream(), self.side
 
         def fork():
@@ -1445,6 +1450,11 @@ class ScOTEngine:
         cfg, cm, adt = self.cfg, self.compute, self.adt
         B, time = tape["B"], tape["time"]
         hd = tape["head"]
+        def fill_done():        # ScOT.zero_grad(overlap=True): the arena's fill runs on the side stream beside the forward
+            ev, self.grad_fill_event = self.grad_fill_event, None
+            if ev is not None:
+                torch.cuda.current_stream().wait_event(ev)
+        self.tdo_dynamic(fill_done)
         self.tdo(self.cpb_dtables.zero_)
         self.mark("bwd head")
         _, Cout, H, W = hd["shape"]

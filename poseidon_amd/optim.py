@@ -141,8 +141,8 @@ class FusedAdamW(torch.optim.Optimizer):
         eng = getattr(self.model, "_engine", None)
         return eng is not None and eng.grad_overflow is not None
 
-    def zero_grad(self, set_to_none: bool = False):
-        self.model.zero_grad(set_to_none=False)   # one memset of the gradient arena; .grad stay views of it
+    def zero_grad(self, set_to_none: bool = False, overlap: bool = False):
+        self.model.zero_grad(set_to_none=False, overlap=overlap)   # one memset of the gradient arena; .grad stay views of it
 
     def state_dict(self) -> Dict:
         sd = super().state_dict()

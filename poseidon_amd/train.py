@@ -469,7 +469,10 @@ class Trainer:
                     self._reducer.allreduce()
                 opt.step()
                 sched.step()
-                opt.zero_grad()
+                if hasattr(opt, "loss_scale_value"):      # this library's FusedAdamW
+                    opt.zero_grad(overlap=True)      # the arena's fill runs beside the next forward (ScOT.zero_grad)
+                else:
+                    opt.zero_grad()
                 step += 1
                 st.update(global_step=step, epoch=epoch + (i + 1) / max(1, batches_per_epoch))
                 self._fire("on_step_end")

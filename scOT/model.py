@@ -400,9 +400,24 @@ class ScOT(nn.Module):
         """fn(model) is called right after the engine finished writing the gradient arena (used by the DP wrapper)."""
         self._grad_hooks.append(fn)
 
-    def zero_grad(self, set_to_none: bool = False):
+    def zero_grad(self, set_to_none: bool = False, overlap: bool = False):
+        """One fill of the gradient arena; `.grad` stay views of it.  overlap=True (the training loops of this library): the fill
+        is queued on the engine's weight-gradient stream behind everything the current stream has been given so far, and the next
+        backward's first gradient writer waits for it — the next FORWARD does not (it never touches gradients), so the 631 MB fill of
+        Poseidon-B runs beside it instead of in front of it.  Code that reads `.grad` on the current stream between this call and
+        the next backward must use the default (ordered on the current stream)."""
         if self._arena is not None:
-            self._arena.grad.zero_()
+            eng = self._engine
+            if overlap and eng is not None and eng.use_side and self._arena.grad.is_cuda:
+                cur, side = torch.cuda.current_stream(), eng.side_stream()
+                side.wait_stream(cur)
+                with torch.cuda.stream(side):
+                    self._arena.grad.zero_()
+                ev = torch.cuda.Event()
+                ev.record(side)
+                eng.grad_fill_event = ev
+            else:
+                self._arena.grad.zero_()
             self._engine.grads_are_zero = True
             if set_to_none:
                 for p in self._params:

@@ -856,3 +856,31 @@ def test_output_attentions_on_16x16_windows():
     for a in out.attentions:
         assert float((a.sum(-1) - 1).abs().max()) < 2e-2 and float(a.min()) >= 0
     assert rel_l2(out.output.detach().cpu().numpy(), f["output"]) < 1e-3
+
+
+def test_overlapped_gradient_fill_is_ordered_before_the_backward():
+    """ScOT.zero_grad(overlap=True): the arena's fill runs on the weight-gradient stream beside the next forward; the backward's
+    gradient writers (both streams) wait for it.  Same gradients as with the in-order fill, on direct, recorded and replayed steps,
+    starting from an arena full of garbage each time."""
+    cfg = ScOTConfig(image_size=32, patch_size=4, num_channels=4, num_out_channels=4, embed_dim=16, depths=[2, 2], num_heads=[1, 2],
+                     skip_connections=[1, 0], window_size=4, mlp_ratio=4.0, p=1, channel_slice_list_normalized_loss=[0, 1, 3, 4],
+                     drop_path_rate=0.0, use_conditioning=True)
+    sd = synth_state_dict(param_shapes(cfg), "trained")
+    pv, t, lab = synth_inputs(2, 4, 4, 32, "smooth")
+    pv, t, lab = pv.to(DEV), t.to(DEV), lab.to(DEV)
+    grads = {}
+    for overlap in (False, True):
+        model = ScOT(cfg, compute="fp32")
+        model.load_state_dict(sd)
+        model = model.to(DEV)
+        for step in range(4):
+            if model._arena is not None:
+                model._arena.grad.fill_(float("nan") if step % 2 else 7.0)      # what a forgotten fill would leave behind
+            model.zero_grad(overlap=overlap)
+            out = model(pixel_values=pv, time=t, labels=lab)
+            out.loss.backward()
+        torch.cuda.synchronize()
+        grads[overlap] = model._arena.grad.clone()
+    assert bool(torch.isfinite(grads[True]).all())
+    d = float((grads[True] - grads[False]).norm() / grads[False].norm())      # (not bit-equal: float atomics commit in any order)
+    assert d < 5e-6, d
