@@ -121,9 +121,21 @@ def _cpu_baseline_worker(model_tag, size, channels, budget_s):
         times.append(time.time() - t0)
     times.sort()
     med = times[len(times) // 2]
+    # ... and on ONE core: the same step on one sample, one torch thread, best of two
+    one = None
+    if cores > 1:
+        torch.set_num_threads(1)
+        pv, lab, tt = pv[:1], lab[:1], tt[:1]
+        t1 = []
+        for _ in range(2):
+            t0 = time.time()
+            step()
+            t1.append(time.time() - t0)
+        one = 1.0 / min(t1)
     return {"value": bs / med, "unit": "samples/s", "cores": cores, "kind": "port",
             "sample": f"oracle/scot_cpu.py fp32 fwd+bwd, Poseidon-{model_tag} batch {bs} {size}x{size}x{channels}, "
-                      f"median of {len(times)} steps, {cores} torch threads"}
+                      f"median of {len(times)} steps, {cores} torch threads",
+            "one_core_value": one, "one_core_sample": "the same step on batch 1 with one torch thread, best of 2"}
 
 
 def parity_check(model_tag, compute, size, channels):
