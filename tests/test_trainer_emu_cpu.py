@@ -276,3 +276,53 @@ def test_gradient_accumulation_steps_on_short_epoch(emu, tmp_path):
     args = TrainingArguments(output_dir=str(tmp_path), per_device_train_batch_size=2, num_train_epochs=1, gradient_accumulation_steps=8,
                              learning_rate=1e-3, logging_steps=1, save_strategy="no")
     assert Trainer(model=model, args=args, train_dataset=Samples(6, cfg, 0)).train().global_step == 1     # fewer batches than acc: still one step
+
+
+def test_resumed_run_equals_the_uninterrupted_one(emu, tmp_path):
+    """Checkpoint / resume as a property: 6 optimizer steps in one go == 4 steps, a checkpoint (model + optimizer moments + device step
+    counter + scheduler + trainer state), a NEW model and trainer resumed from it, 2 more steps — same weights, same learning-rate
+    trace, same data order (the epoch permutation is a function of seed and epoch; a mid-epoch resume skips the consumed batches)."""
+    from scOT.model import ScOT
+    from scOT.trainer import Trainer, TrainingArguments
+    f, meta = load_fixture("tiny_trained")
+    cfg = ScOTConfig(**meta["cfg"])
+    sd = synth_state_dict(param_shapes(cfg), meta["regime"])
+    train = Samples(8, cfg, 0)
+
+    from scOT.trainer import TrainerCallback
+
+    class StopAt(TrainerCallback):          # the "interruption": the run is laid out for 6 steps and stopped after its 4th
+        def __init__(self, n):
+            self.n = n
+
+        def on_step_end(self, args, state, control, **kw):
+            if state.global_step >= self.n:
+                control.should_training_stop = True
+            return control
+
+    def run(out, resume=None, save_steps=4, stop_at=None):
+        model = ScOT(cfg, compute="fp32")
+        model.load_state_dict(sd)
+        args = TrainingArguments(output_dir=str(out), per_device_train_batch_size=2, num_train_epochs=2, max_steps=6,
+                                 learning_rate=2e-3, weight_decay=0.01, lr_scheduler_type="cosine", warmup_ratio=0.25, logging_steps=1,
+                                 max_grad_norm=5.0, save_strategy="steps", save_steps=save_steps, seed=3)
+        tr = Trainer(model=model, args=args, train_dataset=train, callbacks=[StopAt(stop_at)] if stop_at else None)
+        res = tr.train(resume_from_checkpoint=resume)
+        lrs = [h["learning_rate"] for h in tr.state["log_history"] if "learning_rate" in h]
+        return {k: v.detach().clone() for k, v in model.state_dict().items()}, res.global_step, lrs
+
+    straight, n0, lr0 = run(tmp_path / "a", save_steps=100)
+    _, n1, _ = run(tmp_path / "b", stop_at=4)                           # step 4 = the end of epoch 1 (4 batches per epoch): checkpoint-4
+    assert n0 == 6 and n1 == 4 and os.path.isdir(str(tmp_path / "b" / "checkpoint-4"))
+    resumed, n2, lr2 = run(tmp_path / "b", resume=True)
+    assert n2 == 6
+    assert np.allclose(lr2[-2:], lr0[-2:], rtol=1e-6, atol=1e-12)
+    worst = max(float((resumed[k].double() - straight[k].double()).abs().max() / (straight[k].double().abs().max() + 1e-12)) for k in straight)
+    assert worst < 1e-5, worst
+    # ... and interrupted in the MIDDLE of an epoch (after 2 of its 4 batches): the resumed run skips the two consumed batches
+    _, n3, _ = run(tmp_path / "c", save_steps=2, stop_at=2)
+    assert n3 == 2 and os.path.isdir(str(tmp_path / "c" / "checkpoint-2"))
+    mid, n4, lr4 = run(tmp_path / "c", resume=True, save_steps=100)
+    assert n4 == 6 and np.allclose(lr4[-4:], lr0[-4:], rtol=1e-6, atol=1e-12)
+    worst = max(float((mid[k].double() - straight[k].double()).abs().max() / (straight[k].double().abs().max() + 1e-12)) for k in straight)
+    assert worst < 1e-5, worst
