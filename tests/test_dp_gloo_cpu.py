@@ -60,6 +60,14 @@ def _emu_ops():
     ops.ptr = lambda t: None if t is None else t.data_ptr()
 
 
+def _free_port():
+    """a port the OS hands out for 127.0.0.1 (a fixed one shared by consecutive tests can still sit in TIME_WAIT)"""
+    import socket
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        return sk.getsockname()[1]
+
+
 def _worker(rank, world, port, wire, collective, out):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
@@ -103,7 +111,7 @@ def test_two_rank_mean_allreduce(tmp_path, wire, collective):
         if not (os.path.exists(build_emu.CLANG) or shutil.which(build_emu.CLANG)):
             pytest.skip("no host clang with __bf16 vector support")
         build_emu.build_cached()                              # once, before the two ranks race for it
-    port = 29500 + (os.getpid() % 2000) + ["fp32allreduce", "bf16allreduce", "fp32rs_ag", "bf16rs_ag"].index(wire + collective)
+    port = _free_port()
     out = str(tmp_path / "ok")
     mp.spawn(_worker, args=(2, port, wire, collective, out), nprocs=2, join=True)
     assert open(out).read() == "ok"
@@ -183,7 +191,7 @@ def test_engine_ranges_are_final_when_announced(tmp_path):
         pytest.skip("no host clang with __bf16 vector support")
     build_emu.build_cached()                                  # once, before the two ranks race for it
     out = str(tmp_path / "ok")
-    mp.spawn(_engine_worker, args=(2, 31500 + (os.getpid() % 2000), out), nprocs=2, join=True)
+    mp.spawn(_engine_worker, args=(2, _free_port(), out), nprocs=2, join=True)
     assert open(out).read().startswith("ok")
 
 
@@ -266,7 +274,7 @@ def test_taped_step_with_bf16_wire_exchanges_each_range_once(tmp_path):
         pytest.skip("no host clang with __bf16 vector support")
     build_emu.build_cached()
     out = str(tmp_path / "ok")
-    mp.spawn(_taped_bf16_worker, args=(2, 33500 + (os.getpid() % 2000), out), nprocs=2, join=True)
+    mp.spawn(_taped_bf16_worker, args=(2, _free_port(), out), nprocs=2, join=True)
     assert open(out).read().startswith("ok")
 
 
@@ -343,5 +351,5 @@ def test_trainer_two_ranks_stay_in_lock_step(tmp_path):
         pytest.skip("no host clang with __bf16 vector support")
     build_emu.build_cached()
     out = str(tmp_path / "ok")
-    mp.spawn(_trainer_worker, args=(2, 33500 + (os.getpid() % 2000), out), nprocs=2, join=True)
+    mp.spawn(_trainer_worker, args=(2, _free_port(), out), nprocs=2, join=True)
     assert open(out).read() == "ok"
