@@ -169,7 +169,7 @@ def parity_check(model_tag, compute, size, channels):
     lrel = abs(float(out.loss) - float(f["loss"])) / abs(float(f["loss"]))
     del model
     torch.cuda.empty_cache()
-    return {"fixture": f"tests/golden/{name}.npz (real reference, {meta['regime']} parameters, batch {meta['batch']})",
+    return {"fixture": f"tests/golden/{name}.npz (outputs of the real reference on {'trained-like (closed-form, poseidon_amd/synth.py)' if meta['regime'] == 'trained' else meta['regime']} parameters, batch {meta['batch']})",
             "output_rel_l2": rel, "loss_rel": lrel, "bound": 1e-5 if compute == "fp32" else 1e-3, "meets_bound": rel < (1e-5 + 5e-6 if compute == "fp32" else 1e-3)}
 
 
