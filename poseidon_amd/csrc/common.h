@@ -72,6 +72,14 @@ template <typename CT> struct ct_traits;
 template <> struct ct_traits<float> { static constexpr int dtype = SCOT_F32; static constexpr int kpad = 4; };
 template <> struct ct_traits<bf16_t> { static constexpr int dtype = SCOT_BF16; static constexpr int kpad = 8; };
 
+// wait until at most n of this wave's vector-memory operations are outstanding (direct-to-LDS loads are counted by nothing else:
+// the compiler does not order a ds_read behind a global_load_lds)
+#ifdef SCOT_HIPEMU
+#define SCOT_VMCNT(n) ((void)0)
+#else
+#define SCOT_VMCNT(n) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(n) : "memory")
+#endif
+
 // ---- ablation hooks (tools/ablate_kernels.py builds extra copies of ONE source with -DSCOT_ABL=<bits>; the product never defines it).
 // TIMING ONLY — results are garbage: 1 = st8 stores nothing (values kept alive), 2 = gelu_terms is two multiplies, 4 = ld8 loads
 // nothing, 8 = no MFMA (and, dead-code-eliminated with it, no fragment reads), 16 = __syncthreads is a no-op, 32 = no global atomics,

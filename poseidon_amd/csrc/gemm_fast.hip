@@ -151,10 +151,10 @@ __device__ __forceinline__ void fstore_x3(bf16_t* hi, bf16_t* lo, const uint4 (&
 // WM x WN = arrangement of the 4 waves over the BM x BN tile (WM*WN == 4); each wave owns (BM/WM) x (BN/WN).
 // X3 (CT = bf16_t, BKT = 32): fp32 operands in memory, split into hi/lo bf16 tiles in LDS, 3 MFMAs per K-step (see fstore_x3).
 // LDS footprint of one workgroup of gemm_fast_body (operand double buffer, reused by the epilogue's C tile)
-template <typename CT, int BM, int BN, int BKT, int LAYOUT, bool X3, int KG = 1> struct FastLds {
+template <typename CT, int BM, int BN, int BKT, int LAYOUT, bool X3, int KG = 1, int GLDS = 0> struct FastLds {
   static constexpr bool A_KC = (LAYOUT != LAYOUT_TN), B_KC = (LAYOUT == LAYOUT_NT);
   static constexpr int STAGE = (X3 ? 2 : 1) * (FTile<CT, BM, A_KC, BKT>::elems + FTile<CT, BN, B_KC, BKT>::elems);
-  static constexpr size_t AB = (size_t)KG * 2 * STAGE * sizeof(CT), C = (size_t)KG * BM * (BN + 4) * sizeof(float) + BN * sizeof(float);
+  static constexpr size_t AB = (size_t)KG * (GLDS ? GLDS : 2) * STAGE * sizeof(CT), C = (size_t)KG * BM * (BN + 4) * sizeof(float) + BN * sizeof(float);
   static constexpr size_t bytes = AB > C ? AB : C;
 };
 
@@ -164,7 +164,11 @@ template <typename CT, int BM, int BN, int BKT, int LAYOUT, bool X3, int KG = 1>
 // contraction (the deep stages' weight gradients: 432 workgroups x 64 K-tiles at 4096 tokens) the serial K loop — one exposed
 // load -> LDS -> barrier -> MFMA round trip per tile, at one or two workgroups per CU — is what the launch costs; this halves its
 // trip count and doubles the loads in flight per CU without a second pass over partial sums in HBM.
-template <typename CT, int BM, int BN, int WM, int WN, int BKT, int NSET, int LAYOUT, bool X3 = false, int KG = 1>
+// GLDS = 3 | 4 LDS stages (NT, 16-bit swizzled tiles, K a multiple of BK): the operand tiles go global -> LDS directly (global_load_lds_dwordx4: a
+// wave instruction lands 64 x 16 bytes at a wave-uniform LDS base + lane x 16, so a 1 KB piece = 8 tile rows and the chunk swizzle is
+// applied on the SOURCE side: lane (row, position pc) fetches chunk pc ^ ((row >> 1) & 7) — probed in tools/probes/glds_probe.hip) through
+// GLDS LDS stages: no staging registers, no ds_write pass.
+template <typename CT, int BM, int BN, int WM, int WN, int BKT, int NSET, int LAYOUT, bool X3 = false, int KG = 1, int GLDS = 0>
 __device__ __forceinline__ void gemm_fast_body(const FastArgs& p, const int bx, const int by, const int bz, char* smem) {
   static_assert(NSET == 2 || NSET == 4, "pipeline depth");
   static_assert(KG == 1 || (KG == 2 && !X3), "K groups: plain 16-bit or fp32 operands");
@@ -183,7 +187,8 @@ __device__ __forceinline__ void gemm_fast_body(const FastArgs& p, const int bx, 
   constexpr int STAGE = (X3 ? 2 : 1) * (TA::elems + TB::elems);   // X3: [A hi][A lo][B hi][B lo]
   constexpr int BOFF = (X3 ? 2 : 1) * TA::elems;                  // offset of the B tile(s) in a stage
   constexpr int CP = BN + 4;                                  // C tile pitch (floats)
-  static_assert(FastLds<CT, BM, BN, BKT, LAYOUT, X3, KG>::STAGE == STAGE, "LDS sizing");
+  static_assert(FastLds<CT, BM, BN, BKT, LAYOUT, X3, KG, GLDS>::STAGE == STAGE, "LDS sizing");
+  static_assert(GLDS == 0 || (LAYOUT == LAYOUT_NT && TA::SWZ && TB::SWZ && !X3 && KG == 1 && BM % 32 == 0 && BN % 32 == 0), "direct-to-LDS: NT, swizzled 16-bit tiles");
   const int kg = KG > 1 ? (int)(threadIdx.x >> 8) : 0;            // K group of this wave quartet
   CT* lds = (CT*)smem + (size_t)kg * 2 * STAGE;
 
@@ -207,7 +212,7 @@ __device__ __forceinline__ void gemm_fast_body(const FastArgs& p, const int bx, 
   // iteration t+NSET-1, i.e. they have NSET-1 full MFMA phases to land.  NSET = 2 when many workgroups share a CU (their
   // interleaving hides the latency); NSET = 4 for the small grids of stages 2/3, where ONE workgroup per CU walks 12–48 K-tiles
   // and each iteration used to stall ~1000 cycles on the HBM round trip of a load issued only one iteration earlier.
-  uint4 ra[NSET][LA::per_thread], rb[NSET][LB::per_thread];
+  uint4 ra[GLDS ? 1 : NSET][LA::per_thread], rb[GLDS ? 1 : NSET][LB::per_thread];
   // stage `st` <- register set: plain copy, or the hi/lo split of bf16x3
   auto stage_store = [&](CT* st, const uint4 (&a)[LA::per_thread], const uint4 (&b)[LB::per_thread], int k0) {
     if constexpr (X3) {
@@ -220,6 +225,7 @@ __device__ __forceinline__ void gemm_fast_body(const FastArgs& p, const int bx, 
   };
   // K-tile j of THIS group starts at kofs(j) (KG = 1: consecutive tiles)
   auto kofs = [&](int j) { return kbeg + (kg + KG * j) * BK; };
+  if constexpr (GLDS == 0) {
 #pragma unroll
   for (int u = 0; u < NSET; ++u) {   // unconditional: fload clamps its addresses, fstore zero-fills tiles past kend
     fload<MT, BM, A_KC, BKT>(ra[u], A, p.lda, m0, p.M, kofs(u), kend, tid);
@@ -227,6 +233,7 @@ __device__ __forceinline__ void gemm_fast_body(const FastArgs& p, const int bx, 
   }
   stage_store(lds, ra[0], rb[0], kofs(0));
   __syncthreads();
+  }
 
   auto frag_a = [&](const CT* As, int i, int kk) {
     const int r0 = wr * WROWS + i * 16;
@@ -283,6 +290,43 @@ __device__ __forceinline__ void gemm_fast_body(const FastArgs& p, const int bx, 
   // their tiles are zero-filled by fstore and add nothing): with `if (tile exists)` around the loads the compiler cannot count
   // the loads in flight and falls back to s_waitcnt vmcnt(0) before every LDS store — i.e. no prefetch at all.  The trip
   // count is rounded up to a multiple of NSET for the same reason.
+  if constexpr (GLDS != 0) {
+    typedef __attribute__((address_space(3))) void* lds_p;
+    typedef __attribute__((address_space(1))) const void* gbl_p;
+    constexpr int LPW = BM / 32 + BN / 32;       // direct loads per wave and K-tile (1 KB = 8 tile rows each)
+    auto issue = [&](CT* st, int k0) {
+#pragma unroll
+      for (int u = 0; u < BM / 32; ++u) {
+        const int q = wave + 4 * u, row = 8 * q + (lane >> 3), c = (lane & 7) ^ ((row >> 1) & 7);
+        const CT* src = (const CT*)A + (size_t)min(m0 + row, p.M - 1) * p.lda + k0 + c * 8;
+        __builtin_amdgcn_global_load_lds((gbl_p)src, (lds_p)(st + q * 512), 16, 0, 0);
+      }
+#pragma unroll
+      for (int u = 0; u < BN / 32; ++u) {
+        const int q = wave + 4 * u, row = 8 * q + (lane >> 3), c = (lane & 7) ^ ((row >> 1) & 7);
+        const CT* src = (const CT*)B + (size_t)min(n0 + row, p.N - 1) * p.ldb + k0 + c * 8;
+        __builtin_amdgcn_global_load_lds((gbl_p)src, (lds_p)(st + BOFF + q * 512), 16, 0, 0);
+      }
+    };
+    {
+      // GLDS >= 3 stages: tiles t+1 .. t+GLDS-1 are in flight while tile t is multiplied.  The wait that retires tile t leaves the
+      // loads of the (up to GLDS-2) newer tiles outstanding; the barrier behind it makes every wave's pieces visible and says that
+      // stage (t-1) % GLDS — read during iteration t-1 — is free for tile t+GLDS-1
+#pragma unroll
+      for (int u = 0; u < GLDS - 1; ++u)
+        if (u < nk) issue(lds + u * STAGE, kofs(u));
+      for (int t = 0; t < nk; ++t) {
+        const int newer = min(GLDS - 2, nk - 1 - t);
+        if (newer >= 2) SCOT_VMCNT(2 * LPW);
+        else if (newer == 1) SCOT_VMCNT(LPW);
+        else SCOT_VMCNT(0);
+        __builtin_amdgcn_s_barrier();
+        if (t + GLDS - 1 < nk) issue(lds + ((t + GLDS - 1) % GLDS) * STAGE, kofs(t + GLDS - 1));
+        compute(lds + (t % GLDS) * STAGE);
+      }
+      __syncthreads();     // the epilogue's C tile aliases the stages
+    }
+  } else {
   const int nk_pad = ((nk + KG - 1) / KG + NSET - 1) / NSET * NSET;    // tiles per group (the same trip count in both: barriers)
   for (int t = 0; t < nk_pad; t += NSET) {
 #pragma unroll
@@ -295,6 +339,7 @@ __device__ __forceinline__ void gemm_fast_body(const FastArgs& p, const int bx, 
       stage_store(lds + ((u + 1) & 1) * STAGE, ra[(u + 1) % NSET], rb[(u + 1) % NSET], kofs(tt + 1));
       __syncthreads();
     }
+  }
   }
 
   if (LAYOUT == LAYOUT_TN && p.colsum_out && bx == 0 && tid < BM && m0 + tid < p.M) atomicAdd(&p.colsum_out[m0 + tid], bsum);
@@ -399,9 +444,9 @@ __device__ __forceinline__ void gemm_fast_body(const FastArgs& p, const int bx, 
   }
 }
 
-template <typename CT, int BM, int BN, int WM, int WN, int BKT, int NSET, int LAYOUT, bool X3 = false, int KG = 1>
+template <typename CT, int BM, int BN, int WM, int WN, int BKT, int NSET, int LAYOUT, bool X3 = false, int KG = 1, int GLDS = 0>
 __global__ __launch_bounds__(256 * KG) void gemm_fast_kernel(FastArgs p) {
-  __shared__ __attribute__((aligned(16))) char smem[FastLds<CT, BM, BN, BKT, LAYOUT, X3, KG>::bytes];
+  __shared__ __attribute__((aligned(1024))) char smem[FastLds<CT, BM, BN, BKT, LAYOUT, X3, KG, GLDS>::bytes];
   // Workgroup b runs on XCD b % 8 (observed dispatch order, used for speed only).  The tiles that re-read the same streamed
   // operand — all output tiles of one token chunk (TN), all column tiles of one row block (NT/NN) — are renumbered so that they
   // are consecutive ON ONE XCD: its 4 MB L2 then serves the re-reads instead of the fabric (PMC: 3.1x algorithmic bytes before).
@@ -418,7 +463,7 @@ __global__ __launch_bounds__(256 * KG) void gemm_fast_kernel(FastArgs p) {
       else { by = group % gy; bz = group / gy; bx = member; }
     }
   }
-  gemm_fast_body<CT, BM, BN, WM, WN, BKT, NSET, LAYOUT, X3, KG>(p, bx, by, bz, smem);
+  gemm_fast_body<CT, BM, BN, WM, WN, BKT, NSET, LAYOUT, X3, KG, GLDS>(p, bx, by, bz, smem);
 }
 
 // ------------------------------------------------------------------------------------------------------------------------
@@ -537,6 +582,12 @@ template <> int flaunch_tile<bf16_t>(int tile, const FastArgs& a, int layout, in
     case 6: return flaunch_layout<bf16_t, 64, 64, 2, 2, 32>(a, layout, nsplit, s);
     case 7: return flaunch_layout<bf16_t, 128, 96, 4, 1, 32>(a, layout, nsplit, s);
     case 8: return flaunch_layout<bf16_t, 64, 64, 2, 2, 64, 4>(a, layout, nsplit, s);   // deep pipeline (small grids)
+    case 9: {                                                                           // three direct-to-LDS stages (NT only)
+      if (layout != LAYOUT_NT) return flaunch_layout<bf16_t, 64, 64, 2, 2>(a, layout, nsplit, s);
+      dim3 grid((a.N + 63) / 64, (a.M + 63) / 64, nsplit), block(256);
+      hipLaunchKernelGGL((gemm_fast_kernel<bf16_t, 64, 64, 2, 2, 64, 2, LAYOUT_NT, false, 1, 3>), grid, block, 0, s, a);
+      return scot_check_launch();
+    }
     default: return flaunch_layout<bf16_t, 64, 64, 2, 2>(a, layout, nsplit, s);
   }
 }
@@ -571,7 +622,7 @@ static void tile_dims(int tile, int& bm, int& bn, int& bkt) {
     case 4: bm = 96; bn = 96; break;
     case 5: bm = 96; bn = 96; bkt = 32; break;
     case 6: bm = 64; bn = 64; bkt = 32; break;
-    case 8: bm = 64; bn = 64; break;
+    case 8: case 9: bm = 64; bn = 64; break;
     case 7: bm = 128; bn = 96; bkt = 32; break;
     default: bm = 64; bn = 64;
   }
@@ -617,6 +668,8 @@ static int gemm_fast_impl(int layout, int compute, int M, int N, int K, const vo
     for (int i = 0; i < 4; ++i) { const char* e = getenv(names[i]); ov[i] = e ? atoi(e) : -1; }
   }
   int tile = ov[layout] >= 0 ? ov[layout] : (ov[3] >= 0 ? ov[3] : -1);
+  static int glds = -1;
+  if (glds < 0) { const char* e = getenv("SCOT_GEMM_GLDS"); glds = e ? atoi(e) : 1; }   // direct-to-LDS K loop for the NT products it covers (SCOT_GEMM_GLDS=0: register-staged)
   static int deep = -1;
   if (deep < 0) { const char* e = getenv("SCOT_GEMM_DEEP"); deep = e ? atoi(e) : 1; }   // in step: 19.76 -> 19.59 ms (SCOT_GEMM_DEEP=0: off)
   if (tile < 0) {
@@ -630,6 +683,9 @@ static int gemm_fast_impl(int layout, int compute, int M, int N, int K, const vo
     // register sets of loads in flight instead of two (26.4 -> 22.4 / 24.5 -> 21.7 us alone; shorter contractions lose to the padded trip count)
     else if (compute == SCOT_BF16 && layout != LAYOUT_TN && K >= 36 * 64 && (long)((M + 63) / 64) * ((N + 63) / 64) <= 512 && deep) tile = 8;
   }
+  // 64 x 64-tile NT products whose K is whole tiles: three LDS stages filled by global_load_lds (alone -6 % at K = 384, -14..21 % from
+  // K = 1536; in step 19.60 -> 19.45 ms; two stages lose to the register pipeline in step, four to three)
+  if (glds && compute == SCOT_BF16 && layout == LAYOUT_NT && (tile == 0 || tile == 8) && K % 64 == 0 && lda % 8 == 0 && ldb % 8 == 0) tile = 9;
   if (x3 && tile != 2 && tile != 4) tile = 0;                     // bf16x3 instantiates 64x64, 64x96, 96x96
   if (compute == SCOT_F32 && tile != 0 && tile != 3) tile = 0;    // fp32 instantiates 64x64 and 128x128 only
   int bm, bn, bkt;

@@ -159,6 +159,14 @@ inline float bf2f(uint16_t x) { return __uint_as_float(((uint32_t)x) << 16); }
 inline void __syncthreads() { hipemu::g_block->bar->arrive_and_wait(); }
 inline void emu_wave_barrier() { hipemu::wave().bar.arrive_and_wait(); }
 #define __builtin_amdgcn_wave_barrier emu_wave_barrier
+// global_load_lds_*: lane l's `size` bytes land at the (wave-uniform) LDS base + l * size; synchronous here, so the vmcnt waits of the
+// kernels are no-ops (SCOT_HIPEMU) and s_barrier is the block barrier
+#define SCOT_HIPEMU 1
+template <typename G, typename L> inline void emu_global_load_lds(G g, L l, int size, int off, int) {
+  std::memcpy((char*)(const void*)l + (hipemu::lane() & 63) * size + off, (const void*)g, (size_t)size);
+}
+#define __builtin_amdgcn_global_load_lds emu_global_load_lds
+#define __builtin_amdgcn_s_barrier __syncthreads
 #define __builtin_amdgcn_sched_barrier(x) ((void)0)
 
 #ifdef HIPEMU_THREADS
