@@ -137,6 +137,19 @@ class ScOTEngine:
         self.shadow_t, self._wt_names, self._wt_desc, self._wt_tiles = None, {}, None, 0
         if self.shadow is not None and os.environ.get("SCOT_DGRAD_WT", "1") == "1":
             self._plan_transposed_weights()
+        # The deep stages' layer tails (C = 384 / 768) as one launch per direction on FRAGMENT-ORDERED weight copies (csrc/tail_deep.hip):
+        # `shadow_f` holds Wo, W1 (rows permuted), W2, Wqkv of those layers in the order the MFMA operand loads read them (same offsets as
+        # the master).  {C: hidden split} — C = 768 has 1024 rows at batch 64 = 64 row blocks, so four workgroups share a block's hidden
+        # dimension.  OFF by default (SCOT_DEEP_TAIL=1 switches it on): measured in round 4, the kernel alone beats the launches it
+        # replaces (66 vs 90 us at C = 384) but not inside the step (cold output buffers: 82-88 us; and it starves the skip blocks that
+        # share the forward's side stream) — profiles/round4/deep_tail_*.txt, DESIGN.md §6.
+        self.deep_hsplit = {}
+        self.shadow_f, self._wf_desc, self._wf_blocks, self._wf_names = None, None, 0, set()
+        if self.shadow is not None and os.environ.get("SCOT_DEEP_TAIL", "0") == "1":
+            self.deep_hsplit = {int(c): int(h) for c, h in (kv.split(":") for kv in os.environ.get("SCOT_DEEP_HSPLIT", "384:1,768:4").split(",") if kv)}
+            self._plan_fragment_weights()
+            if self.deep_hsplit.get(384) == 1:
+                self.fused_next_qkv = self.fused_next_qkv | {384}
         # fp16 operands have 5 exponent bits: the backward runs on gradients multiplied by a power of two chosen from the loss
         # normalisation (d loss / d prediction = O(1 / number of output elements); see _grad_scale) and the gradient arena is
         # divided by it afterwards (exact; scot_scale_inplace also counts non-finite values → `grad_overflow`).
@@ -274,6 +287,45 @@ class ScOTEngine:
         self._wt_desc = torch.tensor(desc, dtype=torch.int32, device=self.device)
         self._wt_tiles = tile
         self._wtviews = {}
+
+    def _plan_fragment_weights(self):
+        """desc of scot_fragpack for the forward operands of every ScOTLayer whose width has a deep-tail kernel"""
+        ar = self.arena
+        blocks = [b for st in self.enc for b in st.blocks] + [b for st in self.dec for b in st.blocks]
+        desc, blk = [], 0
+        for b in blocks:
+            C = b.dim
+            if C not in self.deep_hsplit or int(self.cfg.mlp_ratio * C) != 4 * C:
+                continue
+            pre, a = b.prefix, b.prefix + ".attention.self."
+            for name, N, K, mode in ((pre + ".attention.output.dense.weight", C, C, 0), (pre + ".intermediate.dense.weight", 4 * C, C, 2),
+                                     (pre + ".output.dense.weight", C, 4 * C, 0), (a + "qkv_weight", 3 * C, C, 0)):
+                off = ar.offsets[name]
+                desc.append((off, N, K, blk, mode, off))
+                blk += (N * K // 8 + 255) // 256
+                self._wf_names.add(name)
+        if not desc:
+            return
+        self.shadow_f = torch.zeros(ar.size, dtype=self.adt, device=self.device)
+        self._wf_desc = torch.tensor(desc, dtype=torch.int32, device=self.device)
+        self._wf_blocks = blk
+        self._wfviews = {}
+
+    def pack_fragments(self):
+        """fp32 master -> the fragment-ordered operand copies of the deep stages' forward weights (one launch)"""
+        if self.shadow_f is not None:
+            ops.fragpack(self.arena.data, self.shadow_f, self._wf_desc, self._wf_desc.shape[0], self._wf_blocks)
+
+    def WF(self, name, numel=None):
+        """fragment-ordered copy of weight `name` (flat), or None"""
+        if self.shadow_f is None or name not in self._wf_names:
+            return None
+        v = self._wfviews.get(name)
+        if v is None:
+            o = self.arena.offsets[name]
+            v = self.shadow_f[o:o + (numel if numel is not None else self.arena.numel(name))]
+            self._wfviews[name] = v
+        return v
 
     def transpose_weights(self):
         ops.transpose_cast(self.arena.data, self.shadow_t, self._wt_desc, len(self._wt_names), self._wt_tiles)
@@ -676,7 +728,40 @@ class ScOTEngine:
         done_tail = False
         lean_used = False
         qkv_next = None
-        if proj_f and mlp_f and self.fused_tail:
+        hs = self.deep_hsplit.get(C, 0)
+        if (hs and not padded and (B * L) % 16 == 0 and L % 16 == 0 and hid == 4 * C and hid % (128 * hs) == 0 and not self.precision_probe
+                and self.WF(pre + ".output.dense.weight") is not None):
+            # deep stages: everything after the attention core in one launch on the fragment-ordered weight copies (csrc/tail_deep.hip)
+            proj = self.new(B * L, C) if train else None
+            st1 = (self.new(B * L), self.new(B * L)) if train else (None, None)
+            h16 = self.new(B * L, C, dtype=self.adt) if train else None
+            h = self.new(B * L, C) if hs > 1 else None
+            u = self.new(B * L, hid, dtype=self.adt) if train else None
+            gp = self.new(B * L, hid, dtype=self.adt) if train else None
+            y2 = self.new(B * L, C) if train else None
+            st2 = (self.new(B * L), self.new(B * L)) if train else (None, None)
+            out, out16 = self.new(B * L, C), self.new(B * L, C, dtype=self.adt)
+            n1, n2 = self._norm_params(pre + ".layernorm_before"), self._norm_params(pre + ".layernorm_after")
+            nq = (None, None, None)
+            if hs == 1 and next_blk is not None and next_blk.dim == C and self.qkv_fusable(next_blk):
+                na = next_blk.prefix + ".attention.self."
+                qkv_next = self.new(B * L, 3 * C, dtype=self.adt)
+                nq = (self.WF(na + "qkv_weight", 3 * C * C), self.arena.span(na + "qkv_bias", 3 * C) if cfg.qkv_bias else None, qkv_next)
+            ypart = self.new(hs, B * L, C) if hs > 1 else None
+            tcond = time if self.cond else None
+            b2 = self.P(pre + ".output.dense.bias")
+            if not ops.deep_tail_fwd(
+                    (attn_c, self.WF(pre + ".attention.output.dense.weight"), self.P(pre + ".attention.output.dense.bias"), x, h, h16, proj,
+                     st1[0], st1[1], n1[0], n1[1], n1[2], n1[3], dp1),
+                    (self.WF(pre + ".intermediate.dense.weight"), self.P(pre + ".intermediate.dense.bias"), self.WF(pre + ".output.dense.weight"),
+                     b2, out, out16, u, gp, y2, st2[0], st2[1], n2[0], n2[1], n2[2], n2[3], dp2),
+                    tcond, B * L, L, C, hid, cfg.layer_norm_eps, *nq, hsplit=hs, ypart=ypart):
+                raise RuntimeError("scot_deep_tail_fwd rejected a shape the engine selected it for")
+            if hs > 1:
+                ops.deep_tail_finish(ypart, hs, b2, h, out, out16, y2, st2[0], st2[1], n2[0], n2[1], n2[2], n2[3], dp2, tcond, B * L, L, C,
+                                     cfg.layer_norm_eps)
+            done_tail = True
+        elif proj_f and mlp_f and self.fused_tail:
             # projection + norm + residual, then MLP + norm + residual, for the same rows in one launch
             lean = train and self.lean_tail and self._lean_ok(pre, B * L, L, C, hid)
             zdt = self.adt if lean else torch.float32        # pre-norm rows: only the norm backward's x-hat reads them
@@ -1109,6 +1194,7 @@ class ScOTEngine:
         try:
             if need:
                 ops.cast(self.arena.data, self.shadow)
+                self.pack_fragments()
                 self._shadow_v = v
             if need_t:
                 self.transpose_weights()

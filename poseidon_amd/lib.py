@@ -48,6 +48,9 @@ PROTOTYPES = {
     "scot_wgrad_mlp": [P, P, P, P, P, P, P, P, P, I, I, I, P, Z, P],
     "scot_transpose_cast": [P, P, P, I, I, P],
     "scot_block_tail_fwd": [P] * 33 + [I, P, I, I, I, I, F, P],
+    "scot_fragpack": [P, P, P, I, I, P],
+    "scot_deep_tail_fwd": [P] * 33 + [I, P, I, I, I, I, F, I, P, P],
+    "scot_deep_tail_finish": [P, I, P, P, P, P, P, I, P, P, P, P, P, P, P, P, I, I, I, F, P],
     "scot_proj_cln_fwd": [P, P, P, P, P, P, P, P, P, P, P, P, P, P, P, I, I, I, F, P],
     "scot_proj_cln_bwd": [P, P, P, P, P, P, P, P, P, P, P, P, P, P, P, I, I, I, P],
     "scot_cln_bwd": [P, I, P, I, P, P, P, P, P, P, I, P, P, P, P, P, I, I, I, P, Z, P, I, P],

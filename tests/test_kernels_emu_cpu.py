@@ -212,6 +212,12 @@ def test_fused_mlp_and_projection_backward(gpu_test_bodies, cond, B, L, C):
     gpu_test_bodies.test_block_tail_bwd_fused(cond, B, L, C, True)
 
 
+@pytest.mark.parametrize("train,cond,next_qkv", [(True, True, True), (False, False, False)])
+@pytest.mark.parametrize("B,L,C,hsplit", [(2, 16, 384, 1), (1, 16, 768, 4), (1, 16, 768, 1), (1, 32, 384, 2)])
+def test_deep_tail_forward(gpu_test_bodies, train, cond, next_qkv, B, L, C, hsplit):
+    gpu_test_bodies.test_deep_tail_fwd(train, cond, next_qkv, B, L, C, hsplit)
+
+
 @pytest.mark.parametrize("cond,B,L,C,prologue", [(True, 1, 64, 96, True), (False, 1, 64, 192, False), (True, 3, 64, 96, False), (True, 2, 64, 192, True)])
 def test_block_tail_lean_forms(gpu_test_bodies, cond, B, L, C, prologue):
     gpu_test_bodies.test_block_tail_lean_forms(cond, B, L, C, prologue)
