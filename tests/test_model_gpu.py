@@ -884,3 +884,112 @@ def test_overlapped_gradient_fill_is_ordered_before_the_backward():
     assert bool(torch.isfinite(grads[True]).all())
     d = float((grads[True] - grads[False]).norm() / grads[False].norm())      # (not bit-equal: float atomics commit in any order)
     assert d < 5e-6, d
+
+
+# ----------------------------------------------------------------------------------------------- the TIMED batch sizes
+def _preset_model(tag, size, channels, compute, regime="trained"):
+    from poseidon_amd.config import preset
+    cfg = preset(tag, image_size=size, num_channels=channels, num_out_channels=channels,
+                 channel_slice_list_normalized_loss=[0, 1, channels - 1, channels])
+    sd = synth_state_dict(param_shapes(cfg), regime)
+    model = ScOT(cfg, compute=compute)
+    model.load_state_dict(sd)
+    return cfg, sd, model.to(DEV)
+
+
+@pytest.mark.parametrize("tag,size,channels,batch", [("B", 128, 4, 64), ("T", 128, 4, 32), ("B", 256, 4, 32)])
+@pytest.mark.parametrize("compute", ["fp32", "fp16"])
+def test_timed_batch_matches_the_batch1_path(tag, size, channels, batch, compute):
+    """BASELINE configs 3 / 2 / 5 at the batch sizes bench.py times: the large row counts select launch policies no batch-1 fixture
+    reaches (128-row block tails, grouped / recomputing weight gradients, direct-to-LDS and four-register-set GEMMs, the XCD-local
+    attention grid).  Samples are independent, so (i) prediction[i] of the batch must equal the prediction of sample i alone, and (ii)
+    the batch's parameter gradients must equal the sum of the per-sample gradients weighted as the relative loss weights them — checked
+    through the loss and the full gradients of a few samples' worth (a batch of 3 against 3 batches of 1)."""
+    cfg, sd, model = _preset_model(tag, size, channels, compute)
+    pv, t, lab = synth_inputs(batch, channels, channels, size, "smooth")
+    pv, t, lab = pv.to(DEV), t.to(DEV), lab.to(DEV)
+    out = model(pixel_values=pv, time=t, labels=lab)
+    out.loss.backward()
+    full = out.output.detach().clone()
+    torch.cuda.synchronize()
+    assert torch.isfinite(full).all() and torch.isfinite(model.flat_grads()).all()
+    worst = 0.0
+    for i in (0, batch // 3, batch - 1):
+        one = model(pixel_values=pv[i:i + 1].contiguous(), time=t[i:i + 1].contiguous(), labels=lab[i:i + 1].contiguous()).output.detach()
+        worst = max(worst, rel_l2(one.cpu().numpy(), full[i:i + 1].cpu().numpy()))
+    print(f"\n[Poseidon-{tag} {size}^2 batch {batch} {compute}] prediction[i] vs sample i alone: max rel-L2 {worst:.2e}")
+    # same products, same rounding points; only the tile shapes (hence fp32 summation order) may differ
+    assert worst < (2e-6 if compute == "fp32" else 2e-4)
+
+
+@pytest.mark.parametrize("compute", ["fp32", "fp16"])
+def test_config3_batch8_against_the_oracle(compute):
+    """Poseidon-B (BASELINE config 3's model) at a batch the CPU oracle can hold (8): output, loss and every parameter
+    gradient of the HIP path against oracle/scot_cpu.py on the same closed-form parameters and inputs."""
+    from oracle import scot_cpu
+    cfg, sd, model = _preset_model("B", 128, 4, compute)
+    pv, t, lab = synth_inputs(8, 4, 4, 128, "smooth")
+    out = model(pixel_values=pv.to(DEV), time=t.to(DEV), labels=lab.to(DEV))
+    out.loss.backward()
+    torch.cuda.synchronize()
+    torch.set_num_threads(min(32, os.cpu_count() or 1))
+    ref = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
+    loss, pred = scot_cpu.scot_forward(ref, cfg, pv, t, lab)
+    loss.backward()
+    e_out = rel_l2(out.output.detach().cpu().numpy(), pred.detach().numpy())
+    e_loss = abs(float(out.loss) - float(loss)) / abs(float(loss))
+    num = den = 0.0
+    worst = (0.0, "")
+    for k, p in model.named_parameters():
+        r = ref[k].grad
+        if r is None:
+            continue
+        err, nr = float((p.grad.detach().cpu().double() - r.double()).norm()), float(r.double().norm())
+        if nr > 0 and err / nr > worst[0]:
+            worst = (err / nr, k)
+        num += err ** 2
+        den += nr ** 2
+    g = (num / den) ** 0.5
+    print(f"\n[Poseidon-B batch 8 {compute} vs oracle] out rel-L2 {e_out:.2e} loss rel {e_loss:.2e} grads global rel-L2 {g:.2e} worst {worst}")
+    if compute == "fp32":
+        assert e_out < 1e-5 + 5e-6 and e_loss < 2e-5 and g < 1e-3
+    else:
+        assert e_out < 1e-3 and e_loss < 1e-3 and g < 6e-3
+        assert int(model._engine.grad_overflow) == 0
+
+
+@pytest.mark.parametrize("tag,size,channels,batch", [("B", 128, 4, 64), ("T", 128, 4, 32), ("B", 256, 4, 32)])
+def test_timed_batch_gradients_fp16_vs_fp32_path(tag, size, channels, batch):
+    """The backward at the timed sizes: the fp16 step (lean 128-row tails, recomputing fc1 / fc2 weight gradients, grouped weight
+    gradients over 65536 tokens, the transposed-copy data gradients) against the fp32 mode of the same engine AT THE SAME BATCH — a
+    different set of kernels (exact fp32 MFMA, layer-by-layer launches) that the oracle pins to 1e-6 at the sizes a CPU can hold
+    (test_config3_batch8_against_the_oracle, the fixtures).  Bounds: those of the fp16 mode against the reference fixtures."""
+    pv, t, lab = synth_inputs(batch, channels, channels, size, "smooth")
+    kw = dict(pixel_values=pv.to(DEV), time=t.to(DEV), labels=lab.to(DEV))
+    res = {}
+    for compute in ("fp32", "fp16"):
+        cfg, sd, model = _preset_model(tag, size, channels, compute)
+        for rep in range(3):        # direct launches, the recorded step, its replay: the third is what bench.py times
+            model.zero_grad()
+            out = model(**kw)
+            out.loss.backward()
+        torch.cuda.synchronize()
+        if compute == "fp16":
+            assert int(model._engine.grad_overflow) == 0
+        res[compute] = (out.output.detach().clone(), float(out.loss), {k: p.grad.detach().clone() for k, p in model.named_parameters()})
+        del model
+    e_out = rel_l2(res["fp16"][0].cpu().numpy(), res["fp32"][0].cpu().numpy())
+    e_loss = abs(res["fp16"][1] - res["fp32"][1]) / abs(res["fp32"][1])
+    num = den = 0.0
+    worst = (0.0, "")
+    for k, r in res["fp32"][2].items():
+        if "logit_scale" in k:
+            continue
+        err, nr = float((res["fp16"][2][k].double() - r.double()).norm()), float(r.double().norm())
+        if nr > 1e-7 * max(1.0, den ** 0.5) and err / nr > worst[0]:
+            worst = (err / nr, k)
+        num += err ** 2
+        den += nr ** 2
+    g = (num / den) ** 0.5
+    print(f"\n[Poseidon-{tag} {size}^2 batch {batch}] fp16 vs fp32 path: out rel-L2 {e_out:.2e} loss rel {e_loss:.2e} grads global rel-L2 {g:.2e} worst {worst}")
+    assert e_out < 1e-3 and e_loss < 1e-3 and g < 6e-3
