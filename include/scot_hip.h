@@ -26,7 +26,7 @@ typedef struct ihipStream_t* scot_stream_t; /* = hipStream_t */
 #define SCOT_LAYOUT_NN 1 /* C[M,N] = A[M,K] B[K,N]   : dgrad of nn.Linear; ConvTranspose2d k=s (ref:616-621)      */
 #define SCOT_LAYOUT_TN 2 /* C[M,N] += A[K,M]^T B[K,N] : wgrad of nn.Linear (autograd of the above)                 */
 
-int scot_abi_version(void);
+int scot_abi_version(void);   /* 2 since round 4 (round 3 changed scot_adamw_step / scot_cpb_bwd_batched / scot_block_tail_*; the bindings check it at load) */
 /* Format of dtype code 1 in THIS build of the library: 0 = bfloat16 (libscot_hip.so), 1 = IEEE binary16 (libscot_hip_f16.so, the
  * same sources compiled with -DSCOT_OPERAND_FP16).  The reference computes in fp32 (ref:1318-1509); 16-bit operands are this
  * library's choice and binary16 is the one that keeps ScOT.forward within 1e-3 of it. */
@@ -247,6 +247,30 @@ int scot_block_tail_fwd(const void* a, const void* Wo, const float* bo, const fl
                         const void* Wqkv, const float* bqkv, void* qkv /* optional epilogue (Wqkv and qkv both or neither): the NEXT
                         layer's fused q/k/v projection qkv[M,3C] = out16 · Wqkv[3C,C]^T + bqkv (HF:396-410) on the rows just produced */,
                         int z_dt, const float* time, int M, int rows_per_sample, int C, int hid, float eps, scot_stream_t stream);
+
+/* Deep stages (C = 384 / 768; 4096 / 1024 token rows at batch 64), csrc/tail_deep.hip — the same tail (ref model.py:560-579,
+ * HF:396-410, 478-489, 533-561) with SIXTEEN rows per workgroup, every weight matrix streamed from L2 straight into MFMA operand
+ * fragments.  That needs FRAGMENT-ORDERED operand copies of the weights:
+ *   scot_fragpack: wf16[dst + ((nt·K/32 + ks)·64 + lane)·8 + j] = w[src + row·K + 32 ks + 8 (lane >> 4) + j], row = 16 nt + (lane & 15),
+ *   for every matrix of desc (int32 [n][6], device: source offset, N, K, first 256-piece block, mode, destination offset; mode bit 0:
+ *   the source holds the transpose [K][N]; bit 1: rows permuted inside 32-row blocks, fragment row 16 t + 4 a + b <- source row
+ *   8 a + 4 t + b — the fc1 weight); N % 16 == 0, K % 32 == 0; blocks = total block count.
+ *   scot_deep_tail_fwd: arguments as scot_block_tail_fwd with Wo_f / W1_f (permuted) / W2_f / Wqkv_f fragment-ordered; h may be NULL
+ *   when hsplit == 1 (the residual never leaves the kernel); the qkv epilogue exists at C = 384.  hsplit > 1: the hidden dimension is
+ *   shared by hsplit workgroups per 16 rows, ypart [hsplit][M][C] fp32 receives the partial fc2 sums and
+ *   scot_deep_tail_finish applies the rest: out = h + s2 · CLN2(Σ_q ypart[q] + b2).  M % 16 == 0, rows_per_sample % 16 == 0,
+ *   hid == 4C, hid % (128·hsplit) == 0; -3 otherwise. */
+int scot_fragpack(const float* w, void* wf16, const int* desc, int n, int blocks, scot_stream_t stream);
+int scot_deep_tail_fwd(const void* a, const void* Wo_f, const float* bo, const float* x, float* h, void* h16, void* z1, float* mean1,
+                       float* rstd1, const float* gw_w1, const float* gw_b1, const float* bw_w1, const float* bw_b1,
+                       const float* sscale1, const void* W1_f, const float* b1, const void* W2_f, const float* b2, float* out, void* out16,
+                       void* act, void* dact, void* z2, float* mean2, float* rstd2, const float* gw_w2, const float* gw_b2,
+                       const float* bw_w2, const float* bw_b2, const float* sscale2, const void* Wqkv_f, const float* bqkv, void* qkv,
+                       int z_dt, const float* time, int M, int rows_per_sample, int C, int hid, float eps, int hsplit, float* ypart,
+                       scot_stream_t stream);
+int scot_deep_tail_finish(const float* ypart, int hsplit, const float* b2, const float* h, float* out, void* out16, void* z2, int z_dt,
+                          float* mean2, float* rstd2, const float* gw_w2, const float* gw_b2, const float* bw_w2, const float* bw_b2,
+                          const float* sscale2, const float* time, int M, int rows_per_sample, int C, float eps, scot_stream_t stream);
 
 /* The fc1 / fc2 weight and bias gradients of a ScOTLayer's MLP WITHOUT gelu(u), gelu'(u), du in HBM (csrc/wgrad_mlp.hip; autograd of
  * HF:545-548, 558-561): per token slice and hidden chunk the kernel recomputes u = h16·W1^T + b1 and dz·W2 and feeds gelu(u) / du from

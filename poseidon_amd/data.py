@@ -15,9 +15,9 @@ What is mirrored (reference `scOT/problems/base.py`, `scOT/problems/fluids/*.py`
     element-wise pixel mask), wave (Wave-Layer / Wave-Gauss: a static wave-speed channel passed through to the labels), Allen-Cahn,
     Poisson and Helmholtz (time-independent; ".time" wraps them with time = 1.0, base.py:372-395).  `...gravity.Blast` is named by
     the reference's registry but has no reader there (ImportError in the reference): ValueError here.
-The index machinery is pinned against the reference's own base classes (tests/golden/make_dataset_pins.py); the per-dataset
-recipes are restated from the reference's readers, which need h5py to import and are therefore unpinned here (tests compare the
-HIP batch with a numpy evaluation of the recipe).
+The index machinery is pinned against the reference's own base classes (tests/golden/make_dataset_pins.py), and so are the
+per-dataset recipes: tests/golden/make_dataset_recipe_pins.py runs the reference's readers on an h5py-shaped synthetic file source
+and pins `get_dataset(name)[i]` for every registry name (138 pins, checked on the CPU readers, the emulated device path and the GPU).
 
 MI355X-native part: `DeviceTrajectories` keeps a whole dataset in HBM (CE-RP: 10000 x 21 x 5 x 128^2 fp32 = 69 GB of 288 GB; a
 training subset far less) and `batch(indices)` gathers + normalises `pixel_values` / `labels` for a batch with ONE launch
@@ -338,11 +338,20 @@ def export_npy(reader, keys: Sequence[str], directory: str) -> None:
 
 
 def open_reader(path: str):
-    """`.nc` / `.h5` files need h5py (HDF5 / netCDF-4).  numpy-only alternatives, tried first: `<path>` itself when it is a `.npy`
-    (one memory-mapped array answering every key), a `.npz`, or a directory of per-array `.npy` files (NpyDirectory); and for a
-    `.nc` / `.h5` name, an export of it lying beside it (`<stem>.npy`, `<stem>.npz`, `<stem>/`)."""
+    """`.nc` / `.h5` files need h5py (HDF5 / netCDF-4).  numpy-only alternatives: `<path>` itself when it is a `.npy` (one
+    memory-mapped array answering every key), a `.npz`, or a directory of per-array `.npy` files (NpyDirectory); and for a `.nc` /
+    `.h5` name an export of it lying beside it (`<stem>/`, `<stem>.npy`, `<stem>.npz`) — used when the file itself is absent, and
+    BEFORE the file on a host without h5py (the case the export exists for)."""
     stem = os.path.splitext(path)[0]
-    for cand in ((path,) if path.endswith((".npy", ".npz")) or os.path.isdir(path) else (path, stem, stem + ".npy", stem + ".npz")):
+    direct = path.endswith((".npy", ".npz")) or os.path.isdir(path)
+    have_h5py = True
+    try:
+        import h5py
+    except ImportError:   # pragma: no cover - environment dependent
+        have_h5py = False
+    # with h5py the file the reference opens wins; without it (or when the file is absent) its numpy export lying beside it does
+    order = (path,) if direct else ((path, stem, stem + ".npy", stem + ".npz") if have_h5py else (stem, stem + ".npy", stem + ".npz", path))
+    for cand in order:
         if os.path.isdir(cand):
             return NpyDirectory(cand)
         if cand.endswith(".npy") and os.path.exists(cand):

@@ -74,6 +74,9 @@ class GradAllReducer:
 
     def broadcast_parameters(self, src: int = 0):
         self.dist.broadcast(self.model.flat_parameters(), src=src, group=self.group)
+        # a collective writes the arena WITHOUT moving torch's version counter (checked on torch 2.10, gloo and nccl): without this the
+        # engine of a non-source rank that has already run a forward would keep computing from 16-bit copies of its pre-broadcast weights
+        self.model.mark_weights_dirty()
 
     def ranges_in_backward_order(self):
         return group_ranges(self.model._arena, backward_order_groups(self.model.config))

@@ -174,6 +174,7 @@ class ScOTEngine:
         # from.  None (an engine built by hand): refresh at every forward.  The fused AdamW writes the copies itself.
         self.weights_version = None
         self._shadow_v = self._shadow_t_v = object()
+        self._copies_maintained = False      # True once an optimizer (FusedAdamW) writes the 16-bit copies itself
         self._build_cpb_plan()
 
     def _build_cpb_plan(self):
@@ -1204,6 +1205,7 @@ class ScOTEngine:
 
     def weight_copies_are_current(self, v):
         """the optimizer has just written both copies from master weights whose version is `v`"""
+        self._copies_maintained = True
         self._shadow_v = v
         if self.shadow_t is not None:
             self._shadow_t_v = v
@@ -1213,6 +1215,18 @@ class ScOTEngine:
         try:
             if not self._capturing():
                 self.refresh_weight_copies(train)
+            elif self.shadow is not None and not self._copies_maintained:
+                # a hipGraph is being captured and nobody but this engine keeps the 16-bit copies current (no FusedAdamW): the cast
+                # and the transposes become part of the captured step, as they were before the version gate existed — a replay after a
+                # foreign optimizer's update would otherwise multiply by stale weights for ever
+                prev_rec = ops.set_recorder(None)
+                try:
+                    ops.cast(self.arena.data, self.shadow)
+                    self.pack_fragments()
+                    if train and self.shadow_t is not None:
+                        self.transpose_weights()
+                finally:
+                    ops.set_recorder(prev_rec)
             if bool_masked_pos is not None:       # masked-position pre-training inputs: not a taped signature
                 self.stochastic = bool(train if stochastic is None else stochastic)
                 return self._forward(pixel_values, time, labels, pixel_mask, train, bool_masked_pos)

@@ -14,6 +14,7 @@ LIB_PATH = os.path.join(_HERE, "libscot_hip.so")
 # The same sources built twice (build.py): the format of the 16-bit operand type is a compile-time property (csrc/common.h).
 LIB_PATHS = {"bf16": LIB_PATH, "f16": os.path.join(_HERE, "libscot_hip_f16.so")}
 OPERAND_FORMAT = {"bf16": 0, "f16": 1}
+ABI_VERSION = 2      # scot_abi_version() of the library these prototypes describe (checked at load)
 
 P, I, F, Z = c_void_p, c_int, c_float, c_size_t
 
@@ -123,6 +124,9 @@ def load(path: str = None, kind: str = "bf16"):
         fn = getattr(lib, name)  # AttributeError if a declared symbol is missing
         fn.argtypes = argtypes
         fn.restype = restype(name)
+    if lib.scot_abi_version() != ABI_VERSION:
+        raise ScotLibraryError(f"{path} implements ABI version {lib.scot_abi_version()}, these bindings expect {ABI_VERSION}; "
+                               "rebuild with `python -m poseidon_amd.build --force`")
     if lib.scot_operand_format() != OPERAND_FORMAT[kind]:
         raise ScotLibraryError(f"{path} was built for operand format {lib.scot_operand_format()}, expected {OPERAND_FORMAT[kind]} "
                                f"({kind}); rebuild with `python -m poseidon_amd.build --force`")

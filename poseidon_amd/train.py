@@ -600,10 +600,13 @@ class Trainer:
             self._skips_seen = sk
             self.state["skipped_steps"] = sk
             entry["skipped_steps"] = sk
-            sched.last_epoch = max(0, sched.last_epoch - new)
-            for grp, lr in zip(opt.param_groups, [b * f(sched.last_epoch) for b, f in zip(sched.base_lrs, sched.lr_lambdas)]):
-                grp["lr"] = lr
-            sched._last_lr = [grp["lr"] for grp in opt.param_groups]
+            if hasattr(sched, "lr_lambdas") and hasattr(sched, "base_lrs"):      # the LambdaLR schedules this trainer builds
+                sched.last_epoch = max(0, sched.last_epoch - new)
+                for grp, lr in zip(opt.param_groups, [b * f(sched.last_epoch) for b, f in zip(sched.base_lrs, sched.lr_lambdas)]):
+                    grp["lr"] = lr
+                sched._last_lr = [grp["lr"] for grp in opt.param_groups]
+            else:       # a scheduler passed in through `optimizers=(opt, sched)`: its state is its own, it runs `new` steps ahead
+                warnings.warn(f"{type(sched).__name__} cannot be rewound: the LR schedule is {new} step(s) ahead of the applied optimizer steps")
             warnings.warn(f"{new} optimizer step(s) skipped: fp16 gradients overflowed under the loss scale "
                           f"(now {getattr(opt, 'loss_scale_value', lambda: 'n/a')()})")
         self.state["log_history"].append(entry)

@@ -363,10 +363,11 @@ class ScOT(nn.Module):
         self._gviews = [ar.gview(n) for n, _ in params]
 
     def _weights_version(self):
-        """Moves whenever the fp32 master weights may have changed: in-place torch ops on a parameter (optimizers, load_state_dict,
-        `p.add_()` under no_grad) or on the flat arena (DP broadcast) bump torch's version counters; kernels that write through raw
-        pointers (the fused AdamW) and code that writes through `p.data` call `mark_weights_dirty()`.  The engine re-casts its
-        16-bit weight copies only when this value differs from the one they were made from."""
+        """Moves whenever the fp32 master weights may have changed: in-place torch ops on a parameter or on the flat arena (optimizers,
+        load_state_dict, `p.add_()` under no_grad) bump torch's version counters; everything that writes behind torch's back — kernels
+        through raw pointers (the fused AdamW), code that writes through `p.data`, and COLLECTIVES (`dist.broadcast` / `all_reduce`
+        leave `tensor._version` unchanged: `GradAllReducer.broadcast_parameters` does it) — calls `mark_weights_dirty()`.  The engine
+        re-casts its 16-bit weight copies only when this value differs from the one they were made from."""
         return (sum(p._version for p in self._params), self._arena.data._version, self._explicit_version)
 
     def mark_weights_dirty(self):

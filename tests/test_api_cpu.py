@@ -100,11 +100,11 @@ def test_c_abi_exports_every_declared_symbol():
     assert declared == set(scotlib.PROTOTYPES.keys())
     for name in declared:
         assert getattr(lib, name) is not None
-    assert lib.scot_abi_version() == 1 and lib.scot_operand_format() == 0
+    assert lib.scot_abi_version() == scotlib.ABI_VERSION and lib.scot_operand_format() == 0
     f16 = scotlib.load(kind="f16")          # the binary16 build of the same sources exports the same C ABI
     for name in declared:
         assert getattr(f16, name) is not None
-    assert f16.scot_abi_version() == 1 and f16.scot_operand_format() == 1
+    assert f16.scot_abi_version() == scotlib.ABI_VERSION and f16.scot_operand_format() == 1
 
 
 def test_workspace_queries_answer_without_a_gpu():
