@@ -132,6 +132,13 @@ int scot_window_attn_fwd(int compute, const void* qkv, void* out, float* lse, co
 int scot_window_attn_bwd(int compute, const void* qkv, const void* out_fwd, const void* dout, const float* lse, const float* bias_table,
                          const float* logit_scale, void* dqkv, float* dbias_table, float* dlogit_scale, int batch,
                          int Hp, int Wp, int C, int heads, int ws, int shift, scot_stream_t stream);
+/* The same with the table gradient written as ONE ROW PER (window, head) — dtab_rows [batch·nW][heads][TSP], TSP = ((2ws-1)^2 + 3) & ~3,
+ * plain stores — instead of (2ws-1)^2 global atomics per workgroup onto the same few addresses (stage 0: 768 workgroups x 961);
+ * scot_table_rows_reduce adds the rows into dbias_table [heads][(2ws-1)^2] (off the backward's dependent chain). */
+int scot_window_attn_bwd_rows(int compute, const void* qkv, const void* out_fwd, const void* dout, const float* lse,
+                              const float* bias_table, const float* logit_scale, void* dqkv, float* dtab_rows, float* dlogit_scale,
+                              int batch, int Hp, int Wp, int C, int heads, int ws, int shift, scot_stream_t stream);
+int scot_table_rows_reduce(const float* rows, int nwin, int heads, int ws, float* dbias_table, scot_stream_t stream);
 /* Attention probabilities of one block, [batch·nW, heads, N, N] fp32, recomputed from qkv and the forward's log-sum-exp — what
  * `output_attentions=True` returns (HF:443-455; the fused kernels never store them).  head_dim <= 64, N·head_dim·4 <= 64 KB. */
 int scot_window_attn_probs(const void* qkv, int qkv_dt, const float* lse, const float* bias_table, const float* logit_scale,
@@ -247,6 +254,20 @@ int scot_block_tail_fwd(const void* a, const void* Wo, const float* bo, const fl
                         const void* Wqkv, const float* bqkv, void* qkv /* optional epilogue (Wqkv and qkv both or neither): the NEXT
                         layer's fused q/k/v projection qkv[M,3C] = out16 · Wqkv[3C,C]^T + bqkv (HF:396-410) on the rows just produced */,
                         int z_dt, const float* time, int M, int rows_per_sample, int C, int hid, float eps, scot_stream_t stream);
+
+/* Step tape (csrc/host_tape.hip).  The reference issues a training step op by op from Python (trainer.py via HF Trainer / autograd);
+ * this library's engine records the step once as a list of the calls of THIS header with their final arguments and replays the list.
+ * scot_tape_replay walks such a list without returning to the host language between launches: prog = records of 64-bit words
+ * {entry point address, n_int, n_flt, the integer-class arguments in order (pointers, int, size_t, the stream handle), the float
+ * arguments as raw IEEE-754 single bits}; n_int <= 48, n_flt <= 8.  Returns 0, or the first non-zero status with *fail_entry = the
+ * index of the record that returned it (nothing after it is issued).  The host-side operations a step needs between launches are
+ * entry points too, so that they can be records: memset / device-to-device copy on a stream, event record, stream-wait-event (event = a
+ * hipEvent_t). */
+int scot_memset_async(void* p, int byte, size_t n, scot_stream_t stream);
+int scot_memcpy_async(void* dst, const void* src, size_t n, scot_stream_t stream);
+int scot_event_record(void* event, scot_stream_t stream);
+int scot_stream_wait_event(scot_stream_t stream, void* event);
+int scot_tape_replay(const unsigned long long* prog, size_t n_words, int* fail_entry);
 
 /* Deep stages (C = 384 / 768; 4096 / 1024 token rows at batch 64), csrc/tail_deep.hip — the same tail (ref model.py:560-579,
  * HF:396-410, 478-489, 533-561) with SIXTEEN rows per workgroup, every weight matrix streamed from L2 straight into MFMA operand

@@ -61,6 +61,11 @@ class ScOTEngine:
         self.stochastic = False
         self.launch_timer = None    # bench.py: list that collects per-launch HIP-event timings of replayed steps
         self.tape_max = max(1, int(os.environ.get("SCOT_TAPE_MAX", "2")))
+        # ... and replayed from C: one scot_tape_replay call per run of launches instead of one ctypes call per launch (SCOT_TAPE_C=0: the
+        # Python loop over the recorded calls)
+        self.tape_c = os.environ.get("SCOT_TAPE_C", "1") == "1"
+        # attention backward: bias-table gradient through per-workgroup rows + one reduce beside the chain instead of global atomics
+        self.attn_table_rows = os.environ.get("SCOT_ATTN_TABLE_ROWS", "1") == "1"
         self._rec = None
         self._rec_keep = None
         self._taped = {}
@@ -69,6 +74,7 @@ class ScOTEngine:
         self._finq = []                                                 # per-workgroup partial sums of norm backwards waiting for their column sums (see finish_partials)
         self._in_side = None                                            # main stream while a side-stream task runs (see fork_task)
         self._task_keep, self._task_keeps = [], {}
+        self._events = []                                               # events of the current step (a recorded step keeps its own alive)
         # ConvNeXt skip blocks off the critical path: a skip's blocks only feed the decoder stage that consumes the skip (forward)
         # / the encoder stage that produced it (backward), so they run on the side stream beside the deep stages' latency-bound
         # chain instead of in front of it (SCOT_SKIP_SIDE=0: in line)
@@ -375,8 +381,45 @@ class ScOTEngine:
 
     def zeros(self, *shape, dtype=torch.float32):
         t = self.new(*shape, dtype=dtype)
-        self.tdo(t.zero_)
+        self.h_zero(t)
         return t
+
+    # Host-side operations between launches, as C-ABI calls on the GPU (so that they are ordinary tape entries and a recorded forward or
+    # backward replays as one run inside the library); torch calls on the CPU emulation of the tests.
+    def _native_host_ops(self):
+        return self.device.type == "cuda"
+
+    def h_zero(self, t):
+        if self._native_host_ops() and t.is_contiguous():
+            ops.memset_async(t, 0)
+        else:
+            self.tdo(t.zero_)
+
+    def h_copy(self, dst, src):
+        if self._native_host_ops() and dst.dtype == src.dtype and dst.is_contiguous() and src.is_contiguous() and dst.numel() == src.numel():
+            ops.memcpy_async(dst, src)
+        else:
+            self.tdo(lambda: dst.copy_(src))
+
+    def _event(self):
+        """a torch event whose HIP handle exists (torch creates it at the first record), alive as long as the launches that name it: for
+        good inside a recorded step, until the next forward otherwise"""
+        ev = torch.cuda.Event()
+        ev.record()
+        (self._rec_keep if self._rec is not None else self._events).append(ev)
+        return ev
+
+    def h_record(self, ev, stream):
+        if self._native_host_ops():
+            ops.event_record(ev.cuda_event, stream.cuda_stream)
+        else:
+            self.tdo(lambda: ev.record(stream))
+
+    def h_wait(self, stream, ev):
+        if self._native_host_ops():
+            ops.stream_wait_event(stream.cuda_stream, ev.cuda_event)
+        else:
+            self.tdo(lambda: stream.wait_event(ev))
 
     def tdo(self, fn):
         """Host-side operation that is part of the step but not a C-ABI launch (torch memset/copy, event record, stream
@@ -423,7 +466,7 @@ class ScOTEngine:
 
     def clone(self, t):
         y = self.new(*t.shape, dtype=t.dtype)
-        self.tdo(lambda: y.copy_(t))
+        self.h_copy(y, t)
         return y
 
     def coords(self, ws: int) -> torch.Tensor:
@@ -534,12 +577,9 @@ class ScOTEngine:
 
     def _run_side(self, fns):
         self.side_stream()
-        ev, cur, side = torch.cuda.Event(), torch.cuda.current_stream(), self.side
-
-        def fork():
-            ev.record(cur)
-            side.wait_event(ev)
-        self.tdo(fork)
+        ev, cur, side = self._event(), torch.cuda.current_stream(), self.side
+        self.h_record(ev, cur)
+        self.h_wait(side, ev)
         prev = ops.set_workspace_slot(1)
         try:
             with torch.cuda.stream(side):
@@ -568,8 +608,8 @@ class ScOTEngine:
                 self._in_side = None
         self._task_keep = []
         self._run_side([run])
-        ev, side = torch.cuda.Event(), self.side
-        self.tdo(lambda: ev.record(side))
+        ev, side = self._event(), self.side
+        self.h_record(ev, side)
         # temporaries of the task come from the main stream's pool: returning them before the main stream is ordered behind the
         # task would hand memory that side-stream kernels still use to the next main-stream allocation
         self._task_keeps[ev], self._task_keep = self._task_keep, []
@@ -578,7 +618,7 @@ class ScOTEngine:
     def wait_task(self, ev):
         if ev is not None:
             cur = torch.cuda.current_stream()
-            self.tdo(lambda: cur.wait_event(ev))
+            self.h_wait(cur, ev)
             self._task_keeps.pop(ev, None)
 
     def finish_partials(self):
@@ -601,7 +641,9 @@ class ScOTEngine:
         self.flush_side()
         if self.use_side and self.side is not None:
             cur, side = torch.cuda.current_stream(), self.side
-            self.tdo(lambda: cur.wait_stream(side))
+            ev = self._event()
+            self.h_record(ev, side)
+            self.h_wait(cur, ev)
             self._keep.clear()
             self._task_keeps.clear()
 
@@ -1037,8 +1079,17 @@ class ScOTEngine:
             d_attn_p = d_attn
         d_qkv = self.new(B * Lp, 3 * C, dtype=adt)
         d_table = self.cpb_table(pre, grad=True)   # zeroed once per backward; its MLP backward is batched per stage
-        ops.window_attn_bwd(self.acm, rec["qkv"], rec["attn_p"], d_attn_p, rec["lse"], rec["table"], self.P(a + "logit_scale"), d_qkv, d_table,
-                            self.G(a + "logit_scale"), B, Hp, Wp, C, heads, ws, shift)
+        if self.attn_table_rows:
+            # the table gradient as one plain row per (window, head); the sum over the windows runs beside the chain, in front of the
+            # stage's bias-MLP backward on the same stream
+            nwin = B * (Hp // ws) * (Wp // ws)
+            rows = self.new(nwin * heads * ops.table_row_floats(ws))
+            ops.window_attn_bwd_rows(self.acm, rec["qkv"], rec["attn_p"], d_attn_p, rec["lse"], rec["table"], self.P(a + "logit_scale"), d_qkv,
+                                     rows, self.G(a + "logit_scale"), B, Hp, Wp, C, heads, ws, shift)
+            self.off_critical_path(lambda: ops.table_rows_reduce(rows, nwin, heads, ws, d_table), rows)
+        else:
+            ops.window_attn_bwd(self.acm, rec["qkv"], rec["attn_p"], d_attn_p, rec["lse"], rec["table"], self.P(a + "logit_scale"), d_qkv, d_table,
+                                self.G(a + "logit_scale"), B, Hp, Wp, C, heads, ws, shift)
         wqkv = self.Wspan(a + "qkv_weight", 3 * C * C).view(3 * C, C)
         gwqkv = self.arena.span(a + "qkv_weight", 3 * C * C, grad=True).view(3 * C, C)
         self.wgrad(cm, d_qkv, rec["xp"], gwqkv, dbias=self.arena.span(a + "qkv_bias", 3 * C, grad=True) if cfg.qkv_bias else None)
@@ -1253,6 +1304,7 @@ class ScOTEngine:
         (forward-forward-backward-backward, the reference's AR training loop trainer.py:466-490, takes the untaped path for
         the second forward); loss and prediction are returned as fresh tensors, never as views of the recorded buffers."""
         self.stochastic = bool(train if stochastic is None else stochastic)
+        self._events.clear()          # (the previous step's: a destroyed event's pending work completes regardless)
         if not (train and self.tape_mode and labels is not None and not self.stage_timing and not self.collect_attn) or self._capturing():
             return self._forward(pixel_values, time, labels, pixel_mask, train)
         key = (tuple(pixel_values.shape), None if time is None else tuple(time.shape), tuple(labels.shape),
@@ -1276,7 +1328,7 @@ class ScOTEngine:
             for dst, src in zip(ent["in"], ins):
                 if dst is not None:
                     dst.copy_(src)
-            self._replay(ent["fwd"])
+            self._replay(ent["fwd"], ent.get("fwd_c"))
             loss, pred, tape = ent["out"]
             tok = _Token()
             ent["pending"] = weakref.ref(tok)
@@ -1291,6 +1343,7 @@ class ScOTEngine:
         finally:
             ops.set_recorder(prev)
             ent["fwd"], ent["keep"] = self._rec, self._rec_keep
+            ent["fwd_c"] = ops.compile_tape(self._rec) if self.tape_c else None
             self._rec = self._rec_keep = None
         tape["_ent"] = ent
         ent["out"] = (loss, pred, tape)
@@ -1305,10 +1358,12 @@ class ScOTEngine:
     def _stream_id(self):
         return torch.cuda.current_stream().cuda_stream if self.device.type == "cuda" else 0
 
-    def _replay(self, cmds):
+    def _replay(self, cmds, compiled=None):
         timer = self.launch_timer
         if timer is not None:
             return self._replay_timed(cmds, timer)
+        if compiled is not None:
+            return ops.replay_tape(compiled)
         for fn, args in cmds:
             if args is None:
                 fn()
@@ -1322,9 +1377,15 @@ class ScOTEngine:
         argument) — bench.py's live per-kernel durations inside a real step (`engine.launch_timer = []` switches it on;
         entries are (entry point, arguments, start event, end event))."""
         streams = {}
+        host_ops = ("scot_event_record", "scot_stream_wait_event", "scot_memset_async", "scot_memcpy_async")
         for fn, args in cmds:
             if args is None:
                 fn()
+                continue
+            if getattr(fn, "__name__", "") in host_ops:       # stream / event plumbing and memsets: issued, not timed
+                rc = fn(*args)
+                if rc:
+                    raise RuntimeError(f"step tape: {fn.__name__} returned {rc}")
                 continue
             h = args[-1] or 0
             st = streams.get(h)
@@ -1355,7 +1416,7 @@ class ScOTEngine:
                 ent["dloss"].fill_(1.0)
             else:
                 ent["dloss"].copy_(dloss.reshape(1))
-            self._replay(ent["bwd"])
+            self._replay(ent["bwd"], ent.get("bwd_c"))
             return
         ent["dloss"] = torch.ones(1, device=self.device) if dloss is None else dloss.reshape(1).to(torch.float32).clone()
         self._rec, self._rec_keep = [], ent["keep"]
@@ -1365,6 +1426,7 @@ class ScOTEngine:
         finally:
             ops.set_recorder(prev)
             ent["bwd"] = self._rec
+            ent["bwd_c"] = ops.compile_tape(self._rec) if self.tape_c else None
             self._rec = self._rec_keep = None
         ent["state"] = "ready"
 
@@ -1555,7 +1617,7 @@ class ScOTEngine:
             if ev is not None:
                 torch.cuda.current_stream().wait_event(ev)
         self.tdo_dynamic(fill_done)
-        self.tdo(self.cpb_dtables.zero_)
+        self.h_zero(self.cpb_dtables)
         self.mark("bwd head")
         _, Cout, H, W = hd["shape"]
         p = cfg.patch_size
@@ -1577,7 +1639,7 @@ class ScOTEngine:
                 dl_in = dloss
                 dloss = self.new(1)
                 if dl_in is None:
-                    self.tdo(lambda: dloss.copy_(S_dev))
+                    self.h_copy(dloss, S_dev)
                 else:
                     self.tdo(lambda: torch.mul(dl_in.reshape(1), S_dev, out=dloss))
         # loss → d pred

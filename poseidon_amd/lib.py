@@ -34,6 +34,8 @@ PROTOTYPES = {
     "scot_window_attn_fwd": [I, P, P, P, P, P, I, I, I, I, I, I, I, P],
     "scot_window_attn_probs": [P, I, P, P, P, P, I, I, I, I, I, I, I, P],
     "scot_window_attn_bwd": [I, P, P, P, P, P, P, P, P, P, I, I, I, I, I, I, I, P],
+    "scot_window_attn_bwd_rows": [I, P, P, P, P, P, P, P, P, P, I, I, I, I, I, I, I, P],
+    "scot_table_rows_reduce": [P, I, I, I, P, P],
     "scot_cpb_fwd": [P, P, P, P, P, P, I, I, P],
     "scot_cpb_bwd": [P, P, P, P, P, P, P, P, P, I, I, P],
     "scot_cpb_fwd_batched": [P, P, I, I, P, P, P, P],
@@ -49,6 +51,11 @@ PROTOTYPES = {
     "scot_wgrad_mlp": [P, P, P, P, P, P, P, P, P, I, I, I, P, Z, P],
     "scot_transpose_cast": [P, P, P, I, I, P],
     "scot_block_tail_fwd": [P] * 33 + [I, P, I, I, I, I, F, P],
+    "scot_memset_async": [P, I, Z, P],
+    "scot_memcpy_async": [P, P, Z, P],
+    "scot_event_record": [P, P],
+    "scot_stream_wait_event": [P, P],
+    "scot_tape_replay": [P, Z, P],
     "scot_fragpack": [P, P, P, I, I, P],
     "scot_deep_tail_fwd": [P] * 33 + [I, P, I, I, I, I, F, I, P, P],
     "scot_deep_tail_finish": [P, I, P, P, P, P, P, I, P, P, P, P, P, P, P, P, I, I, I, F, P],

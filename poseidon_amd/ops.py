@@ -235,6 +235,24 @@ def window_attn_bwd(compute, qkv, out_fwd, dout, lse, bias_table, logit_scale, d
                "scot_window_attn_bwd")
 
 
+def window_attn_bwd_rows(compute, qkv, out_fwd, dout, lse, bias_table, logit_scale, dqkv, dtab_rows, dlogit_scale, batch, Hp, Wp, C, heads, ws,
+                         shift):
+    """window_attn_bwd with the bias-table gradient as one row per (window, head) in dtab_rows [windows, heads, table_row_floats(ws)]
+    (plain stores) instead of global atomics into the table gradient; table_rows_reduce sums the rows."""
+    _lib.check(L().scot_window_attn_bwd_rows(compute, ptr(qkv), ptr(out_fwd), ptr(dout), ptr(lse), ptr(bias_table), ptr(logit_scale), ptr(dqkv),
+                                             ptr(dtab_rows), ptr(dlogit_scale), batch, Hp, Wp, C, heads, ws, shift, stream()),
+               "scot_window_attn_bwd_rows")
+
+
+def table_row_floats(ws: int) -> int:
+    return ((2 * ws - 1) ** 2 + 3) & ~3
+
+
+def table_rows_reduce(rows, nwin, heads, ws, dbias_table):
+    """dbias_table [heads, (2ws-1)^2] += Σ_windows rows"""
+    _lib.check(L().scot_table_rows_reduce(ptr(rows), nwin, heads, ws, ptr(dbias_table), stream()), "scot_table_rows_reduce")
+
+
 def cpb_fwd(coords, w0, b0, w2, table, z, ws, heads):
     _lib.check(L().scot_cpb_fwd(ptr(coords), ptr(w0), ptr(b0), ptr(w2), ptr(table), ptr(z), ws, heads, stream()), "scot_cpb_fwd")
 
@@ -316,6 +334,80 @@ def block_tail_bwd(g, g_out, mlp, proj, time, rows, rows_per_sample, C, hid, dqk
         return False
     _lib.check(rc, "scot_block_tail_bwd")
     return True
+
+
+def memset_async(t, byte: int = 0):
+    """t's bytes <- byte on the current stream (scot_memset_async: a tape entry instead of a torch call between launches)"""
+    _lib.check(L().scot_memset_async(ptr(t), int(byte), t.numel() * t.element_size(), stream()), "scot_memset_async")
+
+
+def memcpy_async(dst, src):
+    """dst <- src (same dtype, contiguous, same device) on the current stream"""
+    if dst.dtype != src.dtype or dst.numel() != src.numel() or not dst.is_contiguous() or not src.is_contiguous():
+        raise TypeError("memcpy_async: contiguous tensors of one dtype and size")
+    _lib.check(L().scot_memcpy_async(ptr(dst), ptr(src), dst.numel() * dst.element_size(), stream()), "scot_memcpy_async")
+
+
+def event_record(event_handle: int, stream_handle):
+    _lib.check(L().scot_event_record(event_handle, stream_handle), "scot_event_record")
+
+
+def stream_wait_event(stream_handle, event_handle: int):
+    _lib.check(L().scot_stream_wait_event(stream_handle, event_handle), "scot_stream_wait_event")
+
+
+def compile_tape(cmds):
+    """A recorded list of (ctypes function, arguments) / (python callable, None) -> segments: ("c", program buffer, words, kept objects)
+    for every run of C-ABI calls (scot_tape_replay's word format, include/scot_hip.h), ("py", callable) for a host-side step."""
+    import ctypes
+    import struct
+    segs, words, keep = [], [], []
+
+    def flush():
+        if words:
+            buf = (ctypes.c_uint64 * len(words))(*words)
+            segs.append(("c", buf, len(words), list(keep)))
+            words.clear()
+            keep.clear()
+    for fn, args in cmds:
+        if args is None:
+            flush()
+            segs.append(("py", fn))
+            continue
+        ints, flts = [], []
+        for a, t in zip(args, fn.argtypes):
+            if t is ctypes.c_float:
+                flts.append(struct.unpack("<I", struct.pack("<f", float(a)))[0])
+            elif a is None:
+                ints.append(0)
+            elif isinstance(a, int):
+                ints.append(a & 0xFFFFFFFFFFFFFFFF)
+            elif isinstance(a, ctypes.c_void_p):
+                ints.append(a.value or 0)
+            elif isinstance(a, ctypes.Array):
+                ints.append(ctypes.addressof(a))
+                keep.append(a)
+            else:
+                raise TypeError(f"compile_tape: argument {a!r} of {fn.__name__}")
+        if len(args) != len(fn.argtypes) or len(ints) > 48 or len(flts) > 8:
+            raise TypeError(f"compile_tape: {fn.__name__} does not fit the replay's calling convention")
+        words += [ctypes.cast(fn, ctypes.c_void_p).value, len(ints), len(flts)] + ints + flts
+    flush()
+    return segs
+
+
+def replay_tape(segs):
+    """issue a compiled tape (the library handle is the ACTIVE build's: the entry points inside the program carry their own addresses)"""
+    import ctypes
+    lib = _raw()
+    fail = ctypes.c_int(-1)
+    for seg in segs:
+        if seg[0] == "py":
+            seg[1]()
+        else:
+            rc = lib.scot_tape_replay(seg[1], seg[2], ctypes.byref(fail))
+            if rc:
+                raise _lib.ScotLibraryError(f"step tape: entry {fail.value} of a replayed run returned {rc}")
 
 
 def fragpack(w, wf16, desc, n: int, blocks: int):

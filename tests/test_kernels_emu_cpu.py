@@ -181,6 +181,13 @@ def test_window_attention_fwd_bwd(emu, case):
     assert rel(dqkv, q64.grad) < tol_g
     assert rel(dtab, t64.grad) < tol_g
     assert rel(dls, l64.grad) < (2e-4 if compute == ops.F32 else 2e-3 if compute == ops.X3 else 0.15)
+    # table gradient through one row per (window, head) + the reduce the engine runs beside the chain
+    dqkv2 = torch.full((B, L, 3 * C), float("nan"), dtype=cdt)
+    dtab2, dls2 = torch.zeros(heads, TS), torch.zeros(heads)
+    rows = torch.full((B * nW * heads * ops.table_row_floats(ws),), float("nan"))
+    ops.window_attn_bwd_rows(compute, qkv, out, dout, lse, table, ls, dqkv2, rows, dls2, B, Hp, Wp, C, heads, ws, shift)
+    ops.table_rows_reduce(rows, B * nW, heads, ws, dtab2)
+    assert torch.equal(dqkv2, dqkv) and rel(dtab2, dtab) < 1e-5
 
 
 # ---- the fused block kernels of csrc/mlp_fused.hip: the bodies of their (still gated) GPU parity tests, run here on CPU tensors
@@ -321,3 +328,66 @@ def test_optimizer_kernels_skip_clock_scale_and_operand_copy(emu):
     x[3] = float("inf")
     ops.scale_inplace_dev(x, scale_state[0:1], cnt)
     assert int(cnt) == 1 and np.isinf(x[3].item())
+
+
+def test_step_tape_program_is_the_recorded_call_sequence(emu):
+    """ops.compile_tape / scot_tape_replay (csrc/host_tape.hip): the program replayed inside the library is, entry by entry, the list of
+    C-ABI calls the recorder logged (same entry points, same integer-class and float arguments in order), host-side steps cut it into
+    runs, and replaying it reproduces the direct calls — including a 21-argument entry point with a float in the middle (scot_cln_fwd)
+    and entry points whose arguments spill to the stack."""
+    import ctypes
+    import struct
+    M, N, K, C = 64, 32, 32, 32
+    x, w, b = rnd(M, K, dtype=torch.bfloat16), rnd(N, K, dtype=torch.bfloat16, seed=1), rnd(N, seed=2)
+    resid = rnd(M, N, seed=3)
+    gw, gb = 1 + rnd(C, seed=4, scale=0.1), rnd(C, seed=5, scale=0.1)
+
+    def run(y, out, out16, mean, rstd, scratch, marks):
+        ops.memset_async(scratch, 0x3f)
+        ops.linear_fwd(ops.BF16, x, w, y, bias=b)
+        marks.append("host step")
+        ops.cln_fwd(y, resid, out, mean, rstd, None, None, gw, None, gb, M, M, C, 1e-5, out2=out16)
+        ops.memcpy_async(scratch, mean)
+
+    def bufs():
+        return (torch.empty(M, N), torch.empty(M, C), torch.empty(M, C, dtype=torch.bfloat16), torch.empty(M), torch.empty(M),
+                torch.zeros(M))
+    ref = bufs()
+    run(*ref, [])
+    got = bufs()
+    log, marks = [], []
+    prev = ops.set_recorder(log)
+    try:
+        ops.memset_async(got[5], 0x3f)
+        ops.linear_fwd(ops.BF16, x, w, got[0], bias=b)
+        log.append((lambda: marks.append("host step"), None))
+        ops.cln_fwd(got[0], resid, got[1], got[3], got[4], None, None, gw, None, gb, M, M, C, 1e-5, out2=got[2])
+        ops.memcpy_async(got[5], got[3])
+    finally:
+        ops.set_recorder(prev)
+    segs = ops.compile_tape(log)
+    assert [s[0] for s in segs] == ["c", "py", "c"]
+    # decode the words back into (address, ints, floats) and compare with the log
+    calls = [(fn, args) for fn, args in log if args is not None]
+    decoded = []
+    for s in segs:
+        if s[0] != "c":
+            continue
+        words, i = list(s[1]), 0
+        while i < s[2]:
+            ni, nf = words[i + 1], words[i + 2]
+            decoded.append((words[i], words[i + 3:i + 3 + ni], words[i + 3 + ni:i + 3 + ni + nf]))
+            i += 3 + ni + nf
+    assert len(decoded) == len(calls) == 4
+    for (addr, ints, flts), (fn, args) in zip(decoded, calls):
+        assert addr == ctypes.cast(fn, ctypes.c_void_p).value
+        want_i = [(0 if a is None else a & 0xFFFFFFFFFFFFFFFF) for a, t in zip(args, fn.argtypes) if t is not ctypes.c_float]
+        want_f = [struct.unpack("<I", struct.pack("<f", a))[0] for a, t in zip(args, fn.argtypes) if t is ctypes.c_float]
+        assert ints == want_i and flts == want_f
+    for t in got:
+        t.fill_(float("nan")) if t.dtype != torch.bfloat16 else t.zero_()
+    marks.clear()
+    ops.replay_tape(segs)
+    assert marks == ["host step"]
+    for a, r in zip(got, ref):
+        assert torch.equal(a, r)
