@@ -132,13 +132,6 @@ int scot_window_attn_fwd(int compute, const void* qkv, void* out, float* lse, co
 int scot_window_attn_bwd(int compute, const void* qkv, const void* out_fwd, const void* dout, const float* lse, const float* bias_table,
                          const float* logit_scale, void* dqkv, float* dbias_table, float* dlogit_scale, int batch,
                          int Hp, int Wp, int C, int heads, int ws, int shift, scot_stream_t stream);
-/* The same with the table gradient written as ONE ROW PER (window, head) — dtab_rows [batch·nW][heads][TSP], TSP = ((2ws-1)^2 + 3) & ~3,
- * plain stores — instead of (2ws-1)^2 global atomics per workgroup onto the same few addresses (stage 0: 768 workgroups x 961);
- * scot_table_rows_reduce adds the rows into dbias_table [heads][(2ws-1)^2] (off the backward's dependent chain). */
-int scot_window_attn_bwd_rows(int compute, const void* qkv, const void* out_fwd, const void* dout, const float* lse,
-                              const float* bias_table, const float* logit_scale, void* dqkv, float* dtab_rows, float* dlogit_scale,
-                              int batch, int Hp, int Wp, int C, int heads, int ws, int shift, scot_stream_t stream);
-int scot_table_rows_reduce(const float* rows, int nwin, int heads, int ws, float* dbias_table, scot_stream_t stream);
 /* Attention probabilities of one block, [batch·nW, heads, N, N] fp32, recomputed from qkv and the forward's log-sum-exp — what
  * `output_attentions=True` returns (HF:443-455; the fused kernels never store them).  head_dim <= 64, N·head_dim·4 <= 64 KB. */
 int scot_window_attn_probs(const void* qkv, int qkv_dt, const float* lse, const float* bias_table, const float* logit_scale,

@@ -12,8 +12,6 @@ struct AttnArgs {
   const float* bias_table;   // [heads][(2ws-1)^2]  = 16·sigmoid(CPB-MLP)
   const float* logit_scale;  // [heads]
   float* dbias_table;        // bwd, atomically accumulated
-  float* dtab_part;          // bwd, optional: [windows][heads][TSP] — each (window, head) workgroup STORES its table-gradient row here
-                             // instead of adding it into dbias_table with TS global atomics (scot_table_partial_reduce sums the rows)
   float* dlogit_scale;       // bwd, atomically accumulated
   int C, heads, Hp, Wp, ws, shift, nwx, nw_per_img;
   int use_tr;

@@ -303,12 +303,7 @@ __device__ __forceinline__ void attn_bwd_dq_body(const AttnArgs& p) {
   dls = wave_sum(dls);
   if (lane == 0) red[wave] = dls;
   __syncthreads();
-  if (p.dtab_part) {
-    float* row = p.dtab_part + ((size_t)win * p.heads + h) * TSP;
-    for (int i = tid; i < TS; i += nthr) row[i] = (float)dtab[i];
-  } else {
-    for (int i = tid; i < TS; i += nthr) atomicAdd(&p.dbias_table[h * TS + i], (float)dtab[i]);
-  }
+  for (int i = tid; i < TS; i += nthr) atomicAdd(&p.dbias_table[h * TS + i], (float)dtab[i]);
   if (tid == 0 && p.logit_scale[h] <= 4.605170185988092f) {
     float tot = 0.f;
     for (int w = 0; w < nwv; ++w) tot += red[w];
@@ -564,53 +559,15 @@ extern "C" int scot_window_attn_probs(const void* qkv, int qkv_dt, const float* 
   return scot_check_launch();
 }
 
-// include/scot_hip.h: scot_window_attn_bwd_rows — as scot_window_attn_bwd, the table gradient as one row per (window, head)
-static int attn_bwd_impl(int compute, const void* qkv, const void* out_fwd, const void* dout, const float* lse,
-                         const float* bias_table, const float* logit_scale, void* dqkv,
-                         float* dbias_table, float* dtab_part, float* dlogit_scale, int batch, int Hp, int Wp, int C,
-                         int heads, int ws, int shift, hipStream_t stream);
 extern "C" int scot_window_attn_bwd(int compute, const void* qkv, const void* out_fwd, const void* dout, const float* lse,
                                     const float* bias_table, const float* logit_scale, void* dqkv,
                                     float* dbias_table, float* dlogit_scale, int batch, int Hp, int Wp, int C,
                                     int heads, int ws, int shift, hipStream_t stream) {
-  return attn_bwd_impl(compute, qkv, out_fwd, dout, lse, bias_table, logit_scale, dqkv, dbias_table, nullptr, dlogit_scale, batch, Hp, Wp, C,
-                       heads, ws, shift, stream);
-}
-extern "C" int scot_window_attn_bwd_rows(int compute, const void* qkv, const void* out_fwd, const void* dout, const float* lse,
-                                         const float* bias_table, const float* logit_scale, void* dqkv,
-                                         float* dtab_rows, float* dlogit_scale, int batch, int Hp, int Wp, int C,
-                                         int heads, int ws, int shift, hipStream_t stream) {
-  if (!dtab_rows) return SCOT_ERR_SHAPE;
-  return attn_bwd_impl(compute, qkv, out_fwd, dout, lse, bias_table, logit_scale, dqkv, nullptr, dtab_rows, dlogit_scale, batch, Hp, Wp, C,
-                       heads, ws, shift, stream);
-}
-// dbias_table[h][i] += Σ_w rows[w][h][i]; rows [nwin][heads][TSP] with TSP = (TS + 3) & ~3, TS = (2 ws - 1)^2
-__global__ __launch_bounds__(256) void table_rows_reduce_kernel(const float* __restrict__ rows, int nwin, int heads, int TS, int TSP,
-                                                                float* __restrict__ dbias_table, int wchunk) {
-  const int i = blockIdx.x * 256 + threadIdx.x, h = blockIdx.y;
-  if (i >= TS) return;
-  const int w0 = blockIdx.z * wchunk, w1 = min(nwin, w0 + wchunk);
-  float acc = 0.f;
-  for (int w = w0; w < w1; ++w) acc += rows[((size_t)w * heads + h) * TSP + i];
-  atomicAdd(&dbias_table[h * TS + i], acc);
-}
-extern "C" int scot_table_rows_reduce(const float* rows, int nwin, int heads, int ws, float* dbias_table, hipStream_t stream) {
-  if (!rows || !dbias_table || nwin <= 0 || heads <= 0 || ws <= 0) return SCOT_ERR_SHAPE;
-  const int TW = 2 * ws - 1, TS = TW * TW, TSP = (TS + 3) & ~3;
-  const int wchunk = 16;
-  hipLaunchKernelGGL(table_rows_reduce_kernel, dim3((TS + 255) / 256, heads, (nwin + wchunk - 1) / wchunk), dim3(256), 0, stream, rows, nwin,
-                     heads, TS, TSP, dbias_table, wchunk);
-  return scot_check_launch();
-}
-static int attn_bwd_impl(int compute, const void* qkv, const void* out_fwd, const void* dout, const float* lse,
-                         const float* bias_table, const float* logit_scale, void* dqkv,
-                         float* dbias_table, float* dtab_part, float* dlogit_scale, int batch, int Hp, int Wp, int C,
-                         int heads, int ws, int shift, hipStream_t stream) {
   AttnArgs a{};
   int rc = fill_args(a, batch, Hp, Wp, C, heads, ws, shift);
   if (rc) return rc;
   a.qkv = qkv; a.out = dqkv; a.dout = dout; a.ofwd = out_fwd; a.lse = (float*)lse; a.bias_table = bias_table; a.logit_scale = logit_scale;
-  a.dbias_table = dbias_table; a.dtab_part = dtab_part; a.dlogit_scale = dlogit_scale;
+  a.dbias_table = dbias_table; a.dlogit_scale = dlogit_scale;
   const int nwin = batch * a.nw_per_img;
   rc = scot_attn_w16(a, compute, C / heads, nwin, true, stream);
   if (rc != SCOT_ERR_UNSUPPORTED) return rc;

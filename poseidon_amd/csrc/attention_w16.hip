@@ -501,15 +501,10 @@ __device__ __forceinline__ void attn16_bwd_dq_body(const AttnArgs& p) {
   __syncthreads();
   // (every (window, head) workgroup of a head flushes the same 961 addresses: start each one somewhere else so that concurrent
   // workgroups do not queue up on the same L2 atomic unit in lockstep)
-  if (p.dtab_part) {       // one plain row per workgroup; summed over the windows off the chain
-    float* row = p.dtab_part + ((size_t)win * p.heads + h) * W16::TSP;
-    for (int i = tid; i < W16::TS; i += blockDim.x) row[i] = (float)dtab[i];
-  } else {
-    for (int i = tid; i < W16::TS; i += blockDim.x) {
-      int k = i + (win % 31) * 31;
-      k = k >= W16::TS ? k - W16::TS : k;
-      atomicAdd(&p.dbias_table[h * W16::TS + k], (float)dtab[k]);
-    }
+  for (int i = tid; i < W16::TS; i += blockDim.x) {
+    int k = i + (win % 31) * 31;
+    k = k >= W16::TS ? k - W16::TS : k;
+    atomicAdd(&p.dbias_table[h * W16::TS + k], (float)dtab[k]);
   }
   if (tid == 0 && p.logit_scale[h] <= 4.605170185988092f) {
     float r = 0.f;

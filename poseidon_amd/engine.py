@@ -64,8 +64,6 @@ class ScOTEngine:
         # ... and replayed from C: one scot_tape_replay call per run of launches instead of one ctypes call per launch (SCOT_TAPE_C=0: the
         # Python loop over the recorded calls)
         self.tape_c = os.environ.get("SCOT_TAPE_C", "1") == "1"
-        # attention backward: bias-table gradient through per-workgroup rows + one reduce beside the chain instead of global atomics
-        self.attn_table_rows = os.environ.get("SCOT_ATTN_TABLE_ROWS", "1") == "1"
         self._rec = None
         self._rec_keep = None
         self._taped = {}
@@ -1079,17 +1077,8 @@ class ScOTEngine:
             d_attn_p = d_attn
         d_qkv = self.new(B * Lp, 3 * C, dtype=adt)
         d_table = self.cpb_table(pre, grad=True)   # zeroed once per backward; its MLP backward is batched per stage
-        if self.attn_table_rows:
-            # the table gradient as one plain row per (window, head); the sum over the windows runs beside the chain, in front of the
-            # stage's bias-MLP backward on the same stream
-            nwin = B * (Hp // ws) * (Wp // ws)
-            rows = self.new(nwin * heads * ops.table_row_floats(ws))
-            ops.window_attn_bwd_rows(self.acm, rec["qkv"], rec["attn_p"], d_attn_p, rec["lse"], rec["table"], self.P(a + "logit_scale"), d_qkv,
-                                     rows, self.G(a + "logit_scale"), B, Hp, Wp, C, heads, ws, shift)
-            self.off_critical_path(lambda: ops.table_rows_reduce(rows, nwin, heads, ws, d_table), rows)
-        else:
-            ops.window_attn_bwd(self.acm, rec["qkv"], rec["attn_p"], d_attn_p, rec["lse"], rec["table"], self.P(a + "logit_scale"), d_qkv, d_table,
-                                self.G(a + "logit_scale"), B, Hp, Wp, C, heads, ws, shift)
+        ops.window_attn_bwd(self.acm, rec["qkv"], rec["attn_p"], d_attn_p, rec["lse"], rec["table"], self.P(a + "logit_scale"), d_qkv, d_table,
+                            self.G(a + "logit_scale"), B, Hp, Wp, C, heads, ws, shift)
         wqkv = self.Wspan(a + "qkv_weight", 3 * C * C).view(3 * C, C)
         gwqkv = self.arena.span(a + "qkv_weight", 3 * C * C, grad=True).view(3 * C, C)
         self.wgrad(cm, d_qkv, rec["xp"], gwqkv, dbias=self.arena.span(a + "qkv_bias", 3 * C, grad=True) if cfg.qkv_bias else None)

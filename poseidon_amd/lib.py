@@ -34,8 +34,6 @@ PROTOTYPES = {
     "scot_window_attn_fwd": [I, P, P, P, P, P, I, I, I, I, I, I, I, P],
     "scot_window_attn_probs": [P, I, P, P, P, P, I, I, I, I, I, I, I, P],
     "scot_window_attn_bwd": [I, P, P, P, P, P, P, P, P, P, I, I, I, I, I, I, I, P],
-    "scot_window_attn_bwd_rows": [I, P, P, P, P, P, P, P, P, P, I, I, I, I, I, I, I, P],
-    "scot_table_rows_reduce": [P, I, I, I, P, P],
     "scot_cpb_fwd": [P, P, P, P, P, P, I, I, P],
     "scot_cpb_bwd": [P, P, P, P, P, P, P, P, P, I, I, P],
     "scot_cpb_fwd_batched": [P, P, I, I, P, P, P, P],

@@ -235,24 +235,6 @@ def window_attn_bwd(compute, qkv, out_fwd, dout, lse, bias_table, logit_scale, d
                "scot_window_attn_bwd")
 
 
-def window_attn_bwd_rows(compute, qkv, out_fwd, dout, lse, bias_table, logit_scale, dqkv, dtab_rows, dlogit_scale, batch, Hp, Wp, C, heads, ws,
-                         shift):
-    """window_attn_bwd with the bias-table gradient as one row per (window, head) in dtab_rows [windows, heads, table_row_floats(ws)]
-    (plain stores) instead of global atomics into the table gradient; table_rows_reduce sums the rows."""
-    _lib.check(L().scot_window_attn_bwd_rows(compute, ptr(qkv), ptr(out_fwd), ptr(dout), ptr(lse), ptr(bias_table), ptr(logit_scale), ptr(dqkv),
-                                             ptr(dtab_rows), ptr(dlogit_scale), batch, Hp, Wp, C, heads, ws, shift, stream()),
-               "scot_window_attn_bwd_rows")
-
-
-def table_row_floats(ws: int) -> int:
-    return ((2 * ws - 1) ** 2 + 3) & ~3
-
-
-def table_rows_reduce(rows, nwin, heads, ws, dbias_table):
-    """dbias_table [heads, (2ws-1)^2] += Σ_windows rows"""
-    _lib.check(L().scot_table_rows_reduce(ptr(rows), nwin, heads, ws, ptr(dbias_table), stream()), "scot_table_rows_reduce")
-
-
 def cpb_fwd(coords, w0, b0, w2, table, z, ws, heads):
     _lib.check(L().scot_cpb_fwd(ptr(coords), ptr(w0), ptr(b0), ptr(w2), ptr(table), ptr(z), ws, heads, stream()), "scot_cpb_fwd")
 

@@ -211,16 +211,6 @@ def _window_attention_fwd_bwd(compute, case, half):
     assert rel(dtab, t64.grad) < tol_g, "dbias_table"
     # d logit_scale is a heavily cancelling sum over all (q,k) pairs: bf16 operand rounding shows up amplified
     assert rel(dls, l64.grad) < tol_ls, "dlogit_scale"
-    # the same backward with the table gradient as one row per (window, head) + scot_table_rows_reduce (what the engine runs): the data
-    # gradients bit for bit, the table gradient to summation order
-    dqkv2 = torch.full((B, L, 3 * C), float("nan"), device=DEV, dtype=cdt)
-    dtab2, dls2 = torch.zeros(heads, TS, device=DEV), torch.zeros(heads, device=DEV)
-    rows = torch.full((B * nW * heads * ops.table_row_floats(ws),), float("nan"), device=DEV)
-    ops.window_attn_bwd_rows(compute, qkv, out, dout, lse, table, ls, dqkv2, rows, dls2, B, Hp, Wp, C, heads, ws, shift)
-    ops.table_rows_reduce(rows, B * nW, heads, ws, dtab2)
-    torch.cuda.synchronize()
-    assert torch.equal(dqkv2, dqkv)
-    assert rel(dtab2, dtab) < 1e-5 and rel(dls2, dls) < 1e-5
 
 
 # ----------------------------------------------------------------------------------------------- CLN
