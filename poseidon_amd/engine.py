@@ -141,19 +141,19 @@ class ScOTEngine:
         self.shadow_t, self._wt_names, self._wt_desc, self._wt_tiles = None, {}, None, 0
         if self.shadow is not None and os.environ.get("SCOT_DGRAD_WT", "1") == "1":
             self._plan_transposed_weights()
-        # The deep stages' layer tails (C = 384 / 768) as one launch per direction on FRAGMENT-ORDERED weight copies (csrc/tail_deep.hip):
-        # `shadow_f` holds Wo, W1 (rows permuted), W2, Wqkv of those layers in the order the MFMA operand loads read them (same offsets as
-        # the master).  {C: hidden split} — C = 768 has 1024 rows at batch 64 = 64 row blocks, so four workgroups share a block's hidden
-        # dimension.  OFF by default (SCOT_DEEP_TAIL=1 switches it on): measured in round 4, the kernel alone beats the launches it
-        # replaces (66 vs 90 us at C = 384) but not inside the step (cold output buffers: 82-88 us; and it starves the skip blocks that
-        # share the forward's side stream) — profiles/round4/deep_tail_*.txt, DESIGN.md §6.
-        self.deep_hsplit = {}
+        # The deep stages' layer tail (C = 384; 768 with a split hidden dimension) as ONE launch on FRAGMENT-ORDERED weight copies
+        # (csrc/tail_deep.hip): `shadow_f` holds Wo, W1 (rows permuted), W2, Wqkv of those layers in the order the MFMA operand loads read
+        # them (same offsets as the master).  {C: hidden split}.  SCOT_DEEP_TAIL = "eval" (default): inference forwards only — measured in
+        # round 4 (profiles/round4/deep_tail_fwd_r4.txt): Poseidon-B batch 64 inference 7.57 -> 6.53 ms per forward, while inside a TRAINING
+        # step the kernel loses to the launches it replaces (its ~60 MB of saved activations go to cold lines, and one 400-register
+        # workgroup per CU starves the skip blocks on the side stream); "all": training forwards too; "0": never.
+        self.deep_hsplit, self.deep_fused_qkv = {}, False
         self.shadow_f, self._wf_desc, self._wf_blocks, self._wf_names = None, None, 0, set()
-        if self.shadow is not None and os.environ.get("SCOT_DEEP_TAIL", "0") == "1":
-            self.deep_hsplit = {int(c): int(h) for c, h in (kv.split(":") for kv in os.environ.get("SCOT_DEEP_HSPLIT", "384:1,768:4").split(",") if kv)}
+        self.deep_tail_mode = os.environ.get("SCOT_DEEP_TAIL", "eval")
+        if self.shadow is not None and self.deep_tail_mode in ("eval", "all", "1"):
+            self.deep_hsplit = {int(c): int(h) for c, h in (kv.split(":") for kv in os.environ.get("SCOT_DEEP_HSPLIT", "384:1").split(",") if kv)}
             self._plan_fragment_weights()
-            if self.deep_hsplit.get(384) == 1:
-                self.fused_next_qkv = self.fused_next_qkv | {384}
+            self.deep_fused_qkv = self.deep_hsplit.get(384) == 1
         # fp16 operands have 5 exponent bits: the backward runs on gradients multiplied by a power of two chosen from the loss
         # normalisation (d loss / d prediction = O(1 / number of output elements); see _grad_scale) and the gradient arena is
         # divided by it afterwards (exact; scot_scale_inplace also counts non-finite values → `grad_overflow`).
@@ -769,7 +769,7 @@ class ScOTEngine:
         done_tail = False
         lean_used = False
         qkv_next = None
-        hs = self.deep_hsplit.get(C, 0)
+        hs = self.deep_hsplit.get(C, 0) if (not train or self.deep_tail_mode in ("all", "1")) else 0
         if (hs and not padded and (B * L) % 16 == 0 and L % 16 == 0 and hid == 4 * C and hid % (128 * hs) == 0 and not self.precision_probe
                 and self.WF(pre + ".output.dense.weight") is not None):
             # deep stages: everything after the attention core in one launch on the fragment-ordered weight copies (csrc/tail_deep.hip)
@@ -784,7 +784,8 @@ class ScOTEngine:
             out, out16 = self.new(B * L, C), self.new(B * L, C, dtype=self.adt)
             n1, n2 = self._norm_params(pre + ".layernorm_before"), self._norm_params(pre + ".layernorm_after")
             nq = (None, None, None)
-            if hs == 1 and next_blk is not None and next_blk.dim == C and self.qkv_fusable(next_blk):
+            if (hs == 1 and self.deep_fused_qkv and next_blk is not None and next_blk.dim == C and next_blk.res[0] % next_blk.window_shift()[0] == 0
+                    and next_blk.res[1] % next_blk.window_shift()[0] == 0):
                 na = next_blk.prefix + ".attention.self."
                 qkv_next = self.new(B * L, 3 * C, dtype=self.adt)
                 nq = (self.WF(na + "qkv_weight", 3 * C * C), self.arena.span(na + "qkv_bias", 3 * C) if cfg.qkv_bias else None, qkv_next)

@@ -993,3 +993,26 @@ def test_timed_batch_gradients_fp16_vs_fp32_path(tag, size, channels, batch):
     g = (num / den) ** 0.5
     print(f"\n[Poseidon-{tag} {size}^2 batch {batch}] fp16 vs fp32 path: out rel-L2 {e_out:.2e} loss rel {e_loss:.2e} grads global rel-L2 {g:.2e} worst {worst}")
     assert e_out < 1e-3 and e_loss < 1e-3 and g < 6e-3
+
+
+@pytest.mark.parametrize("name", ["poseidonB_trained", "poseidonT_trained"])
+def test_inference_forward_on_the_deep_stage_tail_kernel(name):
+    """Inference forwards take scot_deep_tail_fwd at the C = 384 stage (one launch per layer tail on fragment-ordered weights + the next
+    layer's qkv as its epilogue): the prediction must stay within the fp16 bound of the reference fixture and agree with the training
+    forward of the same model (layer-by-layer launches at that stage: same operands and rounding points, other summation orders)."""
+    f, meta = load_fixture(name)
+    cfg, model = build(meta, "fp16")
+    kw = inputs(cfg, meta)
+    with torch.no_grad():
+        model.eval()
+        pred = model(pixel_values=kw["pixel_values"], time=kw.get("time")).output
+    torch.cuda.synchronize()
+    e = rel_l2(pred.cpu().numpy(), f["output"])
+    model.train()
+    out = model(**kw)
+    e2 = rel_l2(pred.cpu().numpy(), out.output.detach().cpu().numpy())
+    used = model._engine.shadow_f is not None and 384 in model._engine.deep_hsplit and any(b.dim == 384 for st in model._engine.enc for b in st.blocks)
+    print(f"\n[{name} fp16 inference] out rel-L2 vs fixture {e:.2e}, vs the training forward {e2:.2e}, deep tail in use: {used}")
+    assert e < 1e-3 and e2 < 6e-4      # (two fp16 paths, each ~7e-4 from the reference: 16-bit rounding flips between them)
+    if "B_" in name:
+        assert used
