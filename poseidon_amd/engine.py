@@ -64,6 +64,7 @@ class ScOTEngine:
         # ... and replayed from C: one scot_tape_replay call per run of launches instead of one ctypes call per launch (SCOT_TAPE_C=0: the
         # Python loop over the recorded calls)
         self.tape_c = os.environ.get("SCOT_TAPE_C", "1") == "1"
+        self.tape_inference = os.environ.get("SCOT_TAPE_INFERENCE", "1") == "1"      # inference forwards are recorded / replayed too
         self._rec = None
         self._rec_keep = None
         self._taped = {}
@@ -143,13 +144,14 @@ class ScOTEngine:
             self._plan_transposed_weights()
         # The deep stages' layer tail (C = 384; 768 with a split hidden dimension) as ONE launch on FRAGMENT-ORDERED weight copies
         # (csrc/tail_deep.hip): `shadow_f` holds Wo, W1 (rows permuted), W2, Wqkv of those layers in the order the MFMA operand loads read
-        # them (same offsets as the master).  {C: hidden split}.  SCOT_DEEP_TAIL = "eval" (default): inference forwards only — measured in
-        # round 4 (profiles/round4/deep_tail_fwd_r4.txt): Poseidon-B batch 64 inference 7.57 -> 6.53 ms per forward, while inside a TRAINING
-        # step the kernel loses to the launches it replaces (its ~60 MB of saved activations go to cold lines, and one 400-register
-        # workgroup per CU starves the skip blocks on the side stream); "all": training forwards too; "0": never.
+        # them (same offsets as the master).  {C: hidden split}.  SCOT_DEEP_TAIL = "0" (default): off; "eval": inference forwards only;
+        # "all": training forwards too.  Measured in round 4 (profiles/round4/deep_tail_fwd_r4.txt): alone the kernel beats the six launches
+        # it replaces (62 vs 90 us at C = 384), inside a training step it loses (its ~60 MB of saved activations go to cold lines; one
+        # 400-register workgroup per CU starves the skip blocks on the side stream: forward 6.86 -> 7.11 ms), and what it bought for
+        # inference (7.57 -> 6.41 ms per Poseidon-B batch-64 forward) was host time that the inference tape now removes (6.33 ms without it).
         self.deep_hsplit, self.deep_fused_qkv = {}, False
         self.shadow_f, self._wf_desc, self._wf_blocks, self._wf_names = None, None, 0, set()
-        self.deep_tail_mode = os.environ.get("SCOT_DEEP_TAIL", "eval")
+        self.deep_tail_mode = os.environ.get("SCOT_DEEP_TAIL", "0")
         if self.shadow is not None and self.deep_tail_mode in ("eval", "all", "1"):
             self.deep_hsplit = {int(c): int(h) for c, h in (kv.split(":") for kv in os.environ.get("SCOT_DEEP_HSPLIT", "384:1").split(",") if kv)}
             self._plan_fragment_weights()
@@ -1295,10 +1297,13 @@ class ScOTEngine:
         the second forward); loss and prediction are returned as fresh tensors, never as views of the recorded buffers."""
         self.stochastic = bool(train if stochastic is None else stochastic)
         self._events.clear()          # (the previous step's: a destroyed event's pending work completes regardless)
-        if not (train and self.tape_mode and labels is not None and not self.stage_timing and not self.collect_attn) or self._capturing():
+        if (not self.tape_mode or (train and labels is None) or self.stage_timing or self.collect_attn or self._capturing()
+                or (not train and (self.stochastic or not self.tape_inference))):
             return self._forward(pixel_values, time, labels, pixel_mask, train)
-        key = (tuple(pixel_values.shape), None if time is None else tuple(time.shape), tuple(labels.shape),
-               None if pixel_mask is None else (tuple(pixel_mask.shape), pixel_mask.dtype), self._stream_id(), self.stochastic)
+        # (inference forwards are taped too — an autoregressive rollout is hundreds of forwards of one signature, and issued through the
+        # Python op wrappers a forward is host-bound: 400 launches at ~10 us each against ~5.5 ms of GPU time)
+        key = (tuple(pixel_values.shape), None if time is None else tuple(time.shape), None if labels is None else tuple(labels.shape),
+               None if pixel_mask is None else (tuple(pixel_mask.shape), pixel_mask.dtype), self._stream_id(), self.stochastic, bool(train))
         ent = self._taped.get(key)
         if ent is None:
             # a recorded step pins all of its buffers (GBs): keep at most `tape_max` signatures (e.g. the full batch and the
@@ -1320,6 +1325,9 @@ class ScOTEngine:
                     dst.copy_(src)
             self._replay(ent["fwd"], ent.get("fwd_c"))
             loss, pred, tape = ent["out"]
+            self.last_hidden = ent["hidden"]      # (views of THIS recorded step's buffers: valid until its next replay)
+            if not train:          # nothing is kept for a backward: the recorded buffers are free again as soon as the outputs are copied
+                return (None if loss is None else loss.clone()), pred.clone(), None
             tok = _Token()
             ent["pending"] = weakref.ref(tok)
             return loss.clone(), pred.clone(), dict(_ent=ent, _tok=tok)
@@ -1335,6 +1343,11 @@ class ScOTEngine:
             ent["fwd"], ent["keep"] = self._rec, self._rec_keep
             ent["fwd_c"] = ops.compile_tape(self._rec) if self.tape_c else None
             self._rec = self._rec_keep = None
+        ent["hidden"] = self.last_hidden
+        if not train:
+            ent["out"] = (loss, pred, None)
+            ent["state"] = "ready"
+            return (None if loss is None else loss.clone()), pred.clone(), None
         tape["_ent"] = ent
         ent["out"] = (loss, pred, tape)
         ent["state"] = "fwd"

@@ -1001,11 +1001,15 @@ def test_inference_forward_on_the_deep_stage_tail_kernel(name):
     layer's qkv as its epilogue): the prediction must stay within the fp16 bound of the reference fixture and agree with the training
     forward of the same model (layer-by-layer launches at that stage: same operands and rounding points, other summation orders)."""
     f, meta = load_fixture(name)
-    cfg, model = build(meta, "fp16")
-    kw = inputs(cfg, meta)
-    with torch.no_grad():
-        model.eval()
-        pred = model(pixel_values=kw["pixel_values"], time=kw.get("time")).output
+    os.environ["SCOT_DEEP_TAIL"] = "eval"       # (read when the engine is built; off by default)
+    try:
+        cfg, model = build(meta, "fp16")
+        kw = inputs(cfg, meta)
+        with torch.no_grad():
+            model.eval()
+            pred = model(pixel_values=kw["pixel_values"], time=kw.get("time")).output
+    finally:
+        del os.environ["SCOT_DEEP_TAIL"]
     torch.cuda.synchronize()
     e = rel_l2(pred.cpu().numpy(), f["output"])
     model.train()
@@ -1016,3 +1020,33 @@ def test_inference_forward_on_the_deep_stage_tail_kernel(name):
     assert e < 1e-3 and e2 < 6e-4      # (two fp16 paths, each ~7e-4 from the reference: 16-bit rounding flips between them)
     if "B_" in name:
         assert used
+
+
+def test_inference_forwards_are_taped_and_replay_like_direct_launches():
+    """Inference forwards of one signature are recorded (call 2) and replayed (call 3+) — a rollout is hundreds of them.  Different inputs
+    per call; against a model that never tapes; interleaved with a training step of another signature (its own tape, its own hidden
+    states)."""
+    f, meta = load_fixture("tiny_trained")
+    cfg, model = build(meta, "fp16")
+    _, plain = build(meta, "fp16")
+    kw = inputs(cfg, meta)
+    with torch.no_grad():
+        plain(pixel_values=kw["pixel_values"], time=kw["time"])      # (creates the engine: a first call only warms a signature)
+    plain._engine.tape_mode = False
+    g = torch.Generator(device="cpu").manual_seed(5)
+    for call in range(5):
+        pv = (kw["pixel_values"] + 0.1 * torch.randn(kw["pixel_values"].shape, generator=g).to(DEV)).contiguous()
+        model.eval()
+        plain.eval()
+        with torch.no_grad():
+            a = model(pixel_values=pv, time=kw["time"], output_hidden_states=True)
+            b = plain(pixel_values=pv, time=kw["time"], output_hidden_states=True)
+        model.train()
+        assert torch.equal(a.output, b.output), call
+        for ha, hb in zip(a.hidden_states, b.hidden_states):
+            assert torch.equal(ha, hb), call
+        if call == 2:       # a training step in between: another signature, another recorded step
+            out = model(**kw)
+            out.loss.backward()
+    states = [e["state"] for e in model._engine._taped.values()]
+    assert "ready" in states
