@@ -29,6 +29,11 @@ class _FakeModel:
     def flat_parameters(self):
         return self._arena.data
 
+    dirty = 0
+
+    def mark_weights_dirty(self):       # (ScOT's: a collective writes the arena without moving torch's version counter)
+        self.dirty += 1
+
 
 def test_backward_order_ranges_cover_arena():
     for cfg in (ScOTConfig(**TINY), preset("B", image_size=128, num_channels=4, num_out_channels=4)):
@@ -82,8 +87,10 @@ def _worker(rank, world, port, wire, collective, out):
     m._arena.data.fill_(float(rank + 7))
     red = GradAllReducer(m, dist, wire=wire, chunk_mb=1, collective=collective)
     red.chunk = 1000                                  # force many chunks (1000 % (2 * 8) != 0: rs_ag pads every chunk)
+    v0 = m._arena.data._version
     red.broadcast_parameters(src=0)
     assert float(m._arena.data.min()) == 7.0 and float(m._arena.data.max()) == 7.0
+    assert m.dirty == 1          # ... so the engine re-casts its 16-bit copies whatever torch's counter did ({m._arena.data._version - v0})
     red.allreduce()
     tol = 1e-6 if wire == "fp32" else 8e-3
     assert torch.allclose(m._arena.grad, 1.5 * base, rtol=tol, atol=tol * 0.01), (rank, wire)
