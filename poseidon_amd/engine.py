@@ -1595,6 +1595,8 @@ class ScOTEngine:
         groups = cfg.channel_slice_list_normalized_loss
         key = (Cout, B, HW, tuple(groups) if groups else None)
         if self._loss_meta and self._loss_meta[0] == key:
+            if self._rec is not None:
+                self._rec_keep.append(self._loss_meta[1])     # a recorded step names these tensors' addresses: it keeps them alive
             return self._loss_meta[1]
         goc = torch.full((Cout,), -1, dtype=torch.int32)
         if groups:
@@ -1609,6 +1611,8 @@ class ScOTEngine:
             counts = torch.tensor([float(B * Cout * HW)])
         meta = dict(G=G, goc=goc.to(self.device), counts=counts.to(self.device), normalized=bool(groups))
         self._loss_meta = (key, meta)
+        if self._rec is not None:
+            self._rec_keep.append(meta)       # (the one-entry cache above is replaced when another batch size comes along)
         return meta
 
     def _backward(self, tape, dloss=None, dpred=None):
