@@ -453,9 +453,7 @@ static int launch_attn(const AttnArgs& a, int nwin, bool bwd, hipStream_t s) {
   if (sh > 160 * 1024) return SCOT_ERR_UNSUPPORTED;
   // waves per workgroup: a 4x4 window has ONE 16-query block — with 4 waves per workgroup three of them only held wave slots and
   // the 3072-workgroup grid needed three rounds of its ~10 us latency chain
-  static int nw_env = -1;
-  if (nw_env < 0) { const char* e = getenv("SCOT_ATTN_NW"); nw_env = e ? atoi(e) : 0; }
-  const int nw = nw_env > 0 ? nw_env : (NT <= 2 ? 1 : 4);   // measured (bwd, cold): 4x4 windows 22 vs 33 us with 1 wave; 8x8 windows best with 4
+  const int nw = NT <= 2 ? 1 : 4;   // measured (bwd, cold): 4x4 windows 22 vs 33 us with 1 wave; 8x8 windows best with 4
   dim3 grid(nwin, a.heads), block(64 * nw);
   if (bwd) {
     if (sh > 64 * 1024) (void)hipFuncSetAttribute((const void*)attn_bwd_kernel<CT, HD, NT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh);

@@ -697,12 +697,8 @@ static int gemm_fast_impl(int layout, int compute, int M, int N, int K, const vo
   a.M = M; a.N = N; a.K = K; a.lda = lda; a.ldb = ldb; a.ldc = ldc; a.ldaux = ldaux; a.ldres = ldres;
   a.c_dt = c_dt; a.aux_dt = aux_dt; a.res_dt = res_dt; a.a_gelu = a_gelu; a.b_gelu = b_gelu; a.aux_gelu_grad = aux != nullptr;
   a.use_tr = g_scot_use_tr; a.atomic = 0; a.ws = nullptr; a.ws_plane = 0; a.rmw = 0; a.C2 = C2; a.aux_mul = aux_mul;
-  static int xcd = -1;
-  if (xcd < 0) { const char* e = getenv("SCOT_GEMM_XCD"); xcd = e ? atoi(e) : 1; }
-  a.xcd_swizzle = xcd;
-  static int pre = -1;
-  if (pre < 0) { const char* e = getenv("SCOT_GEMM_PRE"); pre = e ? atoi(e) : 1; }     // (SCOT_GEMM_PRE=0: epilogue operands loaded in the epilogue, A/B)
-  a.pre = pre;
+  a.xcd_swizzle = 1;
+  a.pre = 1;         // epilogue operands requested before the K loop (round 4: dgrad fc2 · gelu' 43.2 -> 36.6 us in step)
   if (C2 && ((((uintptr_t)C2) & 15) != 0 || layout == LAYOUT_TN)) return SCOT_ERR_UNSUPPORTED;
   if (a_gelu || b_gelu) return SCOT_ERR_UNSUPPORTED;   // GELU-on-load is the general kernel's (the engine stores GELU(u) from the fc1 epilogue)
   int bk = compute == SCOT_BF16 ? 64 : 32;
@@ -716,8 +712,7 @@ static int gemm_fast_impl(int layout, int compute, int M, int N, int K, const vo
   int tile = ov[layout] >= 0 ? ov[layout] : (ov[3] >= 0 ? ov[3] : -1);
   static int glds = -1;
   if (glds < 0) { const char* e = getenv("SCOT_GEMM_GLDS"); glds = e ? atoi(e) : 1; }   // direct-to-LDS K loop for the NT products it covers (SCOT_GEMM_GLDS=0: register-staged)
-  static int deep = -1;
-  if (deep < 0) { const char* e = getenv("SCOT_GEMM_DEEP"); deep = e ? atoi(e) : 1; }   // in step: 19.76 -> 19.59 ms (SCOT_GEMM_DEEP=0: off)
+  const int deep = 1;   // four-register-set pipeline for the long-K small-grid products (round 3, in step: 19.76 -> 19.59 ms)
   if (tile < 0) {
     tile = 0;   // policy (see DESIGN.md §3 for the measurements behind it)
     // wgrad with a long token dimension (stages 0/1): 96x96 (cold-cache sweep: 25.6 vs 38.5 us at stage 1); with K <= 4096
@@ -745,8 +740,7 @@ static int gemm_fast_impl(int layout, int compute, int M, int N, int K, const vo
     // writes a partial tile into the workspace and ONE reduce pass adds them into the gradient (12.6 M fp32 atomics per
     // call in the first version of this kernel cost 300 us; the partials cost < 20 MB of traffic).
     if (c_dt != SCOT_F32 || !accumulate) return SCOT_ERR_UNSUPPORTED;
-    static int tn_wgs = -1;
-    if (tn_wgs < 0) { const char* e = getenv("SCOT_GEMM_TN_WGS"); tn_wgs = e ? atoi(e) : 512; }
+    const int tn_wgs = 512;
     long wantsplit = (tn_wgs + tiles - 1) / tiles;
     const long maxsplit = (K + 8 * bk - 1) / (8 * bk);       // >= 8 K-tiles per workgroup
     long wsmax = workspace ? (long)(ws_bytes / ((size_t)M * N * sizeof(float))) : 1;
@@ -880,8 +874,7 @@ static int wgrad_group_impl(int compute, int n, int K, const void* const* dY, co
   g.tiles = tiles; g.plane = plane;
   // K slices: enough workgroups to fill the chip (~2 per CU), at least 8 K-tiles each, a multiple of 8 so that one slice's
   // tiles share an XCD; none when the group already has >= 256 tiles
-  static int want_wgs = -1;
-  if (want_wgs < 0) { const char* e = getenv("SCOT_WGRAD_GROUP_WGS"); want_wgs = e ? atoi(e) : 256; }   // in-step optimum: 192-256 (448 filled the chip better alone and cost the chain 0.1 ms; 128 makes the side stream the wall)
+  const int want_wgs = 256;   // in-step optimum: 192-256 (448 filled the chip better alone and cost the chain 0.1 ms; 128 makes the side stream the wall)
   const long nkt = (K + bk - 1) / bk;
   // (groups with >= 256 tiles — the deep stages — are never split: two K slices for the 432-tile stage-2 group run 66 instead of 85 us
   // alone and cost the step 0.2 ms; the eight-wave workgroups below halve its serial K loop without a second pass)
@@ -908,8 +901,7 @@ static int wgrad_group_impl(int compute, int n, int K, const void* const* dY, co
     return SCOT_OK;
   }
   // unsplit 64x64-tile groups (the deep stages: 432 / 1728 tiles walking 64 / 16 K-tiles each): two K groups per workgroup
-  static int kg_env = -1;
-  if (kg_env < 0) { const char* e = getenv("SCOT_WGRAD_GROUP_KG"); kg_env = e ? atoi(e) : 2; }   // (measured: stage 2 84.5 -> 62.5 us alone, step -0.12 ms; SCOT_WGRAD_GROUP_KG=1: four waves)
+  const int kg_env = 2;   // (measured: stage 2 84.5 -> 62.5 us alone, step -0.12 ms against four waves)
   int rc;
   if (!t96 && g.nsplit == 1 && kg_env == 2 && nkt >= 4) rc = launch_wgrad_group<64, 64, 64, 2, 2>(g, stream);
   else rc = t96 ? launch_wgrad_group<96, 96, 64, 2>(g, stream) : launch_wgrad_group<64, 64, 64, 2>(g, stream);

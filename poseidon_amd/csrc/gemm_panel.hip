@@ -196,8 +196,7 @@ int scot_gemm_panel(int layout, int compute, int M, int N, int K, const void* A,
                     float* colsum_out, int aux_mul, void* C2, hipStream_t stream) {
   if (compute != SCOT_BF16 || (layout != LAYOUT_NT && layout != LAYOUT_NN)) return SCOT_ERR_UNSUPPORTED;
   if (a_dt != SCOT_BF16 || b_dt != SCOT_BF16 || a_gelu || b_gelu || colscale || colsum_out) return SCOT_ERR_UNSUPPORTED;
-  static int kmax = -1;
-  if (kmax < 0) { const char* e = getenv("SCOT_GEMM_PANEL_KMAX"); kmax = e ? atoi(e) : 192; }   // measured: K = 384 (48-col panels) only ties the tiled kernel
+  const int kmax = 192;   // measured: K = 384 (48-col panels) only ties the tiled kernel
   if (K % 96 || K > kmax || N % 48 || M < 4096) return SCOT_ERR_UNSUPPORTED;
   if ((((uintptr_t)A | (uintptr_t)B | (uintptr_t)C | (uintptr_t)C2 | (uintptr_t)aux | (uintptr_t)resid | (uintptr_t)bias) & 15) != 0)
     return SCOT_ERR_UNSUPPORTED;

@@ -682,8 +682,7 @@ __global__ __launch_bounds__(256) void dwconv7_wgrad_kernel(const void* dy, int 
 extern "C" int scot_dwconv7_wgrad(const void* dy, int dy_dt, const void* x, int x_dt, float* dw, float* db, int B, int H, int W,
                                   int C, hipStream_t s) {
   if (B <= 0 || H <= 0 || W <= 0 || C <= 0) return SCOT_ERR_SHAPE;
-  static int want = -1;
-  if (want < 0) { const char* e = getenv("SCOT_DWCONV_WGRAD_WGS"); want = e ? atoi(e) : 1; }   // measured: 768 makes this kernel 23 % faster and the STEP 0.17 ms slower (wider side-stream kernels take CUs from the latency-bound chain)
+  const int want = 1;   // measured: 768 makes this kernel 23 % faster and the STEP 0.17 ms slower (wider side-stream kernels take CUs from the latency-bound chain)
   const int cb = (C + DW_C - 1) / DW_C, ntiles = ((W + DW_T - 1) / DW_T) * ((H + DW_T - 1) / DW_T);
   int groups = (want + cb * B - 1) / (cb * B);
   groups = groups < 1 ? 1 : (groups > ntiles ? ntiles : groups);

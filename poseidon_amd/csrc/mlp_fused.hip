@@ -211,13 +211,8 @@ __global__ __launch_bounds__(256, 2) void mlp_fused_kernel(MlpArgs p) {
 
 // Hidden units per LDS weight chunk.  The chunk's 16-byte pieces must divide evenly over the 256 threads (HC·C/8 % 256 == 0:
 // with a ragged last piece the skipped LDS stores leave loads the compiler cannot prove consumed, and it then waits for all
-// memory traffic at the top of every chunk iteration): 64 (27 KB of LDS at C = 96, 54 KB at C = 192), or 128 at C = 96
-// (53 KB, half the barriers; SCOT_MLP_HC=128).
-static int mlp_chunk(int C) {
-  static int hc_env = -1;
-  if (hc_env < 0) { const char* e = getenv("SCOT_MLP_HC"); hc_env = e ? atoi(e) : 0; }
-  return (C == 96 && hc_env == 128) ? 128 : 64;
-}
+// memory traffic at the top of every chunk iteration): 64 (27 KB of LDS at C = 96, 54 KB at C = 192).
+static int mlp_chunk(int) { return 64; }     // (128-hidden chunks at C = 96: measured no change, round 2)
 
 template <int C, int HC, int TT>
 static int launch_mlp(const MlpArgs& a, hipStream_t s) {
@@ -253,7 +248,6 @@ extern "C" int scot_mlp_block_fwd(const void* h16, const float* h, const void* W
   // (C = 192 with TT = 2 needs 256 VGPRs + spills: TT = 1 unless forced)
   const int tt = tt_env ? tt_env : ((C == 96 && M >= 64 * 2 * 512) ? 2 : 1);
   if (C == 96) {
-    if (hc == 128) return tt == 2 ? launch_mlp<96, 128, 2>(a, stream) : launch_mlp<96, 128, 1>(a, stream);
     return tt == 2 ? launch_mlp<96, 64, 2>(a, stream) : launch_mlp<96, 64, 1>(a, stream);
   }
   return tt == 2 ? launch_mlp<192, 64, 2>(a, stream) : launch_mlp<192, 64, 1>(a, stream);
@@ -581,7 +575,6 @@ extern "C" int scot_mlp_block_bwd(const float* g, float* g_out, const float* z, 
   a.d_gw_w = d_gw_w; a.d_gw_b = d_gw_b; a.d_bw_w = d_bw_w; a.d_bw_b = d_bw_b;
   a.M = M; a.rows_per_sample = rows_per_sample; a.hid = hid; a.use_tr = g_scot_use_tr;
   if (C == 96) {
-    if (hc == 128) return tt == 2 ? launch_mlp_bwd<96, 128, 2>(a, stream) : launch_mlp_bwd<96, 128, 1>(a, stream);
     return tt == 2 ? launch_mlp_bwd<96, 64, 2>(a, stream) : launch_mlp_bwd<96, 64, 1>(a, stream);
   }
   return tt == 2 ? launch_mlp_bwd<192, 64, 2>(a, stream) : launch_mlp_bwd<192, 64, 1>(a, stream);

@@ -358,16 +358,12 @@ int scot_cln_bwd_fast(ClnFastArgs a, void* workspace, size_t ws_bytes, hipStream
     CLN_DISPATCH(launch_bwd)
     return scot_check_launch();
   }
-  // rows per block: enough blocks to cover the chip (SCOT_CLN_BLOCKS, default 256: every block ends in 5·C global atomics) but at least two
-  // passes of the four waves, at most 128 rows; SCOT_CLN_RPB pins it
-  static int rpb_env = -1, blocks_env = -1;
-  if (rpb_env < 0) { const char* e = getenv("SCOT_CLN_RPB"); rpb_env = e ? atoi(e) : 0; }
-  if (blocks_env < 0) { const char* e = getenv("SCOT_CLN_BLOCKS"); blocks_env = e ? atoi(e) : 256; }
+  // rows per block: enough blocks to cover the chip (256: every block ends in 5·C global atomics) but at least two passes of the four
+  // waves, at most 128 rows
+  const int rpb_env = 0, blocks_env = 256;
   int lpr = 1;
   while (lpr < 64 && lpr * 8 < a.C) lpr <<= 1;
-  static int nwv_env = -1;
-  if (nwv_env < 0) { const char* e = getenv("SCOT_CLN_NWV"); nwv_env = e ? atoi(e) : 0; }
-  a.nwv = nwv_env ? nwv_env : ((a.mode == 0 && a.rows >= 16384) ? 8 : 4);
+  a.nwv = (a.mode == 0 && a.rows >= 16384) ? 8 : 4;
   const int rows_per_pass = a.nwv * (64 / lpr);
   const int target_blocks = a.mode == 1 ? 2048 : blocks_env;   // dx only: nothing to flush per block, so many short blocks
   int rpb = rpb_env > 0 ? rpb_env : (a.rows / target_blocks) / rows_per_pass * rows_per_pass;

@@ -235,9 +235,7 @@ extern int g_scot_use_tr;
 // slices of `rows_per_slice` tokens (a multiple of 32) so that chunks x slices ~ the requested number of workgroups
 static void wgrad_mlp_plan(int M, int C, int hid, int* nslice, int* rps) {
   // workgroups wanted: two per CU at C = 192 (57 vs 85 us alone: twelve chunks of 64 hidden units leave 21 slices at 256), one at C = 96
-  static int want_env = -1;
-  if (want_env < 0) { const char* e = getenv("SCOT_WGRAD_MLP_WGS"); want_env = e ? atoi(e) : 0; }
-  const int want = want_env > 0 ? want_env : (C == 96 ? 256 : 512);
+  const int want = C == 96 ? 256 : 512;     // (round 3: 512 at C = 96 costs the step +0.1 ms)
   const int hw = C == 96 ? 128 : 64, nchunk = hid / hw;
   int ns = (want + nchunk - 1) / nchunk;
   if (ns < 1) ns = 1;

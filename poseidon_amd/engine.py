@@ -85,9 +85,9 @@ class ScOTEngine:
         # pre-norm rows as 16-bit, the backward recomputes gelu'(u) and does not store du, scot_wgrad_mlp recomputes both for the
         # fc1 / fc2 weight gradients, the norms' parameter gradients go through per-workgroup partial rows instead of atomics
         self.lean_tail = os.environ.get("SCOT_LEAN_TAIL", "1") == "1"
-        # ... gelu'(u): "store" = the forward still writes it (16-bit, 8·C bytes per token) and the backward tail loads it; "recompute" =
-        # the backward tail recomputes it from h16 (one more C x 4C product per row tile at the 256-register cap: measured slower)
-        self.lean_dact = os.environ.get("SCOT_LEAN_DACT", "store")
+        # ... gelu'(u) itself IS stored (16-bit, 8·C bytes per token) and the backward tail loads it: recomputing it there (the C ABI's
+        # `dact = NULL` form of scot_block_tail_bwd) is one more C x 4C product per row tile at the 256-register cap — 140-168 B/lane of
+        # scratch, +20 us per launch, +0.3 ms per step (round 3) — so the engine no longer offers it
         self.arena = arena
         # bf16x3: activations and weights stay fp32 in HBM; the GEMMs split them into hi + lo bf16 while staging into LDS and
         # run three bf16 MFMAs per K-step (≈ fp32 accuracy at the bf16 MFMA rate); so do the 16x16-window attention kernels
@@ -813,7 +813,7 @@ class ScOTEngine:
             st1 = (self.new(B * L), self.new(B * L)) if train else (None, None)
             h, h16 = self.new(B * L, C), self.new(B * L, C, dtype=self.adt)
             u = self.new(B * L, hid, dtype=self.adt) if (train and not lean) else None
-            gp = self.new(B * L, hid, dtype=self.adt) if (train and (not lean or self.lean_dact == "store")) else None
+            gp = self.new(B * L, hid, dtype=self.adt) if train else None
             y2 = self.new(B * L, C, dtype=zdt) if train else None
             st2 = (self.new(B * L), self.new(B * L)) if train else (None, None)
             out, out16 = self.new(B * L, C), self.new(B * L, C, dtype=self.adt)

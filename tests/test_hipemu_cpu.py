@@ -27,15 +27,15 @@ def emu(tmp_path_factory):
 
 # the in-process emulation tests (test_kernels_emu_cpu.py) run the default configuration (64 rows per workgroup, 64 hidden units per
 # LDS chunk); the variants selected by environment variables that the library reads once per process are covered here
-CASES = [  # case, C, B, L, cond, train, use_tr, SCOT_MLP_TT (16-row tiles per wave), SCOT_MLP_HC (hidden units per LDS chunk)
-    ("mlp_fwd", 96, 1, 128, 1, 1, 1, 2, 64), ("mlp_fwd", 96, 1, 100, 0, 1, 1, 1, 128), ("mlp_bwd", 96, 1, 128, 1, 1, 1, 2, 64),
-    ("mlp_bwd", 96, 1, 64, 0, 1, 0, 1, 128), ("proj_fwd", 96, 1, 128, 0, 0, 1, 2, 64), ("proj_bwd", 96, 1, 128, 1, 1, 1, 2, 64),
+CASES = [  # case, C, B, L, cond, train, use_tr, SCOT_MLP_TT (16-row tiles per wave)
+    ("mlp_fwd", 96, 1, 128, 1, 1, 1, 2), ("mlp_fwd", 96, 1, 100, 0, 1, 1, 1), ("mlp_bwd", 96, 1, 128, 1, 1, 1, 2),
+    ("mlp_bwd", 96, 1, 64, 0, 1, 0, 1), ("proj_fwd", 96, 1, 128, 0, 0, 1, 2), ("proj_bwd", 96, 1, 128, 1, 1, 1, 2),
 ]
 
 
 @pytest.mark.parametrize("case", CASES, ids=lambda c: "-".join(str(x) for x in c))
 def test_fused_block_kernels_on_cpu(emu, case):
-    *args, tt, hc = case
-    env = dict(os.environ, SCOT_MLP_TT=str(tt), SCOT_MLP_HC=str(hc))
+    *args, tt = case
+    env = dict(os.environ, SCOT_MLP_TT=str(tt))
     r = subprocess.run([emu, *[str(a) for a in args]], capture_output=True, text=True, timeout=600, env=env)
     assert r.returncode == 0 and "FAIL" not in r.stdout, r.stdout + r.stderr[-2000:]

@@ -119,10 +119,9 @@ def run(which):
         return
     if which == "wm":
         for v in VARIANTS:
-            for wgs in ("256", "512", "128"):
-                env = dict(os.environ, SCOT_LIB_F16=os.path.join(OUT, f"libscot_abl_{v}.so"), SCOT_WGRAD_MLP_WGS=wgs)
-                out = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "bench_wgrad_mlp.py")], env=env, capture_output=True, text=True, timeout=300)
-                print(f"abl={v:3d} {out.stdout.strip() or out.stderr[-300:]}", flush=True)
+            env = dict(os.environ, SCOT_LIB_F16=os.path.join(OUT, f"libscot_abl_{v}.so"))
+            out = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "bench_wgrad_mlp.py")], env=env, capture_output=True, text=True, timeout=300)
+            print(f"abl={v:3d} {out.stdout.strip() or out.stderr[-300:]}", flush=True)
         return
     names = {1: "nostore", 2: "nogelu", 4: "noload", 8: "nomfma", 16: "nobarrier", 32: "noatomic", 64: "nodact", 128: "nodu"}
     for v in VARIANTS:

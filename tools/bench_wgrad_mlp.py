@@ -36,7 +36,7 @@ def main():
         e1.record()
         torch.cuda.synchronize()
         us = e0.elapsed_time(e1) / (3 * nset) * 1e3
-        print(f"C={C} M={M} wgrad_mlp {us:7.1f} us (WGS={os.environ.get('SCOT_WGRAD_MLP_WGS', '256')})", end=" | ")
+        print(f"C={C} M={M} wgrad_mlp {us:7.1f} us", end=" | ")
     print()
 
 
