@@ -103,6 +103,11 @@ class ScOTEngine:
         import os as _os
         trunk32 = self.compute == ops.BF16 and _os.environ.get("SCOT_TRUNK_BF16", "0") != "1"
         self.tcm = ops.F32 if (trunk32 or self.compute != ops.BF16) else ops.BF16
+        # ... on the SPLIT 16-bit MFMA in the fp16 mode (fp32 operands, hi + lo bfloat16 halves, three MFMAs: 2^-17 operand error, 1/5 of
+        # the exact fp32 MFMA's time; ops.gemm routes it to the bfloat16 build, whose halves keep fp32's range under the gradient scale).
+        # SCOT_TRUNK_X3=0: exact fp32 MFMA
+        if compute == "fp16" and self.tcm == ops.F32 and os.environ.get("SCOT_TRUNK_X3", "1") == "1":
+            self.tcm = ops.X3
         # (tried in round 2: the trunk on the split 16-bit MFMA instead of the exact fp32 MFMA — 0.19 ms faster, same forward
         # parity, but the fp32 trunk gradients under the fp16 build's gradient scale exceed binary16's range in the split: NaN)
         self.tadt = torch.float32 if self.tcm != ops.BF16 else self.adt

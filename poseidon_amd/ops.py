@@ -145,7 +145,17 @@ def _gemm_ws(layout, compute, M, N, K):
 def gemm(layout: int, compute: int, M: int, N: int, K: int, A, lda: int, B, ldb: int, C, ldc: int, *, bias=None,
          colscale=None, aux=None, ldaux: int = 0, resid=None, ldres: int = 0, a_gelu: bool = False, b_gelu: bool = False,
          accumulate: bool = False, colsum_out=None, aux_mul: bool = False, gelu_deriv_out=None) -> None:
-    """scot_gemm — see include/scot_hip.h."""
+    """scot_gemm — see include/scot_hip.h.  compute = X3 (fp32 operands split into hi + lo while they are staged) always runs in the
+    bfloat16 build: its halves keep fp32's exponent range, which the binary16 build's halves do not (gradients under the fp16 gradient
+    scale overflowed there)."""
+    if compute == X3 and _active != "bf16":
+        prev = use("bf16")
+        try:
+            return gemm(layout, compute, M, N, K, A, lda, B, ldb, C, ldc, bias=bias, colscale=colscale, aux=aux, ldaux=ldaux, resid=resid,
+                        ldres=ldres, a_gelu=a_gelu, b_gelu=b_gelu, accumulate=accumulate, colsum_out=colsum_out, aux_mul=aux_mul,
+                        gelu_deriv_out=gelu_deriv_out)
+        finally:
+            use(prev)
     ws = _gemm_ws(layout, compute, M, N, K)
     rc = L().scot_gemm(layout, compute, M, N, K, ptr(A), dt(A), lda, int(a_gelu), ptr(B), dt(B), ldb, int(b_gelu),
                        ptr(C), dt(C), ldc, ptr(bias), ptr(colscale), ptr(aux), dt(aux) if aux is not None else 0, ldaux,
