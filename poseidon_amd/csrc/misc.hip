@@ -239,11 +239,58 @@ __global__ void s2d_kernel(const void* fine, const void* fine2, int f_dt, void* 
     }
   }
 }
+// the same, 8 channels per thread (16 / 32-byte accesses, one index decomposition per 8 elements): the element-wise kernel above ran the
+// merges' 25-50 MB shuffles at ~1.3 TB/s (24-40 us each, twelve per step)
+__global__ __launch_bounds__(256) void s2d_vec8_kernel(const void* fine, const void* fine2, int f_dt, void* coarse, int c_dt, int B, int H, int W,
+                                                       int H2, int W2, int C8, int order, int scatter) {
+  const size_t n = scatter ? (size_t)B * H * W * C8 : (size_t)B * H2 * W2 * 4 * C8;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+    float v[8];
+    if (scatter) {
+      const int c = i % C8; size_t r = i / C8;
+      const int x = r % W; r /= W;
+      const int y = r % H; const int b = r / H;
+      const int dy = y & 1, dx = x & 1;
+      const int q = order == 0 ? dx * 2 + dy : dy * 2 + dx;
+      const size_t ci = ((((size_t)b * H2 + (y >> 1)) * W2 + (x >> 1)) * 4 + q) * C8 + c;
+      ld8(coarse, c_dt, ci * 8, v);
+      st8((void*)fine, f_dt, i * 8, v);
+    } else {
+      const int c = i % C8; size_t r = i / C8;
+      const int q = r % 4; r /= 4;
+      const int X = r % W2; r /= W2;
+      const int Y = r % H2; const int b = r / H2;
+      const int dy = order == 0 ? (q & 1) : (q >> 1), dx = order == 0 ? (q >> 1) : (q & 1);
+      const int y = 2 * Y + dy, x = 2 * X + dx;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) v[j] = 0.f;
+      if (y < H && x < W) {
+        const size_t fi = ((((size_t)b * H + y) * W + x) * C8 + c) * 8;
+        ld8(fine, f_dt, fi, v);
+        if (fine2) {
+          float w[8];
+          ld8(fine2, f_dt, fi, w);
+#pragma unroll
+          for (int j = 0; j < 8; ++j) v[j] += w[j];
+        }
+      }
+      st8(coarse, c_dt, i * 8, v);
+    }
+  }
+}
+static bool s2d_vec_ok(const void* a, const void* b, const void* c, int C) {
+  return C % 8 == 0 && ((((uintptr_t)a | (uintptr_t)b | (uintptr_t)c) & 31) == 0);
+}
 extern "C" int scot_space_to_depth(const void* fine, const void* fine2, int f_dt, void* coarse, int c_dt, int B, int H, int W,
                                    int C, int order, hipStream_t s) {
   const int H2 = (H + 1) / 2, W2 = (W + 1) / 2;
   const size_t n = (size_t)B * H2 * W2 * 4 * C;
   if (n == 0) return SCOT_ERR_SHAPE;
+  if (s2d_vec_ok(fine, fine2, coarse, C)) {
+    size_t vb = (n / 8 + 255) / 256; if (vb > 16384) vb = 16384;
+    hipLaunchKernelGGL(s2d_vec8_kernel, dim3((unsigned)vb), dim3(256), 0, s, fine, fine2, f_dt, coarse, c_dt, B, H, W, H2, W2, C / 8, order, 0);
+    return scot_check_launch();
+  }
   size_t blocks = (n + 255) / 256; if (blocks > 16384) blocks = 16384;
   hipLaunchKernelGGL(s2d_kernel, dim3((unsigned)blocks), dim3(256), 0, s, fine, fine2, f_dt, coarse, c_dt, B, H, W, H2, W2, C, order, 0);
   return scot_check_launch();
@@ -252,6 +299,12 @@ extern "C" int scot_depth_to_space(const void* coarse, int c_dt, void* fine, int
                                    int C, int order, hipStream_t s) {
   const size_t n = (size_t)B * H * W * C;
   if (n == 0 || H > 2 * H2 || W > 2 * W2) return SCOT_ERR_SHAPE;
+  if (s2d_vec_ok(fine, nullptr, coarse, C)) {
+    size_t vb = (n / 8 + 255) / 256; if (vb > 16384) vb = 16384;
+    hipLaunchKernelGGL(s2d_vec8_kernel, dim3((unsigned)vb), dim3(256), 0, s, (const void*)fine, (const void*)nullptr, f_dt, (void*)coarse, c_dt,
+                       B, H, W, H2, W2, C / 8, order, 1);
+    return scot_check_launch();
+  }
   size_t blocks = (n + 255) / 256; if (blocks > 16384) blocks = 16384;
   hipLaunchKernelGGL(s2d_kernel, dim3((unsigned)blocks), dim3(256), 0, s, (const void*)fine, (const void*)nullptr, f_dt,
                      (void*)coarse, c_dt, B, H, W, H2, W2, C, order, 1);

@@ -248,6 +248,11 @@ def test_transposed_weight_copies(gpu_test_bodies):
     gpu_test_bodies.test_transpose_cast_and_dgrad_nt()
 
 
+@pytest.mark.parametrize("H,W,C", [(8, 8, 6), (9, 5, 16), (8, 8, 96)])
+def test_space_to_depth_shuffles(gpu_test_bodies, H, W, C):
+    gpu_test_bodies.test_space_depth(H, W, C)
+
+
 @pytest.mark.parametrize("H,W,C,B", [(16, 16, 96, 2), (5, 5, 24, 2)])
 def test_depthwise_conv7(gpu_test_bodies, H, W, C, B):
     gpu_test_bodies.test_dwconv7(H, W, C, B)

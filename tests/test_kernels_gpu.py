@@ -460,9 +460,10 @@ def test_copy2d_pad_crop():
     assert torch.equal(crop, x[:, :4, :6].contiguous())
 
 
+@pytest.mark.parametrize("C", [6, 16, 96])        # 6: element-wise kernel; multiples of 8: eight channels per thread
 @pytest.mark.parametrize("H,W", [(8, 8), (9, 5)])
-def test_space_depth(H, W):
-    B, C = 2, 6
+def test_space_depth(H, W, C):
+    B = 2
     a, b = rnd(B, H, W, C), rnd(B, H, W, C, seed=1)
     H2, W2 = (H + 1) // 2, (W + 1) // 2
     co = torch.empty(B, H2, W2, 4 * C, device=DEV)
