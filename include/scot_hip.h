@@ -149,6 +149,16 @@ int scot_cpb_fwd_batched(const float* params, const int* desc, int nlayers, int 
                          float* tables, float* zbuf, scot_stream_t stream);
 /* backward of layers first .. first + count - 1; max_ws / max_heads: the largest window size and head count among them (sizes the
  * launch's LDS: the table-gradient tile of a layer is staged once per workgroup) */
+/* scot_window_attn_bwd with dbias_table / dlogit_scale as `nrep` replicas (strides in floats): window w accumulates into replica w % nrep, so
+ * the same-address atomic chains of a head's windows are nrep times shorter; scot_replica_reduce folds the replicas afterwards.
+ * (Same reference lines as scot_window_attn_bwd: the autograd of modeling_swinv2.py:395-451 via scOT/model.py:166.) */
+int scot_window_attn_bwd_rep(int compute, const void* qkv, const void* out_fwd, const void* dout, const float* lse, const float* bias_table,
+                             const float* logit_scale, void* dqkv, float* dbias_table, float* dlogit_scale, int batch, int Hp, int Wp, int C,
+                             int heads, int ws, int shift, int nrep, size_t rep_stride_tab, size_t rep_stride_ls, hipStream_t stream);
+/* dst[d.dst_off + j] += sum_{r0 <= r < nrep} rep[r*stride + d.src_off + j] for j < d.count, for each of the n entries d = (src_off, dst_off,
+ * count) of desc (int32, device); max_count = the largest count. */
+int scot_replica_reduce(const float* rep, int r0, int nrep, size_t stride, const int* desc, int n, int max_count, float* dst,
+                        hipStream_t stream);
 int scot_cpb_bwd_batched(const float* params, const int* desc, int first, int count, int max_ws, int max_heads,
                          const float* coords_base, const float* zbuf, const float* dtables, float* grads, scot_stream_t stream);
 

@@ -13,6 +13,11 @@ struct AttnArgs {
   const float* logit_scale;  // [heads]
   float* dbias_table;        // bwd, atomically accumulated
   float* dlogit_scale;       // bwd, atomically accumulated
+  // bwd: REPLICAS of the two atomically accumulated buffers.  Every (window, head) workgroup of a head adds into the same (2ws-1)^2 + 1
+  // addresses — 64 (one window per sample) to 256 same-address atomics in a row, each a serialized L2 read-modify-write: 12 of the 22 us of
+  // the 4x4-window backward, 6 of 33 at 8x8, 10 of 88 at 16x16 (ablation, profiles/round4).  Window w adds into replica w % nrep
+  // (dbias_table + r·rep_stride_tab, dlogit_scale + r·rep_stride_ls); scot_replica_reduce folds the replicas beside the chain.
+  int nrep; size_t rep_stride_tab, rep_stride_ls;
   int C, heads, Hp, Wp, ws, shift, nwx, nw_per_img;
   int use_tr;
 };

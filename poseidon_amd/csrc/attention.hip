@@ -303,11 +303,13 @@ __device__ __forceinline__ void attn_bwd_dq_body(const AttnArgs& p) {
   dls = wave_sum(dls);
   if (lane == 0) red[wave] = dls;
   __syncthreads();
-  for (int i = tid; i < TS; i += nthr) atomicAdd(&p.dbias_table[h * TS + i], (float)dtab[i]);
+  const int rep = p.nrep > 1 ? win % p.nrep : 0;
+  float* dbt = p.dbias_table + (size_t)rep * p.rep_stride_tab;
+  for (int i = tid; i < TS; i += nthr) atomicAdd(&dbt[h * TS + i], (float)dtab[i]);
   if (tid == 0 && p.logit_scale[h] <= 4.605170185988092f) {
     float tot = 0.f;
     for (int w = 0; w < nwv; ++w) tot += red[w];
-    atomicAdd(&p.dlogit_scale[h], tot * scale);
+    atomicAdd(&p.dlogit_scale[(size_t)rep * p.rep_stride_ls + h], tot * scale);
   }
 }
 
@@ -557,15 +559,52 @@ extern "C" int scot_window_attn_probs(const void* qkv, int qkv_dt, const float* 
   return scot_check_launch();
 }
 
+static int attn_bwd_impl(int compute, const void* qkv, const void* out_fwd, const void* dout, const float* lse,
+                         const float* bias_table, const float* logit_scale, void* dqkv,
+                         float* dbias_table, float* dlogit_scale, int batch, int Hp, int Wp, int C,
+                         int heads, int ws, int shift, int nrep, size_t stride_tab, size_t stride_ls, hipStream_t stream);
 extern "C" int scot_window_attn_bwd(int compute, const void* qkv, const void* out_fwd, const void* dout, const float* lse,
                                     const float* bias_table, const float* logit_scale, void* dqkv,
                                     float* dbias_table, float* dlogit_scale, int batch, int Hp, int Wp, int C,
                                     int heads, int ws, int shift, hipStream_t stream) {
+  return attn_bwd_impl(compute, qkv, out_fwd, dout, lse, bias_table, logit_scale, dqkv, dbias_table, dlogit_scale, batch, Hp, Wp, C, heads, ws,
+                       shift, 1, 0, 0, stream);
+}
+// include/scot_hip.h: scot_window_attn_bwd_rep — the two accumulated buffers as nrep replicas (window w adds into replica w % nrep)
+extern "C" int scot_window_attn_bwd_rep(int compute, const void* qkv, const void* out_fwd, const void* dout, const float* lse,
+                                        const float* bias_table, const float* logit_scale, void* dqkv,
+                                        float* dbias_table, float* dlogit_scale, int batch, int Hp, int Wp, int C,
+                                        int heads, int ws, int shift, int nrep, size_t rep_stride_tab, size_t rep_stride_ls,
+                                        hipStream_t stream) {
+  if (nrep < 1) return SCOT_ERR_SHAPE;
+  return attn_bwd_impl(compute, qkv, out_fwd, dout, lse, bias_table, logit_scale, dqkv, dbias_table, dlogit_scale, batch, Hp, Wp, C, heads, ws,
+                       shift, nrep, rep_stride_tab, rep_stride_ls, stream);
+}
+// dst[d.dst_off + j] += Σ_{r0 <= r < nrep} rep[r·stride + d.src_off + j], j < d.count, for every entry d of desc (int32 [n][3], device)
+__global__ __launch_bounds__(256) void replica_reduce_kernel(const float* __restrict__ rep, int r0, int nrep, size_t stride,
+                                                             const int* __restrict__ desc, float* __restrict__ dst) {
+  const int* d = desc + 3 * blockIdx.y;
+  const int j = blockIdx.x * 256 + threadIdx.x;
+  if (j >= d[2]) return;
+  float acc = 0.f;
+  for (int r = r0; r < nrep; ++r) acc += rep[(size_t)r * stride + d[0] + j];
+  dst[(size_t)d[1] + j] += acc;
+}
+extern "C" int scot_replica_reduce(const float* rep, int r0, int nrep, size_t stride, const int* desc, int n, int max_count, float* dst,
+                                   hipStream_t stream) {
+  if (!rep || !desc || !dst || n <= 0 || max_count <= 0 || r0 < 0 || nrep < r0) return SCOT_ERR_SHAPE;
+  hipLaunchKernelGGL(replica_reduce_kernel, dim3((max_count + 255) / 256, n), dim3(256), 0, stream, rep, r0, nrep, stride, desc, dst);
+  return scot_check_launch();
+}
+static int attn_bwd_impl(int compute, const void* qkv, const void* out_fwd, const void* dout, const float* lse,
+                         const float* bias_table, const float* logit_scale, void* dqkv,
+                         float* dbias_table, float* dlogit_scale, int batch, int Hp, int Wp, int C,
+                         int heads, int ws, int shift, int nrep, size_t stride_tab, size_t stride_ls, hipStream_t stream) {
   AttnArgs a{};
   int rc = fill_args(a, batch, Hp, Wp, C, heads, ws, shift);
   if (rc) return rc;
   a.qkv = qkv; a.out = dqkv; a.dout = dout; a.ofwd = out_fwd; a.lse = (float*)lse; a.bias_table = bias_table; a.logit_scale = logit_scale;
-  a.dbias_table = dbias_table; a.dlogit_scale = dlogit_scale;
+  a.dbias_table = dbias_table; a.dlogit_scale = dlogit_scale; a.nrep = nrep; a.rep_stride_tab = stride_tab; a.rep_stride_ls = stride_ls;
   const int nwin = batch * a.nw_per_img;
   rc = scot_attn_w16(a, compute, C / heads, nwin, true, stream);
   if (rc != SCOT_ERR_UNSUPPORTED) return rc;

@@ -501,15 +501,17 @@ __device__ __forceinline__ void attn16_bwd_dq_body(const AttnArgs& p) {
   __syncthreads();
   // (every (window, head) workgroup of a head flushes the same 961 addresses: start each one somewhere else so that concurrent
   // workgroups do not queue up on the same L2 atomic unit in lockstep)
+  const int rep = p.nrep > 1 ? win % p.nrep : 0;
+  float* dbt = p.dbias_table + (size_t)rep * p.rep_stride_tab;
   for (int i = tid; i < W16::TS; i += blockDim.x) {
     int k = i + (win % 31) * 31;
     k = k >= W16::TS ? k - W16::TS : k;
-    atomicAdd(&p.dbias_table[h * W16::TS + k], (float)dtab[k]);
+    atomicAdd(&dbt[h * W16::TS + k], (float)dtab[k]);
   }
   if (tid == 0 && p.logit_scale[h] <= 4.605170185988092f) {
     float r = 0.f;
     for (int wv = 0; wv < (int)(blockDim.x >> 6); ++wv) r += red[wv];
-    atomicAdd(&p.dlogit_scale[h], r * scale);
+    atomicAdd(&p.dlogit_scale[(size_t)rep * p.rep_stride_ls + h], r * scale);
   }
 }
 

@@ -218,7 +218,17 @@ class ScOTEngine:
         self.cpb_max_ws = max(wss)
         self.cpb_tables = torch.empty(tab_off, device=self.device)
         self.cpb_z = torch.empty(z_off, device=self.device)
-        self.cpb_dtables = torch.zeros(tab_off, device=self.device)
+        # the attention backward accumulates dtable / dlogit_scale with atomics: R replicas (window w -> replica w % R) keep the
+        # same-address chains short; replica 0 of the tables is what the bias-MLP backward reads after the per-stage fold
+        self.attn_rep = R = max(1, int(os.environ.get("SCOT_ATTN_REP", "16")))
+        self.cpb_tab_total, self.cpb_ls_total = tab_off, sum(b.heads for b in blocks)
+        self.cpb_dtables = torch.zeros(R * tab_off, device=self.device)
+        self.cpb_dls = torch.zeros(R * self.cpb_ls_total, device=self.device) if R > 1 else None
+        self.cpb_ls_off, cur = {}, 0
+        for b in blocks:
+            self.cpb_ls_off[b.prefix] = cur
+            cur += b.heads
+        self._rep_desc = {}
 
     def cpb_table(self, prefix, grad=False):
         off, heads, ts = self.cpb_slices[prefix]
@@ -230,9 +240,31 @@ class ScOTEngine:
         if blocks:
             first, n = self.cpb_index[blocks[0].prefix], len(blocks)
             mw, mh = max(b.window_shift()[0] for b in blocks), max(b.heads for b in blocks)
-            self.off_critical_path(lambda: ops.cpb_bwd_batched(self.arena.data, self.cpb_desc, first, n, mw, mh, self.cpb_coords, self.cpb_z,
-                                                               self.cpb_dtables, self.arena.grad))
+            def run():
+                if self.attn_rep > 1:
+                    td, sd, tmax, smax = self._replica_desc(blocks)
+                    ops.replica_reduce(self.cpb_dtables, 1, self.attn_rep, self.cpb_tab_total, td, 1, tmax, self.cpb_dtables)
+                    ops.replica_reduce(self.cpb_dls, 0, self.attn_rep, self.cpb_ls_total, sd, n, smax, self.arena.grad)
+                ops.cpb_bwd_batched(self.arena.data, self.cpb_desc, first, n, mw, mh, self.cpb_coords, self.cpb_z, self.cpb_dtables,
+                                    self.arena.grad)
+            self.off_critical_path(run)
             self.flush_side()
+
+    def _replica_desc(self, blocks):
+        """(src_off, dst_off, count) entries that fold a stage's table-gradient replicas into replica 0 and its logit-scale replicas
+        into the arena's gradients."""
+        key = blocks[0].prefix
+        d = self._rep_desc.get(key)
+        if d is None:
+            lo = self.cpb_slices[blocks[0].prefix][0]
+            off, heads, ts = self.cpb_slices[blocks[-1].prefix]
+            hi = off + heads * ts
+            sd = []
+            for b in blocks:
+                sd += [self.cpb_ls_off[b.prefix], self.arena.offsets[b.prefix + ".attention.self.logit_scale"], b.heads]
+            d = self._rep_desc[key] = (torch.tensor([lo, lo, hi - lo], dtype=torch.int32).to(self.device),
+                                       torch.tensor(sd, dtype=torch.int32).to(self.device), hi - lo, max(b.heads for b in blocks))
+        return d
 
     # ------------------------------------------------------------------------------------------ helpers
     def P(self, name):
@@ -1085,8 +1117,14 @@ class ScOTEngine:
             d_attn_p = d_attn
         d_qkv = self.new(B * Lp, 3 * C, dtype=adt)
         d_table = self.cpb_table(pre, grad=True)   # zeroed once per backward; its MLP backward is batched per stage
-        ops.window_attn_bwd(self.acm, rec["qkv"], rec["attn_p"], d_attn_p, rec["lse"], rec["table"], self.P(a + "logit_scale"), d_qkv, d_table,
-                            self.G(a + "logit_scale"), B, Hp, Wp, C, heads, ws, shift)
+        if self.attn_rep > 1:
+            lo = self.cpb_ls_off[pre]
+            ops.window_attn_bwd_rep(self.acm, rec["qkv"], rec["attn_p"], d_attn_p, rec["lse"], rec["table"], self.P(a + "logit_scale"), d_qkv,
+                                    d_table, self.cpb_dls[lo:lo + heads], B, Hp, Wp, C, heads, ws, shift, self.attn_rep, self.cpb_tab_total,
+                                    self.cpb_ls_total)
+        else:
+            ops.window_attn_bwd(self.acm, rec["qkv"], rec["attn_p"], d_attn_p, rec["lse"], rec["table"], self.P(a + "logit_scale"), d_qkv,
+                                d_table, self.G(a + "logit_scale"), B, Hp, Wp, C, heads, ws, shift)
         wqkv = self.Wspan(a + "qkv_weight", 3 * C * C).view(3 * C, C)
         gwqkv = self.arena.span(a + "qkv_weight", 3 * C * C, grad=True).view(3 * C, C)
         self.wgrad(cm, d_qkv, rec["xp"], gwqkv, dbias=self.arena.span(a + "qkv_bias", 3 * C, grad=True) if cfg.qkv_bias else None)
@@ -1630,6 +1668,8 @@ class ScOTEngine:
                 torch.cuda.current_stream().wait_event(ev)
         self.tdo_dynamic(fill_done)
         self.h_zero(self.cpb_dtables)
+        if self.cpb_dls is not None:
+            self.h_zero(self.cpb_dls)
         self.mark("bwd head")
         _, Cout, H, W = hd["shape"]
         p = cfg.patch_size

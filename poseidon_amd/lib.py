@@ -34,6 +34,8 @@ PROTOTYPES = {
     "scot_window_attn_fwd": [I, P, P, P, P, P, I, I, I, I, I, I, I, P],
     "scot_window_attn_probs": [P, I, P, P, P, P, I, I, I, I, I, I, I, P],
     "scot_window_attn_bwd": [I, P, P, P, P, P, P, P, P, P, I, I, I, I, I, I, I, P],
+    "scot_window_attn_bwd_rep": [I, P, P, P, P, P, P, P, P, P, I, I, I, I, I, I, I, I, Z, Z, P],
+    "scot_replica_reduce": [P, I, I, Z, P, I, I, P, P],
     "scot_cpb_fwd": [P, P, P, P, P, P, I, I, P],
     "scot_cpb_bwd": [P, P, P, P, P, P, P, P, P, I, I, P],
     "scot_cpb_fwd_batched": [P, P, I, I, P, P, P, P],

@@ -245,6 +245,19 @@ def window_attn_bwd(compute, qkv, out_fwd, dout, lse, bias_table, logit_scale, d
                "scot_window_attn_bwd")
 
 
+def window_attn_bwd_rep(compute, qkv, out_fwd, dout, lse, bias_table, logit_scale, dqkv, dbias_table, dlogit_scale, batch, Hp, Wp, C,
+                        heads, ws, shift, nrep, stride_tab, stride_ls):
+    """window_attn_bwd with the two atomically accumulated buffers as `nrep` replicas (element strides): window w adds into replica w % nrep."""
+    _lib.check(L().scot_window_attn_bwd_rep(compute, ptr(qkv), ptr(out_fwd), ptr(dout), ptr(lse), ptr(bias_table), ptr(logit_scale), ptr(dqkv),
+                                            ptr(dbias_table), ptr(dlogit_scale), batch, Hp, Wp, C, heads, ws, shift, nrep, stride_tab,
+                                            stride_ls, stream()), "scot_window_attn_bwd_rep")
+
+
+def replica_reduce(rep, r0, nrep, stride, desc, n, max_count, dst):
+    """dst[dst_off + j] += Σ_{r0 <= r < nrep} rep[r·stride + src_off + j], j < count, per int32 entry (src_off, dst_off, count) of desc."""
+    _lib.check(L().scot_replica_reduce(ptr(rep), r0, nrep, stride, ptr(desc), n, max_count, ptr(dst), stream()), "scot_replica_reduce")
+
+
 def cpb_fwd(coords, w0, b0, w2, table, z, ws, heads):
     _lib.check(L().scot_cpb_fwd(ptr(coords), ptr(w0), ptr(b0), ptr(w2), ptr(table), ptr(z), ws, heads, stream()), "scot_cpb_fwd")
 

@@ -181,6 +181,14 @@ def test_window_attention_fwd_bwd(emu, case):
     assert rel(dqkv, q64.grad) < tol_g
     assert rel(dtab, t64.grad) < tol_g
     assert rel(dls, l64.grad) < (2e-4 if compute == ops.F32 else 2e-3 if compute == ops.X3 else 0.15)
+    # replica entry (window w -> replica w % R) + the fold of the replicas: the same sums
+    R, st, sl = 2, heads * TS + 3, heads + 1
+    rt, rl, dq2, dst = torch.zeros(R * st), torch.zeros(R * sl), torch.empty_like(dqkv), torch.zeros(heads + 2)
+    ops.window_attn_bwd_rep(compute, qkv, out, dout, lse, table, ls, dq2, rt, rl, B, Hp, Wp, C, heads, ws, shift, R, st, sl)
+    assert torch.equal(dq2, dqkv) and (B * nW > 1) == bool(rt[st:].abs().sum() > 0)
+    ops.replica_reduce(rt, 1, R, st, torch.tensor([0, 0, heads * TS], dtype=torch.int32), 1, heads * TS, rt)
+    ops.replica_reduce(rl, 0, R, sl, torch.tensor([0, 2, heads], dtype=torch.int32), 1, heads, dst)
+    assert rel(rt[:heads * TS].view(heads, TS), dtab) < 1e-5 and rel(dst[2:], dls) < 5e-4 and torch.all(dst[:2] == 0)
 
 
 # ---- the fused block kernels of csrc/mlp_fused.hip: the bodies of their (still gated) GPU parity tests, run here on CPU tensors

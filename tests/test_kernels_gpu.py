@@ -211,6 +211,20 @@ def _window_attention_fwd_bwd(compute, case, half):
     assert rel(dtab, t64.grad) < tol_g, "dbias_table"
     # d logit_scale is a heavily cancelling sum over all (q,k) pairs: bf16 operand rounding shows up amplified
     assert rel(dls, l64.grad) < tol_ls, "dlogit_scale"
+    # the replica entry (window w accumulates into replica w % R of both buffers) + the fold: same sums in another order
+    R, pad = 3, 5
+    st, sl = heads * TS + pad, heads + pad
+    rt, rl = torch.zeros(R * st, device=DEV), torch.zeros(R * sl, device=DEV)
+    dq2 = torch.empty_like(dqkv)
+    ops.window_attn_bwd_rep(compute, qkv, out, dout, lse, table, ls, dq2, rt, rl, B, Hp, Wp, C, heads, ws, shift, R, st, sl)
+    assert torch.equal(dq2, dqkv)
+    used = {w % R for w in range(B * nW)}
+    assert all((rt[r * st:(r + 1) * st].abs().sum() > 0) == (r in used) for r in range(R))
+    dst = torch.zeros(heads + 2, device=DEV)
+    ops.replica_reduce(rt, 1, R, st, torch.tensor([0, 0, heads * TS], dtype=torch.int32, device=DEV), 1, heads * TS, rt)
+    ops.replica_reduce(rl, 0, R, sl, torch.tensor([0, 2, heads], dtype=torch.int32, device=DEV), 1, heads, dst)
+    torch.cuda.synchronize()
+    assert rel(rt[:heads * TS].view(heads, TS), dtab) < 1e-5 and rel(dst[2:], dls) < 5e-4 and torch.all(dst[:2] == 0)
 
 
 # ----------------------------------------------------------------------------------------------- CLN

@@ -20,6 +20,8 @@ if os.environ.get("ABL_SET") == "wm":
     VARIANTS = [0, 2, 8, 16, 2 | 8, 2 | 8 | 16]
 if os.environ.get("ABL_SET") == "bwd2":
     VARIANTS = [0, 32, 64, 128, 64 | 128, 32 | 64 | 128, 1 | 4 | 32 | 64 | 128, 1 | 2 | 4 | 8 | 16 | 32 | 64 | 128]
+if os.environ.get("ABL_VARIANTS"):          # explicit list of SCOT_ABL values, e.g. "0,8,32,5"
+    VARIANTS = [int(v) for v in os.environ["ABL_VARIANTS"].split(",")]
 SRC = os.environ.get("ABL_SRC", "mlp_fused.hip")
 
 
