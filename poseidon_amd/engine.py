@@ -85,6 +85,12 @@ class ScOTEngine:
         # pre-norm rows as 16-bit, the backward recomputes gelu'(u) and does not store du, scot_wgrad_mlp recomputes both for the
         # fc1 / fc2 weight gradients, the norms' parameter gradients go through per-workgroup partial rows instead of atomics
         self.lean_tail = os.environ.get("SCOT_LEAN_TAIL", "1") == "1"
+        # Rows that are dead before a layer ends (the fp32 residual h between a layer's two halves) or once the NEXT layer has read them
+        # (its fp32 output; in inference every intermediate) come from a small pool keyed by (tag, shape) instead of fresh memory: a
+        # recorded step owns every buffer it allocated for good, so without the pool each layer's stores go to lines no cache has
+        # seen — with it they land on lines the previous layer left in L2 / MALL.
+        self.recycle = os.environ.get("SCOT_RECYCLE", "1") == "1"
+        self._pool: Dict[tuple, torch.Tensor] = {}
         # ... gelu'(u) itself IS stored (16-bit, 8·C bytes per token) and the backward tail loads it: recomputing it there (the C ABI's
         # `dact = NULL` form of scot_block_tail_bwd) is one more C x 4C product per row tile at the 256-register cap — 140-168 B/lane of
         # scratch, +20 us per launch, +0.3 ms per step (round 3) — so the engine no longer offers it
@@ -416,6 +422,16 @@ class ScOTEngine:
             self._rec_keep.append(t)   # a recorded step owns its buffers for good: replays reuse these very addresses
         return t
 
+    def pool(self, tag, *shape, dtype=torch.float32):
+        """a buffer nobody reads after the consumer the caller is about to launch (see `recycle`): one allocation per (tag, shape, dtype)"""
+        if not self.recycle or self._in_side is not None:
+            return self.new(*shape, dtype=dtype)
+        key = (tag, shape, dtype)
+        t = self._pool.get(key)
+        if t is None:
+            t = self._pool[key] = torch.empty(*shape, dtype=dtype, device=self.device)
+        return t
+
     def zeros(self, *shape, dtype=torch.float32):
         t = self.new(*shape, dtype=dtype)
         self.h_zero(t)
@@ -526,13 +542,19 @@ class ScOTEngine:
         return (None, self.G(prefix + ".weight"), None, self.G(prefix + ".bias"))
 
     def norm_fwd(self, prefix, x, resid, rows_per_sample, C, eps, time, out_dtype=torch.float32, need_stats=True, copy=False,
-                 sample_scale=None):
-        """→ (out, out16, stats); out16 = operand-dtype copy of out (only when copy=True; == out in fp32 mode)."""
+                 sample_scale=None, out=None, out16=None):
+        """→ (out, out16, stats); out16 = operand-dtype copy of out (only when copy=True; == out in fp32 mode).  out / out16: buffers to
+        write instead of fresh ones (the pooled rows of layer_fwd)."""
         rows = x.numel() // C
-        out = self.new(rows, C, dtype=out_dtype)
-        out16 = None
+        if out is None:
+            out = self.new(rows, C, dtype=out_dtype)
         if copy:
-            out16 = out if (self.adt == torch.float32 or out_dtype == self.adt) else self.new(rows, C, dtype=self.adt)
+            if self.adt == torch.float32 or out_dtype == self.adt:
+                out16 = out
+            elif out16 is None:
+                out16 = self.new(rows, C, dtype=self.adt)
+        else:
+            out16 = None
         mean = self.new(rows) if need_stats else None
         rstd = self.new(rows) if need_stats else None
         gw_w, gw_b, bw_w, bw_b = self._norm_params(prefix)
@@ -690,7 +712,7 @@ class ScOTEngine:
         for i, blk in enumerate(blocks):
             last = i + 1 == len(blocks)
             x, x16, r, q = self.layer_fwd(blk, x, x16, B, time, train, qkv_pre=q, next_blk=None if last else blocks[i + 1],
-                                          want_attn=self.collect_attn and last)      # (a stage returns its LAST block's, ref:859-860)
+                                          want_attn=self.collect_attn and last, idx=i)      # (a stage returns its LAST block's, ref:859-860)
             recs.append(r)
         return x, x16, recs
 
@@ -753,7 +775,7 @@ class ScOTEngine:
         ws, _ = blk.window_shift()
         return H % ws == 0 and W % ws == 0 and blk.dim in self.fused_next_qkv and not self.precision_probe
 
-    def layer_fwd(self, blk: BlockGeom, x, x16, B, time, train, qkv_pre=None, next_blk=None, want_attn=False):
+    def layer_fwd(self, blk: BlockGeom, x, x16, B, time, train, qkv_pre=None, next_blk=None, want_attn=False, idx=0):
         """reference ScOTLayer.forward (model.py:500-581) + Swinv2Attention/Intermediate/Output (HF:389-561).  qkv_pre: this layer's
         q/k/v projection, already produced by the previous layer's fused tail; next_blk: the layer that follows in the same stage
         (its projection becomes this tail's epilogue when the fused tail runs).  Returns (out, out16, rec, qkv_next or None)."""
@@ -766,8 +788,18 @@ class ScOTEngine:
         L, Lp = H * W, Hp * Wp
         pre = blk.prefix
         a = pre + ".attention.self."
+        # buffers: `tmp` = read only inside this layer and not by the backward (everything, in inference); `nxt` = read by the next layer of
+        # the stage only (two alternate: this layer reads the other one).  A stage's last layer writes fresh rows (skips, merges, hidden states).
+        par = idx & 1
+        tmp = self.pool if not train else (lambda tag, *s_, dtype=torch.float32: self.new(*s_, dtype=dtype))
+        alias32 = train and self.adt == torch.float32      # fp32 operands: h16 IS h and out16 IS out, and training keeps the 16-bit rows
+        dead = self.pool if not alias32 else tmp           # dead in training too
+        fresh_out = next_blk is None or alias32
+        nxt = (lambda tag, *s_, dtype=torch.float32: self.pool((tag, par), *s_, dtype=dtype)) if not fresh_out else \
+            (lambda tag, *s_, dtype=torch.float32: self.new(*s_, dtype=dtype))
+        nxt16 = nxt if not train else (lambda tag, *s_, dtype=torch.float32: self.new(*s_, dtype=dtype))    # (training keeps out16: the next layer's xp)
         if padded:
-            xp = self.new(B * Lp, C, dtype=self.adt)
+            xp = tmp("xp", B * Lp, C, dtype=self.adt)
             ops.copy2d(x16, xp, B, H, W, Hp, Wp, C)
         else:
             xp = x16
@@ -780,23 +812,23 @@ class ScOTEngine:
             assert not padded
             qkv = qkv_pre
         else:
-            qkv = self.new(B * Lp, 3 * C, dtype=self.adt)
+            qkv = tmp("qkv", B * Lp, 3 * C, dtype=self.adt)
             ops.linear_fwd(cm, xp, wqkv, qkv, bias=bqkv)
         tw = blk.table_window
         if tw != ws:
             raise NotImplementedError("run-time window differs from the constructor-time CPB table window "
                                       f"({ws} vs {tw}); the reference would fail to broadcast here too")
         table = self.cpb_table(pre)   # computed for all layers by the batched launch at the start of forward()
-        attn = self.new(B * Lp, C, dtype=self.adt)
+        attn = tmp("attn", B * Lp, C, dtype=self.adt)
         nW = (Hp // ws) * (Wp // ws)
-        lse = self.new(B * nW, heads, ws * ws)
+        lse = tmp("lse", B * nW, heads, ws * ws)
         ops.window_attn_fwd(self.acm, qkv, attn, lse, table, self.P(a + "logit_scale"), B, Hp, Wp, C, heads, ws, shift)
         if want_attn:     # output_attentions: the probabilities are recomputed from qkv and lse by a separate kernel, into fresh memory
             probs = torch.empty(B * nW, heads, ws * ws, ws * ws, dtype=torch.float32, device=self.device)
             ops.window_attn_probs(qkv, lse, table, self.P(a + "logit_scale"), probs, B, Hp, Wp, C, heads, ws, shift)
             self.attn_sink.append(probs)
         if padded:
-            attn_c = self.new(B * L, C, dtype=self.adt)
+            attn_c = tmp("attn_c", B * L, C, dtype=self.adt)
             ops.copy2d(attn, attn_c, B, Hp, Wp, H, W, C)
         else:
             attn_c = attn
@@ -848,17 +880,17 @@ class ScOTEngine:
             zdt = self.adt if lean else torch.float32        # pre-norm rows: only the norm backward's x-hat reads them
             proj = self.new(B * L, C, dtype=zdt) if train else None
             st1 = (self.new(B * L), self.new(B * L)) if train else (None, None)
-            h, h16 = self.new(B * L, C), self.new(B * L, C, dtype=self.adt)
+            h, h16 = dead("h", B * L, C), tmp("h16", B * L, C, dtype=self.adt)
             u = self.new(B * L, hid, dtype=self.adt) if (train and not lean) else None
             gp = self.new(B * L, hid, dtype=self.adt) if train else None
             y2 = self.new(B * L, C, dtype=zdt) if train else None
             st2 = (self.new(B * L), self.new(B * L)) if train else (None, None)
-            out, out16 = self.new(B * L, C), self.new(B * L, C, dtype=self.adt)
+            out, out16 = nxt("out", B * L, C), nxt16("out16", B * L, C, dtype=self.adt)
             n1, n2 = self._norm_params(pre + ".layernorm_before"), self._norm_params(pre + ".layernorm_after")
             nq = (None, None, None)
             if next_blk is not None and next_blk.dim == C and self.qkv_fusable(next_blk):
                 na = next_blk.prefix + ".attention.self."
-                qkv_next = self.new(B * L, 3 * C, dtype=self.adt)
+                qkv_next = nxt16("qkvn", B * L, 3 * C, dtype=self.adt)
                 nq = (self.Wspan(na + "qkv_weight", 3 * C * C).view(3 * C, C),
                       self.arena.span(na + "qkv_bias", 3 * C) if cfg.qkv_bias else None, qkv_next)
             done_tail = ops.block_tail_fwd(
@@ -877,18 +909,18 @@ class ScOTEngine:
         elif proj_f:
             proj = self.new(B * L, C) if train else None
             st1 = (self.new(B * L), self.new(B * L)) if train else (None, None)
-            h, h16 = self.new(B * L, C), self.new(B * L, C, dtype=self.adt)
+            h, h16 = dead("h", B * L, C), tmp("h16", B * L, C, dtype=self.adt)
             gw_w, gw_b, bw_w, bw_b = self._norm_params(pre + ".layernorm_before")
             if not ops.proj_cln_fwd(attn_c, self.W(pre + ".attention.output.dense.weight"), self.P(pre + ".attention.output.dense.bias"),
                                     x, h, h16, proj, st1[0], st1[1], time if self.cond else None, gw_w, gw_b, bw_w, bw_b, dp1, B * L, L,
                                     C, cfg.layer_norm_eps):
                 raise RuntimeError("scot_proj_cln_fwd rejected a shape the engine selected it for")
         else:
-            proj = self.new(B * L, C)
+            proj = tmp("proj", B * L, C)
             ops.linear_fwd(cm, attn_c, self.W(pre + ".attention.output.dense.weight"), proj,
                            bias=self.P(pre + ".attention.output.dense.bias"))
             h, h16, st1 = self.norm_fwd(pre + ".layernorm_before", proj, x, L, C, cfg.layer_norm_eps, time, need_stats=train,
-                                        copy=True, sample_scale=dp1)
+                                        copy=True, sample_scale=dp1, out=dead("h", B * L, C), out16=tmp("h16", B * L, C, dtype=self.adt))
         if done_tail:
             pass
         elif mlp_f:
@@ -896,7 +928,7 @@ class ScOTEngine:
             gp = self.new(B * L, hid, dtype=self.adt) if train else None
             y2 = self.new(B * L, C) if train else None
             st2 = (self.new(B * L), self.new(B * L)) if train else (None, None)
-            out, out16 = self.new(B * L, C), self.new(B * L, C, dtype=self.adt)
+            out, out16 = nxt("out", B * L, C), nxt16("out16", B * L, C, dtype=self.adt)
             gw_w, gw_b, bw_w, bw_b = self._norm_params(pre + ".layernorm_after")
             if not ops.mlp_block_fwd(h16, h, self.W(pre + ".intermediate.dense.weight"), self.P(pre + ".intermediate.dense.bias"),
                                      self.W(pre + ".output.dense.weight"), self.P(pre + ".output.dense.bias"), out, out16, u, gp, y2,
@@ -905,14 +937,14 @@ class ScOTEngine:
                 raise RuntimeError("scot_mlp_block_fwd rejected a shape the engine selected it for")
         else:
             # fc1 epilogue emits a = gelu(u) AND gp = gelu'(u) (one erf, fp32 registers); u itself is never stored
-            u = self.new(B * L, hid, dtype=self.adt)
+            u = tmp("u", B * L, hid, dtype=self.adt)
             gp = self.new(B * L, hid, dtype=self.adt) if train else None
             ops.linear_fwd(cm, h16, self.W(pre + ".intermediate.dense.weight"), u, bias=self.P(pre + ".intermediate.dense.bias"),
                            gelu_deriv_out=gp if train else u)     # eval: GELU(u) only (`gelu_deriv_out is out`)
-            y2 = self.new(B * L, C)
+            y2 = tmp("y2", B * L, C)
             ops.linear_fwd(cm, u, self.W(pre + ".output.dense.weight"), y2, bias=self.P(pre + ".output.dense.bias"))
             out, out16, st2 = self.norm_fwd(pre + ".layernorm_after", y2, h, L, C, cfg.layer_norm_eps, time, need_stats=train,
-                                            copy=True, sample_scale=dp2)
+                                            copy=True, sample_scale=dp2, out=nxt("out", B * L, C), out16=nxt16("out16", B * L, C, dtype=self.adt))
         rec = None
         if train:
             rec = dict(blk=blk, xp=xp, qkv=qkv, attn_p=attn, table=table, lse=lse, attn_c=attn_c, proj=proj, st1=st1, h16=h16, u=u, gp=gp,
@@ -1007,7 +1039,7 @@ class ScOTEngine:
         if pend is not None and not can_prologue:
             g = self.dgrad_into(cm, pend[0], pend[1], g, wt=pend[2])
             pend = None
-        d_attn = self.new(B * L, C, dtype=adt)
+        d_attn = self.pool("d_attn", B * L, C, dtype=adt)      # read by this layer's attention backward (same stream) and by nothing else
         done_tail = False
         lean = bool(rec.get("lean"))
         if lean:
@@ -1111,7 +1143,7 @@ class ScOTEngine:
             ops.linear_dgrad(cm, d_proj, self.W(pre + ".attention.output.dense.weight"), d_attn,
                              wt=self.WT(pre + ".attention.output.dense.weight"))
         if padded:
-            d_attn_p = self.new(B * Lp, C, dtype=adt)
+            d_attn_p = self.pool("d_attn_p", B * Lp, C, dtype=adt)
             ops.copy2d(d_attn, d_attn_p, B, H, W, Hp, Wp, C)
         else:
             d_attn_p = d_attn
