@@ -233,6 +233,8 @@ def launch_table(engine, run_step, nsteps=3, dump=None):
             # FLOPs again) instead of reading them — only the two weight-gradient products count as algorithmic work
             key = "wgrad_mlp (fc1 + fc2 weight gradients, gelu(u) / du recomputed in the kernel)"
             fl = 2 * 2.0 * args[9] * args[10] * args[11]
+        if name == "scot_window_attn_bwd_rep":      # the same kernels, accumulating the table / scale gradients into replicas
+            name, key = "scot_window_attn_bwd", "window_attn_bwd"
         if name in ("scot_window_attn_fwd", "scot_window_attn_bwd"):
             # algorithmic work of a (window, head): 4 N^2 d forward (QK^T, PV), 10 N^2 d backward (dV, dP, dQ, dK + the recomputed S);
             # the backward kernels execute 14 N^2 d (S and dP once per half)
