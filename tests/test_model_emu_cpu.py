@@ -237,6 +237,36 @@ def test_engine_lean_layer_tail(emu, monkeypatch):
     assert e < 2e-3 and res["1"][3] == 0 and res["0"][3] == 0
 
 
+@pytest.mark.parametrize("compute", ["fp16", "fp32"])
+def test_engine_pooled_rows_change_nothing(emu, monkeypatch, compute):
+    """Round 4: rows that are dead within a layer (the fp32 residual h, a layer's fp32 output, every inference intermediate, d_attn) come from
+    engine.pool instead of fresh memory.  Same kernels on the same values: loss, prediction, gradients and the inference forward are
+    BIT-identical with the pool on and off — a buffer handed out while somebody still reads it would show here (three layers per stage: both
+    alternating output buffers are re-used; fp32 operands: h16 IS h and out16 IS out, which training keeps — those stay fresh)."""
+    cfg = ScOTConfig(image_size=32, patch_size=4, num_channels=4, num_out_channels=4, embed_dim=96, depths=[3, 3], num_heads=[3, 6],
+                     skip_connections=[1, 0], window_size=16, mlp_ratio=4.0, qkv_bias=True, drop_path_rate=0.0, hidden_act="gelu", p=1,
+                     channel_slice_list_normalized_loss=[0, 1, 3, 4], residual_model="convnext", use_conditioning=True,
+                     learn_residual=False)      # 64 rows per sample at C = 96 (the fused tail), 16 at C = 192 (layer-by-layer launches)
+    sd = synth_state_dict(param_shapes(cfg), "trained")
+    pv, t, lab = synth_inputs(2, 4, 4, 32, "smooth")
+    res = {}
+    for flag in ("0", "1"):
+        monkeypatch.setenv("SCOT_RECYCLE", flag)
+        from scOT.model import ScOT
+        model = ScOT(cfg, compute=compute)
+        model.load_state_dict(sd)
+        model._ensure_arena(torch.device("cpu"))
+        eng = model._engine
+        assert eng.recycle == (flag == "1")
+        loss, pred, tape = eng.forward(pv, t, lab, None, train=True)
+        model._prepare_grads()
+        eng.backward(tape, torch.ones(1), None)
+        _, pred_eval, _ = eng.forward(pv, t, None, None, train=False)
+        res[flag] = (float(loss), pred.clone(), model._arena.grad.clone(), pred_eval.clone(), len(eng._pool))
+    assert res["0"][4] == 0 and res["1"][4] > 0
+    assert res["1"][0] == res["0"][0] and all(torch.equal(res["1"][i], res["0"][i]) for i in (1, 2, 3))
+
+
 @pytest.mark.skipif(not FULL, reason="~3 min of emulated MFMA arithmetic: SCOT_EMU_FULL=1")
 @pytest.mark.parametrize("fused", ["0", "1"])
 def test_engine_poseidon_T_bf16(emu, monkeypatch, fused):
