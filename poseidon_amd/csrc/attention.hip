@@ -14,6 +14,11 @@
 // over (lane>>4, reg, tile) → row max / sum need only two xor-shuffles (16, 32), and the probabilities are
 // already in MFMA A-operand order for P·V (no LDS round trip, no permutes).
 #include "attention.h"
+// Tile-pair loop of the backward at NT = 4 (8x8 and 7x7 windows; 1536 four-wave workgroups at stage 2): unrolled twice it is fully unrolled and
+// holds 178 VGPRs = 2 workgroups per CU = three rounds of the ~12 us per-workgroup chain; rolled it needs 118 = 4 per CU.
+#ifndef SCOT_NT4_UNROLL
+#define SCOT_NT4_UNROLL 1
+#endif
 
 // ================================================================================================= forward
 template <typename CT, int HD, int NT>  // NT = number of 16-key tiles (even), NP = 16*NT >= N
@@ -183,7 +188,7 @@ __device__ __forceinline__ void normalize_bwd_store(const f32x4_t (&acc)[HD / 16
 // produced (no 128-register S/dP pair): S^T, dP^T -> P -> dS -> {table histogram, dQ += dS·Kn}.
 template <typename CT, int HD, int NT>
 __device__ __forceinline__ void attn_bwd_dq_body(const AttnArgs& p) {
-  constexpr int NP = NT * 16, KS = (HD + 31) / 32, DT = HD / 16, pitch = row_pitch<HD, CT>();
+  constexpr int NP = NT * 16, KS = (HD + 31) / 32, DT = HD / 16, pitch = row_pitch<HD, CT>(), TPU = NT == 4 ? SCOT_NT4_UNROLL : 2;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   CT* X = (CT*)smem;            // Kn
   CT* Y = X + NP * pitch;       // V
@@ -247,7 +252,7 @@ __device__ __forceinline__ void attn_bwd_dq_body(const AttnArgs& p) {
 #pragma unroll
     for (int d = 0; d < DT; ++d) dq[d] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
 
-#pragma unroll 2
+#pragma unroll TPU
     for (int tp = 0; tp < NT / 2; ++tp) {
       float ds8[8];
 #pragma unroll
@@ -317,7 +322,7 @@ __device__ __forceinline__ void attn_bwd_dq_body(const AttnArgs& p) {
 // Independent of kernel 1 (delta is recomputed from dO ∘ O while dO is staged), so the two can run concurrently.
 template <typename CT, int HD, int NT>
 __device__ __forceinline__ void attn_bwd_dkv_body(const AttnArgs& p) {
-  constexpr int NP = NT * 16, KS = (HD + 31) / 32, DT = HD / 16, pitch = row_pitch<HD, CT>();
+  constexpr int NP = NT * 16, KS = (HD + 31) / 32, DT = HD / 16, pitch = row_pitch<HD, CT>(), TPU = NT == 4 ? SCOT_NT4_UNROLL : 2;
   constexpr int CPR = KS * 4;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   CT* X = (CT*)smem;            // Qn
@@ -383,7 +388,7 @@ __device__ __forceinline__ void attn_bwd_dkv_body(const AttnArgs& p) {
 #pragma unroll
     for (int d = 0; d < DT; ++d) { dv[d] = (f32x4_t){0.f, 0.f, 0.f, 0.f}; dk[d] = (f32x4_t){0.f, 0.f, 0.f, 0.f}; }
 
-#pragma unroll 2
+#pragma unroll TPU
     for (int tp = 0; tp < NT / 2; ++tp) {
       float pf8[8], df8[8];
 #pragma unroll

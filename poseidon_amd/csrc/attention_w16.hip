@@ -450,8 +450,27 @@ __device__ __forceinline__ void attn16_bwd_dq_body(const AttnArgs& p) {
 #pragma unroll
     for (int d = 0; d < DT; ++d) dq[d] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
 
+    // (as in the dK/dV half below: the LDS operands of tile pair tp + 1 are requested before pair tp is multiplied)
+    constexpr bool PRE = HD <= 32 && !X3;
+    struct PairOps { FragX<CT, X3> k[2][KS], v[2][KS], kt[DT]; float tb[2][4]; };
+    PairOps po[PRE ? 2 : 1];
+    auto fetch = [&](PairOps& o, int tp) {
+#pragma unroll
+      for (int half = 0; half < 2; ++half) {
+        const int t = 2 * tp + half;
+#pragma unroll
+        for (int kk = 0; kk < KS; ++kk) { o.k[half][kk] = rdx_kc<HD>(xb, t, kk); o.v[half][kk] = rdx_kc<HD>(yb, t, kk); }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) o.tb[half][r] = tq[(15 - t) * 31 + 3 - r];
+      }
+#pragma unroll
+      for (int d = 0; d < DT; ++d) o.kt[d] = rdx_ks<HD>(xb, tp, d);
+    };
+    if constexpr (PRE) fetch(po[0], 0);
 #pragma unroll
     for (int tp = 0; tp < NT / 2; ++tp) {
+      const PairOps& o = po[PRE ? (tp & 1) : 0];
+      if constexpr (PRE) { if (tp + 1 < NT / 2) fetch(po[(tp + 1) & 1], tp + 1); }
       float ds8[8];
 #pragma unroll
       for (int half = 0; half < 2; ++half) {
@@ -459,15 +478,15 @@ __device__ __forceinline__ void attn16_bwd_dq_body(const AttnArgs& p) {
         f32x4_t s = {0.f, 0.f, 0.f, 0.f}, dp = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int kk = 0; kk < KS; ++kk) {
-          mmax(s, rdx_kc<HD>(xb, t, kk), qf[kk]);
-          mmax(dp, rdx_kc<HD>(yb, t, kk), gf[kk]);
+          if constexpr (PRE) { mmax(s, o.k[half][kk], qf[kk]); mmax(dp, o.v[half][kk], gf[kk]); }
+          else { mmax(s, rdx_kc<HD>(xb, t, kk), qf[kk]); mmax(dp, rdx_kc<HD>(yb, t, kk), gf[kk]); }
         }
         float madd = nlse2;
         if (SHIFTED) madd += (lastrow && ((qb >= 8) != (t >= 8))) ? kMask2 : mlane;
         float ds[4];
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          const float pr = fast_exp2(fmaf(s[r], scale2, tq[(15 - t) * 31 + 3 - r]) + madd);
+          const float pr = fast_exp2(fmaf(s[r], scale2, PRE ? o.tb[half][r] : tq[(15 - t) * 31 + 3 - r]) + madd);
           ds[r] = pr * (dp[r] - delta);
           ds8[half * 4 + r] = ds[r];
           accD = fmaf(pr, dp[r], accD);
@@ -486,8 +505,10 @@ __device__ __forceinline__ void attn16_bwd_dq_body(const AttnArgs& p) {
       }
       const FragX<CT, X3> df = fragx_from_f32<CT, X3>(ds8);
 #pragma unroll
-      for (int d = 0; d < DT; ++d)   // dQn^T += Kn^T · dS^T
-        mmax(dq[d], rdx_ks<HD>(xb, tp, d), df);
+      for (int d = 0; d < DT; ++d) {  // dQn^T += Kn^T · dS^T
+        if constexpr (PRE) mmax(dq[d], o.kt[d], df);
+        else mmax(dq[d], rdx_ks<HD>(xb, tp, d), df);
+      }
       __builtin_amdgcn_sched_barrier(0);   // one tile pair at a time: unrolled for the immediates, not for hoisting
     }
     accD += __shfl_xor(accD, 16, 64); accD += __shfl_xor(accD, 32, 64);
@@ -585,6 +606,62 @@ __device__ __forceinline__ void attn16_bwd_dkv_body(const AttnArgs& p) {
 #pragma unroll
     for (int d = 0; d < DT; ++d) { dv[d] = (f32x4_t){0.f, 0.f, 0.f, 0.f}; dk[d] = (f32x4_t){0.f, 0.f, 0.f, 0.f}; }
 
+    constexpr bool PRE = HD <= 32 && !X3;      // (head_dim 64 / split operands: the second register set would cost a wave per SIMD or spill)
+    if constexpr (PRE) {
+    // The LDS operands of tile pair tp + 1 are requested before pair tp is multiplied (two register sets): read where they are used,
+    // every tile cost five LDS round trips in a row (83 waits per key block in the ISA) and the wave's chain of waits, not its
+    // ~650 VALU instructions per key block, set the kernel's time at three workgroups per CU.
+    struct PairOps { FragX<CT, X3> q[2][KS], g[2][KS], yt[DT], xt[DT]; float4 nl[2], qd[2]; float tb[2][4]; };
+    PairOps po[2];
+    auto fetch = [&](PairOps& o, int tp) {
+#pragma unroll
+      for (int half = 0; half < 2; ++half) {
+        const int t = 2 * tp + half;
+#pragma unroll
+        for (int kk = 0; kk < KS; ++kk) { o.q[half][kk] = rdx_kc<HD>(xb, t, kk); o.g[half][kk] = rdx_kc<HD>(yb, t, kk); }
+        o.nl[half] = *(const float4*)&nlg[t * 16];
+        o.qd[half] = *(const float4*)&dlg[t * 16];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) o.tb[half][r] = tk[t * 31 + r];
+      }
+#pragma unroll
+      for (int d = 0; d < DT; ++d) { o.yt[d] = rdx_ks<HD>(yb, tp, d); o.xt[d] = rdx_ks<HD>(xb, tp, d); }
+    };
+    fetch(po[0], 0);
+#pragma unroll
+    for (int tp = 0; tp < NT / 2; ++tp) {
+      const PairOps& o = po[tp & 1];
+      if (tp + 1 < NT / 2) fetch(po[(tp + 1) & 1], tp + 1);
+      float pf8[8], df8[8];
+#pragma unroll
+      for (int half = 0; half < 2; ++half) {
+        const int t = 2 * tp + half;
+        f32x4_t s = {0.f, 0.f, 0.f, 0.f}, dp = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int kk = 0; kk < KS; ++kk) {
+          mmax(s, o.q[half][kk], kf[kk]);   // rows = queries 4g + r of row t, col = key
+          mmax(dp, o.g[half][kk], vf[kk]);
+        }
+        const float nla[4] = {o.nl[half].x, o.nl[half].y, o.nl[half].z, o.nl[half].w};
+        const float qda[4] = {o.qd[half].x, o.qd[half].y, o.qd[half].z, o.qd[half].w};
+        float madd = 0.f;
+        if (SHIFTED) madd = (lastrow && ((t >= 8) != (kb >= 8))) ? kMask2 : mlane;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const float pr = fast_exp2(fmaf(s[r], scale2, o.tb[half][r]) + (madd + nla[r]));
+          pf8[half * 4 + r] = pr;
+          df8[half * 4 + r] = pr * (dp[r] - qda[r]);
+        }
+      }
+      const FragX<CT, X3> pf = fragx_from_f32<CT, X3>(pf8), df = fragx_from_f32<CT, X3>(df8);
+#pragma unroll
+      for (int d = 0; d < DT; ++d) {
+        mmax(dv[d], o.yt[d], pf);   // dV^T  += dO^T · P
+        mmax(dk[d], o.xt[d], df);   // dKn^T += Qn^T · dS
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    } else {
 #pragma unroll
     for (int tp = 0; tp < NT / 2; ++tp) {
       float pf8[8], df8[8];
@@ -616,6 +693,7 @@ __device__ __forceinline__ void attn16_bwd_dkv_body(const AttnArgs& p) {
         mmax(dk[d], rdx_ks<HD>(xb, tp, d), df);   // dKn^T += Qn^T · dS
       }
       __builtin_amdgcn_sched_barrier(0);
+    }
     }
 #pragma unroll
     for (int d = 0; d < DT; ++d) {
