@@ -430,6 +430,8 @@ class ScOTEngine:
         t = self._pool.get(key)
         if t is None:
             t = self._pool[key] = torch.empty(*shape, dtype=dtype, device=self.device)
+        if self._rec is not None:
+            self._rec_keep.append(t)      # (a recorded step names the address: it keeps the buffer alive whatever happens to the pool)
         return t
 
     def zeros(self, *shape, dtype=torch.float32):
