@@ -110,6 +110,17 @@ int scot_gemm(int layout, int compute, int M, int N, int K,
  * fp32 atomics without any) — this is the size at which nothing is clipped.  SURVEY.md §8(b): `scot_<op>_workspace_bytes(dims…)`. */
 size_t scot_gemm_workspace_bytes(int layout, int compute, int M, int N, int K);
 
+/* NT products with 16-bit operands, M % 128 == 0, N % 128 == 0, K % 64 == 0 whose 64 x 64-tile grid is small and long or large and
+ * short (the Linear layers of the C = 384 / 768 stages: HF modeling_swinv2.py:396-410, 496-506, 536-561 at scOT/model.py:403-404) run
+ * on 128 x 128 tiles; when that leaves too few tiles, K is cut into slices INSIDE the launch: every slice leaves an fp32 slab in
+ * `workspace`, the workgroup that draws the tile's last arrival ticket adds the slabs in slice order and runs the epilogue (no reduce
+ * launch; results do not depend on the arrival order).  WORKSPACE CONVENTION (all entry points that take one): the LAST 4096 bytes are
+ * the tile arrival counters — zero when the buffer is first handed over; every launch leaves them zero — and nothing else is written
+ * there; scot_*_workspace_bytes answers include them.
+ * scot_gemm_wide_config: mode 0 = never use these tiles, 1 = the library's policy (default), 2 = every eligible call; force_split > 0
+ * fixes the number of K slices (tests, tools/bench_deep_gemm.py).  Process-wide, not thread-safe against concurrent scot_gemm calls. */
+void scot_gemm_wide_config(int mode, int force_split);
+
 /* The weight gradients of one ScOTLayer in ONE launch: for i < n (n <= 8)
  *   dW_i[M_i, N_i] += dY_i[K, M_i]^T · X_i[K, N_i],   dbias_i[M_i] += Σ_k dY_i[k, :]   (dbias / dbias_i may be NULL)
  * i.e. the autograd of query/key/value, attention.output.dense, intermediate.dense and output.dense (HF:396-410, 502-506,

@@ -102,6 +102,7 @@ def L():
 _workspace = {}
 _retired = []                   # outgrown scratch buffers: kept alive (launches already enqueued may still use them)
 WORKSPACE_MIN_BYTES = 8 << 20
+WS_RESERVED = 4096              # csrc/common.h SCOT_WS_RESERVED: the workspace's last bytes are scot_gemm's tile arrival counters (zero between launches)
 
 
 _slot = 0
@@ -121,13 +122,14 @@ def workspace(need: int = 0):
     the address it was recorded with: growth only happens on a shape's first (eager, unrecorded) call."""
     key = (torch.cuda.current_device(), _slot)
     w = _workspace.get(key)
-    if w is None or w.numel() < need:
+    if w is None or w.numel() < need + WS_RESERVED:
         size = WORKSPACE_MIN_BYTES
-        while size < need:
+        while size < need + WS_RESERVED:
             size *= 2
         if w is not None:
             _retired.append(w)
-        w = torch.empty(size, dtype=torch.uint8, device=f"cuda:{key[0]}")
+        # zero-filled: the arrival counters in the tail must read 0 at their first launch (every launch leaves them 0 again)
+        w = torch.zeros(size, dtype=torch.uint8, device=f"cuda:{key[0]}")
         _workspace[key] = w
     return w
 

@@ -67,6 +67,56 @@ def test_gemm_layouts(compute, layout, mixed, M, N, K):
         assert rel(C2, ref + bias.double() + res.double()) < tol
 
 
+WIDE_CASES = [(1024, 768, 3072, 0), (1024, 3072, 768, 0), (4096, 384, 1536, 0), (1024, 768, 2304, 4), (4096, 1536, 384, 1), (1024, 768, 768, 3),
+              (2048, 1536, 1536, 0), (256, 128, 64, 1), (128, 128, 1024, 8)]
+
+
+@pytest.mark.parametrize("kind", ["f16", "bf16"])
+@pytest.mark.parametrize("M,N,K,split", WIDE_CASES)
+def test_gemm_wide_in_launch_split_k(kind, M, N, K, split):
+    """csrc/gemm_wide.hip: the deep stages' NT products on 128 x 128 tiles, K slices reduced by the last-arriving workgroup.  split = 0:
+    the library's own policy for the shape, otherwise forced.  Every epilogue form of the engine's calls against fp64 on the rounded
+    operands; 20 repeated launches are BIT-identical (the slabs are added in slice order whoever arrives last: a stale or missing slab
+    would show here); the arrival counters in the workspace tail are zero afterwards; agrees with gemm_fast's 64 x 64 tiles."""
+    prev = ops.use(kind)
+    lib = ops.L()
+    try:
+        hd = ops.half_dtype()
+        tol16 = 1.2e-3 if kind == "f16" else 6e-3
+        x, w, b = rnd(M, K, dtype=hd), rnd(N, K, dtype=hd, scale=K ** -0.5, seed=1), rnd(N, seed=2)
+        u = x.double() @ w.double().t() + b.double()
+        lib.scot_gemm_wide_config(0, 0)
+        y_fast = torch.empty(M, N, device=DEV)
+        ops.linear_fwd(ops.BF16, x, w, y_fast, bias=b)
+        lib.scot_gemm_wide_config(2 if split else 1, split)
+        y32, y16 = torch.full((M, N), float("nan"), device=DEV), torch.empty(M, N, device=DEV, dtype=hd)
+        ops.linear_fwd(ops.BF16, x, w, y32, bias=b)
+        ops.linear_fwd(ops.BF16, x, w, y16, bias=b)
+        assert rel(y32, u) < 1e-5 and rel(y16, u) < tol16 and rel(y32, y_fast) < 2e-6
+        for _ in range(20):
+            y = torch.full((M, N), float("nan"), device=DEV)
+            ops.linear_fwd(ops.BF16, x, w, y, bias=b)
+            assert torch.equal(y, y32)
+        gv, gd = torch.empty(M, N, device=DEV, dtype=hd), torch.empty(M, N, device=DEV, dtype=hd)
+        ops.linear_fwd(ops.BF16, x, w, gv, bias=b, gelu_deriv_out=gd)
+        assert rel(gv, torch.nn.functional.gelu(u)) < tol16
+        assert rel(gd, 0.5 * (1 + torch.erf(u / math.sqrt(2))) + u * torch.exp(-0.5 * u * u) / math.sqrt(2 * math.pi)) < tol16
+        if K % 128 == 0 and N % 64 == 0:      # the data gradients: dx[M, K] = dy[M, N] w[N, K] as an NT product on the transposed copy
+            dy, wt, aux = rnd(M, N, dtype=hd, seed=3), w.t().contiguous(), rnd(M, K, dtype=hd, seed=4)
+            dx = torch.empty(M, K, device=DEV, dtype=hd)
+            ops.linear_dgrad(ops.BF16, dy, w, dx, aux=aux, aux_mul=True, wt=wt)
+            assert rel(dx, (dy.double() @ w.double()) * aux.double()) < tol16
+            g0 = rnd(M, K, seed=5)
+            g = g0.clone()
+            ops.linear_dgrad(ops.BF16, dy, w, g, accumulate=True, wt=wt)
+            assert rel(g, g0.double() + dy.double() @ w.double()) < 1e-5
+        torch.cuda.synchronize()
+        assert int(ops.workspace()[-4096:].view(torch.int32).abs().sum()) == 0
+    finally:
+        lib.scot_gemm_wide_config(1, 0)
+        ops.use(prev)
+
+
 @pytest.mark.parametrize("compute", [ops.F32, ops.BF16])
 def test_gemm_epilogues(compute):
     M, N, K = 520, 192, 96
