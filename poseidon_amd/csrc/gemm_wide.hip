@@ -18,15 +18,25 @@
 
 #define LAYOUT_NT 0
 
+// Hand-off of a slab to the tile's last arriver (cdna_hip_programming.md §6 Guideline 16, recipe R1): the slab is stored WRITE-THROUGH
+// (16-byte buffer stores with the sc1 bit: the bytes leave this XCD's L2 for memory, no release fence — a `buffer_wbl2` per workgroup
+// wrote back the whole L2 each time and doubled the launch, profiles/round5/gemm_wide_sweep_r5.txt), every storing wave drains its
+// stores, ONE lane takes the ticket (relaxed agent-scope atomic); the last arriver's ONE acquire drops its CU's L1, then plain loads.
 #ifdef SCOT_HIPEMU
 #define SCOT_WAIT_VM0() ((void)0)
-#define SCOT_RELEASE_AGENT() ((void)0)
 #define SCOT_ACQUIRE_AGENT() ((void)0)
+struct wide_rsrc_t { float* base; };
+__device__ __forceinline__ wide_rsrc_t wide_make_rsrc(float* base, int) { return wide_rsrc_t{base}; }
+__device__ __forceinline__ void wide_store_wt(f32x4_t v, wide_rsrc_t r, int byte_off) { *(f32x4_t*)((char*)r.base + byte_off) = v; }
 #else
 #define SCOT_WAIT_VM0() asm volatile("s_waitcnt vmcnt(0)" ::: "memory")
-// release: write back this XCD's dirty L2 lines (the slab), and the wait the compiler may drop behind buffer_wbl2 restated
-#define SCOT_RELEASE_AGENT() do { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent"); asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); } while (0)
 #define SCOT_ACQUIRE_AGENT() __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent")
+typedef __amdgpu_buffer_rsrc_t wide_rsrc_t;
+__device__ __forceinline__ wide_rsrc_t wide_make_rsrc(float* base, int bytes) { return __builtin_amdgcn_make_buffer_rsrc(base, 0, bytes, 0x00020000); }
+typedef unsigned wide_u32x4_t __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void wide_store_wt(f32x4_t v, wide_rsrc_t r, int byte_off) {
+  __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(wide_u32x4_t, v), r, byte_off, 0, /*aux: sc1*/ 16);
+}
 #endif
 
 struct WideArgs {
@@ -61,9 +71,11 @@ __device__ __forceinline__ Frag<bf16_t> wide_frag(const bf16_t* t, int r0, int k
 #define WIDE_EPI_NONE 0
 #define WIDE_EPI_AUX16 1
 #define WIDE_EPI_RES32 2
-template <int BM, int BN, int STAGES, int EPI>
-__global__ __launch_bounds__((BM / 64) * (BN / 64) * 64) void gemm_wide_kernel(WideArgs p) {
-  constexpr int WN = BN / 64, NW = (BM / 64) * WN, NT = NW * 64;
+// WM x WN: arrangement of the NW = WM·WN waves over the tile; a wave owns (BM / WM) x (BN / WN).  More waves, not more bytes in flight, is
+// what raises a workgroup's direct-to-LDS ingest: a wave's global_load_lds instructions complete one after the other (~1 KB per 300 clk).
+template <int BM, int BN, int WM, int WN, int STAGES, int EPI>
+__global__ __launch_bounds__(WM * WN * 64) void gemm_wide_kernel(WideArgs p) {
+  constexpr int NW = WM * WN, NT = NW * 64, MI = BM / WM / 16, NI = BN / WN / 16, WROWS = BM / WM, WCOLS = BN / WN;
   constexpr int STAGE = WideLds<BM, BN, STAGES>::STAGE, BOFF = BM * 64;
   constexpr int PA = BM / 8 / NW, PB = BN / 8 / NW, LPW = PA + PB;      // 1 KB pieces (8 tile rows) per wave and K-tile
   constexpr int CP = BN + 4;
@@ -88,11 +100,11 @@ __global__ __launch_bounds__((BM / 64) * (BN / 64) * 64) void gemm_wide_kernel(W
   const int kt0 = slice * p.kt_slice;
   const int nk = min(p.kt_slice, nkt - kt0);
 
-  f32x4_t acc[4][4];
+  f32x4_t acc[MI][NI];
 #pragma unroll
-  for (int i = 0; i < 4; ++i)
+  for (int i = 0; i < MI; ++i)
 #pragma unroll
-    for (int jj = 0; jj < 4; ++jj) acc[i][jj] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+    for (int jj = 0; jj < NI; ++jj) acc[i][jj] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
 
   // epilogue geometry: a thread owns one 8-column chunk (cc) of the rows tid / CPRW + it * RPP
   constexpr int CPRW = BN / 8, RPP = NT / CPRW, E_IT = BM / RPP;
@@ -139,15 +151,15 @@ __global__ __launch_bounds__((BM / 64) * (BN / 64) * 64) void gemm_wide_kernel(W
     const bf16_t* Bs = st + BOFF;
 #pragma unroll
     for (int kk = 0; kk < 64; kk += 32) {
-      Frag<bf16_t> fa[4], fb[4];
+      Frag<bf16_t> fa[MI], fb[NI];
 #pragma unroll
-      for (int i = 0; i < 4; ++i) fa[i] = wide_frag(As, wr * 64 + i * 16, kk, lane);
+      for (int i = 0; i < MI; ++i) fa[i] = wide_frag(As, wr * WROWS + i * 16, kk, lane);
 #pragma unroll
-      for (int jj = 0; jj < 4; ++jj) fb[jj] = wide_frag(Bs, wc * 64 + jj * 16, kk, lane);
+      for (int jj = 0; jj < NI; ++jj) fb[jj] = wide_frag(Bs, wc * WCOLS + jj * 16, kk, lane);
 #pragma unroll
-      for (int i = 0; i < 4; ++i)
+      for (int i = 0; i < MI; ++i)
 #pragma unroll
-        for (int jj = 0; jj < 4; ++jj) mma16(acc[i][jj], fa[i], fb[jj]);
+        for (int jj = 0; jj < NI; ++jj) mma16(acc[i][jj], fa[i], fb[jj]);
     }
   };
 
@@ -170,19 +182,16 @@ __global__ __launch_bounds__((BM / 64) * (BN / 64) * 64) void gemm_wide_kernel(W
     // slab of (tile, slice): the accumulators in fragment order — one 16-byte store per lane and fragment, 1 KB contiguous per wave instruction
     float* slab0 = p.slabs + (size_t)tile * p.nsplit * (BM * BN);
     {
-      float* mine = slab0 + (size_t)slice * (BM * BN);
+      const wide_rsrc_t mine = wide_make_rsrc(slab0 + (size_t)slice * (BM * BN), BM * BN * 4);
 #pragma unroll
-      for (int i = 0; i < 4; ++i)
+      for (int i = 0; i < MI; ++i)
 #pragma unroll
-        for (int jj = 0; jj < 4; ++jj) *(f32x4_t*)(mine + ((i * 4 + jj) * NT + tid) * 4) = acc[i][jj];
+        for (int jj = 0; jj < NI; ++jj) wide_store_wt(acc[i][jj], mine, ((i * NI + jj) * NT + tid) * 16);
     }
     int* flag = (int*)(smem + WideLds<BM, BN, STAGES>::flag_off);
-    SCOT_WAIT_VM0();
+    SCOT_WAIT_VM0();                 // every storing wave: its write-through stores have reached memory
     __syncthreads();
-    if (tid == 0) {
-      SCOT_RELEASE_AGENT();
-      *flag = atomicAdd(p.counters + tile, 1);
-    }
+    if (tid == 0) *flag = atomicAdd(p.counters + tile, 1);
     __syncthreads();
     if (*flag != p.nsplit - 1) return;
     if (tid == 0) {
@@ -192,46 +201,46 @@ __global__ __launch_bounds__((BM / 64) * (BN / 64) * 64) void gemm_wide_kernel(W
     __syncthreads();
     if constexpr (EPI != WIDE_EPI_NONE) load_epilogue_operands();
     // Σ over the slices in slice order, this workgroup's own term from its registers: bit-identical whoever arrives last
-    f32x4_t tot[4][4];
+    f32x4_t tot[MI][NI];
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+    for (int i = 0; i < MI; ++i)
 #pragma unroll
-      for (int jj = 0; jj < 4; ++jj) tot[i][jj] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+      for (int jj = 0; jj < NI; ++jj) tot[i][jj] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
     for (int s = 0; s < p.nsplit; ++s) {
       if (s == slice) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i)
+        for (int i = 0; i < MI; ++i)
 #pragma unroll
-          for (int jj = 0; jj < 4; ++jj) tot[i][jj] += acc[i][jj];
+          for (int jj = 0; jj < NI; ++jj) tot[i][jj] += acc[i][jj];
       } else {
         const float* other = slab0 + (size_t)s * (BM * BN);
-        f32x4_t v[4][4];
+        f32x4_t v[MI][NI];
 #pragma unroll
-        for (int i = 0; i < 4; ++i)
+        for (int i = 0; i < MI; ++i)
 #pragma unroll
-          for (int jj = 0; jj < 4; ++jj) v[i][jj] = *(const f32x4_t*)(other + ((i * 4 + jj) * NT + tid) * 4);
+          for (int jj = 0; jj < NI; ++jj) v[i][jj] = *(const f32x4_t*)(other + ((i * NI + jj) * NT + tid) * 4);
 #pragma unroll
-        for (int i = 0; i < 4; ++i)
+        for (int i = 0; i < MI; ++i)
 #pragma unroll
-          for (int jj = 0; jj < 4; ++jj) tot[i][jj] += v[i][jj];
+          for (int jj = 0; jj < NI; ++jj) tot[i][jj] += v[i][jj];
       }
     }
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+    for (int i = 0; i < MI; ++i)
 #pragma unroll
-      for (int jj = 0; jj < 4; ++jj) acc[i][jj] = tot[i][jj];
+      for (int jj = 0; jj < NI; ++jj) acc[i][jj] = tot[i][jj];
   }
 
   // ---- epilogue through LDS (the C tile aliases the stages): 16- / 32-byte row segments per thread
   __syncthreads();
   float* Cs = (float*)smem;
 #pragma unroll
-  for (int i = 0; i < 4; ++i)
+  for (int i = 0; i < MI; ++i)
 #pragma unroll
-    for (int jj = 0; jj < 4; ++jj)
+    for (int jj = 0; jj < NI; ++jj)
 #pragma unroll
       for (int r = 0; r < 4; ++r)
-        Cs[(wr * 64 + i * 16 + g * 4 + r) * CP + wc * 64 + jj * 16 + (lane & 15)] = acc[i][jj][r];
+        Cs[(wr * WROWS + i * 16 + g * 4 + r) * CP + wc * WCOLS + jj * 16 + (lane & 15)] = acc[i][jj][r];
   __syncthreads();
   float bv[8];
 #pragma unroll
@@ -272,8 +281,11 @@ __global__ __launch_bounds__((BM / 64) * (BN / 64) * 64) void gemm_wide_kernel(W
 
 // ---- launch policy -------------------------------------------------------------------------------------------------------------
 // mode: 0 = never, 1 = policy (default), 2 = every eligible call (tests / tools); force_split > 0 overrides the slice count
-static int g_wide_mode = 1, g_wide_force_split = 0;
-extern "C" void scot_gemm_wide_config(int mode, int force_split) { g_wide_mode = mode; g_wide_force_split = force_split; }
+static int g_wide_mode = 1, g_wide_force_split = 0, g_wide_variant = 1;
+extern "C" void scot_gemm_wide_config(int mode, int force_split) {
+  g_wide_mode = mode & 0xff; g_wide_force_split = force_split;
+  if (mode >> 8) g_wide_variant = (mode >> 8) - 1;       // (tools/bench_deep_gemm.py: bits 8.. = 1 + kernel variant, see wide_launch)
+}
 
 #define SCOT_WIDE_COUNTER_BYTES SCOT_WS_RESERVED     /* the LAST bytes of the caller's workspace: tile arrival counters, zero between launches */
 
@@ -284,7 +296,6 @@ static bool wide_plan(int M, int N, int K, WidePlan& pl) {
   if (g_wide_mode == 0) return false;
   if (M % 128 || N % 128 || K % 64 || M < 128 || N < 128) return false;
   const int tm = M / 128, tn = N / 128, tiles = tm * tn, nkt = K / 64;
-  if (tiles > (int)(SCOT_WS_RESERVED / sizeof(int))) return false;
   int S = 1;
   if (g_wide_mode == 1) {
     // The tile pays where a 64 x 64 grid is either small and long (stage 3: 192 workgroups x 36-48 K-tiles) or large and short; it needs
@@ -301,6 +312,7 @@ static bool wide_plan(int M, int N, int K, WidePlan& pl) {
   }
   if (g_wide_force_split > 0) S = g_wide_force_split;
   if (S > nkt) S = nkt;
+  if (S > 1 && tiles > (int)(SCOT_WS_RESERVED / sizeof(int))) return false;      // one arrival counter per tile
   pl.kt_slice = (nkt + S - 1) / S;
   pl.S = (nkt + pl.kt_slice - 1) / pl.kt_slice;
   pl.tiles = tiles; pl.tiles_n = tn;
@@ -318,6 +330,14 @@ size_t scot_gemm_wide_workspace_bytes(int layout, int compute, int M, int N, int
   WidePlan pl;
   if (layout != LAYOUT_NT || compute != SCOT_BF16 || !wide_plan(M, N, K, pl)) return 0;
   return pl.slab_bytes ? pl.slab_bytes + SCOT_WIDE_COUNTER_BYTES : 0;
+}
+
+template <int WM, int WN, int STAGES>
+static void wide_launch(int epi, unsigned grid, const WideArgs& a, hipStream_t stream) {
+  const dim3 g(grid), b(WM * WN * 64);
+  if (epi == WIDE_EPI_AUX16) hipLaunchKernelGGL((gemm_wide_kernel<128, 128, WM, WN, STAGES, WIDE_EPI_AUX16>), g, b, 0, stream, a);
+  else if (epi == WIDE_EPI_RES32) hipLaunchKernelGGL((gemm_wide_kernel<128, 128, WM, WN, STAGES, WIDE_EPI_RES32>), g, b, 0, stream, a);
+  else hipLaunchKernelGGL((gemm_wide_kernel<128, 128, WM, WN, STAGES, WIDE_EPI_NONE>), g, b, 0, stream, a);
 }
 
 // Returns SCOT_ERR_UNSUPPORTED when the call does not qualify (scot_gemm then asks gemm_fast).
@@ -349,8 +369,14 @@ int scot_gemm_wide(int layout, int compute, int M, int N, int K, const void* A, 
     a.counters = (int*)((char*)workspace + ws_bytes - SCOT_WIDE_COUNTER_BYTES);
   }
   const unsigned grid = 8u * (unsigned)pl.tpx * (unsigned)pl.S;
-  if (a.aux) hipLaunchKernelGGL((gemm_wide_kernel<128, 128, 3, WIDE_EPI_AUX16>), dim3(grid), dim3(256), 0, stream, a);
-  else if (a.resid) hipLaunchKernelGGL((gemm_wide_kernel<128, 128, 3, WIDE_EPI_RES32>), dim3(grid), dim3(256), 0, stream, a);
-  else hipLaunchKernelGGL((gemm_wide_kernel<128, 128, 3, WIDE_EPI_NONE>), dim3(grid), dim3(256), 0, stream, a);
+  const int epi = a.aux ? WIDE_EPI_AUX16 : (a.resid ? WIDE_EPI_RES32 : WIDE_EPI_NONE);
+  switch (g_wide_variant) {
+    case 0: wide_launch<2, 2, 3>(epi, grid, a, stream); break;      // 4 waves of 64 x 64, three 32 KB stages
+    case 2: wide_launch<2, 4, 4>(epi, grid, a, stream); break;      // 8 waves of 64 x 32, four stages
+    case 3: wide_launch<4, 4, 3>(epi, grid, a, stream); break;      // 16 waves of 32 x 32, three stages
+    case 4: wide_launch<2, 4, 2>(epi, grid, a, stream); break;      // 8 waves, two stages: 68 KB of LDS = two workgroups per CU (large grids)
+    case 5: wide_launch<2, 2, 2>(epi, grid, a, stream); break;      // 4 waves, two stages
+    default: wide_launch<2, 4, 3>(epi, grid, a, stream); break;     // 8 waves of 64 x 32, three stages
+  }
   return scot_check_launch();
 }

@@ -90,6 +90,12 @@ class ScOTEngine:
         # recorded step owns every buffer it allocated for good, so without the pool each layer's stores go to lines no cache has
         # seen — with it they land on lines the previous layer left in L2 / MALL.
         self.recycle = os.environ.get("SCOT_RECYCLE", "1") == "1"
+        # Saved-activation diet of the lean tail (round 5 experiment): the training forward of a C = 96 / 192 layer runs
+        # its tail in the INFERENCE form — it keeps only the layer's fp32 input rows and the attention output (+ what the attention backward
+        # needs) — and the backward first re-runs the tail's training form into ONE pooled buffer set (pre-norm rows, statistics, gelu'(u);
+        # hot in L2 / MALL when scot_block_tail_bwd reads them right behind).  h16 alone gets fresh rows: scot_wgrad_mlp reads it on the
+        # weight-gradient stream, layers later.  Trades 2·M·15C² flop per layer for ≈ 10·C bytes per token of cold stores + their re-reads.
+        self.recompute_tail = os.environ.get("SCOT_RECOMPUTE_TAIL", "0") == "1"
         self._pool: Dict[tuple, torch.Tensor] = {}
         # ... gelu'(u) itself IS stored (16-bit, 8·C bytes per token) and the backward tail loads it: recomputing it there (the C ABI's
         # `dact = NULL` form of scot_block_tail_bwd) is one more C x 4C product per row tile at the 256-register cap — 140-168 B/lane of
@@ -796,7 +802,10 @@ class ScOTEngine:
         tmp = self.pool if not train else (lambda tag, *s_, dtype=torch.float32: self.new(*s_, dtype=dtype))
         alias32 = train and self.adt == torch.float32      # fp32 operands: h16 IS h and out16 IS out, and training keeps the 16-bit rows
         dead = self.pool if not alias32 else tmp           # dead in training too
-        fresh_out = next_blk is None or alias32
+        hid_ = int(cfg.mlp_ratio * C)
+        rcp = bool(train and self.recompute_tail and self.lean_tail and not padded and self.use_fused("proj_fwd", C) and self.use_fused("mlp_fwd", C)
+                   and hid_ % 128 == 0 and self.fused_tail and self._lean_ok(pre, B * L, L, C, hid_))
+        fresh_out = next_blk is None or alias32 or rcp      # (recompute: the NEXT layer's backward re-reads these rows as its input)
         nxt = (lambda tag, *s_, dtype=torch.float32: self.pool((tag, par), *s_, dtype=dtype)) if not fresh_out else \
             (lambda tag, *s_, dtype=torch.float32: self.new(*s_, dtype=dtype))
         nxt16 = nxt if not train else (lambda tag, *s_, dtype=torch.float32: self.new(*s_, dtype=dtype))    # (training keeps out16: the next layer's xp)
@@ -879,14 +888,15 @@ class ScOTEngine:
         elif proj_f and mlp_f and self.fused_tail:
             # projection + norm + residual, then MLP + norm + residual, for the same rows in one launch
             lean = train and self.lean_tail and self._lean_ok(pre, B * L, L, C, hid)
-            zdt = self.adt if lean else torch.float32        # pre-norm rows: only the norm backward's x-hat reads them
-            proj = self.new(B * L, C, dtype=zdt) if train else None
-            st1 = (self.new(B * L), self.new(B * L)) if train else (None, None)
-            h, h16 = dead("h", B * L, C), tmp("h16", B * L, C, dtype=self.adt)
-            u = self.new(B * L, hid, dtype=self.adt) if (train and not lean) else None
-            gp = self.new(B * L, hid, dtype=self.adt) if train else None
-            y2 = self.new(B * L, C, dtype=zdt) if train else None
-            st2 = (self.new(B * L), self.new(B * L)) if train else (None, None)
+            keep = train and not rcp                         # rcp: nothing of the tail is kept, the backward re-runs it (layer_bwd)
+            zdt = self.adt if (lean and keep) else torch.float32        # pre-norm rows: only the norm backward's x-hat reads them
+            proj = self.new(B * L, C, dtype=zdt) if keep else None
+            st1 = (self.new(B * L), self.new(B * L)) if keep else (None, None)
+            h, h16 = dead("h", B * L, C), (tmp if keep or not train else self.pool)("h16", B * L, C, dtype=self.adt)
+            u = self.new(B * L, hid, dtype=self.adt) if (keep and not lean) else None
+            gp = self.new(B * L, hid, dtype=self.adt) if keep else None
+            y2 = self.new(B * L, C, dtype=zdt) if keep else None
+            st2 = (self.new(B * L), self.new(B * L)) if keep else (None, None)
             out, out16 = nxt("out", B * L, C), nxt16("out16", B * L, C, dtype=self.adt)
             n1, n2 = self._norm_params(pre + ".layernorm_before"), self._norm_params(pre + ".layernorm_after")
             nq = (None, None, None)
@@ -900,8 +910,10 @@ class ScOTEngine:
                  st1[0], st1[1], n1[0], n1[1], n1[2], n1[3], dp1),
                 (self.W(pre + ".intermediate.dense.weight"), self.P(pre + ".intermediate.dense.bias"), self.W(pre + ".output.dense.weight"),
                  self.P(pre + ".output.dense.bias"), out, out16, u, gp, y2, st2[0], st2[1], n2[0], n2[1], n2[2], n2[3], dp2),
-                time if self.cond else None, B * L, L, C, hid, cfg.layer_norm_eps, *nq, z16=lean)
+                time if self.cond else None, B * L, L, C, hid, cfg.layer_norm_eps, *nq, z16=bool(lean and keep))
             lean_used = lean
+            if rcp and not done_tail:
+                raise RuntimeError("scot_block_tail_fwd rejected the inference form of a shape the engine selected it for")
             if not done_tail:
                 if lean:
                     raise RuntimeError("scot_block_tail_fwd rejected a shape the engine selected it for")
@@ -950,7 +962,8 @@ class ScOTEngine:
         rec = None
         if train:
             rec = dict(blk=blk, xp=xp, qkv=qkv, attn_p=attn, table=table, lse=lse, attn_c=attn_c, proj=proj, st1=st1, h16=h16, u=u, gp=gp,
-                       y2=y2, st2=st2, geom=(H, W, Hp, Wp, ws, shift, padded), dp=(dp1, dp2), lean=bool(done_tail and lean_used))
+                       y2=y2, st2=st2, geom=(H, W, Hp, Wp, ws, shift, padded), dp=(dp1, dp2), lean=bool(done_tail and lean_used),
+                       recompute=bool(done_tail and rcp), x=x if rcp else None)
         return out, out16, rec, qkv_next
 
     def dgrad_into(self, cm, dy, w, g, wt=None):
@@ -1044,6 +1057,24 @@ class ScOTEngine:
         d_attn = self.pool("d_attn", B * L, C, dtype=adt)      # read by this layer's attention backward (same stream) and by nothing else
         done_tail = False
         lean = bool(rec.get("lean"))
+        if rec.get("recompute"):
+            # the tail's training form, re-run from the layer's input rows and attention output into the pooled set (see `recompute_tail`)
+            zdt = adt
+            proj_r, y2_r = self.pool("rc_z1", B * L, C, dtype=zdt), self.pool("rc_z2", B * L, C, dtype=zdt)
+            st1_r, st2_r = (self.pool("rc_m1", B * L), self.pool("rc_r1", B * L)), (self.pool("rc_m2", B * L), self.pool("rc_r2", B * L))
+            h_r, h16_r = self.pool("h", B * L, C), self.new(B * L, C, dtype=adt)
+            gp_r = self.pool("rc_gp", B * L, hid, dtype=adt)
+            out_r, out16_r = self.pool("rc_out", B * L, C), self.pool("rc_out16", B * L, C, dtype=adt)
+            n1r, n2r = self._norm_params(pre + ".layernorm_before"), self._norm_params(pre + ".layernorm_after")
+            if not ops.block_tail_fwd(
+                    (rec["attn_c"], self.W(pre + ".attention.output.dense.weight"), self.P(pre + ".attention.output.dense.bias"), rec["x"], h_r,
+                     h16_r, proj_r, st1_r[0], st1_r[1], n1r[0], n1r[1], n1r[2], n1r[3], rec["dp"][0]),
+                    (self.W(pre + ".intermediate.dense.weight"), self.P(pre + ".intermediate.dense.bias"), self.W(pre + ".output.dense.weight"),
+                     self.P(pre + ".output.dense.bias"), out_r, out16_r, None, gp_r, y2_r, st2_r[0], st2_r[1], n2r[0], n2r[1], n2r[2], n2r[3],
+                     rec["dp"][1]),
+                    time if self.cond else None, B * L, L, C, hid, cfg.layer_norm_eps, None, None, None, z16=True):
+                raise RuntimeError("scot_block_tail_fwd rejected the recomputation of a layer it ran in the forward")
+            rec = dict(rec, proj=proj_r, st1=st1_r, h16=h16_r, gp=gp_r, y2=y2_r, st2=st2_r)
         if lean:
             # the tail without 4C-wide tensors: gelu'(u) recomputed from h16, du never stored, the norms' parameter gradients as
             # per-workgroup partial rows; on the weight-gradient stream: the partial rows' column sums, the fc1 / fc2 gradients with

@@ -138,6 +138,11 @@ def load(path: str = None, kind: str = "bf16"):
     if lib.scot_operand_format() != OPERAND_FORMAT[kind]:
         raise ScotLibraryError(f"{path} was built for operand format {lib.scot_operand_format()}, expected {OPERAND_FORMAT[kind]} "
                                f"({kind}); rebuild with `python -m poseidon_amd.build --force`")
+    # tuning knob for A/B runs (tools/gpu_ab.sh): SCOT_GEMM_WIDE = "<mode>[,<forced K slices>]" -> scot_gemm_wide_config (include/scot_hip.h)
+    w = os.environ.get("SCOT_GEMM_WIDE")
+    if w:
+        mode, _, split = w.partition(",")
+        lib.scot_gemm_wide_config(int(mode), int(split or 0))
     _libs[kind] = lib
     return lib
 

@@ -72,12 +72,13 @@ def _wide_reference(x, w, b):
     return x.double() @ w.double().t() + (b.double() if b is not None else 0.0)
 
 
+@pytest.mark.parametrize("variant", [0, 1, 2, 3, 4, 5])
 @pytest.mark.parametrize("M,N,K,split", [(128, 128, 128, 0), (256, 128, 256, 2), (128, 256, 448, 3), (256, 256, 384, 6)])
-def test_gemm_wide_tiles_and_in_launch_split_k(emu, M, N, K, split):
+def test_gemm_wide_tiles_and_in_launch_split_k(emu, M, N, K, split, variant):
     """csrc/gemm_wide.hip (mode 2 = every eligible call): 128 x 128 tiles, K slices that meet inside the launch.  Every epilogue form the
     engine uses on the deep stages' NT products, against fp64; the arrival counters in the workspace tail are zero afterwards."""
     lib = emu
-    lib.scot_gemm_wide_config(2, split)
+    lib.scot_gemm_wide_config(2 | ((variant + 1) << 8), split)       # (bits 8..: 1 + kernel variant — 4 / 8 / 16 waves, 3 / 4 LDS stages)
     try:
         ws = ops.workspace()
         x, w, b = rnd(M, K, dtype=torch.bfloat16), rnd(N, K, dtype=torch.bfloat16, scale=K ** -0.5, seed=1), rnd(N, seed=2)
@@ -111,7 +112,7 @@ def test_gemm_wide_tiles_and_in_launch_split_k(emu, M, N, K, split):
             ops.linear_fwd(ops.BF16, x, w, y1, bias=b)
             assert rel(y32, y1) < 1e-6
     finally:
-        lib.scot_gemm_wide_config(1, 0)
+        lib.scot_gemm_wide_config(1 | (2 << 8), 0)
 
 
 def test_gemm_wide_policy_is_what_the_workspace_query_says(emu):

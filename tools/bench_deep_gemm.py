@@ -45,7 +45,7 @@ def main():
     ops.use("f16")
     lib = ops.L()
     hd, dev = ops.half_dtype(), "cuda"
-    stages = {"B": [(1024, 768), (4096, 384)], "L": [(2048, 1536), (8192, 768)]}[a.model]
+    stages = {"B": [(1024, 768), (4096, 384)], "L": [(2048, 1536), (8192, 768), (32768, 384)], "B256": [(2048, 768), (8192, 384)]}[a.model]
     rows = []
     for M, C in stages:
         x = torch.randn(M, C, device=dev).to(hd)
@@ -77,17 +77,20 @@ def main():
             lib.scot_gemm_wide_config(1, 0)
             res["policy"] = graph_time(fn)
             nkt = K // 64
-            for S in (1, 2, 3, 4, 6, 8):
-                if S > nkt or (M // 128) * (N // 128) * S > 1024:
-                    continue
-                lib.scot_gemm_wide_config(2, S)
-                res[f"wide S={S}"] = graph_time(fn)
-            lib.scot_gemm_wide_config(1, 0)
+            tiles = (M // 128) * (N // 128)
+            big = tiles > 512
+            for var, vname in (((1, "8w3s"), (4, "8w2s"), (5, "4w2s")) if big else ((0, "4w3s"), (1, "8w3s"), (2, "8w4s"), (3, "16w3s"), (4, "8w2s"))):
+                for S in ((1,) if big else (1, 2, 3, 4, 6)):
+                    if S > nkt or tiles * S > 1024 or (S > 1 and (tiles * S > 400 or nkt // S < 3)):
+                        continue
+                    lib.scot_gemm_wide_config(2 | ((var + 1) << 8), S)
+                    res[f"{vname} S={S}"] = graph_time(fn)
+            lib.scot_gemm_wide_config(1 | (2 << 8), 0)
             gf = 2.0 * M * N * K / 1e9
             best = min(res, key=res.get)
             rows.append(dict(M=M, N=N, K=K, name=name, tiles128=(M // 128) * (N // 128), us=res, best=best))
             print(f"M={M:5d} N={N:5d} K={K:5d} {name:22s} tiles128={(M // 128) * (N // 128):4d} | " +
-                  " | ".join(f"{k} {v:5.1f}" for k, v in res.items()) + f" | best {best} = {gf / res[best] * 1e-3:.0f} TF/s", flush=True)
+                  " | ".join(f"{k} {v:5.1f}" for k, v in res.items()) + f" | best {best} = {gf / res[best] * 1e3:.0f} TF/s", flush=True)
     if a.json:
         json.dump(rows, open(a.json, "w"), indent=1)
 
