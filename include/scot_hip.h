@@ -110,16 +110,14 @@ int scot_gemm(int layout, int compute, int M, int N, int K,
  * fp32 atomics without any) — this is the size at which nothing is clipped.  SURVEY.md §8(b): `scot_<op>_workspace_bytes(dims…)`. */
 size_t scot_gemm_workspace_bytes(int layout, int compute, int M, int N, int K);
 
-/* NT products with 16-bit operands, M % 128 == 0, N % 128 == 0, K % 64 == 0 whose 64 x 64-tile grid is small and long or large and
- * short (the Linear layers of the C = 384 / 768 stages: HF modeling_swinv2.py:396-410, 496-506, 536-561 at scOT/model.py:403-404) run
- * on 128 x 128 tiles; when that leaves too few tiles, K is cut into slices INSIDE the launch: every slice leaves an fp32 slab in
- * `workspace`, the workgroup that draws the tile's last arrival ticket adds the slabs in slice order and runs the epilogue (no reduce
- * launch; results do not depend on the arrival order).  WORKSPACE CONVENTION (all entry points that take one): the LAST 4096 bytes are
- * the tile arrival counters — zero when the buffer is first handed over; every launch leaves them zero — and nothing else is written
- * there; scot_*_workspace_bytes answers include them.
- * scot_gemm_wide_config: mode 0 = never use these tiles, 1 = the library's policy (default), 2 = every eligible call; force_split > 0
- * fixes the number of K slices (tests, tools/bench_deep_gemm.py).  Process-wide, not thread-safe against concurrent scot_gemm calls. */
-void scot_gemm_wide_config(int mode, int force_split);
+/* NT products with 16-bit operands, M % 128 == 0, N % 128 == 0, K % 64 == 0 whose grid of 128 x 128 output tiles still gives every CU
+ * two workgroups, or one with a long contraction (the Linear layers HF modeling_swinv2.py:396-410, 496-506, 536-561 at the widths and
+ * token counts of Poseidon-L, of Poseidon-B at 256 x 256, and the long-K / gelu'-scaled products of Poseidon-B's deep stages), run in
+ * csrc/gemm_wide.hip (policy and measurements there); results agree with the 64 x 64-tile kernel to fp32 summation order.
+ * scot_gemm_wide_config: mode 0 = never use these tiles, 1 = the library's policy (default), 2 = every eligible call, with kernel
+ * `variant` 0 (8 waves, 4 LDS stages), 1 (8 waves, 2 stages) or 2 (4 waves, 2 stages) — tests and tools/bench_deep_gemm.py.
+ * Process-wide, not thread-safe against concurrent scot_gemm calls. */
+void scot_gemm_wide_config(int mode, int variant);
 
 /* The weight gradients of one ScOTLayer in ONE launch: for i < n (n <= 8)
  *   dW_i[M_i, N_i] += dY_i[K, M_i]^T · X_i[K, N_i],   dbias_i[M_i] += Σ_k dY_i[k, :]   (dbias / dbias_i may be NULL)
@@ -282,30 +280,6 @@ int scot_memcpy_async(void* dst, const void* src, size_t n, scot_stream_t stream
 int scot_event_record(void* event, scot_stream_t stream);
 int scot_stream_wait_event(scot_stream_t stream, void* event);
 int scot_tape_replay(const unsigned long long* prog, size_t n_words, int* fail_entry);
-
-/* Deep stages (C = 384 / 768; 4096 / 1024 token rows at batch 64), csrc/tail_deep.hip — the same tail (ref model.py:560-579,
- * HF:396-410, 478-489, 533-561) with SIXTEEN rows per workgroup, every weight matrix streamed from L2 straight into MFMA operand
- * fragments.  That needs FRAGMENT-ORDERED operand copies of the weights:
- *   scot_fragpack: wf16[dst + ((nt·K/32 + ks)·64 + lane)·8 + j] = w[src + row·K + 32 ks + 8 (lane >> 4) + j], row = 16 nt + (lane & 15),
- *   for every matrix of desc (int32 [n][6], device: source offset, N, K, first 256-piece block, mode, destination offset; mode bit 0:
- *   the source holds the transpose [K][N]; bit 1: rows permuted inside 32-row blocks, fragment row 16 t + 4 a + b <- source row
- *   8 a + 4 t + b — the fc1 weight); N % 16 == 0, K % 32 == 0; blocks = total block count.
- *   scot_deep_tail_fwd: arguments as scot_block_tail_fwd with Wo_f / W1_f (permuted) / W2_f / Wqkv_f fragment-ordered; h may be NULL
- *   when hsplit == 1 (the residual never leaves the kernel); the qkv epilogue exists at C = 384.  hsplit > 1: the hidden dimension is
- *   shared by hsplit workgroups per 16 rows, ypart [hsplit][M][C] fp32 receives the partial fc2 sums and
- *   scot_deep_tail_finish applies the rest: out = h + s2 · CLN2(Σ_q ypart[q] + b2).  M % 16 == 0, rows_per_sample % 16 == 0,
- *   hid == 4C, hid % (128·hsplit) == 0; -3 otherwise. */
-int scot_fragpack(const float* w, void* wf16, const int* desc, int n, int blocks, scot_stream_t stream);
-int scot_deep_tail_fwd(const void* a, const void* Wo_f, const float* bo, const float* x, float* h, void* h16, void* z1, float* mean1,
-                       float* rstd1, const float* gw_w1, const float* gw_b1, const float* bw_w1, const float* bw_b1,
-                       const float* sscale1, const void* W1_f, const float* b1, const void* W2_f, const float* b2, float* out, void* out16,
-                       void* act, void* dact, void* z2, float* mean2, float* rstd2, const float* gw_w2, const float* gw_b2,
-                       const float* bw_w2, const float* bw_b2, const float* sscale2, const void* Wqkv_f, const float* bqkv, void* qkv,
-                       int z_dt, const float* time, int M, int rows_per_sample, int C, int hid, float eps, int hsplit, float* ypart,
-                       scot_stream_t stream);
-int scot_deep_tail_finish(const float* ypart, int hsplit, const float* b2, const float* h, float* out, void* out16, void* z2, int z_dt,
-                          float* mean2, float* rstd2, const float* gw_w2, const float* gw_b2, const float* bw_w2, const float* bw_b2,
-                          const float* sscale2, const float* time, int M, int rows_per_sample, int C, float eps, scot_stream_t stream);
 
 /* The fc1 / fc2 weight and bias gradients of a ScOTLayer's MLP WITHOUT gelu(u), gelu'(u), du in HBM (csrc/wgrad_mlp.hip; autograd of
  * HF:545-548, 558-561): per token slice and hidden chunk the kernel recomputes u = h16·W1^T + b1 and dz·W2 and feeds gelu(u) / du from

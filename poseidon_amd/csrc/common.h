@@ -27,11 +27,6 @@
 #define SCOT_ERR_UNSUPPORTED (-3)
 #define SCOT_ERR_LAUNCH (-4)
 
-// Workspace convention of every entry point that takes (workspace, ws_bytes): the LAST SCOT_WS_RESERVED bytes belong to the tile arrival
-// counters of gemm_wide.hip's in-launch split-K (zero when the buffer is handed over, zero again after every launch); partial tiles of
-// the other kernels stay below them.
-#define SCOT_WS_RESERVED 4096
-
 typedef uint16_t bf16_t;
 #if defined(SCOT_OPERAND_FP16)
 typedef _Float16 h16_scalar_t;

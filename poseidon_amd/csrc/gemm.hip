@@ -214,11 +214,11 @@ int scot_gemm_fast(int layout, int compute, int M, int N, int K, const void* A, 
                    const void* B, int b_dt, int ldb, int b_gelu, void* C, int c_dt, int ldc, const float* bias,
                    const float* colscale, const void* aux, int aux_dt, int ldaux, const void* resid, int res_dt, int ldres,
                    int accumulate, float* colsum_out, void* workspace, size_t ws_bytes, int aux_mul, void* C2, hipStream_t stream);
-// gemm_wide.hip: 128 x 128 tiles with the K split reduced inside the launch (the deep stages' NT products)
+// gemm_wide.hip: 128 x 128 tiles for the NT products whose grid keeps every CU busy with them (policy there)
 int scot_gemm_wide(int layout, int compute, int M, int N, int K, const void* A, int a_dt, int lda, int a_gelu,
                    const void* B, int b_dt, int ldb, int b_gelu, void* C, int c_dt, int ldc, const float* bias,
                    const float* colscale, const void* aux, int aux_dt, int ldaux, const void* resid, int res_dt, int ldres,
-                   int accumulate, float* colsum_out, void* workspace, size_t ws_bytes, int aux_mul, void* C2, hipStream_t stream);
+                   int accumulate, float* colsum_out, int aux_mul, void* C2, hipStream_t stream);
 extern "C" int scot_colsum(const void* x, int x_dt, const void* y, int y_dt, float* out, int M, int N, int ld, hipStream_t s);
 int scot_gemm_panel(int layout, int compute, int M, int N, int K, const void* A, int a_dt, int lda, int a_gelu, const void* B,
                     int b_dt, int ldb, int b_gelu, void* C, int c_dt, int ldc, const float* bias, const float* colscale,
@@ -249,14 +249,12 @@ extern "C" int scot_gemm(int layout, int compute, int M, int N, int K,
   }
   {
     const int rc = scot_gemm_wide(layout, compute, M, N, K, A, a_dt, lda, a_gelu, B, b_dt, ldb, b_gelu, C, c_dt, ldc, bias, colscale,
-                                  aux, aux_dt, ldaux, resid, res_dt, ldres, accumulate, colsum_out, workspace, ws_bytes, aux_mul, C2, stream);
+                                  aux, aux_dt, ldaux, resid, res_dt, ldres, accumulate, colsum_out, aux_mul, C2, stream);
     if (rc != SCOT_ERR_UNSUPPORTED) return rc;
   }
   {
-    // (the last SCOT_WS_RESERVED bytes of the workspace hold gemm_wide's arrival counters: nobody else's partial tiles may reach them)
-    const size_t ws_fast = ws_bytes > SCOT_WS_RESERVED ? ws_bytes - SCOT_WS_RESERVED : 0;
     const int rc = scot_gemm_fast(layout, compute, M, N, K, A, a_dt, lda, a_gelu, B, b_dt, ldb, b_gelu, C, c_dt, ldc, bias, colscale,
-                                  aux, aux_dt, ldaux, resid, res_dt, ldres, accumulate, colsum_out, workspace, ws_fast, aux_mul, C2, stream);
+                                  aux, aux_dt, ldaux, resid, res_dt, ldres, accumulate, colsum_out, workspace, ws_bytes, aux_mul, C2, stream);
     if (rc != SCOT_ERR_UNSUPPORTED) return rc;
   }
   GemmArgs a;

@@ -796,16 +796,14 @@ int scot_gemm_fast(int layout, int compute, int M, int N, int K, const void* A, 
 
 // include/scot_hip.h: scot_gemm_workspace_bytes — dense operands (leading dimensions = row lengths) in the compute mode's
 // operand type, fp32 result for TN (accumulate) / 16-bit otherwise; 0 = the call would not touch the workspace.
-size_t scot_gemm_wide_workspace_bytes(int layout, int compute, int M, int N, int K);     // gemm_wide.hip (slabs + the reserved counter tail)
 extern "C" size_t scot_gemm_workspace_bytes(int layout, int compute, int M, int N, int K) {
-  if (const size_t w = scot_gemm_wide_workspace_bytes(layout, compute, M, N, K)) return w;
   const int dt = compute == SCOT_BF16 ? SCOT_BF16 : SCOT_F32;
   const int lda = layout == LAYOUT_TN ? M : K, ldb = layout == LAYOUT_NT ? K : N;
   void* al = (void*)(uintptr_t)64;
   size_t q = 0;
   const int rc = gemm_fast_impl(layout, compute, M, N, K, al, dt, lda, 0, al, dt, ldb, 0, al, layout == LAYOUT_TN ? SCOT_F32 : dt, N, nullptr,
                                 nullptr, nullptr, 0, 0, nullptr, 0, 0, layout == LAYOUT_TN ? 1 : 0, nullptr, nullptr, 0, 0, nullptr, nullptr, &q);
-  return rc == SCOT_OK && q ? q + SCOT_WS_RESERVED : 0;
+  return rc == SCOT_OK ? q : 0;
 }
 
 // C_i[m][n] += Σ_z ws[z·plane + ws_off_i + m·N_i + n] for every problem of the group (one launch)
@@ -845,7 +843,6 @@ static int wgrad_group_impl(int compute, int n, int K, const void* const* dY, co
                             float* const* dbias, const int* Ms, const int* Ns, void* workspace, size_t ws_bytes,
                             hipStream_t stream, size_t* query) {
   if (query) { *query = 0; workspace = (void*)(uintptr_t)64; ws_bytes = (size_t)1 << 60; }
-  else ws_bytes = ws_bytes > SCOT_WS_RESERVED ? ws_bytes - SCOT_WS_RESERVED : 0;      // (common.h: the workspace's tail is gemm_wide's)
   if (n <= 0 || n > SCOT_WGRAD_GROUP_MAX || K <= 0) return SCOT_ERR_SHAPE;
   if (compute != SCOT_BF16) return SCOT_ERR_UNSUPPORTED;     // fp32 / split modes use scot_gemm per problem
   if (K % 8) return SCOT_ERR_UNSUPPORTED;
@@ -931,5 +928,5 @@ extern "C" int scot_wgrad_group(int compute, int n, int K, const void* const* dY
 extern "C" size_t scot_wgrad_group_workspace_bytes(int n, int K, const int* Ms, const int* Ns) {
   size_t q = 0;
   const int rc = wgrad_group_impl(SCOT_BF16, n, K, nullptr, nullptr, nullptr, nullptr, Ms, Ns, nullptr, 0, nullptr, &q);
-  return rc == SCOT_OK && q ? q + SCOT_WS_RESERVED : 0;
+  return rc == SCOT_OK ? q : 0;
 }

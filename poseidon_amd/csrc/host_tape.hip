@@ -62,6 +62,11 @@ static inline double bits_to_xmm(W u) {
 // prog: n_entries records {fn, n_int, n_flt, int words..., float words (raw IEEE-754 single bits in the low half)...}.  Returns 0, or the
 // first non-zero status with *fail_entry = index of the entry that returned it (the rest of the program is not issued).
 extern "C" int scot_tape_replay(const uint64_t* prog, size_t n_words, int* fail_entry) {
+#if !defined(__x86_64__) || defined(_WIN32)
+  // the one-prototype call below IS the System V x86-64 register / stack convention; anywhere else the engine replays its Python list
+  (void)prog; (void)n_words; (void)fail_entry;
+  return SCOT_ERR_UNSUPPORTED;
+#else
   size_t i = 0;
   int entry = 0;
   while (i < n_words) {
@@ -86,4 +91,5 @@ extern "C" int scot_tape_replay(const uint64_t* prog, size_t n_words, int* fail_
     ++entry;
   }
   return SCOT_OK;
+#endif
 }

@@ -63,7 +63,7 @@ class ScOTEngine:
         self.tape_max = max(1, int(os.environ.get("SCOT_TAPE_MAX", "2")))
         # ... and replayed from C: one scot_tape_replay call per run of launches instead of one ctypes call per launch (SCOT_TAPE_C=0: the
         # Python loop over the recorded calls)
-        self.tape_c = os.environ.get("SCOT_TAPE_C", "1") == "1"
+        self.tape_c = os.environ.get("SCOT_TAPE_C", "1") == "1" and __import__("platform").machine() in ("x86_64", "AMD64")     # (scot_tape_replay is System V x86-64 only)
         self.tape_inference = os.environ.get("SCOT_TAPE_INFERENCE", "1") == "1"      # inference forwards are recorded / replayed too
         self._rec = None
         self._rec_keep = None
@@ -90,12 +90,7 @@ class ScOTEngine:
         # recorded step owns every buffer it allocated for good, so without the pool each layer's stores go to lines no cache has
         # seen — with it they land on lines the previous layer left in L2 / MALL.
         self.recycle = os.environ.get("SCOT_RECYCLE", "1") == "1"
-        # Saved-activation diet of the lean tail (round 5 experiment): the training forward of a C = 96 / 192 layer runs
-        # its tail in the INFERENCE form — it keeps only the layer's fp32 input rows and the attention output (+ what the attention backward
-        # needs) — and the backward first re-runs the tail's training form into ONE pooled buffer set (pre-norm rows, statistics, gelu'(u);
-        # hot in L2 / MALL when scot_block_tail_bwd reads them right behind).  h16 alone gets fresh rows: scot_wgrad_mlp reads it on the
-        # weight-gradient stream, layers later.  Trades 2·M·15C² flop per layer for ≈ 10·C bytes per token of cold stores + their re-reads.
-        self.recompute_tail = os.environ.get("SCOT_RECOMPUTE_TAIL", "0") == "1"
+        self.last_hidden, self.last_hidden_aliased = None, False
         self._pool: Dict[tuple, torch.Tensor] = {}
         # ... gelu'(u) itself IS stored (16-bit, 8·C bytes per token) and the backward tail loads it: recomputing it there (the C ABI's
         # `dact = NULL` form of scot_block_tail_bwd) is one more C x 4C product per row tile at the 256-register cap — 140-168 B/lane of
@@ -159,20 +154,6 @@ class ScOTEngine:
         self.shadow_t, self._wt_names, self._wt_desc, self._wt_tiles = None, {}, None, 0
         if self.shadow is not None and os.environ.get("SCOT_DGRAD_WT", "1") == "1":
             self._plan_transposed_weights()
-        # The deep stages' layer tail (C = 384; 768 with a split hidden dimension) as ONE launch on FRAGMENT-ORDERED weight copies
-        # (csrc/tail_deep.hip): `shadow_f` holds Wo, W1 (rows permuted), W2, Wqkv of those layers in the order the MFMA operand loads read
-        # them (same offsets as the master).  {C: hidden split}.  SCOT_DEEP_TAIL = "0" (default): off; "eval": inference forwards only;
-        # "all": training forwards too.  Measured in round 4 (profiles/round4/deep_tail_fwd_r4.txt): alone the kernel beats the six launches
-        # it replaces (62 vs 90 us at C = 384), inside a training step it loses (its ~60 MB of saved activations go to cold lines; one
-        # 400-register workgroup per CU starves the skip blocks on the side stream: forward 6.86 -> 7.11 ms), and what it bought for
-        # inference (7.57 -> 6.41 ms per Poseidon-B batch-64 forward) was host time that the inference tape now removes (6.33 ms without it).
-        self.deep_hsplit, self.deep_fused_qkv = {}, False
-        self.shadow_f, self._wf_desc, self._wf_blocks, self._wf_names = None, None, 0, set()
-        self.deep_tail_mode = os.environ.get("SCOT_DEEP_TAIL", "0")
-        if self.shadow is not None and self.deep_tail_mode in ("eval", "all", "1"):
-            self.deep_hsplit = {int(c): int(h) for c, h in (kv.split(":") for kv in os.environ.get("SCOT_DEEP_HSPLIT", "384:1").split(",") if kv)}
-            self._plan_fragment_weights()
-            self.deep_fused_qkv = self.deep_hsplit.get(384) == 1
         # fp16 operands have 5 exponent bits: the backward runs on gradients multiplied by a power of two chosen from the loss
         # normalisation (d loss / d prediction = O(1 / number of output elements); see _grad_scale) and the gradient arena is
         # divided by it afterwards (exact; scot_scale_inplace also counts non-finite values → `grad_overflow`).
@@ -344,45 +325,6 @@ class ScOTEngine:
         self._wt_tiles = tile
         self._wtviews = {}
 
-    def _plan_fragment_weights(self):
-        """desc of scot_fragpack for the forward operands of every ScOTLayer whose width has a deep-tail kernel"""
-        ar = self.arena
-        blocks = [b for st in self.enc for b in st.blocks] + [b for st in self.dec for b in st.blocks]
-        desc, blk = [], 0
-        for b in blocks:
-            C = b.dim
-            if C not in self.deep_hsplit or int(self.cfg.mlp_ratio * C) != 4 * C:
-                continue
-            pre, a = b.prefix, b.prefix + ".attention.self."
-            for name, N, K, mode in ((pre + ".attention.output.dense.weight", C, C, 0), (pre + ".intermediate.dense.weight", 4 * C, C, 2),
-                                     (pre + ".output.dense.weight", C, 4 * C, 0), (a + "qkv_weight", 3 * C, C, 0)):
-                off = ar.offsets[name]
-                desc.append((off, N, K, blk, mode, off))
-                blk += (N * K // 8 + 255) // 256
-                self._wf_names.add(name)
-        if not desc:
-            return
-        self.shadow_f = torch.zeros(ar.size, dtype=self.adt, device=self.device)
-        self._wf_desc = torch.tensor(desc, dtype=torch.int32, device=self.device)
-        self._wf_blocks = blk
-        self._wfviews = {}
-
-    def pack_fragments(self):
-        """fp32 master -> the fragment-ordered operand copies of the deep stages' forward weights (one launch)"""
-        if self.shadow_f is not None:
-            ops.fragpack(self.arena.data, self.shadow_f, self._wf_desc, self._wf_desc.shape[0], self._wf_blocks)
-
-    def WF(self, name, numel=None):
-        """fragment-ordered copy of weight `name` (flat), or None"""
-        if self.shadow_f is None or name not in self._wf_names:
-            return None
-        v = self._wfviews.get(name)
-        if v is None:
-            o = self.arena.offsets[name]
-            v = self.shadow_f[o:o + (numel if numel is not None else self.arena.numel(name))]
-            self._wfviews[name] = v
-        return v
-
     def transpose_weights(self):
         ops.transpose_cast(self.arena.data, self.shadow_t, self._wt_desc, len(self._wt_names), self._wt_tiles)
 
@@ -432,7 +374,7 @@ class ScOTEngine:
         """a buffer nobody reads after the consumer the caller is about to launch (see `recycle`): one allocation per (tag, shape, dtype)"""
         if not self.recycle or self._in_side is not None:
             return self.new(*shape, dtype=dtype)
-        key = (tag, shape, dtype)
+        key = (tag, shape, dtype, self._stream_id())      # (forwards issued from two streams must not share rows)
         t = self._pool.get(key)
         if t is None:
             t = self._pool[key] = torch.empty(*shape, dtype=dtype, device=self.device)
@@ -802,10 +744,7 @@ class ScOTEngine:
         tmp = self.pool if not train else (lambda tag, *s_, dtype=torch.float32: self.new(*s_, dtype=dtype))
         alias32 = train and self.adt == torch.float32      # fp32 operands: h16 IS h and out16 IS out, and training keeps the 16-bit rows
         dead = self.pool if not alias32 else tmp           # dead in training too
-        hid_ = int(cfg.mlp_ratio * C)
-        rcp = bool(train and self.recompute_tail and self.lean_tail and not padded and self.use_fused("proj_fwd", C) and self.use_fused("mlp_fwd", C)
-                   and hid_ % 128 == 0 and self.fused_tail and self._lean_ok(pre, B * L, L, C, hid_))
-        fresh_out = next_blk is None or alias32 or rcp      # (recompute: the NEXT layer's backward re-reads these rows as its input)
+        fresh_out = next_blk is None or alias32
         nxt = (lambda tag, *s_, dtype=torch.float32: self.pool((tag, par), *s_, dtype=dtype)) if not fresh_out else \
             (lambda tag, *s_, dtype=torch.float32: self.new(*s_, dtype=dtype))
         nxt16 = nxt if not train else (lambda tag, *s_, dtype=torch.float32: self.new(*s_, dtype=dtype))    # (training keeps out16: the next layer's xp)
@@ -851,52 +790,17 @@ class ScOTEngine:
         done_tail = False
         lean_used = False
         qkv_next = None
-        hs = self.deep_hsplit.get(C, 0) if (not train or self.deep_tail_mode in ("all", "1")) else 0
-        if (hs and not padded and (B * L) % 16 == 0 and L % 16 == 0 and hid == 4 * C and hid % (128 * hs) == 0 and not self.precision_probe
-                and self.WF(pre + ".output.dense.weight") is not None):
-            # deep stages: everything after the attention core in one launch on the fragment-ordered weight copies (csrc/tail_deep.hip)
-            proj = self.new(B * L, C) if train else None
-            st1 = (self.new(B * L), self.new(B * L)) if train else (None, None)
-            h16 = self.new(B * L, C, dtype=self.adt) if train else None
-            h = self.new(B * L, C) if hs > 1 else None
-            u = self.new(B * L, hid, dtype=self.adt) if train else None
-            gp = self.new(B * L, hid, dtype=self.adt) if train else None
-            y2 = self.new(B * L, C) if train else None
-            st2 = (self.new(B * L), self.new(B * L)) if train else (None, None)
-            out, out16 = self.new(B * L, C), self.new(B * L, C, dtype=self.adt)
-            n1, n2 = self._norm_params(pre + ".layernorm_before"), self._norm_params(pre + ".layernorm_after")
-            nq = (None, None, None)
-            if (hs == 1 and self.deep_fused_qkv and next_blk is not None and next_blk.dim == C and next_blk.res[0] % next_blk.window_shift()[0] == 0
-                    and next_blk.res[1] % next_blk.window_shift()[0] == 0):
-                na = next_blk.prefix + ".attention.self."
-                qkv_next = self.new(B * L, 3 * C, dtype=self.adt)
-                nq = (self.WF(na + "qkv_weight", 3 * C * C), self.arena.span(na + "qkv_bias", 3 * C) if cfg.qkv_bias else None, qkv_next)
-            ypart = self.new(hs, B * L, C) if hs > 1 else None
-            tcond = time if self.cond else None
-            b2 = self.P(pre + ".output.dense.bias")
-            if not ops.deep_tail_fwd(
-                    (attn_c, self.WF(pre + ".attention.output.dense.weight"), self.P(pre + ".attention.output.dense.bias"), x, h, h16, proj,
-                     st1[0], st1[1], n1[0], n1[1], n1[2], n1[3], dp1),
-                    (self.WF(pre + ".intermediate.dense.weight"), self.P(pre + ".intermediate.dense.bias"), self.WF(pre + ".output.dense.weight"),
-                     b2, out, out16, u, gp, y2, st2[0], st2[1], n2[0], n2[1], n2[2], n2[3], dp2),
-                    tcond, B * L, L, C, hid, cfg.layer_norm_eps, *nq, hsplit=hs, ypart=ypart):
-                raise RuntimeError("scot_deep_tail_fwd rejected a shape the engine selected it for")
-            if hs > 1:
-                ops.deep_tail_finish(ypart, hs, b2, h, out, out16, y2, st2[0], st2[1], n2[0], n2[1], n2[2], n2[3], dp2, tcond, B * L, L, C,
-                                     cfg.layer_norm_eps)
-            done_tail = True
-        elif proj_f and mlp_f and self.fused_tail:
+        if proj_f and mlp_f and self.fused_tail:
             # projection + norm + residual, then MLP + norm + residual, for the same rows in one launch
             lean = train and self.lean_tail and self._lean_ok(pre, B * L, L, C, hid)
-            keep = train and not rcp                         # rcp: nothing of the tail is kept, the backward re-runs it (layer_bwd)
-            zdt = self.adt if (lean and keep) else torch.float32        # pre-norm rows: only the norm backward's x-hat reads them
-            proj = self.new(B * L, C, dtype=zdt) if keep else None
-            st1 = (self.new(B * L), self.new(B * L)) if keep else (None, None)
-            h, h16 = dead("h", B * L, C), (tmp if keep or not train else self.pool)("h16", B * L, C, dtype=self.adt)
-            u = self.new(B * L, hid, dtype=self.adt) if (keep and not lean) else None
-            gp = self.new(B * L, hid, dtype=self.adt) if keep else None
-            y2 = self.new(B * L, C, dtype=zdt) if keep else None
-            st2 = (self.new(B * L), self.new(B * L)) if keep else (None, None)
+            zdt = self.adt if lean else torch.float32        # pre-norm rows: only the norm backward's x-hat reads them
+            proj = self.new(B * L, C, dtype=zdt) if train else None
+            st1 = (self.new(B * L), self.new(B * L)) if train else (None, None)
+            h, h16 = dead("h", B * L, C), tmp("h16", B * L, C, dtype=self.adt)
+            u = self.new(B * L, hid, dtype=self.adt) if (train and not lean) else None
+            gp = self.new(B * L, hid, dtype=self.adt) if train else None
+            y2 = self.new(B * L, C, dtype=zdt) if train else None
+            st2 = (self.new(B * L), self.new(B * L)) if train else (None, None)
             out, out16 = nxt("out", B * L, C), nxt16("out16", B * L, C, dtype=self.adt)
             n1, n2 = self._norm_params(pre + ".layernorm_before"), self._norm_params(pre + ".layernorm_after")
             nq = (None, None, None)
@@ -910,10 +814,8 @@ class ScOTEngine:
                  st1[0], st1[1], n1[0], n1[1], n1[2], n1[3], dp1),
                 (self.W(pre + ".intermediate.dense.weight"), self.P(pre + ".intermediate.dense.bias"), self.W(pre + ".output.dense.weight"),
                  self.P(pre + ".output.dense.bias"), out, out16, u, gp, y2, st2[0], st2[1], n2[0], n2[1], n2[2], n2[3], dp2),
-                time if self.cond else None, B * L, L, C, hid, cfg.layer_norm_eps, *nq, z16=bool(lean and keep))
+                time if self.cond else None, B * L, L, C, hid, cfg.layer_norm_eps, *nq, z16=lean)
             lean_used = lean
-            if rcp and not done_tail:
-                raise RuntimeError("scot_block_tail_fwd rejected the inference form of a shape the engine selected it for")
             if not done_tail:
                 if lean:
                     raise RuntimeError("scot_block_tail_fwd rejected a shape the engine selected it for")
@@ -962,8 +864,7 @@ class ScOTEngine:
         rec = None
         if train:
             rec = dict(blk=blk, xp=xp, qkv=qkv, attn_p=attn, table=table, lse=lse, attn_c=attn_c, proj=proj, st1=st1, h16=h16, u=u, gp=gp,
-                       y2=y2, st2=st2, geom=(H, W, Hp, Wp, ws, shift, padded), dp=(dp1, dp2), lean=bool(done_tail and lean_used),
-                       recompute=bool(done_tail and rcp), x=x if rcp else None)
+                       y2=y2, st2=st2, geom=(H, W, Hp, Wp, ws, shift, padded), dp=(dp1, dp2), lean=bool(done_tail and lean_used))
         return out, out16, rec, qkv_next
 
     def dgrad_into(self, cm, dy, w, g, wt=None):
@@ -1057,24 +958,6 @@ class ScOTEngine:
         d_attn = self.pool("d_attn", B * L, C, dtype=adt)      # read by this layer's attention backward (same stream) and by nothing else
         done_tail = False
         lean = bool(rec.get("lean"))
-        if rec.get("recompute"):
-            # the tail's training form, re-run from the layer's input rows and attention output into the pooled set (see `recompute_tail`)
-            zdt = adt
-            proj_r, y2_r = self.pool("rc_z1", B * L, C, dtype=zdt), self.pool("rc_z2", B * L, C, dtype=zdt)
-            st1_r, st2_r = (self.pool("rc_m1", B * L), self.pool("rc_r1", B * L)), (self.pool("rc_m2", B * L), self.pool("rc_r2", B * L))
-            h_r, h16_r = self.pool("h", B * L, C), self.new(B * L, C, dtype=adt)
-            gp_r = self.pool("rc_gp", B * L, hid, dtype=adt)
-            out_r, out16_r = self.pool("rc_out", B * L, C), self.pool("rc_out16", B * L, C, dtype=adt)
-            n1r, n2r = self._norm_params(pre + ".layernorm_before"), self._norm_params(pre + ".layernorm_after")
-            if not ops.block_tail_fwd(
-                    (rec["attn_c"], self.W(pre + ".attention.output.dense.weight"), self.P(pre + ".attention.output.dense.bias"), rec["x"], h_r,
-                     h16_r, proj_r, st1_r[0], st1_r[1], n1r[0], n1r[1], n1r[2], n1r[3], rec["dp"][0]),
-                    (self.W(pre + ".intermediate.dense.weight"), self.P(pre + ".intermediate.dense.bias"), self.W(pre + ".output.dense.weight"),
-                     self.P(pre + ".output.dense.bias"), out_r, out16_r, None, gp_r, y2_r, st2_r[0], st2_r[1], n2r[0], n2r[1], n2r[2], n2r[3],
-                     rec["dp"][1]),
-                    time if self.cond else None, B * L, L, C, hid, cfg.layer_norm_eps, None, None, None, z16=True):
-                raise RuntimeError("scot_block_tail_fwd rejected the recomputation of a layer it ran in the forward")
-            rec = dict(rec, proj=proj_r, st1=st1_r, h16=h16_r, gp=gp_r, y2=y2_r, st2=st2_r)
         if lean:
             # the tail without 4C-wide tensors: gelu'(u) recomputed from h16, du never stored, the norms' parameter gradients as
             # per-workgroup partial rows; on the weight-gradient stream: the partial rows' column sums, the fc1 / fc2 gradients with
@@ -1346,7 +1229,6 @@ class ScOTEngine:
         try:
             if need:
                 ops.cast(self.arena.data, self.shadow)
-                self.pack_fragments()
                 self._shadow_v = v
             if need_t:
                 self.transpose_weights()
@@ -1373,7 +1255,6 @@ class ScOTEngine:
                 prev_rec = ops.set_recorder(None)
                 try:
                     ops.cast(self.arena.data, self.shadow)
-                    self.pack_fragments()
                     if train and self.shadow_t is not None:
                         self.transpose_weights()
                 finally:
@@ -1416,8 +1297,11 @@ class ScOTEngine:
         if ent is None:
             # a recorded step pins all of its buffers (GBs): keep at most `tape_max` signatures (e.g. the full batch and the
             # epoch's short last batch); the least recently used one is dropped, its buffers go back to the allocator
-            while len(self._taped) >= self.tape_max:
-                self._taped.pop(next(iter(self._taped)))
+            # Inference signatures (small: no backward state) are counted on their own, so an eval pass between epochs never evicts the
+            # training tapes (several GB each, and possibly a recorded forward still waiting for its backward)
+            same = [k for k in self._taped if k[-1] == key[-1]]
+            while len(same) >= self.tape_max:
+                self._taped.pop(same.pop(0))
             self._taped[key] = dict(state="warm")
             return self._forward(pixel_values, time, labels, pixel_mask, train)
         self._taped[key] = self._taped.pop(key)   # most recently used last
@@ -1433,7 +1317,9 @@ class ScOTEngine:
                     dst.copy_(src)
             self._replay(ent["fwd"], ent.get("fwd_c"))
             loss, pred, tape = ent["out"]
-            self.last_hidden = ent["hidden"]      # (views of THIS recorded step's buffers: valid until its next replay)
+            # views of THIS recorded step's buffers, valid until its next replay: ScOT.forward hands the caller clones (the reference
+            # returns fresh tensors; a rollout that keeps `hidden_states` across calls must not see them change)
+            self.last_hidden, self.last_hidden_aliased = ent["hidden"], True
             if not train:          # nothing is kept for a backward: the recorded buffers are free again as soon as the outputs are copied
                 return (None if loss is None else loss.clone()), pred.clone(), None
             tok = _Token()
@@ -1446,11 +1332,15 @@ class ScOTEngine:
         prev = ops.set_recorder(self._rec)
         try:
             loss, pred, tape = self._forward(*ent["in"], train)
+        except BaseException:
+            self._taped.pop(key, None)        # a partial recording is never replayed (and never compiled: the original error surfaces)
+            raise
         finally:
             ops.set_recorder(prev)
-            ent["fwd"], ent["keep"] = self._rec, self._rec_keep
-            ent["fwd_c"] = ops.compile_tape(self._rec) if self.tape_c else None
+            rec, keep = self._rec, self._rec_keep
             self._rec = self._rec_keep = None
+        ent["fwd"], ent["keep"] = rec, keep
+        ent["fwd_c"] = ops.compile_tape(rec) if self.tape_c else None
         ent["hidden"] = self.last_hidden
         if not train:
             ent["out"] = (loss, pred, None)
@@ -1534,16 +1424,21 @@ class ScOTEngine:
         prev = ops.set_recorder(self._rec)
         try:
             self._backward(tape, ent["dloss"], None)
+        except BaseException:
+            ent["state"] = "broken"           # never replayed; the signature falls back to direct launches
+            raise
         finally:
             ops.set_recorder(prev)
-            ent["bwd"] = self._rec
-            ent["bwd_c"] = ops.compile_tape(self._rec) if self.tape_c else None
+            rec = self._rec
             self._rec = self._rec_keep = None
+        ent["bwd"] = rec
+        ent["bwd_c"] = ops.compile_tape(rec) if self.tape_c else None
         ent["state"] = "ready"
 
     def reset_tapes(self):
         """Forget recorded steps (call after changing anything a tape bakes in: hooks, environment knobs)."""
         self._taped.clear()
+        self._pool.clear()        # (recorded steps keep the rows they name alive themselves; inference with many shapes would pin one set each)
 
     def _forward(self, pixel_values, time=None, labels=None, pixel_mask=None, train=True, bool_masked_pos=None):
         cfg, cm = self.cfg, self.compute
@@ -1694,6 +1589,7 @@ class ScOTEngine:
                                 shape=(B, Cout, H, W))
             tape["hidden"] = (hidden_dec, hidden_enc)
         self.last_hidden = (hidden_dec, hidden_enc)
+        self.last_hidden_aliased = self._rec is not None      # rows of a step being recorded: its replays overwrite them
         return loss, pred, tape
 
     def _loss_setup(self, Cout, B, HW):

@@ -57,9 +57,6 @@ PROTOTYPES = {
     "scot_event_record": [P, P],
     "scot_stream_wait_event": [P, P],
     "scot_tape_replay": [P, Z, P],
-    "scot_fragpack": [P, P, P, I, I, P],
-    "scot_deep_tail_fwd": [P] * 33 + [I, P, I, I, I, I, F, I, P, P],
-    "scot_deep_tail_finish": [P, I, P, P, P, P, P, I, P, P, P, P, P, P, P, P, I, I, I, F, P],
     "scot_proj_cln_fwd": [P, P, P, P, P, P, P, P, P, P, P, P, P, P, P, I, I, I, F, P],
     "scot_proj_cln_bwd": [P, P, P, P, P, P, P, P, P, P, P, P, P, P, P, I, I, I, P],
     "scot_cln_bwd": [P, I, P, I, P, P, P, P, P, P, I, P, P, P, P, P, I, I, I, P, Z, P, I, P],
@@ -138,7 +135,7 @@ def load(path: str = None, kind: str = "bf16"):
     if lib.scot_operand_format() != OPERAND_FORMAT[kind]:
         raise ScotLibraryError(f"{path} was built for operand format {lib.scot_operand_format()}, expected {OPERAND_FORMAT[kind]} "
                                f"({kind}); rebuild with `python -m poseidon_amd.build --force`")
-    # tuning knob for A/B runs (tools/gpu_ab.sh): SCOT_GEMM_WIDE = "<mode>[,<forced K slices>]" -> scot_gemm_wide_config (include/scot_hip.h)
+    # tuning knob for A/B runs (tools/gpu_ab.sh): SCOT_GEMM_WIDE = "<mode>[,<kernel variant>]" -> scot_gemm_wide_config (include/scot_hip.h)
     w = os.environ.get("SCOT_GEMM_WIDE")
     if w:
         mode, _, split = w.partition(",")

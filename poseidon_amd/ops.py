@@ -102,7 +102,6 @@ def L():
 _workspace = {}
 _retired = []                   # outgrown scratch buffers: kept alive (launches already enqueued may still use them)
 WORKSPACE_MIN_BYTES = 8 << 20
-WS_RESERVED = 4096              # csrc/common.h SCOT_WS_RESERVED: the workspace's last bytes are scot_gemm's tile arrival counters (zero between launches)
 
 
 _slot = 0
@@ -122,14 +121,13 @@ def workspace(need: int = 0):
     the address it was recorded with: growth only happens on a shape's first (eager, unrecorded) call."""
     key = (torch.cuda.current_device(), _slot)
     w = _workspace.get(key)
-    if w is None or w.numel() < need + WS_RESERVED:
+    if w is None or w.numel() < need:
         size = WORKSPACE_MIN_BYTES
-        while size < need + WS_RESERVED:
+        while size < need:
             size *= 2
         if w is not None:
             _retired.append(w)
-        # zero-filled: the arrival counters in the tail must read 0 at their first launch (every launch leaves them 0 again)
-        w = torch.zeros(size, dtype=torch.uint8, device=f"cuda:{key[0]}")
+        w = torch.empty(size, dtype=torch.uint8, device=f"cuda:{key[0]}")
         _workspace[key] = w
     return w
 
@@ -415,34 +413,6 @@ def replay_tape(segs):
             rc = lib.scot_tape_replay(seg[1], seg[2], ctypes.byref(fail))
             if rc:
                 raise _lib.ScotLibraryError(f"step tape: entry {fail.value} of a replayed run returned {rc}")
-
-
-def fragpack(w, wf16, desc, n: int, blocks: int):
-    """wf16 (operand format) <- fragment-ordered copies of matrices of the fp32 arena w (csrc/tail_deep.hip); desc int32 [n, 6] on the
-    device = (source offset, N, K, first block, mode, destination offset) — scot_fragpack."""
-    _lib.check(L().scot_fragpack(ptr(w), ptr(wf16), ptr(desc), n, blocks, stream()), "scot_fragpack")
-
-
-def deep_tail_fwd(proj, mlp, time, rows, rows_per_sample, C, hid, eps, wqkv=None, bqkv=None, qkv=None, z16: bool = False, hsplit: int = 1,
-                  ypart=None) -> bool:
-    """block_tail_fwd's counterpart for C = 384 / 768 (csrc/tail_deep.hip): same tuples, but wo / w1 / w2 / wqkv are the FRAGMENT-ORDERED
-    weight copies (fragpack; w1 with the row permutation).  hsplit > 1: the hidden dimension is split over hsplit workgroups per 16 rows,
-    ypart [hsplit, rows, C] fp32 receives the partial fc2 sums and deep_tail_finish completes the layer (out / z2 / statistics / qkv of
-    `mlp` are then ignored here).  False = not covered."""
-    rc = L().scot_deep_tail_fwd(*[ptr(t) for t in proj], *[ptr(t) for t in mlp], ptr(wqkv), ptr(bqkv), ptr(qkv), BF16 if z16 else F32,
-                                ptr(time), rows, rows_per_sample, C, hid, float(eps), int(hsplit), ptr(ypart), stream())
-    if rc == -3:
-        return False
-    _lib.check(rc, "scot_deep_tail_fwd")
-    return True
-
-
-def deep_tail_finish(ypart, hsplit, b2, h, out, out16, z2, mean2, rstd2, gw_w2, gw_b2, bw_w2, bw_b2, sscale2, time, rows, rows_per_sample, C,
-                     eps, z16: bool = False):
-    """out = h + s2 · CLN2(Σ_q ypart[q] + b2): the second half of a hidden-split deep_tail_fwd."""
-    _lib.check(L().scot_deep_tail_finish(ptr(ypart), int(hsplit), ptr(b2), ptr(h), ptr(out), ptr(out16), ptr(z2), BF16 if z16 else F32,
-                                         ptr(mean2), ptr(rstd2), ptr(gw_w2), ptr(gw_b2), ptr(bw_w2), ptr(bw_b2), ptr(sscale2), ptr(time),
-                                         rows, rows_per_sample, C, float(eps), stream()), "scot_deep_tail_finish")
 
 
 def tail_workgroups(rows, rows_per_sample, C) -> int:

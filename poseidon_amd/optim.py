@@ -117,7 +117,6 @@ class FusedAdamW(torch.optim.Optimizer):
                                            int(self.growth_interval) if fp16 else 0, float(self.max_scale), st), "scot_optim_finish")
             self.model.mark_weights_dirty()
             if shadow is not None:
-                eng.pack_fragments()                # the deep stages' fragment-ordered operand copies
                 if eng.shadow_t is not None:
                     eng.transpose_weights()         # the data gradients' W^T operands, from the new master weights
                 eng.weight_copies_are_current(self.model._weights_version())

@@ -490,6 +490,8 @@ class ScOT(nn.Module):
         want_hs = bool(output_hidden_states or (output_hidden_states is None and cfg.output_hidden_states))
         if want_hs or not return_dict:
             hd, he = self._engine.last_hidden
+            if self._engine.last_hidden_aliased:      # rows of a recorded step (overwritten by its next replay): the caller gets its own
+                hd, he = [h.clone() for h in hd], [h.clone() for h in he]
             hs, rhs, enc_hs, enc_rhs, dec_hs, dec_rhs = self._hidden_tuples(hd, he, B)
         enc_at = dec_at = None
         if want_attn:

@@ -17,7 +17,7 @@ def pytest_configure(config):
     import emu_session
     from poseidon_amd import ops
     lib = emu_session.load_emu()
-    ws = torch.zeros(96 << 20, dtype=torch.uint8)
+    ws = torch.empty(96 << 20, dtype=torch.uint8)
     ops.L = lambda: lib
     ops.ptr = lambda t: None if t is None else t.data_ptr()
     ops.stream = lambda: None

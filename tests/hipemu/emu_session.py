@@ -33,7 +33,7 @@ def load_emu(kind="bf16"):
 def patch_ops(monkeypatch, lib, workspace_bytes=32 << 20):
     """CPU tensors go down the same wrappers for the duration of one test (the product's `ops.ptr` refuses them).
     `lib` is the bf16 build; the fp16 build is loaded on demand when an engine selects it (`ops.use("f16")`)."""
-    ws = torch.zeros(workspace_bytes, dtype=torch.uint8)      # (zero: the arrival counters in its tail, csrc/common.h)
+    ws = torch.empty(workspace_bytes, dtype=torch.uint8)
 
     def L():
         l = lib if ops._active == "bf16" else load_emu(ops._active)

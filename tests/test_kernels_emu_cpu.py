@@ -68,63 +68,40 @@ def test_linear_fwd_dgrad_wgrad(emu, compute, M, N, K):
     assert rel(db, dy.double().sum(0)) < 1e-4
 
 
-def _wide_reference(x, w, b):
-    return x.double() @ w.double().t() + (b.double() if b is not None else 0.0)
-
-
-@pytest.mark.parametrize("variant", [0, 1, 2, 3, 4, 5])
-@pytest.mark.parametrize("M,N,K,split", [(128, 128, 128, 0), (256, 128, 256, 2), (128, 256, 448, 3), (256, 256, 384, 6)])
-def test_gemm_wide_tiles_and_in_launch_split_k(emu, M, N, K, split, variant):
-    """csrc/gemm_wide.hip (mode 2 = every eligible call): 128 x 128 tiles, K slices that meet inside the launch.  Every epilogue form the
-    engine uses on the deep stages' NT products, against fp64; the arrival counters in the workspace tail are zero afterwards."""
+@pytest.mark.parametrize("variant", [0, 1, 2])
+@pytest.mark.parametrize("M,N,K", [(128, 128, 64), (256, 128, 256), (128, 256, 448), (256, 384, 128)])
+def test_gemm_wide_tiles(emu, M, N, K, variant):
+    """csrc/gemm_wide.hip (mode 2 = every eligible call, kernel variant 0 / 1 / 2: 8 waves x 4 LDS stages, 8 x 2, 4 x 2): every epilogue
+    form the engine uses on NT products, against fp64 on the rounded operands, and against gemm_fast's 64 x 64 tiles."""
     lib = emu
-    lib.scot_gemm_wide_config(2 | ((variant + 1) << 8), split)       # (bits 8..: 1 + kernel variant — 4 / 8 / 16 waves, 3 / 4 LDS stages)
+    x, w, b = rnd(M, K, dtype=torch.bfloat16), rnd(N, K, dtype=torch.bfloat16, scale=K ** -0.5, seed=1), rnd(N, seed=2)
+    u = x.double() @ w.double().t() + b.double()
+    lib.scot_gemm_wide_config(0, 0)
+    y_fast = torch.empty(M, N)
+    ops.linear_fwd(ops.BF16, x, w, y_fast, bias=b)
+    lib.scot_gemm_wide_config(2, variant)
     try:
-        ws = ops.workspace()
-        x, w, b = rnd(M, K, dtype=torch.bfloat16), rnd(N, K, dtype=torch.bfloat16, scale=K ** -0.5, seed=1), rnd(N, seed=2)
-        u = _wide_reference(x, w, b)
         # forward with bias, 16-bit and fp32 results
-        y16, y32 = torch.empty(M, N, dtype=torch.bfloat16), torch.empty(M, N)
+        y16, y32 = torch.empty(M, N, dtype=torch.bfloat16), torch.full((M, N), float("nan"))
         ops.linear_fwd(ops.BF16, x, w, y16, bias=b)
         ops.linear_fwd(ops.BF16, x, w, y32, bias=b)
-        assert rel(y32, u) < 2e-5 * max(1.0, K ** 0.5 / 8) and rel(y16, u) < 6e-3
+        assert rel(y32, u) < 2e-6 and rel(y16, u) < 6e-3 and rel(y32, y_fast) < 1e-6
         # the fc1 form: gelu(u) and gelu'(u) from one pass
         gv, gd = torch.empty(M, N, dtype=torch.bfloat16), torch.empty(M, N, dtype=torch.bfloat16)
         ops.linear_fwd(ops.BF16, x, w, gv, bias=b, gelu_deriv_out=gd)
         assert rel(gv, torch.nn.functional.gelu(u)) < 6e-3
         assert rel(gd, 0.5 * (1 + torch.erf(u / math.sqrt(2))) + u * torch.exp(-0.5 * u * u) / math.sqrt(2 * math.pi)) < 6e-3
         # data gradients (NT on the transposed weight copy): * aux, and accumulated into an fp32 tensor
-        dy, wt = rnd(M, N, dtype=torch.bfloat16, seed=3), w.t().contiguous()          # dx[M, K] = dy[M, N] @ w[N, K]
-        aux = rnd(M, K, dtype=torch.bfloat16, seed=4)
         if K % 128 == 0:
+            dy, wt = rnd(M, N, dtype=torch.bfloat16, seed=3), w.t().contiguous()          # dx[M, K] = dy[M, N] @ w[N, K]
+            aux = rnd(M, K, dtype=torch.bfloat16, seed=4)
             dx = torch.empty(M, K, dtype=torch.bfloat16)
             ops.linear_dgrad(ops.BF16, dy, w, dx, aux=aux, aux_mul=True, wt=wt)
             assert rel(dx, (dy.double() @ w.double()) * aux.double()) < 6e-3
             g0 = rnd(M, K, seed=5)
             g = g0.clone()
             ops.linear_dgrad(ops.BF16, dy, w, g, accumulate=True, wt=wt)
-            assert rel(g, g0.double() + dy.double() @ w.double()) < 1e-4
-        assert int(ws[-4096:].view(torch.int32).abs().sum()) == 0
-        # the same product unsplit: the split result must agree to fp32 summation order (no dropped / doubled slice)
-        if split:
-            lib.scot_gemm_wide_config(2, 1)
-            y1 = torch.empty(M, N)
-            ops.linear_fwd(ops.BF16, x, w, y1, bias=b)
-            assert rel(y32, y1) < 1e-6
-    finally:
-        lib.scot_gemm_wide_config(1 | (2 << 8), 0)
-
-
-def test_gemm_wide_policy_is_what_the_workspace_query_says(emu):
-    """the launch and scot_gemm_workspace_bytes take the same decision from (M, N, K): a split product asks for its slabs + the counter tail"""
-    lib = emu
-    q = lambda M, N, K: int(lib.scot_gemm_workspace_bytes(ops.NT, ops.BF16, M, N, K))
-    assert q(1024, 768, 3072) >= 48 * 2 * 128 * 128 * 4 + 4096          # stage 3 fc2: 48 tiles, split
-    assert q(1024, 3072, 768) == 0                                       # 192 tiles: unsplit
-    assert q(65536, 96, 96) == 0 and q(1000, 768, 768) == 0              # not the wide kernel's shapes
-    lib.scot_gemm_wide_config(0, 0)
-    try:
-        assert q(1024, 768, 3072) == 0
+            assert rel(g, g0.double() + dy.double() @ w.double()) < 1e-6
     finally:
         lib.scot_gemm_wide_config(1, 0)
 
@@ -279,12 +256,6 @@ def test_fused_mlp_and_projection_backward(gpu_test_bodies, cond, B, L, C):
     gpu_test_bodies.test_proj_cln_bwd_fused(cond, B, L, C)
     gpu_test_bodies.test_block_tail_bwd_fused(cond, B, L, C, False)
     gpu_test_bodies.test_block_tail_bwd_fused(cond, B, L, C, True)
-
-
-@pytest.mark.parametrize("train,cond,next_qkv", [(True, True, True), (False, False, False)])
-@pytest.mark.parametrize("B,L,C,hsplit", [(2, 16, 384, 1), (1, 16, 768, 4), (1, 16, 768, 1), (1, 32, 384, 2)])
-def test_deep_tail_forward(gpu_test_bodies, train, cond, next_qkv, B, L, C, hsplit):
-    gpu_test_bodies.test_deep_tail_fwd(train, cond, next_qkv, B, L, C, hsplit)
 
 
 @pytest.mark.parametrize("cond,B,L,C,prologue", [(True, 1, 64, 96, True), (False, 1, 64, 192, False), (True, 3, 64, 96, False), (True, 2, 64, 192, True)])

@@ -67,17 +67,17 @@ def test_gemm_layouts(compute, layout, mixed, M, N, K):
         assert rel(C2, ref + bias.double() + res.double()) < tol
 
 
-WIDE_CASES = [(1024, 768, 3072, 0), (1024, 3072, 768, 0), (4096, 384, 1536, 0), (1024, 768, 2304, 4), (4096, 1536, 384, 1), (1024, 768, 768, 3),
-              (2048, 1536, 1536, 0), (256, 128, 64, 1), (128, 128, 1024, 8)]
+# (M, N, K, variant): -1 = the library's own policy for the shape (Poseidon-B's deep stages, Poseidon-L, Poseidon-B at 256 x 256), else forced
+WIDE_CASES = [(1024, 3072, 768, -1), (4096, 1536, 384, -1), (1024, 768, 3072, -1), (2048, 6144, 1536, -1), (8192, 768, 3072, -1), (32768, 384, 1536, -1),
+              (2048, 1536, 1536, 0), (1024, 768, 768, 1), (256, 128, 64, 2), (128, 128, 1024, 0), (4096, 384, 384, 2)]
 
 
 @pytest.mark.parametrize("kind", ["f16", "bf16"])
-@pytest.mark.parametrize("M,N,K,split", WIDE_CASES)
-def test_gemm_wide_in_launch_split_k(kind, M, N, K, split):
-    """csrc/gemm_wide.hip: the deep stages' NT products on 128 x 128 tiles, K slices reduced by the last-arriving workgroup.  split = 0:
-    the library's own policy for the shape, otherwise forced.  Every epilogue form of the engine's calls against fp64 on the rounded
-    operands; 20 repeated launches are BIT-identical (the slabs are added in slice order whoever arrives last: a stale or missing slab
-    would show here); the arrival counters in the workspace tail are zero afterwards; agrees with gemm_fast's 64 x 64 tiles."""
+@pytest.mark.parametrize("M,N,K,variant", WIDE_CASES)
+def test_gemm_wide_tiles(kind, M, N, K, variant):
+    """csrc/gemm_wide.hip: NT products on 128 x 128 tiles (three instantiations: 8 waves x 4 LDS stages, 8 x 2, 4 x 2).  Every epilogue form
+    of the engine's calls against fp64 on the rounded operands, and against gemm_fast's 64 x 64 tiles (same products, another summation
+    order); repeated launches are bit-identical."""
     prev = ops.use(kind)
     lib = ops.L()
     try:
@@ -88,12 +88,12 @@ def test_gemm_wide_in_launch_split_k(kind, M, N, K, split):
         lib.scot_gemm_wide_config(0, 0)
         y_fast = torch.empty(M, N, device=DEV)
         ops.linear_fwd(ops.BF16, x, w, y_fast, bias=b)
-        lib.scot_gemm_wide_config(2 if split else 1, split)
+        lib.scot_gemm_wide_config(1 if variant < 0 else 2, max(variant, 0))
         y32, y16 = torch.full((M, N), float("nan"), device=DEV), torch.empty(M, N, device=DEV, dtype=hd)
         ops.linear_fwd(ops.BF16, x, w, y32, bias=b)
         ops.linear_fwd(ops.BF16, x, w, y16, bias=b)
         assert rel(y32, u) < 1e-5 and rel(y16, u) < tol16 and rel(y32, y_fast) < 2e-6
-        for _ in range(20):
+        for _ in range(5):
             y = torch.full((M, N), float("nan"), device=DEV)
             ops.linear_fwd(ops.BF16, x, w, y, bias=b)
             assert torch.equal(y, y32)
@@ -111,7 +111,6 @@ def test_gemm_wide_in_launch_split_k(kind, M, N, K, split):
             ops.linear_dgrad(ops.BF16, dy, w, g, accumulate=True, wt=wt)
             assert rel(g, g0.double() + dy.double() @ w.double()) < 1e-5
         torch.cuda.synchronize()
-        assert int(ops.workspace()[-4096:].view(torch.int32).abs().sum()) == 0
     finally:
         lib.scot_gemm_wide_config(1, 0)
         ops.use(prev)
@@ -837,83 +836,6 @@ def test_block_tail_fwd_fused(train, cond, B, L, C, next_qkv):
         ref = r["out16"].float() @ wq.float().t() + bq
         assert rel(q.float(), ref) < 4e-3 and rel(q.float(), qr.float()) < 2e-3, (rel(q.float(), ref), rel(q.float(), qr.float()))
         assert (q != qr).float().mean() < 0.02      # same products, fp32 sums in a different order: rare last-place flips only
-
-
-def fragpack_host(w32, mode=0):
-    """fragment-ordered 16-bit copy of ONE fp32 matrix [N, K] (mode 1: w32 holds the transpose [K, N]; 2: permuted rows) via scot_fragpack"""
-    if mode & 1:
-        K, N = w32.shape
-    else:
-        N, K = w32.shape
-    desc = torch.tensor([[0, N, K, 0, mode, 0]], dtype=torch.int32, device=DEV)
-    out = torch.full((N * K,), float("nan"), device=DEV, dtype=ops.half_dtype())
-    ops.fragpack(w32.contiguous().view(-1), out, desc, 1, (N * K // 8 + 255) // 256)
-    return out
-
-
-def close16(a, b, what, tol=3e-3, flips=0.03):
-    """16-bit tensors computed from the same products with fp32 sums in a different order: equal up to rare last-place flips"""
-    assert torch.isfinite(a.float()).all(), what
-    assert rel(a.float(), b.float()) < tol, (what, rel(a.float(), b.float()))
-    assert (a != b).float().mean() < flips, (what, float((a != b).float().mean()))
-
-
-DEEP_CASES = [(2, 16, 384, 1), (3, 64, 384, 1), (2, 16, 768, 4), (1, 16, 768, 1), (1, 32, 384, 2)]
-
-
-@pytest.mark.parametrize("train,cond,next_qkv", [(True, True, True), (False, False, False), (True, False, False)])
-@pytest.mark.parametrize("B,L,C,hsplit", DEEP_CASES + [(64, 64, 384, 1), (64, 16, 768, 4)])
-def test_deep_tail_fwd(train, cond, next_qkv, B, L, C, hsplit):
-    """scot_deep_tail_fwd (+ scot_deep_tail_finish when the hidden dimension is split) == the seven launches it replaces at the deep
-    stages: projection GEMM, cond-LN + residual, fc1 with the GELU epilogue, fc2, cond-LN + residual, the next layer's qkv GEMM — same
-    operands, same rounding points, fp32 sums in a different order."""
-    M, hid = B * L, 4 * C
-    bf = ops.half_dtype()
-    a = rnd(M, C, seed=11).to(bf)
-    x = rnd(M, C, seed=12)
-    wo32, bo = rnd(C, C, scale=C ** -0.5, seed=13), rnd(C, seed=14, scale=0.2)
-    w132, b1 = rnd(hid, C, scale=C ** -0.5, seed=2), rnd(hid, seed=3, scale=0.2)
-    w232, b2 = rnd(C, hid, scale=hid ** -0.5, seed=4), rnd(C, seed=5, scale=0.2)
-    wq32, bq = rnd(3 * C, C, scale=C ** -0.5, seed=41), rnd(3 * C, seed=42, scale=0.2)
-    t = torch.rand(B, device=DEV) if cond else None
-    s1 = (torch.rand(B, device=DEV) > 0.3).float() / 0.7
-    s2 = (torch.rand(B, device=DEV) > 0.3).float() / 0.7
-    n1 = [rnd(C, seed=20, scale=0.3) if cond else None, 1 + rnd(C, seed=21, scale=0.1), rnd(C, seed=22, scale=0.1) if cond else None, rnd(C, seed=23, scale=0.1)]
-    n2 = [rnd(C, seed=6, scale=0.3) if cond else None, 1 + rnd(C, seed=7, scale=0.1), rnd(C, seed=8, scale=0.1) if cond else None, rnd(C, seed=9, scale=0.1)]
-    f = lambda *s, dtype=torch.float32: torch.full(s, float("nan"), device=DEV, dtype=dtype)
-    # ---- the launches it replaces
-    wo, w1, w2, wq = wo32.to(bf), w132.to(bf), w232.to(bf), wq32.to(bf)
-    r = dict(z1=f(M, C), h=f(M, C), h16=f(M, C, dtype=bf), m1=f(M), r1=f(M), u=f(M, hid, dtype=bf), gp=f(M, hid, dtype=bf), z2=f(M, C), out=f(M, C),
-             out16=f(M, C, dtype=bf), m2=f(M), r2=f(M), q=f(M, 3 * C, dtype=bf))
-    ops.linear_fwd(ops.BF16, a, wo, r["z1"], bias=bo)
-    ops.cln_fwd(r["z1"], x, r["h"], r["m1"], r["r1"], t, n1[0], n1[1], n1[2], n1[3], M, L, C, 1e-5, out2=r["h16"], sample_scale=s1)
-    ops.linear_fwd(ops.BF16, r["h16"], w1, r["u"], bias=b1, gelu_deriv_out=r["gp"])
-    ops.linear_fwd(ops.BF16, r["u"], w2, r["z2"], bias=b2)
-    ops.cln_fwd(r["z2"], r["h"], r["out"], r["m2"], r["r2"], t, n2[0], n2[1], n2[2], n2[3], M, L, C, 1e-5, out2=r["out16"], sample_scale=s2)
-    ops.linear_fwd(ops.BF16, r["out16"], wq, r["q"], bias=bq)
-    # ---- one launch (two with a split hidden dimension)
-    wof, w1f, w2f, wqf = fragpack_host(wo32), fragpack_host(w132, 2), fragpack_host(w232), fragpack_host(wq32)
-    fuse_q = next_qkv and hsplit == 1 and C == 384
-    d = dict(h=f(M, C) if hsplit > 1 else None, h16=f(M, C, dtype=bf) if train else None, out=f(M, C), out16=f(M, C, dtype=bf),
-             q=f(M, 3 * C, dtype=bf) if fuse_q else None)
-    d.update(dict(z1=f(M, C), m1=f(M), r1=f(M), u=f(M, hid, dtype=bf), gp=f(M, hid, dtype=bf), z2=f(M, C), m2=f(M), r2=f(M)) if train else
-             dict(z1=None, m1=None, r1=None, u=None, gp=None, z2=None, m2=None, r2=None))
-    yp = f(hsplit, M, C) if hsplit > 1 else None
-    assert ops.deep_tail_fwd((a, wof, bo, x, d["h"], d["h16"], d["z1"], d["m1"], d["r1"], n1[0], n1[1], n1[2], n1[3], s1),
-                             (w1f, b1, w2f, b2, d["out"], d["out16"], d["u"], d["gp"], d["z2"], d["m2"], d["r2"], n2[0], n2[1], n2[2], n2[3], s2),
-                             t, M, L, C, hid, 1e-5, *((wqf, bq, d["q"]) if fuse_q else ()), hsplit=hsplit, ypart=yp)
-    if hsplit > 1:
-        ops.deep_tail_finish(yp, hsplit, b2, d["h"], d["out"], d["out16"], d["z2"], d["m2"], d["r2"], n2[0], n2[1], n2[2], n2[3], s2, t, M, L, C, 1e-5)
-    torch.cuda.synchronize()
-    for k, v in d.items():
-        if v is None:
-            continue
-        if v.dtype == torch.float32:
-            assert torch.isfinite(v).all(), k
-            # z2 = fc2 sums of 16-bit gelu(u) whose last place may flip with the summation order of fc1
-            assert rel(v, r[k]) < (2e-5 if k in ("z1", "m1", "r1", "h") else 3e-4), (k, rel(v, r[k]))
-        else:
-            close16(v, r[k], k)
 
 
 @pytest.mark.parametrize("prologue", [False, True])

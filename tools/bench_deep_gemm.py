@@ -1,8 +1,8 @@
-"""The deep stages' NT products (C = 384 / 768 of Poseidon-B at batch 64, or --model L): gemm_fast's 64 x 64 tiles against gemm_wide's
-128 x 128 tiles with S K-slices reduced inside the launch.  Each configuration is captured as a hipGraph of R back-to-back launches and
+"""The Linear layers' NT products at the deep stages of Poseidon-B (batch 64), Poseidon-L (batch 128) or Poseidon-B at 256 x 256 (batch 32):
+gemm_fast's 64 x 64 tiles against gemm_wide's 128 x 128 tiles (three instantiations) and the library's policy.  Each configuration is captured as a hipGraph of R back-to-back launches and
 replayed, so the number is GPU time per launch incl. the dependent-launch gap (a Python -> ctypes loop cannot issue faster than ~8 us).
 
-    python tools/bench_deep_gemm.py [--model B|L] [--json out.json]
+    python tools/bench_deep_gemm.py [--model B|L|B256] [--json out.json]
 """
 import argparse
 import json
@@ -76,16 +76,10 @@ def main():
             res["fast64"] = graph_time(fn)
             lib.scot_gemm_wide_config(1, 0)
             res["policy"] = graph_time(fn)
-            nkt = K // 64
-            tiles = (M // 128) * (N // 128)
-            big = tiles > 512
-            for var, vname in (((1, "8w3s"), (4, "8w2s"), (5, "4w2s")) if big else ((0, "4w3s"), (1, "8w3s"), (2, "8w4s"), (3, "16w3s"), (4, "8w2s"))):
-                for S in ((1,) if big else (1, 2, 3, 4, 6)):
-                    if S > nkt or tiles * S > 1024 or (S > 1 and (tiles * S > 400 or nkt // S < 3)):
-                        continue
-                    lib.scot_gemm_wide_config(2 | ((var + 1) << 8), S)
-                    res[f"{vname} S={S}"] = graph_time(fn)
-            lib.scot_gemm_wide_config(1 | (2 << 8), 0)
+            for var, vname in ((0, "8w4s"), (1, "8w2s"), (2, "4w2s")):
+                lib.scot_gemm_wide_config(2, var)
+                res[vname] = graph_time(fn)
+            lib.scot_gemm_wide_config(1, 0)
             gf = 2.0 * M * N * K / 1e9
             best = min(res, key=res.get)
             rows.append(dict(M=M, N=N, K=K, name=name, tiles128=(M // 128) * (N // 128), us=res, best=best))

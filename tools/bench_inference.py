@@ -23,5 +23,4 @@ with torch.no_grad():
         out = m(pixel_values=pv, time=t)
     torch.cuda.synchronize()
     ms = (time.perf_counter() - t0) / 20 * 1e3
-print(f"inference Poseidon-B batch {B}: {ms:.2f} ms/forward = {B / ms * 1e3:.0f} samples/s (SCOT_DEEP_TAIL={os.environ.get('SCOT_DEEP_TAIL', '0')} "
-      f"SCOT_DEEP_HSPLIT={os.environ.get('SCOT_DEEP_HSPLIT', 'default')})")
+print(f"inference Poseidon-B batch {B}: {ms:.2f} ms/forward = {B / ms * 1e3:.0f} samples/s")
