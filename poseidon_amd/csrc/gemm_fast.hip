@@ -516,19 +516,7 @@ __global__ __launch_bounds__(256 * KG) void gemm_fast_kernel(FastArgs p) {
 // the chip and moved 19 MB of partial tiles.  Together the four problems of a block have 12 tiles: 40 K slices fill the chip,
 // the partials shrink 3x, 8 launches become 2 (this kernel + one grouped reduce), and the deep stages' problems (hundreds of
 // 64x64 tiles each, no split) share one launch instead of four tail effects.
-#define SCOT_WGRAD_GROUP_MAX 8
-struct WgradProblem {
-  const void* A; const void* B; float* C; float* colsum;   // A = dY [K, M] (lda), B = X [K, N] (ldb), C = dW [M, N] (ldc, +=)
-  int M, N, lda, ldb, ldc;
-  int tiles_n, tile0;          // tiles along N; index of this problem's first tile in the group
-  unsigned ws_off;             // offset (floats) of this problem's partial tiles inside one K-slice plane of the workspace
-};
-struct WgradGroupArgs {
-  WgradProblem p[SCOT_WGRAD_GROUP_MAX];
-  int n, K, ksplit, nsplit, tiles;
-  float* ws; size_t plane;     // ws[z][plane]: partial sums of K slice z (all problems back to back); plane in floats
-  int use_tr;
-};
+#include "wgrad_group.h"
 
 template <typename CT, int BM, int BN, int BKT, int NSET, int KG = 1>
 __global__ __launch_bounds__(256 * KG) void wgrad_group_kernel(WgradGroupArgs g) {
@@ -837,6 +825,8 @@ static int launch_wgrad_group(const WgradGroupArgs& g, hipStream_t s) {
   return scot_check_launch();
 }
 
+int scot_wgrad_group_wide_launch(const WgradGroupArgs& g, int variant, hipStream_t s);      // wgrad_wide.hip
+int scot_gemm_wide_mode(int* variant);                                                       // gemm_wide.hip
 // include/scot_hip.h: scot_wgrad_group.  dY_i: [K, M_i] (16-bit operands), X_i: [K, N_i], dW_i: [M_i, N_i] fp32 (+=),
 // dbias_i: [M_i] fp32 (+= column sums of dY_i) or NULL.  All leading dimensions = the row lengths (dense).
 static int wgrad_group_impl(int compute, int n, int K, const void* const* dY, const void* const* X, float* const* dW,
@@ -853,9 +843,34 @@ static int wgrad_group_impl(int compute, int n, int K, const void* const* dY, co
     if (!query && (((uintptr_t)dY[i] | (uintptr_t)X[i] | (uintptr_t)dW[i]) & 15) != 0) return SCOT_ERR_UNSUPPORTED;
     all96 = all96 && Ms[i] % 96 == 0 && Ns[i] % 96 == 0;
   }
+  // 128 x 128 tiles (wgrad_wide.hip) for groups of 128-multiples: eight waves, two LDS stages (two workgroups per CU) — unsplit from 256 tiles,
+  // below that with K cut so that ~860 workgroups exist (>= 8 K-tiles each).  profiles/round5/wgrad_wide_sweep_r5.txt, us per launch,
+  // 64 x 64 grouped kernel -> this: Poseidon-B stage 3 57.0 -> 42.8, stage 2 (108 tiles) 58.6 -> 54.4; Poseidon-L 299.8 -> 210.1,
+  // 393.5 -> 267.2, 433.7 -> 293.9 (four waves or four stages lose everywhere: 243.9 / 347.5 at L's stage 3)
+  int wide = -1, wide_split = 1;
+  {
+    int forced = 0;
+    const int mode = scot_gemm_wide_mode(&forced);
+    bool all128 = K % 64 == 0;
+    long t128 = 0;
+    for (int i = 0; i < n; ++i) { all128 = all128 && Ms[i] % 128 == 0 && Ns[i] % 128 == 0; t128 += (long)(Ms[i] / 128) * (Ns[i] / 128); }
+    const long nkt128 = K / 64;
+    if (mode != 0 && all128 && t128 > 0) {
+      if (t128 >= 256) wide = 1;
+      else if (t128 >= 64 && nkt128 >= 32) {
+        wide = 1;
+        wide_split = (int)((864 + t128 - 1) / t128);
+        if (wide_split > nkt128 / 8) wide_split = (int)(nkt128 / 8);
+      }
+      if (mode == 2) {      // tests / sweeps: bits 0-3 of the forced variant = kernel instantiation, bits 4.. = K slices (0: the policy's)
+        wide = forced & 15;
+        if (forced >> 4) wide_split = forced >> 4;
+      }
+    }
+  }
   // tile policy of the single-problem path: 96x96 for the long-K gradients of the token-heavy stages, 64x64 otherwise
-  const bool t96 = all96 && K >= 8192;
-  const int bm = t96 ? 96 : 64, bn = bm, bk = 64;
+  const bool t96 = wide < 0 && all96 && K >= 8192;
+  const int bm = wide >= 0 ? 128 : (t96 ? 96 : 64), bn = bm, bk = 64;
   WgradGroupArgs g;
   g.n = n; g.K = K; g.use_tr = g_scot_use_tr;
   int tiles = 0;
@@ -879,13 +894,14 @@ static int wgrad_group_impl(int compute, int n, int K, const void* const* dY, co
   // (groups with >= 256 tiles — the deep stages — are never split: two K slices for the 432-tile stage-2 group run 66 instead of 85 us
   // alone and cost the step 0.2 ms; the eight-wave workgroups below halve its serial K loop without a second pass)
   long nsplit = tiles >= 256 ? 1 : (want_wgs + tiles - 1) / tiles;
+  if (wide >= 0) nsplit = wide_split;
   if (nsplit < 1) nsplit = 1;
   const long maxsplit = nkt / 8 > 0 ? nkt / 8 : 1;
   if (nsplit > maxsplit) nsplit = maxsplit;
   const long wsmax = (workspace && plane) ? (long)(ws_bytes / (plane * sizeof(float))) : 1;
   if (nsplit > wsmax) nsplit = wsmax < 1 ? 1 : wsmax;
   int per = (int)(((K + nsplit - 1) / nsplit + bk - 1) / bk * bk);
-  if (nsplit >= 8) {
+  if (nsplit >= 8 && wide < 0) {
     for (int tries = 0; tries < 64 && ((K + per - 1) / per) % 8 != 0; ++tries) per += bk;
     if (((K + per - 1) / per) % 8 != 0) per = (int)(((K + nsplit - 1) / nsplit + bk - 1) / bk * bk);
   }
@@ -903,7 +919,8 @@ static int wgrad_group_impl(int compute, int n, int K, const void* const* dY, co
   // unsplit 64x64-tile groups (the deep stages: 432 / 1728 tiles walking 64 / 16 K-tiles each): two K groups per workgroup
   const int kg_env = 2;   // (measured: stage 2 84.5 -> 62.5 us alone, step -0.12 ms against four waves)
   int rc;
-  if (!t96 && g.nsplit == 1 && kg_env == 2 && nkt >= 4) rc = launch_wgrad_group<64, 64, 64, 2, 2>(g, stream);
+  if (wide >= 0) rc = scot_wgrad_group_wide_launch(g, wide, stream);
+  else if (!t96 && g.nsplit == 1 && kg_env == 2 && nkt >= 4) rc = launch_wgrad_group<64, 64, 64, 2, 2>(g, stream);
   else rc = t96 ? launch_wgrad_group<96, 96, 64, 2>(g, stream) : launch_wgrad_group<64, 64, 64, 2>(g, stream);
   if (rc == SCOT_OK && g.ws) {
     const size_t n8 = plane / 8;

@@ -218,6 +218,7 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_wide_kernel(WideArgs p) {
 #define WIDE_V_4W2S 2      /* 4 waves, 2 stages: two workgroups per CU */
 static int g_wide_mode = 1, g_wide_variant = WIDE_V_8W4S;
 extern "C" void scot_gemm_wide_config(int mode, int variant) { g_wide_mode = mode; g_wide_variant = variant; }
+int scot_gemm_wide_mode(int* variant) { if (variant) *variant = g_wide_variant; return g_wide_mode; }      // (wgrad_wide.hip's policy in gemm_fast.hip)
 
 // Which instantiation, or -1 = leave the call to gemm_fast.  From profiles/round5/gemm_wide_sweep_v3_{B,L,B256}.txt (hipGraph replays of 20
 // dependent launches per configuration, binary16 operands; us per launch, 64 x 64 tiles -> chosen instantiation):
@@ -230,7 +231,7 @@ extern "C" void scot_gemm_wide_config(int mode, int variant) { g_wide_mode = mod
 static int wide_variant(int M, int N, int K, int epi) {
   if (g_wide_mode == 0) return -1;
   if (M % 128 || N % 128 || K % 64 || M < 128 || N < 128 || K < 64) return -1;
-  if (g_wide_mode == 2) return g_wide_variant;
+  if (g_wide_mode == 2) return g_wide_variant & 15;      // (bits 4..: K slices of the grouped weight gradients, gemm_fast.hip)
   const long tiles = (long)(M / 128) * (N / 128);
   const int nkt = K / 64;
   if (nkt < 6) return -1;

@@ -139,6 +139,30 @@ def test_wgrad_group(emu, K, dims):
     assert not ops.wgrad_group(ops.F32, [(p[0].float(), p[1].float(), p[2], p[3]) for p in probs])
 
 
+@pytest.mark.parametrize("forced", [0, 1, 2, 1 | (2 << 4), 2 | (3 << 4)])
+def test_wgrad_group_wide_tiles(emu, forced):
+    """csrc/wgrad_wide.hip: the grouped weight gradients on 128 x 128 tiles — K-strided operands in swizzled [64 tokens][128] LDS tiles read with
+    the transposing fragment read, bias gradients from the dY tile, unsplit (read-modify-write by the tile's only writer) and with K slices
+    through the grouped reduce.  forced = kernel instantiation | K slices << 4 (scot_gemm_wide_config mode 2)."""
+    lib = emu
+    K, dims = 256, [(128, 256), (256, 128), (128, 128), (384, 128)]
+    probs, refs = [], []
+    for i, (M, N) in enumerate(dims):
+        dy, x = rnd(K, M, dtype=torch.bfloat16, seed=10 + i), rnd(K, N, dtype=torch.bfloat16, seed=20 + i)
+        dw, db = rnd(M, N, seed=30 + i), (rnd(M, seed=40 + i) if i != 2 else None)
+        refs.append((dw.double() + dy.double().t() @ x.double(), None if db is None else db.double() + dy.double().sum(0)))
+        probs.append((dy, x, dw, db))
+    lib.scot_gemm_wide_config(2, forced)
+    try:
+        assert ops.wgrad_group(ops.BF16, probs)
+    finally:
+        lib.scot_gemm_wide_config(1, 0)
+    for (dy, x, dw, db), (rw, rb) in zip(probs, refs):
+        assert rel(dw, rw) < 1e-5
+        if db is not None:
+            assert rel(db, rb) < 1e-4
+
+
 @pytest.mark.parametrize("cond", [True, False])
 @pytest.mark.parametrize("xdt,B,L,C", [(torch.float32, 2, 40, 96), (torch.bfloat16, 2, 64, 192), (torch.float32, 3, 9, 20), (torch.float32, 3, 16, 768),
                                        (torch.float32, 2, 6, 384)])

@@ -961,6 +961,40 @@ def test_wgrad_group_direct(kind, K, C):
         ops.use(prev)
 
 
+@pytest.mark.parametrize("kind", ["f16", "bf16"])
+@pytest.mark.parametrize("K,C,forced", [(1024, 768, 0), (1024, 768, 2), (4096, 384, 1 | (4 << 4)), (4096, 384, 2 | (2 << 4)), (2048, 1536, -1), (8192, 768, -1),
+                                        (512, 128, 1), (192, 256, 0 | (3 << 4))])
+def test_wgrad_group_wide_tiles(kind, K, C, forced):
+    """csrc/wgrad_wide.hip (128 x 128 tiles; forced = kernel instantiation | K slices << 4, -1 = the library's policy) against fp64 and against the
+    64 x 64-tile grouped kernel, += semantics, bias gradients; repeated launches of the unsplit form are bit-identical."""
+    prev = ops.use(kind)
+    lib = ops.L()
+    try:
+        hd = ops.half_dtype()
+        dims = [(C, 4 * C), (4 * C, C), (C, C), (3 * C, C)]
+        dys = [rnd(K, m, dtype=hd, scale=0.5, seed=10 + i) for i, (m, _) in enumerate(dims)]
+        xs = [rnd(K, n, dtype=hd, seed=20 + i) for i, (_, n) in enumerate(dims)]
+        dws0 = [rnd(m, n, seed=30 + i) for i, (m, n) in enumerate(dims)]
+        dbs0 = [rnd(m, seed=40 + i) for i, (m, _) in enumerate(dims)]
+        out = {}
+        for mode in ("narrow", "wide", "wide2"):
+            lib.scot_gemm_wide_config(0 if mode == "narrow" else (1 if forced < 0 else 2), max(forced, 0))
+            dws, dbs = [t.clone() for t in dws0], [t.clone() for t in dbs0]
+            assert ops.wgrad_group(ops.BF16, [(dy, x, dw, db) for dy, x, dw, db in zip(dys, xs, dws, dbs)])
+            torch.cuda.synchronize()
+            out[mode] = (dws, dbs)
+        for i, (dy, x) in enumerate(zip(dys, xs)):
+            ref = dy.double().t() @ x.double()
+            assert rel(out["wide"][0][i].double() - dws0[i].double(), ref) < 1e-6
+            assert rel(out["wide"][1][i].double() - dbs0[i].double(), dy.double().sum(0)) < 2e-6
+            assert rel(out["wide"][0][i], out["narrow"][0][i]) < 1e-6
+            if forced >= 0 and (forced >> 4) == 0:
+                assert torch.equal(out["wide"][0][i], out["wide2"][0][i])
+    finally:
+        lib.scot_gemm_wide_config(1, 0)
+        ops.use(prev)
+
+
 # ----------------------------------------------------------------------------------------------- the layer tail without 4C-wide tensors in HBM
 @pytest.mark.parametrize("prologue", [False, True])
 @pytest.mark.parametrize("cond", [True, False])

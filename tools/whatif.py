@@ -20,6 +20,10 @@ def main():
             f = getattr(ops, n[2:])
             setattr(ops, n[2:], lambda *a, _f=f, **k: (_f(*a, **k), _f(*a, **k))[1])
             continue
+        if n == "wgrad_group_deep":     # the grouped weight gradients of the deep stages only (<= 4096 token rows): what a faster TN kernel there could buy at most
+            f = ops.wgrad_group
+            ops.wgrad_group = lambda cm, problems, _f=f: True if problems[0][0].numel() // problems[0][0].shape[-1] <= 4096 else _f(cm, problems)
+            continue
         if not hasattr(ops, n):
             raise SystemExit(f"no op wrapper named {n}")
         ret = True if n in ("wgrad_mlp", "wgrad_group", "block_tail_fwd", "block_tail_bwd") else None
