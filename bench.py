@@ -307,7 +307,7 @@ def main():
     if world > 1 or "RANK" in os.environ:   # under torchrun the collective path is exercised even with one rank
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        if rank == 0 and "NCCL_DEBUG" not in os.environ:
+        if rank == 0 and "NCCL_DEBUG_FILE" not in os.environ:      # (a box-wide NCCL_DEBUG=VERSION / WARN is overridden for this process)
             # what RCCL chose for the gradient exchange (rings / trees, channels, algorithm and protocol per message size): parsed from
             # its own INFO log into config.rccl, so that an N-GPU line can be read without re-running it
             rccl_log = f"/tmp/scot_rccl_{os.getpid()}.log"
@@ -639,8 +639,9 @@ def main():
                 txt = open(rccl_log, errors="replace").read()
                 rccl = {"log": rccl_log,
                         "version": (_re.findall(r"(?:RCCL|NCCL) version[^\n]*", txt) or [None])[0],
-                        "rings_trees": sorted(set(_re.findall(r"(?:Ring|Tree|Trees|Channel)\s+\d+[^\n]{0,60}", txt)))[:6],
-                        "n_channels": (_re.findall(r"(\d+) coll channels", txt) or [None])[0],
+                        "n_channels": (_re.findall(r"Channel \d+/(\d+)", txt) or [None])[0],
+                        "graph_search": sorted(set(_re.findall(r"Pattern \d+, crossNic \d+, nChannels \d+, bw [\d./]+, type \S+", txt)))[:6],
+                        "rings": [l.strip()[:160] for l in _re.findall(r"\[RINGS\][^\n]*", txt)[:2]],
                         "algo_proto": sorted(set(_re.findall(r"[Aa]lgo(?:rithm)?\s*[:=]?\s*\w+[^\n]{0,40}[Pp]roto(?:col)?\s*[:=]?\s*\w+", txt)))[:8],
                         "transports": sorted(set(_re.findall(r"via (P2P[^\s]*|SHM[^\s]*|NET[^\s]*|direct[^\s]*)", txt)))[:6]}
             except Exception as e:  # pragma: no cover

@@ -116,7 +116,14 @@ def test_workspace_queries_answer_without_a_gpu():
     need = [lib.scot_wgrad_group_workspace_bytes(4, K, IA(C, 4 * C, C, 3 * C), IA(4 * C, C, C, C))
             for K, C in ((65536, 96), (16384, 192), (4096, 384), (1024, 768))]
     plane = [12 * C * C * 4 for C in (96, 192, 384, 768)]          # Σ M_i N_i floats of a layer's four weight gradients
-    assert need[0] > 0 and need[0] % plane[0] == 0 and need[1] > 0 and need[1] % plane[1] == 0 and need[2:] == [0, 0]
+    # (round 5: the stage-2 group — 108 tiles of 128 x 128 — cuts its 4096 tokens into slices for csrc/wgrad_wide.hip; stage 3's 432 tiles run unsplit)
+    assert need[0] > 0 and need[0] % plane[0] == 0 and need[1] > 0 and need[1] % plane[1] == 0
+    assert need[2] > 0 and need[2] % plane[2] == 0 and need[3] == 0
+    lib.scot_gemm_wide_config(0, 0)          # the 64 x 64-tile grouped kernel: both deep stages unsplit
+    try:
+        assert [lib.scot_wgrad_group_workspace_bytes(4, K, IA(C, 4 * C, C, 3 * C), IA(4 * C, C, C, C)) for K, C in ((4096, 384), (1024, 768))] == [0, 0]
+    finally:
+        lib.scot_gemm_wide_config(1, 0)
     assert 8 <= need[0] // plane[0] <= 128                          # nsplit: enough K slices to fill the chip, >= 8 K-tiles each
     tn = lib.scot_gemm_workspace_bytes(2, 1, 96, 384, 65536)        # one long-K weight gradient alone (TN)
     assert tn > 0 and tn % (96 * 384 * 4) == 0
