@@ -749,9 +749,7 @@ template <typename CT, bool X3> static int dispatch_w16(const AttnArgs& a, int h
 // compute: SCOT_F32 / SCOT_BF16 / SCOT_BF16X3 (fp32 tensors, split bf16 MFMAs).
 // returns SCOT_ERR_UNSUPPORTED when the geometry is not the fast path's (the caller then uses the general kernels)
 int scot_attn_w16(const AttnArgs& a, int compute, int hd, int nwin, bool bwd, hipStream_t s) {
-  static int enabled = -1;
-  if (enabled < 0) { const char* e = getenv("SCOT_ATTN_W16"); enabled = e ? atoi(e) : 1; }
-  if (!enabled || !a.use_tr || a.ws != 16 || (a.shift != 0 && a.shift != 8)) return SCOT_ERR_UNSUPPORTED;
+  if (!a.use_tr || a.ws != 16 || (a.shift != 0 && a.shift != 8)) return SCOT_ERR_UNSUPPORTED;
   if (compute == SCOT_BF16X3) return dispatch_w16<bf16_t, true>(a, hd, nwin, bwd, s);
   return compute == SCOT_BF16 ? dispatch_w16<bf16_t, false>(a, hd, nwin, bwd, s) : dispatch_w16<float, false>(a, hd, nwin, bwd, s);
 }

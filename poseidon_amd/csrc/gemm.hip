@@ -239,13 +239,9 @@ extern "C" int scot_gemm(int layout, int compute, int M, int N, int K,
   if ((a_dt | b_dt | c_dt) & ~1) return SCOT_ERR_DTYPE;
   if (compute == SCOT_BF16X3 && (a_dt != SCOT_F32 || b_dt != SCOT_F32)) return SCOT_ERR_DTYPE;   // bf16x3 splits fp32 operands
   {
-    static int use_panel = -1;
-    if (use_panel < 0) { const char* e = getenv("SCOT_GEMM_PANEL"); use_panel = e ? atoi(e) : 1; }
-    if (use_panel) {
-      const int rc = scot_gemm_panel(layout, compute, M, N, K, A, a_dt, lda, a_gelu, B, b_dt, ldb, b_gelu, C, c_dt, ldc, bias, colscale,
-                                     aux, aux_dt, ldaux, resid, res_dt, ldres, accumulate, colsum_out, aux_mul, C2, stream);
-      if (rc != SCOT_ERR_UNSUPPORTED) return rc;
-    }
+    const int rc = scot_gemm_panel(layout, compute, M, N, K, A, a_dt, lda, a_gelu, B, b_dt, ldb, b_gelu, C, c_dt, ldc, bias, colscale,
+                                   aux, aux_dt, ldaux, resid, res_dt, ldres, accumulate, colsum_out, aux_mul, C2, stream);
+    if (rc != SCOT_ERR_UNSUPPORTED) return rc;
   }
   {
     const int rc = scot_gemm_wide(layout, compute, M, N, K, A, a_dt, lda, a_gelu, B, b_dt, ldb, b_gelu, C, c_dt, ldc, bias, colscale,

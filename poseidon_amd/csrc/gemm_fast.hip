@@ -691,15 +691,10 @@ static int gemm_fast_impl(int layout, int compute, int M, int N, int K, const vo
   if (a_gelu || b_gelu) return SCOT_ERR_UNSUPPORTED;   // GELU-on-load is the general kernel's (the engine stores GELU(u) from the fc1 epilogue)
   int bk = compute == SCOT_BF16 ? 64 : 32;
   int nsplit = 1;
-  // tile choice: SCOT_GEMM_TILE[_NT|_NN|_TN] = 0..3 forces a shape (tuning), otherwise the per-layout policy below
-  static int ov[4] = {-2, -2, -2, -2};
-  if (ov[3] == -2) {
-    const char* names[4] = {"SCOT_GEMM_TILE_NT", "SCOT_GEMM_TILE_NN", "SCOT_GEMM_TILE_TN", "SCOT_GEMM_TILE"};
-    for (int i = 0; i < 4; ++i) { const char* e = getenv(names[i]); ov[i] = e ? atoi(e) : -1; }
-  }
-  int tile = ov[layout] >= 0 ? ov[layout] : (ov[3] >= 0 ? ov[3] : -1);
-  static int glds = -1;
-  if (glds < 0) { const char* e = getenv("SCOT_GEMM_GLDS"); glds = e ? atoi(e) : 1; }   // direct-to-LDS K loop for the NT products it covers (SCOT_GEMM_GLDS=0: register-staged)
+  // tile choice: the per-layout policy below (the SCOT_GEMM_TILE* / SCOT_GEMM_GLDS overrides of rounds 1-4 are retired: their sweeps are
+  // under profiles/round2..4 — micro_deep_gemm_tiles_r3.txt, gemm_lds_ring_depth_r4.txt — and in profiles/HISTORY.md)
+  int tile = -1;
+  const int glds = 1;   // direct-to-LDS K loop for the NT products it covers (register-staged: +0.15 ms per step, round 3)
   const int deep = 1;   // four-register-set pipeline for the long-K small-grid products (round 3, in step: 19.76 -> 19.59 ms)
   if (tile < 0) {
     tile = 0;   // policy (see DESIGN.md §3 for the measurements behind it)

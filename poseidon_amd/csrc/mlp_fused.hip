@@ -223,6 +223,14 @@ static int launch_mlp(const MlpArgs& a, hipStream_t s) {
   return scot_check_launch();
 }
 
+// token rows per workgroup of the fused block kernels, forced (64 x SCOT_MLP_TT) by the sanitizer / emulator harness (tests/test_hipemu_cpu.py);
+// 0 = the launch policies' own choice.  The one environment read left in the library's launch paths.
+static int scot_mlp_tt_override() {
+  static int tt_env = -1;
+  if (tt_env < 0) { const char* e = getenv("SCOT_MLP_TT"); tt_env = e ? atoi(e) : 0; }
+  return tt_env;
+}
+
 // include/scot_hip.h: scot_mlp_block_fwd.  Returns SCOT_ERR_UNSUPPORTED for shapes this kernel does not cover (the caller
 // then runs linear + linear + cln).
 extern "C" int scot_mlp_block_fwd(const void* h16, const float* h, const void* W1, const float* b1, const void* W2, const float* b2,
@@ -242,8 +250,7 @@ extern "C" int scot_mlp_block_fwd(const void* h16, const float* h, const void* W
   a.out = out; a.out16 = (bf16_t*)out16; a.act = (bf16_t*)act; a.dact = (bf16_t*)dact; a.z = z; a.z_dt = SCOT_F32; a.mean = mean; a.rstd = rstd;
   a.time = time; a.gw_w = gw_w; a.gw_b = gw_b; a.bw_w = bw_w; a.bw_b = bw_b; a.sscale = sample_scale;
   a.M = M; a.rows_per_sample = rows_per_sample; a.hid = hid; a.eps = eps;
-  static int tt_env = -1;
-  if (tt_env < 0) { const char* e = getenv("SCOT_MLP_TT"); tt_env = e ? atoi(e) : 0; }
+  const int tt_env = scot_mlp_tt_override();
   // 64·TT rows per workgroup: TT = 2 halves the LDS weight reads per MFMA; TT = 1 when that would leave CUs without work
   // (C = 192 with TT = 2 needs 256 VGPRs + spills: TT = 1 unless forced)
   const int tt = tt_env ? tt_env : ((C == 96 && M >= 64 * 2 * 512) ? 2 : 1);
@@ -563,8 +570,7 @@ extern "C" int scot_mlp_block_bwd(const float* g, float* g_out, const float* z, 
   if (hid < hc || hid % hc != 0) return SCOT_ERR_UNSUPPORTED;
   if (!g || !g_out || !z || !mean || !rstd || !gw_b || !dact || !W1 || !W2 || !dz || !du || !d_gw_b || !d_bw_b) return SCOT_ERR_SHAPE;
   if ((gw_w == nullptr) != (d_gw_w == nullptr) || (d_gw_w == nullptr) != (d_bw_w == nullptr)) return SCOT_ERR_SHAPE;
-  static int tt_env = -1;
-  if (tt_env < 0) { const char* e = getenv("SCOT_MLP_TT"); tt_env = e ? atoi(e) : 0; }
+  const int tt_env = scot_mlp_tt_override();
   int tt = tt_env ? tt_env : ((C == 96 && M >= 64 * 2 * 512) ? 2 : 1);
   if (rows_per_sample % (64 * tt) != 0) tt = 1;
   if (rows_per_sample % 64 != 0) return SCOT_ERR_UNSUPPORTED;      // the conditioning time must be uniform per workgroup
@@ -965,8 +971,7 @@ static int launch_tail_bwd(const TailBwdArgs& a, hipStream_t s) {
 }
 
 static int rows_tile_count(int C, int M, int rows_per_sample) {
-  static int tt_env = -1;
-  if (tt_env < 0) { const char* e = getenv("SCOT_MLP_TT"); tt_env = e ? atoi(e) : 0; }
+  const int tt_env = scot_mlp_tt_override();
   int tt = tt_env ? tt_env : ((C == 96 && M >= 64 * 2 * 512) ? 2 : 1);
   if (rows_per_sample % (64 * tt) != 0) tt = 1;
   return tt;
@@ -1026,8 +1031,7 @@ extern "C" int scot_proj_cln_bwd(const float* g, const float* z, const float* me
 // Rows a workgroup of the block tail owns at (C, M, rows_per_sample) — the geometry both directions use; the backward's partial-sum
 // scratch is one row of 4C (2C without conditioning) floats per workgroup and per norm.
 static int tail_rows_per_wg(int C, int M, int rows_per_sample) {
-  static int tt_env = -1;
-  if (tt_env < 0) { const char* e = getenv("SCOT_MLP_TT"); tt_env = e ? atoi(e) : 0; }
+  const int tt_env = scot_mlp_tt_override();
   int tt = tt_env ? tt_env : ((C == 96 && M >= 64 * 2 * 512) ? 2 : 1);
   if (C != 96 || rows_per_sample % (64 * tt) != 0) tt = 1;
   return 64 * tt;
@@ -1123,8 +1127,7 @@ extern "C" int scot_block_tail_fwd(/* attention-output half */ const void* a, co
   t.m.M = M; t.m.rows_per_sample = rows_per_sample; t.m.hid = hid; t.m.eps = eps;
   if ((Wqkv == nullptr) != (qkv == nullptr)) return SCOT_ERR_SHAPE;
   t.Wqkv = (const bf16_t*)Wqkv; t.bqkv = bqkv; t.qkv = (bf16_t*)qkv;
-  static int tt_env = -1;
-  if (tt_env < 0) { const char* e = getenv("SCOT_MLP_TT"); tt_env = e ? atoi(e) : 0; }
+  const int tt_env = scot_mlp_tt_override();
   const int tt = C == 96 ? (tt_env ? tt_env : (M >= 64 * 2 * 512 ? 2 : 1)) : 1;
   if (C == 96) return tt == 2 ? launch_tail_fwd<96, 64, 2>(t, stream) : launch_tail_fwd<96, 64, 1>(t, stream);
   return launch_tail_fwd<192, 64, 1>(t, stream);

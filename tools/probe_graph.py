@@ -74,12 +74,21 @@ def run_form(form, out):
         step()
     torch.cuda.synchronize()
     eager_ms, eager_enq = timed(step)
+    # what a captured graph of this program contains: launches and cross-stream edges, counted from the engine's own recorded step
+    prog = {}
+    for ent in model._engine._taped.values():
+        for part in ("fwd", "bwd"):
+            for fn, _ in ent.get(part) or []:
+                name = getattr(fn, "__name__", None) or "host"
+                kind = "event_record" if name == "scot_event_record" else "stream_wait_event" if name == "scot_stream_wait_event" else \
+                    "memset/memcpy" if name in ("scot_memset_async", "scot_memcpy_async") else "host" if name in ("host", "run", "<lambda>") else "launch"
+                prog[kind] = prog.get(kind, 0) + 1
     g = torch.cuda.CUDAGraph()
     g.enable_debug_mode()
     with torch.cuda.graph(g):
         step()
     torch.cuda.synchronize()
-    dot = os.path.join(out, f"step_{form}.dot")
+    dot = os.path.abspath(os.path.join(out, f"step_{form}.dot"))
     stats = None
     try:
         g.debug_dump(dot)
@@ -89,7 +98,7 @@ def run_form(form, out):
     except Exception as e:  # pragma: no cover
         stats = {"error": repr(e)}
     graph_ms, graph_enq = timed(g.replay)
-    res = {"form": form, "eager_ms": eager_ms, "eager_enqueue_ms": eager_enq, "graph_ms": graph_ms, "graph_enqueue_ms": graph_enq, "graph": stats,
+    res = {"form": form, "recorded_program": prog, "eager_ms": eager_ms, "eager_enqueue_ms": eager_enq, "graph_ms": graph_ms, "graph_enqueue_ms": graph_enq, "graph": stats,
            "GPU_MAX_HW_QUEUES": os.environ.get("GPU_MAX_HW_QUEUES")}
     print(json.dumps(res), flush=True)
 
