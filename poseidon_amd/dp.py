@@ -142,12 +142,20 @@ class OverlappedGradAllReducer(GradAllReducer):
     def __init__(self, model, dist, wire: str = "fp32", chunk_mb: int = 64, group=None, collective: str = "allreduce"):
         super().__init__(model, dist, wire=wire, chunk_mb=chunk_mb, group=group, collective=collective)
         self._ranges = None
-        self.comm_stream = torch.cuda.Stream()
+        # a stream measured to overlap the engine's main chain and its weight-gradient stream (streams.py; created lazily in attach(): the
+        # engine's side stream exists by then)
+        self.comm_stream = None
         self._pending = False
         self._hooked = False
         self.timing = None      # set to [] to collect (prefix, start event, end event) per range on the comm stream
 
     def attach(self):
+        if self.comm_stream is None:
+            from .streams import independent_stream
+            eng = self.model._engine
+            dev = self._flat().device
+            self.comm_stream = independent_stream(dev, [torch.cuda.current_stream(dev), eng.side_stream() if eng.use_side else None]) \
+                if dev.type == "cuda" else None
         self.model._engine.on_grads_final = self._on_final
         self.model._engine.reset_tapes()   # a recorded step bakes the hook in
         if not self._hooked:

@@ -581,7 +581,10 @@ class ScOTEngine:
 
     def side_stream(self):
         if self.side is None:
-            self.side = torch.cuda.Stream(device=self.device)
+            # a stream that is MEASURED to run beside the current one (streams.py: torch's pooled streams and the runtime's hardware queues
+            # are both handed out round-robin, and two that share a queue serialise silently)
+            from .streams import independent_stream
+            self.side = independent_stream(self.device, [torch.cuda.current_stream(self.device)])
         return self.side
 
     def _run_side(self, fns):

@@ -758,6 +758,21 @@ def test_short_training_run_fp16_tracks_fp32(regime_fixture, lr, tol):
     assert np.max(np.abs(a - b) / a) < tol
 
 
+def test_streams_that_must_overlap_are_measured_to():
+    """poseidon_amd/streams.py: torch hands out 32 pooled streams round-robin and the ROCm runtime maps them onto GPU_MAX_HW_QUEUES hardware queues,
+    so in a long-lived process some pooled stream shares the main stream's queue and serialises with it (3 of 34 handles on this box).  The engine's
+    weight-gradient stream and the gradient exchange's comm stream are therefore chosen by measurement."""
+    from poseidon_amd.streams import independent_stream, overlaps
+    main = torch.cuda.current_stream()
+    assert not overlaps(main, main)
+    pool = [torch.cuda.Stream() for _ in range(34)]
+    shared = [i for i, s in enumerate(pool) if not overlaps(main, s)]
+    print(f"\npooled streams sharing the main stream's hardware queue: {shared}")
+    side = independent_stream(torch.device(DEV), [main])
+    comm = independent_stream(torch.device(DEV), [main, side])
+    assert overlaps(main, side) and overlaps(side, main) and overlaps(main, comm) and overlaps(side, comm) and overlaps(comm, side)
+
+
 def test_overlapped_gradient_exchange_under_a_one_rank_rccl_group():
     """Data-parallel readiness on the one GPU the driver's run has (reference: `accelerate launch` / DDP, README.md:50-57, train.py:281): a
     1-rank `nccl` (= RCCL) process group, `OverlappedGradAllReducer` attached with the fp32 and then the bf16 wire, three steps each
