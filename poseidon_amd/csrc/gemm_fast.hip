@@ -839,7 +839,7 @@ static int wgrad_group_impl(int compute, int n, int K, const void* const* dY, co
     all96 = all96 && Ms[i] % 96 == 0 && Ns[i] % 96 == 0;
   }
   // 128 x 128 tiles (wgrad_wide.hip) for groups of 128-multiples: eight waves, two LDS stages (two workgroups per CU) — unsplit from 256 tiles,
-  // below that with K cut so that ~860 workgroups exist (>= 8 K-tiles each).  profiles/round5/wgrad_wide_sweep_r5.txt, us per launch,
+  // below that, from 8192 tokens, with K cut so that ~860 workgroups exist (>= 8 K-tiles each).  profiles/round5/wgrad_wide_sweep_r5.txt, us per launch,
   // 64 x 64 grouped kernel -> this: Poseidon-B stage 3 57.0 -> 42.8, stage 2 (108 tiles) 58.6 -> 54.4; Poseidon-L 299.8 -> 210.1,
   // 393.5 -> 267.2, 433.7 -> 293.9 (four waves or four stages lose everywhere: 243.9 / 347.5 at L's stage 3)
   int wide = -1, wide_split = 1;
@@ -852,7 +852,8 @@ static int wgrad_group_impl(int compute, int n, int K, const void* const* dY, co
     const long nkt128 = K / 64;
     if (mode != 0 && all128 && t128 > 0) {
       if (t128 >= 256) wide = 1;
-      else if (t128 >= 64 && nkt128 >= 32) {
+      else if (t128 >= 64 && nkt128 >= 128) {      // (shorter K — Poseidon-B's stage 2, 4096 tokens: 58.6 -> 54.4 us alone for 113 MB of partial tiles
+                                                   //  written and read back per launch, nothing in step: stays on the unsplit 64 x 64 kernel)
         wide = 1;
         wide_split = (int)((864 + t128 - 1) / t128);
         if (wide_split > nkt128 / 8) wide_split = (int)(nkt128 / 8);

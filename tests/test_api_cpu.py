@@ -116,12 +116,14 @@ def test_workspace_queries_answer_without_a_gpu():
     need = [lib.scot_wgrad_group_workspace_bytes(4, K, IA(C, 4 * C, C, 3 * C), IA(4 * C, C, C, C))
             for K, C in ((65536, 96), (16384, 192), (4096, 384), (1024, 768))]
     plane = [12 * C * C * 4 for C in (96, 192, 384, 768)]          # Σ M_i N_i floats of a layer's four weight gradients
-    # (round 5: the stage-2 group — 108 tiles of 128 x 128 — cuts its 4096 tokens into slices for csrc/wgrad_wide.hip; stage 3's 432 tiles run unsplit)
-    assert need[0] > 0 and need[0] % plane[0] == 0 and need[1] > 0 and need[1] % plane[1] == 0
-    assert need[2] > 0 and need[2] % plane[2] == 0 and need[3] == 0
-    lib.scot_gemm_wide_config(0, 0)          # the 64 x 64-tile grouped kernel: both deep stages unsplit
+    assert need[0] > 0 and need[0] % plane[0] == 0 and need[1] > 0 and need[1] % plane[1] == 0 and need[2:] == [0, 0]
+    # round 5, csrc/wgrad_wide.hip (128 x 128 tiles): a group with < 256 tiles and >= 8192 tokens cuts K into slices — Poseidon-B at 256 x 256, stage 2
+    q = lib.scot_wgrad_group_workspace_bytes(4, 8192, IA(384, 1536, 384, 1152), IA(1536, 384, 384, 384))
+    assert q > 0 and q % plane[2] == 0
+    lib.scot_gemm_wide_config(0, 0)          # the 96 x 96-tile grouped kernel splits this shape too, by its own policy (fewer slices)
     try:
-        assert [lib.scot_wgrad_group_workspace_bytes(4, K, IA(C, 4 * C, C, 3 * C), IA(4 * C, C, C, C)) for K, C in ((4096, 384), (1024, 768))] == [0, 0]
+        q0 = lib.scot_wgrad_group_workspace_bytes(4, 8192, IA(384, 1536, 384, 1152), IA(1536, 384, 384, 384))
+        assert q0 % plane[2] == 0 and q0 != q
     finally:
         lib.scot_gemm_wide_config(1, 0)
     assert 8 <= need[0] // plane[0] <= 128                          # nsplit: enough K slices to fill the chip, >= 8 K-tiles each
