@@ -307,11 +307,14 @@ def main():
     if world > 1 or "RANK" in os.environ:   # under torchrun the collective path is exercised even with one rank
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        if rank == 0 and "NCCL_DEBUG_FILE" not in os.environ:      # (a box-wide NCCL_DEBUG=VERSION / WARN is overridden for this process)
-            # what RCCL chose for the gradient exchange (rings / trees, channels, algorithm and protocol per message size): parsed from
-            # its own INFO log into config.rccl, so that an N-GPU line can be read without re-running it
-            rccl_log = f"/tmp/scot_rccl_{os.getpid()}.log"
-            os.environ.update(NCCL_DEBUG="INFO", NCCL_DEBUG_SUBSYS="INIT,GRAPH,TUNING,ENV", NCCL_DEBUG_FILE=rccl_log)
+        if "NCCL_DEBUG_FILE" not in os.environ:
+            # RCCL's own log goes to a per-rank file (a box-wide NCCL_DEBUG=VERSION would otherwise put its banner on stdout beside the one
+            # JSON line); rank 0 asks for INFO: what RCCL chose for the gradient exchange (rings, channels, algorithm / protocol) is parsed
+            # into the line's `rccl`, so that an N-GPU line can be read without re-running it
+            os.environ["NCCL_DEBUG_FILE"] = f"/tmp/scot_rccl_{os.getpid()}.log"
+            if rank == 0:
+                rccl_log = os.environ["NCCL_DEBUG_FILE"]
+                os.environ.update(NCCL_DEBUG="INFO", NCCL_DEBUG_SUBSYS="INIT,GRAPH,TUNING,ENV")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
         if dist.get_world_size() != a.gpus:
             raise SystemExit(f"RCCL process group has {dist.get_world_size()} ranks, --gpus {a.gpus}")
