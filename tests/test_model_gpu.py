@@ -148,7 +148,8 @@ def test_poseidon_presets(name, compute):
         # stored full gradients, global rel-L2: measured 1.1e-3 (T) / 2.6e-3 (B) / 1.6e-3 (B@256²) trained-like, 3e-4 / 1e-4 HF-init
         # per tensor (round 3, MI355X): worst 2.9e-2 (T trained: a key.weight) / 2.8e-3 (B trained) / 5.1e-3 (B@256²) / 4.3e-2 (B HF-init: the last
         # layer of a bias MLP); tensors whose true gradient is round-off in the reference itself (|g| < 1e-6 absolute) fall under `floor`
-        g, worst = grads_report(model, f, tol_each=8e-2, tol_global=6e-3, floor=1e-6, skip=("logit_scale",))
+        # (round 5, re-measured: global 1.2e-3 / 1.8e-3 / 1.9e-3 trained-like, 3.2e-4 / 1.1e-4 HF-init; worst tensor 4.0e-2 / 3.4e-3 / 6.1e-3 / 4.9e-2)
+        g, worst = grads_report(model, f, tol_each=8e-2, tol_global=4e-3, floor=1e-6, skip=("logit_scale",))
         print(f"[{name} fp16] stored gradients: global rel-L2 {g:.2e}, worst {worst}")
         # the ConvNeXt skip blocks' branch gradients (behind the layer scale: 1e-6 in the HF-init regime, ~2^-20 below the rest)
         # survive binary16 through the device-side local power-of-two rescale (engine.convnext_bwd)
@@ -191,7 +192,7 @@ def test_poseidon_L_config4(compute):
     dev = np.array([abs(mine[n] - r) / max(r, 1e-12) for n, r in zip(names, f["grad_norms"]) if r > 1e-7])
     print(f"\n[poseidonL {compute}] out rel-L2 {e_out:.2e} loss rel {e_loss:.2e} grad-norm dev median {np.median(dev):.2e} max {dev.max():.2e}")
     if compute == "fp16":       # the headline mode on config 4's model (head_dim 64): the north star's 1e-3
-        assert e_out < 1e-3 and e_loss < 1e-3 and np.median(dev) < 5e-3 and int(model._engine.grad_overflow) == 0
+        assert e_out < 1e-3 and e_loss < 1e-3 and np.median(dev) < 1.5e-3 and int(model._engine.grad_overflow) == 0      # (measured 6.2e-4 / 8.9e-6 / 4.1e-4)
         return
     assert e_out < 1e-5 + 5e-6
     assert e_loss < 2e-5
@@ -856,7 +857,7 @@ def test_short_training_run_fp16_tracks_fp32_on_poseidon_T():
     a, b = traj["fp32"], traj["fp16"]
     print(f"\n[Poseidon-T] fp32 {a[0]:.4f} -> {a[-1]:.4f}; fp16 {b[0]:.4f} -> {b[-1]:.4f}; max rel gap {np.max(np.abs(a - b) / a):.2e}")
     assert a[-1] < a[0] and b[-1] < b[0]
-    assert np.max(np.abs(a - b) / a) < 1e-2
+    assert np.max(np.abs(a - b) / a) < 2e-3          # (measured 2.4e-4: 15.337 -> 9.132 in both modes)
 
 
 @pytest.mark.parametrize("compute", ["fp16", "fp32"])
@@ -1061,7 +1062,7 @@ def test_config3_batch8_against_the_oracle(compute):
     if compute == "fp32":
         assert e_out < 1e-5 + 5e-6 and e_loss < 2e-5 and g < 1e-3
     else:
-        assert e_out < 1e-3 and e_loss < 1e-3 and g < 6e-3
+        assert e_out < 1e-3 and e_loss < 1e-3 and g < 2.5e-3      # (measured 7.1e-4 / 1.6e-4 / 8.2e-4)
         assert int(model._engine.grad_overflow) == 0
 
 
@@ -1099,7 +1100,8 @@ def test_timed_batch_gradients_fp16_vs_fp32_path(tag, size, channels, batch):
         den += nr ** 2
     g = (num / den) ** 0.5
     print(f"\n[Poseidon-{tag} {size}^2 batch {batch}] fp16 vs fp32 path: out rel-L2 {e_out:.2e} loss rel {e_loss:.2e} grads global rel-L2 {g:.2e} worst {worst}")
-    assert e_out < 1e-3 and e_loss < 1e-3 and g < 6e-3
+    # measured (round 5): out 6.1e-4 .. 8.9e-4, loss 1.3e-5 .. 1.6e-4, gradients 4.5e-4 .. 8.0e-4 over the five timed configurations
+    assert e_out < 1e-3 and e_loss < 1e-3 and g < 2.5e-3
 
 
 def test_inference_forwards_are_taped_and_replay_like_direct_launches():
