@@ -30,6 +30,9 @@ sys.path.insert(0, ROOT)
 
 # forward GFLOP/sample F (excl. CPB) and batch-independent CPB GFLOP/step P; fwd+bwd = 3(B·F + P)
 FLOPS = {"T": (2.784, 0.139), "B": (18.286, 0.277), "L": (67.948, 0.277)}
+FLOPS_AT = {("B", 256): (74.502, 0.521)}      # Poseidon-B at 256 x 256 (not 4x the 128 x 128 figure: windows / shifts differ)
+# BASELINE.json configs 2, 5, 4 (config 3 is the headline; config 1 is the CPU plumbing case inside cpu_baseline): (model, per-GPU batch, size, channels)
+OTHER_CONFIGS = [("T", 32, 128, 4), ("B", 32, 256, 4), ("L", 128, 128, 5)]
 PEAK_TFLOPS = {"fp16": 2500.0, "bf16": 2500.0, "fp32": 157.3, "bf16x3": 2500.0 / 3}   # bf16x3 = three bf16 MFMAs per product  # dense MFMA peaks, /opt/skills/guides/MI355X_MICROARCH.md
 
 
@@ -47,6 +50,11 @@ def parse():
     ap.add_argument("--no-graph", action="store_true", help="eager launches instead of one hipGraph per step")
     ap.add_argument("--graph", action="store_true", help="force hipGraph replay (default: time both in the warm-up, keep the faster)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-other-configs", action="store_true",
+                    help="skip the short runs of BASELINE.json's configs 2, 4 and 5 that the default single-GPU headline run appends (`other_configs`)")
+    ap.add_argument("--rccl-channels", type=int, default=0,
+                    help="N>1: cap RCCL at this many channels (NCCL_MAX_NCHANNELS, set before the process group exists): every channel is a "
+                         "workgroup the collectives take from a backward that is throughput-bound on both of its streams; 0 = RCCL's choice")
     ap.add_argument("--cpu-seconds", type=float, default=20.0)
     ap.add_argument("--wire", default="fp32", choices=["bf16", "fp32"], help="gradient all-reduce wire format (N>1)")
     ap.add_argument("--dp-collective", default="allreduce", choices=["allreduce", "rs_ag"],
@@ -58,6 +66,7 @@ def parse():
     ap.add_argument("--launch-dump", default=None, help="write every launch of the replayed steps (entry point, integer arguments, "
                                                         "stream, start/end in ms since the step's first launch) to this JSON file")
     ap.add_argument("--_cpu-worker", dest="cpu_worker", action="store_true", help=argparse.SUPPRESS)
+    ap.add_argument("--_emu", dest="emu", action="store_true", help=argparse.SUPPRESS)      # tests/test_bench_flow_cpu.py (see _enter_emulation)
     return ap.parse_args()
 
 
@@ -198,6 +207,74 @@ def parity_check(model_tag, compute, size, channels):
             "output_rel_l2": rel, "loss_rel": lrel, "bound": 1e-5 if compute == "fp32" else 1e-3, "meets_bound": rel < (1e-5 + 5e-6 if compute == "fp32" else 1e-3)}
 
 
+def step_flops(model_tag, size, batch):
+    """algorithmic TFLOP of one forward + backward step per GPU: 3 (B F + P), SURVEY.md 8(d)"""
+    F, P = FLOPS_AT.get((model_tag, size)) or (FLOPS[model_tag][0] * (size / 128.0) ** 2, FLOPS[model_tag][1])
+    return 3.0 * (batch * F + P) / 1e3
+
+
+def trained_like_model(cfg, compute):
+    """random weights with "trained-like" statistics, so that every branch carries O(1) signal (random data, section 5.4 rule 25)"""
+    from scOT.model import ScOT
+    model = ScOT(cfg, compute=compute)
+    with torch.no_grad():
+        for k, p in model.named_parameters():
+            if k.endswith("weight.bias") and ("norm" in k):
+                p.fill_(1.0)
+            elif k.startswith("residual_blocks") and k.count(".") == 2 and k.endswith(".weight"):
+                p.fill_(0.5)
+            elif p.dim() >= 2 and p.shape[-1] > 2:
+                fan = p[0].numel()
+                p.normal_(0, 1.0 / fan ** 0.5)
+    return model.to(DEV)
+
+
+def other_config(model_tag, batch, size, channels, compute, steps=10, warmup=5):
+    """One of BASELINE.json's non-headline configurations through the SAME step as the headline (zero-grad + forward + loss + backward on
+    resident synthetic inputs, eager replay of the recorded step), `warmup` untimed + `steps` timed steps, with the parity of the mode
+    against the real reference's fixture of that configuration."""
+    from poseidon_amd.config import preset
+    res = {"workload": f"Poseidon-{model_tag} fwd+bwd, {size}x{size}x{channels} grids, per-GPU batch {batch}", "dtype": compute}
+    try:
+        par = parity_check(model_tag, compute, size, channels)
+        res["parity_output_rel_l2"] = par.get("output_rel_l2")
+        res["parity_fixture"] = par.get("fixture") or par.get("note")
+        res["parity_meets_bound"] = par.get("meets_bound")
+        cfg = preset(model_tag, image_size=size, num_channels=channels, num_out_channels=channels,
+                     channel_slice_list_normalized_loss=[0, 1, channels - 1, channels])
+        torch.manual_seed(1234)
+        model = trained_like_model(cfg, compute)
+        torch.manual_seed(100)
+        kw = dict(pixel_values=torch.randn(batch, channels, size, size, device="cuda"),
+                  time=torch.randint(0, 8, (batch,), device="cuda").float() / 10.0,
+                  labels=torch.randn(batch, channels, size, size, device="cuda"))
+        loss = torch.zeros((), device="cuda")
+
+        def one():
+            model.zero_grad(overlap=True)
+            out = model(**kw)
+            out.loss.backward()
+            loss.copy_(out.loss.detach())
+        for _ in range(max(3, warmup)):      # (call 1 runs the ops, call 2 records the step, later calls replay it)
+            one()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            one()
+        torch.cuda.synchronize()
+        ms = (time.perf_counter() - t0) / steps * 1e3
+        tf = step_flops(model_tag, size, batch) / (ms / 1e3)
+        ovf = model._engine.grad_overflow
+        res.update({"ms_per_step": ms, "samples_per_s": batch / (ms / 1e3), "steps": steps, "warmup": max(3, warmup), "tflops": tf,
+                    "frac_of_mfma_peak": tf / PEAK_TFLOPS[compute], "loss": float(loss), "grad_overflow": int(ovf) if ovf is not None else None})
+        model._engine.reset_tapes()
+        del model, kw
+        torch.cuda.empty_cache()
+    except Exception as e:  # pragma: no cover
+        res["error"] = repr(e)
+    return res
+
+
 def launch_table(engine, run_step, nsteps=3, dump=None):
     """Per-launch GPU durations INSIDE real steps: the recorded step is replayed with a HIP-event pair around every C-ABI
     call, each pair on the stream the call launches on (main or weight-gradient side stream), so concurrency and cache state
@@ -205,7 +282,7 @@ def launch_table(engine, run_step, nsteps=3, dump=None):
     engine.launch_timer = []
     for _ in range(nsteps):
         run_step()
-    torch.cuda.synchronize()
+    _sync()
     log, engine.launch_timer = engine.launch_timer, None
     fam, inst = {}, {}
     main = torch.cuda.current_stream().cuda_stream
@@ -276,6 +353,50 @@ def launch_table(engine, run_step, nsteps=3, dump=None):
     return table, worst
 
 
+DEV = "cuda"     # "cpu" only under the hidden --_emu switch: the CPU-emulated kernels of tests/hipemu over gloo, for the control-flow test
+
+
+class _HostEvent:
+    """stand-in for torch.cuda.Event on the emulated (CPU) run: execution is synchronous there, so host time is device time"""
+
+    def __init__(self, enable_timing=True):
+        self.t = None
+
+    def record(self, stream=None):
+        self.t = time.perf_counter()
+
+    def elapsed_time(self, other):
+        return (other.t - self.t) * 1e3
+
+
+def _sync():
+    if DEV == "cuda":
+        torch.cuda.synchronize()
+
+
+def _event():
+    return torch.cuda.Event(enable_timing=True) if DEV == "cuda" else _HostEvent()
+
+
+def _enter_emulation():
+    """tests/test_bench_flow_cpu.py: this file's main() — launcher contract, rank-0-only sections, --dp auto probes, timing all-reduces, the
+    JSON line — with world size 2 over gloo on the CPU-emulated kernels and a tiny model.  Never a measurement: the line says `emulated`."""
+    global DEV
+    DEV = "cpu"
+    here = os.path.join(ROOT, "tests", "hipemu")
+    sys.path.insert(0, here)
+    import emu_session
+    import scOT.model as M
+    from poseidon_amd import ops
+    lib = emu_session.load_emu()
+    ws = torch.empty(32 << 20, dtype=torch.uint8)
+    ops.L = lambda: ops._Recording(lib if ops._active == "bf16" else emu_session.load_emu(ops._active), ops._recorder) \
+        if ops._recorder is not None else (lib if ops._active == "bf16" else emu_session.load_emu(ops._active))
+    ops.stream, ops.workspace = (lambda: None), (lambda need=0: ws)
+    ops.ptr = lambda t: None if t is None else t.data_ptr()
+    M._require_hip = lambda t: None
+
+
 def main():
     a = parse()
     if a.cpu_worker:
@@ -301,20 +422,35 @@ def main():
     if world != a.gpus:
         raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}: launch as `python bench.py --gpus N` (self-launching) or under "
                          "`python -m torch.distributed.run --nproc-per-node N bench.py --gpus N`")
-    torch.cuda.set_device(local)
+    if a.emu:
+        _enter_emulation()
+        a.no_parity = a.no_graph = a.no_cpu_baseline = a.no_other_configs = True
+    else:
+        torch.cuda.set_device(local)
     dist = None
     rccl_log = None
-    if world > 1 or "RANK" in os.environ:   # under torchrun the collective path is exercised even with one rank
+    if a.emu and (world > 1 or "RANK" in os.environ):
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+    elif world > 1 or "RANK" in os.environ:   # under torchrun the collective path is exercised even with one rank
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if a.rccl_channels > 0:
+            # every RCCL channel is one workgroup of each collective kernel: a cap bounds the CUs the gradient exchange takes from a
+            # backward that is throughput-bound on both of its streams (DESIGN.md section 7 has the recommended value)
+            os.environ["NCCL_MAX_NCHANNELS"] = str(a.rccl_channels)
+            os.environ["NCCL_MIN_NCHANNELS"] = str(min(a.rccl_channels, int(os.environ.get("NCCL_MIN_NCHANNELS", a.rccl_channels))))
         if "NCCL_DEBUG_FILE" not in os.environ:
-            # RCCL's own log goes to a per-rank file (a box-wide NCCL_DEBUG=VERSION would otherwise put its banner on stdout beside the one
-            # JSON line); rank 0 asks for INFO: what RCCL chose for the gradient exchange (rings, channels, algorithm / protocol) is parsed
-            # into the line's `rccl`, so that an N-GPU line can be read without re-running it
-            os.environ["NCCL_DEBUG_FILE"] = f"/tmp/scot_rccl_{os.getpid()}.log"
-            if rank == 0:
-                rccl_log = os.environ["NCCL_DEBUG_FILE"]
-                os.environ.update(NCCL_DEBUG="INFO", NCCL_DEBUG_SUBSYS="INIT,GRAPH,TUNING,ENV")
+            # RCCL's own log goes to a per-rank file in a private directory (a box-wide NCCL_DEBUG=VERSION would otherwise put its banner on
+            # stdout beside the one JSON line), removed once parsed.  Every rank asks for the same INFO subsystems (init-time lines only:
+            # nothing is logged per collective), rank 0's file is parsed into the line's `rccl` — what RCCL chose for the gradient exchange
+            # (rings, channels, algorithm / protocol) — so that an N-GPU line can be read without re-running it
+            import tempfile
+            rccl_dir = tempfile.mkdtemp(prefix="scot_rccl_")
+            os.environ["NCCL_DEBUG_FILE"] = os.path.join(rccl_dir, f"rank{rank}.log")
+            os.environ.update(NCCL_DEBUG="INFO", NCCL_DEBUG_SUBSYS="INIT,GRAPH,TUNING,ENV")
+            rccl_log = os.environ["NCCL_DEBUG_FILE"]
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
         if dist.get_world_size() != a.gpus:
             raise SystemExit(f"RCCL process group has {dist.get_world_size()} ranks, --gpus {a.gpus}")
@@ -326,6 +462,11 @@ def main():
     ch = a.channels
     cfg = preset(a.model, image_size=a.size, num_channels=ch, num_out_channels=ch,
                  channel_slice_list_normalized_loss=[0, 1, ch - 1, ch])
+    if a.emu:      # a model the emulated kernels step through in seconds (the control flow is what is under test)
+        from poseidon_amd.config import ScOTConfig
+        cfg = ScOTConfig(image_size=a.size, patch_size=4, num_channels=ch, num_out_channels=ch, embed_dim=16, depths=[2, 2], num_heads=[1, 2],
+                         skip_connections=[1, 0], window_size=4, mlp_ratio=4.0, qkv_bias=True, drop_path_rate=0.0, p=1,
+                         channel_slice_list_normalized_loss=[0, 1, ch - 1, ch], use_conditioning=True)
     parity = None
     if rank == 0 and not a.no_parity:
         parity = parity_check(a.model, a.compute, a.size, ch)
@@ -333,22 +474,12 @@ def main():
             print(f"bench.py: --compute {a.compute} is at {parity['output_rel_l2']:.2e} from the reference fixture (bound "
                   f"{parity['bound']:.0e}): the number below is NOT a compliant measurement", file=sys.stderr)
     torch.manual_seed(1234)  # identical initial weights on every rank (no broadcast needed)
-    model = ScOT(cfg, compute=a.compute)
-    with torch.no_grad():  # "trained-like" statistics so that every branch carries O(1) signal (random data, §5.4 rule 25)
-        for k, p in model.named_parameters():
-            if k.endswith("weight.bias") and ("norm" in k):
-                p.fill_(1.0)
-            elif k.startswith("residual_blocks") and k.count(".") == 2 and k.endswith(".weight"):
-                p.fill_(0.5)
-            elif p.dim() >= 2 and p.shape[-1] > 2:
-                fan = p[0].numel()
-                p.normal_(0, 1.0 / fan ** 0.5)
-    model = model.to("cuda")
+    model = trained_like_model(cfg, a.compute)
     torch.manual_seed(100 + rank)
     B = a.batch
-    pv = torch.randn(B, ch, a.size, a.size, device="cuda")
-    lab = torch.randn(B, ch, a.size, a.size, device="cuda")
-    tt = torch.randint(0, 8, (B,), device="cuda").float() / 10.0
+    pv = torch.randn(B, ch, a.size, a.size, device=DEV)
+    lab = torch.randn(B, ch, a.size, a.size, device=DEV)
+    tt = torch.randint(0, 8, (B,), device=DEV).float() / 10.0
     kw = dict(pixel_values=pv, time=tt, labels=lab)
 
     # The launch policies of the TIMED batch against the batch-1 path (the golden fixture above is batch 1: 128-row tails, grouped weight
@@ -371,7 +502,7 @@ def main():
     overlapped = (OverlappedGradAllReducer(model, dist, wire=a.wire, collective=a.dp_collective)
                   if (dist is not None and a.dp != "after") else None)
     exchange = [None if (dist is None or a.dp == "none") else ("after" if a.dp != "overlap" else "overlap")]   # current mode
-    loss_buf = torch.zeros((), device="cuda")
+    loss_buf = torch.zeros((), device=DEV)
 
     def compute_step():
         model.zero_grad(overlap=True)      # as poseidon_amd.train.Trainer does: the gradient arena's fill runs beside the forward
@@ -386,14 +517,14 @@ def main():
             after.allreduce()
         if exchange[0] == "overlap" and i == 0:
             overlapped.attach()   # the engine exists now: from here on the backward launches the range all-reduces itself
-    torch.cuda.synchronize()
+    _sync()
 
     graph = None
     if not a.no_graph and exchange[0] != "overlap":
         graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(graph):
             compute_step()
-        torch.cuda.synchronize()
+        _sync()
 
     use_graph = [graph is not None]
 
@@ -408,12 +539,12 @@ def main():
     def probe(flag, n=3):
         use_graph[0] = flag
         step()
-        torch.cuda.synchronize()
+        _sync()
         t = time.perf_counter()
         for _ in range(n):
             step()
         t_enq = time.perf_counter() - t
-        torch.cuda.synchronize()
+        _sync()
         return (time.perf_counter() - t) / n, t_enq / n
 
     # hipGraph replay removes the CPU launch cost but (ROCm 7.2) serialises most of the side-stream overlap; eager launches
@@ -423,7 +554,7 @@ def main():
         tg, _ = probe(True)
         te, te_enq = probe(False)
         if dist:
-            tt2 = torch.tensor([tg, te], device="cuda", dtype=torch.float64)
+            tt2 = torch.tensor([tg, te], device=DEV, dtype=torch.float64)
             dist.all_reduce(tt2, op=dist.ReduceOp.MAX)
             tg, te = float(tt2[0]), float(tt2[1])
         use_graph[0] = tg <= te
@@ -437,7 +568,7 @@ def main():
         for _ in range(3):
             probe(False, n=1)                       # warm / record / first replay of the hooked step
         t_over, _ = probe(False)
-        tt2 = torch.tensor([t_after, t_over], device="cuda", dtype=torch.float64)
+        tt2 = torch.tensor([t_after, t_over], device=DEV, dtype=torch.float64)
         dist.all_reduce(tt2, op=dist.ReduceOp.MAX)
         t_after, t_over = float(tt2[0]), float(tt2[1])
         mode_info.update({"probe_dp_after_ms": t_after * 1e3, "probe_dp_overlap_ms": t_over * 1e3})
@@ -453,16 +584,16 @@ def main():
         step()
     if dist:
         dist.barrier()
-    torch.cuda.synchronize()
+    _sync()
     t0 = time.perf_counter()
     for _ in range(a.steps):
         step()
-    torch.cuda.synchronize()
+    _sync()
     if dist:
         dist.barrier()
     dt = time.perf_counter() - t0
     if dist:
-        tmax = torch.tensor([dt], device="cuda", dtype=torch.float64)
+        tmax = torch.tensor([dt], device=DEV, dtype=torch.float64)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax)
     ms = dt / a.steps * 1e3
@@ -476,7 +607,7 @@ def main():
         for _ in range(3):
             probe(use_graph[0] if mode != "overlap" else False, n=1)
         t_bare, _ = probe(use_graph[0] if mode != "overlap" else False, n=max(3, a.steps // 2))
-        tb = torch.tensor([t_bare], device="cuda", dtype=torch.float64)
+        tb = torch.tensor([t_bare], device=DEV, dtype=torch.float64)
         dist.all_reduce(tb, op=dist.ReduceOp.MAX)
         exposed = {"step_without_exchange_ms": float(tb) * 1e3, "exposed_ms_per_step": ms - float(tb) * 1e3}
         exchange[0] = mode
@@ -490,17 +621,17 @@ def main():
             overlapped.timing = []
             for _ in range(3):
                 step()
-            torch.cuda.synchronize()
+            _sync()
             comm = overlapped.comm_ms() / 3
             overlapped.timing = None
         else:
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            torch.cuda.synchronize()
+            e0, e1 = _event(), _event()
+            _sync()
             e0.record()
             for _ in range(3):
                 after.allreduce()
             e1.record()
-            torch.cuda.synchronize()
+            _sync()
             comm = e0.elapsed_time(e1) / 3
     # What the metric (forward + backward, no optimizer) does NOT contain: producing the 16-bit / transposed operand copies of changed
     # weights.  In training the fused optimizer emits them while it updates the master weights (scot_adamw_step + scot_transpose_cast);
@@ -511,14 +642,14 @@ def main():
         from poseidon_amd import ops as _ops
         prev = _ops.use(eng.lib_kind)
         try:
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            torch.cuda.synchronize()
+            e0, e1 = _event(), _event()
+            _sync()
             e0.record()
             for _ in range(3):
                 model.mark_weights_dirty()
                 eng.refresh_weight_copies(True)
             e1.record()
-            torch.cuda.synchronize()
+            _sync()
             refresh_ms = e0.elapsed_time(e1) / 3
         finally:
             _ops.use(prev)
@@ -527,7 +658,7 @@ def main():
     # steps (the backward's last act is the main stream's wait for the weight-gradient stream, so its end covers both streams)
     phase = None
     if not use_graph[0]:
-        ev = [[torch.cuda.Event(enable_timing=True) for _ in range(3)] for _ in range(5)]
+        ev = [[_event() for _ in range(3)] for _ in range(5)]
         for e in ev:
             model.zero_grad(overlap=True)
             e[0].record()
@@ -537,11 +668,13 @@ def main():
             e[2].record()
             if exchange[0] == "after":
                 after.allreduce()
-        torch.cuda.synchronize()
+        _sync()
         phase = {"forward_ms": sorted(e[0].elapsed_time(e[1]) for e in ev)[2], "backward_ms": sorted(e[1].elapsed_time(e[2]) for e in ev)[2]}
     table = worst = None
     table_err = None
     try:   # every rank steps (under DP a step contains collectives); rank 0 reports
+        if a.emu:
+            raise RuntimeError("per-launch HIP-event timing needs the GPU")
         eager = use_graph[0]
         use_graph[0] = False
         table, worst = launch_table(model._engine, step, dump=a.launch_dump if rank == 0 else None)
@@ -552,9 +685,7 @@ def main():
     value = total_samples / dt
 
     if rank == 0:
-        F, P = FLOPS[a.model]
-        scale = (a.size / 128.0) ** 2
-        step_tflop = 3.0 * (B * F * scale + P) / 1e3            # per GPU per step
+        step_tflop = step_flops(a.model, a.size, B)             # per GPU per step
         achieved = step_tflop / (ms / 1e3)                       # TFLOP/s per GPU
         peak = PEAK_TFLOPS[a.compute]
         step_roof = {"bound": "mfma", "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak,
@@ -640,7 +771,7 @@ def main():
             try:
                 import re as _re
                 txt = open(rccl_log, errors="replace").read()
-                rccl = {"log": rccl_log,
+                rccl = {"max_nchannels_requested": a.rccl_channels or None,
                         "version": (_re.findall(r"(?:RCCL|NCCL) version[^\n]*", txt) or [None])[0],
                         "n_channels": (_re.findall(r"Channel \d+/(\d+)", txt) or [None])[0],
                         "graph_search": sorted(set(_re.findall(r"Pattern \d+, crossNic \d+, nChannels \d+, bw [\d./]+, type \S+", txt)))[:6],
@@ -649,7 +780,8 @@ def main():
                         "transports": sorted(set(_re.findall(r"via (P2P[^\s]*|SHM[^\s]*|NET[^\s]*|direct[^\s]*)", txt)))[:6]}
             except Exception as e:  # pragma: no cover
                 rccl = {"error": repr(e)}
-        res = {"metric": "PDE-grid samples/sec (fwd+bwd)", "value": value, "unit": "samples/s", "n_gpus": world, "steps": a.steps,
+        res = {**({"emulated": "CPU emulation of the kernels over gloo (tests/test_bench_flow_cpu.py): control flow only, NOT a measurement"} if a.emu else {}),
+               "metric": "PDE-grid samples/sec (fwd+bwd)", "value": value, "unit": "samples/s", "n_gpus": world, "steps": a.steps,
                "warmup": a.warmup, "ms_per_step": ms, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
                "dtype": a.compute, "data": "synthetic",
                "baseline_dtype": "bf16 in BASELINE.json's config text; this library's bf16 build sits at 6.2e-3 from the reference (non-compliant with "
@@ -664,6 +796,12 @@ def main():
                           "weight_refresh": weight_refresh, "parity": parity, "grad_overflow": overflow, "phases": phase,
                           "in_step_launches": launches},
                "roofline": roof}
+        headline = (a.model, B, a.size, ch) == ("B", 64, 128, 4)
+        if world == 1 and dist is None and headline and not a.no_other_configs:
+            # the other BASELINE.json configurations, timed by this same process (the driver's line then referees all five)
+            model._engine.reset_tapes()
+            torch.cuda.empty_cache()
+            res["other_configs"] = [other_config(*c, a.compute) for c in OTHER_CONFIGS]
         if world == 1 and not a.no_cpu_baseline:
             try:
                 res["cpu_baseline"] = cpu_baseline(a.model, a.size, ch, a.cpu_seconds)
@@ -672,6 +810,9 @@ def main():
         print(json.dumps(res), flush=True)
     if dist:
         dist.destroy_process_group()
+    if rccl_log:      # this rank's RCCL log and its private directory
+        import shutil
+        shutil.rmtree(os.path.dirname(rccl_log), ignore_errors=True)
 
 
 if __name__ == "__main__":

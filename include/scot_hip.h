@@ -119,6 +119,14 @@ size_t scot_gemm_workspace_bytes(int layout, int compute, int M, int N, int K);
  * Process-wide, not thread-safe against concurrent scot_gemm calls. */
 void scot_gemm_wide_config(int mode, int variant);
 
+/* K slices for the NT products whose result is fp32 and whose epilogue is bias-only (HF modeling_swinv2.py:552-561 forward at the deep
+ * stages; the data gradients of HF:536-548 and HF:396-410 accumulating into the fp32 residual-stream gradient): every slice adds its
+ * partial tile into the result with fp32 atomics (csrc/gemm_fast.hip; a non-accumulating call zeroes the result on `stream` first).
+ * Results agree with the unsplit kernel to fp32 summation order and are not bit-reproducible run to run.
+ * scot_gemm_splitk_config: slices 0 = the library's policy (default), -1 = never, S > 0 = S slices for every eligible call;
+ * zeroed_too 0 = only accumulating calls are split.  Process-wide, like scot_gemm_wide_config. */
+void scot_gemm_splitk_config(int slices, int zeroed_too);
+
 /* The weight gradients of one ScOTLayer in ONE launch: for i < n (n <= 8)
  *   dW_i[M_i, N_i] += dY_i[K, M_i]^T · X_i[K, N_i],   dbias_i[M_i] += Σ_k dY_i[k, :]   (dbias / dbias_i may be NULL)
  * i.e. the autograd of query/key/value, attention.output.dense, intermediate.dense and output.dense (HF:396-410, 502-506,

@@ -387,6 +387,24 @@ __device__ __forceinline__ void gemm_fast_body(const FastArgs& p, const int bx, 
   if (want_colsum && etid < BN) colacc[etid] = 0.f;
   __syncthreads();
 
+  if (LAYOUT != LAYOUT_TN && p.atomic) {
+    // K slices of an NT / NN product (grid z): every slice ADDS its partial tile into the fp32 result — no partial planes, no ticket, no
+    // second pass; slice 0 carries the bias.  A wave instruction covers 64 consecutive floats of one row (4 cache lines, one L2 atomic
+    // request each).  The result is either an accumulation target (data gradients into the fp32 residual-stream gradient) or was zeroed
+    // by the launcher.  fp32 addition order varies run to run: last-bit differences only.
+    float* C = (float*)p.C;
+    for (int idx = etid; idx < BM * BN; idx += 256 * KG) {
+      const int row = idx / BN, c = idx % BN;
+      const int grow = m0 + row, gcol = n0 + c;
+      if (grow < p.M && gcol < p.N) {
+        float v = Cs[row * CP + c];
+        if constexpr (KG == 2) v += Cs[BM * CP + row * CP + c];
+        if (p.bias && bz == 0) v += p.bias[gcol];
+        atomicAdd(C + (size_t)grow * p.ldc + gcol, v);
+      }
+    }
+    return;
+  }
   constexpr int CPRW = BN / 8;            // 8-column chunks per tile row
   constexpr int RPP = (256 * KG) / CPRW;  // rows per pass; threads >= RPP*CPRW idle (BN = 96: 252 of 256 active)
   const int cc = etid % CPRW;             // constant per thread over the row loop
@@ -661,6 +679,22 @@ static void tile_dims(int tile, int& bm, int& bn, int& bkt) {
 
 extern int g_scot_use_tr;
 
+// K slices of the fp32-result NT products (see gemm_fast_impl).  g_nt_splitk: 0 = the policy below, -1 = never, S > 0 = S slices for
+// every eligible call (sweeps: tools/bench_deep_gemm.py).
+static int g_nt_splitk = 0, g_nt_splitk_zeroed = 1;
+extern "C" void scot_gemm_splitk_config(int slices, int zeroed_too) { g_nt_splitk = slices; g_nt_splitk_zeroed = zeroed_too; }
+static int nt_splitk_policy(int M, int N, int K, int accumulate, long tiles, long nkt) {
+  if (g_nt_splitk < 0) return 1;
+  if (!accumulate && !g_nt_splitk_zeroed) return 1;
+  if (g_nt_splitk > 0) return nkt >= 2 * g_nt_splitk ? g_nt_splitk : 1;
+  // profiles/round6/splitk_atomic_probe.txt (us per launch, operands cold as in the step, unsplit -> 2 / 3 / 4 slices): the atomics cost
+  // ~1.8 us per slice per 0.8 M result elements, so only two slices of a long contraction into a small accumulation target pay —
+  // [1024, 768] += K 3072: 21.8 -> 16.8 / 18.7 / 18.0;  K 2304: 16.6 -> 13.8 / 15.7 / 16.2;  [4096, 384] += K 1536: 17.7 -> 18.5 (no);
+  // the zeroed forward form never does ([1024, 768] = K 3072: 21.8 -> 24.2 with the memset in front).
+  if (accumulate && (long)M * N <= (1L << 20) && nkt >= 32 && tiles <= 256) return 2;
+  return 1;
+}
+
 // Returns SCOT_ERR_UNSUPPORTED when the call does not qualify (the caller then uses the generic kernel).
 
 // `query` != NULL: plan only — the tile / split policy below runs against an unlimited workspace and *query receives the bytes it
@@ -741,12 +775,25 @@ static int gemm_fast_impl(int layout, int compute, int M, int N, int K, const vo
     else if (workspace && (((uintptr_t)workspace & 31) == 0)) a.ws = (float*)workspace;
     else a.atomic = 1;
   } else {
-    if (accumulate) {
+    // K slices with fp32 atomics into the result (round 6; the hand-off-free form of split-K: partial planes + an epilogue pass lost in
+    // rounds 2-3, an in-launch ticket + combine in round 5).  Only where the result is fp32 and the epilogue is bias-only: the deep stages'
+    // fc2 forward (result zeroed here first) and the fc1 / qkv data gradients, which accumulate into the fp32 residual-stream gradient.
+    int S = 1;
+    const bool split_ok = compute == SCOT_BF16 && layout == LAYOUT_NT && c_dt == SCOT_F32 && !aux && !C2 && !colsum_out && !colscale &&
+                          resid == nullptr && (accumulate || ldc == N) && (tile == 9 || tile == 8 || tile == 0);
+    if (split_ok) S = nt_splitk_policy(M, N, K, accumulate, tiles, nkt);
+    if (S > 1) {
+      const long per = (nkt + S - 1) / S;
+      a.ksplit = (int)(per * bk);
+      nsplit = (int)((nkt + per - 1) / per);
+    }
+    if (nsplit > 1) {
+      a.atomic = 1;
+      if (!accumulate && !query && hipMemsetAsync(C, 0, (size_t)M * N * sizeof(float), stream) != hipSuccess) return SCOT_ERR_LAUNCH;
+    } else if (accumulate) {
       if (resid != nullptr) return SCOT_ERR_UNSUPPORTED;
       a.resid = C; a.res_dt = c_dt; a.ldres = ldc;
     }
-    // (NT / NN products are never split along K: partial sums through the workspace + an epilogue pass were measured slower in step
-    // in rounds 2 and 3 for every deep-stage shape; the long-K small-grid case takes the four-register-set pipeline instead, above)
   }
   if (query) {
     *query = a.ws ? (size_t)nsplit * M * N * sizeof(float) : 0;

@@ -19,27 +19,71 @@ from typing import List, Optional, Tuple
 import torch
 
 
+SPLIT_FRACTION = 8      # a stage holding more than 1/8 of the parameters is announced in two halves (see stage_split)
+
+
+def stage_split(cfg, stage_prefix: str) -> int:
+    """Block index at which stage `stage_prefix` ("encoder.layers.3." / "decoder.layers.0.") is announced in two halves, 0 = whole.
+    The widest stages (Poseidon-B: 8 blocks at C = 768 in the encoder's last and the decoder's first stage, 36 % of the gradient bytes
+    each, reference train.py:35-72) finish half of their blocks' gradients — 114 MB — four layers before the other half: announcing
+    `blocks[s:]` (+ the stage's resampling layer, whose backward runs first) when the backward has passed block s lets the first
+    collective start after 4 layers of backward instead of 8.  Pure function of the configuration: engine and exchange agree by
+    construction."""
+    side, idx = stage_prefix.split(".")[0], int(stage_prefix.split(".")[2])
+    nl = len(cfg.depths)
+    depth = int(cfg.depths[idx if side == "encoder" else nl - 1 - idx])
+    width = int(cfg.embed_dim) << (idx if side == "encoder" else nl - 1 - idx)
+    # parameters of a block ~ 12 width^2; of the model ~ 2 sum_stages depth 12 width^2
+    total = 2 * sum(int(d) * 12 * (int(cfg.embed_dim) << i) ** 2 for i, d in enumerate(cfg.depths))
+    if depth >= 4 and depth * 12 * width * width * SPLIT_FRACTION > total:
+        return depth // 2
+    return 0
+
+
+def stage_groups(cfg, stage_prefix: str) -> List[str]:
+    """the group keys of one stage in announcement order: [prefix] or [prefix + "blocks[s:]", prefix + "blocks[:s]"]"""
+    s = stage_split(cfg, stage_prefix)
+    return [stage_prefix] if not s else [f"{stage_prefix}blocks[{s}:]", f"{stage_prefix}blocks[:{s}]"]
+
+
 def backward_order_groups(cfg, skips_on_side: bool = True) -> List[str]:
-    """Name-prefix groups in the order the backward announces them final.  The ConvNeXt skip blocks' backward runs on the side
-    stream beside the encoder stages (engine.skip_side), so their range is announced after the encoder's (before it with
+    """Group keys in the order the backward announces them final: name prefixes, and for a stage announced in halves (stage_split)
+    `<stage>blocks[s:]` (blocks s.. and the stage's other parameters) then `<stage>blocks[:s]`.  The ConvNeXt skip blocks' backward runs
+    on the side stream beside the encoder stages (engine.skip_side), so their range is announced after the encoder's (before it with
     SCOT_SKIP_SIDE=0 / no side stream)."""
     nl = len(cfg.depths)
     g = ["patch_recovery."]
-    g += [f"decoder.layers.{k}." for k in reversed(range(nl))]
+    for k in reversed(range(nl)):
+        g += stage_groups(cfg, f"decoder.layers.{k}.")
     if not skips_on_side:
         g += ["residual_blocks."]
-    g += [f"encoder.layers.{s}." for s in reversed(range(nl))]
+    for s in reversed(range(nl)):
+        g += stage_groups(cfg, f"encoder.layers.{s}.")
     if skips_on_side:
         g += ["residual_blocks."]
     g += ["embeddings."]
     return g
 
 
+def _in_group(name: str, key: str) -> bool:
+    if "blocks[" not in key:
+        return name.startswith(key)
+    stage, sl = key.split("blocks[")
+    if not name.startswith(stage):
+        return False
+    lo, hi = sl.rstrip("]").split(":")
+    rest = name[len(stage):]
+    if not rest.startswith("blocks."):
+        return lo != ""                    # the stage's resampling layer goes with the upper half (its backward runs before the blocks')
+    b = int(rest.split(".")[1])
+    return (b >= int(lo)) if lo != "" else (b < int(hi))
+
+
 def group_ranges(arena, groups: List[str]) -> List[Tuple[str, int, int]]:
-    """Contiguous [start, end) element ranges of the arena covering each name-prefix group."""
+    """Contiguous [start, end) element ranges of the arena covering each group (a name prefix or a stage half, see backward_order_groups)."""
     out = []
     for pre in groups:
-        offs = [(arena.offsets[n], arena.offsets[n] + arena.numel(n)) for n in arena.shapes if n.startswith(pre)]
+        offs = [(arena.offsets[n], arena.offsets[n] + arena.numel(n)) for n in arena.shapes if _in_group(n, pre)]
         if not offs:
             continue
         out.append((pre, min(o[0] for o in offs), max(o[1] for o in offs)))
@@ -172,6 +216,9 @@ class OverlappedGradAllReducer(GradAllReducer):
             self._ranges = {p: (s, e) for p, s, e in self.ranges_in_backward_order()}
         rng = self._ranges.get(prefix)
         if rng is None:
+            return
+        if self.comm_stream is None:      # no HIP streams (gloo on CPU tensors: the emulated tests): the range's exchange runs in line
+            self.reduce_range(rng[0], rng[1])
             return
         ev = torch.cuda.Event()
         ev.record()

@@ -669,11 +669,14 @@ class ScOTEngine:
             recs.append(r)
         return x, x16, recs
 
-    def blocks_bwd(self, recs, g, B, time):
+    def blocks_bwd(self, recs, g, B, time, split=0, on_upper_half=None):
+        """split / on_upper_half: called once the backward has passed block `split` (the gradients of blocks split.. are final: dp.stage_split)"""
         pend = None      # (d_qkv, Wqkv) of the layer just processed, to be applied by the next layer's fused tail as a prologue
         n = len(recs)
         for i, blk_rec in enumerate(reversed(recs)):
             g, pend = self.layer_bwd(blk_rec, g, B, time, pend, defer_qkv_dgrad=(i + 1 < n))
+            if split and on_upper_half is not None and n - 1 - i == split:
+                on_upper_half()
         assert pend is None
         self.finish_partials()
         self.flush_side()
@@ -1732,6 +1735,25 @@ class ScOTEngine:
             self.finish_partials()
             _range_done(prefix)
         done("patch_recovery.")
+        from .dp import stage_groups, stage_split
+
+        def stage_bwd(prefix, st, recs, g):
+            """the blocks of one stage; a stage announced in halves (dp.stage_split) hands over blocks[s:] as soon as block s is done"""
+            s_ = stage_split(cfg, prefix)
+            keys = stage_groups(cfg, prefix)
+            if not s_:
+                g = self.blocks_bwd(recs, g, B, time)
+                self.cpb_backward_range(st.blocks)
+                done(keys[0])
+                return g
+
+            def upper():
+                self.cpb_backward_range(st.blocks[s_:])
+                done(keys[0])
+            g = self.blocks_bwd(recs, g, B, time, split=s_, on_upper_half=upper)
+            self.cpb_backward_range(st.blocks[:s_])
+            done(keys[1])
+            return g
 
         # decoder, shallow → deep
         nl = len(self.dec)
@@ -1751,9 +1773,7 @@ class ScOTEngine:
             recs, urec = tape["dec"][k]
             if st.resample:
                 g = self.unmerge_bwd(st, urec, g, B, time)
-            g = self.blocks_bwd(recs, g, B, time)
-            self.cpb_backward_range(st.blocks)
-            done(f"decoder.layers.{k}.")
+            g = stage_bwd(f"decoder.layers.{k}.", st, recs, g)
             if k != 0:
                 i = nl - 1 - k
                 g_skips[i] = g   # x = x_prev + skip: both get g (g keeps flowing to x_prev unchanged)
@@ -1786,11 +1806,9 @@ class ScOTEngine:
             else:
                 g = g_skips[s]
                 d_sum = None
-            g = self.blocks_bwd(recs, g, B, time)
+            g = stage_bwd(f"encoder.layers.{s}.", st, recs, g)
             if d_sum is not None:
                 ops.add(g, d_sum, g)
-            self.cpb_backward_range(st.blocks)
-            done(f"encoder.layers.{s}.")
         if side_skips:
             done("residual_blocks.")     # (their side-stream tasks were joined by the encoder stages that consumed them)
 

@@ -14,7 +14,7 @@ LIB_PATH = os.path.join(_HERE, "libscot_hip.so")
 # The same sources built twice (build.py): the format of the 16-bit operand type is a compile-time property (csrc/common.h).
 LIB_PATHS = {"bf16": LIB_PATH, "f16": os.path.join(_HERE, "libscot_hip_f16.so")}
 OPERAND_FORMAT = {"bf16": 0, "f16": 1}
-ABI_VERSION = 3      # scot_abi_version() of the library these prototypes describe (checked at load)
+ABI_VERSION = 4      # scot_abi_version() of the library these prototypes describe (checked at load)
 
 P, I, F, Z = c_void_p, c_int, c_float, c_size_t
 
@@ -31,6 +31,7 @@ PROTOTYPES = {
     "scot_wgrad_group": [I, I, I, P, P, P, P, P, P, P, Z, P],
     "scot_gemm_workspace_bytes": [I, I, I, I, I],
     "scot_gemm_wide_config": [I, I],
+    "scot_gemm_splitk_config": [I, I],
     "scot_wgrad_group_workspace_bytes": [I, I, P, P],
     "scot_window_attn_fwd": [I, P, P, P, P, P, I, I, I, I, I, I, I, P],
     "scot_window_attn_probs": [P, I, P, P, P, P, I, I, I, I, I, I, I, P],
@@ -95,7 +96,7 @@ PROTOTYPES = {
     "scot_adamw_step": [P, P, P, P, P, Z, P, P, I, F, F, F, I, P, P, P, P],
     "scot_optim_finish": [P, P, P, F, F, I, F, P],
 }
-_VOID = {"scot_set_use_tr", "scot_gemm_wide_config"}
+_VOID = {"scot_set_use_tr", "scot_gemm_wide_config", "scot_gemm_splitk_config"}
 _SIZE = {"scot_gemm_workspace_bytes", "scot_wgrad_group_workspace_bytes", "scot_cln_bwd_workspace_bytes", "scot_wgrad_mlp_workspace_bytes"}      # return size_t
 
 
@@ -140,6 +141,10 @@ def load(path: str = None, kind: str = "bf16"):
     if w:
         mode, _, split = w.partition(",")
         lib.scot_gemm_wide_config(int(mode), int(split or 0))
+    k = os.environ.get("SCOT_GEMM_SPLITK")      # A/B runs: "<slices>[,<zeroed too>]" -> scot_gemm_splitk_config (-1 = never split)
+    if k:
+        sl, _, z = k.partition(",")
+        lib.scot_gemm_splitk_config(int(sl), int(z or 1))
     _libs[kind] = lib
     return lib
 

@@ -76,6 +76,7 @@ inline float emu_rcpf(float x) { return 1.0f / x; }
 #define __builtin_amdgcn_exp2f emu_exp2f
 #define hipMemcpyDeviceToHost 2
 inline hipError_t hipMemcpyAsync(void* dst, const void* src, size_t n, int, hipStream_t) { std::memcpy(dst, src, n); return hipSuccess; }
+inline hipError_t hipMemsetAsync(void* dst, int byte, size_t n, hipStream_t) { std::memset(dst, byte, n); return hipSuccess; }
 inline hipError_t hipStreamSynchronize(hipStream_t) { return hipSuccess; }
 template <typename T> inline hipError_t hipMalloc(T** p, size_t n) { *p = (T*)std::malloc(n); return *p ? hipSuccess : 1; }
 inline hipError_t hipFree(void* p) { std::free(p); return hipSuccess; }

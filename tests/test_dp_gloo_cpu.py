@@ -40,6 +40,10 @@ def test_backward_order_ranges_cover_arena():
         ar = Arena(param_shapes(cfg), "cpu")
         rngs = group_ranges(ar, backward_order_groups(cfg))
         assert [r[0] for r in rngs][0] == "patch_recovery." and rngs[-1][0] == "embeddings."
+        if cfg.embed_dim == 96:     # Poseidon-B: the two C = 768 stages are announced in halves of four blocks (dp.stage_split)
+            keys = [r[0] for r in rngs]
+            assert keys[4:8] == ["decoder.layers.0.blocks[4:]", "decoder.layers.0.blocks[:4]", "encoder.layers.3.blocks[4:]", "encoder.layers.3.blocks[:4]"]
+            assert max(e - s for _, s, e in rngs) * 4 < 125e6      # no range above 119 MB (was 233 MB)
         spans = sorted((s, e) for _, s, e in rngs)
         for (s0, e0), (s1, e1) in zip(spans, spans[1:]):
             assert e0 <= s1  # disjoint
@@ -129,7 +133,7 @@ def test_two_rank_mean_allreduce(tmp_path, wire, collective):
 # of its shard and the engine's `on_grads_final(prefix)` callback — the hook the overlapped RCCL exchange hangs on — reduces that
 # prefix's arena range IMMEDIATELY.  If a range were announced before the backward had finished writing it, the contributions
 # accumulated afterwards would stay un-averaged and the result would differ from the mean of the two ranks' gradients.
-def _engine_worker(rank, world, port, out):
+def _engine_worker(rank, world, port, out, depths=(2, 2)):
     import sys
     here = os.path.dirname(os.path.abspath(__file__))
     sys.path.insert(0, os.path.join(here, "hipemu"))
@@ -144,7 +148,7 @@ def _engine_worker(rank, world, port, out):
     ops.L, ops.stream, ops.workspace = (lambda: lib), (lambda: None), (lambda need=0: ws)
     ops.ptr = lambda t: None if t is None else t.data_ptr()
     dist.init_process_group("gloo", rank=rank, world_size=world)
-    cfg = ScOTConfig(**dict(TINY, mlp_ratio=4.0, qkv_bias=True, p=1, channel_slice_list_normalized_loss=[0, 1, 3, 4],
+    cfg = ScOTConfig(**dict(TINY, depths=list(depths), mlp_ratio=4.0, qkv_bias=True, p=1, channel_slice_list_normalized_loss=[0, 1, 3, 4],
                             drop_path_rate=0.0))      # (stochastic depth would make the two steps below differ)
     model = ScOT(cfg, compute="fp32")
     model.load_state_dict(synth_state_dict(param_shapes(cfg), "trained"))
@@ -178,6 +182,8 @@ def _engine_worker(rank, world, port, out):
     got = step()
     # (no side stream on the CPU emulation: the skip blocks' backward runs in line, before the encoder stages)
     assert seen == [p for p in backward_order_groups(cfg, skips_on_side=False) if p in ranges], seen
+    if tuple(depths) == (2, 4):      # the widest stages are announced in halves: the upper blocks (+ the resampling layer) first
+        assert seen[2:4] == ["decoder.layers.0.blocks[2:]", "decoder.layers.0.blocks[:2]"] and "encoder.layers.1.blocks[2:]" in seen, seen
     err = float((got - expect).norm() / expect.norm())
     bad = [n for n in model._arena.shapes
            if not torch.allclose(model._arena.gview(n), expect[model._arena.offsets[n]:model._arena.offsets[n] + model._arena.numel(n)]
@@ -199,6 +205,21 @@ def test_engine_ranges_are_final_when_announced(tmp_path):
     build_emu.build_cached()                                  # once, before the two ranks race for it
     out = str(tmp_path / "ok")
     mp.spawn(_engine_worker, args=(2, _free_port(), out), nprocs=2, join=True)
+    assert open(out).read().startswith("ok")
+
+
+def test_engine_stage_halves_are_final_when_announced(tmp_path):
+    """a model whose widest stages hold > 1/8 of the parameters each (as Poseidon-T / B / L's do): dp.stage_split announces them in two
+    halves, the upper one in the middle of the stage's backward — still only after its last gradient writer"""
+    import shutil
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "hipemu"))
+    import build_emu
+    if not (os.path.exists(build_emu.CLANG) or shutil.which(build_emu.CLANG)):
+        pytest.skip("no host clang with __bf16 vector support")
+    build_emu.build_cached()
+    out = str(tmp_path / "ok")
+    mp.spawn(_engine_worker, args=(2, _free_port(), out, (2, 4)), nprocs=2, join=True)
     assert open(out).read().startswith("ok")
 
 

@@ -106,6 +106,45 @@ def test_gemm_wide_tiles(emu, M, N, K, variant):
         lib.scot_gemm_wide_config(1, 0)
 
 
+@pytest.mark.parametrize("S", [2, 3, 5])
+@pytest.mark.parametrize("M,N,K", [(128, 64, 384), (96, 136, 640), (64, 192, 1024)])
+def test_gemm_nt_split_k_atomic(emu, M, N, K, S):
+    """csrc/gemm_fast.hip, K slices of the fp32-result NT products adding into the result with fp32 atomics (scot_gemm_splitk_config): the
+    forward form (bias from slice 0, result zeroed by the launcher — it starts as NaN here) and the accumulating data-gradient form,
+    against fp64 on the rounded operands and against the unsplit kernel; ragged M / N edges and a K that the slices do not divide."""
+    lib = emu
+    x, w, b = rnd(M, K, dtype=torch.bfloat16), rnd(N, K, dtype=torch.bfloat16, scale=K ** -0.5, seed=1), rnd(N, seed=2)
+    u = x.double() @ w.double().t() + b.double()
+    lib.scot_gemm_wide_config(0, 0)
+    lib.scot_gemm_splitk_config(-1, 0)
+    y0 = torch.empty(M, N)
+    ops.linear_fwd(ops.BF16, x, w, y0, bias=b)
+    g0 = rnd(M, N, seed=5)
+    try:
+        lib.scot_gemm_splitk_config(S, 1)
+        y = torch.full((M, N), float("nan"))
+        ops.linear_fwd(ops.BF16, x, w, y, bias=b)
+        assert rel(y, u) < 2e-6 and rel(y, y0) < 1e-6
+        g = g0.clone()
+        ops.linear_dgrad(ops.BF16, x, w.t().contiguous(), g, accumulate=True, wt=w)      # g += x @ (w^T)^T ... the NT product on w itself
+        assert rel(g, g0.double() + x.double() @ w.double().t()) < 1e-6
+        # accumulating calls only: a non-accumulating call stays unsplit and bit-identical to the unsplit kernel
+        lib.scot_gemm_splitk_config(S, 0)
+        y = torch.full((M, N), float("nan"))
+        ops.linear_fwd(ops.BF16, x, w, y, bias=b)
+        assert torch.equal(y, y0)
+        # 16-bit results and epilogues beyond the bias are never split
+        lib.scot_gemm_splitk_config(S, 1)
+        y16a, y16b = torch.empty(M, N, dtype=torch.bfloat16), torch.empty(M, N, dtype=torch.bfloat16)
+        ops.linear_fwd(ops.BF16, x, w, y16a, bias=b)
+        lib.scot_gemm_splitk_config(-1, 0)
+        ops.linear_fwd(ops.BF16, x, w, y16b, bias=b)
+        assert torch.equal(y16a, y16b)
+    finally:
+        lib.scot_gemm_splitk_config(0, 1)
+        lib.scot_gemm_wide_config(1, 0)
+
+
 def test_wgrad_split_k(emu):
     """TN layout with split-K partials + reduce pass (many token rows, small output)."""
     M, N, K = 2048, 96, 96
