@@ -213,6 +213,38 @@ def step_flops(model_tag, size, batch):
     return 3.0 * (batch * F + P) / 1e3
 
 
+def attainable_model(cfg, batch):
+    """What THIS decomposition (one launch per Linear / norm / attention core at C >= 384, one fused tail + one attention launch per direction at
+    C = 96 / 192, weight gradients beside the chain) could reach if every kernel sat on its own roof: per stage the maximum of
+      mfma   algorithmic FLOPs / 2.5 PF                                   (2 M 12 C^2 + 4 M Nw C per layer forward, x 3 for fwd + bwd)
+      hbm    bytes the layout moves / 6.3 TB/s                            (110 C B/token/layer fused, 270 C unfused + 28 C^2 B of weights / gradients)
+      floor  dependent launches x 1.5 us boundary + GEMM K loops          (64 x 64 tile, 16 KB per 64-deep K step at ~50 GB/s per CU = 0.33 us, + 3 us ramp)
+    summed over the stages (+ 0.6 ms of trunk / skip / head launches that overlap nothing).  The constants are measured ones: profiles/round6/attainable.md."""
+    from poseidon_amd.geometry import stage_plan
+    _, enc, dec = stage_plan(cfg)
+    stages, total = [], 0.0
+    for st in enc + dec:
+        C, M, nl = st.dim, batch * st.res[0] * st.res[1], len(st.blocks)
+        ws = st.blocks[0].window_shift()[0]
+        fused = C in (96, 192)
+        flops = 3.0 * nl * (2.0 * M * 12 * C * C + 4.0 * M * ws * ws * C)
+        mfma = flops / 2.5e15 * 1e3
+        hbm = nl * ((110 if fused else 270) * C * M + 28.0 * C * C) / 6.3e12 * 1e3
+        if fused:
+            floor = nl * 5 * 1.5e-3
+        else:       # forward 7 + backward 9 dependent launches; K steps of qkv, proj, fc1, fc2 and their data gradients (the same four contractions)
+            ksteps = 2 * (C + C + C + 4 * C) / 64.0
+            floor = nl * (16 * 1.5e-3 + ksteps * 0.33e-3 + 8 * 3e-3 + 2 * 5e-3 + 4 * 4e-3)     # + attention fwd / bwd (5 us each) + 4 norm launches (4 us)
+        t = max(mfma, hbm, floor)
+        total += t
+        stages.append({"stage": st.prefix, "tokens": M, "C": C, "mfma_ms": round(mfma, 3), "hbm_ms": round(hbm, 3), "floor_ms": round(floor, 3),
+                       "bound": "mfma" if t == mfma else ("hbm" if t == hbm else "launch+K-loop")})
+    total += 0.6
+    return {"ms_per_step": round(total, 2), "samples_per_s": round(batch / total * 1e3, 1), "stages": stages,
+            "note": "ceiling of the layer-by-layer decomposition with every kernel on its own roof (profiles/round6/attainable.md); the 70 % MFMA "
+                    "target needs a different decomposition (whole layers on chip: ~10x fewer bytes, ~7x fewer launches), not faster kernels"}
+
+
 def trained_like_model(cfg, compute):
     """random weights with "trained-like" statistics, so that every branch carries O(1) signal (random data, section 5.4 rule 25)"""
     from scOT.model import ScOT
@@ -766,6 +798,13 @@ def main():
                 break
         if isinstance(roof, dict):
             roof["hbm"] = hbm
+            try:
+                att = attainable_model(cfg, B)
+                att["frac_of_mfma_peak"] = round(step_tflop / (att["ms_per_step"] / 1e3) / peak, 4)
+                att["measured_over_attainable"] = round(ms / att["ms_per_step"], 2)
+                roof["attainable"] = att
+            except Exception as e:  # pragma: no cover
+                roof["attainable"] = {"error": repr(e)}
         rccl = None
         if rccl_log and os.path.exists(rccl_log):
             try:

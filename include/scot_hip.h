@@ -38,6 +38,13 @@ int scot_scale_inplace(float* x, size_t n, float scale, int* nonfinite, scot_str
 /* The same with the factor read from the device (x *= *scale_dev): the fp16 build's DYNAMIC gradient scale — a recorded step holds
  * the address, scot_optim_finish changes the value between steps. */
 int scot_scale_inplace_dev(float* x, size_t n, const float* scale_dev, int* nonfinite, scot_stream_t stream);
+/* The same on a LIST of pieces of x in one launch: chunks = nchunks pairs (offset, count) of int64 on the device, in floats, both
+ * multiples of 4, count <= 4096.  scale_dev NULL: the pieces are zeroed instead.  This is how the part of the gradient arena that is
+ * NOT written by a storing first writer (biases, norm / bias-MLP / convolution parameters, trunk weights: ~5 % of Poseidon-B's bytes)
+ * is cleared by zero_grad and brought back from the fp16 gradient scale after the backward; the Linear weights of the ScOTLayers
+ * take the scale in the store of their weight-gradient kernels (scot_wgrad_group / scot_wgrad_mlp `mode`).  Reference semantics:
+ * autograd's accumulate-into-.grad, trainer.py:605-635 via HF Trainer. */
+int scot_segments_scale(float* x, const long long* chunks, int nchunks, const float* scale_dev, int* nonfinite, scot_stream_t stream);
 /* Local power-of-two rescale of a gradient branch behind a tiny per-channel scale (ConvNeXt layer scale, model.py:191-195,212-213)
  * in the binary16 build — all factors stay on the device:
  *   scot_pow2_rescale: out2[0] = c = 2^k (k >= 0) with max|v|·c in (1/2, 1], out2[1] = 1/c;
@@ -133,9 +140,16 @@ void scot_gemm_splitk_config(int slices, int zeroed_too);
  * 545-561) over the same K tokens.  Operands dense row-major in the 16-bit operand format, dW fp32; the arrays of pointers /
  * sizes are HOST arrays, read before the call returns.  K is split over workgroups, partial tiles go through `workspace`
  * (32-byte aligned device scratch, >= nsplit · Σ M_i N_i floats) and one grouped pass adds them into the gradients.
- * compute must be 1 (16-bit MFMA); returns -3 for anything else (use scot_gemm per problem). */
+ * compute must be 1 (16-bit MFMA); returns -3 for anything else (use scot_gemm per problem).
+ * modes (host array of n ints, or NULL = all 0) says how each result meets dW_i, with s = *grad_scale (device float, NULL = 1):
+ *   0  dW_i += acc            the gradient arena's accumulate semantics (autograd's += into .grad)
+ *   1  dW_i  = s · acc        the FIRST writer of a gradient that zero_grad left unfilled: no fill, no re-read of zeros, and the fp16
+ *                             build's un-scale 1/S rides in the store (no separate pass over the arena)
+ *   2  dW_i += s · acc        later backwards of an accumulation window (the tensor holds unscaled values)
+ * dbias_i is always a plain accumulation. */
 int scot_wgrad_group(int compute, int n, int K, const void* const* dY, const void* const* X, float* const* dW,
-                     float* const* dbias, const int* M, const int* N, void* workspace, size_t ws_bytes, scot_stream_t stream);
+                     float* const* dbias, const int* M, const int* N, void* workspace, size_t ws_bytes, const int* modes,
+                     const float* grad_scale, scot_stream_t stream);
 /* nsplit · Σ M_i N_i · 4 bytes for the K split scot_wgrad_group chooses for these shapes (0: unsplit, or shapes it does not cover).
  * With less it splits less; with none and a split wanted it returns -3. */
 size_t scot_wgrad_group_workspace_bytes(int n, int K, const int* M, const int* N);
@@ -293,10 +307,12 @@ int scot_tape_replay(const unsigned long long* prog, size_t n_words, int* fail_e
  * HF:545-548, 558-561): per token slice and hidden chunk the kernel recomputes u = h16·W1^T + b1 and dz·W2 and feeds gelu(u) / du from
  * registers into dW2 += dz^T·gelu(u), dW1 += du^T·h16 (+ both bias gradients).  h16, dz [M, C] 16-bit; W1 [hid, C]; W2T [hid, C] = W2^T;
  * dW1 [hid, C] | db1 [hid] | dW2 [C, hid] | db2 [C] must be CONTIGUOUS in this order (the gradient arena's layout); workspace >=
- * scot_wgrad_mlp_workspace_bytes, 32-byte aligned.  C in {96, 192}, hid = 4C; -3 otherwise. */
+ * scot_wgrad_mlp_workspace_bytes, 32-byte aligned.  C in {96, 192}, hid = 4C; -3 otherwise.  mode / grad_scale: how dW1 and dW2 meet the
+ * arena (scot_wgrad_group's modes); db1 / db2 are always plain accumulations. */
 size_t scot_wgrad_mlp_workspace_bytes(int M, int C, int hid);
 int scot_wgrad_mlp(const void* h16, const void* dz, const void* W1, const float* b1, const void* W2T, float* dW1, float* db1, float* dW2,
-                   float* db2, int M, int C, int hid, void* workspace, size_t ws_bytes, scot_stream_t stream);
+                   float* db2, int M, int C, int hid, void* workspace, size_t ws_bytes, int mode, const float* grad_scale,
+                   scot_stream_t stream);
 
 /* Data movement */
 int scot_add(const void* a, int a_dt, const void* b, int b_dt, void* out, int out_dt, size_t n, size_t period,

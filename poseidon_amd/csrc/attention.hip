@@ -169,7 +169,10 @@ __device__ __forceinline__ void normalize_bwd_store(const f32x4_t (&acc)[HD / 16
     for (int o = 1; o < 16; o <<= 1) ss += __shfl_xor(ss, o, 64);
     const float nrm = sqrtf(ss);
     const bool clamped = nrm < 1e-12f;
-    const float rn = 1.0f / fmaxf(nrm, 1e-12f);
+    // (16-bit results: g / eps = 1e12 g is out of binary16's range, and the Inf would meet the all-zero input row that produced the clamped
+    //  norm — a padded window token under the bias-free key projection — as 0 · Inf = NaN in the weight gradient.  Its true contribution
+    //  there is 0 · 1e12 g = 0, and the data gradient of a padded token is cropped: the 16-bit builds store 0 for a clamped row.)
+    const float rn = (clamped && sizeof(CT) == 2) ? 0.f : 1.0f / fmaxf(nrm, 1e-12f);
 #pragma unroll
     for (int d = 0; d < DT; ++d) dot += (x[r][d] * rn) * (acc[d][r] * mul);
 #pragma unroll

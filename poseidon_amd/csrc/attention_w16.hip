@@ -215,7 +215,7 @@ __device__ __forceinline__ void normalize_bwd_store_t(const f32x4_t (&acc)[HD / 
   ss += __shfl_xor(ss, 16, 64);
   ss += __shfl_xor(ss, 32, 64);
   const float nrm = sqrtf(ss);
-  const float rn = 1.0f / fmaxf(nrm, 1e-12f);
+  const float rn = (nrm < 1e-12f && sizeof(CT) == 2) ? 0.f : 1.0f / fmaxf(nrm, 1e-12f);      // (clamped row, 16-bit result: see attention.hip)
 #pragma unroll
   for (int d = 0; d < DT; ++d)
 #pragma unroll

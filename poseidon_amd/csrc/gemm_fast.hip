@@ -12,6 +12,7 @@
 //     dY tile that is already in LDS.
 #include <type_traits>
 #include "common.h"
+#include "wgrad_group.h"   // the grouped weight-gradient argument block, and how a gradient meets the arena (grad_commit8)
 #include <stdlib.h>
 
 #define LAYOUT_NT 0
@@ -35,6 +36,8 @@ struct FastArgs {
   float* ws;       // TN split-K: partial tiles ws[z][M][N] (fp32), reduced by splitk_reduce_kernel
   size_t ws_plane; // distance (floats) between the partial tiles of consecutive K slices; 0 = M·N (grouped wgrad: Σ_i M_i·N_i)
   int rmw;         // TN, single split: C += acc by the unique owner (no atomics)
+  int out_mode;    // rmw only: WgradProblem::mode (0 = C += acc, 1 = C = s·acc, 2 = C += s·acc), s = *out_scale (NULL: 1)
+  const float* out_scale;
 };
 
 template <typename CT> struct FT;
@@ -469,11 +472,7 @@ __device__ __forceinline__ void gemm_fast_body(const FastArgs& p, const int bx, 
         if (p.ws) {            // split-K partial tile (dense [M][N], 32-byte aligned rows since N % 8 == 0)
           st8(p.ws + (size_t)bz * (p.ws_plane ? p.ws_plane : (size_t)p.M * p.N), SCOT_F32, (size_t)grow * p.N + col, v);
         } else if (p.rmw) {    // single split: this workgroup is the only writer of the tile
-          float o[8];
-          ld8(p.C, SCOT_F32, ci, o);
-#pragma unroll
-          for (int j = 0; j < 8; ++j) o[j] += v[j];
-          st8(p.C, SCOT_F32, ci, o);
+          grad_commit8((float*)p.C, ci, v, p.out_mode, p.out_scale);
         } else {
 #pragma unroll
           for (int j = 0; j < 8; ++j) atomicAdd((float*)p.C + ci + j, v[j]);
@@ -534,7 +533,6 @@ __global__ __launch_bounds__(256 * KG) void gemm_fast_kernel(FastArgs p) {
 // the chip and moved 19 MB of partial tiles.  Together the four problems of a block have 12 tiles: 40 K slices fill the chip,
 // the partials shrink 3x, 8 launches become 2 (this kernel + one grouped reduce), and the deep stages' problems (hundreds of
 // 64x64 tiles each, no split) share one launch instead of four tail effects.
-#include "wgrad_group.h"
 
 template <typename CT, int BM, int BN, int BKT, int NSET, int KG = 1>
 __global__ __launch_bounds__(256 * KG) void wgrad_group_kernel(WgradGroupArgs g) {
@@ -564,6 +562,7 @@ __global__ __launch_bounds__(256 * KG) void wgrad_group_kernel(WgradGroupArgs g)
   a.ws = g.ws ? g.ws + pr.ws_off : nullptr;     // partial tiles of slice z at ws[z·plane + ws_off ..]
   a.ws_plane = g.plane;
   a.rmw = g.ws ? 0 : 1;
+  a.out_mode = pr.mode; a.out_scale = g.scale;
   gemm_fast_body<CT, BM, BN, 2, 2, BKT, NSET, LAYOUT_TN, false, KG>(a, local % pr.tiles_n, local / pr.tiles_n, slice, smem);
 }
 
@@ -691,7 +690,10 @@ static int nt_splitk_policy(int M, int N, int K, int accumulate, long tiles, lon
   // ~1.8 us per slice per 0.8 M result elements, so only two slices of a long contraction into a small accumulation target pay —
   // [1024, 768] += K 3072: 21.8 -> 16.8 / 18.7 / 18.0;  K 2304: 16.6 -> 13.8 / 15.7 / 16.2;  [4096, 384] += K 1536: 17.7 -> 18.5 (no);
   // the zeroed forward form never does ([1024, 768] = K 3072: 21.8 -> 24.2 with the memset in front).
-  if (accumulate && (long)M * N <= (1L << 20) && nkt >= 32 && tiles <= 256) return 2;
+  // ... and in the step those two launches change nothing (profiles/round6/splitk_in_step_ab.txt: 18.70 / 18.55 ms without, 18.54 / 18.53 with,
+  // `gemm NT` family 7.00-7.10 ms either way), so the policy splits NOTHING: results stay bit-reproducible run to run, the mechanism stays
+  // for scot_gemm_splitk_config (tests, tools/bench_splitk.py).
+  (void)M; (void)N; (void)K; (void)tiles;
   return 1;
 }
 
@@ -719,6 +721,7 @@ static int gemm_fast_impl(int layout, int compute, int M, int N, int K, const vo
   a.M = M; a.N = N; a.K = K; a.lda = lda; a.ldb = ldb; a.ldc = ldc; a.ldaux = ldaux; a.ldres = ldres;
   a.c_dt = c_dt; a.aux_dt = aux_dt; a.res_dt = res_dt; a.a_gelu = a_gelu; a.b_gelu = b_gelu; a.aux_gelu_grad = aux != nullptr;
   a.use_tr = g_scot_use_tr; a.atomic = 0; a.ws = nullptr; a.ws_plane = 0; a.rmw = 0; a.C2 = C2; a.aux_mul = aux_mul;
+  a.out_mode = 0; a.out_scale = nullptr;
   a.xcd_swizzle = 1;
   a.pre = 1;         // epilogue operands requested before the K loop (round 4: dgrad fc2 · gelu' 43.2 -> 36.6 us in step)
   if (C2 && ((((uintptr_t)C2) & 15) != 0 || layout == LAYOUT_TN)) return SCOT_ERR_UNSUPPORTED;
@@ -851,13 +854,7 @@ __global__ __launch_bounds__(256) void wgrad_group_reduce_kernel(WgradGroupArgs 
     const int m = le / pr.N, n = le % pr.N;
     float acc[8];
     splitk_sum<ZL>(acc, g.ws, e, g.plane, g.nsplit, zl);
-    if (zl == 0) {
-      float c[8];
-      ld8(pr.C, SCOT_F32, (size_t)m * pr.ldc + n, c);
-#pragma unroll
-      for (int j = 0; j < 8; ++j) c[j] += acc[j];
-      st8(pr.C, SCOT_F32, (size_t)m * pr.ldc + n, c);
-    }
+    if (zl == 0) grad_commit8(pr.C, (size_t)m * pr.ldc + n, acc, pr.mode, g.scale);
   }
 }
 
@@ -873,7 +870,7 @@ int scot_gemm_wide_mode(int* variant);                                          
 // dbias_i: [M_i] fp32 (+= column sums of dY_i) or NULL.  All leading dimensions = the row lengths (dense).
 static int wgrad_group_impl(int compute, int n, int K, const void* const* dY, const void* const* X, float* const* dW,
                             float* const* dbias, const int* Ms, const int* Ns, void* workspace, size_t ws_bytes,
-                            hipStream_t stream, size_t* query) {
+                            const int* modes, const float* grad_scale, hipStream_t stream, size_t* query) {
   if (query) { *query = 0; workspace = (void*)(uintptr_t)64; ws_bytes = (size_t)1 << 60; }
   if (n <= 0 || n > SCOT_WGRAD_GROUP_MAX || K <= 0) return SCOT_ERR_SHAPE;
   if (compute != SCOT_BF16) return SCOT_ERR_UNSUPPORTED;     // fp32 / split modes use scot_gemm per problem
@@ -922,6 +919,8 @@ static int wgrad_group_impl(int compute, int n, int K, const void* const* dY, co
     WgradProblem& p = g.p[i];
     p.A = query ? nullptr : dY[i]; p.B = query ? nullptr : X[i]; p.C = query ? nullptr : dW[i]; p.colsum = (dbias && !query) ? dbias[i] : nullptr;
     p.M = Ms[i]; p.N = Ns[i]; p.lda = Ms[i]; p.ldb = Ns[i]; p.ldc = Ns[i];
+    p.mode = modes ? modes[i] : SCOT_GRAD_ADD;
+    if (p.mode < 0 || p.mode > SCOT_GRAD_ADD_SCALED) return SCOT_ERR_SHAPE;
     p.tiles_n = (Ns[i] + bn - 1) / bn;
     p.tile0 = tiles;
     p.ws_off = (unsigned)plane;
@@ -929,7 +928,7 @@ static int wgrad_group_impl(int compute, int n, int K, const void* const* dY, co
     plane += (size_t)Ms[i] * Ns[i];
   }
   for (int i = n; i < SCOT_WGRAD_GROUP_MAX; ++i) { g.p[i] = g.p[0]; g.p[i].tile0 = 0x7fffffff; g.p[i].ws_off = 0xffffffffu; }
-  g.tiles = tiles; g.plane = plane;
+  g.tiles = tiles; g.plane = plane; g.scale = grad_scale;
   // K slices: enough workgroups to fill the chip (~2 per CU), at least 8 K-tiles each, a multiple of 8 so that one slice's
   // tiles share an XCD; none when the group already has >= 256 tiles
   const int want_wgs = 256;   // in-step optimum: 192-256 (448 filled the chip better alone and cost the chain 0.1 ms; 128 makes the side stream the wall)
@@ -980,13 +979,13 @@ static int wgrad_group_impl(int compute, int n, int K, const void* const* dY, co
 
 extern "C" int scot_wgrad_group(int compute, int n, int K, const void* const* dY, const void* const* X, float* const* dW,
                                 float* const* dbias, const int* Ms, const int* Ns, void* workspace, size_t ws_bytes,
-                                hipStream_t stream) {
-  return wgrad_group_impl(compute, n, K, dY, X, dW, dbias, Ms, Ns, workspace, ws_bytes, stream, nullptr);
+                                const int* modes, const float* grad_scale, hipStream_t stream) {
+  return wgrad_group_impl(compute, n, K, dY, X, dW, dbias, Ms, Ns, workspace, ws_bytes, modes, grad_scale, stream, nullptr);
 }
 
 // include/scot_hip.h: scot_wgrad_group_workspace_bytes (0: no split, or the shapes are not covered by the grouped kernel)
 extern "C" size_t scot_wgrad_group_workspace_bytes(int n, int K, const int* Ms, const int* Ns) {
   size_t q = 0;
-  const int rc = wgrad_group_impl(SCOT_BF16, n, K, nullptr, nullptr, nullptr, nullptr, Ms, Ns, nullptr, 0, nullptr, &q);
+  const int rc = wgrad_group_impl(SCOT_BF16, n, K, nullptr, nullptr, nullptr, nullptr, Ms, Ns, nullptr, 0, nullptr, nullptr, nullptr, &q);
   return rc == SCOT_OK ? q : 0;
 }

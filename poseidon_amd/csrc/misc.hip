@@ -1413,6 +1413,33 @@ extern "C" int scot_scale_inplace(float* x, size_t n, float scale, int* nonfinit
   hipLaunchKernelGGL(scale_inplace_kernel, dim3((unsigned)blocks), dim3(256), 0, s, x, n / 4, n, scale, nonfinite, (const float*)nullptr);
   return scot_check_launch();
 }
+// One workgroup per chunk (offset, count <= 4096 floats, both multiples of 4) of `x`: the chunks are zeroed (scale_dev == NULL) or
+// multiplied by *scale_dev, counting non-finite results like scale_inplace_kernel.
+__global__ __launch_bounds__(256) void segments_scale_kernel(float* x, const long long* __restrict__ chunks, const float* scale_dev, int* nonfinite) {
+  const long long off = chunks[2 * blockIdx.x], cnt = chunks[2 * blockIdx.x + 1];
+  float4* p = (float4*)(x + off);
+  const int n4 = (int)(cnt >> 2);
+  if (!scale_dev) {
+    for (int i = threadIdx.x; i < n4; i += 256) p[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+    return;
+  }
+  const float s = *scale_dev;
+  int bad = 0;
+  for (int i = threadIdx.x; i < n4; i += 256) {
+    float4 v = p[i];
+    v.x *= s; v.y *= s; v.z *= s; v.w *= s;
+    bad |= !(fabsf(v.x) <= 3.4e38f) | !(fabsf(v.y) <= 3.4e38f) | !(fabsf(v.z) <= 3.4e38f) | !(fabsf(v.w) <= 3.4e38f);
+    p[i] = v;
+  }
+  if (nonfinite != nullptr && __ballot(bad) != 0ull && (threadIdx.x & 63) == 0) atomicAdd(nonfinite, 1);
+}
+// include/scot_hip.h: scot_segments_scale
+extern "C" int scot_segments_scale(float* x, const long long* chunks, int nchunks, const float* scale_dev, int* nonfinite, hipStream_t s) {
+  if (nchunks == 0) return SCOT_OK;
+  if (!x || !chunks || nchunks < 0 || (((uintptr_t)x) & 15)) return SCOT_ERR_SHAPE;
+  hipLaunchKernelGGL(segments_scale_kernel, dim3((unsigned)nchunks), dim3(256), 0, s, x, chunks, scale_dev, nonfinite);
+  return scot_check_launch();
+}
 // include/scot_hip.h: scot_scale_inplace_dev — x *= *scale_dev (a device float), counting non-finite results as above
 extern "C" int scot_scale_inplace_dev(float* x, size_t n, const float* scale_dev, int* nonfinite, hipStream_t s) {
   if (n == 0) return SCOT_OK;

@@ -17,7 +17,7 @@
 // HBM traffic: h16 + dz = 4·C bytes per token (the hidden chunks of one token slice run on ONE XCD: its L2 serves the re-reads),
 // against 20·C for the four operands of the GEMMs it replaces; partial sums [slice][W1 | b1 | W2 | b2] in the parameter arena's own
 // order, added into the gradient arena by one flat reduce.
-#include "common.h"
+#include "wgrad_group.h"      // grad_commit8 / SCOT_GRAD_*: how a weight gradient meets the arena
 #include <stdlib.h>
 
 typedef unsigned int u32x4_t __attribute__((ext_vector_type(4)));
@@ -200,9 +200,12 @@ __global__ __launch_bounds__(256, 2) void wgrad_mlp_kernel(WgradMlpArgs p) {
   if (chunk == 0 && tid < C) pl[ob2 + tid] = sdz;
 }
 
-// grad[i] += Σ_z ws[z·plane + i]   (i < plane, plane % 8 == 0; ZL lanes share the slices of one 8-float group)
+// grad[i] += Σ_z ws[z·plane + i]   (i < plane, plane % 8 == 0; ZL lanes share the slices of one 8-float group).  The two weight matrices
+// ([0, wlen) and [w2beg, w2beg + wlen) of the plane) meet the arena according to `mode` / `scale` (WgradProblem::mode); the two bias
+// vectors between and behind them are always plain accumulations (they belong to the zero-filled part of the gradient arena).
 template <int ZL>
-__global__ __launch_bounds__(256) void plane_reduce_kernel(const float* __restrict__ ws, float* __restrict__ grad, size_t plane, int nz) {
+__global__ __launch_bounds__(256) void plane_reduce_kernel(const float* __restrict__ ws, float* __restrict__ grad, size_t plane, int nz,
+                                                           size_t wlen, size_t w2beg, int mode, const float* scale) {
   const size_t n8 = plane / 8;
   const int zl = threadIdx.x % ZL;
   for (size_t i = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) / ZL; i < n8; i += (size_t)gridDim.x * blockDim.x / ZL) {
@@ -221,11 +224,9 @@ __global__ __launch_bounds__(256) void plane_reduce_kernel(const float* __restri
 #pragma unroll
       for (int j = 0; j < 8; ++j) acc[j] += __shfl_xor(acc[j], o, 64);
     if (zl == 0) {
-      float c[8];
-      ld8(grad, SCOT_F32, i * 8, c);
-#pragma unroll
-      for (int j = 0; j < 8; ++j) c[j] += acc[j];
-      st8(grad, SCOT_F32, i * 8, c);
+      const size_t e = i * 8;
+      const bool weight = e < wlen || (e >= w2beg && e < w2beg + wlen);
+      grad_commit8(grad, e, acc, weight ? mode : SCOT_GRAD_ADD, scale);
     }
   }
 }
@@ -259,8 +260,9 @@ extern "C" size_t scot_wgrad_mlp_workspace_bytes(int M, int C, int hid) {
 // dW1 / db1 / dW2 / db2 must be CONTIGUOUS in this order (they are in the gradient arena: intermediate.dense.weight, .bias,
 // output.dense.weight, .bias): the partial planes are laid out the same way and one flat pass adds them in.
 extern "C" int scot_wgrad_mlp(const void* h16, const void* dz, const void* W1, const float* b1, const void* W2T, float* dW1, float* db1,
-                              float* dW2, float* db2, int M, int C, int hid, void* workspace, size_t ws_bytes, hipStream_t stream) {
-  if (M <= 0) return SCOT_ERR_SHAPE;
+                              float* dW2, float* db2, int M, int C, int hid, void* workspace, size_t ws_bytes, int mode,
+                              const float* grad_scale, hipStream_t stream) {
+  if (M <= 0 || mode < 0 || mode > SCOT_GRAD_ADD_SCALED) return SCOT_ERR_SHAPE;
   if ((C != 96 && C != 192) || hid != 4 * C) return SCOT_ERR_UNSUPPORTED;
   if (!h16 || !dz || !W1 || !b1 || !W2T || !dW1 || !db1 || !dW2 || !db2 || !workspace) return SCOT_ERR_SHAPE;
   if (db1 != dW1 + (size_t)hid * C || dW2 != db1 + hid || db2 != dW2 + (size_t)C * hid) return SCOT_ERR_UNSUPPORTED;
@@ -282,8 +284,9 @@ extern "C" int scot_wgrad_mlp(const void* h16, const void* dz, const void* W1, c
   const int zl = a.nslice >= 32 ? 8 : a.nslice >= 4 ? 4 : 1;
   size_t blocks = (n8 * zl + 255) / 256; if (blocks > 2048) blocks = 2048;
   const dim3 gr((unsigned)blocks), b(256);
-  if (zl == 8) hipLaunchKernelGGL(plane_reduce_kernel<8>, gr, b, 0, stream, a.ws, dW1, a.plane, a.nslice);
-  else if (zl == 4) hipLaunchKernelGGL(plane_reduce_kernel<4>, gr, b, 0, stream, a.ws, dW1, a.plane, a.nslice);
-  else hipLaunchKernelGGL(plane_reduce_kernel<1>, gr, b, 0, stream, a.ws, dW1, a.plane, a.nslice);
+  const size_t wlen = (size_t)hid * C, w2beg = wlen + hid;
+  if (zl == 8) hipLaunchKernelGGL(plane_reduce_kernel<8>, gr, b, 0, stream, a.ws, dW1, a.plane, a.nslice, wlen, w2beg, mode, grad_scale);
+  else if (zl == 4) hipLaunchKernelGGL(plane_reduce_kernel<4>, gr, b, 0, stream, a.ws, dW1, a.plane, a.nslice, wlen, w2beg, mode, grad_scale);
+  else hipLaunchKernelGGL(plane_reduce_kernel<1>, gr, b, 0, stream, a.ws, dW1, a.plane, a.nslice, wlen, w2beg, mode, grad_scale);
   return scot_check_launch();
 }

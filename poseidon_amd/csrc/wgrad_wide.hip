@@ -170,12 +170,7 @@ __global__ __launch_bounds__(WM * WN * 64) void wgrad_wide_kernel(WgradGroupArgs
     if (part) {
       st8(part, SCOT_F32, (size_t)(m0 + row) * pr.N + n0 + cc * 8, v);
     } else {
-      const size_t ci = (size_t)(m0 + row) * pr.ldc + n0 + cc * 8;
-      float o[8];
-      ld8(pr.C, SCOT_F32, ci, o);
-#pragma unroll
-      for (int j = 0; j < 8; ++j) o[j] += v[j];
-      st8(pr.C, SCOT_F32, ci, o);
+      grad_commit8(pr.C, (size_t)(m0 + row) * pr.ldc + n0 + cc * 8, v, pr.mode, g.scale);
     }
   }
 }

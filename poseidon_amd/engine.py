@@ -165,6 +165,15 @@ class ScOTEngine:
         self.scale_state = torch.tensor([1.0, 1.0, 0.0, 0.0], dtype=torch.float32, device=self.device) if self.scale_grads else None
         self._scale_ready = False
         self.grads_are_zero = False   # set by ScOT.zero_grad / _prepare_grads: the arena needs no pre-scaling then
+        # Lazy zero-grad (16-bit modes): the Linear weights of the ScOTLayers — 95 % of the gradient bytes — are written by two kernel
+        # families only (scot_wgrad_group, scot_wgrad_mlp), which can STORE `acc / S` instead of adding into a zero-filled tensor: after
+        # ScOT.zero_grad(lazy=True) only the rest of the arena (`_small_chunks`) is cleared, the first backward's weight gradients are
+        # stores that also carry the fp16 un-scale, and the un-scale pass only visits the rest.  Per step of Poseidon-B that is 600 MB not
+        # filled, 600 MB of zeros not re-read, 1.2 GB not read + rewritten by the un-scale.  Later backwards of an accumulation window add
+        # `acc / S` (the tensors hold unscaled values).  autograd's accumulate-into-.grad semantics: reference trainer.py:605-635.
+        self.lazy_grads = False       # set by ScOT.zero_grad(lazy=True), cleared by the backward that consumed it
+        self._lazy_now = False        # ... as seen by the backward in flight (a recorded backward exists per value)
+        self._big_ptrs, self._small_chunks, self._small_by_key = set(), None, {}
         self.collect_attn, self.attn_sink = False, []   # output_attentions: one probability tensor per stage (encoder stages first)
         # ... and one global scale cannot also lift the gradients of a branch behind a ~1e-6 layer scale (2^-20 below the rest):
         # the ConvNeXt skip blocks run their backward under an extra, device-side power of two (convnext_bwd)
@@ -180,6 +189,8 @@ class ScOTEngine:
         self._shadow_v = self._shadow_t_v = object()
         self._copies_maintained = False      # True once an optimizer (FusedAdamW) writes the 16-bit copies itself
         self._build_cpb_plan()
+        if self.compute == ops.BF16 and arena.grad is not None and os.environ.get("SCOT_LAZY_GRADS", "1") == "1":
+            self._plan_grad_partition()
 
     def _build_cpb_plan(self):
         """All layers' continuous-position-bias MLPs run as ONE batched launch per step (forward) and one per stage
@@ -226,6 +237,88 @@ class ScOTEngine:
     def cpb_table(self, prefix, grad=False):
         off, heads, ts = self.cpb_slices[prefix]
         return (self.cpb_dtables if grad else self.cpb_tables)[off:off + heads * ts].view(heads, ts)
+
+    # ------------------------------------------------------------------------------------------ gradient arena: stored part / filled part
+    def _plan_grad_partition(self):
+        """`_big_ptrs`: addresses of the gradient tensors whose first writer stores (q/k/v as one [3C, C] span, attention.output.dense,
+        intermediate.dense, output.dense weights of every ScOTLayer); `_small_chunks`: the rest of the arena as (offset, count <= 4096)
+        pieces for scot_segments_scale."""
+        ar = self.arena
+        big = []
+        for blk in [b for st in self.enc for b in st.blocks] + [b for st in self.dec for b in st.blocks]:
+            pre, C = blk.prefix, blk.dim
+            hid = int(self.cfg.mlp_ratio * C)
+            for name, n in ((pre + ".attention.self.qkv_weight", 3 * C * C), (pre + ".attention.output.dense.weight", C * C),
+                            (pre + ".intermediate.dense.weight", hid * C), (pre + ".output.dense.weight", C * hid)):
+                o = ar.offsets[name]
+                if o % 64 or n % 64:
+                    continue
+                big.append((o, o + n))
+                self._big_ptrs.add(ar.grad.data_ptr() + 4 * o)
+        big.sort()
+        small, cur = [], 0
+        for lo, hi in big:
+            if lo > cur:
+                small.append((cur, lo))
+            cur = max(cur, hi)
+        if cur < ar.size:
+            small.append((cur, ar.size))
+        self._small_segs = small
+        self._small_chunks = self._chunk_tensor(small)
+
+    def _chunk_tensor(self, segs):
+        rows = []
+        for lo, hi in segs:
+            for o in range(lo, hi, 4096):
+                rows += [o, min(4096, hi - o)]
+        t = torch.tensor(rows, dtype=torch.int64).reshape(-1, 2).to(self.device) if rows else torch.zeros(0, 2, dtype=torch.int64, device=self.device)
+        return t, t.shape[0]
+
+    def small_chunks(self, key=None):
+        """(descriptor tensor, count) of the zero-filled / un-scaled part of the gradient arena, whole or inside one announced range"""
+        if key is None:
+            return self._small_chunks
+        c = self._small_by_key.get(key)
+        if c is None:
+            from .dp import group_ranges
+            segs = []
+            for _, lo, hi in group_ranges(self.arena, [key]):
+                segs += [(max(a, lo), min(b, hi)) for a, b in self._small_segs if max(a, lo) < min(b, hi)]
+            c = self._small_by_key[key] = self._chunk_tensor(segs)
+        return c
+
+    def fill_small_grads(self):
+        """zero the part of the gradient arena that is accumulated into (ScOT.zero_grad(lazy=True))"""
+        prev = ops.use(self.lib_kind)
+        try:
+            ops.segments_scale(self.arena.grad, self._small_chunks[0], self._small_chunks[1], None)
+        finally:
+            ops.use(prev)
+
+    def grad_mode(self, gw) -> int:
+        """how a weight gradient meets its tensor in the backward in flight (ops.GRAD_*)"""
+        if gw.data_ptr() not in self._big_ptrs:
+            return ops.GRAD_ADD
+        if self._lazy_now:
+            return ops.GRAD_STORE_SCALED
+        return ops.GRAD_ADD_SCALED if self.scale_grads else ops.GRAD_ADD
+
+    def grad_unscale(self):
+        return self.scale_state[1:2] if self.scale_grads else None
+
+    def scale_grad_range(self, factor_dev, key=None, count=False):
+        """the arena (or one announced range of it) to / from the gradient scale: only the part the scale is not folded into"""
+        ov = self.grad_overflow if count else None
+        if self._small_chunks is not None:
+            ch, n = self.small_chunks(key)
+            ops.segments_scale(self.arena.grad, ch, n, factor_dev, ov)
+            return
+        if key is None:
+            ops.scale_inplace_dev(self.arena.grad, factor_dev, ov)
+            return
+        from .dp import group_ranges
+        for _, lo, hi in group_ranges(self.arena, [key]):
+            ops.scale_inplace_dev(self.arena.grad[lo:hi], factor_dev, ov)
 
     def cpb_backward_range(self, blocks):
         """Bias-MLP backward of a stage's layers (reads the table gradients the attention backward accumulated, writes only
@@ -705,12 +798,31 @@ class ScOTEngine:
             for i in range(0, len(items), 8):
                 part = items[i:i + 8]
 
-                def run(cm=cm, part=part):
-                    if cm == ops.BF16 and len(part) > 1 and ops.wgrad_group(cm, [(dy, x, gw, db) for _, dy, x, gw, db in part]):
+                modes = [self.grad_mode(it[3]) for it in part]
+                special = any(m != ops.GRAD_ADD for m in modes)
+
+                def run(cm=cm, part=part, modes=modes, special=special):
+                    if cm == ops.BF16 and (len(part) > 1 or special) and \
+                            ops.wgrad_group(cm, [(dy, x, gw, db) for _, dy, x, gw, db in part], modes if special else None,
+                                            self.grad_unscale() if special else None):
                         return
-                    for _, dy, x, gw, db in part:
-                        ops.linear_wgrad(cm, dy, x, gw, dbias=db)
+                    for (_, dy, x, gw, db), m in zip(part, modes):
+                        self._wgrad_single(cm, dy, x, gw, db, m)
                 self.off_critical_path(run, *[t for it in part for t in (it[1], it[2])])
+
+    def _wgrad_single(self, cm, dy, x, gw, db, mode):
+        """one weight gradient through scot_gemm (shapes the grouped kernel does not cover), honouring `mode` with plain launches"""
+        if mode == ops.GRAD_ADD:
+            ops.linear_wgrad(cm, dy, x, gw, dbias=db)
+        elif mode == ops.GRAD_STORE_SCALED:
+            self.h_zero(gw)
+            ops.linear_wgrad(cm, dy, x, gw, dbias=db)
+            if self.scale_grads:
+                ops.scale_inplace_dev(gw.view(-1), self.grad_unscale())
+        else:       # += s · acc through a scratch tensor
+            tmp = self.zeros(*gw.shape)
+            ops.linear_wgrad(cm, dy, x, tmp, dbias=db)
+            ops.axpy_dev(gw.view(-1), tmp.view(-1), self.grad_unscale())
 
     def linear_bwd_params(self, wname, bname, dy, x, b_gelu=False):
         """dW += dy^T x and db += Σ dy in ONE wgrad launch (the bias sum rides on the dY tiles already in LDS)."""
@@ -994,8 +1106,12 @@ class ScOTEngine:
 
             self._finq += [(part2, nwg, ncol, first2), (part1, nwg, ncol, first1)]
 
+            mlp_mode = self.grad_mode(gW1)
+            assert mlp_mode == self.grad_mode(gW2)
+
             def side():
-                if not ops.wgrad_mlp(h16r, d_y2, self.W(w1n), b1, w2t, gW1, gb1, gW2, gb2):
+                if not ops.wgrad_mlp(h16r, d_y2, self.W(w1n), b1, w2t, gW1, gb1, gW2, gb2, mode=mlp_mode,
+                                     grad_scale=self.grad_unscale() if mlp_mode != ops.GRAD_ADD else None):
                     raise RuntimeError("scot_wgrad_mlp rejected a shape the engine selected it for")
             self.off_critical_path(side, h16r, d_y2)
             self.linear_bwd_params(pre + ".attention.output.dense.weight", pre + ".attention.output.dense.bias", d_proj, rec["attn_c"])
@@ -1279,6 +1395,7 @@ class ScOTEngine:
         finally:
             ops.use(prev)
             self.grads_are_zero = False
+            self.lazy_grads = False
 
     def _forward_step(self, pixel_values, time=None, labels=None, pixel_mask=None, train=True, stochastic=None):
         """→ (loss [1] or None, prediction [B,Cout,H,W], tape or None).  Inputs: fp32 contiguous CUDA tensors.
@@ -1363,7 +1480,7 @@ class ScOTEngine:
         return self.device.type == "cuda" and torch.cuda.is_current_stream_capturing()
 
     def _stream_id(self):
-        return torch.cuda.current_stream().cuda_stream if self.device.type == "cuda" else 0
+        return torch.cuda.current_stream(self.device).cuda_stream if self.device.type == "cuda" else 0
 
     def _replay(self, cmds, compiled=None):
         timer = self.launch_timer
@@ -1418,27 +1535,42 @@ class ScOTEngine:
         if dpred is not None or self._capturing():   # not the recorded pattern: plain path, tape off
             ent["state"] = "off"
             return self._backward(tape, dloss, dpred)
-        if ent["state"] == "ready":
+        # one recorded backward per way the weight gradients meet the arena (first writers store after a lazy zero_grad, add otherwise:
+        # the mode is an argument of the recorded launches)
+        variant = bool(self.lazy_grads and self._small_chunks is not None)
+        have = ent.setdefault("bwd", {}).get(variant)
+        if ent["state"] == "ready" and have is not None:
             if dloss is None:
                 ent["dloss"].fill_(1.0)
             else:
                 ent["dloss"].copy_(dloss.reshape(1))
-            self._replay(ent["bwd"], ent.get("bwd_c"))
+            self._lazy_now = variant
+            self._replay(*have)
             return
-        ent["dloss"] = torch.ones(1, device=self.device) if dloss is None else dloss.reshape(1).to(torch.float32).clone()
+        if ent["state"] not in ("fwd", "ready"):
+            return self._backward(tape, dloss, dpred)
+        if "dloss" not in ent:
+            ent["dloss"] = torch.ones(1, device=self.device) if dloss is None else dloss.reshape(1).to(torch.float32).clone()
+        elif dloss is None:
+            ent["dloss"].fill_(1.0)
+        else:
+            ent["dloss"].copy_(dloss.reshape(1))
         self._rec, self._rec_keep = [], ent["keep"]
         prev = ops.set_recorder(self._rec)
         try:
             self._backward(tape, ent["dloss"], None)
         except BaseException:
-            ent["state"] = "broken"           # never replayed; the signature falls back to direct launches
+            # never replayed: the signature is recorded afresh by its next steps (a failed forward recording already did that)
+            self._taped = {k: v for k, v in self._taped.items() if v is not ent}
+            ent["state"] = "off"
+            import warnings
+            warnings.warn("scOT engine: recording the backward of a step failed; the step tape of this input signature was dropped")
             raise
         finally:
             ops.set_recorder(prev)
             rec = self._rec
             self._rec = self._rec_keep = None
-        ent["bwd"] = rec
-        ent["bwd_c"] = ops.compile_tape(rec) if self.tape_c else None
+        ent["bwd"][variant] = (rec, ops.compile_tape(rec) if self.tape_c else None)
         ent["state"] = "ready"
 
     def reset_tapes(self):
@@ -1629,6 +1761,7 @@ class ScOTEngine:
         cfg, cm, adt = self.cfg, self.compute, self.adt
         B, time = tape["B"], tape["time"]
         hd = tape["head"]
+        self._lazy_now = bool(self.lazy_grads and self._small_chunks is not None)
         def fill_done():        # ScOT.zero_grad(overlap=True): the arena's fill runs on the side stream beside the forward
             ev, self.grad_fill_event = self.grad_fill_event, None
             if ev is not None:
@@ -1649,7 +1782,7 @@ class ScOTEngine:
 
             def prescale():
                 if not self.grads_are_zero:
-                    ops.scale_inplace_dev(self.arena.grad, S_dev)
+                    self.scale_grad_range(S_dev)
             self.tdo_dynamic(prescale)
             if dpred is not None:
                 dpred = self.clone(dpred.contiguous())
@@ -1700,8 +1833,7 @@ class ScOTEngine:
                 if not self.use_side:
                     self.flush_side()  # (no side stream: the range's queued weight gradients run here, in line)
                     if scaled:         # back at scale 1 before the range goes on the wire
-                        for _, lo, hi in group_ranges(self.arena, [prefix]):
-                            ops.scale_inplace_dev(self.arena.grad[lo:hi], Sinv_dev, self.grad_overflow)
+                        self.scale_grad_range(Sinv_dev, prefix, count=True)
                     # (the callback launches through ops — pack / collective / unpack: with the recorder left on, those launches would
                     # be logged IN ADDITION to the callback itself and a replayed step would run them twice)
                     self.tdo_dynamic(lambda: _cb(prefix))
@@ -1710,9 +1842,7 @@ class ScOTEngine:
                 # main-stream gradient kernel): the range's queued weight gradients, its un-scale, then the announcement
                 self.flush_side()
                 if scaled:
-                    for _, lo, hi in group_ranges(self.arena, [prefix]):
-                        seg = self.arena.grad[lo:hi]
-                        self.off_critical_path(lambda seg=seg: ops.scale_inplace_dev(seg, Sinv_dev, self.grad_overflow))
+                    self.off_critical_path(lambda: self.scale_grad_range(Sinv_dev, prefix, count=True))
                 self.off_critical_path(lambda: self.tdo_dynamic(lambda: announce(prefix)))
                 self.flush_side()
         elif scaled and self.use_side:
@@ -1722,9 +1852,7 @@ class ScOTEngine:
                 # fp16 build: bring each range back from the gradient scale as soon as the backward has finished writing it, on
                 # the side stream behind the range's weight gradients (one 0.24 ms pass at the very end of the step before)
                 self.flush_side()          # the range's queued weight gradients go first
-                for _, lo, hi in group_ranges(self.arena, [prefix]):
-                    seg = self.arena.grad[lo:hi]
-                    self.off_critical_path(lambda seg=seg: ops.scale_inplace_dev(seg, Sinv_dev, self.grad_overflow))
+                self.off_critical_path(lambda: self.scale_grad_range(Sinv_dev, prefix, count=True))
                 self.flush_side()
         else:
             def done(prefix):
@@ -1825,7 +1953,7 @@ class ScOTEngine:
                    dbias=self.G("embeddings.patch_embeddings.projection.bias"))
         if scaled and self.on_grads_final is None and not self.use_side:
             self.join_side()
-            ops.scale_inplace_dev(self.arena.grad, Sinv_dev, self.grad_overflow)
+            self.scale_grad_range(Sinv_dev, count=True)
         self.mark("end")
         done("embeddings.")
         self.join_side()

@@ -28,7 +28,8 @@ PROTOTYPES = {
     "scot_set_use_tr": [I],
     "scot_get_use_tr": [],
     "scot_gemm": [I, I, I, I, I, P, I, I, I, P, I, I, I, P, I, I, P, P, P, I, I, P, I, I, I, P, P, Z, I, P, P],
-    "scot_wgrad_group": [I, I, I, P, P, P, P, P, P, P, Z, P],
+    "scot_wgrad_group": [I, I, I, P, P, P, P, P, P, P, Z, P, P, P],
+    "scot_segments_scale": [P, P, I, P, P, P],
     "scot_gemm_workspace_bytes": [I, I, I, I, I],
     "scot_gemm_wide_config": [I, I],
     "scot_gemm_splitk_config": [I, I],
@@ -50,7 +51,7 @@ PROTOTYPES = {
     "scot_partial_colsum": [P, I, I, P, P],
     "scot_partial_colsum_batch": [I, P, P, P, P, P],
     "scot_wgrad_mlp_workspace_bytes": [I, I, I],
-    "scot_wgrad_mlp": [P, P, P, P, P, P, P, P, P, I, I, I, P, Z, P],
+    "scot_wgrad_mlp": [P, P, P, P, P, P, P, P, P, I, I, I, P, Z, I, P, P],
     "scot_transpose_cast": [P, P, P, I, I, P],
     "scot_block_tail_fwd": [P] * 33 + [I, P, I, I, I, I, F, P],
     "scot_memset_async": [P, I, Z, P],

@@ -199,9 +199,13 @@ def linear_wgrad(compute, dy, x, dw, b_gelu=False, dbias=None):
     gemm(TN, compute, N, K, M, dy, N, x, K, dw, K, b_gelu=b_gelu, accumulate=True, colsum_out=dbias)
 
 
-def wgrad_group(compute, problems) -> bool:
+GRAD_ADD, GRAD_STORE_SCALED, GRAD_ADD_SCALED = 0, 1, 2      # how a weight gradient meets the arena (include/scot_hip.h, scot_wgrad_group)
+
+
+def wgrad_group(compute, problems, modes=None, grad_scale=None) -> bool:
     """The weight gradients of one ScOTLayer in ONE launch (+ one grouped split-K reduce): problems = [(dy, x, dw, dbias)], every
     dy [K, M_i] / x [K, N_i] in the 16-bit operand format over the SAME K rows, dw [M_i, N_i] fp32 (+=), dbias [M_i] or None.
+    modes (one GRAD_* per problem, default all GRAD_ADD) / grad_scale (1-element fp32 device tensor): see the header.
     False = not covered (the caller launches them one by one)."""
     import ctypes
     n = len(problems)
@@ -214,7 +218,8 @@ def wgrad_group(compute, problems) -> bool:
         if dt(dy) != BF16 or dt(x) != BF16 or dw.dtype != torch.float32 or dy.numel() // dy.shape[-1] != K or x.numel() // x.shape[-1] != K:
             return False
     ws = workspace(int(_raw().scot_wgrad_group_workspace_bytes(n, K, Ms, Ns)))
-    rc = L().scot_wgrad_group(compute, n, K, dys, xs, dws, dbs, Ms, Ns, ws.data_ptr(), ws.numel(), stream())
+    md = IA(*[int(m) for m in modes]) if modes is not None else None
+    rc = L().scot_wgrad_group(compute, n, K, dys, xs, dws, dbs, Ms, Ns, ws.data_ptr(), ws.numel(), md, ptr(grad_scale), stream())
     if rc == -3:
         return False
     _lib.check(rc, "scot_wgrad_group")
@@ -434,9 +439,10 @@ def partial_colsum_batch(items):
                                              VP(*[ptr(i[3]) for i in items]), stream()), "scot_partial_colsum_batch")
 
 
-def wgrad_mlp(h16, dz, w1, b1, w2t, dW1, db1, dW2, db2) -> bool:
+def wgrad_mlp(h16, dz, w1, b1, w2t, dW1, db1, dW2, db2, mode=0, grad_scale=None) -> bool:
     """fc1 / fc2 weight + bias gradients of a ScOTLayer's MLP with gelu(u), gelu'(u), du recomputed on the fly (csrc/wgrad_mlp.hip).
-    dW1 | db1 | dW2 | db2 contiguous (the gradient arena's layout).  False = not covered."""
+    dW1 | db1 | dW2 | db2 contiguous (the gradient arena's layout).  mode / grad_scale: how dW1 / dW2 meet the arena (GRAD_*).
+    False = not covered."""
     M, C = h16.numel() // h16.shape[-1], h16.shape[-1]
     hid = w1.shape[0]
     need = int(_raw().scot_wgrad_mlp_workspace_bytes(M, C, hid))
@@ -444,7 +450,7 @@ def wgrad_mlp(h16, dz, w1, b1, w2t, dW1, db1, dW2, db2) -> bool:
         return False
     ws = workspace(need)
     rc = L().scot_wgrad_mlp(ptr(h16), ptr(dz), ptr(w1), ptr(b1), ptr(w2t), ptr(dW1), ptr(db1), ptr(dW2), ptr(db2), M, C, hid,
-                            ws.data_ptr(), ws.numel(), stream())
+                            ws.data_ptr(), ws.numel(), int(mode), ptr(grad_scale), stream())
     if rc == -3:
         return False
     _lib.check(rc, "scot_wgrad_mlp")
@@ -604,6 +610,13 @@ def dp_unpack(wire, dst, scale: float = 1.0):
 def scale_inplace(x, scale: float, nonfinite=None):
     """x (flat fp32, 16-byte aligned) *= scale; nonfinite (int32[1], optional) counts waves that saw Inf/NaN."""
     _lib.check(L().scot_scale_inplace(ptr(x), x.numel(), float(scale), ptr(nonfinite), stream()), "scot_scale_inplace")
+
+
+def segments_scale(x, chunks, nchunks: int, scale_dev=None, nonfinite=None):
+    """the pieces `chunks` (int64 [nchunks, 2] on the device: offset, count in floats) of the flat fp32 tensor x are multiplied by
+    scale_dev[0], or zeroed when scale_dev is None — one launch (scot_segments_scale)"""
+    if nchunks:
+        _lib.check(L().scot_segments_scale(ptr(x), ptr(chunks), int(nchunks), ptr(scale_dev), ptr(nonfinite), stream()), "scot_segments_scale")
 
 
 def scale_inplace_dev(x, scale_dev, nonfinite=None):

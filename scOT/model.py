@@ -339,15 +339,14 @@ class ScOT(nn.Module):
 
     # ------------------------------------------------------------------------------------------ arena management
     def _ensure_arena(self, device):
-        params = list(self.named_parameters())
         ar = self._arena
-        ok = ar is not None and ar.data.device == device
-        if ok:
-            n0, p0 = params[0]
-            n1, p1 = params[-1]
-            ok = p0.data_ptr() == ar.view(n0).data_ptr() and p1.data_ptr() == ar.view(n1).data_ptr()
-        if ok:
-            return
+        if ar is not None and ar.data.device == device:
+            # the parameters still are views of the arena (first and last one checked; `_params` is the list the arena was built from: walking
+            # the module tree with named_parameters() on EVERY forward cost 4 ms of host time per step of Poseidon-B)
+            ps, gv = self._params, self._pviews
+            if ps[0].data_ptr() == gv[0] and ps[-1].data_ptr() == gv[1]:
+                return
+        params = list(self.named_parameters())
         ar = Arena(self._shapes, device)
         with torch.no_grad():
             for n, p in params:
@@ -360,6 +359,7 @@ class ScOT(nn.Module):
         self._engine.weights_version = self._weights_version
         self._anchor = torch.zeros(1, device=device, requires_grad=True)
         self._params = [p for _, p in params]
+        self._pviews = (ar.view(params[0][0]).data_ptr(), ar.view(params[-1][0]).data_ptr())
         self._gviews = [ar.gview(n) for n, _ in params]
 
     def _weights_version(self):
@@ -390,6 +390,7 @@ class ScOT(nn.Module):
         if ps[first].grad is None or ps[first].grad.data_ptr() != self._gviews[first].data_ptr():
             self._arena.grad.zero_()
             self._engine.grads_are_zero = True
+            self._engine.lazy_grads = False
             for p, g in zip(ps, self._gviews):
                 p.grad = g if p.requires_grad else None
 
@@ -401,25 +402,32 @@ class ScOT(nn.Module):
         """fn(model) is called right after the engine finished writing the gradient arena (used by the DP wrapper)."""
         self._grad_hooks.append(fn)
 
-    def zero_grad(self, set_to_none: bool = False, overlap: bool = False):
+    def zero_grad(self, set_to_none: bool = False, overlap: bool = False, lazy: Optional[bool] = None):
         """One fill of the gradient arena; `.grad` stay views of it.  overlap=True (the training loops of this library): the fill
         is queued on the engine's weight-gradient stream behind everything the current stream has been given so far, and the next
-        backward's first gradient writer waits for it — the next FORWARD does not (it never touches gradients), so the 631 MB fill of
-        Poseidon-B runs beside it instead of in front of it.  Code that reads `.grad` on the current stream between this call and
-        the next backward must use the default (ordered on the current stream)."""
+        backward's first gradient writer waits for it — the next FORWARD does not (it never touches gradients), so the fill
+        runs beside it instead of in front of it.  Code that reads `.grad` on the current stream between this call and
+        the next backward must use the default (ordered on the current stream).
+        lazy (default: = overlap; 16-bit compute modes): the Linear weights of the ScOTLayers — 95 % of the bytes — are NOT filled; the
+        next backward's weight-gradient kernels store into them instead of accumulating (engine.lazy_grads), so between this call and
+        that backward those `.grad` still hold the previous step's values: the contract of the overlapped form already (nobody may
+        read `.grad` in between), spelled out."""
         if self._arena is not None:
             eng = self._engine
+            lazy = bool(overlap if lazy is None else lazy) and eng is not None and eng._small_chunks is not None
+            fill = eng.fill_small_grads if lazy else self._arena.grad.zero_
             if overlap and eng is not None and eng.use_side and self._arena.grad.is_cuda:
                 cur, side = torch.cuda.current_stream(), eng.side_stream()
                 side.wait_stream(cur)
                 with torch.cuda.stream(side):
-                    self._arena.grad.zero_()
+                    fill()
                 ev = torch.cuda.Event()
                 ev.record(side)
                 eng.grad_fill_event = ev
             else:
-                self._arena.grad.zero_()
+                fill()
             self._engine.grads_are_zero = True
+            self._engine.lazy_grads = lazy
             if set_to_none:
                 for p in self._params:
                     p.grad = None

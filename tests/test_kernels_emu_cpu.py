@@ -178,6 +178,65 @@ def test_wgrad_group(emu, K, dims):
     assert not ops.wgrad_group(ops.F32, [(p[0].float(), p[1].float(), p[2], p[3]) for p in probs])
 
 
+@pytest.mark.parametrize("K,dims,forced", [(2048, [(96, 384), (384, 96), (96, 96), (288, 96)], None),      # 96x96 tiles, K slices + grouped reduce
+                                           (256, [(128, 512), (512, 128), (128, 128), (384, 128)], None),  # 64x64 tiles, unsplit (single owner)
+                                           (256, [(128, 256), (256, 128), (128, 128)], 1),                 # 128x128 tiles, unsplit
+                                           (256, [(128, 256), (256, 128), (128, 128)], 1 | (2 << 4)),      # 128x128 tiles, 2 K slices
+                                           (512, [(72, 40)], None)])                                       # one ragged problem
+def test_wgrad_group_store_and_scaled_modes(emu, K, dims, forced):
+    """scot_wgrad_group's `modes` (round 6, lazy zero-grad): 1 = the first writer STORES s·acc over whatever the tensor held (NaN here),
+    2 = adds s·acc to unscaled contents, 0 = the plain accumulation; bias gradients always accumulate unscaled.  Every kernel family that
+    finishes a grouped weight gradient: single-owner epilogue of the 64x64 / 128x128 tiles, the grouped split-K reduce."""
+    lib = emu
+    s = torch.tensor([0.125])
+    probs, refs, modes = [], [], []
+    for i, (M, N) in enumerate(dims):
+        dy, x = rnd(K, M, dtype=torch.bfloat16, seed=10 + i), rnd(K, N, dtype=torch.bfloat16, seed=20 + i)
+        mode = (ops.GRAD_STORE_SCALED, ops.GRAD_ADD_SCALED, ops.GRAD_ADD)[i % 3]
+        dw0 = rnd(M, N, seed=30 + i)
+        dw = torch.full((M, N), float("nan")) if mode == ops.GRAD_STORE_SCALED else dw0.clone()
+        db = rnd(M, seed=40 + i)
+        prod = dy.double().t() @ x.double()
+        refs.append(({ops.GRAD_STORE_SCALED: 0.125 * prod, ops.GRAD_ADD_SCALED: dw0.double() + 0.125 * prod, ops.GRAD_ADD: dw0.double() + prod}[mode],
+                     db.double() + dy.double().sum(0)))
+        probs.append((dy, x, dw, db))
+        modes.append(mode)
+    if forced is not None:
+        lib.scot_gemm_wide_config(2, forced)
+    try:
+        assert ops.wgrad_group(ops.BF16, probs, modes, s)
+    finally:
+        lib.scot_gemm_wide_config(1, 0)
+    for (dy, x, dw, db), (rw, rb) in zip(probs, refs):
+        assert rel(dw, rw) < 1e-5 and rel(db, rb) < 1e-4
+    # without a scale tensor the factor is 1
+    dy, x, _, _ = probs[0]
+    dw = torch.full((dims[0][0], dims[0][1]), float("nan"))
+    assert ops.wgrad_group(ops.BF16, [(dy, x, dw, None)], [ops.GRAD_STORE_SCALED], None)
+    assert rel(dw, dy.double().t() @ x.double()) < 1e-5
+
+
+def test_segments_scale_and_fill(emu):
+    """scot_segments_scale: a list of (offset, count) pieces of one flat tensor scaled by a device factor (non-finite results counted) or zeroed,
+    everything else untouched."""
+    x0 = rnd(3 * 4096 + 640)
+    segs = [(0, 64), (128, 4096), (4096 + 512, 1000 * 4), (3 * 4096 + 576, 64)]
+    chunks = torch.tensor([v for sg in segs for v in sg], dtype=torch.int64).reshape(-1, 2)
+    x, cnt = x0.clone(), torch.zeros(1, dtype=torch.int32)
+    ops.segments_scale(x, chunks, len(segs), torch.tensor([4.0]), cnt)
+    ref = x0.clone()
+    for o, n in segs:
+        ref[o:o + n] *= 4.0
+    assert torch.equal(x, ref) and int(cnt) == 0
+    x[130] = float("inf")
+    ops.segments_scale(x, chunks, len(segs), torch.tensor([0.25]), cnt)
+    assert int(cnt) == 1
+    ops.segments_scale(x, chunks, len(segs), None)
+    for o, n in segs:
+        ref[o:o + n] = 0.0
+    assert torch.equal(x, ref)
+
+
 @pytest.mark.parametrize("forced", [0, 1, 2, 1 | (2 << 4), 2 | (3 << 4)])
 def test_wgrad_group_wide_tiles(emu, forced):
     """csrc/wgrad_wide.hip: the grouped weight gradients on 128 x 128 tiles — K-strided operands in swizzled [64 tokens][128] LDS tiles read with

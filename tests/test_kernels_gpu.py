@@ -995,6 +995,96 @@ def test_wgrad_group_wide_tiles(kind, K, C, forced):
         ops.use(prev)
 
 
+@pytest.mark.parametrize("kind", ["f16", "bf16"])
+@pytest.mark.parametrize("K,C,forced", [(65536, 96, -1), (16384, 192, -1), (4096, 384, -1), (1024, 768, -1), (4096, 384, 1 | (4 << 4)), (2008, 96, -1)])
+def test_wgrad_group_store_and_scaled_modes(kind, K, C, forced):
+    """Round 6 (lazy zero-grad): scot_wgrad_group's `modes` at every Poseidon-B stage shape — 1 = the first writer stores s·acc over a tensor
+    full of NaN, 2 = adds s·acc to unscaled contents, 0 = plain accumulation — through every kernel that finishes a grouped weight gradient
+    (64 x 64 / 96 x 96 tiles with the grouped split-K reduce, the unsplit single-owner epilogues of the 64 x 64 and 128 x 128 tiles, the
+    K-sliced 128 x 128 form); bias gradients always accumulate unscaled.  Reference: fp64 on the operands as stored."""
+    prev = ops.use(kind)
+    lib = ops.L()
+    try:
+        hd = ops.half_dtype()
+        dims = [(C, 4 * C), (4 * C, C), (C, C), (3 * C, C)]
+        modes = [ops.GRAD_STORE_SCALED, ops.GRAD_ADD_SCALED, ops.GRAD_ADD, ops.GRAD_STORE_SCALED]
+        s = torch.tensor([2.0 ** -7], device=DEV)
+        dys = [rnd(K, m, dtype=hd, scale=0.5, seed=10 + i) for i, (m, _) in enumerate(dims)]
+        xs = [rnd(K, n, dtype=hd, seed=20 + i) for i, (_, n) in enumerate(dims)]
+        dws0 = [rnd(m, n, seed=30 + i) for i, (m, n) in enumerate(dims)]
+        dbs0 = [rnd(m, seed=40 + i) for i, (m, _) in enumerate(dims)]
+        dws = [torch.full_like(t, float("nan")) if md == ops.GRAD_STORE_SCALED else t.clone() for t, md in zip(dws0, modes)]
+        dbs = [t.clone() for t in dbs0]
+        if forced >= 0:
+            lib.scot_gemm_wide_config(2, forced)
+        assert ops.wgrad_group(ops.BF16, [(dy, x, dw, db) for dy, x, dw, db in zip(dys, xs, dws, dbs)], modes, s)
+        torch.cuda.synchronize()
+        for dy, x, dw0, dw, db0, db, md in zip(dys, xs, dws0, dws, dbs0, dbs, modes):
+            prod = dy.double().t() @ x.double()
+            ref = {ops.GRAD_STORE_SCALED: prod * 2.0 ** -7, ops.GRAD_ADD_SCALED: dw0.double() + prod * 2.0 ** -7, ops.GRAD_ADD: dw0.double() + prod}[md]
+            assert bool(torch.isfinite(dw).all()) and rel(dw, ref) < 1e-6, (K, C, md)
+            assert rel(db.double() - db0.double(), dy.double().sum(0)) < 2e-6
+    finally:
+        lib.scot_gemm_wide_config(1, 0)
+        ops.use(prev)
+
+
+def test_segments_scale_and_fill():
+    """scot_segments_scale: pieces (offset, count <= 4096) of one flat tensor scaled by a device factor — non-finite results counted — or zeroed
+    (scale NULL); everything between the pieces untouched."""
+    n = 5_000_000
+    x0 = rnd(n)
+    g = torch.Generator().manual_seed(5)
+    segs, o = [], 0
+    while o + 8192 < n:
+        c = int(torch.randint(1, 1025, (1,), generator=g)) * 4
+        segs.append((o, c))
+        o += c + int(torch.randint(0, 4096, (1,), generator=g)) * 4
+    chunks = torch.tensor([v for sg in segs for v in sg], dtype=torch.int64, device=DEV).reshape(-1, 2)
+    mask = torch.zeros(n, dtype=torch.bool, device=DEV)
+    for o, c in segs:
+        mask[o:o + c] = True
+    x, cnt = x0.clone(), torch.zeros(1, dtype=torch.int32, device=DEV)
+    ops.segments_scale(x, chunks, len(segs), torch.tensor([0.5], device=DEV), cnt)
+    assert torch.equal(x, torch.where(mask, x0 * 0.5, x0)) and int(cnt) == 0
+    x[segs[3][0] + 1] = float("inf")
+    ops.segments_scale(x, chunks, len(segs), torch.tensor([2.0], device=DEV), cnt)
+    assert int(cnt) == 1
+    ops.segments_scale(x, chunks, len(segs), None)
+    assert torch.equal(x, torch.where(mask, torch.zeros_like(x0), x0))
+
+
+@pytest.mark.parametrize("kind", ["f16", "bf16"])
+@pytest.mark.parametrize("M,N,K,S", [(1024, 768, 3072, 2), (1024, 768, 2304, 3), (4096, 384, 1536, 4), (1000, 200, 1088, 2)])
+def test_gemm_nt_split_k_atomic(kind, M, N, K, S):
+    """csrc/gemm_fast.hip, K slices of the fp32-result NT products adding into the result with fp32 atomics (scot_gemm_splitk_config; the
+    library's policy never selects it — profiles/round6/splitk_*): the zeroed forward form and the accumulating data-gradient form against fp64
+    and against the unsplit kernel."""
+    prev = ops.use(kind)
+    lib = ops.L()
+    try:
+        hd = ops.half_dtype()
+        x, w, b = rnd(M, K, dtype=hd), rnd(N, K, dtype=hd, scale=K ** -0.5, seed=1), rnd(N, seed=2)
+        u = x.double() @ w.double().t() + b.double()
+        lib.scot_gemm_wide_config(0, 0)
+        lib.scot_gemm_splitk_config(-1, 0)
+        y0 = torch.empty(M, N, device=DEV)
+        ops.linear_fwd(ops.BF16, x, w, y0, bias=b)
+        lib.scot_gemm_splitk_config(S, 1)
+        y = torch.full((M, N), float("nan"), device=DEV)
+        ops.linear_fwd(ops.BF16, x, w, y, bias=b)
+        g0 = rnd(M, N, seed=5)
+        g = g0.clone()
+        ops.linear_dgrad(ops.BF16, x, w.t().contiguous(), g, accumulate=True, wt=w)
+        torch.cuda.synchronize()
+        assert rel(y, u) < 2e-6 and rel(y, y0) < 1e-6
+        assert rel(g, g0.double() + x.double() @ w.double().t()) < 1e-6
+    finally:
+        lib.scot_gemm_splitk_config(0, 1)
+        lib.scot_gemm_wide_config(1, 0)
+        ops.use(prev)
+
+
 # ----------------------------------------------------------------------------------------------- the layer tail without 4C-wide tensors in HBM
 @pytest.mark.parametrize("prologue", [False, True])
 @pytest.mark.parametrize("cond", [True, False])

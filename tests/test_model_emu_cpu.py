@@ -168,6 +168,91 @@ def test_engine_fp16_gradient_scale_accumulates(emu):
     assert int(eng.grad_overflow) == 0
 
 
+@pytest.mark.parametrize("compute", ["fp16", "bf16"])
+def test_engine_lazy_zero_grad_stores_first_writers(emu, compute):
+    """Round 6: after ScOT.zero_grad(lazy=True) the Linear weights of the ScOTLayers are NOT cleared (poisoned with NaN here): their first
+    writers in the next backward store acc / S, the rest of the arena was zero-filled and is un-scaled piecewise — the gradients equal
+    those of the eager form (full fill, accumulate, un-scale of the whole arena: SCOT_LAZY_GRADS=0 semantics reproduced by zero_grad()),
+    a second backward without zero_grad accumulates onto them (x 2), and no tensor outside the stored set is left unfilled.  C = 96 / 192 with
+    16x16 windows (lean tail: scot_wgrad_mlp + grouped gradients) and a ragged tiny model (grouped / single-problem launches)."""
+    from scOT.model import ScOT
+    cfgs = [ScOTConfig(image_size=64, patch_size=4, num_channels=4, num_out_channels=4, embed_dim=96, depths=[2, 1], num_heads=[3, 6],
+                       skip_connections=[1, 0], window_size=16, mlp_ratio=4.0, qkv_bias=True, drop_path_rate=0.0, hidden_act="gelu", p=1,
+                       channel_slice_list_normalized_loss=[0, 1, 3, 4], residual_model="convnext", use_conditioning=True, learn_residual=False),
+            ScOTConfig(**load_fixture("tiny_odd")[1]["cfg"])]
+    for cfg in cfgs:
+        sd = synth_state_dict(param_shapes(cfg), "trained")
+        if cfg.embed_dim == 96:
+            pv, t, lab = synth_inputs(2, cfg.num_channels, cfg.num_out_channels, cfg.image_size, "smooth")
+        else:
+            pv, t, lab, _ = fixture_inputs(load_fixture("tiny_odd")[1], cfg)
+        model = ScOT(cfg, compute=compute)
+        model.load_state_dict(sd)
+        model._ensure_arena(torch.device("cpu"))
+        eng, ar = model._engine, model._arena
+        assert eng._small_chunks is not None and eng._big_ptrs
+        covered = sum(n for _, n in eng._small_chunks[0].tolist())
+        assert 0 < covered < ar.size
+
+        def step():
+            _, _, tp = eng.forward(pv, t, lab, None, train=True)
+            model._prepare_grads()
+            eng.backward(tp, torch.ones(1), None)
+            return ar.grad.clone()
+        model.zero_grad()                       # eager: the whole arena filled
+        assert not eng.lazy_grads
+        g_eager = step()
+        assert torch.isfinite(g_eager).all()
+        small = torch.zeros(ar.size, dtype=torch.bool)
+        for o, n in eng._small_chunks[0].tolist():
+            small[o:o + n] = True
+        ar.grad[~small] = float("nan")          # what a lazy zero_grad leaves behind could be anything
+        ar.grad[small] = 123.0
+        model.zero_grad(lazy=True)
+        assert eng.lazy_grads and eng.grads_are_zero and float(ar.grad[small].abs().max()) == 0.0
+        g_lazy = step()
+        assert not eng.lazy_grads
+        assert torch.isfinite(g_lazy).all()
+        assert rel_l2(g_lazy.numpy(), g_eager.numpy()) < 1e-6, cfg.embed_dim
+        g2 = step()                             # accumulation window: no zero_grad in between
+        assert rel_l2(g2.numpy(), 2.0 * g_eager.numpy()) < 1e-6
+        assert eng.grad_overflow is None or int(eng.grad_overflow) == 0
+
+
+def test_engine_lazy_zero_grad_through_the_step_tape(emu, monkeypatch):
+    """the recorded step keeps one backward per way the weight gradients meet the arena: store (after a lazy zero_grad) and add (accumulation
+    window / eager zero_grad); replays of either equal the direct launches"""
+    monkeypatch.setenv("SCOT_TAPE", "1")
+    from scOT.model import ScOT
+    f, meta = load_fixture("tiny_trained")
+    cfg = ScOTConfig(**meta["cfg"])
+    pv, t, lab, pm = fixture_inputs(meta, cfg)
+    model = ScOT(cfg, compute="fp16")
+    model.load_state_dict(synth_state_dict(param_shapes(cfg), meta["regime"]))
+    model._ensure_arena(torch.device("cpu"))
+    eng, ar = model._engine, model._arena
+
+    def step(lazy, zero=True):
+        if zero:
+            model.zero_grad(lazy=lazy)
+            if lazy:
+                for p_ in eng._big_ptrs:
+                    o = (p_ - ar.grad.data_ptr()) // 4
+                    ar.grad[o:o + 64] = float("nan")
+        _, _, tp = eng.forward(pv, t, lab, pm, train=True)
+        model._prepare_grads()
+        eng.backward(tp, torch.ones(1), None)
+        return ar.grad.clone()
+    ref = step(False)                                         # call 1: direct launches
+    seq = [step(True), step(True), step(False), step(True), step(False)]      # call 2 records forward + the store backward; the add variant is recorded at its first use
+    for g in seq:
+        assert rel_l2(g.numpy(), ref.numpy()) < 1e-6
+    acc = step(False, zero=False)                             # accumulate onto the last result through the recorded `add` variant
+    assert rel_l2(acc.numpy(), 2.0 * ref.numpy()) < 1e-6
+    ent = list(eng._taped.values())[0]
+    assert ent["state"] == "ready" and set(ent["bwd"]) == {True, False}
+
+
 def test_engine_window16_fast_path(emu):
     """16x16 windows, head_dim 32 (the Poseidon-B attention shape), bf16x3: the W16 kernels inside the whole program."""
     f, meta = load_fixture("tiny_w16")

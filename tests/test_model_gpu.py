@@ -760,18 +760,34 @@ def test_short_training_run_fp16_tracks_fp32(regime_fixture, lr, tol):
 
 
 def test_streams_that_must_overlap_are_measured_to():
-    """poseidon_amd/streams.py: torch hands out 32 pooled streams round-robin and the ROCm runtime maps them onto GPU_MAX_HW_QUEUES hardware queues,
-    so in a long-lived process some pooled stream shares the main stream's queue and serialises with it (3 of 34 handles on this box).  The engine's
-    weight-gradient stream and the gradient exchange's comm stream are therefore chosen by measurement."""
+    """poseidon_amd/streams.py: the ROCm runtime maps a process's streams onto GPU_MAX_HW_QUEUES hardware queues round-robin, so every 7th
+    stream created shares the default stream's queue (with 8 queues) — and a pair that shares a queue serialises as soon as it exchanges
+    events, which the engine's fork / join pattern does ~130 times per step.  The weight-gradient stream and the gradient exchange's comm
+    stream are therefore chosen by MEASURING that pattern (round 6: three spin kernels across a fork / join take two kernel times, not
+    three), and a verified stream is shared by every engine of the process.  The census over 20 fresh streams must find both kinds on a box
+    with the default 8 queues; whatever it finds, the chosen streams must pass."""
+    from poseidon_amd import streams
     from poseidon_amd.streams import independent_stream, overlaps
     main = torch.cuda.current_stream()
     assert not overlaps(main, main)
-    pool = [torch.cuda.Stream() for _ in range(34)]
+    pool = [torch.cuda.Stream() for _ in range(20)]
     shared = [i for i, s in enumerate(pool) if not overlaps(main, s)]
-    print(f"\npooled streams sharing the main stream's hardware queue: {shared}")
+    print(f"\nfresh streams that serialise with the main stream under fork / join: {shared} of {len(pool)}")
+    assert len(shared) < len(pool)
     side = independent_stream(torch.device(DEV), [main])
     comm = independent_stream(torch.device(DEV), [main, side])
     assert overlaps(main, side) and overlaps(side, main) and overlaps(main, comm) and overlaps(side, comm) and overlaps(comm, side)
+    assert independent_stream(torch.device(DEV), [main]) is side            # measured once per process, then shared
+    # every engine of the process runs its weight gradients on that one stream
+    f, meta = load_fixture("tiny_trained")
+    engines = []
+    for _ in range(3):
+        cfg, model = build(meta, "fp32")
+        model(**inputs(cfg, meta)).loss.backward()
+        engines.append(model._engine)
+    torch.cuda.synchronize()
+    assert all(e.side is engines[0].side for e in engines) and overlaps(main, engines[0].side)
+    assert len(streams._cache) <= 4
 
 
 def test_overlapped_gradient_exchange_under_a_one_rank_rccl_group():
@@ -779,7 +795,7 @@ def test_overlapped_gradient_exchange_under_a_one_rank_rccl_group():
     1-rank `nccl` (= RCCL) process group, `OverlappedGradAllReducer` attached with the fp32 and then the bf16 wire, three steps each
     (direct, recorded, replayed).  The exchanged gradients must equal the bare run's (fp32 wire: a one-rank mean is the identity — up to the
     order in which the backward's float atomics commit, 5e-6 run to run; bf16 wire: to bfloat16 rounding), and the step must not fall off the hardware-queue cliff DESIGN §7 describes (an RCCL
-    communicator's streams sharing a queue with the engine's two: 27.1 vs 21.0 ms) — bound 10 % here, 1-2 % measured."""
+    communicator's streams sharing a queue with the engine's two: 27.1 vs 21.0 ms) — bound 25 % here, 1-5 % measured."""
     import socket
     import torch.distributed as dist
     from poseidon_amd.dp import OverlappedGradAllReducer
@@ -826,7 +842,9 @@ def test_overlapped_gradient_exchange_under_a_one_rank_rccl_group():
             print(f"\n[1-rank RCCL, {wire} wire] step {ms:.2f} ms (bare {bare_ms:.2f}); gradients vs bare run rel-L2 {d:.2e}; "
                   f"{red.bytes_on_wire / 1e6:.0f} MB handed to the collectives")
             assert torch.isfinite(g).all() and d <= tol
-            assert ms < 1.10 * bare_ms + 0.3
+            # (the hardware-queue cliff is 1.8x — 21.6 vs 11.4 ms when the side stream shared the default stream's queue, round 6; the bound
+            #  leaves room for a busy box: ADVICE r5)
+            assert ms < 1.25 * bare_ms + 0.5, (ms, bare_ms)
             red.detach()
     finally:
         dist.destroy_process_group()
@@ -986,6 +1004,49 @@ def test_overlapped_gradient_fill_is_ordered_before_the_backward():
     assert bool(torch.isfinite(grads[True]).all())
     d = float((grads[True] - grads[False]).norm() / grads[False].norm())      # (not bit-equal: float atomics commit in any order)
     assert d < 5e-6, d
+
+
+@pytest.mark.parametrize("tag,size,channels,batch", [("B", 128, 4, 8), ("T", 128, 4, 4)])
+@pytest.mark.parametrize("compute", ["fp16", "bf16"])
+def test_lazy_zero_grad_equals_the_eager_fill(tag, size, channels, batch, compute):
+    """Round 6: ScOT.zero_grad(overlap=True) fills only the part of the gradient arena that is accumulated into; the Linear weights of the
+    ScOTLayers (95 % of the bytes) are STORED by the next backward's weight-gradient kernels, fp16 un-scale included.  Starting from NaN in
+    the unfilled part every time: direct launches, the recorded step and its replays give the gradients of the eager form (whole arena
+    filled, accumulated into, un-scaled); a second backward without zero_grad accumulates (the recorded `add` variant); every tensor is
+    finite, i.e. nothing in the stored set was left without its first writer."""
+    cfg, sd, model = _preset_model(tag, size, channels, compute)
+    pv, t, lab = synth_inputs(batch, channels, channels, size, "smooth")
+    kw = dict(pixel_values=pv.to(DEV), time=t.to(DEV), labels=lab.to(DEV))
+    model(**kw).loss.backward()
+    eng, ar = model._engine, model._arena
+    assert eng._small_chunks is not None
+    small = torch.zeros(ar.size, dtype=torch.bool, device=DEV)
+    for o, n in eng._small_chunks[0].tolist():
+        small[o:o + n] = True
+    frac = float(small.float().mean())
+    assert frac < 0.12, frac                      # > 88 % of the arena is never filled (Poseidon-B: 95 %)
+    model.zero_grad()
+    model(**kw).loss.backward()
+    torch.cuda.synchronize()
+    ref = ar.grad.clone()
+    assert bool(torch.isfinite(ref).all())
+    for step in range(4):                          # direct / recorded / replayed / replayed
+        ar.grad[~small] = float("nan")
+        ar.grad[small] = 3.0
+        model.zero_grad(overlap=True)
+        assert eng.lazy_grads
+        model(**kw).loss.backward()
+        torch.cuda.synchronize()
+        assert bool(torch.isfinite(ar.grad).all()), step
+        d = float((ar.grad - ref).norm() / ref.norm())
+        assert d < 5e-6, (step, d)                 # (float atomics of the accumulated part commit in any order)
+    model(**kw).loss.backward()                    # accumulation window: no zero_grad
+    torch.cuda.synchronize()
+    d = float((ar.grad - 2 * ref).norm() / (2 * ref).norm())
+    assert d < 5e-6, d
+    assert eng.grad_overflow is None or int(eng.grad_overflow) == 0
+    ents = [e for e in eng._taped.values() if e.get("state") == "ready"]
+    assert ents and any(set(e["bwd"]) == {True, False} for e in ents)
 
 
 # ----------------------------------------------------------------------------------------------- the TIMED batch sizes

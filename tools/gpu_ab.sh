@@ -3,7 +3,7 @@ set -u
 out=gpurun_out/$1; shift; mkdir -p $out
 for kv in "$@"; do
   label=$(echo "$kv" | tr ' =/' '___')
-  env $kv timeout 200 python bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-parity 2>$out/err_$label.txt | tail -1 > $out/bench_$label.json
+  env $kv timeout 200 python bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-parity --no-other-configs 2>$out/err_$label.txt | tail -1 > $out/bench_$label.json
   python - <<PY | tee -a $out/summary.txt
 import json
 try:
