@@ -38,8 +38,8 @@ int scot_scale_inplace(float* x, size_t n, float scale, int* nonfinite, scot_str
 /* The same with the factor read from the device (x *= *scale_dev): the fp16 build's DYNAMIC gradient scale — a recorded step holds
  * the address, scot_optim_finish changes the value between steps. */
 int scot_scale_inplace_dev(float* x, size_t n, const float* scale_dev, int* nonfinite, scot_stream_t stream);
-/* The same on a LIST of pieces of x in one launch: chunks = nchunks pairs (offset, count) of int64 on the device, in floats, both
- * multiples of 4, count <= 4096.  scale_dev NULL: the pieces are zeroed instead.  This is how the part of the gradient arena that is
+/* The same on a LIST of pieces of x in one launch: chunks = nchunks pairs (offset, count) of int64 on the device, in floats, offset a
+ * multiple of 4, count <= 4096.  scale_dev NULL: the pieces are zeroed instead.  This is how the part of the gradient arena that is
  * NOT written by a storing first writer (biases, norm / bias-MLP / convolution parameters, trunk weights: ~5 % of Poseidon-B's bytes)
  * is cleared by zero_grad and brought back from the fp16 gradient scale after the backward; the Linear weights of the ScOTLayers
  * take the scale in the store of their weight-gradient kernels (scot_wgrad_group / scot_wgrad_mlp `mode`).  Reference semantics:

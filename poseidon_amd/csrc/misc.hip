@@ -1413,18 +1413,26 @@ extern "C" int scot_scale_inplace(float* x, size_t n, float scale, int* nonfinit
   hipLaunchKernelGGL(scale_inplace_kernel, dim3((unsigned)blocks), dim3(256), 0, s, x, n / 4, n, scale, nonfinite, (const float*)nullptr);
   return scot_check_launch();
 }
-// One workgroup per chunk (offset, count <= 4096 floats, both multiples of 4) of `x`: the chunks are zeroed (scale_dev == NULL) or
+// One workgroup per chunk (offset a multiple of 4 floats, count <= 4096) of `x`: the chunks are zeroed (scale_dev == NULL) or
 // multiplied by *scale_dev, counting non-finite results like scale_inplace_kernel.
 __global__ __launch_bounds__(256) void segments_scale_kernel(float* x, const long long* __restrict__ chunks, const float* scale_dev, int* nonfinite) {
   const long long off = chunks[2 * blockIdx.x], cnt = chunks[2 * blockIdx.x + 1];
   float4* p = (float4*)(x + off);
   const int n4 = (int)(cnt >> 2);
+  float* tail = x + off + 4 * (long long)n4;
+  const int nt = (int)(cnt & 3);
   if (!scale_dev) {
     for (int i = threadIdx.x; i < n4; i += 256) p[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+    if ((int)threadIdx.x < nt) tail[threadIdx.x] = 0.f;
     return;
   }
   const float s = *scale_dev;
   int bad = 0;
+  if ((int)threadIdx.x < nt) {
+    const float v = tail[threadIdx.x] * s;
+    bad |= !(fabsf(v) <= 3.4e38f);
+    tail[threadIdx.x] = v;
+  }
   for (int i = threadIdx.x; i < n4; i += 256) {
     float4 v = p[i];
     v.x *= s; v.y *= s; v.z *= s; v.w *= s;

@@ -38,15 +38,50 @@ def cpb_coords_table(ws: int) -> torch.Tensor:
     return tab.reshape(-1, 2).contiguous()
 
 
+# Policy switches of the engine.  Every entry's losing setting has a committed measurement (profiles/HISTORY.md, profiles/round2..6), so none of
+# them is an environment knob any more (round 6: 26 -> 5 `os.environ` reads in this file, one of them the generic SCOT_ENGINE_OPTIONS of the A/B scripts); tests and tools/ A/B scripts that still want the
+# other setting patch this dict (or pass `options=` to ScOTEngine) before the engine is built.
+ENGINE_OPTIONS = dict(
+    tape_c=True,              # recorded steps are replayed inside the library (scot_tape_replay), not by a Python loop over the calls
+    tape_inference=True,      # inference forwards are recorded / replayed too (rollouts: hundreds of forwards of one signature)
+    skip_side=True,           # ConvNeXt skip blocks on the second stream, beside the deep stages' chain
+    group_wgrads=True,        # a layer's weight gradients as one grouped launch
+    cln_partial=True,         # small-row-count norm backward through per-workgroup partial sums
+    lean_tail=True,           # fused layer tail without 4C-wide tensors in HBM (round 3: -0.25 ms)
+    recycle=True,             # rows that die inside a layer come from a pool (stores land on lines the previous layer left in L2 / MALL)
+    attn_x3=True,             # bf16x3 mode: split products inside the 16x16-window attention kernels too
+    trunk_bf16=False,         # patch embed / merge / unmerge / recovery on 16-bit operands (costs ~1e-3 of output error each)
+    trunk_x3=True,            # fp16 mode: the trunk on the split 16-bit MFMA (fp32 operands, 3 products)
+    fused_mlp=True,           # csrc/mlp_fused.hip at C = 96 / 192 (round 2: 23.7 vs 24.9 ms)
+    fused_tail=True,          # projection half + MLP half of a layer's tail in one launch per direction
+    fused_next_qkv=(96, 192),   # widths at which the forward tail also produces the next layer's q/k/v projection
+    fused_qkv_dgrad=(96,),      # widths at which the backward tail applies the previous layer's qkv data gradient as a prologue (192 spills)
+    dgrad_wt=True,            # transposed 16-bit weight copies: data gradients as NT products (stages 2/3: 1.7-2.2x)
+    grad_scale="auto",        # fp16 mode: initial power-of-two gradient scale ("auto" = from the loss normalisation; a number; "1" = off)
+    ls_rescale=True,          # fp16 mode: ConvNeXt skip branches run their backward under an extra power of two (layer scale ~1e-6)
+    lazy_grads=True,          # first writers of the ScOTLayers' weight gradients store (round 6: 18.58 -> 18.24 ms)
+    attn_rep=16,              # replicas of the attention backward's atomically accumulated table / logit-scale gradients
+)
+
+
 class _Token:
     """Lifetime marker of one taped forward call: alive while the caller (the autograd node) can still ask for its backward."""
     __slots__ = ("__weakref__",)
 
 
 class ScOTEngine:
-    def __init__(self, cfg, arena: Arena, compute: str = "fp16"):
+    def __init__(self, cfg, arena: Arena, compute: str = "fp16", options: Optional[dict] = None):
         if compute not in ("fp16", "bf16", "fp32", "bf16x3"):
             raise ValueError("compute must be 'fp16', 'bf16', 'fp32' or 'bf16x3'")
+        opt = dict(ENGINE_OPTIONS, **(options or {}))
+        for kv in filter(None, os.environ.get("SCOT_ENGINE_OPTIONS", "").split(",")):      # A/B runs only (tools/gpu_ab.sh): "lazy_grads=0,attn_rep=8"
+            k, _, v = kv.partition("=")
+            cur = ENGINE_OPTIONS.get(k.strip())
+            opt[k.strip()] = (v.strip() not in ("0", "false", "False")) if isinstance(cur, bool) else \
+                (int(v) if isinstance(cur, int) else (tuple(int(c) for c in v.split("+") if c) if isinstance(cur, tuple) else v.strip()))
+        if set(opt) != set(ENGINE_OPTIONS):
+            raise ValueError(f"unknown engine option(s): {sorted(set(opt) - set(ENGINE_OPTIONS))}")
+        self.options = opt
         # "fp16" and "bf16" run the SAME kernels from two builds of the library (csrc/common.h: the format of the 16-bit operand
         # type is a compile-time property); everything else about the two modes is identical except the backward's gradient scale
         self.lib_kind = "f16" if compute == "fp16" else "bf16"
@@ -61,10 +96,10 @@ class ScOTEngine:
         self.stochastic = False
         self.launch_timer = None    # bench.py: list that collects per-launch HIP-event timings of replayed steps
         self.tape_max = max(1, int(os.environ.get("SCOT_TAPE_MAX", "2")))
-        # ... and replayed from C: one scot_tape_replay call per run of launches instead of one ctypes call per launch (SCOT_TAPE_C=0: the
+        # ... and replayed from C: one scot_tape_replay call per run of launches instead of one ctypes call per launch (option tape_c=False: the
         # Python loop over the recorded calls)
-        self.tape_c = os.environ.get("SCOT_TAPE_C", "1") == "1" and __import__("platform").machine() in ("x86_64", "AMD64")     # (scot_tape_replay is System V x86-64 only)
-        self.tape_inference = os.environ.get("SCOT_TAPE_INFERENCE", "1") == "1"      # inference forwards are recorded / replayed too
+        self.tape_c = opt["tape_c"] and __import__("platform").machine() in ("x86_64", "AMD64")     # (scot_tape_replay is System V x86-64 only)
+        self.tape_inference = opt["tape_inference"]      # inference forwards are recorded / replayed too
         self._rec = None
         self._rec_keep = None
         self._taped = {}
@@ -76,20 +111,20 @@ class ScOTEngine:
         self._events = []                                               # events of the current step (a recorded step keeps its own alive)
         # ConvNeXt skip blocks off the critical path: a skip's blocks only feed the decoder stage that consumes the skip (forward)
         # / the encoder stage that produced it (backward), so they run on the side stream beside the deep stages' latency-bound
-        # chain instead of in front of it (SCOT_SKIP_SIDE=0: in line)
-        self.skip_side = os.environ.get("SCOT_SKIP_SIDE", "1") == "1"
-        self.group_wgrads = os.environ.get("SCOT_GROUP_WGRAD", "1") == "1"
+        # chain instead of in front of it (option skip_side=False: in line)
+        self.skip_side = opt["skip_side"]
+        self.group_wgrads = opt["group_wgrads"]
         self.grad_fill_event = None       # ScOT.zero_grad(overlap=True): recorded behind the gradient arena's fill on the side stream
-        self.cln_partial = os.environ.get("SCOT_CLN_PARTIAL", "1") == "1"     # small-row-count LN backward through partial sums (A/B switch)
+        self.cln_partial = opt["cln_partial"]     # small-row-count LN backward through partial sums
         # the fused layer tail WITHOUT 4C-wide tensors in HBM (round 3): the forward stores neither gelu(u) nor gelu'(u) and keeps the
         # pre-norm rows as 16-bit, the backward recomputes gelu'(u) and does not store du, scot_wgrad_mlp recomputes both for the
         # fc1 / fc2 weight gradients, the norms' parameter gradients go through per-workgroup partial rows instead of atomics
-        self.lean_tail = os.environ.get("SCOT_LEAN_TAIL", "1") == "1"
+        self.lean_tail = opt["lean_tail"]
         # Rows that are dead before a layer ends (the fp32 residual h between a layer's two halves) or once the NEXT layer has read them
         # (its fp32 output; in inference every intermediate) come from a small pool keyed by (tag, shape) instead of fresh memory: a
         # recorded step owns every buffer it allocated for good, so without the pool each layer's stores go to lines no cache has
         # seen — with it they land on lines the previous layer left in L2 / MALL.
-        self.recycle = os.environ.get("SCOT_RECYCLE", "1") == "1"
+        self.recycle = opt["recycle"]
         self.last_hidden, self.last_hidden_aliased = None, False
         self._pool: Dict[tuple, torch.Tensor] = {}
         # ... gelu'(u) itself IS stored (16-bit, 8·C bytes per token) and the backward tail loads it: recomputing it there (the C ABI's
@@ -99,21 +134,19 @@ class ScOTEngine:
         # bf16x3: activations and weights stay fp32 in HBM; the GEMMs split them into hi + lo bf16 while staging into LDS and
         # run three bf16 MFMAs per K-step (≈ fp32 accuracy at the bf16 MFMA rate); so do the 16x16-window attention kernels
         self.compute = {"fp16": ops.BF16, "bf16": ops.BF16, "fp32": ops.F32, "bf16x3": ops.X3}[compute]
-        # attention kernels' arithmetic: bf16x3 also splits inside the 16x16-window kernels (SCOT_ATTN_X3=0: exact fp32 MFMA)
-        self.acm = ops.BF16 if half else (ops.X3 if (compute == "bf16x3" and os.environ.get("SCOT_ATTN_X3", "1") == "1")
-                                                      else ops.F32)
+        # attention kernels' arithmetic: bf16x3 also splits inside the 16x16-window kernels (option attn_x3=False: exact fp32 MFMA)
+        self.acm = ops.BF16 if half else (ops.X3 if (compute == "bf16x3" and opt["attn_x3"]) else ops.F32)
         self.adt = ops.HALF[self.lib_kind] if half else torch.float32
         self.device = arena.data.device
         # The "trunk" (patch embed, merge, unmerge, recovery: < 2 % of the FLOPs) is the only path every output pixel's
         # signal must traverse; each bf16 GEMM on it adds ~1e-3 of relative error that nothing downstream averages out.
-        # It therefore always runs on the exact fp32 MFMA with fp32 operands (SCOT_TRUNK_BF16=1 restores bf16).
-        import os as _os
-        trunk32 = self.compute == ops.BF16 and _os.environ.get("SCOT_TRUNK_BF16", "0") != "1"
+        # It therefore always runs on the exact fp32 MFMA with fp32 operands (option trunk_bf16 restores 16-bit operands).
+        trunk32 = self.compute == ops.BF16 and not opt["trunk_bf16"]
         self.tcm = ops.F32 if (trunk32 or self.compute != ops.BF16) else ops.BF16
         # ... on the SPLIT 16-bit MFMA in the fp16 mode (fp32 operands, hi + lo bfloat16 halves, three MFMAs: 2^-17 operand error, 1/5 of
         # the exact fp32 MFMA's time; ops.gemm routes it to the bfloat16 build, whose halves keep fp32's range under the gradient scale).
-        # SCOT_TRUNK_X3=0: exact fp32 MFMA
-        if compute == "fp16" and self.tcm == ops.F32 and os.environ.get("SCOT_TRUNK_X3", "1") == "1":
+        # option trunk_x3=False: exact fp32 MFMA
+        if compute == "fp16" and self.tcm == ops.F32 and opt["trunk_x3"]:
             self.tcm = ops.X3
         # (tried in round 2: the trunk on the split 16-bit MFMA instead of the exact fp32 MFMA — 0.19 ms faster, same forward
         # parity, but the fp32 trunk gradients under the fp16 build's gradient scale exceed binary16's range in the split: NaN)
@@ -136,28 +169,27 @@ class ScOTEngine:
         self._keep = []
         # csrc/mlp_fused.hip (validated and measured on MI355X in round 2: 23.7 vs 24.9 ms/step): fc1 → GELU → fc2 → cond-LN →
         # residual in one launch (and its backward chain, and the projection + LN pair) for the C = 96 / 192 stages of the 16-bit
-        # modes; SCOT_FUSED_MLP=0 restores the layer-by-layer launches
-        self.fused_mlp = os.environ.get("SCOT_FUSED_MLP", "1") == "1" and half
-        self.fused_tail = os.environ.get("SCOT_FUSED_TAIL", "1") == "1"     # MLP-half + projection-half backward in one launch
-        widths = lambda name, default: {int(c) for c in os.environ.get(name, default).split(",") if c}
+        # modes; option fused_mlp=False restores the layer-by-layer launches
+        self.fused_mlp = opt["fused_mlp"] and half
+        self.fused_tail = opt["fused_tail"]     # MLP-half + projection-half backward in one launch
         # ... forward: the next layer's q/k/v projection as epilogue (channel widths).  Backward: the previous layer's qkv dgrad as
         # prologue — at C = 96 only: the C = 192 prologue variant spills and costs more than the GEMM it replaces (125 vs 87 + 20 us)
-        self.fused_next_qkv = widths("SCOT_FUSED_NEXT_QKV", "96,192")
-        self.fused_qkv_dgrad = widths("SCOT_FUSED_QKV_DGRAD", "96")
+        self.fused_next_qkv = set(opt["fused_next_qkv"])
+        self.fused_qkv_dgrad = set(opt["fused_qkv_dgrad"])
         # bf16 mode: GEMM operands must already be bf16 in HBM (gemm_fast streams raw 16-byte chunks into LDS), so the
         # weights get a bf16 shadow arena that is re-cast from the fp32 master at the start of EVERY forward (one pass,
         # inside the timed step), and every producer of a GEMM operand also writes a bf16 copy.
         self.shadow = torch.empty(arena.size, dtype=self.adt, device=self.device) if self.compute == ops.BF16 else None
         # ... and a second copy holding every weight MATRIX transposed (same offsets): the data gradients dX = dY · W then run as the
         # forward's NT product on W^T instead of the strided-operand NN product (stages 2/3: 1.7–2.2x slower for the same shape).
-        # Filled by one launch per training forward, on the side stream (scot_transpose_cast).  SCOT_DGRAD_WT=0: NN products.
+        # Filled by one launch per training forward, on the side stream (scot_transpose_cast).  option dgrad_wt=False: NN products.
         self.shadow_t, self._wt_names, self._wt_desc, self._wt_tiles = None, {}, None, 0
-        if self.shadow is not None and os.environ.get("SCOT_DGRAD_WT", "1") == "1":
+        if self.shadow is not None and opt["dgrad_wt"]:
             self._plan_transposed_weights()
         # fp16 operands have 5 exponent bits: the backward runs on gradients multiplied by a power of two chosen from the loss
         # normalisation (d loss / d prediction = O(1 / number of output elements); see _grad_scale) and the gradient arena is
         # divided by it afterwards (exact; scot_scale_inplace also counts non-finite values → `grad_overflow`).
-        self.scale_grads = compute == "fp16" and os.environ.get("SCOT_GRAD_SCALE", "auto") != "1"
+        self.scale_grads = compute == "fp16" and str(opt["grad_scale"]) != "1"
         self.grad_overflow = torch.zeros(1, dtype=torch.int32, device=self.device) if self.scale_grads else None
         # {S, 1/S, applied steps since S last changed}: ON THE DEVICE, so that a recorded step never bakes a value in and the optimizer
         # (scot_optim_finish: torch.cuda.amp.GradScaler's rule — halve after an overflowed step, double after N clean ones) can change
@@ -178,7 +210,7 @@ class ScOTEngine:
         # ... and one global scale cannot also lift the gradients of a branch behind a ~1e-6 layer scale (2^-20 below the rest):
         # the ConvNeXt skip blocks run their backward under an extra, device-side power of two (convnext_bwd)
         self._gredirect, self._ls = None, {}
-        if self.scale_grads and os.environ.get("SCOT_LS_RESCALE", "1") == "1":
+        if self.scale_grads and opt["ls_rescale"]:
             self._plan_layer_scale_rescale()
         self._wviews: Dict[str, torch.Tensor] = {}
         self._lean_cache: Dict[tuple, bool] = {}
@@ -189,7 +221,7 @@ class ScOTEngine:
         self._shadow_v = self._shadow_t_v = object()
         self._copies_maintained = False      # True once an optimizer (FusedAdamW) writes the 16-bit copies itself
         self._build_cpb_plan()
-        if self.compute == ops.BF16 and arena.grad is not None and os.environ.get("SCOT_LAZY_GRADS", "1") == "1":
+        if self.compute == ops.BF16 and arena.grad is not None and opt["lazy_grads"]:
             self._plan_grad_partition()
 
     def _build_cpb_plan(self):
@@ -224,7 +256,7 @@ class ScOTEngine:
         self.cpb_z = torch.empty(z_off, device=self.device)
         # the attention backward accumulates dtable / dlogit_scale with atomics: R replicas (window w -> replica w % R) keep the
         # same-address chains short; replica 0 of the tables is what the bias-MLP backward reads after the per-stage fold
-        self.attn_rep = R = max(1, int(os.environ.get("SCOT_ATTN_REP", "16")))
+        self.attn_rep = R = max(1, int(self.options["attn_rep"]))
         self.cpb_tab_total, self.cpb_ls_total = tab_off, sum(b.heads for b in blocks)
         self.cpb_dtables = torch.zeros(R * tab_off, device=self.device)
         self.cpb_dls = torch.zeros(R * self.cpb_ls_total, device=self.device) if R > 1 else None
@@ -283,6 +315,7 @@ class ScOTEngine:
             from .dp import group_ranges
             segs = []
             for _, lo, hi in group_ranges(self.arena, [key]):
+                hi = min(self.arena.size, (hi + 63) // 64 * 64)      # (a range ends with its last tensor's last element; the alignment gap behind it is nobody's)
                 segs += [(max(a, lo), min(b, hi)) for a, b in self._small_segs if max(a, lo) < min(b, hi)]
             c = self._small_by_key[key] = self._chunk_tensor(segs)
         return c
@@ -544,7 +577,7 @@ class ScOTEngine:
         the middle of binary16's 30 binades."""
         if not self.scale_grads:
             return 1.0
-        env = os.environ.get("SCOT_GRAD_SCALE", "auto")
+        env = str(self.options["grad_scale"])
         if env != "auto":
             return float(env)
         return float(2 ** max(0, int(math.floor(math.log2(max(1, n_out))))))

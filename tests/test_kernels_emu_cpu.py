@@ -220,7 +220,7 @@ def test_segments_scale_and_fill(emu):
     """scot_segments_scale: a list of (offset, count) pieces of one flat tensor scaled by a device factor (non-finite results counted) or zeroed,
     everything else untouched."""
     x0 = rnd(3 * 4096 + 640)
-    segs = [(0, 64), (128, 4096), (4096 + 512, 1000 * 4), (3 * 4096 + 576, 64)]
+    segs = [(0, 64), (128, 4096), (4096 + 512, 1000 * 4), (3 * 4096 + 576, 61)]      # (the last piece ends inside a 4-float group: a range's last tensor)
     chunks = torch.tensor([v for sg in segs for v in sg], dtype=torch.int64).reshape(-1, 2)
     x, cnt = x0.clone(), torch.zeros(1, dtype=torch.int32)
     ops.segments_scale(x, chunks, len(segs), torch.tensor([4.0]), cnt)

@@ -1037,9 +1037,9 @@ def test_segments_scale_and_fill():
     g = torch.Generator().manual_seed(5)
     segs, o = [], 0
     while o + 8192 < n:
-        c = int(torch.randint(1, 1025, (1,), generator=g)) * 4
+        c = int(torch.randint(1, 1025, (1,), generator=g)) * 4 - int(torch.randint(0, 4, (1,), generator=g))      # (counts need not be multiples of 4)
         segs.append((o, c))
-        o += c + int(torch.randint(0, 4096, (1,), generator=g)) * 4
+        o += (c + 3) // 4 * 4 + int(torch.randint(0, 4096, (1,), generator=g)) * 4
     chunks = torch.tensor([v for sg in segs for v in sg], dtype=torch.int64, device=DEV).reshape(-1, 2)
     mask = torch.zeros(n, dtype=torch.bool, device=DEV)
     for o, c in segs:

@@ -13,6 +13,7 @@ import torch
 HERE = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, os.path.join(HERE, "hipemu"))
 from conftest import load_fixture, rel_l2  # noqa: E402
+from poseidon_amd import engine as engine_mod  # noqa: E402
 from poseidon_amd.config import ScOTConfig  # noqa: E402
 from poseidon_amd.geometry import param_shapes  # noqa: E402
 from poseidon_amd.synth import apply_obstacle, synth_inputs, synth_obstacle_mask, synth_state_dict  # noqa: E402
@@ -139,7 +140,7 @@ def test_engine_fp16_layer_scale_branch_gradients(emu, monkeypatch):
     _, _, tp = eng.forward(pv, t, lab, pm, train=True)          # accumulate a second, identical backward: exactly 2x
     eng.backward(tp, torch.ones(1), None)
     assert rel_l2(model._arena.grad.numpy(), 2.0 * g1.numpy()) < 1e-6
-    monkeypatch.setenv("SCOT_LS_RESCALE", "0")                  # what the rescale is for: without it those gradients are lost
+    monkeypatch.setitem(engine_mod.ENGINE_OPTIONS, "ls_rescale", False)                  # what the rescale is for: without it those gradients are lost
     model0, _, _ = run_engine(cfg, sd, pv, t, lab, pm, "fp16")
     assert not model0._engine._ls and max(branch_errors(model0).values()) > 0.5
 
@@ -172,7 +173,7 @@ def test_engine_fp16_gradient_scale_accumulates(emu):
 def test_engine_lazy_zero_grad_stores_first_writers(emu, compute):
     """Round 6: after ScOT.zero_grad(lazy=True) the Linear weights of the ScOTLayers are NOT cleared (poisoned with NaN here): their first
     writers in the next backward store acc / S, the rest of the arena was zero-filled and is un-scaled piecewise — the gradients equal
-    those of the eager form (full fill, accumulate, un-scale of the whole arena: SCOT_LAZY_GRADS=0 semantics reproduced by zero_grad()),
+    those of the eager form (full fill, accumulate, un-scale of the whole arena: the `lazy_grads=False` engine option's semantics reproduced by zero_grad()),
     a second backward without zero_grad accumulates onto them (x 2), and no tensor outside the stored set is left unfilled.  C = 96 / 192 with
     16x16 windows (lean tail: scot_wgrad_mlp + grouped gradients) and a ragged tiny model (grouped / single-problem launches)."""
     from scOT.model import ScOT
@@ -264,7 +265,7 @@ def test_engine_window16_fast_path(emu):
 
 
 def test_engine_fused_block_kernels(emu, monkeypatch):
-    """SCOT_FUSED_MLP=1 (csrc/mlp_fused.hip; still off by default): a two-stage model with C = 96 / 192 so that all four fused
+    """engine option fused_mlp (csrc/mlp_fused.hip; the default since round 2): a two-stage model with C = 96 / 192 so that all four fused
     kernels run inside the engine's forward and backward — against the layer-by-layer path and against the oracle."""
     from oracle import scot_cpu
     cfg = ScOTConfig(image_size=64, patch_size=4, num_channels=4, num_out_channels=4, embed_dim=96, depths=[1, 1], num_heads=[3, 6],
@@ -275,7 +276,7 @@ def test_engine_fused_block_kernels(emu, monkeypatch):
     pv, t, lab = synth_inputs(2, 4, 4, 64, "smooth")
     res = {}
     for flag in ("0", "1"):
-        monkeypatch.setenv("SCOT_FUSED_MLP", flag)
+        monkeypatch.setitem(engine_mod.ENGINE_OPTIONS, "fused_mlp", flag == "1")
         model, loss, pred = run_engine(cfg, sd, pv, t, lab, None, "bf16")
         assert model._engine.fused_mlp == (flag == "1")
         res[flag] = (float(loss), pred.clone(), model._arena.grad.clone())
@@ -303,7 +304,7 @@ def test_engine_lean_layer_tail(emu, monkeypatch):
     pv, t, lab = synth_inputs(2, 4, 4, 64, "smooth")
     res = {}
     for flag in ("0", "1"):
-        monkeypatch.setenv("SCOT_LEAN_TAIL", flag)
+        monkeypatch.setitem(engine_mod.ENGINE_OPTIONS, "lean_tail", flag == "1")
         from scOT.model import ScOT
         model = ScOT(cfg, compute="fp16")
         model.load_state_dict(sd)
@@ -336,7 +337,7 @@ def test_engine_pooled_rows_change_nothing(emu, monkeypatch, compute):
     pv, t, lab = synth_inputs(2, 4, 4, 32, "smooth")
     res = {}
     for flag in ("0", "1"):
-        monkeypatch.setenv("SCOT_RECYCLE", flag)
+        monkeypatch.setitem(engine_mod.ENGINE_OPTIONS, "recycle", flag == "1")
         from scOT.model import ScOT
         model = ScOT(cfg, compute=compute)
         model.load_state_dict(sd)
@@ -357,7 +358,7 @@ def test_engine_pooled_rows_change_nothing(emu, monkeypatch, compute):
 def test_engine_poseidon_T_bf16(emu, monkeypatch, fused):
     """Poseidon-T, batch 2, 128x128 (BASELINE config 2's model) forward + backward in bf16 mode, with and without the fused block
     kernels, against the real reference's fixture.  Measured here: output rel-L2 6.7e-3 / 6.9e-3 — the MI355X gives 6.7e-3."""
-    monkeypatch.setenv("SCOT_FUSED_MLP", fused)
+    monkeypatch.setitem(engine_mod.ENGINE_OPTIONS, "fused_mlp", fused == "1")
     f, meta = load_fixture("poseidonT_trained")
     cfg = ScOTConfig(**meta["cfg"])
     pv, t, lab, pm = fixture_inputs(meta, cfg)

@@ -305,7 +305,7 @@ def test_step_tape_replay_matches_direct_launches(name):
             n = float(g1[k].norm())
             assert float((g0[k] - g1[k]).norm()) <= 2e-5 * n + 1e-9, (step, k)
     ent = [e for e in taped._engine._taped.values() if e["state"] == "ready"]
-    assert len(ent) == 1 and len(ent[0]["fwd"]) > 20 and len(ent[0]["bwd"]) > 20
+    assert len(ent) == 1 and len(ent[0]["fwd"]) > 20 and len(ent[0]["bwd"][False][0]) > 20      # (one recorded backward per gradient-commit variant; eager zero_grad: the `add` one)
     assert not plain._engine._taped or all(e["state"] == "warm" for e in plain._engine._taped.values())
 
 
@@ -830,7 +830,7 @@ def test_overlapped_gradient_exchange_under_a_one_rank_rccl_group():
         port = sk.getsockname()[1]
     dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{port}", rank=0, world_size=1, device_id=torch.device("cuda", torch.cuda.current_device()))
     try:
-        for wire, tol in (("fp32", 2e-5), ("bf16", 4e-3)):
+        for wire, tol in (("fp32", 1e-4), ("bf16", 4e-3)):      # (fp32 wire: the 16-bit backward's own run-to-run noise, 1.5e-5 measured for this model)
             red = OverlappedGradAllReducer(model, dist, wire=wire)
             red.attach()
             steps(3)
@@ -1030,6 +1030,16 @@ def test_lazy_zero_grad_equals_the_eager_fill(tag, size, channels, batch, comput
     torch.cuda.synchronize()
     ref = ar.grad.clone()
     assert bool(torch.isfinite(ref).all())
+    # the 16-bit backward is not bit-reproducible (fp32 atomics commit in any order, an ulp upstream flips 16-bit roundings downstream): the
+    # floor is what two EAGER steps differ by — 1.5e-5 (B) .. 1e-4 (T) in fp16, ~8x that in bf16 on this box; a missing 1/S, a stale or
+    # an unfilled tensor is an O(1) error
+    model.zero_grad()
+    model(**kw).loss.backward()
+    torch.cuda.synchronize()
+    floor = float((ar.grad - ref).norm() / ref.norm())
+    bound = 4.0 * floor + 2e-5
+    print(f"\n[lazy zero-grad {tag} {compute}] eager-vs-eager floor {floor:.2e}, bound {bound:.2e}; filled fraction of the arena {frac:.3f}")
+    assert bound < 2e-2
     for step in range(4):                          # direct / recorded / replayed / replayed
         ar.grad[~small] = float("nan")
         ar.grad[small] = 3.0
@@ -1039,11 +1049,15 @@ def test_lazy_zero_grad_equals_the_eager_fill(tag, size, channels, batch, comput
         torch.cuda.synchronize()
         assert bool(torch.isfinite(ar.grad).all()), step
         d = float((ar.grad - ref).norm() / ref.norm())
-        assert d < 5e-6, (step, d)                 # (float atomics of the accumulated part commit in any order)
+        assert d < bound, (step, d, floor)
+        for p_ in sorted(eng._big_ptrs)[::7]:
+            o = (p_ - ar.grad.data_ptr()) // 4
+            a_, b_ = ar.grad[o:o + 4096], ref[o:o + 4096]
+            assert float((a_ - b_).norm()) <= 0.25 * float(b_.norm()) + 1e-12, (step, o)      # (a stored tensor is its eager value, not 2^k times it or stale)
     model(**kw).loss.backward()                    # accumulation window: no zero_grad
     torch.cuda.synchronize()
     d = float((ar.grad - 2 * ref).norm() / (2 * ref).norm())
-    assert d < 5e-6, d
+    assert d < bound, (d, floor)
     assert eng.grad_overflow is None or int(eng.grad_overflow) == 0
     ents = [e for e in eng._taped.values() if e.get("state") == "ready"]
     assert ents and any(set(e["bwd"]) == {True, False} for e in ents)
