@@ -741,7 +741,7 @@ def main():
                 name, wg = max(gemm_fams.items(), key=lambda kv: kv[1]["ms_per_step"])
                 tf = wg["gflop_per_step"] / wg["ms_per_step"]      # GFLOP / ms = TFLOP/s
                 traffic, traffic_src, tj = None, None, {}
-                for rnd in ("round5", "round4", "round3", "round2"):   # HBM bytes per launch (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes)
+                for rnd in ("round6", "round5", "round4", "round3", "round2"):   # HBM bytes per launch (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes)
                     tpath = os.path.join(ROOT, "profiles", rnd, "pmc_traffic.json")
                     if os.path.exists(tpath):
                         tj = json.load(open(tpath))
@@ -785,7 +785,7 @@ def main():
                                   "FusedAdamW.step (outside forward + backward), or by the next forward after a foreign optimizer"}
         # whole-step HBM traffic of the newest committed PMC passes against the 8 TB/s peak and SURVEY 8(d)'s ideal fused traffic
         hbm = None
-        for rnd in ("round5", "round4", "round3"):
+        for rnd in ("round6", "round5", "round4", "round3"):
             tpath = os.path.join(ROOT, "profiles", rnd, "pmc_traffic.json")
             if os.path.exists(tpath) and a.model == "B" and a.size == 128 and B == 64:
                 ws_ = (json.load(open(tpath)).get("whole_step") or {})

@@ -12,8 +12,11 @@
 // ((k >> 1) & 4), which gives the eight rows one half-wave touches eight different 8-bank groups; applied on the SOURCE side of the
 // direct-to-LDS load (the destination is lane-linear) and in the fragment address.
 // Bias gradients (column sums of dY over the tokens) come from the dY tile in LDS, as in gemm_fast's TN kernel.
-// Too few tiles for two workgroups per CU (Poseidon-B stage 2: 108): K is cut into slices, partial tiles go to the workspace in the
-// layout of wgrad_group_reduce_kernel (gemm_fast.hip), which adds them into the gradients.
+// Groups of 64-255 tiles over >= 8192 tokens (Poseidon-L's and B@256²'s middle stages) cut K into slices: partial tiles go to the workspace in
+// the layout of wgrad_group_reduce_kernel (gemm_fast.hip), which commits them to the gradients.  Shorter contractions stay on the unsplit
+// 64 x 64 grouped kernel — Poseidon-B's stage 2 (108 tiles, 4096 tokens): 58.6 -> 54.4 us alone for 113 MB of partials, nothing in the step
+// (the policy is wgrad_group_impl's, gemm_fast.hip).  How a result meets its gradient tensor (add / store scaled / add scaled: the lazy
+// zero-grad of round 6) is WgradProblem::mode, applied by grad_commit8 here and in the reduce.
 #include "wgrad_group.h"
 #include <stdlib.h>
 

@@ -1084,7 +1084,7 @@ TIMED = [("B", 128, 4, 64), ("T", 128, 4, 32), ("B", 256, 4, 32), ("L", 128, 5, 
 def test_timed_batch_matches_the_batch1_path(tag, size, channels, batch, compute):
     """BASELINE configs 3 / 2 / 5 / 4 at the batch sizes bench.py times: the large row counts select launch policies no batch-1 fixture
     reaches (128-row block tails, grouped / recomputing weight gradients, direct-to-LDS and four-register-set GEMMs, the 128 x 128-tile
-    GEMMs with their in-launch K split — whose fp32 sums are grouped by slice, so the batch-1 path's 64 x 64 tiles agree to summation
+    GEMMs and grouped weight gradients — whose fp32 sums run in another order than the batch-1 path's 64 x 64 tiles: agreement to summation
     order, not bit for bit —, the XCD-local attention grid).  Samples are independent, so (i) prediction[i] of the batch must equal the prediction of sample i alone, and (ii)
     the batch's parameter gradients must equal the sum of the per-sample gradients weighted as the relative loss weights them — checked
     through the loss and the full gradients of a few samples' worth (a batch of 3 against 3 batches of 1)."""

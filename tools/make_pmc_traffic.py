@@ -1,4 +1,4 @@
-"""profiles/round3/pmc_traffic.json from the two PMC passes of tools/gpu_r3_evidence.sh (tools/pmc_summary.py output files).
+"""profiles/round3/pmc_traffic.json from the two PMC passes of tools/gpu_r6_evidence.sh (round 3: profiles/round3/gpu_r3_evidence.sh) (tools/pmc_summary.py output files).
 usage: python tools/make_pmc_traffic.py <pmc_FETCH_SIZE.txt> <pmc_WRITE_SIZE.txt> [<fetch_total.txt> <write_total.txt>] > pmc_traffic.json"""
 import json
 import re
