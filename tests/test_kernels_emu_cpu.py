@@ -106,8 +106,7 @@ def test_gemm_wide_tiles(emu, M, N, K, variant):
         lib.scot_gemm_wide_config(1, 0)
 
 
-@pytest.mark.parametrize("S", [2, 3, 5])
-@pytest.mark.parametrize("M,N,K", [(128, 64, 384), (96, 136, 640), (64, 192, 1024)])
+@pytest.mark.parametrize("M,N,K,S", [(128, 64, 384, 2), (96, 136, 640, 3), (96, 136, 640, 5), (64, 192, 1024, 2)])
 def test_gemm_nt_split_k_atomic(emu, M, N, K, S):
     """csrc/gemm_fast.hip, K slices of the fp32-result NT products adding into the result with fp32 atomics (scot_gemm_splitk_config): the
     forward form (bias from slice 0, result zeroed by the launcher — it starts as NaN here) and the accumulating data-gradient form,

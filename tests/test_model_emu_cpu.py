@@ -182,6 +182,8 @@ def test_engine_lazy_zero_grad_stores_first_writers(emu, compute):
                        channel_slice_list_normalized_loss=[0, 1, 3, 4], residual_model="convnext", use_conditioning=True, learn_residual=False),
             ScOTConfig(**load_fixture("tiny_odd")[1]["cfg"])]
     for cfg in cfgs:
+        if (cfg.embed_dim == 96) != (compute == "fp16"):
+            continue            # (the 96-wide model in fp16, the ragged tiny one in bf16: half the emulation time, both code paths in both formats' kernels)
         sd = synth_state_dict(param_shapes(cfg), "trained")
         if cfg.embed_dim == 96:
             pv, t, lab = synth_inputs(2, cfg.num_channels, cfg.num_out_channels, cfg.image_size, "smooth")
