@@ -192,7 +192,9 @@ def parity_check(model_tag, compute, size, channels):
     if cfg.image_size != size:
         return {"fixture": None, "note": f"golden fixture is at {cfg.image_size}x{cfg.image_size}"}
     with torch.device("cuda"):
-        model = ScOT(cfg, compute=compute)
+        # the fixture is a batch of 1-2: `fused_min_rows=0` makes it run the kernels the TIMED batch selects (the fused layer tails, which the
+        # engine's policy leaves to batches of >= 4096 token rows), so that what is checked against the reference is what is timed
+        model = ScOT(cfg, compute=compute, engine_options={"fused_min_rows": 0})
     model.load_state_dict(synth_state_dict(param_shapes(cfg), meta["regime"]))
     pv, t, lab = synth_inputs(meta["batch"], cfg.num_channels, cfg.num_out_channels, cfg.image_size, meta["kind"])
     with torch.no_grad():
@@ -245,10 +247,10 @@ def attainable_model(cfg, batch):
                     "target needs a different decomposition (whole layers on chip: ~10x fewer bytes, ~7x fewer launches), not faster kernels"}
 
 
-def trained_like_model(cfg, compute):
+def trained_like_model(cfg, compute, engine_options=None):
     """random weights with "trained-like" statistics, so that every branch carries O(1) signal (random data, section 5.4 rule 25)"""
     from scOT.model import ScOT
-    model = ScOT(cfg, compute=compute)
+    model = ScOT(cfg, compute=compute, engine_options=engine_options)
     with torch.no_grad():
         for k, p in model.named_parameters():
             if k.endswith("weight.bias") and ("norm" in k):
@@ -506,7 +508,13 @@ def main():
             print(f"bench.py: --compute {a.compute} is at {parity['output_rel_l2']:.2e} from the reference fixture (bound "
                   f"{parity['bound']:.0e}): the number below is NOT a compliant measurement", file=sys.stderr)
     torch.manual_seed(1234)  # identical initial weights on every rank (no broadcast needed)
-    model = trained_like_model(cfg, a.compute)
+    # (fused_min_rows=0 changes no launch of the timed batch — every fused stage has >= 16384 token rows at the headline batch; it keeps the
+    #  one-sample forwards of the consistency check below on the same kernel family as the batch they are compared with)
+    from poseidon_amd.engine import ENGINE_OPTIONS
+    from poseidon_amd.geometry import stage_plan
+    fused_rows = [a.batch * st.res[0] * st.res[1] for st in stage_plan(cfg)[1] if st.dim in (96, 192)]
+    same_launches = bool(fused_rows) and min(fused_rows) >= ENGINE_OPTIONS["fused_min_rows"] and not a.emu
+    model = trained_like_model(cfg, a.compute, engine_options={"fused_min_rows": 0} if same_launches else None)
     torch.manual_seed(100 + rank)
     B = a.batch
     pv = torch.randn(B, ch, a.size, a.size, device=DEV)

@@ -54,6 +54,9 @@ ENGINE_OPTIONS = dict(
     trunk_x3=True,            # fp16 mode: the trunk on the split 16-bit MFMA (fp32 operands, 3 products)
     fused_mlp=True,           # csrc/mlp_fused.hip at C = 96 / 192 (round 2: 23.7 vs 24.9 ms)
     fused_tail=True,          # projection half + MLP half of a layer's tail in one launch per direction
+    fused_min_rows=4096,      # ... from this many token rows on: a tail workgroup owns 64 / 128 rows, so 2048 rows are 32 workgroups on 256 CUs
+                              # (round 6, profiles/round6/fused_min_rows_ab.txt: Poseidon-T batch 32 6.18 -> 5.72 ms, Poseidon-B batch 8 10.42 -> 9.41 ms;
+                              #  16384 loses again: 5.85 — at 8192 rows the fused tail still wins)
     fused_next_qkv=(96, 192),   # widths at which the forward tail also produces the next layer's q/k/v projection
     fused_qkv_dgrad=(96,),      # widths at which the backward tail applies the previous layer's qkv data gradient as a prologue (192 spills)
     dgrad_wt=True,            # transposed 16-bit weight copies: data gradients as NT products (stages 2/3: 1.7-2.2x)
@@ -172,6 +175,7 @@ class ScOTEngine:
         # modes; option fused_mlp=False restores the layer-by-layer launches
         self.fused_mlp = opt["fused_mlp"] and half
         self.fused_tail = opt["fused_tail"]     # MLP-half + projection-half backward in one launch
+        self.fused_min_rows = int(opt["fused_min_rows"])
         # ... forward: the next layer's q/k/v projection as epilogue (channel widths).  Backward: the previous layer's qkv dgrad as
         # prologue — at C = 96 only: the C = 192 prologue variant spills and costs more than the GEMM it replaces (125 vs 87 + 20 us)
         self.fused_next_qkv = set(opt["fused_next_qkv"])
@@ -665,7 +669,7 @@ class ScOTEngine:
         ok = self._lean_cache.get(key)
         if ok is None:
             w2 = pre + ".output.dense.weight"
-            ok = (self.use_fused("mlp_bwd", C) and self.use_fused("proj_bwd", C) and self.use_fused("mlp_fwd", C) and self.use_fused("proj_fwd", C)
+            ok = (self.use_fused("mlp_bwd", C, rows) and self.use_fused("proj_bwd", C, rows) and self.use_fused("mlp_fwd", C, rows) and self.use_fused("proj_fwd", C, rows)
                   and self.fused_tail and hid == 4 * C and hid % 128 == 0 and rows_per_sample % 64 == 0
                   and self.WT(w2, self.W(w2)) is not None and ops.tail_workgroups(rows, rows_per_sample, C) > 0)
             if ok:
@@ -808,9 +812,10 @@ class ScOTEngine:
         self.flush_side()
         return g
 
-    def use_fused(self, part: str, C: int) -> bool:
-        """csrc/mlp_fused.hip covers C = 96 / 192 in the 16-bit modes"""
-        return self.fused_mlp and C in (96, 192)
+    def use_fused(self, part: str, C: int, rows: Optional[int] = None) -> bool:
+        """csrc/mlp_fused.hip covers C = 96 / 192 in the 16-bit modes; a tail workgroup owns 64 (128) rows, so below `fused_min_rows` rows the
+        launch leaves most CUs idle and the layer-by-layer GEMMs (hundreds of 64 x 64 tiles) win"""
+        return self.fused_mlp and C in (96, 192) and (rows is None or rows >= self.fused_min_rows)
 
     def wgrad(self, cm, dy, x, gw, b_gelu=False, dbias=None):
         """dW += dy^T x (+ dbias): queued until the next flush_side(), where the queued problems that share a compute mode and
@@ -936,8 +941,8 @@ class ScOTEngine:
         dp1 = self.drop_path_scale(pre, B, 0) if self.stochastic else None
         dp2 = self.drop_path_scale(pre, B, 1) if self.stochastic else None
         hid = int(cfg.mlp_ratio * C)
-        proj_f = self.use_fused("proj_fwd", C)
-        mlp_f = self.use_fused("mlp_fwd", C) and hid % 128 == 0
+        proj_f = self.use_fused("proj_fwd", C, B * L)
+        mlp_f = self.use_fused("mlp_fwd", C, B * L) and hid % 128 == 0
         done_tail = False
         lean_used = False
         qkv_next = None
@@ -1099,8 +1104,8 @@ class ScOTEngine:
         a = pre + ".attention.self."
         L, Lp = H * W, Hp * Wp
         hid = int(cfg.mlp_ratio * C)
-        mlp_f = self.use_fused("mlp_bwd", C) and hid % 128 == 0 and L % 64 == 0
-        proj_f = self.use_fused("proj_bwd", C) and L % 64 == 0
+        mlp_f = self.use_fused("mlp_bwd", C, B * L) and hid % 128 == 0 and L % 64 == 0
+        proj_f = self.use_fused("proj_bwd", C, B * L) and L % 64 == 0
         tail_f = mlp_f and proj_f and self.fused_tail
         can_prologue = tail_f and C in self.fused_qkv_dgrad and not padded
         if pend is not None and not can_prologue:

@@ -169,8 +169,9 @@ class ScOT(nn.Module):
     base_model_prefix = "swinv2"
     main_input_name = "pixel_values"
 
-    def __init__(self, config: ScOTConfig, use_mask_token: bool = False, compute: Optional[str] = None):
+    def __init__(self, config: ScOTConfig, use_mask_token: bool = False, compute: Optional[str] = None, engine_options: Optional[dict] = None):
         super().__init__()
+        self.engine_options = dict(engine_options or {})      # overrides of poseidon_amd.engine.ENGINE_OPTIONS for this model's engine
         if config.residual_model not in ("convnext", "resnet"):
             raise ValueError("residual_model must be 'convnext' or 'resnet'")
         if config.residual_model != "convnext":
@@ -355,7 +356,7 @@ class ScOT(nn.Module):
                 p.data = v
                 p.grad = None
         self._arena = ar
-        self._engine = ScOTEngine(self.config, ar, self.compute)
+        self._engine = ScOTEngine(self.config, ar, self.compute, options=self.engine_options)
         self._engine.weights_version = self._weights_version
         self._anchor = torch.zeros(1, device=device, requires_grad=True)
         self._params = [p for _, p in params]

@@ -28,6 +28,9 @@ def emu(monkeypatch):
     emu_session.patch_ops(monkeypatch, lib)
     monkeypatch.setenv("SCOT_SIDE_STREAM", "0")     # HIP streams / events do not exist here: one in-order "stream"
     monkeypatch.setenv("SCOT_TAPE", "0")
+    # the emulated models are tiny: without this the engine's policy (fused layer tails from 4096 token rows) would keep them off the
+    # fused kernels these tests are here to drive through the engine
+    monkeypatch.setitem(engine_mod.ENGINE_OPTIONS, "fused_min_rows", 0)
     return lib
 
 
