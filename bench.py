@@ -59,6 +59,9 @@ def parse():
     ap.add_argument("--wire", default="fp32", choices=["bf16", "fp32"], help="gradient all-reduce wire format (N>1)")
     ap.add_argument("--dp-collective", default="allreduce", choices=["allreduce", "rs_ag"],
                     help="N>1: one all-reduce per gradient chunk, or reduce-scatter + all-gather (poseidon_amd/dp.py)")
+    ap.add_argument("--dp-backend", default="torch", choices=["torch", "native"],
+                    help="N>1: the collectives of the torch process group (default), or the C ABI's own RCCL communicator "
+                         "(scot_dp_init / scot_dp_allreduce_bucket, include/scot_hip.h; all-reduce only)")
     ap.add_argument("--dp", default="auto", choices=["auto", "overlap", "after", "none"],
                     help="N>1: all-reduce each gradient range from inside the backward as soon as it is final (RCCL on a side "
                          "stream, eager launches), or one chunked all-reduce after the step (works with hipGraph replay); "
@@ -538,8 +541,8 @@ def main():
         if parity is not None:
             parity["batch_consistency"] = consistency
 
-    after = GradAllReducer(model, dist, wire=a.wire, collective=a.dp_collective) if dist is not None else None
-    overlapped = (OverlappedGradAllReducer(model, dist, wire=a.wire, collective=a.dp_collective)
+    after = GradAllReducer(model, dist, wire=a.wire, collective=a.dp_collective, backend=a.dp_backend) if dist is not None else None
+    overlapped = (OverlappedGradAllReducer(model, dist, wire=a.wire, collective=a.dp_collective, backend=a.dp_backend)
                   if (dist is not None and a.dp != "after") else None)
     exchange = [None if (dist is None or a.dp == "none") else ("after" if a.dp != "overlap" else "overlap")]   # current mode
     loss_buf = torch.zeros((), device=DEV)
@@ -838,7 +841,7 @@ def main():
                "config": {"workload": f"Poseidon-{a.model} fwd+bwd, {a.size}x{a.size}x{ch} grids, per-GPU batch {B}",
                           "global_batch": B * world, "parallelism": f"dp{world}", "graph": bool(use_graph[0]), **mode_info,
                           "grad_wire": a.wire if dist is not None else None, "grad_exchange": exchange[0],
-                          "grad_collective": a.dp_collective if dist is not None else None, "grad_comm_ms_per_step": comm,
+                          "grad_collective": a.dp_collective if dist is not None else None, "grad_backend": a.dp_backend if dist is not None else None, "grad_comm_ms_per_step": comm,
                           "loss": float(loss_buf),
                           "weight_refresh": weight_refresh, "parity": parity, "grad_overflow": overflow, "phases": phase,
                           "in_step_launches": launches},

@@ -26,7 +26,7 @@ typedef struct ihipStream_t* scot_stream_t; /* = hipStream_t */
 #define SCOT_LAYOUT_NN 1 /* C[M,N] = A[M,K] B[K,N]   : dgrad of nn.Linear; ConvTranspose2d k=s (ref:616-621)      */
 #define SCOT_LAYOUT_TN 2 /* C[M,N] += A[K,M]^T B[K,N] : wgrad of nn.Linear (autograd of the above)                 */
 
-int scot_abi_version(void);   /* 2 since round 4 (round 3 changed scot_adamw_step / scot_cpb_bwd_batched / scot_block_tail_*; the bindings check it at load) */
+int scot_abi_version(void);   /* 5 (round 6: 4 = scot_wgrad_group / scot_wgrad_mlp modes, scot_segments_scale, scot_gemm_splitk_config; 5 = scot_dp_init .. finalize); the bindings check it at load */
 /* Format of dtype code 1 in THIS build of the library: 0 = bfloat16 (libscot_hip.so), 1 = IEEE binary16 (libscot_hip_f16.so, the
  * same sources compiled with -DSCOT_OPERAND_FP16).  The reference computes in fp32 (ref:1318-1509); 16-bit operands are this
  * library's choice and binary16 is the one that keeps ScOT.forward within 1e-3 of it. */
@@ -86,6 +86,24 @@ int scot_spectral_apply(const float* U, const float* Pr, const float* Pi, float*
  * src/dst fp32 (32-byte aligned), wire bfloat16 (16-byte aligned) — bfloat16 in BOTH builds of the library. */
 int scot_dp_pack(const float* src, void* wire, size_t n, float scale, scot_stream_t stream);
 int scot_dp_unpack(const void* wire, float* dst, size_t n, float scale, scot_stream_t stream);
+/* The exchange itself for a host WITHOUT torch.distributed (reference: the DDP all-reduce behind `accelerate launch`,
+ * README.md:50-57, per-device batch scOT/train.py:281).  RCCL is resolved at run time (dlopen: the copy already mapped into the
+ * process, else the loader path, else /opt/rocm/lib) — no link-time dependency; without it these return -3 and say so on stderr.
+ *   scot_dp_unique_id:        rank 0 draws the 128-byte rendezvous token (ncclGetUniqueId) into host memory; the host distributes it.
+ *   scot_dp_init:             collective; joins `world` ranks as `rank` on the CURRENT HIP device (one process per GPU).  -3 if this
+ *                             process already holds a communicator.
+ *   scot_dp_allreduce_bucket: in-place SUM over ranks of grads[0..n) on comm_stream; dtype 0 = fp32, 1 = the bfloat16 wire format of
+ *                             scot_dp_pack (bfloat16 in both builds).  The mean's 1/world is applied by the caller BEFORE the sum
+ *                             (scot_dp_pack's scale; on fp32 ranges a scale pass), so a 16-bit wire cannot overflow.  -3 before init.
+ *   scot_dp_world / _rank:    0 / -1 outside init..finalize.
+ *   scot_dp_finalize:         destroys the communicator (caller has synchronised comm_stream); idempotent.
+ * These are the only entry points that block (init) or touch host memory (unique_id). */
+int scot_dp_unique_id(void* id128_host);
+int scot_dp_init(const void* id128_host, int rank, int world);
+int scot_dp_allreduce_bucket(void* grads, size_t n, int dtype, scot_stream_t comm_stream);
+int scot_dp_world(void);
+int scot_dp_rank(void);
+int scot_dp_finalize(void);
 int scot_selftest_tr(scot_stream_t stream); /* 1: ds_read_b64_tr_b16 path verified & on, 0: scalar-gather fallback */
 void scot_set_use_tr(int v);
 int scot_get_use_tr(void);

@@ -8,7 +8,7 @@ import time
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
-SOURCES = ["gemm.hip", "gemm_fast.hip", "gemm_wide.hip", "wgrad_wide.hip", "gemm_panel.hip", "attention.hip", "attention_w16.hip", "norm.hip", "norm_fast.hip", "mlp_fused.hip", "wgrad_mlp.hip", "host_tape.hip", "misc.hip", "optim.hip"]
+SOURCES = ["gemm.hip", "gemm_fast.hip", "gemm_wide.hip", "wgrad_wide.hip", "gemm_panel.hip", "attention.hip", "attention_w16.hip", "norm.hip", "norm_fast.hip", "mlp_fused.hip", "wgrad_mlp.hip", "host_tape.hip", "misc.hip", "optim.hip", "dp.hip"]
 LIB = os.path.join(HERE, "libscot_hip.so")
 # the same sources with the 16-bit operand type meaning IEEE binary16 instead of bfloat16 (csrc/common.h)
 LIB_F16 = os.path.join(HERE, "libscot_hip_f16.so")

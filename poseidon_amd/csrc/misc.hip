@@ -1307,7 +1307,7 @@ extern "C" int scot_selftest_tr(hipStream_t s) {
 }
 extern "C" void scot_set_use_tr(int v) { g_scot_use_tr = v ? 1 : 0; }
 extern "C" int scot_get_use_tr() { return g_scot_use_tr; }
-extern "C" int scot_abi_version() { return 4; }      // 3: scot_gemm_wide_config; 4: scot_gemm_splitk_config
+extern "C" int scot_abi_version() { return 5; }      // 3: scot_gemm_wide_config; 4: scot_gemm_splitk_config; 5: scot_dp_* (dp.hip)
 // Format of the 16-bit operand type this build of the library computes with: 0 = bfloat16, 1 = IEEE binary16 (common.h).
 extern "C" int scot_operand_format() {
 #if defined(SCOT_OPERAND_FP16)

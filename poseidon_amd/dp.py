@@ -90,21 +90,48 @@ def group_ranges(arena, groups: List[str]) -> List[Tuple[str, int, int]]:
     return out
 
 
+def native_init(dist=None, group=None, unique_id: Optional[bytes] = None, rank: Optional[int] = None, world: Optional[int] = None):
+    """Bring up the communicator of the C ABI (`scot_dp_init`, csrc/dp.hip) once per process and return (world, rank).
+    With a torch process group the 128-byte token travels through it (`broadcast_object_list` from rank 0) — the only use of
+    torch.distributed on this path; a host without one passes `unique_id` (ops.dp_unique_id() of rank 0), `rank` and `world` itself."""
+    from . import ops
+    if ops.dp_world():
+        return ops.dp_world(), ops.dp_rank()
+    if unique_id is None:
+        if dist is None:
+            rank, world, unique_id = 0, 1, ops.dp_unique_id()
+        else:
+            rank, world = dist.get_rank(group), dist.get_world_size(group)
+            box = [ops.dp_unique_id() if rank == 0 else None]
+            dist.broadcast_object_list(box, src=dist.get_global_rank(group, 0) if group is not None else 0, group=group)
+            unique_id = box[0]
+    ops.dp_init(unique_id, rank, world)
+    return world, rank
+
+
 class GradAllReducer:
-    """wire: "fp32" (the reference's DDP semantics) or "bf16" (half the xGMI bytes: one HIP pass packs 1/N·g into bfloat16,
+    """backend: "torch" (the collectives of the process group `dist`: the default) or "native" (the C ABI's own RCCL communicator:
+    scot_dp_init / scot_dp_allreduce_bucket, include/scot_hip.h — what a host without torch.distributed calls).
+    wire: "fp32" (the reference's DDP semantics) or "bf16" (half the xGMI bytes: one HIP pass packs 1/N·g into bfloat16,
     the sum runs on the 16-bit buffer, one pass unpacks — scot_dp_pack / scot_dp_unpack).
     collective: "allreduce" (one RCCL all-reduce per chunk) or "rs_ag" (reduce-scatter + all-gather per chunk: the same ring
     traffic, but every rank owns the mean of 1/N of each chunk between the two halves — the seam a sharded optimizer step
     hangs on; backends without reduce_scatter_tensor (gloo, CPU tests) take the same bookkeeping through all_reduce)."""
 
-    def __init__(self, model, dist, wire: str = "fp32", chunk_mb: int = 128, group=None, collective: str = "allreduce"):
-        if wire not in ("fp32", "bf16") or collective not in ("allreduce", "rs_ag"):
-            raise ValueError("wire: fp32 | bf16; collective: allreduce | rs_ag")
+    def __init__(self, model, dist, wire: str = "fp32", chunk_mb: int = 128, group=None, collective: str = "allreduce",
+                 backend: str = "torch"):
+        if wire not in ("fp32", "bf16") or collective not in ("allreduce", "rs_ag") or backend not in ("torch", "native"):
+            raise ValueError("wire: fp32 | bf16; collective: allreduce | rs_ag; backend: torch | native")
+        if backend == "native" and collective != "allreduce":
+            raise ValueError("backend='native' exports the all-reduce only (scot_dp_allreduce_bucket)")
         self.model = model
         self.dist = dist
         self.group = group
+        self.backend = backend
         self.world = dist.get_world_size(group) if dist is not None else 1
         self.rank = dist.get_rank(group) if dist is not None else 0
+        if backend == "native":
+            self.world, self.rank = native_init(dist, group)
         self.wire = wire
         self.collective = collective
         self.chunk = chunk_mb * (1 << 20) // 4
@@ -117,7 +144,14 @@ class GradAllReducer:
         return self.model.flat_grads()
 
     def broadcast_parameters(self, src: int = 0):
-        self.dist.broadcast(self.model.flat_parameters(), src=src, group=self.group)
+        if self.backend == "native":       # the ABI exports ONE collective: a broadcast is the sum of the source's values and zeros
+            from . import ops
+            flat = self.model.flat_parameters()
+            if self.rank != src:
+                flat.zero_()
+            ops.dp_allreduce(flat)
+        else:
+            self.dist.broadcast(self.model.flat_parameters(), src=src, group=self.group)
         # a collective writes the arena WITHOUT moving torch's version counter (checked on torch 2.10, gloo and nccl): without this the
         # engine of a non-source rank that has already run a forward would keep computing from 16-bit copies of its pre-broadcast weights
         self.model.mark_weights_dirty()
@@ -128,7 +162,10 @@ class GradAllReducer:
     def _sum(self, buf: torch.Tensor):
         """In-place sum over ranks of `buf` (a multiple of `world` elements long when collective == "rs_ag")."""
         self.bytes_on_wire += buf.numel() * buf.element_size()
-        if self.collective == "rs_ag":
+        if self.backend == "native":
+            from . import ops
+            ops.dp_allreduce(buf)
+        elif self.collective == "rs_ag":
             shard = buf.view(self.world, -1)[self.rank]
             if hasattr(self.dist, "reduce_scatter_tensor") and self.dist.get_backend(self.group) != "gloo":
                 self.dist.reduce_scatter_tensor(shard, buf, group=self.group)        # this rank now owns its shard's sum
@@ -183,8 +220,9 @@ class OverlappedGradAllReducer(GradAllReducer):
     (engine.on_grads_final), so that only the last range (the small C=96 encoder stage + embeddings) is exposed.
     Roughly 73 % of Poseidon-B's gradient bytes (the two C=768 stages) are final by mid-backward."""
 
-    def __init__(self, model, dist, wire: str = "fp32", chunk_mb: int = 64, group=None, collective: str = "allreduce"):
-        super().__init__(model, dist, wire=wire, chunk_mb=chunk_mb, group=group, collective=collective)
+    def __init__(self, model, dist, wire: str = "fp32", chunk_mb: int = 64, group=None, collective: str = "allreduce",
+                 backend: str = "torch"):
+        super().__init__(model, dist, wire=wire, chunk_mb=chunk_mb, group=group, collective=collective, backend=backend)
         self._ranges = None
         # a stream measured to overlap the engine's main chain and its weight-gradient stream (streams.py; created lazily in attach(): the
         # engine's side stream exists by then)
@@ -195,11 +233,16 @@ class OverlappedGradAllReducer(GradAllReducer):
 
     def attach(self):
         if self.comm_stream is None:
-            from .streams import independent_stream
+            from .streams import forget, independent_stream
             eng = self.model._engine
             dev = self._flat().device
-            self.comm_stream = independent_stream(dev, [torch.cuda.current_stream(dev), eng.side_stream() if eng.use_side else None]) \
-                if dev.type == "cuda" else None
+            if dev.type == "cuda":
+                # the engine's weight-gradient stream and the communication stream are both picked AFTER the communicator exists (a reducer
+                # is built on one): a weight-gradient stream older than the communicator can serialise against RCCL's internal streams
+                # although every visible pair measures as overlapping — 21.6 vs 11.7 ms, streams.py "Communicators"
+                forget(dev)
+                eng.side = None
+                self.comm_stream = independent_stream(dev, [torch.cuda.current_stream(dev), eng.side_stream() if eng.use_side else None])
         self.model._engine.on_grads_final = self._on_final
         self.model._engine.reset_tapes()   # a recorded step bakes the hook in
         if not self._hooked:

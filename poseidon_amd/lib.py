@@ -14,7 +14,7 @@ LIB_PATH = os.path.join(_HERE, "libscot_hip.so")
 # The same sources built twice (build.py): the format of the 16-bit operand type is a compile-time property (csrc/common.h).
 LIB_PATHS = {"bf16": LIB_PATH, "f16": os.path.join(_HERE, "libscot_hip_f16.so")}
 OPERAND_FORMAT = {"bf16": 0, "f16": 1}
-ABI_VERSION = 4      # scot_abi_version() of the library these prototypes describe (checked at load)
+ABI_VERSION = 5      # scot_abi_version() of the library these prototypes describe (checked at load)
 
 P, I, F, Z = c_void_p, c_int, c_float, c_size_t
 
@@ -91,6 +91,12 @@ PROTOTYPES = {
     "scot_spectral_apply": [P, P, P, P, I, I, I, P],
     "scot_dp_pack": [P, P, Z, F, P],
     "scot_dp_unpack": [P, P, Z, F, P],
+    "scot_dp_unique_id": [P],
+    "scot_dp_init": [P, I, I],
+    "scot_dp_allreduce_bucket": [P, Z, I, P],
+    "scot_dp_world": [],
+    "scot_dp_rank": [],
+    "scot_dp_finalize": [],
     "scot_optim_blocks": [Z],
     "scot_grad_sqnorm": [P, P, Z, P, P],
     "scot_clip_coef": [P, I, F, P, P],

@@ -607,6 +607,49 @@ def dp_unpack(wire, dst, scale: float = 1.0):
     _lib.check(L().scot_dp_unpack(ptr(wire), ptr(dst), dst.numel(), float(scale), stream()), "scot_dp_unpack")
 
 
+# --- the exchange behind the C ABI (csrc/dp.hip): one RCCL communicator per process, owned by ONE build of the library (the
+# communicator is library state and bf16 / f16 are two libraries; the wire format is bfloat16 in both) ---
+def _dp_lib():
+    return _lib.load(kind="bf16")
+
+
+def dp_unique_id() -> bytes:
+    """The 128-byte rendezvous token of a new communicator (drawn by rank 0, handed to every rank by the host)."""
+    import ctypes
+    buf = ctypes.create_string_buffer(128)
+    _lib.check(_dp_lib().scot_dp_unique_id(ctypes.cast(buf, ctypes.c_void_p)), "scot_dp_unique_id")
+    return buf.raw
+
+
+def dp_init(unique_id: bytes, rank: int, world: int):
+    """Collective: join the communicator on the current HIP device."""
+    import ctypes
+    if len(unique_id) != 128:
+        raise ValueError("dp_init: the unique id is 128 bytes (ops.dp_unique_id() on rank 0)")
+    buf = ctypes.create_string_buffer(bytes(unique_id), 128)
+    _lib.check(_dp_lib().scot_dp_init(ctypes.cast(buf, ctypes.c_void_p), int(rank), int(world)), "scot_dp_init")
+
+
+def dp_allreduce(buf):
+    """In-place SUM over the native communicator's ranks of a flat fp32 or bfloat16 device tensor, on the current stream."""
+    if buf.dtype not in (torch.float32, torch.bfloat16) or not buf.is_contiguous():
+        raise TypeError("dp_allreduce: contiguous fp32 or bfloat16 (wire format) tensor")
+    _lib.check(_dp_lib().scot_dp_allreduce_bucket(ptr(buf), buf.numel(), 0 if buf.dtype == torch.float32 else 1, stream()),
+               "scot_dp_allreduce_bucket")
+
+
+def dp_world() -> int:
+    return int(_dp_lib().scot_dp_world())
+
+
+def dp_rank() -> int:
+    return int(_dp_lib().scot_dp_rank())
+
+
+def dp_finalize():
+    _lib.check(_dp_lib().scot_dp_finalize(), "scot_dp_finalize")
+
+
 def scale_inplace(x, scale: float, nonfinite=None):
     """x (flat fp32, 16-byte aligned) *= scale; nonfinite (int32[1], optional) counts waves that saw Inf/NaN."""
     _lib.check(L().scot_scale_inplace(ptr(x), x.numel(), float(scale), ptr(nonfinite), stream()), "scot_scale_inplace")

@@ -12,6 +12,14 @@ HIP does not say which queue a stream got, so this module MEASURES the pattern t
 barrier — which is how a queue-sharing side stream got through: round 6, `test_overlapped_gradient_exchange_under_a_one_rank_rccl_group` run
 alone, and bench.py's other_configs, 46 vs 30 ms.)
 
+**Communicators (round 6, second finding).**  An RCCL communicator brings internal streams of its own, and every collective exchanges events
+between them and the stream it is enqueued on.  A weight-gradient stream that was picked BEFORE the communicator existed can then collide with
+one of those although every pair this module can see still measures as overlapping: Poseidon-B batch 16, communicator created after the first
+steps: 21.6 ms per step with the exchange attached against 11.7 ms when the communicator came first — torch's process group and the C ABI's own
+communicator alike (`tools/probe_rccl_alone.py`, profiles/round6/rccl_late_init_cliff.txt).  Re-picking the weight-gradient stream after the
+communicator exists removes it (11.65 ms), so `OverlappedGradAllReducer.attach()` drops the cached picks (`forget`) and takes fresh ones for
+the engine it attaches to: the state of a process that created its communicator first — what bench.py and the Trainer do anyway.
+
 A verified stream is cached per (device, streams it must run beside): every engine of a process shares ONE weight-gradient stream (engines
 step one at a time), so a long-lived process — a test session, a notebook, bench.py's five configurations — neither accumulates streams nor
 re-measures, and a capture in progress reuses what was measured before it began."""
@@ -66,6 +74,18 @@ def overlaps(a: "torch.cuda.Stream", b: "torch.cuda.Stream") -> bool:
     one = e0.elapsed_time(e1)
     best = min(_fork_join_ms(a, b) for _ in range(2))       # (a foreign kernel on a shared GPU can stretch one trial)
     return best < 2.5 * one
+
+
+def forget(device=None):
+    """Drop the cached picks (of `device`, or all): the next `independent_stream` measures fresh candidates.  Streams already handed out stay
+    valid for their holders."""
+    if device is None:
+        _cache.clear()
+        return
+    device = torch.device(device)
+    idx = device.index if device.index is not None else torch.cuda.current_device()
+    for k in [k for k in _cache if k[0] == idx]:
+        del _cache[k]
 
 
 def independent_stream(device, beside: Iterable["torch.cuda.Stream"], tries: int = 24, priority: int = 0) -> "torch.cuda.Stream":

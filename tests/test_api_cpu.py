@@ -107,6 +107,25 @@ def test_c_abi_exports_every_declared_symbol():
     assert f16.scot_abi_version() == scotlib.ABI_VERSION and f16.scot_operand_format() == 1
 
 
+def test_dp_entry_points_without_a_communicator():
+    """`scot_dp_*` (csrc/dp.hip) outside init..finalize: world 0 / rank -1, the all-reduce refuses (-3: unsupported configuration),
+    bad arguments are shape errors before RCCL is touched, finalize is idempotent — no GPU and no RCCL call involved."""
+    import ctypes
+    for kind in ("bf16", "f16"):
+        lib = scotlib.load(kind=kind)
+        assert lib.scot_dp_world() == 0 and lib.scot_dp_rank() == -1
+        assert lib.scot_dp_allreduce_bucket(None, 16, 0, None) == -3
+        buf = ctypes.create_string_buffer(128)
+        assert lib.scot_dp_init(None, 0, 1) == -1 and lib.scot_dp_init(ctypes.cast(buf, ctypes.c_void_p), 2, 2) == -1
+        assert lib.scot_dp_unique_id(None) == -1
+        assert lib.scot_dp_finalize() == 0 and lib.scot_dp_finalize() == 0
+    from poseidon_amd.dp import GradAllReducer
+    with pytest.raises(ValueError):
+        GradAllReducer(None, None, backend="native", collective="rs_ag")
+    with pytest.raises(ValueError):
+        GradAllReducer(None, None, backend="mpi")
+
+
 def test_workspace_queries_answer_without_a_gpu():
     """SURVEY.md §8(b) `scot_<op>_workspace_bytes(dims…)`: the split policy of the launching entry points, asked without launching.
     Poseidon-B at batch 64: the stage-0 / stage-1 grouped weight gradients split K (partial tiles), the deep stages run unsplit."""

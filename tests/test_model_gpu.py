@@ -852,6 +852,65 @@ def test_overlapped_gradient_exchange_under_a_one_rank_rccl_group():
         dist.destroy_process_group()
 
 
+def test_native_exchange_through_the_c_abi_on_a_one_rank_communicator():
+    """SURVEY §8(b)'s `scot_dp_init / scot_dp_allreduce_bucket / scot_dp_finalize` (csrc/dp.hip; reference: the DDP all-reduce behind
+    `accelerate launch`, README.md:50-57, train.py:281) with NO torch process group: rank 0 draws the token, joins a 1-rank RCCL
+    communicator, and the overlapped exchange of a Poseidon-B backward runs on it (`backend="native"`): a one-rank mean is the identity on
+    the fp32 wire and bfloat16 rounding on the 16-bit wire; the raw entry points sum in place on the stream they are given."""
+    from poseidon_amd import ops
+    from poseidon_amd.dp import OverlappedGradAllReducer, native_init
+    assert ops.dp_world() == 0 and ops.dp_rank() == -1
+    x = torch.randn(1 << 20, device=DEV)
+    with pytest.raises(Exception):
+        ops.dp_allreduce(x)                                  # before init: SCOT_ERR_UNSUPPORTED, loudly
+    assert native_init(None) == (1, 0) and ops.dp_world() == 1 and ops.dp_rank() == 0
+    try:
+        with pytest.raises(Exception):
+            ops.dp_init(ops.dp_unique_id(), 0, 1)            # one communicator per process
+        ref = x.clone()
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            ops.dp_allreduce(x)
+            w = x.to(torch.bfloat16)
+            w0 = w.clone()
+            ops.dp_allreduce(w)
+        side.synchronize()
+        assert torch.equal(x, ref) and torch.equal(w, w0)
+        pv, t, lab = synth_inputs(16, 4, 4, 128, "smooth")
+        kw = dict(pixel_values=pv.to(DEV), time=t.to(DEV), labels=lab.to(DEV))
+        cfg, sd, model = _preset_model("B", 128, 4, "fp16")
+
+        def steps(n):
+            for _ in range(n):
+                model.zero_grad()
+                model(**kw).loss.backward()
+            torch.cuda.synchronize()
+
+        steps(3)
+        bare = model.flat_grads().clone()
+        for wire, tol in (("fp32", 1e-4), ("bf16", 4e-3)):
+            red = OverlappedGradAllReducer(model, None, wire=wire, backend="native")
+            assert (red.world, red.rank) == (1, 0)
+            red.attach()
+            steps(3)                                          # direct, recorded, replayed
+            red.finish()
+            torch.cuda.synchronize()
+            g = model.flat_grads()
+            d = float((g - bare).norm() / bare.norm())
+            print(f"\n[native 1-rank RCCL, {wire} wire] gradients vs bare run rel-L2 {d:.2e}; {red.bytes_on_wire / 1e6:.0f} MB handed to scot_dp_allreduce_bucket")
+            assert torch.isfinite(g).all() and d <= tol and red.bytes_on_wire >= 2.9 * g.numel() * (4 if wire == "fp32" else 2)
+            red.detach()
+        p0 = model.flat_parameters().clone()
+        red.broadcast_parameters(0)
+        torch.cuda.synchronize()
+        assert torch.equal(model.flat_parameters(), p0)
+    finally:
+        ops.dp_finalize()
+    assert ops.dp_world() == 0
+    ops.dp_finalize()                                        # idempotent
+
+
 def test_short_training_run_fp16_tracks_fp32_on_poseidon_T():
     """The same check on a BASELINE model (Poseidon-T, 128 x 128 x 4, batch 4, trained-like parameters): 6 fused-AdamW steps in fp32 and in
     fp16 from the same state — the reference trains in fp32 (train.py:277-323), the headline number is measured in fp16."""

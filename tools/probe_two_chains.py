@@ -1,5 +1,6 @@
 """What-if: does the chip fill up when TWO half-batch steps run concurrently (two engines, two main streams + their side streams)?
-Poseidon-B, 2 x batch 32 against 1 x batch 64 (fwd + bwd, fp16 build).  usage: python tools/probe_two_chains.py [total_batch]"""
+Poseidon-B, 2 x batch 32 against 1 x batch 64 (fwd + bwd, fp16 build).  usage: python tools/probe_two_chains.py [total_batch] [fwd]
+("fwd": forward only under no_grad — the phase in which the weight-gradient stream is idle)"""
 import os
 import sys
 import time
@@ -10,19 +11,28 @@ from poseidon_amd.config import preset
 from scOT.model import ScOT
 
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 64
+FWD_ONLY = len(sys.argv) > 2 and sys.argv[2] == "fwd"
 cfg = preset("B", image_size=128, num_channels=4, num_out_channels=4, channel_slice_list_normalized_loss=[0, 1, 3, 4])
 
 
 def make(batch, seed):
     torch.manual_seed(1234)
     m = ScOT(cfg, compute="fp16").to("cuda")
+    if FWD_ONLY:
+        m.eval()
     torch.manual_seed(seed)
     kw = dict(pixel_values=torch.randn(batch, 4, 128, 128, device="cuda"), labels=torch.randn(batch, 4, 128, 128, device="cuda"),
               time=torch.rand(batch, device="cuda"))
+    if FWD_ONLY:
+        del kw["labels"]
     return m, kw
 
 
 def step(m, kw):
+    if FWD_ONLY:
+        with torch.no_grad():
+            m(**kw)
+        return
     m.zero_grad(overlap=True)
     out = m(**kw)
     out.loss.backward()
