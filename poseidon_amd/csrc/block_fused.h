@@ -21,10 +21,14 @@ struct ClnRowsOut {
 // patch_base: LDS, 4 waves x 16 x (C+4) floats, must be dead (the caller has passed a __syncthreads since its last use).
 // tile16 (optional): per-wave LDS tile [16·TT][C + 8] that also receives the 16-bit output rows (the fused block tail reads them
 // back as MFMA operand fragments instead of re-loading out16 from HBM); must not overlap the fp32 patches.
+// C % 32 != 0 (C = 48, Poseidon-T / -S stage 0: forward tail only): the row layout keeps ceil(C / 32) pieces per lane and the pieces
+// whose first column is >= C do not exist (no load, no store, nothing in the statistics); every `pv` below is compile-time true otherwise.
 template <int C, int TT>
 __device__ __forceinline__ void cln_rows_epilogue(f32x4_t (&Y)[TT][C / 16], float* patch_base, int row0, const ClnRowsOut& p,
                                                   bf16_t* tile16 = nullptr) {
-  constexpr int KJ = C / 32, NT = C / 16, CP = C + 4;   // CP % 16 == 4: the 4 row groups of a tile write disjoint banks
+  constexpr int KJ = (C + 31) / 32, NT = C / 16, CP = C + 4;   // CP % 16 == 4: the 4 row groups of a tile write disjoint banks
+  constexpr bool RAG = (C % 32) != 0;
+  static_assert(C % 16 == 0, "channel tiles");
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, g = lane >> 4, lc = lane & 15;
   float* Ct = patch_base + wave * 16 * CP;
   const int prow = lane >> 2, q = lane & 3;
@@ -42,11 +46,16 @@ __device__ __forceinline__ void cln_rows_epilogue(f32x4_t (&Y)[TT][C / 16], floa
 #pragma unroll
     for (int pp = 0; pp < KJ; ++pp) {
       const int col = pp * 32 + q * 8;
-      const float4 x0 = *(const float4*)(Ct + prow * CP + col), x1 = *(const float4*)(Ct + prow * CP + col + 4);
-      float bb[8];
-      ld8(p.bias, SCOT_F32, col, bb);
-      v[pp][0] = x0.x + bb[0]; v[pp][1] = x0.y + bb[1]; v[pp][2] = x0.z + bb[2]; v[pp][3] = x0.w + bb[3];
-      v[pp][4] = x1.x + bb[4]; v[pp][5] = x1.y + bb[5]; v[pp][6] = x1.z + bb[6]; v[pp][7] = x1.w + bb[7];
+      const bool pv = !RAG || col < C;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) v[pp][j] = 0.f;
+      if (pv) {
+        const float4 x0 = *(const float4*)(Ct + prow * CP + col), x1 = *(const float4*)(Ct + prow * CP + col + 4);
+        float bb[8];
+        ld8(p.bias, SCOT_F32, col, bb);
+        v[pp][0] = x0.x + bb[0]; v[pp][1] = x0.y + bb[1]; v[pp][2] = x0.z + bb[2]; v[pp][3] = x0.w + bb[3];
+        v[pp][4] = x1.x + bb[4]; v[pp][5] = x1.y + bb[5]; v[pp][6] = x1.z + bb[6]; v[pp][7] = x1.w + bb[7];
+      }
 #pragma unroll
       for (int j = 0; j < 8; ++j) s1 += v[pp][j];
     }
@@ -54,9 +63,11 @@ __device__ __forceinline__ void cln_rows_epilogue(f32x4_t (&Y)[TT][C / 16], floa
     const float mean = s1 * (1.0f / C);
     float s2 = 0.f;
 #pragma unroll
-    for (int pp = 0; pp < KJ; ++pp)
+    for (int pp = 0; pp < KJ; ++pp) {
+      if (RAG && pp * 32 + q * 8 >= C) continue;
 #pragma unroll
       for (int j = 0; j < 8; ++j) { const float d = v[pp][j] - mean; s2 += d * d; }
+    }
     s2 += __shfl_xor(s2, 1, 64); s2 += __shfl_xor(s2, 2, 64);
     const float rstd = 1.0f / sqrtf(s2 * (1.0f / C) + p.eps);
     if (valid) {
@@ -68,6 +79,7 @@ __device__ __forceinline__ void cln_rows_epilogue(f32x4_t (&Y)[TT][C / 16], floa
 #pragma unroll
       for (int pp = 0; pp < KJ; ++pp) {
         const int col = pp * 32 + q * 8;
+        if (RAG && col >= C) continue;
         if (p.z) st8(p.z, p.z_dt, base + col, v[pp]);
         float gw[8], gb[8], bw[8], bbv[8], res[8], o[8];
         ld8(p.gw_b, SCOT_F32, col, gb); ld8(p.bw_b, SCOT_F32, col, bbv);
@@ -86,7 +98,8 @@ __device__ __forceinline__ void cln_rows_epilogue(f32x4_t (&Y)[TT][C / 16], floa
     } else if (tile16) {
       const float zero[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-      for (int pp = 0; pp < KJ; ++pp) store8_ct(tile16 + (tt * 16 + prow) * (C + 8) + pp * 32 + q * 8, zero);
+      for (int pp = 0; pp < KJ; ++pp)
+        if (!RAG || pp * 32 + q * 8 < C) store8_ct(tile16 + (tt * 16 + prow) * (C + 8) + pp * 32 + q * 8, zero);
     }
     __builtin_amdgcn_wave_barrier();
   }

@@ -41,8 +41,11 @@ struct MlpArgs {
   float eps;
 };
 
+// K pitch of a weight tile whose contraction runs over the C channels: C + 8, or — C % 32 != 0 (C = 48: the forward tail of Poseidon-T / -S
+// stage 0) — the channels rounded up to whole 32-wide MFMA K-steps + 8, the columns >= C zero-filled
+template <int C> struct KPitch { static constexpr int KP = (C + 31) / 32 * 32, P = KP + 8; };
 template <int C, int HC> struct MlpFwdLds {
-  static constexpr size_t WBYTES = (size_t)(HC * (C + 8) + C * (HC + 8)) * 2 + (size_t)256 * 4, PBYTES = (size_t)4 * 16 * (C + 4) * 4;
+  static constexpr size_t WBYTES = (size_t)(HC * KPitch<C>::P + C * (HC + 8)) * 2 + (size_t)256 * 4, PBYTES = (size_t)4 * 16 * (C + 4) * 4;
   static constexpr size_t bytes = WBYTES > PBYTES ? WBYTES : PBYTES;
 };
 
@@ -50,18 +53,19 @@ template <int C, int HC> struct MlpFwdLds {
 // written by the projection half's epilogue in the fused block tail) instead of from p.h16; the tile may alias `smem`.
 template <int C, int HC, int TT, bool HTILE>
 __device__ __forceinline__ void mlp_fwd_body(const MlpArgs& p, char* smem, const bf16_t* htile, bf16_t* otile = nullptr) {
-  constexpr int KJ = C / 32;           // K-steps of GEMM 1 (K = C)
+  constexpr bool RAG = (C % 32) != 0;  // C = 48: the last K-step of GEMM 1 is half empty (zero operands on both sides)
+  constexpr int KJ = (C + 31) / 32;    // K-steps of GEMM 1 (K = C)
   constexpr int NT = C / 16;           // channel tiles of GEMM 2 / of the output
   constexpr int NB = HC / 32;          // 32-hidden blocks per chunk
-  constexpr int P1 = C + 8;            // pitch of the W1 chunk  [HC][P1]  (bf16 elements)
+  constexpr int P1 = KPitch<C>::P;     // pitch of the W1 chunk  [HC][P1]  (bf16 elements)
   constexpr int P2 = HC + 8;           // pitch of the W2 chunk  [C][P2]
   constexpr int CP = C + 4;            // pitch of the epilogue patch (floats); CP % 16 == 4: the 4 row groups hit disjoint banks
   constexpr int W1_EL = HC * P1, W2_EL = C * P2;
   constexpr int N1 = HC * C / 8, N2 = C * HC / 8;          // 16-byte pieces per chunk
   constexpr int PW1 = (N1 + 255) / 256, PW2 = (N2 + 255) / 256;
   // LDS (MlpFwdLds<C, HC>::bytes): weight chunks + b1 chunk (one slot per thread, HC used), later the epilogue's fp32 patches
-  static_assert(N1 % 256 == 0 && N2 % 256 == 0, "weight chunk pieces must divide over the 256 threads");
-  static_assert(HC <= 256 && C % 32 == 0 && HC % 32 == 0 && (W1_EL * 2) % 16 == 0 && ((W1_EL + W2_EL) * 2) % 16 == 0, "layout");
+  static_assert(RAG || (N1 % 256 == 0 && N2 % 256 == 0), "weight chunk pieces must divide over the 256 threads");
+  static_assert(HC <= 256 && C % 16 == 0 && HC % 32 == 0 && (W1_EL * 2) % 16 == 0 && ((W1_EL + W2_EL) * 2) % 16 == 0, "layout");
   bf16_t* W1c = (bf16_t*)smem;
   bf16_t* W2c = W1c + W1_EL;
   float* b1c = (float*)(W2c + W2_EL);
@@ -74,14 +78,16 @@ __device__ __forceinline__ void mlp_fwd_body(const MlpArgs& p, char* smem, const
   Frag<bf16_t> hf[TT][KJ];
 #pragma unroll
   for (int tt = 0; tt < TT; ++tt) {
+    const s16x8_t zero8 = {0, 0, 0, 0, 0, 0, 0, 0};
     if (HTILE) {
 #pragma unroll
-      for (int j = 0; j < KJ; ++j) hf[tt][j].v = *(const s16x8_t*)(htile + (tt * 16 + lc) * (C + 8) + j * 32 + g * 8);
+      for (int j = 0; j < KJ; ++j)
+        hf[tt][j].v = (!RAG || j * 32 + g * 8 < C) ? *(const s16x8_t*)(htile + (tt * 16 + lc) * (C + 8) + j * 32 + g * 8) : zero8;
     } else {
       const int row = min(row0 + tt * 16 + lc, p.M - 1);
       const bf16_t* src = p.h16 + (size_t)row * C + g * 8;
 #pragma unroll
-      for (int j = 0; j < KJ; ++j) hf[tt][j].v = *(const s16x8_t*)(src + j * 32);
+      for (int j = 0; j < KJ; ++j) hf[tt][j].v = (!RAG || j * 32 + g * 8 < C) ? *(const s16x8_t*)(src + j * 32) : zero8;
     }
   }
   if (HTILE) __syncthreads();          // every wave has its rows in registers: the tile may alias the weight chunk filled next
@@ -108,6 +114,7 @@ __device__ __forceinline__ void mlp_fwd_body(const MlpArgs& p, char* smem, const
 #pragma unroll
     for (int u = 0; u < PW1; ++u) {
       const int i = tid + u * 256;                           // < N1: the pieces divide evenly (static_assert), no guard —
+      if (RAG && i >= N1) continue;                          // (C = 48 runs ONE chunk: nothing is left pending across a loop)
       const int x = i / (C / 8), k8 = (i % (C / 8)) * 8;     // a guarded store would leave its load unconsumed on the skipped path
       const int y = x & 31;                                  // x: hidden unit within the chunk
       const int rho = (x & ~31) + (((y >> 2) & 1) << 4) + ((y >> 3) << 2) + (y & 3);   // [blk][t][a][b] of y = 8a + 4t + b
@@ -116,10 +123,16 @@ __device__ __forceinline__ void mlp_fwd_body(const MlpArgs& p, char* smem, const
 #pragma unroll
     for (int u = 0; u < PW2; ++u) {
       const int i = tid + u * 256;
+      if (RAG && i >= N2) continue;
       const int row = i / (HC / 8), c8 = (i % (HC / 8)) * 8;
       *(u32x4_t*)(W2c + row * P2 + c8) = r2[u];
     }
     b1c[tid] = rb1;
+    if (RAG) {                                               // columns C .. of every W1 row: zero, once (no chunk store touches them)
+      constexpr int PADP = (KPitch<C>::KP - C) / 8;
+      const u32x4_t z = {0u, 0u, 0u, 0u};
+      for (int i = tid; i < HC * PADP; i += 256) *(u32x4_t*)(W1c + (i / PADP) * P1 + C + (i % PADP) * 8) = z;
+    }
   };
 
   f32x4_t Y[TT][NT];
@@ -603,10 +616,12 @@ template <int C> struct ProjFwdLds {
 // `tile16`: see cln_rows_epilogue (per-wave LDS tile of the 16-bit output rows, beyond the fp32 patches), or nullptr.
 template <int C, int TT>
 __device__ __forceinline__ void proj_cln_fwd_body(const ProjClnArgs& p, char* smem, bf16_t* tile16) {
-  constexpr int KJ = C / 32, NT = C / 16, KC = 96, NKC = C / KC;
+  constexpr bool RAG = (C % 32) != 0;              // C = 48: one chunk of 64 K columns, the last 16 zero
+  constexpr int KJ = (C + 31) / 32, NT = C / 16, KC = RAG ? KJ * 32 : 96, NKC = RAG ? 1 : C / KC;
+  constexpr int KCR = RAG ? C : KC;                // columns of a chunk that exist in W
   constexpr int PW = KC + 8;                       // W chunk [C][PW]: K-contiguous columns kc·96 .. +95 of every row
-  constexpr int NP = C * KC / 8, PWN = (NP + 255) / 256;
-  static_assert(C % KC == 0, "K chunking");
+  constexpr int NP = C * KCR / 8, PWN = (NP + 255) / 256;
+  static_assert(RAG || C % KC == 0, "K chunking");
   bf16_t* Wc = (bf16_t*)smem;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4, lc = lane & 15;
   const int row0 = (blockIdx.x * 4 + wave) * (16 * TT);
@@ -615,8 +630,9 @@ __device__ __forceinline__ void proj_cln_fwd_body(const ProjClnArgs& p, char* sm
 #pragma unroll
   for (int tt = 0; tt < TT; ++tt) {
     const bf16_t* src = p.a + (size_t)min(row0 + tt * 16 + lc, p.e.M - 1) * C + g * 8;
+    const s16x8_t zero8 = {0, 0, 0, 0, 0, 0, 0, 0};
 #pragma unroll
-    for (int j = 0; j < KJ; ++j) af[tt][j].v = *(const s16x8_t*)(src + j * 32);
+    for (int j = 0; j < KJ; ++j) af[tt][j].v = (!RAG || j * 32 + g * 8 < C) ? *(const s16x8_t*)(src + j * 32) : zero8;
   }
   f32x4_t Y[TT][NT];
 #pragma unroll
@@ -629,13 +645,18 @@ __device__ __forceinline__ void proj_cln_fwd_body(const ProjClnArgs& p, char* sm
 #pragma unroll
     for (int u = 0; u < PWN; ++u) {
       const int i = min(tid + u * 256, NP - 1);
-      rw[u] = *(const u32x4_t*)(p.W + (size_t)(i / (KC / 8)) * C + kc * KC + (i % (KC / 8)) * 8);
+      rw[u] = *(const u32x4_t*)(p.W + (size_t)(i / (KCR / 8)) * C + kc * KC + (i % (KCR / 8)) * 8);
     }
     if (kc) __syncthreads();                       // every wave is done with the previous chunk
 #pragma unroll
     for (int u = 0; u < PWN; ++u) {
       const int i = tid + u * 256;
-      if (i < NP) *(u32x4_t*)(Wc + (i / (KC / 8)) * PW + (i % (KC / 8)) * 8) = rw[u];
+      if (i < NP) *(u32x4_t*)(Wc + (i / (KCR / 8)) * PW + (i % (KCR / 8)) * 8) = rw[u];
+    }
+    if (RAG) {
+      constexpr int PADP = (KC - KCR) / 8;
+      const u32x4_t z = {0u, 0u, 0u, 0u};
+      for (int i = tid; i < C * PADP; i += 256) *(u32x4_t*)(Wc + (i / PADP) * PW + KCR + (i % PADP) * 8) = z;
     }
     __syncthreads();
 #pragma unroll
@@ -670,17 +691,26 @@ struct TailFwdArgs {
 // The NEXT layer's fused q/k/v projection (HF:396-410) on the rows this workgroup has just produced: qkv = out16 · Wqkv^T + b.
 // Same row ownership as the tail, so the stand-alone QKV GEMM launch (and its re-read of out16) leaves the chain.  `tile`: the
 // wave's 16-bit output rows in LDS ([16·TT][C + 8], written by the final epilogue); the weight chunk and the patches reuse smem.
+template <int C> struct QkvEpi {
+  static constexpr int NC = (3 * C) % 96 == 0 ? 96 : 48;
+  static constexpr size_t bytes = (size_t)NC * KPitch<C>::P * 2 + (size_t)4 * 16 * (NC + 4) * 4;       // weight chunk + patches
+};
 template <int C, int TT>
 __device__ __forceinline__ void qkv_epilogue(const bf16_t* tile, const bf16_t* Wqkv, const float* bqkv, bf16_t* qkv, int M, char* smem) {
-  constexpr int KJ = C / 32, NC = 96, NCH = 3 * C / NC;          // 96 output columns per weight chunk
-  constexpr int PW = C + 8, NP = NC * C / 8, PWN = (NP + 255) / 256, CP = NC + 4;
+  constexpr bool RAG = (C % 32) != 0;
+  constexpr int KJ = (C + 31) / 32, NC = QkvEpi<C>::NC, NCH = 3 * C / NC;          // 96 (C = 48: 48) output columns per weight chunk
+  constexpr int PW = KPitch<C>::P, NP = NC * C / 8, PWN = (NP + 255) / 256, CP = NC + 4;
+  static_assert((3 * C) % NC == 0 && NC % 16 == 0, "qkv column chunks");
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4, lc = lane & 15;
   const int row0 = (blockIdx.x * 4 + wave) * (16 * TT);
   Frag<bf16_t> af[TT][KJ];
 #pragma unroll
   for (int tt = 0; tt < TT; ++tt)
 #pragma unroll
-    for (int j = 0; j < KJ; ++j) af[tt][j].v = *(const s16x8_t*)(tile + (tt * 16 + lc) * (C + 8) + j * 32 + g * 8);
+    for (int j = 0; j < KJ; ++j) {
+      const s16x8_t zero8 = {0, 0, 0, 0, 0, 0, 0, 0};
+      af[tt][j].v = (!RAG || j * 32 + g * 8 < C) ? *(const s16x8_t*)(tile + (tt * 16 + lc) * (C + 8) + j * 32 + g * 8) : zero8;
+    }
   bf16_t* Wc = (bf16_t*)smem;                                    // [NC][PW], K-contiguous rows (= output columns)
   float* Ct = (float*)(smem + (size_t)NC * PW * 2) + wave * 16 * CP;
   const int prow = lane >> 2, q = lane & 3;
@@ -695,6 +725,11 @@ __device__ __forceinline__ void qkv_epilogue(const bf16_t* tile, const bf16_t* W
     for (int u = 0; u < PWN; ++u) {
       const int i = tid + u * 256;
       if (i < NP) *(u32x4_t*)(Wc + (i / (C / 8)) * PW + (i % (C / 8)) * 8) = rw[u];
+    }
+    if (RAG) {
+      constexpr int PADP = (KPitch<C>::KP - C) / 8;
+      const u32x4_t z = {0u, 0u, 0u, 0u};
+      for (int i = tid; i < NC * PADP; i += 256) *(u32x4_t*)(Wc + (i / PADP) * PW + C + (i % PADP) * 8) = z;
     }
     __syncthreads();
     f32x4_t Y[TT][NC / 16];
@@ -720,8 +755,9 @@ __device__ __forceinline__ void qkv_epilogue(const bf16_t* tile, const bf16_t* W
       const int grow = row0 + tt * 16 + prow;
       if (grow < M) {
 #pragma unroll
-        for (int pp = 0; pp < NC / 32; ++pp) {
+        for (int pp = 0; pp < (NC + 31) / 32; ++pp) {
           const int col = pp * 32 + q * 8;
+          if (NC % 32 != 0 && col >= NC) continue;
           const float4 x0 = *(const float4*)(Ct + prow * CP + col), x1 = *(const float4*)(Ct + prow * CP + col + 4);
           float o[8] = {x0.x, x0.y, x0.z, x0.w, x1.x, x1.y, x1.z, x1.w};
           if (bqkv) {
@@ -742,7 +778,7 @@ template <int C, int HC, int TT, bool QKV>
 __global__ __launch_bounds__(256, 2) void tail_fwd_fused_kernel(TailFwdArgs p) {
   constexpr size_t PATCH = (size_t)4 * 16 * (C + 4) * 4, TILE = (size_t)4 * 16 * TT * (C + 8) * 2;
   constexpr size_t A = ProjFwdLds<C>::bytes > PATCH + TILE ? ProjFwdLds<C>::bytes : PATCH + TILE;
-  constexpr size_t QB = (size_t)96 * (C + 8) * 2 + (size_t)4 * 16 * (96 + 4) * 4;           // qkv epilogue: weight chunk + patches
+  constexpr size_t QB = QkvEpi<C>::bytes;           // qkv epilogue: weight chunk + patches
   constexpr size_t B = A > MlpFwdLds<C, HC>::bytes ? A : MlpFwdLds<C, HC>::bytes;
   constexpr size_t LDS = (QKV && QB > B) ? QB : B;
   __shared__ __attribute__((aligned(16))) char smem[LDS];
@@ -1109,7 +1145,8 @@ extern "C" int scot_block_tail_fwd(/* attention-output half */ const void* a, co
                                    /* dtype of z1 / z2: fp32, or the 16-bit operand format (only the backward's x-hat reads them) */ int z_dt,
                                    const float* time, int M, int rows_per_sample, int C, int hid, float eps, hipStream_t stream) {
   if (M <= 0 || rows_per_sample <= 0) return SCOT_ERR_SHAPE;
-  if (C != 96 && C != 192) return SCOT_ERR_UNSUPPORTED;
+  if (C != 96 && C != 192 && C != 48) return SCOT_ERR_UNSUPPORTED;
+  if (C == 48 && hid != 192) return SCOT_ERR_UNSUPPORTED;     // (one 192-wide hidden chunk: Poseidon-T / -S stage 0, mlp_ratio 4)
   if (mlp_chunk(C) != 64 || hid < 64 || hid % 64 != 0) return SCOT_ERR_UNSUPPORTED;
   if (z_dt != SCOT_F32 && z_dt != SCOT_BF16) return SCOT_ERR_DTYPE;
   if (!a || !Wo || !bo || !x || !h || !h16 || !gw_b1 || !bw_b1 || !W1 || !b1 || !W2 || !b2 || !out || !gw_b2 || !bw_b2) return SCOT_ERR_SHAPE;
@@ -1129,6 +1166,7 @@ extern "C" int scot_block_tail_fwd(/* attention-output half */ const void* a, co
   t.Wqkv = (const bf16_t*)Wqkv; t.bqkv = bqkv; t.qkv = (bf16_t*)qkv;
   const int tt_env = scot_mlp_tt_override();
   const int tt = C == 96 ? (tt_env ? tt_env : (M >= 64 * 2 * 512 ? 2 : 1)) : 1;
+  if (C == 48) return launch_tail_fwd<48, 192, 1>(t, stream);       // forward only: the backward of these layers stays layer by layer
   if (C == 96) return tt == 2 ? launch_tail_fwd<96, 64, 2>(t, stream) : launch_tail_fwd<96, 64, 1>(t, stream);
   return launch_tail_fwd<192, 64, 1>(t, stream);
 }

@@ -57,7 +57,9 @@ ENGINE_OPTIONS = dict(
     fused_min_rows=4096,      # ... from this many token rows on: a tail workgroup owns 64 / 128 rows, so 2048 rows are 32 workgroups on 256 CUs
                               # (round 6, profiles/round6/fused_min_rows_ab.txt: Poseidon-T batch 32 6.18 -> 5.72 ms, Poseidon-B batch 8 10.42 -> 9.41 ms;
                               #  16384 loses again: 5.85 — at 8192 rows the fused tail still wins)
-    fused_next_qkv=(96, 192),   # widths at which the forward tail also produces the next layer's q/k/v projection
+    fused_fwd48=True,         # C = 48 (Poseidon-T / -S stage 0): the FORWARD tail fused too (one 192-wide hidden chunk; the backward of these layers
+                              # stays layer by layer: mlp_fused.hip's backward layouts need C % 32 == 0) — round 6, profiles/round6/tail48_forward_ab.txt
+    fused_next_qkv=(48, 96, 192),   # widths at which the forward tail also produces the next layer's q/k/v projection
     fused_qkv_dgrad=(96,),      # widths at which the backward tail applies the previous layer's qkv data gradient as a prologue (192 spills)
     dgrad_wt=True,            # transposed 16-bit weight copies: data gradients as NT products (stages 2/3: 1.7-2.2x)
     grad_scale="auto",        # fp16 mode: initial power-of-two gradient scale ("auto" = from the loss normalisation; a number; "1" = off)
@@ -815,6 +817,9 @@ class ScOTEngine:
     def use_fused(self, part: str, C: int, rows: Optional[int] = None) -> bool:
         """csrc/mlp_fused.hip covers C = 96 / 192 in the 16-bit modes; a tail workgroup owns 64 (128) rows, so below `fused_min_rows` rows the
         launch leaves most CUs idle and the layer-by-layer GEMMs (hundreds of 64 x 64 tiles) win"""
+        if C == 48:     # forward tail only, as ONE launch (there are no stand-alone C = 48 halves)
+            return (self.fused_mlp and self.fused_tail and self.options["fused_fwd48"] and part in ("proj_fwd", "mlp_fwd")
+                    and (rows is None or rows >= self.fused_min_rows))
         return self.fused_mlp and C in (96, 192) and (rows is None or rows >= self.fused_min_rows)
 
     def wgrad(self, cm, dy, x, gw, b_gelu=False, dbias=None):
@@ -942,7 +947,9 @@ class ScOTEngine:
         dp2 = self.drop_path_scale(pre, B, 1) if self.stochastic else None
         hid = int(cfg.mlp_ratio * C)
         proj_f = self.use_fused("proj_fwd", C, B * L)
-        mlp_f = self.use_fused("mlp_fwd", C, B * L) and hid % 128 == 0
+        mlp_f = self.use_fused("mlp_fwd", C, B * L) and (hid % 128 == 0 if C != 48 else hid == 192)
+        if C == 48 and not (proj_f and mlp_f):
+            proj_f = mlp_f = False           # C = 48 exists as the whole tail only
         done_tail = False
         lean_used = False
         qkv_next = None
@@ -976,6 +983,8 @@ class ScOTEngine:
                 if lean:
                     raise RuntimeError("scot_block_tail_fwd rejected a shape the engine selected it for")
                 qkv_next = None
+                if C == 48:
+                    proj_f = mlp_f = False   # layer by layer
         if done_tail:
             pass
         elif proj_f:

@@ -838,6 +838,71 @@ def test_block_tail_fwd_fused(train, cond, B, L, C, next_qkv):
         assert (q != qr).float().mean() < 0.02      # same products, fp32 sums in a different order: rare last-place flips only
 
 
+@pytest.mark.parametrize("train", [True, False])
+@pytest.mark.parametrize("cond", [True, False])
+@pytest.mark.parametrize("B,L", [(2, 1024), (3, 200), (32, 1024)])
+@pytest.mark.parametrize("next_qkv", [False, True])
+def test_block_tail_fwd_fused_c48(train, cond, B, L, next_qkv):
+    """scot_block_tail_fwd at C = 48 (Poseidon-T / -S stage 0, reference train.py:35-47; forward only): the contraction over the 48 channels
+    runs as two 32-wide MFMA K-steps whose last 16 columns are zero on both sides, the row layout skips the pieces that do not exist, the
+    statistics divide by 48.  There are no stand-alone C = 48 fused halves to compare with, so the reference is the chain restated in torch
+    with the kernel's rounding points (16-bit h16 / gelu(u) / out16, fp32 everything else): fp32 tensors to accumulation order, 16-bit
+    tensors to rare last-place flips."""
+    C, hid = 48, 192
+    M = B * L
+    hd = ops.half_dtype() if hasattr(ops, "half_dtype") else torch.bfloat16
+    a = rnd(M, C, seed=11).to(hd)
+    x = rnd(M, C, seed=12)
+    wo, bo = rnd(C, C, scale=C ** -0.5, seed=13).to(hd), rnd(C, seed=14, scale=0.2)
+    w1, b1 = rnd(hid, C, scale=C ** -0.5, seed=2).to(hd), rnd(hid, seed=3, scale=0.2)
+    w2, b2 = rnd(C, hid, scale=hid ** -0.5, seed=4).to(hd), rnd(C, seed=5, scale=0.2)
+    t = torch.rand(B, device=DEV) if cond else None
+    s1 = (torch.rand(B, device=DEV) > 0.3).float() / 0.7
+    s2 = (torch.rand(B, device=DEV) > 0.3).float() / 0.7
+    n1 = [rnd(C, seed=20, scale=0.3) if cond else None, 1 + rnd(C, seed=21, scale=0.1), rnd(C, seed=22, scale=0.1) if cond else None, rnd(C, seed=23, scale=0.1)]
+    n2 = [rnd(C, seed=6, scale=0.3) if cond else None, 1 + rnd(C, seed=7, scale=0.1), rnd(C, seed=8, scale=0.1) if cond else None, rnd(C, seed=9, scale=0.1)]
+    f = lambda *s, dtype=torch.float32: torch.full(s, float("nan"), device=DEV, dtype=dtype)
+    o = dict(h=f(M, C), h16=f(M, C, dtype=hd), out=f(M, C), out16=f(M, C, dtype=hd))
+    o.update(dict(z1=f(M, C), m1=f(M), r1=f(M), u=f(M, hid, dtype=hd), gp=f(M, hid, dtype=hd), z2=f(M, C), m2=f(M), r2=f(M)) if train else
+             dict(z1=None, m1=None, r1=None, u=None, gp=None, z2=None, m2=None, r2=None))
+    wq, bq = rnd(3 * C, C, scale=C ** -0.5, seed=41).to(hd), rnd(3 * C, seed=42, scale=0.2)
+    q = torch.full((M, 3 * C), float("nan"), device=DEV, dtype=hd) if next_qkv else None
+    assert ops.block_tail_fwd((a, wo, bo, x, o["h"], o["h16"], o["z1"], o["m1"], o["r1"], n1[0], n1[1], n1[2], n1[3], s1),
+                              (w1, b1, w2, b2, o["out"], o["out16"], o["u"], o["gp"], o["z2"], o["m2"], o["r2"], n2[0], n2[1], n2[2], n2[3], s2),
+                              t, M, L, C, hid, 1e-5, *((wq, bq, q) if next_qkv else ()))
+    torch.cuda.synchronize()
+    D = torch.float64
+    per_row = lambda v: v.repeat_interleave(L).unsqueeze(1).to(D)
+
+    def cln(z, n, s, resid):
+        mu = z.mean(-1, keepdim=True)
+        var = (z * z).mean(-1, keepdim=True) - mu * mu
+        rs = 1.0 / torch.sqrt(var + 1e-5)
+        ga = n[1].to(D) + (n[0].to(D) * per_row(t) if cond else 0.0)
+        be = n[3].to(D) + (n[2].to(D) * per_row(t) if cond else 0.0)
+        return resid.to(D) + per_row(s) * (ga * ((z - mu) * rs) + be), mu.squeeze(1), rs.squeeze(1)
+    z1 = a.to(D) @ wo.to(D).t() + bo.to(D)
+    h, m1, r1 = cln(z1, n1, s1, x)
+    h16 = o["h16"]                                     # the kernel's own rounding of h feeds its second half
+    assert rel(o["h"], h) < 2e-6 and rel(h16.float(), h) < 3e-3 and (h16 != h.to(torch.float32).to(hd)).float().mean() < 0.02
+    u = h16.to(D) @ w1.to(D).t() + b1.to(D)
+    act = torch.nn.functional.gelu(u)
+    gp = 0.5 * (1 + torch.erf(u / math.sqrt(2))) + u * torch.exp(-0.5 * u * u) / math.sqrt(2 * math.pi)
+    act16 = o["u"] if train else act.to(torch.float32).to(hd)
+    z2 = act16.to(D) @ w2.to(D).t() + b2.to(D)
+    out, m2, r2 = cln(z2, n2, s2, o["h"])
+    tol16 = 6e-3 if hd == torch.bfloat16 else 1e-3
+    assert torch.isfinite(o["out"]).all() and rel(o["out"], out) < (2e-6 if train else tol16), rel(o["out"], out)
+    assert rel(o["out16"].float(), o["out"]) < tol16
+    if train:
+        assert rel(o["z1"], z1) < 2e-6 and rel(o["m1"], m1) < 2e-6 and rel(o["r1"], r1) < 2e-6
+        assert rel(o["u"].float(), act) < tol16 and rel(o["gp"].float(), gp) < tol16
+        assert rel(o["z2"], z2) < 2e-6 and rel(o["m2"], m2) < 1e-5 and rel(o["r2"], r2) < 2e-6
+    if next_qkv:
+        ref = o["out16"].to(D) @ wq.to(D).t() + bq.to(D)
+        assert torch.isfinite(q.float()).all() and rel(q.float(), ref) < tol16
+
+
 @pytest.mark.parametrize("prologue", [False, True])
 @pytest.mark.parametrize("cond", [True, False])
 @pytest.mark.parametrize("B,L,C", [(2, 1024, 96), (3, 192, 96), (64, 1024, 96), (2, 256, 192), (5, 64, 192)])

@@ -13,7 +13,7 @@ import torch
 HERE = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, os.path.join(HERE, "hipemu"))
 from conftest import load_fixture, rel_l2  # noqa: E402
-from poseidon_amd import engine as engine_mod  # noqa: E402
+from poseidon_amd import engine as engine_mod, ops  # noqa: E402
 from poseidon_amd.config import ScOTConfig  # noqa: E402
 from poseidon_amd.geometry import param_shapes  # noqa: E402
 from poseidon_amd.synth import apply_obstacle, synth_inputs, synth_obstacle_mask, synth_state_dict  # noqa: E402
@@ -294,6 +294,36 @@ def test_engine_fused_block_kernels(emu, monkeypatch):
     assert rel_l2(res["1"][1].numpy(), res["0"][1].numpy()) < 2e-2
     assert rel_l2(res["1"][2].numpy(), res["0"][2].numpy()) < 5e-2  # gradient arena (every parameter), two bf16 rounding realisations
     assert abs(res["1"][0] - res["0"][0]) < 5e-3 * abs(res["0"][0])
+
+
+def test_engine_fused_forward_tail_c48(emu, monkeypatch):
+    """Round 6: the forward tail fused at C = 48 (Poseidon-T / -S stage 0, reference train.py:35-47) with the layer-by-layer backward behind
+    it, inside the engine (fp16, two blocks at C = 48 so that the next layer's qkv epilogue runs, one at C = 96): against the layer-by-layer
+    forward of the same model — same loss, prediction and gradients up to the order of the fp32 sums — and against the oracle."""
+    from oracle import scot_cpu
+    cfg = ScOTConfig(image_size=32, patch_size=4, num_channels=4, num_out_channels=4, embed_dim=48, depths=[2, 1], num_heads=[3, 6],
+                     skip_connections=[1, 0], window_size=4, mlp_ratio=4.0, qkv_bias=True, drop_path_rate=0.0, hidden_act="gelu", p=1,
+                     channel_slice_list_normalized_loss=[0, 1, 3, 4], residual_model="convnext", use_conditioning=True,
+                     learn_residual=False)
+    sd = synth_state_dict(param_shapes(cfg), "trained")
+    pv, t, lab = synth_inputs(1, 4, 4, 32, "smooth")
+    res = {}
+    for flag in (False, True):
+        monkeypatch.setitem(engine_mod.ENGINE_OPTIONS, "fused_fwd48", flag)
+        calls = []
+        real = ops.block_tail_fwd
+        monkeypatch.setattr(ops, "block_tail_fwd", lambda *a, **k: (calls.append(a[5]), real(*a, **k))[1])
+        model, loss, pred = run_engine(cfg, sd, pv, t, lab, None, "fp16")
+        monkeypatch.setattr(ops, "block_tail_fwd", real)
+        assert (48 in calls) == flag, calls
+        res[flag] = (float(loss), pred.clone(), model._arena.grad.clone())
+    with torch.no_grad():
+        oloss, opred = scot_cpu.scot_forward({k: v.clone() for k, v in sd.items()}, cfg, pv, t, lab)
+    e_plain, e_fused = rel_l2(res[False][1].numpy(), opred.numpy()), rel_l2(res[True][1].numpy(), opred.numpy())
+    dp, dg = rel_l2(res[True][1].numpy(), res[False][1].numpy()), rel_l2(res[True][2].numpy(), res[False][2].numpy())
+    print(f"\n[C = 48 forward tail] vs oracle: layer-by-layer {e_plain:.2e}, fused {e_fused:.2e}; fused vs layer-by-layer {dp:.2e}; grads {dg:.2e}")
+    assert e_fused < max(4e-3, 1.5 * e_plain) and dp < 2e-3 and dg < 1e-2
+    assert abs(res[True][0] - res[False][0]) < 1e-3 * abs(res[False][0])
 
 
 def test_engine_lean_layer_tail(emu, monkeypatch):
