@@ -6,6 +6,10 @@
 #pragma once
 #include "common.h"
 
+// K pitch of an LDS tile whose contraction (or fragment k index) runs over the C channels: C + 8, or — C % 32 != 0 (C = 48: the layer tails of
+// Poseidon-T / -S stage 0) — the channels rounded up to whole 32-wide MFMA K-steps + 8, the columns >= C zero-filled
+template <int C> struct KPitch { static constexpr int KP = (C + 31) / 32 * 32, P = KP + 8; };
+
 struct ClnRowsOut {
   const float* bias;                    // [C] bias of the GEMM that produced the accumulators
   void* z; int z_dt;                    // training: pre-norm rows [M, C] (fp32, or 16-bit: only the backward's x-hat reads them)
@@ -119,7 +123,7 @@ struct ClnRowsBwd {
 
 // LDS needed at `lds` (16-byte aligned, dead): 4 waves x 16 x (C+8) bf16 patches, then 4 x 2 x C floats of column sums.
 template <int C> struct ClnBwdLds {
-  static constexpr size_t patch_bytes = (size_t)4 * 16 * (C + 8) * 2;
+  static constexpr size_t patch_bytes = (size_t)4 * 16 * KPitch<C>::P * 2;
   static constexpr size_t bytes = patch_bytes + (size_t)4 * 2 * C * 4;
 };
 
@@ -131,9 +135,10 @@ template <int C> struct ClnBwdLds {
 // GREG: the rows of g are already in registers (greg[tt][pp][j], same lane layout as the loads they replace) — the fused
 // block-tail backward hands the MLP half's result straight to the attention half's norm.
 template <int C, int TT, bool GREG = false>
-__device__ __forceinline__ void cln_bwd_rows(Frag<bf16_t> (&dzf)[TT][C / 32], char* lds, int wg_row0, const ClnRowsBwd& p,
-                                             const float (*greg)[C / 32][8] = nullptr) {
-  constexpr int KJ = C / 32, PD = C + 8;
+__device__ __forceinline__ void cln_bwd_rows(Frag<bf16_t> (&dzf)[TT][(C + 31) / 32], char* lds, int wg_row0, const ClnRowsBwd& p,
+                                             const float (*greg)[(C + 31) / 32][8] = nullptr) {
+  constexpr int KJ = (C + 31) / 32, PD = KPitch<C>::P;
+  constexpr bool RAG = (C % 32) != 0;          // C = 48: the row pieces at columns >= C do not exist; their lanes keep the dz patch's pad zero
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int prow = lane >> 2, q = lane & 3;
   bf16_t* Dz = (bf16_t*)lds + wave * 16 * PD;
@@ -168,6 +173,11 @@ __device__ __forceinline__ void cln_bwd_rows(Frag<bf16_t> (&dzf)[TT][C / 32], ch
     for (int pp = 0; pp < KJ; ++pp) {
       const int col = pp * 32 + q * 8;
       float zz[8], ga[8];
+      if (RAG && col >= C) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { d[pp][j] = 0.f; xh[pp][j] = 0.f; }
+        continue;
+      }
       if (GREG) {
 #pragma unroll
         for (int j = 0; j < 8; ++j) d[pp][j] = greg[tt][pp][j];
@@ -195,7 +205,10 @@ __device__ __forceinline__ void cln_bwd_rows(Frag<bf16_t> (&dzf)[TT][C / 32], ch
       float o[8];
 #pragma unroll
       for (int j = 0; j < 8; ++j) o[j] = rstd * (d[pp][j] - m1 - xh[pp][j] * m2);
-      if (valid) st8(p.dz, SCOT_BF16, base + col, o);
+      if (RAG && col >= C) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) o[j] = 0.f;
+      } else if (valid) st8(p.dz, SCOT_BF16, base + col, o);
       store8_ct(Dz + prow * PD + col, o);
     }
     __builtin_amdgcn_wave_barrier();
@@ -213,12 +226,14 @@ __device__ __forceinline__ void cln_bwd_rows(Frag<bf16_t> (&dzf)[TT][C / 32], ch
     }
   if (lane < 4) {
 #pragma unroll
-    for (int pp = 0; pp < KJ; ++pp)
+    for (int pp = 0; pp < KJ; ++pp) {
+      if (RAG && pp * 32 + q * 8 >= C) continue;
 #pragma unroll
       for (int j = 0; j < 8; ++j) {
         red[(wave * 2 + 0) * C + pp * 32 + q * 8 + j] = ag[pp][j];
         red[(wave * 2 + 1) * C + pp * 32 + q * 8 + j] = ab[pp][j];
       }
+    }
   }
   __syncthreads();
   constexpr int CP = (C + 63) / 64 * 64;

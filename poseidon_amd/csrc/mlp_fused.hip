@@ -41,9 +41,6 @@ struct MlpArgs {
   float eps;
 };
 
-// K pitch of a weight tile whose contraction runs over the C channels: C + 8, or — C % 32 != 0 (C = 48: the forward tail of Poseidon-T / -S
-// stage 0) — the channels rounded up to whole 32-wide MFMA K-steps + 8, the columns >= C zero-filled
-template <int C> struct KPitch { static constexpr int KP = (C + 31) / 32 * 32, P = KP + 8; };
 template <int C, int HC> struct MlpFwdLds {
   static constexpr size_t WBYTES = (size_t)(HC * KPitch<C>::P + C * (HC + 8)) * 2 + (size_t)256 * 4, PBYTES = (size_t)4 * 16 * (C + 4) * 4;
   static constexpr size_t bytes = WBYTES > PBYTES ? WBYTES : PBYTES;
@@ -322,7 +319,8 @@ __device__ __forceinline__ Frag<bf16_t> lds_frag_ks_perm(const bf16_t* t, int pi
 }
 
 template <int C, int HC> struct MlpBwdLds {
-  static constexpr size_t WBYTES = (size_t)(HC * (C + 8) + C * (HC + 8)) * 2, PBYTES = (size_t)4 * 16 * (C + 4) * 4;
+  // (the W2 chunk is read with the channels as the fragment's k index: KPitch<C>::KP rows, the rows >= C zero)
+  static constexpr size_t WBYTES = (size_t)(HC * (C + 8) + KPitch<C>::KP * (HC + 8)) * 2, PBYTES = (size_t)4 * 16 * (C + 4) * 4;
   static constexpr size_t P1BYTES = ClnBwdLds<C>::bytes;
   static constexpr size_t bytes = WBYTES > PBYTES ? (WBYTES > P1BYTES ? WBYTES : P1BYTES) : (PBYTES > P1BYTES ? PBYTES : P1BYTES);
   // RECOMP: the workgroup's 64·TT rows of h16 stay in LDS BEHIND the region above for the whole hidden loop ([64·TT][C + 8])
@@ -337,9 +335,10 @@ template <int C, int HC> struct MlpBwdLds {
 // the data gradient anyway (read K-contiguously here, with the row permutation 8a+4t+b of the forward's fragment convention applied
 // at the read), bit-identical to the forward's u, and the derivative is rounded to 16 bits exactly as the forward used to store it.
 template <int C, int HC, int TT, bool KEEP, bool GIN = false, bool RECOMP = false>
-__device__ __forceinline__ void mlp_bwd_body(const MlpBwdArgs& p, char* smem, float (*gkeep)[C / 32][8],
-                                             const float (*gin)[C / 32][8] = nullptr) {
-  constexpr int KJ = C / 32, NT = C / 16, NB = HC / 32;
+__device__ __forceinline__ void mlp_bwd_body(const MlpBwdArgs& p, char* smem, float (*gkeep)[(C + 31) / 32][8],
+                                             const float (*gin)[(C + 31) / 32][8] = nullptr) {
+  constexpr bool RAG = (C % 32) != 0;  // C = 48 (one hidden chunk, no recomputation): the channel K-steps' last 16 columns are zero on both sides
+  constexpr int KJ = (C + 31) / 32, NT = C / 16, NB = HC / 32;
   constexpr int P1 = C + 8;            // W1 chunk [HC][P1]: k = hidden (rows), columns = channels
   constexpr int P2 = HC + 8;           // W2 chunk [C][P2]:  k = channels (rows), columns = hidden
   constexpr int CP = C + 4;            // epilogue patch pitch (floats)
@@ -349,7 +348,8 @@ __device__ __forceinline__ void mlp_bwd_body(const MlpBwdArgs& p, char* smem, fl
   // one LDS region (MlpBwdLds<C, HC>::bytes), three lives: [dz patches | column sums] (phase 1) -> weight chunks (phase 2) ->
   // fp32 patches (phase 3)
   static_assert((W1_EL * 2) % 16 == 0, "layout");
-  static_assert(N1 % 256 == 0 && N2 % 256 == 0, "weight chunk pieces must divide over the 256 threads");
+  static_assert(RAG || (N1 % 256 == 0 && N2 % 256 == 0), "weight chunk pieces must divide over the 256 threads");
+  static_assert(!RAG || !RECOMP, "the recomputing form reads W1 K-contiguously: C % 32 == 0 only");
   bf16_t* W1c = (bf16_t*)smem;
   bf16_t* W2c = W1c + W1_EL;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4, lc = lane & 15;
@@ -377,12 +377,18 @@ __device__ __forceinline__ void mlp_bwd_body(const MlpBwdArgs& p, char* smem, fl
 #pragma unroll
     for (int u = 0; u < PW1; ++u) {
       const int i = tid + u * 256;                 // pieces divide evenly (static_assert): unguarded, see the forward kernel
+      if (RAG && i >= N1) continue;                // (C = 48 runs one chunk)
       *(u32x4_t*)(W1c + (i / (C / 8)) * P1 + (i % (C / 8)) * 8) = r1[u];
     }
 #pragma unroll
     for (int u = 0; u < PW2; ++u) {
       const int i = tid + u * 256;
+      if (RAG && i >= N2) continue;
       *(u32x4_t*)(W2c + (i / (HC / 8)) * P2 + (i % (HC / 8)) * 8) = r2[u];
+    }
+    if (RAG) {                                     // rows C .. KP-1 of the W2 chunk (k index of dz·W2 beyond the channels): zero
+      const u32x4_t z = {0u, 0u, 0u, 0u};
+      for (int i = tid; i < (KPitch<C>::KP - C) * (HC / 8); i += 256) *(u32x4_t*)(W2c + (C + i / (HC / 8)) * P2 + (i % (HC / 8)) * 8) = z;
     }
   };
 
@@ -535,6 +541,13 @@ __device__ __forceinline__ void mlp_bwd_body(const MlpBwdArgs& p, char* smem, fl
 #pragma unroll
       for (int pp = 0; pp < KJ; ++pp) {
         const int col = pp * 32 + q * 8;
+        if (RAG && col >= C) {
+          if (KEEP) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) gkeep[tt][pp][j] = 0.f;
+          }
+          continue;
+        }
         const float4 x0 = *(const float4*)(Ct + prow * CP + col), x1 = *(const float4*)(Ct + prow * CP + col + 4);
         float gi[8], o[8];
         ld8(p.g, SCOT_F32, base + col, gi);
@@ -814,17 +827,19 @@ template <int C> struct ProjBwdLds {
 
 // GREG: g rows come in registers (fused block tail), see cln_bwd_rows.  `smem`: ProjBwdLds<C>::bytes, dead on entry.
 template <int C, int TT, bool GREG>
-__device__ __forceinline__ void proj_cln_bwd_body(const ProjClnBwdArgs& p, char* smem, const float (*greg)[C / 32][8]) {
-  constexpr int NT = C / 16, KC = 96, NKC = C / KC;
+__device__ __forceinline__ void proj_cln_bwd_body(const ProjClnBwdArgs& p, char* smem, const float (*greg)[(C + 31) / 32][8]) {
+  constexpr bool RAG = (C % 32) != 0;              // C = 48: one chunk of 64 rows n, the last 16 zero
+  constexpr int NT = C / 16, KC = RAG ? KPitch<C>::KP : 96, NKC = RAG ? 1 : C / KC;
+  constexpr int KCR = RAG ? C : KC;                // rows of a chunk that exist in W
   constexpr int PW = C + 8;                        // W chunk [KC rows n][PW]: the contraction index runs over rows (K-strided)
-  constexpr int NP = KC * C / 8, PWN = (NP + 255) / 256;
+  constexpr int NP = KCR * C / 8, PWN = (NP + 255) / 256;
   constexpr int CP = C + 4;
   bf16_t* Wc = (bf16_t*)smem;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4, lc = lane & 15;
   const int wg_row0 = blockIdx.x * (64 * TT);
   const int row0 = wg_row0 + wave * (16 * TT);
 
-  Frag<bf16_t> dzf[TT][C / 32];
+  Frag<bf16_t> dzf[TT][(C + 31) / 32];
   cln_bwd_rows<C, TT, GREG>(dzf, smem, wg_row0, p.b, greg);
   f32x4_t Y[TT][NT];
 #pragma unroll
@@ -842,6 +857,10 @@ __device__ __forceinline__ void proj_cln_bwd_body(const ProjClnBwdArgs& p, char*
     for (int u = 0; u < PWN; ++u) {
       const int i = tid + u * 256;
       if (i < NP) *(u32x4_t*)(Wc + (i / (C / 8)) * PW + (i % (C / 8)) * 8) = rw[u];
+    }
+    if (RAG) {
+      const u32x4_t z = {0u, 0u, 0u, 0u};
+      for (int i = tid; i < (KC - KCR) * (C / 8); i += 256) *(u32x4_t*)(Wc + (KCR + i / (C / 8)) * PW + (i % (C / 8)) * 8) = z;
     }
     __syncthreads();
 #pragma unroll
@@ -867,8 +886,9 @@ __device__ __forceinline__ void proj_cln_bwd_body(const ProjClnBwdArgs& p, char*
     const int grow = row0 + tt * 16 + prow;
     if (grow < p.b.M) {
 #pragma unroll
-      for (int pp = 0; pp < C / 32; ++pp) {
+      for (int pp = 0; pp < (C + 31) / 32; ++pp) {
         const int col = pp * 32 + q * 8;
+        if (RAG && col >= C) continue;
         const float4 x0 = *(const float4*)(Ct + prow * CP + col), x1 = *(const float4*)(Ct + prow * CP + col + 4);
         const float o[8] = {x0.x, x0.y, x0.z, x0.w, x1.x, x1.y, x1.z, x1.w};
         st8(p.da, SCOT_BF16, (size_t)grow * C + col, o);
@@ -978,8 +998,9 @@ __global__ __launch_bounds__(256, 2) void tail_bwd_fused_kernel(TailBwdArgs p) {
   constexpr size_t L1 = MlpBwdLds<C, HC>::bytes + (RECOMP ? MlpBwdLds<C, HC>::htile_bytes(TT) : 0);
   constexpr size_t LDS = L0 > L1 ? L0 : L1;        // (the prologue's weight chunk + patches fit inside ProjBwdLds)
   __shared__ __attribute__((aligned(16))) char smem[LDS];
-  float gk[TT][C / 32][8];
-  if (PRO) {
+  float gk[TT][(C + 31) / 32][8];
+  if constexpr (PRO) {
+    static_assert(C % 32 == 0, "the qkv-dgrad prologue exists for C % 32 == 0 only");
     qkv_dgrad_prologue<C, TT>(p.dqkv, p.Wqkv, (float*)p.m.g, p.m.M, smem, p.m.use_tr, gk);
     __syncthreads();                     // the prologue's patches are dead
     // C = 96 without recomputation: the updated rows go on in registers; otherwise (no registers to spare) the norm re-reads the
@@ -1073,7 +1094,7 @@ static int tail_rows_per_wg(int C, int M, int rows_per_sample) {
   return 64 * tt;
 }
 extern "C" int scot_block_tail_workgroups(int M, int rows_per_sample, int C) {
-  if (M <= 0 || rows_per_sample <= 0 || (C != 96 && C != 192)) return 0;
+  if (M <= 0 || rows_per_sample <= 0 || (C != 96 && C != 192 && C != 48)) return 0;
   const int r = tail_rows_per_wg(C, M, rows_per_sample);
   return (M + r - 1) / r;
 }
@@ -1101,7 +1122,9 @@ extern "C" int scot_block_tail_bwd(const float* g, float* g_out,
                                    float* partial1,
                                    const float* time, int M, int rows_per_sample, int C, int hid, hipStream_t stream) {
   if (M <= 0 || rows_per_sample <= 0) return SCOT_ERR_SHAPE;
-  if (C != 96 && C != 192) return SCOT_ERR_UNSUPPORTED;
+  if (C != 96 && C != 192 && C != 48) return SCOT_ERR_UNSUPPORTED;
+  // C = 48 (Poseidon-T / -S stage 0): the stored-gelu' form without the qkv prologue, one 192-wide hidden chunk
+  if (C == 48 && (hid != 192 || dact == nullptr || dqkv != nullptr)) return SCOT_ERR_UNSUPPORTED;
   if (mlp_chunk(C) != 64 || hid < 64 || hid % 64 != 0 || rows_per_sample % 64 != 0) return SCOT_ERR_UNSUPPORTED;
   if ((dqkv == nullptr) != (Wqkv == nullptr)) return SCOT_ERR_SHAPE;
   if (dqkv && g_out != g) return SCOT_ERR_UNSUPPORTED;        // the prologue updates g in place
@@ -1128,6 +1151,10 @@ extern "C" int scot_block_tail_bwd(const float* g, float* g_out,
   a.pj.b.sscale = sscale1; a.pj.b.dz = (bf16_t*)dz1; a.pj.b.d_gw_w = d_gw_w1; a.pj.b.d_gw_b = d_gw_b1; a.pj.b.d_bw_w = d_bw_w1;
   a.pj.b.d_bw_b = d_bw_b1; a.pj.b.partial = partial1; a.pj.b.M = M; a.pj.b.rows_per_sample = rows_per_sample;
   a.dqkv = (const bf16_t*)dqkv; a.Wqkv = (const bf16_t*)Wqkv;
+  if (C == 48) {
+    hipLaunchKernelGGL((tail_bwd_fused_kernel<48, 192, 1, false, false>), dim3((M + 63) / 64), dim3(256), 0, stream, a);
+    return scot_check_launch();
+  }
   if (C == 96) return tt == 2 ? launch_tail_bwd<96, 64, 2>(a, stream) : launch_tail_bwd<96, 64, 1>(a, stream);
   return launch_tail_bwd<192, 64, 1>(a, stream);
 }

@@ -57,8 +57,10 @@ ENGINE_OPTIONS = dict(
     fused_min_rows=4096,      # ... from this many token rows on: a tail workgroup owns 64 / 128 rows, so 2048 rows are 32 workgroups on 256 CUs
                               # (round 6, profiles/round6/fused_min_rows_ab.txt: Poseidon-T batch 32 6.18 -> 5.72 ms, Poseidon-B batch 8 10.42 -> 9.41 ms;
                               #  16384 loses again: 5.85 — at 8192 rows the fused tail still wins)
-    fused_fwd48=True,         # C = 48 (Poseidon-T / -S stage 0): the FORWARD tail fused too (one 192-wide hidden chunk; the backward of these layers
-                              # stays layer by layer: mlp_fused.hip's backward layouts need C % 32 == 0) — round 6, profiles/round6/tail48_forward_ab.txt
+    fused_fwd48=True,         # C = 48 (Poseidon-T / -S stage 0): the forward tail fused too (one 192-wide hidden chunk, padded-K MFMA steps)
+    fused_bwd48=False,        # ... and the backward tail (the round-2 form: gelu'(u) stored, du stored, no qkv prologue; the lean form and
+                              # scot_wgrad_mlp need C % 32 == 0): built and tested, measured NEUTRAL on Poseidon-T batch 32 (the weight-gradient
+                              # stream paces that backward: 3.56 ms either way) — profiles/round6/tail48_ab.txt
     fused_next_qkv=(48, 96, 192),   # widths at which the forward tail also produces the next layer's q/k/v projection
     fused_qkv_dgrad=(96,),      # widths at which the backward tail applies the previous layer's qkv data gradient as a prologue (192 spills)
     dgrad_wt=True,            # transposed 16-bit weight copies: data gradients as NT products (stages 2/3: 1.7-2.2x)
@@ -671,7 +673,7 @@ class ScOTEngine:
         ok = self._lean_cache.get(key)
         if ok is None:
             w2 = pre + ".output.dense.weight"
-            ok = (self.use_fused("mlp_bwd", C, rows) and self.use_fused("proj_bwd", C, rows) and self.use_fused("mlp_fwd", C, rows) and self.use_fused("proj_fwd", C, rows)
+            ok = (C != 48 and self.use_fused("mlp_bwd", C, rows) and self.use_fused("proj_bwd", C, rows) and self.use_fused("mlp_fwd", C, rows) and self.use_fused("proj_fwd", C, rows)
                   and self.fused_tail and hid == 4 * C and hid % 128 == 0 and rows_per_sample % 64 == 0
                   and self.WT(w2, self.W(w2)) is not None and ops.tail_workgroups(rows, rows_per_sample, C) > 0)
             if ok:
@@ -817,8 +819,8 @@ class ScOTEngine:
     def use_fused(self, part: str, C: int, rows: Optional[int] = None) -> bool:
         """csrc/mlp_fused.hip covers C = 96 / 192 in the 16-bit modes; a tail workgroup owns 64 (128) rows, so below `fused_min_rows` rows the
         launch leaves most CUs idle and the layer-by-layer GEMMs (hundreds of 64 x 64 tiles) win"""
-        if C == 48:     # forward tail only, as ONE launch (there are no stand-alone C = 48 halves)
-            return (self.fused_mlp and self.fused_tail and self.options["fused_fwd48"] and part in ("proj_fwd", "mlp_fwd")
+        if C == 48:     # the whole tail as ONE launch per direction (there are no stand-alone C = 48 halves)
+            return (self.fused_mlp and self.fused_tail and self.options["fused_fwd48" if part.endswith("_fwd") else "fused_bwd48"]
                     and (rows is None or rows >= self.fused_min_rows))
         return self.fused_mlp and C in (96, 192) and (rows is None or rows >= self.fused_min_rows)
 
@@ -1113,8 +1115,10 @@ class ScOTEngine:
         a = pre + ".attention.self."
         L, Lp = H * W, Hp * Wp
         hid = int(cfg.mlp_ratio * C)
-        mlp_f = self.use_fused("mlp_bwd", C, B * L) and hid % 128 == 0 and L % 64 == 0
+        mlp_f = self.use_fused("mlp_bwd", C, B * L) and (hid % 128 == 0 if C != 48 else hid == 192) and L % 64 == 0
         proj_f = self.use_fused("proj_bwd", C, B * L) and L % 64 == 0
+        if C == 48 and not (mlp_f and proj_f and rec.get("gp") is not None):
+            mlp_f = proj_f = False           # C = 48 exists as the whole tail only
         tail_f = mlp_f and proj_f and self.fused_tail
         can_prologue = tail_f and C in self.fused_qkv_dgrad and not padded
         if pend is not None and not can_prologue:
@@ -1178,6 +1182,8 @@ class ScOTEngine:
             if not done_tail and pend is not None:
                 g = self.dgrad_into(cm, pend[0], pend[1], g, wt=pend[2])
             pend = None
+            if not done_tail and C == 48:
+                mlp_f = proj_f = False       # layer by layer
             if done_tail:
                 g = gout
                 self.linear_bwd_params(pre + ".output.dense.weight", pre + ".output.dense.bias", d_y2, rec["u"])

@@ -375,6 +375,11 @@ def test_fused_tail_forward_c48(gpu_test_bodies, train, cond, B, L):
     gpu_test_bodies.test_block_tail_fwd_fused_c48(train, cond, B, L, next_qkv=True)
 
 
+@pytest.mark.parametrize("cond,B,L", [(True, 1, 64), (False, 2, 64)])
+def test_fused_tail_backward_c48(gpu_test_bodies, cond, B, L):
+    gpu_test_bodies.test_block_tail_bwd_fused_c48(cond, B, L)
+
+
 @pytest.mark.parametrize("cond,B,L,C", [(True, 1, 64, 96), (False, 1, 64, 192)] + full_only((False, 2, 128, 96), (True, 3, 64, 96),
                                                                                           (True, 1, 64, 192)))
 def test_fused_mlp_and_projection_backward(gpu_test_bodies, cond, B, L, C):

@@ -903,6 +903,64 @@ def test_block_tail_fwd_fused_c48(train, cond, B, L, next_qkv):
         assert torch.isfinite(q.float()).all() and rel(q.float(), ref) < tol16
 
 
+@pytest.mark.parametrize("cond", [True, False])
+@pytest.mark.parametrize("B,L", [(2, 1024), (3, 192), (32, 1024)])
+def test_block_tail_bwd_fused_c48(cond, B, L):
+    """scot_block_tail_bwd at C = 48 (the stored-gelu' form: Poseidon-T / -S stage 0) against the chain restated in fp64, stage by stage
+    from the kernel's own 16-bit intermediates: dz2 = CLN_bwd(s2·g) -> du = (dz2·W2) ⊙ gelu'(u) -> g' = g + du·W1 -> dz1 = CLN_bwd(s1·g')
+    -> da = dz1·Wo, and the eight norm-parameter gradients (atomics)."""
+    C, hid = 48, 192
+    M = B * L
+    hd = ops.half_dtype()
+    D = torch.float64
+    g0 = rnd(M, C, seed=31)
+    z2, z1 = rnd(M, C, seed=32), rnd(M, C, seed=33)
+    st = lambda z: (z.mean(-1).contiguous(), (1.0 / torch.sqrt(z.var(-1, unbiased=False) + 1e-5)).contiguous())
+    (m2, r2), (m1, r1) = st(z2), st(z1)
+    gp = rnd(M, hid, seed=34).to(hd)
+    w1, w2 = rnd(hid, C, scale=C ** -0.5, seed=2).to(hd), rnd(C, hid, scale=hid ** -0.5, seed=4).to(hd)
+    wo = rnd(C, C, scale=C ** -0.5, seed=13).to(hd)
+    t = torch.rand(B, device=DEV) if cond else None
+    s1 = (torch.rand(B, device=DEV) > 0.3).float() / 0.7
+    s2 = (torch.rand(B, device=DEV) > 0.3).float() / 0.7
+    gw2 = (rnd(C, seed=6, scale=0.3) if cond else None, 1 + rnd(C, seed=7, scale=0.1))
+    gw1 = (rnd(C, seed=20, scale=0.3) if cond else None, 1 + rnd(C, seed=21, scale=0.1))
+    f = lambda *s_, dtype=torch.float32: torch.full(s_, float("nan"), device=DEV, dtype=dtype)
+    zc = lambda: torch.zeros(C, device=DEV)
+    o = dict(g=f(M, C), dz2=f(M, C, dtype=hd), du=f(M, hid, dtype=hd), dz1=f(M, C, dtype=hd), da=f(M, C, dtype=hd))
+    p2, p1 = [zc() if cond else None, zc(), zc() if cond else None, zc()], [zc() if cond else None, zc(), zc() if cond else None, zc()]
+    assert ops.block_tail_bwd(g0, o["g"], (z2, m2, r2, gw2[0], gw2[1], s2, gp, w1, w2, o["dz2"], o["du"], p2[0], p2[1], p2[2], p2[3]),
+                              (z1, m1, r1, gw1[0], gw1[1], s1, wo, o["dz1"], o["da"], p1[0], p1[1], p1[2], p1[3]), t, M, L, C, hid)
+    torch.cuda.synchronize()
+    per_row = lambda v: v.repeat_interleave(L).unsqueeze(1).to(D)
+
+    def cln_bwd(gin, z, mean, rstd, gw, s):
+        dd = gin.to(D) * per_row(s)
+        xh = (z.to(D) - mean.to(D).unsqueeze(1)) * rstd.to(D).unsqueeze(1)
+        ga = gw[1].to(D) + (gw[0].to(D) * per_row(t) if cond else 0.0)
+        d = dd * ga
+        m_1, m_2 = d.mean(-1, keepdim=True), (d * xh).mean(-1, keepdim=True)
+        dz = rstd.to(D).unsqueeze(1) * (d - m_1 - xh * m_2)
+        tt_ = per_row(t) if cond else None
+        pg = [(tt_ * dd * xh).sum(0) if cond else None, (dd * xh).sum(0), (tt_ * dd).sum(0) if cond else None, dd.sum(0)]
+        return dz, pg
+    tol16 = 6e-3 if hd == torch.bfloat16 else 1e-3
+    for k in o:
+        assert torch.isfinite(o[k].float()).all(), k
+    dz2, pg2 = cln_bwd(g0, z2, m2, r2, gw2, s2)
+    assert rel(o["dz2"].float(), dz2) < tol16
+    du = (o["dz2"].to(D) @ w2.to(D)) * gp.to(D)
+    assert rel(o["du"].float(), du) < tol16
+    g1 = g0.to(D) + o["du"].to(D) @ w1.to(D)
+    assert rel(o["g"], g1) < 2e-6
+    dz1, pg1 = cln_bwd(o["g"], z1, m1, r1, gw1, s1)
+    assert rel(o["dz1"].float(), dz1) < tol16
+    assert rel(o["da"].float(), o["dz1"].to(D) @ wo.to(D)) < tol16
+    for got, ref in zip(p2 + p1, pg2 + pg1):
+        if got is not None:
+            assert rel(got, ref) < 1e-4
+
+
 @pytest.mark.parametrize("prologue", [False, True])
 @pytest.mark.parametrize("cond", [True, False])
 @pytest.mark.parametrize("B,L,C", [(2, 1024, 96), (3, 192, 96), (64, 1024, 96), (2, 256, 192), (5, 64, 192)])

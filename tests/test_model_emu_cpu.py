@@ -296,9 +296,9 @@ def test_engine_fused_block_kernels(emu, monkeypatch):
     assert abs(res["1"][0] - res["0"][0]) < 5e-3 * abs(res["0"][0])
 
 
-def test_engine_fused_forward_tail_c48(emu, monkeypatch):
-    """Round 6: the forward tail fused at C = 48 (Poseidon-T / -S stage 0, reference train.py:35-47) with the layer-by-layer backward behind
-    it, inside the engine (fp16, two blocks at C = 48 so that the next layer's qkv epilogue runs, one at C = 96): against the layer-by-layer
+def test_engine_fused_tails_c48(emu, monkeypatch):
+    """Round 6: the layer tails fused at C = 48 (Poseidon-T / -S stage 0, reference train.py:35-47; the backward in its stored-gelu' form),
+    inside the engine (fp16, two blocks at C = 48 so that the next layer's qkv epilogue runs, one at C = 96): against the layer-by-layer
     forward of the same model — same loss, prediction and gradients up to the order of the fp32 sums — and against the oracle."""
     from oracle import scot_cpu
     cfg = ScOTConfig(image_size=32, patch_size=4, num_channels=4, num_out_channels=4, embed_dim=48, depths=[2, 1], num_heads=[3, 6],
@@ -310,12 +310,15 @@ def test_engine_fused_forward_tail_c48(emu, monkeypatch):
     res = {}
     for flag in (False, True):
         monkeypatch.setitem(engine_mod.ENGINE_OPTIONS, "fused_fwd48", flag)
-        calls = []
-        real = ops.block_tail_fwd
+        monkeypatch.setitem(engine_mod.ENGINE_OPTIONS, "fused_bwd48", flag)
+        calls, bcalls = [], []
+        real, realb = ops.block_tail_fwd, ops.block_tail_bwd
         monkeypatch.setattr(ops, "block_tail_fwd", lambda *a, **k: (calls.append(a[5]), real(*a, **k))[1])
+        monkeypatch.setattr(ops, "block_tail_bwd", lambda *a, **k: (bcalls.append(a[7]), realb(*a, **k))[1])
         model, loss, pred = run_engine(cfg, sd, pv, t, lab, None, "fp16")
         monkeypatch.setattr(ops, "block_tail_fwd", real)
-        assert (48 in calls) == flag, calls
+        monkeypatch.setattr(ops, "block_tail_bwd", realb)
+        assert (48 in calls) == flag and (48 in bcalls) == flag, (calls, bcalls)
         res[flag] = (float(loss), pred.clone(), model._arena.grad.clone())
     with torch.no_grad():
         oloss, opred = scot_cpu.scot_forward({k: v.clone() for k, v in sd.items()}, cfg, pv, t, lab)
