@@ -271,6 +271,7 @@ int scot_proj_cln_bwd(const float* g, const float* z, const float* mean, const f
  * ref:566-579 and of HF:478-489 + ref:560-565 along the dependent chain): g_out is still written (the qkv dgrad accumulates
  * into it) but not re-read.  Suffix 2 = the MLP half's norm (layernorm_after), 1 = the attention half's (layernorm_before);
  * arguments as in the two entry points above.  C in {96, 192}, rows_per_sample % 64 == 0; returns -3 otherwise.
+ * C = 48 with hid = 192 (Poseidon-T / -S stage 0, ref train.py:35-47) in the stored-gelu' form without the qkv prologue (dact != NULL, dqkv == NULL).
  * Round 3 — the form without 4C-wide tensors in HBM: dact == NULL makes the kernel RECOMPUTE gelu'(u) from u = h16·W1^T + b1
  * (h16 [M, C] 16-bit and b1 [hid] then required); du == NULL: the product dz2·W2 ⊙ gelu'(u) is not stored (scot_wgrad_mlp recomputes
  * it); z_dt: dtype of z1 / z2 (0 = fp32, 1 = the 16-bit operand format); partial2 / partial1 (both or neither): instead of 4·C
@@ -296,6 +297,7 @@ int scot_partial_colsum_batch(int n, const float* const* partial, const int* nbl
 /* scot_proj_cln_fwd followed by scot_mlp_block_fwd on its output, for the same rows, in ONE launch (HF:478-489 + ref:560-565, then
  * HF:533-561 + ref:566-579): h / h16 are written (the backward reads them) but not re-read.  Suffix 1 = attention half's norm
  * (layernorm_before), 2 = MLP half's (layernorm_after); arguments as in the two entry points.  C in {96, 192}; -3 otherwise.
+ * Also C = 48 with hid = 192 (Poseidon-T / -S stage 0): only this whole-tail form exists at that width.
  * act / dact NULL (and z / statistics given): training without the 4C-wide saves (the backward recomputes, see above); z_dt: dtype
  * z1 / z2 are stored in (0 = fp32, 1 = 16-bit: only the norm backward's x-hat reads them). */
 int scot_block_tail_fwd(const void* a, const void* Wo, const float* bo, const float* x, float* h, void* h16, void* z1, float* mean1,
