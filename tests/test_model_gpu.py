@@ -228,7 +228,7 @@ def test_vs_cpu_oracle_other_config():
                                        kwargs["labels"].cpu().double())
     loss.backward()
     assert rel_l2(out.output.detach().cpu().numpy(), pred.detach().numpy()) < 1e-5
-    assert abs(float(out.loss) - float(loss)) < 1e-5 * abs(float(loss))
+    assert abs(float(out.loss.detach()) - float(loss.detach())) < 1e-5 * abs(float(loss.detach()))
     num = den = 0.0
     for k, p in model.named_parameters():
         ref = sd[k].grad.numpy()
