@@ -572,6 +572,22 @@ def test_patchify_unpatchify(H, W, Cc, cdt):
     assert torch.allclose(back, img + bias.view(1, -1, 1, 1))
 
 
+@pytest.mark.parametrize("M,N", [(65536 + 37, 96), (4099, 48), (1024, 768), (300, 2048), (129, 8), (777, 200), (513, 100)])
+@pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16])
+def test_colsum_shapes(M, N, dt):
+    """`scot_colsum` (bias / layer-scale gradients): the 8-column vector form (N % 8 == 0) and the scalar form, ragged row counts,
+    both operand types, with and without the elementwise factor; the result is ADDED to `out`."""
+    if DEV == "cpu" and M > 8192:                       # the CPU emulation of the kernels (tests/hipemu)
+        M = 2048 + 37
+    a, b = rnd(M, N, dtype=dt), rnd(M, N, seed=1, dtype=dt)
+    o = torch.ones(N, device=DEV)
+    ops.colsum(a, o)
+    assert rel(o, 1 + a.double().sum(0)) < 2e-5
+    o = torch.zeros(N, device=DEV)
+    ops.colsum(a, o, y=b)
+    assert rel(o, (a.double() * b.double()).sum(0)) < 2e-5
+
+
 def test_reductions_and_scale_residual():
     B, Cc, HW = 3, 4, 1000
     x = rnd(B, Cc, HW)
