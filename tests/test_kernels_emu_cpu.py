@@ -439,6 +439,14 @@ def test_conv5_tiled(gpu_test_bodies, Cc, H, W):
     gpu_test_bodies.test_conv5(Cc, H, W)
 
 
+@pytest.mark.parametrize("M,N,dt", [(4099, 48, torch.float32), (1024, 768, torch.bfloat16), (300, 2048, torch.float32), (129, 8, torch.bfloat16),
+                                    (777, 200, torch.float32), (513, 100, torch.bfloat16)])
+def test_colsum_vector_and_scalar_forms(gpu_test_bodies, M, N, dt):
+    """scot_colsum: the 8-column vector kernel (N % 8 == 0; round 6) and the scalar one, ragged row counts"""
+    gpu_test_bodies.test_colsum_shapes(M, N, dt)
+    gpu_test_bodies.test_reductions_and_scale_residual()
+
+
 def test_optimizer_kernels_skip_clock_scale_and_operand_copy(emu):
     """csrc/optim.hip on the CPU: scot_clip_coef's non-finite flag, scot_adamw_step (torch.optim.AdamW arithmetic, Adam's clock read
     from the device, skip on a non-finite norm, 16-bit operand copy of the new weights in the same pass), scot_optim_finish
