@@ -189,7 +189,7 @@ def test_engine_lazy_zero_grad_stores_first_writers(emu, compute):
             continue            # (the 96-wide model in fp16, the ragged tiny one in bf16: half the emulation time, both code paths in both formats' kernels)
         sd = synth_state_dict(param_shapes(cfg), "trained")
         if cfg.embed_dim == 96:
-            pv, t, lab = synth_inputs(2, cfg.num_channels, cfg.num_out_channels, cfg.image_size, "smooth")
+            pv, t, lab = synth_inputs(1, cfg.num_channels, cfg.num_out_channels, cfg.image_size, "smooth")
         else:
             pv, t, lab, _ = fixture_inputs(load_fixture("tiny_odd")[1], cfg)
         model = ScOT(cfg, compute=compute)
@@ -339,7 +339,7 @@ def test_engine_lean_layer_tail(emu, monkeypatch):
                      channel_slice_list_normalized_loss=[0, 1, 3, 4], residual_model="convnext", use_conditioning=True,
                      learn_residual=False)
     sd = synth_state_dict(param_shapes(cfg), "trained")
-    pv, t, lab = synth_inputs(2, 4, 4, 64, "smooth")
+    pv, t, lab = synth_inputs(1, 4, 4, 64, "smooth")      # (batch 1: half the emulation time; the batch-2 indexing of the same kernels is test_engine_fused_block_kernels')
     res = {}
     for flag in ("0", "1"):
         monkeypatch.setitem(engine_mod.ENGINE_OPTIONS, "lean_tail", flag == "1")
@@ -372,7 +372,7 @@ def test_engine_pooled_rows_change_nothing(emu, monkeypatch, compute):
                      channel_slice_list_normalized_loss=[0, 1, 3, 4], residual_model="convnext", use_conditioning=True,
                      learn_residual=False)      # 64 rows per sample at C = 96 (the fused tail), 16 at C = 192 (layer-by-layer launches)
     sd = synth_state_dict(param_shapes(cfg), "trained")
-    pv, t, lab = synth_inputs(2, 4, 4, 32, "smooth")
+    pv, t, lab = synth_inputs(1, 4, 4, 32, "smooth")
     res = {}
     for flag in ("0", "1"):
         monkeypatch.setitem(engine_mod.ENGINE_OPTIONS, "recycle", flag == "1")
